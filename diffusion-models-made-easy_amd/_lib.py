@@ -1,0 +1,150 @@
+"""ctypes binding of libdmme_hip.so (the C ABI declared in include/dmme_hip.h).
+
+The product path has no CPU fallback: `lib()` raises if the shared library is missing,
+and `require_gpu()` raises if it loaded but sees no HIP device."""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdmme_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+F32, BF16 = 0, 1
+DTYPES = {"fp32": F32, "float32": F32, "32": F32, "bf16": BF16, "bfloat16": BF16, "16": BF16, "bf16-mixed": BF16, "16-mixed": BF16}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class UNetCfg(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int),
+        ("pos_dim", C.c_int),
+        ("emb_dim", C.c_int),
+        ("num_groups", C.c_int),
+        ("dropout", C.c_float),
+        ("num_depths", C.c_int),
+        ("channels_per_depth", C.c_int * 8),
+        ("num_blocks", C.c_int),
+        ("num_attention_depths", C.c_int),
+        ("attention_depths", C.c_int * 8),
+    ]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "dtype", "N", "Hin", "Win", "C1", "C2", "upsample", "stride", "taps", "Cout", "pro_silu", "out_silu",
+        "nt", "tproj_ld", "in_nchw", "out_nchw", "force_generic")]
+
+
+class DmmeError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into libdmme_hip.so (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise DmmeError("building libdmme_hip.so failed")
+    return LIB_PATH
+
+
+_vp, _i, _i64, _f, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
+
+# name -> (restype, argtypes); must list every symbol include/dmme_hip.h declares
+PROTOTYPES = {
+    "dmme_last_error": (C.c_char_p, []),
+    "dmme_version": (_i, []),
+    "dmme_device_count": (_i, []),
+    "dmme_unet_plan_create": (_i, [C.POINTER(UNetCfg), _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "dmme_unet_plan_destroy": (None, [_vp]),
+    "dmme_unet_plan_num_params": (_i, [_vp]),
+    "dmme_unet_plan_param_info": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i)]),
+    "dmme_unet_plan_ref_numel": (_i64, [_vp]),
+    "dmme_unet_plan_packed_bytes": (_i64, [_vp]),
+    "dmme_unet_plan_workspace_bytes": (_i64, [_vp]),
+    "dmme_unet_plan_dropmask_numel": (_i64, [_vp]),
+    "dmme_unet_plan_num_launches": (_i, [_vp]),
+    "dmme_unet_pack_params": (_i, [_vp, _vp, _vp, _vp]),
+    "dmme_unet_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "dmme_unet_debug_read": (_i, [_vp, _vp, C.c_char_p, _vp, _i64, C.POINTER(_i64), _vp]),
+    "dmme_dropout_masks": (_i, [_vp, _u64, _u64, _vp, _vp]),
+    "dmme_randn": (_i, [_vp, _i64, _u64, _u64, _vp]),
+    "dmme_q_sample": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp]),
+    "dmme_ddpm_step": (_i, [_vp, _vp, _vp, _f, _f, _f, _i, _i64, _vp]),
+    "dmme_ddim_step": (_i, [_vp, _vp, _f, _f, _i64, _vp]),
+    "dmme_mse_loss": (_i, [_vp, _vp, _i64, _vp, _vp, _f, _vp, _vp]),
+    "dmme_conv2d": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "dmme_groupnorm_scale_shift": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _i, _vp]),
+    "dmme_attention": (_i, [_i, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "dmme_nchw_to_nhwc": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),
+    "dmme_nhwc_to_nchw": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),
+    "dmme_pack_weight": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),
+    "dmme_event_create": (_i, [C.POINTER(_vp)]),
+    "dmme_event_record": (_i, [_vp, _vp]),
+    "dmme_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(_f)]),
+    "dmme_event_destroy": (_i, [_vp]),
+}
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises loudly if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise DmmeError(
+                f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C diffusion-models-made-easy_amd/csrc`). There is no CPU fallback for the product path."
+            )
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(h, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().dmme_last_error().decode("utf-8", "replace")
+        if rc == -2:
+            raise NotImplementedError(f"{what}: {msg}")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise DmmeError(f"{what} failed (status {rc}): {msg}")
+
+
+def require_gpu():
+    if lib().dmme_device_count() <= 0:
+        raise DmmeError("libdmme_hip.so loaded but no HIP device is visible; the denoiser path only runs on an MI355X")
+
+
+def dtype_code(precision) -> int:
+    key = str(precision).lower()
+    if key not in DTYPES:
+        raise ValueError(f"unknown precision {precision!r}; use 'fp32' or 'bf16'")
+    return DTYPES[key]
+
+
+def stream_ptr():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """device/host pointer of a tensor (None -> NULL)."""
+    return C.c_void_p(0 if t is None else t.data_ptr())

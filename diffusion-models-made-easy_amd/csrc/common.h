@@ -1,0 +1,167 @@
+// Shared device/host helpers for libdmme_hip (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dmme_hip.h"
+
+namespace dmme {
+
+void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+
+#define DMME_CHECK_HIP(expr)                                                                          \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            ::dmme::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return DMME_ERR_HIP;                                                                      \
+        }                                                                                             \
+    } while (0)
+
+#define DMME_REQUIRE(cond, code, ...)        \
+    do {                                     \
+        if (!(cond)) {                       \
+            ::dmme::set_error(__VA_ARGS__);  \
+            return (code);                   \
+        }                                    \
+    } while (0)
+
+// launch check: catches configuration errors without synchronising
+#define DMME_CHECK_LAUNCH() DMME_CHECK_HIP(hipGetLastError())
+
+typedef __bf16 bf16;
+
+template <typename T>
+struct dtype_of;
+template <>
+struct dtype_of<float> {
+    static constexpr int value = DMME_F32;
+};
+template <>
+struct dtype_of<bf16> {
+    static constexpr int value = DMME_BF16;
+};
+
+__host__ __device__ inline size_t dtype_size(int dt) { return dt == DMME_BF16 ? 2 : 4; }
+
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(bf16 v) { return (float)v; }
+template <typename T>
+__device__ __forceinline__ T from_f(float v);
+template <>
+__device__ __forceinline__ float from_f<float>(float v) {
+    return v;
+}
+template <>
+__device__ __forceinline__ bf16 from_f<bf16>(float v) {
+    return (bf16)v;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserving
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide sum for blockDim.x <= 1024 (multiple of 64); `red` needs 16 floats of LDS
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += red[i];
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < nw; ++i) r = fmaxf(r, red[i]);
+    return r;
+}
+
+// Device-side description of one convolution launch (generic and MFMA kernels share it).
+struct ConvArgs {
+    const void* src1;
+    const void* src2;
+    const void* w;      // [Cout][taps][Cin] T
+    const float* bias;  // [Cout]
+    const float* scale; // [N][Cin] or null
+    const float* shift;
+    const float* dmask; // [N][Cin] or null
+    const float* tproj; // [nt][tproj_ld] or null
+    const void* res1;   // NHWC T [.., R1]
+    const void* res2;   // NHWC T [.., Cout-R1] or null
+    void* dst;
+    int N, Hin, Win, C1, C2;
+    int up, stride, taps;
+    int Hout, Wout, Cout;
+    int pro_silu, out_silu;
+    int nt, tproj_ld, R1;
+    int in_nchw, out_nchw;
+};
+
+// ---- kernel launchers (defined in the .hip files) ------------------------------------
+int launch_conv_generic(int dtype, const ConvArgs& a, hipStream_t s);
+// returns DMME_ERR_UNSUPPORTED (without setting the error) when the shape is outside
+// the MFMA kernel's domain, so callers can fall back to the generic kernel.
+bool conv_mfma_supported(int dtype, const ConvArgs& a);
+int launch_conv_mfma(int dtype, const ConvArgs& a, hipStream_t s);
+
+int launch_gn_generic(int dtype, const void* src1, const void* src2, int N, int HW, int C1, int C2, int groups,
+                      const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                      hipStream_t s);
+bool gn_fast_supported(int dtype, int N, int HW, int C1, int C2, int groups);
+// partial: scratch of gn_fast_scratch_floats(...) floats
+size_t gn_fast_scratch_floats(int N, int HW, int C, int groups);
+int launch_gn_fast(int dtype, const void* src1, const void* src2, int N, int HW, int C1, int C2, int groups,
+                   const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                   float* partial, hipStream_t s);
+
+int launch_attn_generic(int dtype, const void* qkv, int N, int S, int C, void* out, hipStream_t s);
+bool attn_mfma_supported(int dtype, int N, int S, int C);
+int launch_attn_mfma(int dtype, const void* qkv, int N, int S, int C, void* out, hipStream_t s);
+
+int launch_time_sinusoid(const int64_t* t, int nt, const float* freqs, int half, float* out, hipStream_t s);
+// out[nt][Nout] = act(in[nt][K] . W[Nout][K]^T + b); in/out fp32, W in dtype
+int launch_linear_wave(int dtype, const float* in, int nt, int K, const void* W, const float* bias, int Nout,
+                       int out_silu, float* out, hipStream_t s);
+
+int launch_nchw_to_nhwc(int dtype, const float* src, int N, int C, int HW, void* dst, hipStream_t s);
+int launch_nhwc_to_nchw(int dtype, const void* src, int N, int C, int HW, float* dst, hipStream_t s);
+int launch_pack_weight(int dtype, const float* src, int Cout, int Cin, int taps, void* dst, hipStream_t s);
+
+struct PackItem {  // one chunk of the table-driven parameter re-pack
+    int64_t src_off;   // element offset in the fp32 reference-layout flat buffer
+    int64_t dst_off;   // BYTE offset in the packed buffer
+    int32_t cout, cin, taps;  // tensor geometry (cin*taps = row length)
+    int32_t row0, rows;       // rows [row0, row0+rows) of this tensor handled by this item
+    int32_t as_f32;           // 1: keep fp32 (biases, gammas, freqs); 0: convert to dtype
+};
+int launch_pack_table(int dtype, const PackItem* items_dev, int n_items, const float* ref_flat, void* packed,
+                      hipStream_t s);
+
+int launch_randn(float* out, int64_t numel, uint64_t seed, uint64_t offset, hipStream_t s);
+int launch_dropmask(float* out, int64_t numel, float p, uint64_t seed, uint64_t offset, hipStream_t s);
+int launch_q_sample(const float* x0, const float* z, const float* abar, const int64_t* t, int B, int64_t chw,
+                    float* x_t, float* target, hipStream_t s);
+int launch_ddpm_step(float* x, const float* eps, const float* z, float c1, float c2, float sigma, int add_noise,
+                     int64_t numel, hipStream_t s);
+int launch_ddim_step(float* x, const float* eps, float s1, float s2, int64_t numel, hipStream_t s);
+int launch_mse(const float* eps, const float* target, int64_t numel, float* loss, float* d_eps, float gscale,
+               float* scratch, hipStream_t s);
+
+}  // namespace dmme

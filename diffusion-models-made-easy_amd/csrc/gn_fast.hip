@@ -1,0 +1,186 @@
+// GroupNorm statistics for NHWC tensors, HBM-bound: every element is read exactly once
+// with 16-byte coalesced loads and kept in registers for a numerically robust local
+// two-pass (mean, then centred second moment).  Per-workgroup partials (mean, M2) are
+// merged with Chan's parallel-variance formula in a tiny finalize kernel that also
+// folds gamma/beta into per-(n, channel) scale/shift vectors for the consumer conv.
+//
+// Replaces the statistics half of nn.GroupNorm (models/ddpm.py:17-18); the apply half
+// is fused into the prologue of the convolution that consumes it (conv_mfma.hip).
+#include "common.h"
+
+namespace dmme {
+
+constexpr int GN_MAX_SWEEPS = 8;
+
+template <typename T>
+__global__ void __launch_bounds__(256) gn_partial_kernel(const T* __restrict__ s1, const T* __restrict__ s2, int HW,
+                                                         int C1, int C2, int groups, int chunk_px, int nsweeps,
+                                                         float* __restrict__ partial) {
+    constexpr int EPV = 16 / sizeof(T);
+    __shared__ float red[256 * EPV];
+    __shared__ float gstat[256];
+    const int tid = threadIdx.x;
+    const int C = C1 + C2, VPP = C / EPV, cg = C / groups;
+    const int slot = tid % VPP, prow = tid / VPP, ppw = 256 / VPP;
+    const int c0 = slot * EPV;
+    const bool second = c0 >= C1;
+    const T* src = second ? s2 : s1;
+    const int Cs = second ? C2 : C1, cs0 = second ? c0 - C1 : c0;
+    const int n = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    const int64_t p0 = (int64_t)n * HW + (int64_t)chunk * chunk_px;
+
+    float v[GN_MAX_SWEEPS][EPV];
+#pragma unroll
+    for (int sw = 0; sw < GN_MAX_SWEEPS; ++sw) {
+        if (sw < nsweeps) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(src + (p0 + sw * ppw + prow) * Cs + cs0);
+            if constexpr (sizeof(T) == 4) {
+                const float4 f = __builtin_bit_cast(float4, raw);
+                v[sw][0] = f.x; v[sw][1] = f.y; v[sw][2] = f.z; v[sw][3] = f.w;
+            } else {
+                typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+                const bf16x8 b = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) v[sw][j] = (float)b[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) v[sw][j] = 0.f;
+        }
+    }
+    const float inv_cnt = 1.0f / (float)(chunk_px * cg);
+
+    // ---- pass 1: local mean per group ----
+    float e[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int sw = 0; sw < GN_MAX_SWEEPS; ++sw) s += v[sw][j];
+        e[j] = s;
+    }
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) red[tid * EPV + j] = e[j];
+    __syncthreads();
+    if (tid < groups) {
+        float acc = 0.f;
+        for (int c = tid * cg; c < (tid + 1) * cg; ++c) {
+            const int sl = c / EPV, j = c % EPV;
+            for (int pr = 0; pr < ppw; ++pr) acc += red[(pr * VPP + sl) * EPV + j];
+        }
+        gstat[tid] = acc * inv_cnt;
+    }
+    __syncthreads();
+    // ---- pass 2: centred second moment ----
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+        const float m = gstat[(c0 + j) / cg];
+        float s = 0.f;
+#pragma unroll
+        for (int sw = 0; sw < GN_MAX_SWEEPS; ++sw) {
+            if (sw < nsweeps) {
+                const float d = v[sw][j] - m;
+                s = fmaf(d, d, s);
+            }
+        }
+        e[j] = s;
+    }
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) red[tid * EPV + j] = e[j];
+    __syncthreads();
+    if (tid < groups) {
+        float acc = 0.f;
+        for (int c = tid * cg; c < (tid + 1) * cg; ++c) {
+            const int sl = c / EPV, j = c % EPV;
+            for (int pr = 0; pr < ppw; ++pr) acc += red[(pr * VPP + sl) * EPV + j];
+        }
+        float* o = partial + (((int64_t)n * nchunks + chunk) * groups + tid) * 2;
+        o[0] = gstat[tid];
+        o[1] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ partial, int N, int nchunks, int groups,
+                                                          int C, int chunk_cnt, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          float* __restrict__ scale, float* __restrict__ shift) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * groups) return;
+    const int n = i / groups, g = i % groups, cg = C / groups;
+    float na = 0.f, mean = 0.f, m2 = 0.f;
+    const float m = (float)chunk_cnt;
+    for (int k = 0; k < nchunks; ++k) {
+        const float* p = partial + (((int64_t)n * nchunks + k) * groups + g) * 2;
+        const float delta = p[0] - mean;
+        const float tot = na + m;
+        mean += delta * (m / tot);
+        m2 += p[1] + delta * delta * (na * m / tot);
+        na = tot;
+    }
+    const float rstd = 1.0f / sqrtf(m2 / na + eps);
+    for (int j = 0; j < cg; ++j) {
+        const int c = g * cg + j;
+        const float a = rstd * gamma[c];
+        scale[(int64_t)n * C + c] = a;
+        shift[(int64_t)n * C + c] = beta[c] - mean * a;
+    }
+}
+
+static bool gn_geometry(int dtype, int HW, int C1, int C2, int groups, int& chunk_px, int& nsweeps, int& nchunks) {
+    const int EPV = dtype == DMME_BF16 ? 8 : 4;
+    const int C = C1 + C2;
+    if (C % EPV || C1 % EPV || groups > 256 || C % groups) return false;
+    const int VPP = C / EPV;
+    if (VPP > 256 || 256 % VPP) return false;
+    const int ppw = 256 / VPP;
+    if (HW % ppw) return false;
+    int sweeps = HW / ppw;
+    if (sweeps > GN_MAX_SWEEPS) sweeps = GN_MAX_SWEEPS;
+    while (sweeps > 1 && (HW / ppw) % sweeps) --sweeps;
+    chunk_px = sweeps * ppw;
+    nsweeps = sweeps;
+    nchunks = HW / chunk_px;
+    return true;
+}
+
+bool gn_fast_supported(int dtype, int N, int HW, int C1, int C2, int groups) {
+    int a, b, c;
+    (void)N;
+    return gn_geometry(dtype, HW, C1, C2, groups, a, b, c);
+}
+
+size_t gn_fast_scratch_floats(int N, int HW, int C, int groups) {
+    // worst case over dtypes: chunk of one sweep of the fp32 geometry
+    int chunk_px, nsweeps, nchunks = 0;
+    size_t best = 0;
+    for (int dt = 0; dt < 2; ++dt)
+        if (gn_geometry(dt, HW, C, 0, groups, chunk_px, nsweeps, nchunks)) {
+            const size_t v = (size_t)N * nchunks * groups * 2;
+            if (v > best) best = v;
+        }
+    return best;
+}
+
+int launch_gn_fast(int dtype, const void* src1, const void* src2, int N, int HW, int C1, int C2, int groups,
+                   const float* gamma, const float* beta, float eps, float* scale, float* shift, float* partial,
+                   hipStream_t s) {
+    int chunk_px, nsweeps, nchunks;
+    DMME_REQUIRE(gn_geometry(dtype, HW, C1, C2, groups, chunk_px, nsweeps, nchunks), DMME_ERR_UNSUPPORTED,
+                 "gn_fast: unsupported geometry");
+    const int C = C1 + C2;
+    dim3 grid(nchunks, N);
+    if (dtype == DMME_BF16)
+        hipLaunchKernelGGL(gn_partial_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)src1, (const bf16*)src2, HW, C1, C2,
+                           groups, chunk_px, nsweeps, partial);
+    else
+        hipLaunchKernelGGL(gn_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)src1, (const float*)src2, HW, C1,
+                           C2, groups, chunk_px, nsweeps, partial);
+    DMME_CHECK_LAUNCH();
+    const int tot = N * groups;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, partial, N, nchunks, groups, C,
+                       chunk_px * (C / groups), gamma, beta, eps, scale, shift);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+}  // namespace dmme

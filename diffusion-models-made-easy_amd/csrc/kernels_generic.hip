@@ -1,0 +1,334 @@
+// Shape-generic HIP kernels: any channel count / resolution, used for the layers the
+// MFMA kernels do not cover (3-channel input/output convs, odd test configurations)
+// and as a second, structurally independent implementation for parity tests.
+// Also: time embedding, small linears, layout converters, the parameter re-packer.
+#include "common.h"
+
+namespace dmme {
+
+// ------------------------------------------------------------------ generic convolution
+// One thread per output element; replaces nn.Conv2d 3x3/1x1 (+ the fused prologue /
+// epilogue described in DESIGN.md) for arbitrary shapes.
+template <typename T>
+__global__ void __launch_bounds__(256) conv_generic_kernel(ConvArgs a) {
+    const int64_t total = (int64_t)a.N * a.Hout * a.Wout * a.Cout;
+    const int Cin = a.C1 + a.C2;
+    const int Hv = a.up ? 2 * a.Hin : a.Hin, Wv = a.up ? 2 * a.Win : a.Win;
+    const int k = a.taps == 9 ? 3 : 1, pad = a.taps == 9 ? 1 : 0;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(idx % a.Cout);
+        int64_t p = idx / a.Cout;
+        const int ow = (int)(p % a.Wout);
+        p /= a.Wout;
+        const int oh = (int)(p % a.Hout);
+        const int n = (int)(p / a.Hout);
+        const T* w = (const T*)a.w + (int64_t)co * a.taps * Cin;
+        const float* sc = a.scale ? a.scale + (int64_t)n * Cin : nullptr;
+        const float* sh = a.scale ? a.shift + (int64_t)n * Cin : nullptr;
+        const float* dm = a.dmask ? a.dmask + (int64_t)n * Cin : nullptr;
+        float acc = 0.f;
+        for (int kh = 0; kh < k; ++kh) {
+            const int iy = oh * a.stride - pad + kh;
+            if (iy < 0 || iy >= Hv) continue;
+            const int sy = a.up ? (iy >> 1) : iy;
+            for (int kw = 0; kw < k; ++kw) {
+                const int ix = ow * a.stride - pad + kw;
+                if (ix < 0 || ix >= Wv) continue;
+                const int sx = a.up ? (ix >> 1) : ix;
+                const T* wt = w + (kh * k + kw) * Cin;
+                const int64_t pix = ((int64_t)n * a.Hin + sy) * a.Win + sx;
+                for (int ci = 0; ci < Cin; ++ci) {
+                    float v;
+                    if (a.in_nchw)
+                        v = ((const float*)a.src1)[(((int64_t)n * a.C1 + ci) * a.Hin + sy) * a.Win + sx];
+                    else if (ci < a.C1)
+                        v = to_f(((const T*)a.src1)[pix * a.C1 + ci]);
+                    else
+                        v = to_f(((const T*)a.src2)[pix * a.C2 + (ci - a.C1)]);
+                    if (sc) v = fmaf(v, sc[ci], sh[ci]);
+                    if (a.pro_silu) v = silu_f(v);
+                    if (dm) v *= dm[ci];
+                    v = to_f(from_f<T>(v));  // the MFMA path feeds operands in T
+                    acc = fmaf(v, to_f(wt[ci]), acc);
+                }
+            }
+        }
+        acc += a.bias[co];
+        if (a.tproj) acc += a.tproj[(int64_t)(a.nt == 1 ? 0 : n) * a.tproj_ld + co];
+        const int64_t opix = ((int64_t)n * a.Hout + oh) * a.Wout + ow;
+        if (a.res1) {
+            if (co < a.R1)
+                acc += to_f(((const T*)a.res1)[opix * a.R1 + co]);
+            else
+                acc += to_f(((const T*)a.res2)[opix * (a.Cout - a.R1) + (co - a.R1)]);
+        }
+        if (a.out_silu) acc = silu_f(acc);
+        if (a.out_nchw)
+            ((float*)a.dst)[(((int64_t)n * a.Cout + co) * a.Hout + oh) * a.Wout + ow] = acc;
+        else
+            ((T*)a.dst)[opix * a.Cout + co] = from_f<T>(acc);
+    }
+}
+
+int launch_conv_generic(int dtype, const ConvArgs& a, hipStream_t s) {
+    const int64_t total = (int64_t)a.N * a.Hout * a.Wout * a.Cout;
+    if (total == 0) return DMME_OK;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (dtype == DMME_BF16)
+        hipLaunchKernelGGL(conv_generic_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(conv_generic_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+// ------------------------------------------------------------------ generic GroupNorm stats
+// One workgroup per (n, group); two passes (mean, then centred second moment) in fp32.
+// Handles groups that straddle the two concatenated sources.
+template <typename T>
+__global__ void __launch_bounds__(256) gn_generic_kernel(const T* __restrict__ s1, const T* __restrict__ s2, int HW,
+                                                         int C1, int C2, int groups, const float* gamma,
+                                                         const float* beta, float eps, float* scale, float* shift) {
+    __shared__ float red[16];
+    const int n = blockIdx.y, g = blockIdx.x;
+    const int C = C1 + C2, cg = C / groups;
+    const int64_t cnt = (int64_t)cg * HW;
+    auto at = [&](int64_t e) -> float {
+        const int c = g * cg + (int)(e % cg);
+        const int64_t p = (int64_t)n * HW + e / cg;
+        return c < C1 ? to_f(s1[p * C1 + c]) : to_f(s2[p * C2 + (c - C1)]);
+    };
+    float s = 0.f;
+    for (int64_t e = threadIdx.x; e < cnt; e += blockDim.x) s += at(e);
+    const float mean = block_sum(s, red) / (float)cnt;
+    float q = 0.f;
+    for (int64_t e = threadIdx.x; e < cnt; e += blockDim.x) {
+        const float d = at(e) - mean;
+        q = fmaf(d, d, q);
+    }
+    const float var = block_sum(q, red) / (float)cnt;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    for (int j = threadIdx.x; j < cg; j += blockDim.x) {
+        const int c = g * cg + j;
+        const float a = rstd * gamma[c];
+        scale[(int64_t)n * C + c] = a;
+        shift[(int64_t)n * C + c] = beta[c] - mean * a;
+    }
+}
+
+int launch_gn_generic(int dtype, const void* src1, const void* src2, int N, int HW, int C1, int C2, int groups,
+                      const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                      hipStream_t s) {
+    dim3 grid(groups, N);
+    if (dtype == DMME_BF16)
+        hipLaunchKernelGGL(gn_generic_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)src1, (const bf16*)src2, HW,
+                           C1, C2, groups, gamma, beta, eps, scale, shift);
+    else
+        hipLaunchKernelGGL(gn_generic_kernel<float>, grid, dim3(256), 0, s, (const float*)src1, (const float*)src2,
+                           HW, C1, C2, groups, gamma, beta, eps, scale, shift);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+// ------------------------------------------------------------------ generic attention
+// One workgroup per (query token, image).  scores in LDS (S floats) + q (C floats).
+template <typename T>
+__global__ void __launch_bounds__(256) attn_generic_kernel(const T* __restrict__ qkv, int S, int C, T* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* qs = sm;       // C
+    float* ps = sm + C;   // S
+    float* red = ps + S;  // 16
+    const int n = blockIdx.y, i = blockIdx.x;
+    const T* base = qkv + (int64_t)n * S * 3 * C;
+    const float kscale = powf((float)C, -0.5f);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) qs[c] = to_f(base[(int64_t)i * 3 * C + c]);
+    __syncthreads();
+    float lmax = -INFINITY;
+    for (int j = threadIdx.x; j < S; j += blockDim.x) {
+        const T* kr = base + (int64_t)j * 3 * C + C;
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) acc = fmaf(qs[c], to_f(from_f<T>(to_f(kr[c]) * kscale)), acc);
+        ps[j] = acc;
+        lmax = fmaxf(lmax, acc);
+    }
+    const float m = block_max(lmax, red);
+    float lsum = 0.f;
+    for (int j = threadIdx.x; j < S; j += blockDim.x) {
+        const float e = expf(ps[j] - m);
+        ps[j] = e;
+        lsum += e;
+    }
+    const float tot = block_sum(lsum, red);
+    __syncthreads();
+    const float inv = 1.0f / tot;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc = 0.f;
+        for (int j = 0; j < S; ++j) acc = fmaf(to_f(from_f<T>(ps[j] * inv)), to_f(base[(int64_t)j * 3 * C + 2 * C + c]), acc);
+        out[((int64_t)n * S + i) * C + c] = from_f<T>(acc);
+    }
+}
+
+int launch_attn_generic(int dtype, const void* qkv, int N, int S, int C, void* out, hipStream_t s) {
+    const size_t lds = (size_t)(C + S + 16) * sizeof(float);
+    DMME_REQUIRE(lds <= 64 * 1024, DMME_ERR_UNSUPPORTED, "attention generic: C+S too large (%d+%d)", C, S);
+    dim3 grid(S, N);
+    if (dtype == DMME_BF16)
+        hipLaunchKernelGGL(attn_generic_kernel<bf16>, grid, dim3(256), lds, s, (const bf16*)qkv, S, C, (bf16*)out);
+    else
+        hipLaunchKernelGGL(attn_generic_kernel<float>, grid, dim3(256), lds, s, (const float*)qkv, S, C, (float*)out);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+// ------------------------------------------------------------------ time embedding pieces
+// SinusoidalPositionEmbeddings.forward (models/ddpm.py:347-348): [sin(t f), cos(t f)]
+__global__ void time_sinusoid_kernel(const int64_t* t, int nt, const float* freqs, int half, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nt * half) return;
+    const int r = i / half, k = i % half;
+    const float arg = (float)t[r] * freqs[k];
+    out[(int64_t)r * 2 * half + k] = sinf(arg);
+    out[(int64_t)r * 2 * half + half + k] = cosf(arg);
+}
+
+int launch_time_sinusoid(const int64_t* t, int nt, const float* freqs, int half, float* out, hipStream_t s) {
+    const int total = nt * half;
+    hipLaunchKernelGGL(time_sinusoid_kernel, dim3((total + 255) / 256), dim3(256), 0, s, t, nt, freqs, half, out);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+// nn.Linear on tiny batches: one wavefront per output feature, coalesced weight row,
+// shuffle reduction; loops over the nt input rows (1 when sampling, B when training).
+template <typename T>
+__global__ void __launch_bounds__(256) linear_wave_kernel(const float* __restrict__ in, int nt, int K,
+                                                          const T* __restrict__ W, const float* __restrict__ bias,
+                                                          int Nout, int out_silu, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= Nout) return;
+    const T* wr = W + (int64_t)o * K;
+    for (int r = 0; r < nt; ++r) {
+        const float* xr = in + (int64_t)r * K;
+        float acc = 0.f;
+        for (int k = lane; k < K; k += 64) acc = fmaf(xr[k], to_f(wr[k]), acc);
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            float v = acc + bias[o];
+            if (out_silu) v = silu_f(v);
+            out[(int64_t)r * Nout + o] = v;
+        }
+    }
+}
+
+int launch_linear_wave(int dtype, const float* in, int nt, int K, const void* W, const float* bias, int Nout,
+                       int out_silu, float* out, hipStream_t s) {
+    dim3 grid((Nout + 3) / 4);
+    if (dtype == DMME_BF16)
+        hipLaunchKernelGGL(linear_wave_kernel<bf16>, grid, dim3(256), 0, s, in, nt, K, (const bf16*)W, bias, Nout,
+                           out_silu, out);
+    else
+        hipLaunchKernelGGL(linear_wave_kernel<float>, grid, dim3(256), 0, s, in, nt, K, (const float*)W, bias, Nout,
+                           out_silu, out);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+// ------------------------------------------------------------------ layout converters
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* src, int C, int HW, T* dst, int64_t total) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t p = i / C;  // n*HW + hw
+        const int64_t n = p / HW, hw = p % HW;
+        dst[i] = from_f<T>(src[(n * C + c) * HW + hw]);
+    }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* src, int C, int HW, float* dst, int64_t total) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t hw = i % HW;
+        const int64_t q = i / HW;  // n*C + c
+        const int64_t n = q / C, c = q % C;
+        dst[i] = to_f(src[(n * HW + hw) * C + c]);
+    }
+}
+static inline unsigned grid_for(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    return (unsigned)(b > 16384 ? 16384 : (b < 1 ? 1 : b));
+}
+int launch_nchw_to_nhwc(int dtype, const float* src, int N, int C, int HW, void* dst, hipStream_t s) {
+    const int64_t total = (int64_t)N * C * HW;
+    if (dtype == DMME_BF16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, src, C, HW, (bf16*)dst, total);
+    else
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, src, C, HW, (float*)dst, total);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+int launch_nhwc_to_nchw(int dtype, const void* src, int N, int C, int HW, float* dst, hipStream_t s) {
+    const int64_t total = (int64_t)N * C * HW;
+    if (dtype == DMME_BF16)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)src, C, HW, dst, total);
+    else
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)src, C, HW, dst, total);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+// ------------------------------------------------------------------ weight re-pack
+// (Cout, Cin, k, k) fp32 -> [Cout][k*k][Cin] T.  Linear / 1x1 weights have taps = 1.
+template <typename T>
+__global__ void pack_weight_kernel(const float* src, int Cin, int taps, T* dst, int64_t total) {
+    const int64_t row = (int64_t)Cin * taps;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / row, rem = e % row;
+        const int tap = (int)(rem / Cin), ci = (int)(rem % Cin);
+        dst[e] = from_f<T>(src[(r * Cin + ci) * taps + tap]);
+    }
+}
+int launch_pack_weight(int dtype, const float* src, int Cout, int Cin, int taps, void* dst, hipStream_t s) {
+    const int64_t total = (int64_t)Cout * Cin * taps;
+    if (dtype == DMME_BF16)
+        hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, src, Cin, taps, (bf16*)dst, total);
+    else
+        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, src, Cin, taps, (float*)dst, total);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+// table-driven: one workgroup per PackItem (a run of rows of one tensor)
+template <typename T>
+__global__ void __launch_bounds__(256) pack_table_kernel(const PackItem* items, const float* ref, char* packed) {
+    const PackItem it = items[blockIdx.x];
+    const int64_t row = (int64_t)it.cin * it.taps;
+    const int64_t total = (int64_t)it.rows * row;
+    const float* src = ref + it.src_off;
+    const int64_t e0 = (int64_t)it.row0 * row;
+    if (it.as_f32) {
+        float* dst = (float*)(packed + it.dst_off);
+        for (int64_t e = threadIdx.x; e < total; e += blockDim.x) dst[e0 + e] = src[e0 + e];
+    } else {
+        T* dst = (T*)(packed + it.dst_off);
+        for (int64_t e = threadIdx.x; e < total; e += blockDim.x) {
+            const int64_t g = e0 + e;
+            const int64_t r = g / row, rem = g % row;
+            const int tap = (int)(rem / it.cin), ci = (int)(rem % it.cin);
+            dst[g] = from_f<T>(src[(r * it.cin + ci) * it.taps + tap]);
+        }
+    }
+}
+int launch_pack_table(int dtype, const PackItem* items_dev, int n_items, const float* ref_flat, void* packed,
+                      hipStream_t s) {
+    if (n_items == 0) return DMME_OK;
+    if (dtype == DMME_BF16)
+        hipLaunchKernelGGL(pack_table_kernel<bf16>, dim3(n_items), dim3(256), 0, s, items_dev, ref_flat, (char*)packed);
+    else
+        hipLaunchKernelGGL(pack_table_kernel<float>, dim3(n_items), dim3(256), 0, s, items_dev, ref_flat, (char*)packed);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+}  // namespace dmme

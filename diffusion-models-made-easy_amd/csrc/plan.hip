@@ -1,0 +1,794 @@
+// Host side of libdmme_hip: the UNet execution plan (layer graph, parameter table,
+// packed-weight layout, workspace layout, launch sequence) and the extern "C" API.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+
+namespace dmme {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+struct Param {
+    std::string name;
+    int ndim = 0;
+    int64_t shape[4] = {1, 1, 1, 1};
+    int64_t ref_off = 0;     // elements, fp32 reference-layout flat buffer
+    int64_t packed_off = 0;  // bytes
+    bool is_buffer = false;
+    bool as_f32 = true;      // stays fp32 in the packed buffer (bias / gamma / beta / freqs)
+    int cout = 1, cin = 1, taps = 1;
+    int64_t numel() const { return shape[0] * shape[1] * shape[2] * shape[3]; }
+};
+
+struct Tensor {  // an activation in the workspace, NHWC in the compute dtype
+    int64_t off = 0;
+    int C = 0, H = 0, W = 0;
+};
+
+enum OpKind { OP_SINUS, OP_LINEAR, OP_GN, OP_CONV, OP_ATTN };
+
+struct Op {
+    OpKind kind;
+    // OP_LINEAR: in (fp32 ws offset) -> out (fp32 ws offset)
+    int64_t lin_in = 0, lin_out = 0;
+    int lin_K = 0, lin_N = 0, lin_w = -1, lin_b = -1, lin_silu = 0;
+    // OP_GN
+    int gn_src1 = -1, gn_src2 = -1, gn_gamma = -1, gn_beta = -1;
+    int64_t gn_scale = 0, gn_shift = 0;
+    // OP_CONV
+    int src1 = -1, src2 = -1;  // tensor ids; -2: network input (NCHW fp32)
+    int w = -1, b = -1;
+    int gn = -1;               // op index of the GN providing scale/shift
+    int pro_silu = 0, out_silu = 0;
+    int64_t dmask_off = -1;    // float offset into the drop-mask buffer
+    int tproj_col = -1;        // column offset into tproj
+    int res1 = -1, res2 = -1;
+    int dst = -1;              // tensor id; -2: network output (NCHW fp32)
+    int up = 0, stride = 1, taps = 9;
+    // OP_ATTN
+    int at_qkv = -1, at_out = -1;
+};
+
+}  // namespace dmme
+
+using namespace dmme;
+
+struct dmme_plan {
+    dmme_unet_cfg cfg;
+    int B, H, W, dtype, device;
+    std::vector<Param> params;
+    std::vector<Tensor> tensors;
+    std::vector<Op> ops;
+    std::unordered_map<std::string, int> named;  // module name -> tensor id
+    int64_t ref_numel = 0, packed_bytes = 0, ws_bytes = 0, dropmask_numel = 0;
+    int64_t ws_tsin = 0, ws_th1 = 0, ws_temb = 0, ws_tproj = 0, ws_gnpart = 0;
+    int tproj_cols = 0;
+    int64_t tproj_w_off = 0, tproj_b_off = 0;  // packed byte offsets of the concatenated projection
+    int freqs_param = -1;
+    PackItem* items_dev = nullptr;
+    int n_items = 0;
+    int n_launches = 0;
+};
+
+namespace {
+
+struct Node {
+    int kind;  // 0 res, 1 down, 2 up
+    std::string prefix;
+    int cin, cout;
+    bool attn;
+    // parameter indices
+    int gn1w = -1, gn1b = -1, c1w = -1, c1b = -1, tw = -1, tb = -1, gn2w = -1, gn2b = -1, c2w = -1, c2b = -1;
+    int rw = -1, rb = -1, anw = -1, anb = -1, qw = -1, qb = -1, pw = -1, pb = -1;
+    int cw = -1, cb = -1;  // down / up conv
+    int tproj_col = 0;
+};
+
+struct Builder {
+    dmme_plan* P;
+    int64_t ref_cursor = 0;
+
+    int add_param(const std::string& name, std::initializer_list<int64_t> shape, bool is_buffer, bool as_f32,
+                  int cout, int cin, int taps) {
+        Param p;
+        p.name = name;
+        p.ndim = (int)shape.size();
+        int i = 0;
+        for (auto s : shape) p.shape[i++] = s;
+        p.ref_off = ref_cursor;
+        p.is_buffer = is_buffer;
+        p.as_f32 = as_f32;
+        p.cout = cout;
+        p.cin = cin;
+        p.taps = taps;
+        ref_cursor += p.numel();
+        P->params.push_back(p);
+        return (int)P->params.size() - 1;
+    }
+    void conv(const std::string& p, int ci, int co, int k, int& w, int& b) {
+        w = add_param(p + ".weight", {co, ci, k, k}, false, false, co, ci, k * k);
+        b = add_param(p + ".bias", {co}, false, true, 1, co, 1);
+    }
+    void lin(const std::string& p, int ci, int co, int& w, int& b) {
+        w = add_param(p + ".weight", {co, ci}, false, false, co, ci, 1);
+        b = add_param(p + ".bias", {co}, false, true, 1, co, 1);
+    }
+    void gn(const std::string& p, int c, int& w, int& b) {
+        w = add_param(p + ".weight", {c}, false, true, 1, c, 1);
+        b = add_param(p + ".bias", {c}, false, true, 1, c, 1);
+    }
+    void res_params(Node& n) {
+        const dmme_unet_cfg& c = P->cfg;
+        const std::string& p = n.prefix;
+        gn(p + ".conv1.0", n.cin, n.gn1w, n.gn1b);
+        conv(p + ".conv1.2", n.cin, n.cout, 3, n.c1w, n.c1b);
+        lin(p + ".condition.0", c.emb_dim, n.cout, n.tw, n.tb);
+        gn(p + ".conv2.0", n.cout, n.gn2w, n.gn2b);
+        // norm_act_drop_conv (models/ddpm.py:25-35): conv index 3 with Dropout2d, 2 without
+        conv(p + (c.dropout > 0 ? ".conv2.3" : ".conv2.2"), n.cout, n.cout, 3, n.c2w, n.c2b);
+        if (n.cin != n.cout) conv(p + ".residual", n.cin, n.cout, 1, n.rw, n.rb);
+        if (n.attn) {
+            gn(p + ".attention.norm", n.cout, n.anw, n.anb);
+            conv(p + ".attention.qkv_proj", n.cout, 3 * n.cout, 1, n.qw, n.qb);
+            conv(p + ".attention.proj", n.cout, n.cout, 1, n.pw, n.pb);
+        }
+    }
+};
+
+bool in_list(const int* v, int n, int x) {
+    for (int i = 0; i < n; ++i)
+        if (v[i] == x) return true;
+    return false;
+}
+
+int build_plan(dmme_plan* P) {
+    const dmme_unet_cfg& c = P->cfg;
+    const int nb = c.num_blocks, nd = c.num_depths;
+    const int B = P->B;
+    const int64_t es = (int64_t)dtype_size(P->dtype);
+
+    // ---- layer graph: UNet.__init__ (models/ddpm.py:203-279) ----
+    std::vector<int> chans;
+    chans.push_back(c.channels_per_depth[0]);
+    for (int d = 0; d < nd; ++d)
+        for (int b = 0; b < nb; ++b) chans.push_back(c.channels_per_depth[d]);
+    const int L = (int)chans.size();  // len(channels)
+    auto is_cut = [&](int layer_num) {  // layer_num in downsample_layers = {nb*i : 1 <= i < nd}
+        return layer_num > 0 && layer_num % nb == 0 && layer_num / nb <= nd - 1;
+    };
+    auto has_attn = [&](int depth) { return in_list(c.attention_depths, c.num_attention_depths, depth); };
+
+    std::vector<Node> down, mid, up;
+    int depth = 1;
+    for (int i = 0; i + 1 < L; ++i) {
+        Node n{0, "down_layers." + std::to_string(down.size()), chans[i], chans[i + 1], has_attn(depth)};
+        down.push_back(n);
+        if (is_cut(i + 1)) {
+            Node d{1, "down_layers." + std::to_string(down.size()), chans[i + 1], chans[i + 1], false};
+            down.push_back(d);
+            ++depth;
+        }
+    }
+    // the reference's `if down_layers[-1] == len(channels) - 1` (:242) compares a module
+    // with an int and is never true: the up path starts with ResBlocks, never an UpSample
+    depth = nd;
+    for (int i = 0; i + 1 < L; ++i) {
+        const int ci = chans[L - 1 - i], co = chans[L - 2 - i];
+        const bool at = has_attn(depth);
+        const int layer_num = L - 1 - i;
+        up.push_back(Node{0, "up_layers." + std::to_string(up.size()), 2 * ci, co, at});
+        if (is_cut(layer_num - 1)) {
+            up.push_back(Node{0, "up_layers." + std::to_string(up.size()), 2 * co, co, at});
+            up.push_back(Node{2, "up_layers." + std::to_string(up.size()), co, co, false});
+            --depth;
+        }
+    }
+    up.push_back(Node{0, "up_layers." + std::to_string(up.size()), 2 * chans[0], chans[0], has_attn(1)});
+    const int top = chans[L - 1];
+    mid.push_back(Node{0, "middle_layers.0", top, top, true});
+    mid.push_back(Node{0, "middle_layers.1", top, top, false});
+
+    // ---- parameter table in nn.Module registration order ----
+    Builder bld{P};
+    const int half = c.pos_dim / 2;
+    P->freqs_param = bld.add_param("condition.0.embeddings", {1, half}, true, true, 1, half, 1);
+    int l1w, l1b, l2w, l2b, icw, icb, ogw, ogb, ocw, ocb;
+    bld.lin("condition.1", c.pos_dim, c.emb_dim, l1w, l1b);
+    bld.lin("condition.3", c.emb_dim, c.emb_dim, l2w, l2b);
+    bld.conv("input_conv", c.in_channels, chans[0], 3, icw, icb);
+    for (auto* seq : {&down, &up, &mid})
+        for (auto& n : *seq) {
+            if (n.kind == 0)
+                bld.res_params(n);
+            else if (n.kind == 1)
+                bld.conv(n.prefix, n.cin, n.cout, 3, n.cw, n.cb);
+            else
+                bld.conv(n.prefix + ".conv", n.cin, n.cout, 3, n.cw, n.cb);
+        }
+    bld.gn("output_conv.0", chans[0], ogw, ogb);
+    bld.conv("output_conv.2", chans[0], c.in_channels, 3, ocw, ocb);
+    P->ref_numel = bld.ref_cursor;
+
+    // ---- packed layout: the per-block time projections form one [sumCout][emb] matrix ----
+    int tcols = 0;
+    for (auto* seq : {&down, &up, &mid})
+        for (auto& n : *seq)
+            if (n.kind == 0) {
+                n.tproj_col = tcols;
+                tcols += n.cout;
+            }
+    P->tproj_cols = tcols;
+    int64_t cur = 0;
+    P->tproj_w_off = cur;
+    cur = align_up(cur + (int64_t)tcols * c.emb_dim * es, 256);
+    P->tproj_b_off = cur;
+    cur = align_up(cur + (int64_t)tcols * 4, 256);
+    std::unordered_map<int, const Node*> tw_owner, tb_owner;
+    for (auto* seq : {&down, &up, &mid})
+        for (auto& n : *seq)
+            if (n.kind == 0) {
+                tw_owner[n.tw] = &n;
+                tb_owner[n.tb] = &n;
+            }
+    for (int i = 0; i < (int)P->params.size(); ++i) {
+        Param& p = P->params[i];
+        if (tw_owner.count(i)) {
+            p.packed_off = P->tproj_w_off + (int64_t)tw_owner[i]->tproj_col * c.emb_dim * es;
+        } else if (tb_owner.count(i)) {
+            p.packed_off = P->tproj_b_off + (int64_t)tb_owner[i]->tproj_col * 4;
+        } else {
+            p.packed_off = cur;
+            cur = align_up(cur + p.numel() * (p.as_f32 ? 4 : es), 256);
+        }
+    }
+    P->packed_bytes = cur;
+
+    // ---- workspace + op list ----
+    int64_t ws = 0;
+    auto ws_alloc = [&](int64_t bytes) {
+        const int64_t o = ws;
+        ws = align_up(ws + bytes, 256);
+        return o;
+    };
+    auto new_tensor = [&](int C, int H, int W) {
+        Tensor t;
+        t.C = C;
+        t.H = H;
+        t.W = W;
+        t.off = ws_alloc((int64_t)B * H * W * C * es);
+        P->tensors.push_back(t);
+        return (int)P->tensors.size() - 1;
+    };
+    P->ws_tsin = ws_alloc((int64_t)B * c.pos_dim * 4);
+    P->ws_th1 = ws_alloc((int64_t)B * c.emb_dim * 4);
+    P->ws_temb = ws_alloc((int64_t)B * c.emb_dim * 4);
+    P->ws_tproj = ws_alloc((int64_t)B * tcols * 4);
+
+    std::vector<Op>& ops = P->ops;
+    {
+        Op o{};
+        o.kind = OP_SINUS;
+        ops.push_back(o);
+        Op a{};
+        a.kind = OP_LINEAR;
+        a.lin_in = P->ws_tsin; a.lin_out = P->ws_th1; a.lin_K = c.pos_dim; a.lin_N = c.emb_dim;
+        a.lin_w = l1w; a.lin_b = l1b; a.lin_silu = 1;
+        ops.push_back(a);
+        Op b{};
+        b.kind = OP_LINEAR;
+        b.lin_in = P->ws_th1; b.lin_out = P->ws_temb; b.lin_K = c.emb_dim; b.lin_N = c.emb_dim;
+        b.lin_w = l2w; b.lin_b = l2b; b.lin_silu = 1;
+        ops.push_back(b);
+        Op d{};
+        d.kind = OP_LINEAR;  // all per-block projections at once (w/b = -1: concatenated region)
+        d.lin_in = P->ws_temb; d.lin_out = P->ws_tproj; d.lin_K = c.emb_dim; d.lin_N = tcols;
+        d.lin_w = -1; d.lin_b = -1; d.lin_silu = 0;
+        ops.push_back(d);
+    }
+    size_t gn_part_max = 0;
+    auto emit_gn = [&](int s1, int s2, int gw, int gb) {
+        Op o{};
+        o.kind = OP_GN;
+        o.gn_src1 = s1; o.gn_src2 = s2; o.gn_gamma = gw; o.gn_beta = gb;
+        const Tensor& t1 = P->tensors[s1];
+        const int C = t1.C + (s2 >= 0 ? P->tensors[s2].C : 0);
+        o.gn_scale = ws_alloc((int64_t)B * C * 4);
+        o.gn_shift = ws_alloc((int64_t)B * C * 4);
+        const size_t part = gn_fast_scratch_floats(B, t1.H * t1.W, C, c.num_groups);
+        if (part > gn_part_max) gn_part_max = part;
+        ops.push_back(o);
+        return (int)ops.size() - 1;
+    };
+    int64_t dmask_cursor = 0;
+    int cur_t, H = P->H, W = P->W;
+    {
+        Op o{};
+        o.kind = OP_CONV;
+        o.src1 = -2; o.w = icw; o.b = icb; o.taps = 9;
+        o.dst = new_tensor(chans[0], H, W);
+        ops.push_back(o);
+        cur_t = o.dst;
+        P->named["input_conv"] = cur_t;
+    }
+    std::vector<int> skips{cur_t};
+
+    auto emit_res = [&](const Node& n, int x1, int x2) {
+        const Tensor tx = P->tensors[x1];
+        const int h = tx.H, w = tx.W;
+        const int g1 = emit_gn(x1, x2, n.gn1w, n.gn1b);
+        Op c1{};
+        c1.kind = OP_CONV;
+        c1.src1 = x1; c1.src2 = x2; c1.w = n.c1w; c1.b = n.c1b; c1.gn = g1; c1.pro_silu = 1;
+        c1.tproj_col = n.tproj_col; c1.taps = 9;
+        c1.dst = new_tensor(n.cout, h, w);
+        ops.push_back(c1);
+        const int hmid = c1.dst;
+        const int g2 = emit_gn(hmid, -1, n.gn2w, n.gn2b);
+        int r1 = x1, r2 = x2;
+        if (n.cin != n.cout) {
+            Op rc{};
+            rc.kind = OP_CONV;
+            rc.src1 = x1; rc.src2 = x2; rc.w = n.rw; rc.b = n.rb; rc.taps = 1;
+            rc.dst = new_tensor(n.cout, h, w);
+            ops.push_back(rc);
+            r1 = rc.dst;
+            r2 = -1;
+        }
+        Op c2{};
+        c2.kind = OP_CONV;
+        c2.src1 = hmid; c2.w = n.c2w; c2.b = n.c2b; c2.gn = g2; c2.pro_silu = 1; c2.taps = 9;
+        if (P->cfg.dropout > 0) c2.dmask_off = dmask_cursor;
+        dmask_cursor += (int64_t)B * n.cout;
+        c2.res1 = r1; c2.res2 = r2;
+        c2.dst = new_tensor(n.cout, h, w);
+        ops.push_back(c2);
+        int out = c2.dst;
+        if (n.attn) {
+            const int g3 = emit_gn(out, -1, n.anw, n.anb);
+            Op q{};
+            q.kind = OP_CONV;
+            q.src1 = out; q.w = n.qw; q.b = n.qb; q.gn = g3; q.taps = 1;
+            q.dst = new_tensor(3 * n.cout, h, w);
+            ops.push_back(q);
+            Op at{};
+            at.kind = OP_ATTN;
+            at.at_qkv = q.dst;
+            at.at_out = new_tensor(n.cout, h, w);
+            ops.push_back(at);
+            Op pr{};
+            pr.kind = OP_CONV;
+            pr.src1 = at.at_out; pr.w = n.pw; pr.b = n.pb; pr.taps = 1; pr.res1 = out;
+            pr.dst = new_tensor(n.cout, h, w);
+            ops.push_back(pr);
+            out = pr.dst;
+        }
+        P->named[n.prefix] = out;
+        return out;
+    };
+
+    for (auto& n : down) {
+        if (n.kind == 0) {
+            cur_t = emit_res(n, cur_t, -1);
+        } else {
+            DMME_REQUIRE(H % 2 == 0 && W % 2 == 0, DMME_ERR_UNSUPPORTED, "odd resolution %dx%d at a DownSample", H, W);
+            Op o{};
+            o.kind = OP_CONV;
+            o.src1 = cur_t; o.w = n.cw; o.b = n.cb; o.taps = 9; o.stride = 2;
+            H /= 2; W /= 2;
+            o.dst = new_tensor(n.cout, H, W);
+            ops.push_back(o);
+            cur_t = o.dst;
+            P->named[n.prefix] = cur_t;
+        }
+        skips.push_back(cur_t);
+    }
+    for (auto& n : mid) cur_t = emit_res(n, cur_t, -1);
+    for (auto& n : up) {
+        if (n.kind == 0) {
+            DMME_REQUIRE(!skips.empty(), DMME_ERR_INVALID, "skip stack underflow");
+            const int sk = skips.back();
+            skips.pop_back();
+            const Tensor &a = P->tensors[cur_t], &b = P->tensors[sk];
+            DMME_REQUIRE(a.C + b.C == n.cin && a.H == b.H && a.W == b.W, DMME_ERR_INVALID,
+                         "%s: concat %d+%d channels does not match conv input %d", n.prefix.c_str(), a.C, b.C, n.cin);
+            cur_t = emit_res(n, cur_t, sk);  // torch.cat([x, skip]) : x first (:310)
+        } else {
+            Op o{};
+            o.kind = OP_CONV;
+            o.src1 = cur_t; o.w = n.cw; o.b = n.cb; o.taps = 9; o.up = 1;
+            H *= 2; W *= 2;
+            o.dst = new_tensor(n.cout, H, W);
+            ops.push_back(o);
+            cur_t = o.dst;
+            P->named[n.prefix] = cur_t;
+        }
+    }
+    {
+        const int g = emit_gn(cur_t, -1, ogw, ogb);
+        Op o{};
+        o.kind = OP_CONV;
+        o.src1 = cur_t; o.w = ocw; o.b = ocb; o.gn = g; o.pro_silu = 1; o.taps = 9; o.dst = -2;
+        ops.push_back(o);
+    }
+    P->dropmask_numel = dmask_cursor;
+    P->ws_gnpart = ws_alloc((int64_t)(gn_part_max ? gn_part_max : 1) * 4);
+    P->ws_bytes = ws;
+    P->n_launches = (int)ops.size();
+    return DMME_OK;
+}
+
+int build_pack_items(dmme_plan* P, std::vector<PackItem>& items) {
+    const int64_t CHUNK = 16384;
+    for (const Param& p : P->params) {
+        const int64_t row = (int64_t)p.cin * p.taps;
+        int64_t rows_per = CHUNK / row;
+        if (rows_per < 1) rows_per = 1;
+        for (int64_t r0 = 0; r0 < p.cout; r0 += rows_per) {
+            PackItem it;
+            it.src_off = p.ref_off;
+            it.dst_off = p.packed_off;
+            it.cout = p.cout;
+            it.cin = p.cin;
+            it.taps = p.taps;
+            it.row0 = (int32_t)r0;
+            it.rows = (int32_t)((p.cout - r0) < rows_per ? (p.cout - r0) : rows_per);
+            it.as_f32 = p.as_f32 ? 1 : 0;
+            items.push_back(it);
+        }
+    }
+    return DMME_OK;
+}
+
+// fill the device-side descriptor of a conv op
+int run_conv(const dmme_plan* P, const Op& o, const char* packed, const float* x, float* y, char* ws,
+             const float* drop_masks, int nt, hipStream_t s) {
+    ConvArgs a{};
+    const int64_t es = (int64_t)dtype_size(P->dtype);
+    (void)es;
+    a.N = P->B;
+    if (o.src1 == -2) {
+        a.src1 = x;
+        a.in_nchw = 1;
+        a.C1 = P->cfg.in_channels;
+        a.Hin = P->H;
+        a.Win = P->W;
+    } else {
+        const Tensor& t = P->tensors[o.src1];
+        a.src1 = ws + t.off;
+        a.C1 = t.C;
+        a.Hin = t.H;
+        a.Win = t.W;
+    }
+    if (o.src2 >= 0) {
+        a.src2 = ws + P->tensors[o.src2].off;
+        a.C2 = P->tensors[o.src2].C;
+    }
+    const Param& w = P->params[o.w];
+    a.w = packed + w.packed_off;
+    a.bias = (const float*)(packed + P->params[o.b].packed_off);
+    a.Cout = w.cout;
+    a.taps = o.taps;
+    a.stride = o.stride;
+    a.up = o.up;
+    const int Hv = o.up ? 2 * a.Hin : a.Hin, Wv = o.up ? 2 * a.Win : a.Win;
+    a.Hout = Hv / o.stride;
+    a.Wout = Wv / o.stride;
+    if (o.gn >= 0) {
+        a.scale = (const float*)(ws + P->ops[o.gn].gn_scale);
+        a.shift = (const float*)(ws + P->ops[o.gn].gn_shift);
+    }
+    a.pro_silu = o.pro_silu;
+    a.out_silu = o.out_silu;
+    if (o.dmask_off >= 0 && drop_masks) a.dmask = drop_masks + o.dmask_off;
+    if (o.tproj_col >= 0) {
+        a.tproj = (const float*)(ws + P->ws_tproj) + o.tproj_col;
+        a.tproj_ld = P->tproj_cols;
+        a.nt = nt;
+    }
+    if (o.res1 >= 0) {
+        a.res1 = ws + P->tensors[o.res1].off;
+        a.R1 = P->tensors[o.res1].C;
+        if (o.res2 >= 0) a.res2 = ws + P->tensors[o.res2].off;
+    }
+    if (o.dst == -2) {
+        a.dst = y;
+        a.out_nchw = 1;
+    } else {
+        a.dst = ws + P->tensors[o.dst].off;
+    }
+    if (conv_mfma_supported(P->dtype, a)) return launch_conv_mfma(P->dtype, a, s);
+    return launch_conv_generic(P->dtype, a, s);
+}
+
+}  // namespace
+
+// ======================================================================== extern "C"
+extern "C" {
+
+DMME_API const char* dmme_last_error(void) { return g_err; }
+DMME_API int dmme_version(void) { return 100; }
+DMME_API int dmme_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W, int dtype, int device, dmme_plan** out) {
+    DMME_REQUIRE(cfg && out, DMME_ERR_INVALID, "plan_create: null argument");
+    DMME_REQUIRE(B > 0 && H > 0 && W > 0, DMME_ERR_INVALID, "plan_create: bad shape B=%d H=%d W=%d", B, H, W);
+    DMME_REQUIRE(dtype == DMME_F32 || dtype == DMME_BF16, DMME_ERR_INVALID, "plan_create: bad dtype %d", dtype);
+    DMME_REQUIRE(cfg->num_depths >= 1 && cfg->num_depths <= 8 && cfg->num_blocks >= 1, DMME_ERR_INVALID,
+                 "plan_create: bad depth/blocks");
+    DMME_REQUIRE(cfg->num_attention_depths >= 0 && cfg->num_attention_depths <= 8, DMME_ERR_INVALID, "bad attention_depths");
+    DMME_REQUIRE(cfg->pos_dim >= 4 && cfg->pos_dim % 2 == 0, DMME_ERR_INVALID, "pos_dim must be even and >= 4");
+    for (int d = 0; d < cfg->num_depths; ++d)
+        DMME_REQUIRE(cfg->channels_per_depth[d] > 0 && cfg->channels_per_depth[d] % cfg->num_groups == 0,
+                     DMME_ERR_INVALID, "channels_per_depth[%d]=%d not divisible by num_groups=%d", d,
+                     cfg->channels_per_depth[d], cfg->num_groups);
+    dmme_plan* P = new dmme_plan();
+    P->cfg = *cfg;
+    P->B = B;
+    P->H = H;
+    P->W = W;
+    P->dtype = dtype;
+    P->device = device;
+    int rc = build_plan(P);
+    if (rc != DMME_OK) {
+        delete P;
+        return rc;
+    }
+    if (device >= 0) {
+        std::vector<PackItem> items;
+        build_pack_items(P, items);
+        P->n_items = (int)items.size();
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) e = hipMalloc((void**)&P->items_dev, items.size() * sizeof(PackItem));
+        if (e == hipSuccess) e = hipMemcpy(P->items_dev, items.data(), items.size() * sizeof(PackItem), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            set_error("plan_create: device table setup failed: %s", hipGetErrorString(e));
+            delete P;
+            return DMME_ERR_HIP;
+        }
+    }
+    *out = P;
+    return DMME_OK;
+}
+
+DMME_API void dmme_unet_plan_destroy(dmme_plan* plan) {
+    if (!plan) return;
+    if (plan->items_dev) (void)hipFree(plan->items_dev);
+    delete plan;
+}
+
+DMME_API int dmme_unet_plan_num_params(const dmme_plan* plan) { return plan ? (int)plan->params.size() : 0; }
+
+DMME_API int dmme_unet_plan_param_info(const dmme_plan* plan, int index, char* name, int name_cap, int* ndim,
+                              int64_t shape[4], int64_t* ref_offset, int* is_buffer) {
+    DMME_REQUIRE(plan && index >= 0 && index < (int)plan->params.size(), DMME_ERR_INVALID, "param_info: bad index %d", index);
+    const Param& p = plan->params[index];
+    if (name && name_cap > 0) {
+        strncpy(name, p.name.c_str(), (size_t)name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (ndim) *ndim = p.ndim;
+    if (shape)
+        for (int i = 0; i < 4; ++i) shape[i] = p.shape[i];
+    if (ref_offset) *ref_offset = p.ref_off;
+    if (is_buffer) *is_buffer = p.is_buffer ? 1 : 0;
+    return DMME_OK;
+}
+
+DMME_API int64_t dmme_unet_plan_ref_numel(const dmme_plan* plan) { return plan ? plan->ref_numel : 0; }
+DMME_API int64_t dmme_unet_plan_packed_bytes(const dmme_plan* plan) { return plan ? plan->packed_bytes : 0; }
+DMME_API int64_t dmme_unet_plan_workspace_bytes(const dmme_plan* plan) { return plan ? plan->ws_bytes : 0; }
+DMME_API int64_t dmme_unet_plan_dropmask_numel(const dmme_plan* plan) { return plan ? plan->dropmask_numel : 0; }
+DMME_API int dmme_unet_plan_num_launches(const dmme_plan* plan) { return plan ? plan->n_launches : 0; }
+
+DMME_API int dmme_unet_pack_params(const dmme_plan* plan, const float* ref_flat, void* packed, void* stream) {
+    DMME_REQUIRE(plan && ref_flat && packed, DMME_ERR_INVALID, "pack_params: null argument");
+    DMME_REQUIRE(plan->items_dev, DMME_ERR_INVALID, "pack_params: plan was created without a device");
+    return launch_pack_table(plan->dtype, plan->items_dev, plan->n_items, ref_flat, packed, (hipStream_t)stream);
+}
+
+DMME_API int dmme_unet_forward(const dmme_plan* plan, const void* packed, const float* x, const int64_t* t, int t_len,
+                      float* y, void* workspace, const float* drop_masks, void* stream) {
+    DMME_REQUIRE(plan && packed && x && t && y && workspace, DMME_ERR_INVALID, "unet_forward: null argument");
+    DMME_REQUIRE(t_len == 1 || t_len == plan->B, DMME_ERR_INVALID,
+                 "unet_forward: timestep tensor of length %d does not broadcast against batch %d", t_len, plan->B);
+    hipStream_t s = (hipStream_t)stream;
+    const dmme_plan* P = plan;
+    const char* pk = (const char*)packed;
+    char* ws = (char*)workspace;
+    const int nt = t_len;
+    for (const Op& o : P->ops) {
+        int rc = DMME_OK;
+        switch (o.kind) {
+            case OP_SINUS:
+                rc = launch_time_sinusoid(t, nt, (const float*)(pk + P->params[P->freqs_param].packed_off),
+                                          P->cfg.pos_dim / 2, (float*)(ws + P->ws_tsin), s);
+                break;
+            case OP_LINEAR: {
+                const char* w = o.lin_w >= 0 ? pk + P->params[o.lin_w].packed_off : pk + P->tproj_w_off;
+                const float* b = (const float*)(o.lin_b >= 0 ? pk + P->params[o.lin_b].packed_off : pk + P->tproj_b_off);
+                rc = launch_linear_wave(P->dtype, (const float*)(ws + o.lin_in), nt, o.lin_K, w, b, o.lin_N, o.lin_silu,
+                                        (float*)(ws + o.lin_out), s);
+                break;
+            }
+            case OP_GN: {
+                const Tensor& t1 = P->tensors[o.gn_src1];
+                const void* s1 = ws + t1.off;
+                const void* s2 = o.gn_src2 >= 0 ? ws + P->tensors[o.gn_src2].off : nullptr;
+                const int C2 = o.gn_src2 >= 0 ? P->tensors[o.gn_src2].C : 0;
+                const float* gam = (const float*)(pk + P->params[o.gn_gamma].packed_off);
+                const float* bet = (const float*)(pk + P->params[o.gn_beta].packed_off);
+                float* sc = (float*)(ws + o.gn_scale);
+                float* sh = (float*)(ws + o.gn_shift);
+                if (gn_fast_supported(P->dtype, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups))
+                    rc = launch_gn_fast(P->dtype, s1, s2, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups, gam, bet, 1e-5f,
+                                        sc, sh, (float*)(ws + P->ws_gnpart), s);
+                else
+                    rc = launch_gn_generic(P->dtype, s1, s2, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups, gam, bet,
+                                           1e-5f, sc, sh, s);
+                break;
+            }
+            case OP_CONV:
+                rc = run_conv(P, o, pk, x, y, ws, drop_masks, nt, s);
+                break;
+            case OP_ATTN: {
+                const Tensor& q = P->tensors[o.at_qkv];
+                const int S = q.H * q.W, C = q.C / 3;
+                if (attn_mfma_supported(P->dtype, P->B, S, C))
+                    rc = launch_attn_mfma(P->dtype, ws + q.off, P->B, S, C, ws + P->tensors[o.at_out].off, s);
+                else
+                    rc = launch_attn_generic(P->dtype, ws + q.off, P->B, S, C, ws + P->tensors[o.at_out].off, s);
+                break;
+            }
+        }
+        if (rc != DMME_OK) return rc;
+    }
+    return DMME_OK;
+}
+
+DMME_API int dmme_unet_debug_read(const dmme_plan* plan, const void* workspace, const char* name, float* dst,
+                         int64_t numel_cap, int64_t* numel_out, void* stream) {
+    DMME_REQUIRE(plan && workspace && name && dst, DMME_ERR_INVALID, "debug_read: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (strcmp(name, "condition") == 0) {
+        const int64_t n = (int64_t)plan->B * plan->cfg.emb_dim;  // rows beyond t_len are unspecified
+        DMME_REQUIRE(n <= numel_cap, DMME_ERR_INVALID, "debug_read: destination too small");
+        DMME_CHECK_HIP(hipMemcpyAsync(dst, (const char*)workspace + plan->ws_temb, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        if (numel_out) *numel_out = n;
+        return DMME_OK;
+    }
+    auto it = plan->named.find(name);
+    DMME_REQUIRE(it != plan->named.end(), DMME_ERR_INVALID, "debug_read: unknown module '%s'", name);
+    const Tensor& t = plan->tensors[it->second];
+    const int64_t n = (int64_t)plan->B * t.C * t.H * t.W;
+    DMME_REQUIRE(n <= numel_cap, DMME_ERR_INVALID, "debug_read: destination too small (%lld > %lld)", (long long)n,
+                 (long long)numel_cap);
+    if (numel_out) *numel_out = n;
+    return launch_nhwc_to_nchw(plan->dtype, (const char*)workspace + t.off, plan->B, t.C, t.H * t.W, dst, s);
+}
+
+DMME_API int dmme_dropout_masks(const dmme_plan* plan, uint64_t seed, uint64_t offset, float* masks, void* stream) {
+    DMME_REQUIRE(plan && masks, DMME_ERR_INVALID, "dropout_masks: null argument");
+    return launch_dropmask(masks, plan->dropmask_numel, plan->cfg.dropout, seed, offset, (hipStream_t)stream);
+}
+
+DMME_API int dmme_randn(float* out, int64_t numel, uint64_t seed, uint64_t offset, void* stream) {
+    DMME_REQUIRE(out && numel >= 0, DMME_ERR_INVALID, "randn: bad argument");
+    return launch_randn(out, numel, seed, offset, (hipStream_t)stream);
+}
+
+DMME_API int dmme_q_sample(const float* x0, const float* z, const float* alpha_bar, const int64_t* t, int B, int64_t chw,
+                  float* x_t, float* target, void* stream) {
+    DMME_REQUIRE(x0 && z && alpha_bar && t && x_t && B > 0 && chw > 0, DMME_ERR_INVALID, "q_sample: bad argument");
+    return launch_q_sample(x0, z, alpha_bar, t, B, chw, x_t, target, (hipStream_t)stream);
+}
+
+DMME_API int dmme_ddpm_step(float* x, const float* eps, const float* z, float inv_sqrt_alpha, float eps_coef, float sigma,
+                   int add_noise, int64_t numel, void* stream) {
+    DMME_REQUIRE(x && eps && (z || !add_noise), DMME_ERR_INVALID, "ddpm_step: null argument");
+    return launch_ddpm_step(x, eps, z, inv_sqrt_alpha, eps_coef, sigma, add_noise, numel, (hipStream_t)stream);
+}
+
+DMME_API int dmme_ddim_step(float* x, const float* eps, float sqrt_one_minus_abar, float sqrt_abar_prev, int64_t numel,
+                   void* stream) {
+    DMME_REQUIRE(x && eps, DMME_ERR_INVALID, "ddim_step: null argument");
+    return launch_ddim_step(x, eps, sqrt_one_minus_abar, sqrt_abar_prev, numel, (hipStream_t)stream);
+}
+
+DMME_API int dmme_mse_loss(const float* eps, const float* target, int64_t numel, float* loss, float* d_eps, float grad_scale,
+                  float* scratch, void* stream) {
+    DMME_REQUIRE(eps && target && loss && scratch, DMME_ERR_INVALID, "mse_loss: null argument");
+    return launch_mse(eps, target, numel, loss, d_eps, grad_scale, scratch, (hipStream_t)stream);
+}
+
+DMME_API int dmme_conv2d(const dmme_conv_desc* d, const void* src1, const void* src2, const void* weight, const float* bias,
+                const float* scale, const float* shift, const float* dmask, const float* tproj, const void* res1,
+                const void* res2, int R1, void* dst, void* stream) {
+    DMME_REQUIRE(d && src1 && weight && bias && dst, DMME_ERR_INVALID, "conv2d: null argument");
+    DMME_REQUIRE(d->taps == 9 || d->taps == 1, DMME_ERR_INVALID, "conv2d: taps must be 1 or 9");
+    DMME_REQUIRE(d->stride == 1 || d->stride == 2, DMME_ERR_INVALID, "conv2d: stride must be 1 or 2");
+    ConvArgs a{};
+    a.src1 = src1; a.src2 = src2; a.w = weight; a.bias = bias; a.scale = scale; a.shift = shift; a.dmask = dmask;
+    a.tproj = d->nt > 0 ? tproj : nullptr;
+    a.res1 = res1; a.res2 = res2; a.R1 = R1; a.dst = dst;
+    a.N = d->N; a.Hin = d->Hin; a.Win = d->Win; a.C1 = d->C1; a.C2 = src2 ? d->C2 : 0;
+    a.up = d->upsample; a.stride = d->stride; a.taps = d->taps;
+    const int Hv = a.up ? 2 * a.Hin : a.Hin, Wv = a.up ? 2 * a.Win : a.Win;
+    a.Hout = Hv / a.stride; a.Wout = Wv / a.stride; a.Cout = d->Cout;
+    a.pro_silu = d->pro_silu; a.out_silu = d->out_silu; a.nt = d->nt; a.tproj_ld = d->tproj_ld;
+    a.in_nchw = d->in_nchw; a.out_nchw = d->out_nchw;
+    if (!d->force_generic && conv_mfma_supported(d->dtype, a)) return launch_conv_mfma(d->dtype, a, (hipStream_t)stream);
+    return launch_conv_generic(d->dtype, a, (hipStream_t)stream);
+}
+
+DMME_API int dmme_groupnorm_scale_shift(int dtype, const void* src1, const void* src2, int N, int HW, int C1, int C2, int groups,
+                               const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                               float* partial_scratch, int force_generic, void* stream) {
+    DMME_REQUIRE(src1 && gamma && beta && scale && shift, DMME_ERR_INVALID, "groupnorm: null argument");
+    if (!src2) C2 = 0;
+    DMME_REQUIRE(groups > 0 && (C1 + C2) % groups == 0, DMME_ERR_INVALID, "groupnorm: %d channels not divisible by %d groups",
+                 C1 + C2, groups);
+    if (!force_generic && partial_scratch && gn_fast_supported(dtype, N, HW, C1, C2, groups))
+        return launch_gn_fast(dtype, src1, src2, N, HW, C1, C2, groups, gamma, beta, eps, scale, shift, partial_scratch,
+                              (hipStream_t)stream);
+    return launch_gn_generic(dtype, src1, src2, N, HW, C1, C2, groups, gamma, beta, eps, scale, shift, (hipStream_t)stream);
+}
+
+DMME_API int dmme_attention(int dtype, const void* qkv, int N, int S, int C, void* out, int force_generic, void* stream) {
+    DMME_REQUIRE(qkv && out && N > 0 && S > 0 && C > 0, DMME_ERR_INVALID, "attention: bad argument");
+    if (!force_generic && attn_mfma_supported(dtype, N, S, C)) return launch_attn_mfma(dtype, qkv, N, S, C, out, (hipStream_t)stream);
+    return launch_attn_generic(dtype, qkv, N, S, C, out, (hipStream_t)stream);
+}
+
+DMME_API int dmme_nchw_to_nhwc(int dtype, const float* src, int N, int C, int HW, void* dst, void* stream) {
+    DMME_REQUIRE(src && dst, DMME_ERR_INVALID, "nchw_to_nhwc: null argument");
+    return launch_nchw_to_nhwc(dtype, src, N, C, HW, dst, (hipStream_t)stream);
+}
+DMME_API int dmme_nhwc_to_nchw(int dtype, const void* src, int N, int C, int HW, float* dst, void* stream) {
+    DMME_REQUIRE(src && dst, DMME_ERR_INVALID, "nhwc_to_nchw: null argument");
+    return launch_nhwc_to_nchw(dtype, src, N, C, HW, dst, (hipStream_t)stream);
+}
+DMME_API int dmme_pack_weight(int dtype, const float* src, int Cout, int Cin, int taps, void* dst, void* stream) {
+    DMME_REQUIRE(src && dst, DMME_ERR_INVALID, "pack_weight: null argument");
+    return launch_pack_weight(dtype, src, Cout, Cin, taps, dst, (hipStream_t)stream);
+}
+
+DMME_API int dmme_event_create(void** ev) {
+    DMME_REQUIRE(ev, DMME_ERR_INVALID, "event_create: null");
+    hipEvent_t e;
+    DMME_CHECK_HIP(hipEventCreate(&e));
+    *ev = (void*)e;
+    return DMME_OK;
+}
+DMME_API int dmme_event_record(void* ev, void* stream) {
+    DMME_CHECK_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+    return DMME_OK;
+}
+DMME_API int dmme_event_elapsed_ms(void* start, void* stop, float* ms) {
+    DMME_CHECK_HIP(hipEventSynchronize((hipEvent_t)stop));
+    DMME_CHECK_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return DMME_OK;
+}
+DMME_API int dmme_event_destroy(void* ev) {
+    DMME_CHECK_HIP(hipEventDestroy((hipEvent_t)ev));
+    return DMME_OK;
+}
+
+}  // extern "C"

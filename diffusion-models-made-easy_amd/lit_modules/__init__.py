@@ -1,0 +1,2 @@
+from .ddpm import LitDDPM  # noqa: F401
+from .ddim import LitDDIM  # noqa: F401

@@ -1,0 +1,291 @@
+"""UNet noise predictor eps_theta(x_t, t) executed by libdmme_hip on an MI355X.
+
+Drop-in for the reference's `dmme.models.ddpm.UNet` (src/dmme/models/ddpm.py:176-316):
+same constructor arguments, same `forward(x, c)`, same 305-entry state_dict (key names,
+shapes, order).  The layer graph, the parameter table and the launch sequence live in
+the C++ plan (csrc/plan.hip); this class only owns the parameters (fp32 master copy in
+one flat buffer; every named nn.Parameter is a view into it) and hands raw pointers to
+the C ABI.  There is no PyTorch math on the device and no CPU fallback."""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from .. import _lib
+
+
+class _Scope(nn.Module):
+    """Parameter container used to reproduce the reference's dotted state_dict keys."""
+
+
+def _cfg_struct(in_channels, pos_dim, emb_dim, num_groups, dropout, channels_per_depth, num_blocks, attention_depths):
+    cfg = _lib.UNetCfg()
+    cfg.in_channels, cfg.pos_dim, cfg.emb_dim, cfg.num_groups = in_channels, pos_dim, emb_dim, num_groups
+    cfg.dropout = float(dropout)
+    if not 1 <= len(channels_per_depth) <= 8 or len(attention_depths) > 8:
+        raise ValueError("channels_per_depth must have 1..8 entries and attention_depths at most 8")
+    cfg.num_depths = len(channels_per_depth)
+    for i, c in enumerate(channels_per_depth):
+        cfg.channels_per_depth[i] = int(c)
+    cfg.num_blocks = num_blocks
+    cfg.num_attention_depths = len(attention_depths)
+    for i, d in enumerate(attention_depths):
+        cfg.attention_depths[i] = int(d)
+    return cfg
+
+
+class _Plan:
+    """Owns one dmme_plan handle plus the device buffers it needs (workspace, packed weights)."""
+
+    def __init__(self, cfg, B, H, W, dtype, device_index):
+        self.lib = _lib.lib()
+        h = C.c_void_p()
+        _lib.check(self.lib.dmme_unet_plan_create(C.byref(cfg), B, H, W, dtype, device_index, C.byref(h)), "dmme_unet_plan_create")
+        self.h = h
+        self.B, self.H, self.W, self.dtype = B, H, W, dtype
+        self.workspace = None
+        self.packed = None
+        self.packed_version = None
+
+    def param_table(self):
+        n = self.lib.dmme_unet_plan_num_params(self.h)
+        out = []
+        name = C.create_string_buffer(256)
+        ndim, off, isb = C.c_int(), C.c_int64(), C.c_int()
+        shape = (C.c_int64 * 4)()
+        for i in range(n):
+            _lib.check(self.lib.dmme_unet_plan_param_info(self.h, i, name, 256, C.byref(ndim), shape, C.byref(off), C.byref(isb)), "param_info")
+            out.append((name.value.decode(), tuple(int(shape[k]) for k in range(ndim.value)), int(off.value), bool(isb.value)))
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.dmme_unet_plan_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class UNet(nn.Module):
+    r"""U-Net for predicting noise in images (same arguments as the reference, models/ddpm.py:190-200).
+
+    Extra keyword `precision` ("fp32" | "bf16") selects the compute dtype of the HIP
+    kernels; parameters are always held in fp32."""
+
+    def __init__(
+        self,
+        in_channels: int = 3,
+        pos_dim: int = 128,
+        emb_dim: int = 512,
+        num_groups: int = 32,
+        dropout: float = 0.1,
+        channels_per_depth: Sequence[int] = (128, 256, 256, 256),
+        num_blocks: int = 2,
+        attention_depths: Sequence[int] = (2,),
+        precision: str = "fp32",
+    ):
+        super().__init__()
+        self.in_channels = in_channels
+        self.dropout = float(dropout)
+        self.precision = precision
+        self._dtype = _lib.dtype_code(precision)
+        self._cfg = _cfg_struct(in_channels, pos_dim, emb_dim, num_groups, dropout, tuple(channels_per_depth), num_blocks, tuple(attention_depths))
+        self._plans: Dict[Tuple, _Plan] = {}
+        self._injected_masks: Optional[Tensor] = None
+        self._mask_calls = 0
+
+        # parameter table from the C++ plan (host only: device = -1)
+        table_plan = _Plan(self._cfg, 1, 32, 32, _lib.F32, -1)
+        self._table = table_plan.param_table()
+        self._ref_numel = int(table_plan.lib.dmme_unet_plan_ref_numel(table_plan.h))
+        del table_plan
+
+        flat = torch.zeros(self._ref_numel, dtype=torch.float32)
+        self._flat = flat
+        self._init_parameters(flat, pos_dim)
+        self._register_views(flat)
+
+    # ------------------------------------------------------------------ parameters
+    def _init_parameters(self, flat: Tensor, pos_dim: int):
+        """torch default initialisation (the reference defines no custom init):
+        conv / linear weights kaiming_uniform(a=sqrt 5) => U(+-1/sqrt(fan_in)), biases
+        U(+-1/sqrt(fan_in)), GroupNorm affine (1, 0), sinusoid table from the formula."""
+        import math
+
+        last_fan_in, prev_was_norm = 1, False
+        for name, shape, off, is_buf in self._table:
+            n = 1
+            for s in shape:
+                n *= s
+            view = flat[off : off + n].view(shape)
+            if is_buf:
+                half = pos_dim // 2
+                step = math.log(10000) / (half - 1)
+                view.copy_(torch.exp(torch.arange(half) * -step).unsqueeze(0))
+            elif len(shape) >= 2:  # conv / linear weight
+                last_fan_in = n // shape[0]
+                nn.init.uniform_(view, -1.0 / math.sqrt(last_fan_in), 1.0 / math.sqrt(last_fan_in))
+                prev_was_norm = False
+            elif name.endswith(".weight"):  # 1-D weight: GroupNorm gamma
+                view.fill_(1.0)
+                prev_was_norm = True
+            elif prev_was_norm:  # GroupNorm beta
+                view.zero_()
+                prev_was_norm = False
+            else:  # conv / linear bias
+                b = 1.0 / math.sqrt(last_fan_in)
+                nn.init.uniform_(view, -b, b)
+
+    def _register_views(self, flat: Tensor):
+        self._views = []
+        for name, shape, off, is_buf in self._table:
+            n = 1
+            for s in shape:
+                n *= s
+            parts = name.split(".")
+            mod = self
+            for p in parts[:-1]:
+                if p not in mod._modules:
+                    mod.add_module(p, _Scope())
+                mod = mod._modules[p]
+            view = flat[off : off + n].view(shape)
+            if is_buf:
+                mod.register_buffer(parts[-1], view)  # persistent, like the reference (:336)
+            else:
+                mod.register_parameter(parts[-1], nn.Parameter(view))
+            self._views.append((mod, parts[-1], off, n, shape, is_buf))
+
+    def _current(self, mod, leaf, is_buf) -> Tensor:
+        return mod._buffers[leaf] if is_buf else mod._parameters[leaf]
+
+    def _ensure_flat(self) -> Tensor:
+        """Make every named parameter a view of one contiguous fp32 buffer again (after
+        .to()/.cuda() moved them tensor by tensor).  Cheap check, rare re-flatten."""
+        mod0, leaf0, off0, _, _, isb0 = self._views[0]
+        first = self._current(mod0, leaf0, isb0)
+        flat = self._flat
+        ok = flat.device == first.device and flat.dtype == torch.float32
+        if ok:
+            base = flat.data_ptr()
+            for mod, leaf, off, n, shape, is_buf in self._views:
+                t = self._current(mod, leaf, is_buf)
+                if t.data_ptr() != base + 4 * off or t.dtype != torch.float32:
+                    ok = False
+                    break
+        if ok:
+            return flat
+        new = torch.empty(self._ref_numel, dtype=torch.float32, device=first.device)
+        with torch.no_grad():
+            for mod, leaf, off, n, shape, is_buf in self._views:
+                t = self._current(mod, leaf, is_buf)
+                new[off : off + n].copy_(t.detach().reshape(-1).to(torch.float32))
+                v = new[off : off + n].view(shape)
+                if is_buf:
+                    mod._buffers[leaf] = v
+                else:
+                    t.data = v
+        self._flat = new
+        for p in self._plans.values():
+            p.packed_version = None
+        return new
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self._ensure_flat()
+        return out
+
+    def flat_parameters(self) -> Tensor:
+        """The contiguous fp32 master buffer (reference state_dict order and layouts)."""
+        return self._ensure_flat()
+
+    def set_precision(self, precision: str):
+        self.precision = precision
+        self._dtype = _lib.dtype_code(precision)
+        return self
+
+    # ------------------------------------------------------------------ plan / buffers
+    def _plan_for(self, B: int, H: int, W: int, device: torch.device) -> _Plan:
+        key = (B, H, W, self._dtype, device.index)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = _Plan(self._cfg, B, H, W, self._dtype, device.index if device.index is not None else torch.cuda.current_device())
+            lib = plan.lib
+            plan.workspace = torch.empty(int(lib.dmme_unet_plan_workspace_bytes(plan.h)), dtype=torch.uint8, device=device)
+            plan.packed = torch.empty(int(lib.dmme_unet_plan_packed_bytes(plan.h)), dtype=torch.uint8, device=device)
+            plan.dropmask_numel = int(lib.dmme_unet_plan_dropmask_numel(plan.h))
+            plan.masks = None
+            self._plans[key] = plan
+        return plan
+
+    def _packed_for(self, plan: _Plan) -> Tensor:
+        flat = self._ensure_flat()
+        ver = (flat.data_ptr(), flat._version)
+        if plan.packed_version != ver:
+            _lib.check(plan.lib.dmme_unet_pack_params(plan.h, _lib.ptr(flat), _lib.ptr(plan.packed), _lib.stream_ptr()), "dmme_unet_pack_params")
+            plan.packed_version = ver
+        return plan.packed
+
+    def inject_dropout_masks(self, masks: Optional[Tensor]):
+        """Test hook: use these Dropout2d multipliers (layout of dmme_unet_plan_dropmask_numel)
+        instead of drawing them, for train-mode parity with injected randomness."""
+        self._injected_masks = masks
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: Tensor, c: Tensor) -> Tensor:
+        r"""Predicts noise from x (reference: models/ddpm.py:281-316).
+
+        x: (N, C, H, W) on an MI355X; c: timesteps of shape (N,) or (1,)."""
+        _lib.require_gpu()
+        if not x.is_cuda:
+            raise _lib.DmmeError("UNet.forward needs a GPU tensor: the HIP denoiser has no CPU fallback")
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise ValueError(f"expected input of shape (N, {self.in_channels}, H, W), got {tuple(x.shape)}")
+        B, _, H, W = x.shape
+        if c.numel() not in (1, B):
+            raise RuntimeError(f"timestep tensor of {c.numel()} elements does not broadcast against batch {B}")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from ..autograd import unet_apply  # training path (HIP backward)
+
+            return unet_apply(self, x, c)
+        return self._forward_impl(x, c)
+
+    def _forward_impl(self, x: Tensor, c: Tensor, keep: bool = False) -> Tensor:
+        B, _, H, W = x.shape
+        plan = self._plan_for(B, H, W, x.device)
+        packed = self._packed_for(plan)
+        xin = x.detach().to(torch.float32).contiguous()
+        t = c.detach().reshape(-1).to(device=x.device, dtype=torch.int64).contiguous()
+        y = torch.empty_like(xin)
+        masks = None
+        if self.training and self.dropout > 0:
+            if self._injected_masks is not None:
+                masks = self._injected_masks.to(device=x.device, dtype=torch.float32).contiguous()
+                if masks.numel() != plan.dropmask_numel:
+                    raise ValueError(f"injected dropout masks have {masks.numel()} elements, plan needs {plan.dropmask_numel}")
+            else:
+                if plan.masks is None:
+                    plan.masks = torch.empty(plan.dropmask_numel, dtype=torch.float32, device=x.device)
+                masks = plan.masks
+                self._mask_calls += 1
+                seed = (torch.initial_seed() & 0xFFFFFFFFFFFF) ^ 0x5DEECE66D
+                _lib.check(plan.lib.dmme_dropout_masks(plan.h, seed, self._mask_calls << 32, _lib.ptr(masks), _lib.stream_ptr()), "dmme_dropout_masks")
+        _lib.check(
+            plan.lib.dmme_unet_forward(plan.h, _lib.ptr(packed), _lib.ptr(xin), _lib.ptr(t), int(t.numel()), _lib.ptr(y), _lib.ptr(plan.workspace), _lib.ptr(masks), _lib.stream_ptr()),
+            "dmme_unet_forward",
+        )
+        self._last_plan = plan
+        return y
+
+    def debug_activation(self, name: str) -> Tensor:
+        """fp32 NCHW copy of the output of module `name` from the last forward (parity tests)."""
+        plan = self._last_plan
+        cap = plan.B * 4096 * max(plan.H * plan.W, 1)
+        buf = torch.empty(cap, dtype=torch.float32, device=plan.workspace.device)
+        n = C.c_int64()
+        _lib.check(plan.lib.dmme_unet_debug_read(plan.h, _lib.ptr(plan.workspace), name.encode(), _lib.ptr(buf), cap, C.byref(n), _lib.stream_ptr()), "dmme_unet_debug_read")
+        return buf[: n.value].clone()

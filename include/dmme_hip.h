@@ -1,0 +1,202 @@
+/*
+ * dmme_hip.h -- C ABI of libdmme_hip.so: the MI355X (gfx950) denoiser hot path.
+ *
+ * The reference (urw7rs/diffusion-models-made-easy v0.5.2) is pure Python and has no
+ * FFI of its own; every entry point below replaces a *Python* interface of the hot
+ * path and cites it (paths relative to the reference root).  A maintainer binds these
+ * with ctypes.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; no torch / C++ types cross the boundary;
+ *   - every device pointer is caller-owned (the plan never owns tensor memory; it
+ *     owns host metadata plus one small device table used by the weight re-packer);
+ *   - every call is asynchronous on the caller's HIP stream (`stream` is a
+ *     hipStream_t passed as void*); no hidden synchronisation or allocation in the
+ *     launch path, so calls can be captured into a hipGraph;
+ *   - return value: 0 (DMME_OK) or a negative dmme_status; the message of the last
+ *     failure on the calling thread is available from dmme_last_error();
+ *   - no exceptions cross the ABI.
+ *
+ * Tensor layouts at the boundary
+ *   - images x / y / eps / z: NCHW fp32 (what the reference's UNet.forward takes,
+ *     src/dmme/models/ddpm.py:281-316);
+ *   - timesteps: int64 device array of length 1 or B (reference passes `all_t[t]`
+ *     of shape (1,) when sampling, (B,) when training; diffusion_models/ddpm.py:65-77,124-131);
+ *   - parameters: one flat fp32 buffer in reference state_dict order and reference
+ *     layouts (conv OIHW, linear (out,in)); dmme_unet_pack_params() converts it to
+ *     the library's packed layout ([Cout][kh][kw][Cin], compute dtype).
+ */
+#ifndef DMME_HIP_H
+#define DMME_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(DMME_BUILD)
+#define DMME_API __attribute__((visibility("default")))
+#else
+#define DMME_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    DMME_OK = 0,
+    DMME_ERR_INVALID = -1,     /* bad argument / shape the reference would also reject */
+    DMME_ERR_UNSUPPORTED = -2, /* valid in the reference, not supported by this build */
+    DMME_ERR_HIP = -3,         /* a HIP runtime call failed */
+    DMME_ERR_NOMEM = -4
+} dmme_status;
+
+typedef enum { DMME_F32 = 0, DMME_BF16 = 1 } dmme_dtype;
+
+/* Constructor arguments of the reference UNet (src/dmme/models/ddpm.py:190-200). */
+typedef struct {
+    int in_channels;
+    int pos_dim;
+    int emb_dim;
+    int num_groups;
+    float dropout;
+    int num_depths;
+    int channels_per_depth[8];
+    int num_blocks;
+    int num_attention_depths;
+    int attention_depths[8];
+} dmme_unet_cfg;
+
+typedef struct dmme_plan dmme_plan;
+
+DMME_API const char* dmme_last_error(void);
+DMME_API int dmme_version(void);
+/* number of HIP devices visible to the library (0 => the library loaded but cannot compute) */
+DMME_API int dmme_device_count(void);
+
+/* ---- UNet plan: replaces UNet.__init__ (models/ddpm.py:190-279) --------------------
+ * Builds the layer graph (including the reference's always-false `if` at :242), the
+ * parameter table, the packed-weight layout and the activation workspace layout for a
+ * fixed (B, H, W, dtype).  Host-only; `device` selects which GPU owns the small
+ * re-pack table (-1: do not touch any device, for CPU-side inspection of the table). */
+DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W, int dtype, int device, dmme_plan** out);
+DMME_API void dmme_unet_plan_destroy(dmme_plan* plan);
+
+/* Parameter table in reference state_dict order (305 entries for the default config;
+ * SURVEY 8b).  `ref_offset` is the element offset inside the flat fp32 buffer. */
+DMME_API int dmme_unet_plan_num_params(const dmme_plan* plan);
+DMME_API int dmme_unet_plan_param_info(const dmme_plan* plan, int index, char* name, int name_cap, int* ndim,
+                              int64_t shape[4], int64_t* ref_offset, int* is_buffer);
+DMME_API int64_t dmme_unet_plan_ref_numel(const dmme_plan* plan);
+DMME_API int64_t dmme_unet_plan_packed_bytes(const dmme_plan* plan);
+DMME_API int64_t dmme_unet_plan_workspace_bytes(const dmme_plan* plan);
+/* floats in a full set of Dropout2d multipliers: sum over ResBlocks of B*Cout, laid out
+ * block after block (graph order: down, middle, up), each [B][Cout]. */
+DMME_API int64_t dmme_unet_plan_dropmask_numel(const dmme_plan* plan);
+/* number of kernel launches one forward issues (for launch-overhead accounting) */
+DMME_API int dmme_unet_plan_num_launches(const dmme_plan* plan);
+
+/* fp32 reference-layout flat buffer -> packed buffer (replaces nothing in the
+ * reference; it is the load_state_dict side of the boundary). */
+DMME_API int dmme_unet_pack_params(const dmme_plan* plan, const float* ref_flat, void* packed, void* stream);
+
+/* ---- UNet forward: replaces UNet.forward (models/ddpm.py:281-316) -------------------
+ * y = eps_theta(x, t).  x, y: (B, C, H, W) fp32 NCHW.  t: int64[t_len], t_len in {1, B}.
+ * drop_masks: NULL for eval(); else the Dropout2d multipliers (0 or 1/(1-p)) laid out
+ * as dmme_unet_plan_dropmask_numel() describes (nn.Dropout2d, models/ddpm.py:29). */
+DMME_API int dmme_unet_forward(const dmme_plan* plan, const void* packed, const float* x, const int64_t* t, int t_len,
+                      float* y, void* workspace, const float* drop_masks, void* stream);
+
+/* Copy an intermediate activation (the output of module `name`, e.g. "down_layers.3",
+ * "input_conv", "condition") out of the workspace as fp32 NCHW for parity tests.
+ * numel_cap guards the destination size. */
+DMME_API int dmme_unet_debug_read(const dmme_plan* plan, const void* workspace, const char* name, float* dst,
+                         int64_t numel_cap, int64_t* numel_out, void* stream);
+
+/* Dropout2d multipliers from the library's own Philox stream (train mode without
+ * injected masks): keep with probability 1-p, value 1/(1-p). */
+DMME_API int dmme_dropout_masks(const dmme_plan* plan, uint64_t seed, uint64_t offset, float* masks, void* stream);
+
+/* ---- diffusion process (elementwise; all NCHW fp32) --------------------------------- */
+
+/* standard normal fill from the library's Philox4x32-10 stream: replaces dmme.gaussian
+ * (src/dmme/common/noise.py:4-6) / the draw inside Normal.sample(). */
+DMME_API int dmme_randn(float* out, int64_t numel, uint64_t seed, uint64_t offset, void* stream);
+
+/* forward noising: replaces forward_process(...).sample() and the target re-derivation
+ * of DDPM.training_step (equations/ddpm/ddpm.py:36-41, diffusion_models/ddpm.py:72-79):
+ *   mean = sqrt(abar[t_n]) x0 ; std = sqrt(1-abar[t_n]) ; x_t = mean + std z ;
+ *   target = (x_t - mean)/std   (optional).  abar: device fp32 table indexed by t. */
+DMME_API int dmme_q_sample(const float* x0, const float* z, const float* alpha_bar, const int64_t* t, int B,
+                  int64_t chw, float* x_t, float* target, void* stream);
+
+/* one DDPM reverse update, in place on x: replaces DDPM.sampling_step after the model
+ * call (diffusion_models/ddpm.py:99-110, equations/ddpm/ddpm.py:65-71):
+ *   mean = inv_sqrt_alpha * (x - eps_coef * eps);  x = add_noise ? mean + sigma * z : mean
+ * The three coefficients are the reference's fp32 values 1/sqrt(alpha_t),
+ * beta_t/sqrt(1-abar_t), sqrt(beta_t); add_noise = (t != 1). */
+DMME_API int dmme_ddpm_step(float* x, const float* eps, const float* z, float inv_sqrt_alpha, float eps_coef,
+                   float sigma, int add_noise, int64_t numel, void* stream);
+
+/* one DDIM update as shipped: replaces DDIM.sampling_step after the model call
+ * (diffusion_models/ddim.py:73-77, equations/ddim/ddim.py:52-57):
+ *   x = sqrt_abar_prev * ((x - sqrt_one_minus_abar * eps) / sqrt_abar_prev). */
+DMME_API int dmme_ddim_step(float* x, const float* eps, float sqrt_one_minus_abar, float sqrt_abar_prev, int64_t numel,
+                   void* stream);
+
+/* simple_loss (equations/ddpm/losses.py:13): loss[0] = mean((target-eps)^2); optional
+ * d_eps = 2 (eps - target) / numel * grad_scale.  `scratch` needs 1024 floats. */
+DMME_API int dmme_mse_loss(const float* eps, const float* target, int64_t numel, float* loss, float* d_eps,
+                  float grad_scale, float* scratch, void* stream);
+
+/* ---- single-op entry points used by the unit parity tests ---------------------------
+ * Activations here are NHWC in the compute dtype; weights in the packed layout
+ * [Cout][taps][Cin]; they exercise exactly the kernels the plan launches.
+ * force_generic = 1 selects the shape-generic kernel instead of the MFMA kernel. */
+typedef struct {
+    int dtype;         /* dmme_dtype of activations / weights */
+    int N, Hin, Win;   /* source dims (before the optional nearest 2x upsample) */
+    int C1, C2;        /* channels of source 1 and (concat) source 2; C2 = 0: none */
+    int upsample;      /* 1: nearest 2x upsample fused in front of the conv */
+    int stride;        /* 1 or 2 */
+    int taps;          /* 9: 3x3 pad 1; 1: 1x1 pad 0 */
+    int Cout;
+    int pro_silu;      /* SiLU after the affine prologue */
+    int out_silu;      /* SiLU on the output */
+    int nt;            /* rows of tproj (1 or N); 0: no time-embedding add */
+    int tproj_ld;      /* leading dimension of tproj */
+    int in_nchw;       /* src1 is fp32 NCHW (network input) */
+    int out_nchw;      /* dst is fp32 NCHW (network output) */
+    int force_generic;
+} dmme_conv_desc;
+
+DMME_API int dmme_conv2d(const dmme_conv_desc* d, const void* src1, const void* src2, const void* weight,
+                const float* bias, const float* scale, const float* shift, const float* dmask,
+                const float* tproj, const void* res1, const void* res2, int R1, void* dst, void* stream);
+
+/* GroupNorm statistics folded with the affine: scale[n][c] = rstd*gamma[c],
+ * shift[n][c] = beta[c] - mean*rstd*gamma[c]  (nn.GroupNorm(eps=1e-5), models/ddpm.py:17-18). */
+DMME_API int dmme_groupnorm_scale_shift(int dtype, const void* src1, const void* src2, int N, int HW, int C1, int C2,
+                               int groups, const float* gamma, const float* beta, float eps, float* scale,
+                               float* shift, float* partial_scratch, int force_generic, void* stream);
+
+/* single-head self-attention over S tokens: qkv [N][S][3C] -> out [N][S][C]
+ * softmax(q (k*C^-0.5)^T) v   (Attention.forward_attention, models/ddpm.py:54-63). */
+DMME_API int dmme_attention(int dtype, const void* qkv, int N, int S, int C, void* out, int force_generic, void* stream);
+
+/* NCHW fp32 <-> NHWC compute-dtype converters (test plumbing for the single-op calls) */
+DMME_API int dmme_nchw_to_nhwc(int dtype, const float* src, int N, int C, int HW, void* dst, void* stream);
+DMME_API int dmme_nhwc_to_nchw(int dtype, const void* src, int N, int C, int HW, float* dst, void* stream);
+/* reference-layout fp32 weight (Cout, Cin, k, k) -> packed [Cout][k*k][Cin] in dtype */
+DMME_API int dmme_pack_weight(int dtype, const float* src, int Cout, int Cin, int taps, void* dst, void* stream);
+
+/* timing helper: records a HIP event pair around nothing; used by bench.py to time
+ * on the launch stream.  Returns elapsed ms between two events created by the lib. */
+DMME_API int dmme_event_create(void** ev);
+DMME_API int dmme_event_record(void* ev, void* stream);
+DMME_API int dmme_event_elapsed_ms(void* start, void* stop, float* ms);
+DMME_API int dmme_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMME_HIP_H */

@@ -1,0 +1,141 @@
+"""-m gpu: single-kernel parity of the HIP ops (through the C ABI) against a plain fp32
+torch reference of the same op, for the shape classes the UNet uses plus ragged ones."""
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+FP32_ATOL = 1e-5  # north_star tolerance for fp32
+BF16_RTOL = 1e-2  # one bf16 output rounding (2^-9) + accumulation-order noise, vs a reference fed the same bf16 operands
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _ref_conv(x1, w, b, x2, scale, shift, dmask, tproj, res, stride, upsample, pro_silu, out_silu, bf16):
+    x = x1 if x2 is None else torch.cat([x1, x2], 1)
+    q = _bf if bf16 else (lambda t: t)
+    x = q(x)
+    if scale is not None:
+        x = x * scale[:, :, None, None] + shift[:, :, None, None]
+    if pro_silu:
+        x = F.silu(x)
+    if dmask is not None:
+        x = x * dmask[:, :, None, None]
+    x = q(x)
+    if upsample:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    y = F.conv2d(x.double(), q(w).double(), b.double(), stride=stride, padding=w.shape[-1] // 2).float()
+    if tproj is not None:
+        y = y + (tproj if tproj.shape[0] > 1 else tproj.expand(x.shape[0], -1))[:, :, None, None]
+    if res is not None:
+        y = y + q(res)
+    if out_silu:
+        y = F.silu(y)
+    return y
+
+
+CASES = [
+    # (name, N, C1, C2, H, Cout, k, stride, up, fused prologue, tproj rows, residual)
+    ("rb128_32", 3, 128, 0, 32, 128, 3, 1, False, True, 3, True),
+    ("cat512_8", 5, 256, 256, 8, 256, 3, 1, False, True, 1, False),
+    ("cat256_16_to128", 2, 128, 128, 16, 128, 3, 1, False, True, 2, False),
+    ("down128", 2, 128, 0, 32, 128, 3, 2, False, False, 0, False),
+    ("up256", 3, 256, 0, 4, 256, 3, 1, True, False, 0, False),
+    ("mid4x4", 9, 256, 0, 4, 256, 3, 1, False, True, 9, True),
+    ("qkv1x1", 2, 256, 0, 16, 768, 1, 1, False, True, 0, False),
+    ("res1x1_cat", 2, 256, 256, 8, 256, 1, 1, False, False, 0, False),
+    ("proj1x1_res", 2, 128, 0, 16, 128, 1, 1, False, False, 0, True),
+    ("input3", 2, 3, 0, 32, 128, 3, 1, False, False, 0, False),
+    ("output3", 2, 128, 0, 32, 3, 3, 1, False, True, 0, False),
+    ("tiny_odd", 3, 12, 0, 8, 6, 3, 1, False, True, 3, False),
+    ("tiny_cat", 2, 8, 4, 16, 4, 3, 1, False, True, 1, False),
+    ("linear_as_conv", 128, 512, 0, 1, 4736, 1, 1, False, False, 0, False),
+]
+
+
+@pytest.mark.parametrize("dtname", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv(case, dtname):
+    from dmme_amd import _lib
+    from tests import gpu_util as G
+
+    name, N, C1, C2, H, Cout, k, stride, up, pro, ntp, has_res = case
+    dt = _lib.dtype_code(dtname)
+    Cin = C1 + C2
+    seed = sum(ord(ch) for ch in name) % 10000
+    x1 = synth.normal(seed, (N, C1, H, H))
+    x2 = synth.normal(seed + 1, (N, C2, H, H)) if C2 else None
+    w = synth.uniform(seed + 2, (Cout, Cin, k, k)) / np.sqrt(Cin * k * k)
+    b = synth.uniform(seed + 3, (Cout,)) * 0.1
+    scale = (1 + 0.3 * synth.normal(seed + 4, (N, Cin))) if pro else None
+    shift = 0.2 * synth.normal(seed + 5, (N, Cin)) if pro else None
+    dmask = ((synth.uniform(seed + 6, (N, Cin), 0, 1) < 0.9).float() / 0.9) if pro else None
+    tproj = 0.3 * synth.normal(seed + 7, (ntp, Cout)) if ntp else None
+    Ho = (2 * H if up else H) // stride
+    res = synth.normal(seed + 8, (N, Cout, Ho, Ho)) if has_res else None
+    ref = _ref_conv(x1, w, b, x2, scale, shift, dmask, tproj, res, stride, up, pro, False, dtname == "bf16")
+    cu = lambda t: None if t is None else t.cuda()
+    outs = {}
+    for force_generic in (True, False):
+        y = G.conv2d(dt, cu(x1), cu(w), cu(b), cu(x2), cu(scale), cu(shift), cu(dmask), cu(tproj), cu(res), stride, up, pro, False, force_generic)
+        torch.cuda.synchronize()
+        outs[force_generic] = y.cpu()
+        err = (y.cpu() - ref).abs().max().item()
+        tol = FP32_ATOL * max(1.0, ref.abs().max().item()) if dtname == "fp32" else BF16_RTOL * ref.abs().max().item()
+        assert err <= tol, f"{name} {dtname} generic={force_generic}: max err {err:.3e} > {tol:.3e}"
+
+
+GN_CASES = [(3, 128, 0, 32, 32), (2, 256, 256, 8, 32), (2, 128, 128, 16, 32), (5, 256, 0, 4, 32), (2, 8, 4, 16, 2), (3, 16, 0, 8, 2), (2, 256, 0, 16, 32)]
+
+
+@pytest.mark.parametrize("dtname", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", GN_CASES, ids=[f"n{c[0]}_c{c[1]}+{c[2]}_h{c[3]}" for c in GN_CASES])
+def test_groupnorm_scale_shift(case, dtname):
+    from dmme_amd import _lib
+    from tests import gpu_util as G
+
+    N, C1, C2, H, groups = case
+    dt = _lib.dtype_code(dtname)
+    x1 = 1.5 * synth.normal(1, (N, C1, H, H)) + 0.7
+    x2 = synth.normal(2, (N, C2, H, H)) - 0.3 if C2 else None
+    gamma = 1 + 0.2 * synth.normal(3, (C1 + C2,))
+    beta = 0.1 * synth.normal(4, (C1 + C2,))
+    x = x1 if x2 is None else torch.cat([x1, x2], 1)
+    if dtname == "bf16":
+        x = _bf(x)
+    want = F.group_norm(x.double(), groups, gamma.double(), beta.double(), eps=1e-5).float()
+    for force_generic in (True, False):
+        sc, sh = G.gn_scale_shift(dt, x1.cuda(), gamma.cuda(), beta.cuda(), groups, None if x2 is None else x2.cuda(), force_generic)
+        got = x * sc.cpu()[:, :, None, None] + sh.cpu()[:, :, None, None]
+        err = (got - want).abs().max().item()
+        assert err <= 2e-5, f"gn {case} {dtname} generic={force_generic}: {err:.3e}"
+
+
+ATTN_CASES = [(2, 256, 256), (3, 256, 128), (5, 16, 256), (2, 64, 32), (2, 16, 12)]
+
+
+@pytest.mark.parametrize("dtname", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", ATTN_CASES, ids=[f"n{c[0]}_s{c[1]}_c{c[2]}" for c in ATTN_CASES])
+def test_attention(case, dtname):
+    from dmme_amd import _lib
+    from tests import gpu_util as G
+
+    N, S, Cc = case
+    dt = _lib.dtype_code(dtname)
+    qkv = synth.normal(7, (N, S, 3 * Cc))
+    qkv[:, :, :Cc] *= 2.0  # sharper softmax
+    src = _bf(qkv) if dtname == "bf16" else qkv
+    q, k, v = src[:, :, :Cc].double(), src[:, :, Cc : 2 * Cc].double(), src[:, :, 2 * Cc :].double()
+    want = (torch.softmax(q @ (k.transpose(1, 2) * Cc**-0.5), dim=2) @ v).float()
+    for force_generic in (True, False):
+        got = G.attention(dt, qkv.cuda(), force_generic).cpu()
+        err = (got - want).abs().max().item()
+        tol = 1e-5 if dtname == "fp32" else 2e-2 * want.abs().max().item()
+        assert err <= tol, f"attention {case} {dtname} generic={force_generic}: {err:.3e} > {tol:.3e}"

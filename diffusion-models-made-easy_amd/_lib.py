@@ -39,7 +39,7 @@ class UNetCfg(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "dtype", "N", "Hin", "Win", "C1", "C2", "upsample", "stride", "taps", "Cout", "pro_silu", "out_silu",
-        "nt", "tproj_ld", "in_nchw", "out_nchw", "force_generic")]
+        "nt", "tproj_ld", "in_nchw", "out_nchw", "force_generic")]  # 0: best kernel, 1: generic kernel, 2: first-generation MFMA kernel
 
 
 class DmmeError(RuntimeError):
@@ -75,10 +75,13 @@ PROTOTYPES = {
     "dmme_unet_plan_num_launches": (_i, [_vp]),
     "dmme_unet_pack_params": (_i, [_vp, _vp, _vp, _vp]),
     "dmme_unet_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "dmme_unet_plan_num_ops": (_i, [_vp]),
+    "dmme_unet_plan_op_info": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "dmme_unet_forward_profiled": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "dmme_unet_debug_read": (_i, [_vp, _vp, C.c_char_p, _vp, _i64, C.POINTER(_i64), _vp]),
     "dmme_dropout_masks": (_i, [_vp, _u64, _u64, _vp, _vp]),
     "dmme_randn": (_i, [_vp, _i64, _u64, _u64, _vp]),
-    "dmme_q_sample": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp]),
+    "dmme_q_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp]),
     "dmme_ddpm_step": (_i, [_vp, _vp, _vp, _f, _f, _f, _i, _i64, _vp]),
     "dmme_ddim_step": (_i, [_vp, _vp, _f, _f, _i64, _vp]),
     "dmme_mse_loss": (_i, [_vp, _vp, _i64, _vp, _vp, _f, _vp, _vp]),

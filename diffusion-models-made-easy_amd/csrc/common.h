@@ -59,6 +59,11 @@ __device__ __forceinline__ bf16 from_f<bf16>(float v) {
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// hardware-transcendental SiLU for the bf16 path: v_exp_f32 + v_rcp_f32 (~1 ulp each), far
+// inside the 2^-9 rounding the value gets when it is stored as bf16
+__device__ __forceinline__ float silu_fast(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -116,10 +121,17 @@ struct ConvArgs {
 
 // ---- kernel launchers (defined in the .hip files) ------------------------------------
 int launch_conv_generic(int dtype, const ConvArgs& a, hipStream_t s);
+const char* conv_generic_kernel_name(const ConvArgs& a);
 // returns DMME_ERR_UNSUPPORTED (without setting the error) when the shape is outside
 // the MFMA kernel's domain, so callers can fall back to the generic kernel.
 bool conv_mfma_supported(int dtype, const ConvArgs& a);
 int launch_conv_mfma(int dtype, const ConvArgs& a, hipStream_t s);
+// "conv_mfma_kernel<bf16,9,128,128>" for the variant launch_conv_mfma would pick
+void conv_mfma_label(int dtype, const ConvArgs& a, char* buf, int cap);
+// software-pipelined 3x3 stride-1 variant (conv_pipe.hip); preferred when it applies
+bool conv_pipe_supported(int dtype, const ConvArgs& a);
+int launch_conv_pipe(int dtype, const ConvArgs& a, hipStream_t s);
+void conv_pipe_label(int dtype, const ConvArgs& a, char* buf, int cap);
 
 int launch_gn_generic(int dtype, const void* src1, const void* src2, int N, int HW, int C1, int C2, int groups,
                       const float* gamma, const float* beta, float eps, float* scale, float* shift,
@@ -156,8 +168,8 @@ int launch_pack_table(int dtype, const PackItem* items_dev, int n_items, const f
 
 int launch_randn(float* out, int64_t numel, uint64_t seed, uint64_t offset, hipStream_t s);
 int launch_dropmask(float* out, int64_t numel, float p, uint64_t seed, uint64_t offset, hipStream_t s);
-int launch_q_sample(const float* x0, const float* z, const float* abar, const int64_t* t, int B, int64_t chw,
-                    float* x_t, float* target, hipStream_t s);
+int launch_q_sample(const float* x0, const float* z, const float* sqrt_abar, const float* sqrt_1m_abar,
+                    const int64_t* t, int B, int64_t chw, float* x_t, float* target, hipStream_t s);
 int launch_ddpm_step(float* x, const float* eps, const float* z, float c1, float c2, float sigma, int add_noise,
                      int64_t numel, hipStream_t s);
 int launch_ddim_step(float* x, const float* eps, float s1, float s2, int64_t numel, hipStream_t s);

@@ -17,102 +17,11 @@
 //
 // dtype float  : v_mfma_f32_32x32x2_f32   (exact fp32 fma chain, 157 TFLOP/s peak)
 // dtype bf16   : v_mfma_f32_32x32x16_bf16 (fp32 accumulate, 2.5 PFLOP/s peak)
-#include "common.h"
+#include <stdio.h>
+
+#include "conv_common.h"
 
 namespace dmme {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int ROW_DATA = 128;          // data bytes per LDS row (one Cin chunk of one pixel / cout)
-constexpr int ROW_PITCH = ROW_DATA + 16;  // padded pitch
-
-struct ConvTile {  // host-computed geometry, passed by value
-    int TW, TH, TN;       // output tile: TN images x TH x TW pixels (product = BM)
-    int HH, HWd;          // halo extent in (virtual) input space
-    int tiles_x, tiles_y; // tiles per image
-    int tiles_m, tiles_n;
-    int a_rows;           // TN*HH*HWd
-};
-
-template <typename T>
-struct Frag;
-template <>
-struct Frag<float> {
-    static constexpr int KC = 32;  // channels per 128-byte chunk
-    static constexpr int EPV = 4;  // elements per 16-byte vector
-};
-template <>
-struct Frag<bf16> {
-    static constexpr int KC = 64;
-    static constexpr int EPV = 8;
-};
-
-__device__ __forceinline__ void mma_group(const uint4& a, const uint4& b, f32x16& acc, float*) {
-    const f32x4 av = __builtin_bit_cast(f32x4, a), bv = __builtin_bit_cast(f32x4, b);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
-}
-__device__ __forceinline__ void mma_group(const uint4& a, const uint4& b, f32x16& acc, bf16*) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
-}
-
-// apply the fused prologue to one 16-byte vector of activations
-template <typename T>
-__device__ __forceinline__ uint4 prologue_vec(uint4 raw, const float* sc, const float* sh, const float* dm, int pro_silu);
-
-template <>
-__device__ __forceinline__ uint4 prologue_vec<float>(uint4 raw, const float* sc, const float* sh, const float* dm, int pro_silu) {
-    f32x4 v = __builtin_bit_cast(f32x4, raw);
-    if (sc) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(sc), b = *reinterpret_cast<const f32x4*>(sh);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], a[j], b[j]);
-    }
-    if (pro_silu) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
-    }
-    if (dm) {
-        const f32x4 m = *reinterpret_cast<const f32x4*>(dm);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] *= m[j];
-    }
-    return __builtin_bit_cast(uint4, v);
-}
-template <>
-__device__ __forceinline__ uint4 prologue_vec<bf16>(uint4 raw, const float* sc, const float* sh, const float* dm, int pro_silu) {
-    if (!sc && !pro_silu && !dm) return raw;
-    bf16x8 x = __builtin_bit_cast(bf16x8, raw);
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (float)x[j];
-    if (sc) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(sc), a1 = *reinterpret_cast<const f32x4*>(sc + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(sh), b1 = *reinterpret_cast<const f32x4*>(sh + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v[j] = fmaf(v[j], a0[j], b0[j]);
-            v[4 + j] = fmaf(v[4 + j], a1[j], b1[j]);
-        }
-    }
-    if (pro_silu) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = silu_f(v[j]);
-    }
-    if (dm) {
-        const f32x4 m0 = *reinterpret_cast<const f32x4*>(dm), m1 = *reinterpret_cast<const f32x4*>(dm + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v[j] *= m0[j];
-            v[4 + j] *= m1[j];
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = (bf16)v[j];
-    return __builtin_bit_cast(uint4, x);
-}
 
 template <typename T, int TAPS, int BM, int BN>
 __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a, ConvTile g) {
@@ -136,13 +45,15 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a, ConvTile g) 
     const int Cin = a.C1 + a.C2;
     const int Hv = a.up ? 2 * a.Hin : a.Hin, Wv = a.up ? 2 * a.Win : a.Win;
     const int iy0 = oy0 * a.stride - PAD, ix0 = ox0 * a.stride - PAD;
+    const int shTW = __builtin_ctz(g.TW), shTH = __builtin_ctz(g.TH);  // tile extents are powers of two
+    const int mTW = g.TW - 1, mTH = g.TH - 1;
 
     // LDS row of this lane's output pixel (tap 0) for each M sub-tile
     int a_row[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int m = wm0 + mi * 32 + r;
-        const int tx = m % g.TW, ty = (m / g.TW) % g.TH, tn = m / (g.TW * g.TH);
+        const int tx = m & mTW, ty = (m >> shTW) & mTH, tn = m >> (shTW + shTH);
         a_row[mi] = (tn * g.HH + ty * a.stride) * g.HWd + tx * a.stride;
     }
 
@@ -223,7 +134,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a, ConvTile g) 
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int m = wm0 + mi * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
-                const int tx = m % g.TW, ty = (m / g.TW) % g.TH, tn = m / (g.TW * g.TH);
+                const int tx = m & mTW, ty = (m >> shTW) & mTH, tn = m >> (shTW + shTH);
                 const int n = n0 + tn;
                 if (n >= a.N) continue;
                 const int64_t opix = ((int64_t)n * a.Hout + oy0 + ty) * a.Wout + ox0 + tx;
@@ -231,71 +142,55 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a, ConvTile g) 
                 if (a.tproj) v += a.tproj[(int64_t)(a.nt == 1 ? 0 : n) * a.tproj_ld + co];
                 if (a.res1) v += to_f(((const T*)a.res1)[opix * a.Cout + co]);
                 if (a.out_silu) v = silu_f(v);
-                ((T*)a.dst)[opix * a.Cout + co] = from_f<T>(v);
+                if (a.out_nchw)
+                    ((float*)a.dst)[(((int64_t)n * a.Cout + co) * a.Hout + oy0 + ty) * a.Wout + ox0 + tx] = v;
+                else
+                    ((T*)a.dst)[opix * a.Cout + co] = from_f<T>(v);
             }
         }
     }
 }
 
-static bool make_tile(const ConvArgs& a, int BM, int BN, ConvTile& g) {
-    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-    int TW = a.Wout < 16 ? a.Wout : 16;
-    if (!pow2(TW) || a.Wout % TW) return false;
-    if (BM % TW) return false;
-    int TH = BM / TW;
-    if (TH > a.Hout) TH = a.Hout;
-    if (!pow2(TH) || a.Hout % TH) return false;
-    if (BM % (TW * TH)) return false;
-    g.TW = TW;
-    g.TH = TH;
-    g.TN = BM / (TW * TH);
-    const int k = a.taps == 9 ? 3 : 1;
-    g.HH = (TH - 1) * a.stride + k;
-    g.HWd = (TW - 1) * a.stride + k;
-    g.tiles_x = a.Wout / TW;
-    g.tiles_y = a.Hout / TH;
-    g.tiles_m = g.tiles_x * g.tiles_y * ((a.N + g.TN - 1) / g.TN);
-    g.tiles_n = (a.Cout + BN - 1) / BN;
-    g.a_rows = g.TN * g.HH * g.HWd;
-    return true;
-}
-
-static size_t tile_lds(const ConvTile& g, int BN) { return (size_t)(g.a_rows + BN) * ROW_PITCH; }
-
 bool conv_mfma_supported(int dtype, const ConvArgs& a) {
     const int KC = dtype == DMME_BF16 ? 64 : 32;
-    if (a.in_nchw || a.out_nchw) return false;
+    if (a.in_nchw) return false;
     if (a.taps != 9 && a.taps != 1) return false;
     if (a.taps == 1 && (a.stride != 1 || a.up)) return false;
     if (a.stride != 1 && a.stride != 2) return false;
     if (a.C1 % KC || a.C2 % KC || a.C1 == 0) return false;
     if (a.res2) return false;  // two-source residual only in the generic kernel
     if (a.res1 && a.R1 != a.Cout) return false;
-    if (a.Cout < 32) return false;
+    if (a.Cout < 32 && !a.out_nchw) return false;  // the 3-channel output conv runs on a zero-padded cout tile
     ConvTile g;
     if (!make_tile(a, 64, 64, g)) return false;
     if (tile_lds(g, 64) > 64 * 1024) return false;
     return true;
 }
 
-template <typename T, int TAPS>
-static int launch_sized(const ConvArgs& a, hipStream_t s) {
-    // pick the largest tile that still yields enough workgroups to fill 256 CUs twice
-    const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
-    ConvTile g{};
+static const int kCand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+
+// pick the largest tile that still yields enough workgroups to fill 256 CUs twice
+static int pick_tile(const ConvArgs& a, ConvTile& g) {
     int pick = -1;
     for (int i = 0; i < 3; ++i) {
         ConvTile t;
-        if (!make_tile(a, cand[i][0], cand[i][1], t)) continue;
-        if (tile_lds(t, cand[i][1]) > 64 * 1024) continue;
-        if (a.Cout <= 64 && cand[i][1] > 64) continue;
+        if (!make_tile(a, kCand[i][0], kCand[i][1], t)) continue;
+        if (tile_lds(t, kCand[i][1]) > 64 * 1024) continue;
+        if (a.Cout <= 64 && kCand[i][1] > 64) continue;
         pick = i;
         g = t;
         if ((int64_t)t.tiles_m * t.tiles_n >= 512) break;
     }
+    return pick;
+}
+
+template <typename T, int TAPS>
+static int launch_sized(const ConvArgs& a, hipStream_t s) {
+    ConvTile g{};
+    const int pick = pick_tile(a, g);
     DMME_REQUIRE(pick >= 0, DMME_ERR_UNSUPPORTED, "conv_mfma: no tile fits (H=%d W=%d)", a.Hout, a.Wout);
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
-    const size_t lds = tile_lds(g, cand[pick][1]);
+    const size_t lds = tile_lds(g, kCand[pick][1]);
     switch (pick) {
         case 0: hipLaunchKernelGGL((conv_mfma_kernel<T, TAPS, 128, 128>), grid, dim3(256), lds, s, a, g); break;
         case 1: hipLaunchKernelGGL((conv_mfma_kernel<T, TAPS, 128, 64>), grid, dim3(256), lds, s, a, g); break;
@@ -303,6 +198,13 @@ static int launch_sized(const ConvArgs& a, hipStream_t s) {
     }
     DMME_CHECK_LAUNCH();
     return DMME_OK;
+}
+
+void conv_mfma_label(int dtype, const ConvArgs& a, char* buf, int cap) {
+    ConvTile g{};
+    const int pick = pick_tile(a, g);
+    snprintf(buf, (size_t)cap, "conv_mfma_kernel<%s,%d,%d,%d>", dtype == DMME_BF16 ? "bf16" : "float", a.taps,
+             pick >= 0 ? kCand[pick][0] : 0, pick >= 0 ? kCand[pick][1] : 0);
 }
 
 int launch_conv_mfma(int dtype, const ConvArgs& a, hipStream_t s) {

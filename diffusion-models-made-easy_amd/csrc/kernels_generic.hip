@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(256) conv_generic_kernel(ConvArgs a) {
                     if (sc) v = fmaf(v, sc[ci], sh[ci]);
                     if (a.pro_silu) v = silu_f(v);
                     if (dm) v *= dm[ci];
-                    v = to_f(from_f<T>(v));  // the MFMA path feeds operands in T
+                    if (!a.in_nchw) v = to_f(from_f<T>(v));  // the MFMA path feeds operands in T; the fp32 network input stays fp32
                     acc = fmaf(v, to_f(wt[ci]), acc);
                 }
             }
@@ -71,7 +71,76 @@ __global__ void __launch_bounds__(256) conv_generic_kernel(ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ first-layer convolution
+// 3x3 pad 1 stride 1 on the NCHW fp32 network input (Cin <= 4), NHWC T output: replaces
+// UNet.input_conv (models/ddpm.py:219).  K = 9*Cin is far too small for MFMA; the op is
+// bound by the output write.  Each thread computes 8 consecutive couts of one pixel from
+// its 9*Cin inputs in registers; weights sit in LDS as [tap*Cin + ci][Cout] fp32.
+template <typename T>
+__global__ void __launch_bounds__(256) conv_in_kernel(ConvArgs a, int px_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [9*Cin][Cout]
+    const int Cin = a.C1, K = 9 * Cin, Cout = a.Cout;
+    for (int e = threadIdx.x; e < K * Cout; e += blockDim.x) {
+        const int co = e / K, k = e % K;  // packed layout [Cout][tap][Cin] == [Cout][k]
+        wl[k * Cout + co] = to_f(((const T*)a.w)[e]);
+    }
+    __syncthreads();
+    const int tpp = Cout / 8;              // threads per pixel
+    const int ppb = 256 / tpp;             // pixels per pass
+    const int cg = (threadIdx.x % tpp) * 8;
+    const int64_t npix = (int64_t)a.N * a.Hout * a.Wout;
+    const int64_t p0 = (int64_t)blockIdx.x * px_per_block;
+    for (int pp = threadIdx.x / tpp; pp < px_per_block; pp += ppb) {
+        const int64_t p = p0 + pp;
+        if (p >= npix) break;
+        const int ox = (int)(p % a.Wout), oy = (int)((p / a.Wout) % a.Hout), n = (int)(p / ((int64_t)a.Wout * a.Hout));
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = a.bias[cg + j];
+        for (int kh = 0; kh < 3; ++kh) {
+            const int iy = oy - 1 + kh;
+            if (iy < 0 || iy >= a.Hin) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ix = ox - 1 + kw;
+                if (ix < 0 || ix >= a.Win) continue;
+                for (int ci = 0; ci < Cin; ++ci) {
+                    const float v = ((const float*)a.src1)[(((int64_t)n * Cin + ci) * a.Hin + iy) * a.Win + ix];
+                    const float* wr = wl + ((kh * 3 + kw) * Cin + ci) * Cout + cg;
+                    const float4 w0 = *reinterpret_cast<const float4*>(wr), w1 = *reinterpret_cast<const float4*>(wr + 4);
+                    acc[0] = fmaf(v, w0.x, acc[0]); acc[1] = fmaf(v, w0.y, acc[1]);
+                    acc[2] = fmaf(v, w0.z, acc[2]); acc[3] = fmaf(v, w0.w, acc[3]);
+                    acc[4] = fmaf(v, w1.x, acc[4]); acc[5] = fmaf(v, w1.y, acc[5]);
+                    acc[6] = fmaf(v, w1.z, acc[6]); acc[7] = fmaf(v, w1.w, acc[7]);
+                }
+            }
+        }
+        T* o = (T*)a.dst + p * Cout + cg;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = from_f<T>(acc[j]);
+    }
+}
+
+static bool conv_in_supported(const ConvArgs& a) {
+    return a.in_nchw && !a.out_nchw && a.taps == 9 && a.stride == 1 && !a.up && a.C2 == 0 && a.C1 <= 4 && !a.scale &&
+           !a.pro_silu && !a.dmask && !a.tproj && !a.res1 && !a.out_silu && a.Cout % 8 == 0 && a.Cout <= 2048 &&
+           256 % (a.Cout / 8) == 0 && (size_t)9 * a.C1 * a.Cout * 4 <= 48 * 1024;
+}
+
+const char* conv_generic_kernel_name(const ConvArgs& a) { return conv_in_supported(a) ? "conv_in_kernel" : "conv_generic_kernel"; }
+
 int launch_conv_generic(int dtype, const ConvArgs& a, hipStream_t s) {
+    if (conv_in_supported(a)) {
+        const int64_t npix = (int64_t)a.N * a.Hout * a.Wout;
+        const int ppb = 256 / (a.Cout / 8) * 8;  // 8 passes per block
+        const unsigned blocks = (unsigned)((npix + ppb - 1) / ppb);
+        const size_t lds = (size_t)9 * a.C1 * a.Cout * 4;
+        if (dtype == DMME_BF16)
+            hipLaunchKernelGGL(conv_in_kernel<bf16>, dim3(blocks), dim3(256), lds, s, a, ppb);
+        else
+            hipLaunchKernelGGL(conv_in_kernel<float>, dim3(blocks), dim3(256), lds, s, a, ppb);
+        DMME_CHECK_LAUNCH();
+        return DMME_OK;
+    }
     const int64_t total = (int64_t)a.N * a.Hout * a.Wout * a.Cout;
     if (total == 0) return DMME_OK;
     int64_t blocks = (total + 255) / 256;

@@ -1,10 +1,9 @@
 // Elementwise kernels of the diffusion process: forward noising, DDPM / DDIM updates,
 // MSE loss, Philox normals / Dropout2d multipliers.  All HBM-bound, fp32, NCHW.
-// FP contraction is disabled so each expression rounds exactly like the reference's
-// sequence of separate torch ops (mul then add, never fma).
+// The translation unit is compiled with -ffp-contract=off (csrc/Makefile) so each
+// expression rounds exactly like the reference's sequence of separate torch ops
+// (mul then add, never fma); square roots come from host tables.
 #include "common.h"
-
-#pragma clang fp contract(off)
 
 namespace dmme {
 
@@ -99,30 +98,36 @@ int launch_dropmask(float* out, int64_t numel, float p, uint64_t seed, uint64_t 
 // ------------------------------------------------------------------ forward noising
 // forward_process + Normal.sample + target re-derivation (see dmme_hip.h)
 __global__ void __launch_bounds__(256) q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ z,
-                                                       const float* __restrict__ abar, const int64_t* __restrict__ t,
-                                                       int64_t chw, int64_t total, float* __restrict__ x_t,
-                                                       float* __restrict__ target) {
+                                                       const float* __restrict__ sqrt_abar,
+                                                       const float* __restrict__ sqrt_1m_abar,
+                                                       const int64_t* __restrict__ t, int64_t chw, int64_t total,
+                                                       float* __restrict__ x_t, float* __restrict__ target) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t n = i / chw;
-        const float ab = abar[t[n]];
-        const float sa = sqrtf(ab);
-        const float sd = sqrtf(1.0f - ab);
+        const int64_t tn = t[i / chw];
+        const float sa = sqrt_abar[tn], sd = sqrt_1m_abar[tn];
         const float mean = sa * x0[i];
         const float xt = mean + sd * z[i];
         x_t[i] = xt;
         if (target) target[i] = (xt - mean) / sd;
     }
 }
-int launch_q_sample(const float* x0, const float* z, const float* abar, const int64_t* t, int B, int64_t chw,
-                    float* x_t, float* target, hipStream_t s) {
+int launch_q_sample(const float* x0, const float* z, const float* sqrt_abar, const float* sqrt_1m_abar,
+                    const int64_t* t, int B, int64_t chw, float* x_t, float* target, hipStream_t s) {
     const int64_t total = (int64_t)B * chw;
     if (total <= 0) return DMME_OK;
-    hipLaunchKernelGGL(q_sample_kernel, dim3(grid_for(total)), dim3(256), 0, s, x0, z, abar, t, chw, total, x_t, target);
+    hipLaunchKernelGGL(q_sample_kernel, dim3(grid_for(total)), dim3(256), 0, s, x0, z, sqrt_abar, sqrt_1m_abar, t, chw, total,
+                       x_t, target);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }
 
 // ------------------------------------------------------------------ reverse updates
+// explicitly rounded ops (never contracted into fma): same rounding sequence as the
+// reference's separate torch ops
+__device__ __forceinline__ float ddpm_update(float x, float e, float z, float c1, float c2, float sigma, int add_noise) {
+    const float m = __fmul_rn(c1, __fsub_rn(x, __fmul_rn(c2, e)));
+    return add_noise ? __fadd_rn(m, __fmul_rn(sigma, z)) : m;
+}
 __global__ void __launch_bounds__(256) ddpm_step_kernel(float* __restrict__ x, const float* __restrict__ eps,
                                                         const float* __restrict__ z, float c1, float c2, float sigma,
                                                         int add_noise, int64_t n4, int64_t numel) {
@@ -133,17 +138,13 @@ __global__ void __launch_bounds__(256) ddpm_step_kernel(float* __restrict__ x, c
             const float4 ev = *reinterpret_cast<const float4*>(eps + b);
             float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (add_noise) zv = *reinterpret_cast<const float4*>(z + b);
-            float m;
-            m = c1 * (xv.x - c2 * ev.x); xv.x = add_noise ? m + sigma * zv.x : m;
-            m = c1 * (xv.y - c2 * ev.y); xv.y = add_noise ? m + sigma * zv.y : m;
-            m = c1 * (xv.z - c2 * ev.z); xv.z = add_noise ? m + sigma * zv.z : m;
-            m = c1 * (xv.w - c2 * ev.w); xv.w = add_noise ? m + sigma * zv.w : m;
+            xv.x = ddpm_update(xv.x, ev.x, zv.x, c1, c2, sigma, add_noise);
+            xv.y = ddpm_update(xv.y, ev.y, zv.y, c1, c2, sigma, add_noise);
+            xv.z = ddpm_update(xv.z, ev.z, zv.z, c1, c2, sigma, add_noise);
+            xv.w = ddpm_update(xv.w, ev.w, zv.w, c1, c2, sigma, add_noise);
             *reinterpret_cast<float4*>(x + b) = xv;
         } else {
-            for (int64_t i = b; i < numel; ++i) {
-                const float m = c1 * (x[i] - c2 * eps[i]);
-                x[i] = add_noise ? m + sigma * z[i] : m;
-            }
+            for (int64_t i = b; i < numel; ++i) x[i] = ddpm_update(x[i], eps[i], add_noise ? z[i] : 0.f, c1, c2, sigma, add_noise);
         }
     }
 }
@@ -159,8 +160,8 @@ int launch_ddpm_step(float* x, const float* eps, const float* z, float c1, float
 __global__ void __launch_bounds__(256) ddim_step_kernel(float* __restrict__ x, const float* __restrict__ eps, float s1,
                                                         float s2, int64_t numel) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x) {
-        const float x0_hat = (x[i] - s1 * eps[i]) / s2;
-        x[i] = s2 * x0_hat;
+        const float x0_hat = __fdiv_rn(__fsub_rn(x[i], __fmul_rn(s1, eps[i])), s2);
+        x[i] = __fmul_rn(s2, x0_hat);
     }
 }
 int launch_ddim_step(float* x, const float* eps, float s1, float s2, int64_t numel, hipStream_t s) {

@@ -454,9 +454,8 @@ int build_pack_items(dmme_plan* P, std::vector<PackItem>& items) {
 }
 
 // fill the device-side descriptor of a conv op
-int run_conv(const dmme_plan* P, const Op& o, const char* packed, const float* x, float* y, char* ws,
-             const float* drop_masks, int nt, hipStream_t s) {
-    ConvArgs a{};
+void fill_conv(const dmme_plan* P, const Op& o, const char* packed, const float* x, float* y, char* ws,
+               const float* drop_masks, int nt, ConvArgs& a) {
     const int64_t es = (int64_t)dtype_size(P->dtype);
     (void)es;
     a.N = P->B;
@@ -510,8 +509,101 @@ int run_conv(const dmme_plan* P, const Op& o, const char* packed, const float* x
     } else {
         a.dst = ws + P->tensors[o.dst].off;
     }
-    if (conv_mfma_supported(P->dtype, a)) return launch_conv_mfma(P->dtype, a, s);
-    return launch_conv_generic(P->dtype, a, s);
+}
+
+int run_op(const dmme_plan* P, const Op& o, const char* pk, const float* x, const int64_t* t, int nt, float* y,
+           char* ws, const float* drop_masks, hipStream_t s) {
+    switch (o.kind) {
+        case OP_SINUS:
+            return launch_time_sinusoid(t, nt, (const float*)(pk + P->params[P->freqs_param].packed_off),
+                                        P->cfg.pos_dim / 2, (float*)(ws + P->ws_tsin), s);
+        case OP_LINEAR: {
+            const char* w = o.lin_w >= 0 ? pk + P->params[o.lin_w].packed_off : pk + P->tproj_w_off;
+            const float* b = (const float*)(o.lin_b >= 0 ? pk + P->params[o.lin_b].packed_off : pk + P->tproj_b_off);
+            return launch_linear_wave(P->dtype, (const float*)(ws + o.lin_in), nt, o.lin_K, w, b, o.lin_N, o.lin_silu,
+                                      (float*)(ws + o.lin_out), s);
+        }
+        case OP_GN: {
+            const Tensor& t1 = P->tensors[o.gn_src1];
+            const void* s1 = ws + t1.off;
+            const void* s2 = o.gn_src2 >= 0 ? ws + P->tensors[o.gn_src2].off : nullptr;
+            const int C2 = o.gn_src2 >= 0 ? P->tensors[o.gn_src2].C : 0;
+            const float* gam = (const float*)(pk + P->params[o.gn_gamma].packed_off);
+            const float* bet = (const float*)(pk + P->params[o.gn_beta].packed_off);
+            float* sc = (float*)(ws + o.gn_scale);
+            float* sh = (float*)(ws + o.gn_shift);
+            if (gn_fast_supported(P->dtype, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups))
+                return launch_gn_fast(P->dtype, s1, s2, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups, gam, bet, 1e-5f, sc,
+                                      sh, (float*)(ws + P->ws_gnpart), s);
+            return launch_gn_generic(P->dtype, s1, s2, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups, gam, bet, 1e-5f,
+                                     sc, sh, s);
+        }
+        case OP_CONV: {
+            ConvArgs a{};
+            fill_conv(P, o, pk, x, y, ws, drop_masks, nt, a);
+            if (conv_pipe_supported(P->dtype, a)) return launch_conv_pipe(P->dtype, a, s);
+            if (conv_mfma_supported(P->dtype, a)) return launch_conv_mfma(P->dtype, a, s);
+            return launch_conv_generic(P->dtype, a, s);
+        }
+        case OP_ATTN: {
+            const Tensor& q = P->tensors[o.at_qkv];
+            const int S = q.H * q.W, C = q.C / 3;
+            if (attn_mfma_supported(P->dtype, P->B, S, C))
+                return launch_attn_mfma(P->dtype, ws + q.off, P->B, S, C, ws + P->tensors[o.at_out].off, s);
+            return launch_attn_generic(P->dtype, ws + q.off, P->B, S, C, ws + P->tensors[o.at_out].off, s);
+        }
+    }
+    return DMME_OK;
+}
+
+// kernel label + algorithmic flops / bytes of one op (bench.py's roofline accounting)
+void op_account(const dmme_plan* P, const Op& o, char* label, int cap, double* flops, double* bytes) {
+    const double es = (double)dtype_size(P->dtype);
+    const char* tn = P->dtype == DMME_BF16 ? "bf16" : "float";
+    const double B = P->B;
+    *flops = 0;
+    *bytes = 0;
+    switch (o.kind) {
+        case OP_SINUS:
+            snprintf(label, cap, "time_sinusoid_kernel");
+            break;
+        case OP_LINEAR:
+            snprintf(label, cap, "linear_wave_kernel<%s>", tn);
+            *flops = 2.0 * o.lin_K * o.lin_N;  // one timestep row when sampling
+            *bytes = (double)o.lin_K * o.lin_N * es + 4.0 * (o.lin_K + 2.0 * o.lin_N);
+            break;
+        case OP_GN: {
+            const Tensor& t1 = P->tensors[o.gn_src1];
+            const int C = t1.C + (o.gn_src2 >= 0 ? P->tensors[o.gn_src2].C : 0);
+            const bool fast = gn_fast_supported(P->dtype, P->B, t1.H * t1.W, t1.C, C - t1.C, P->cfg.num_groups);
+            snprintf(label, cap, fast ? "gn_partial_kernel<%s>" : "gn_generic_kernel<%s>", tn);
+            *bytes = B * t1.H * t1.W * C * es + 2.0 * B * C * 4;
+            break;
+        }
+        case OP_CONV: {
+            ConvArgs a{};
+            fill_conv(P, o, (const char*)4096, (const float*)4096, (float*)4096, (char*)4096, nullptr, 1, a);
+            if (conv_pipe_supported(P->dtype, a))
+                conv_pipe_label(P->dtype, a, label, cap);
+            else if (conv_mfma_supported(P->dtype, a))
+                conv_mfma_label(P->dtype, a, label, cap);
+            else
+                snprintf(label, cap, "%s<%s>", conv_generic_kernel_name(a), tn);
+            const double Cin = a.C1 + a.C2, opix = B * a.Hout * a.Wout;
+            *flops = 2.0 * opix * a.Cout * Cin * a.taps;
+            *bytes = B * a.Hin * a.Win * Cin * (a.in_nchw ? 4.0 : es) + opix * a.Cout * (a.out_nchw ? 4.0 : es) +
+                     (double)a.Cout * Cin * a.taps * es + (a.res1 ? opix * a.Cout * es : 0.0);
+            break;
+        }
+        case OP_ATTN: {
+            const Tensor& q = P->tensors[o.at_qkv];
+            const double S = q.H * q.W, C = q.C / 3;
+            snprintf(label, cap, attn_mfma_supported(P->dtype, P->B, (int)S, (int)C) ? "attn_mfma_kernel<%s>" : "attn_generic_kernel<%s>", tn);
+            *flops = 4.0 * B * S * S * C;
+            *bytes = B * S * 4.0 * C * es;
+            break;
+        }
+    }
 }
 
 }  // namespace
@@ -615,52 +707,43 @@ DMME_API int dmme_unet_forward(const dmme_plan* plan, const void* packed, const 
     char* ws = (char*)workspace;
     const int nt = t_len;
     for (const Op& o : P->ops) {
-        int rc = DMME_OK;
-        switch (o.kind) {
-            case OP_SINUS:
-                rc = launch_time_sinusoid(t, nt, (const float*)(pk + P->params[P->freqs_param].packed_off),
-                                          P->cfg.pos_dim / 2, (float*)(ws + P->ws_tsin), s);
-                break;
-            case OP_LINEAR: {
-                const char* w = o.lin_w >= 0 ? pk + P->params[o.lin_w].packed_off : pk + P->tproj_w_off;
-                const float* b = (const float*)(o.lin_b >= 0 ? pk + P->params[o.lin_b].packed_off : pk + P->tproj_b_off);
-                rc = launch_linear_wave(P->dtype, (const float*)(ws + o.lin_in), nt, o.lin_K, w, b, o.lin_N, o.lin_silu,
-                                        (float*)(ws + o.lin_out), s);
-                break;
-            }
-            case OP_GN: {
-                const Tensor& t1 = P->tensors[o.gn_src1];
-                const void* s1 = ws + t1.off;
-                const void* s2 = o.gn_src2 >= 0 ? ws + P->tensors[o.gn_src2].off : nullptr;
-                const int C2 = o.gn_src2 >= 0 ? P->tensors[o.gn_src2].C : 0;
-                const float* gam = (const float*)(pk + P->params[o.gn_gamma].packed_off);
-                const float* bet = (const float*)(pk + P->params[o.gn_beta].packed_off);
-                float* sc = (float*)(ws + o.gn_scale);
-                float* sh = (float*)(ws + o.gn_shift);
-                if (gn_fast_supported(P->dtype, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups))
-                    rc = launch_gn_fast(P->dtype, s1, s2, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups, gam, bet, 1e-5f,
-                                        sc, sh, (float*)(ws + P->ws_gnpart), s);
-                else
-                    rc = launch_gn_generic(P->dtype, s1, s2, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups, gam, bet,
-                                           1e-5f, sc, sh, s);
-                break;
-            }
-            case OP_CONV:
-                rc = run_conv(P, o, pk, x, y, ws, drop_masks, nt, s);
-                break;
-            case OP_ATTN: {
-                const Tensor& q = P->tensors[o.at_qkv];
-                const int S = q.H * q.W, C = q.C / 3;
-                if (attn_mfma_supported(P->dtype, P->B, S, C))
-                    rc = launch_attn_mfma(P->dtype, ws + q.off, P->B, S, C, ws + P->tensors[o.at_out].off, s);
-                else
-                    rc = launch_attn_generic(P->dtype, ws + q.off, P->B, S, C, ws + P->tensors[o.at_out].off, s);
-                break;
-            }
-        }
+        const int rc = run_op(P, o, pk, x, t, nt, y, ws, drop_masks, s);
         if (rc != DMME_OK) return rc;
     }
     return DMME_OK;
+}
+
+DMME_API int dmme_unet_plan_num_ops(const dmme_plan* plan) { return plan ? (int)plan->ops.size() : 0; }
+
+DMME_API int dmme_unet_plan_op_info(const dmme_plan* plan, int index, char* label, int label_cap, double* flops,
+                                    double* bytes) {
+    DMME_REQUIRE(plan && index >= 0 && index < (int)plan->ops.size() && label && label_cap > 0 && flops && bytes,
+                 DMME_ERR_INVALID, "op_info: bad argument");
+    op_account(plan, plan->ops[index], label, label_cap, flops, bytes);
+    return DMME_OK;
+}
+
+DMME_API int dmme_unet_forward_profiled(const dmme_plan* plan, const void* packed, const float* x, const int64_t* t,
+                                        int t_len, float* y, void* workspace, const float* drop_masks, void* stream,
+                                        float* op_ms) {
+    DMME_REQUIRE(plan && packed && x && t && y && workspace && op_ms, DMME_ERR_INVALID, "forward_profiled: null argument");
+    DMME_REQUIRE(t_len == 1 || t_len == plan->B, DMME_ERR_INVALID, "forward_profiled: bad t_len %d", t_len);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = plan->ops.size();
+    std::vector<hipEvent_t> ev(n + 1);
+    for (auto& e : ev) DMME_CHECK_HIP(hipEventCreate(&e));
+    int rc = DMME_OK;
+    DMME_CHECK_HIP(hipEventRecord(ev[0], s));
+    for (size_t i = 0; i < n && rc == DMME_OK; ++i) {
+        rc = run_op(plan, plan->ops[i], (const char*)packed, x, t, t_len, y, (char*)workspace, drop_masks, s);
+        if (rc == DMME_OK && hipEventRecord(ev[i + 1], s) != hipSuccess) rc = DMME_ERR_HIP;
+    }
+    if (rc == DMME_OK && hipEventSynchronize(ev[n]) != hipSuccess) rc = DMME_ERR_HIP;
+    for (size_t i = 0; i < n && rc == DMME_OK; ++i)
+        if (hipEventElapsedTime(&op_ms[i], ev[i], ev[i + 1]) != hipSuccess) rc = DMME_ERR_HIP;
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    if (rc == DMME_ERR_HIP) set_error("forward_profiled: HIP event error");
+    return rc;
 }
 
 DMME_API int dmme_unet_debug_read(const dmme_plan* plan, const void* workspace, const char* name, float* dst,
@@ -694,10 +777,10 @@ DMME_API int dmme_randn(float* out, int64_t numel, uint64_t seed, uint64_t offse
     return launch_randn(out, numel, seed, offset, (hipStream_t)stream);
 }
 
-DMME_API int dmme_q_sample(const float* x0, const float* z, const float* alpha_bar, const int64_t* t, int B, int64_t chw,
-                  float* x_t, float* target, void* stream) {
-    DMME_REQUIRE(x0 && z && alpha_bar && t && x_t && B > 0 && chw > 0, DMME_ERR_INVALID, "q_sample: bad argument");
-    return launch_q_sample(x0, z, alpha_bar, t, B, chw, x_t, target, (hipStream_t)stream);
+DMME_API int dmme_q_sample(const float* x0, const float* z, const float* sqrt_abar, const float* sqrt_1m_abar,
+                           const int64_t* t, int B, int64_t chw, float* x_t, float* target, void* stream) {
+    DMME_REQUIRE(x0 && z && sqrt_abar && sqrt_1m_abar && t && x_t && B > 0 && chw > 0, DMME_ERR_INVALID, "q_sample: bad argument");
+    return launch_q_sample(x0, z, sqrt_abar, sqrt_1m_abar, t, B, chw, x_t, target, (hipStream_t)stream);
 }
 
 DMME_API int dmme_ddpm_step(float* x, const float* eps, const float* z, float inv_sqrt_alpha, float eps_coef, float sigma,
@@ -734,6 +817,8 @@ DMME_API int dmme_conv2d(const dmme_conv_desc* d, const void* src1, const void* 
     a.Hout = Hv / a.stride; a.Wout = Wv / a.stride; a.Cout = d->Cout;
     a.pro_silu = d->pro_silu; a.out_silu = d->out_silu; a.nt = d->nt; a.tproj_ld = d->tproj_ld;
     a.in_nchw = d->in_nchw; a.out_nchw = d->out_nchw;
+    if (d->force_generic == 2 && conv_mfma_supported(d->dtype, a)) return launch_conv_mfma(d->dtype, a, (hipStream_t)stream);
+    if (!d->force_generic && conv_pipe_supported(d->dtype, a)) return launch_conv_pipe(d->dtype, a, (hipStream_t)stream);
     if (!d->force_generic && conv_mfma_supported(d->dtype, a)) return launch_conv_mfma(d->dtype, a, (hipStream_t)stream);
     return launch_conv_generic(d->dtype, a, (hipStream_t)stream);
 }

@@ -34,6 +34,10 @@ class DDPM(nn.Module):
         self.register_buffer("beta", beta, persistent=False)
         self.register_buffer("alpha", alpha, persistent=False)
         self.register_buffer("alpha_bar", alpha_bar, persistent=False)
+        # fp32 tables for the forward-noising kernel, evaluated like forward_process does
+        # (reference: equations/ddpm/ddpm.py:36-39); device-resident, not part of the state_dict
+        self.register_buffer("_sqrt_alpha_bar", torch.sqrt(alpha_bar).reshape(-1).contiguous(), persistent=False)
+        self.register_buffer("_sqrt_one_minus_alpha_bar", torch.sqrt(1 - alpha_bar).reshape(-1).contiguous(), persistent=False)
         # host copies of the per-step scalars of the reverse update (python floats)
         self._c1, self._c2, self._sigma = sampling_coefficients(beta, alpha, alpha_bar)
         self._all_t: Optional[Tensor] = None
@@ -57,7 +61,7 @@ class DDPM(nn.Module):
         x_t = torch.empty_like(x0)
         target = torch.empty_like(x0)
         _lib.check(
-            _lib.lib().dmme_q_sample(_lib.ptr(x0), _lib.ptr(z), _lib.ptr(self.alpha_bar), _lib.ptr(t), B, x0[0].numel(), _lib.ptr(x_t), _lib.ptr(target), _lib.stream_ptr()),
+            _lib.lib().dmme_q_sample(_lib.ptr(x0), _lib.ptr(z), _lib.ptr(self._sqrt_alpha_bar), _lib.ptr(self._sqrt_one_minus_alpha_bar), _lib.ptr(t), B, x0[0].numel(), _lib.ptr(x_t), _lib.ptr(target), _lib.stream_ptr()),
             "dmme_q_sample",
         )
         noise_in_x_t = self.model(x_t, t)

@@ -10,6 +10,8 @@ class WarmupLR(LRScheduler):
         super().__init__(optimizer, last_epoch)
 
     def get_lr(self):
-        done = getattr(self.optimizer, "_step_count", 0) + 1
+        # the reference keys on optimizer._step_count (+1); newer torch dropped that counter from
+        # optimizers, where the scheduler's own call count minus the construction-time call is equal
+        done = getattr(self.optimizer, "_step_count", self._step_count - 1) + 1
         scale = done / self.warmup_steps if done < self.warmup_steps else 1.0
         return [g["initial_lr"] * scale for g in self.optimizer.param_groups]

@@ -106,6 +106,19 @@ DMME_API int dmme_unet_pack_params(const dmme_plan* plan, const float* ref_flat,
 DMME_API int dmme_unet_forward(const dmme_plan* plan, const void* packed, const float* x, const int64_t* t, int t_len,
                       float* y, void* workspace, const float* drop_masks, void* stream);
 
+/* ---- per-op accounting + event-bracketed profiling (bench.py's roofline leg) --------
+ * op_info: kernel label (the kernel symbol the op launches, e.g.
+ * "conv_mfma_kernel<bf16,9,128,128>"), its algorithmic FLOPs and algorithmic HBM bytes
+ * (every operand read once, result written once) for the plan's (B,H,W).
+ * forward_profiled: same launches as dmme_unet_forward, but each op is bracketed by HIP
+ * events on `stream`; synchronises, then writes one elapsed time per op (ms). */
+DMME_API int dmme_unet_plan_num_ops(const dmme_plan* plan);
+DMME_API int dmme_unet_plan_op_info(const dmme_plan* plan, int index, char* label, int label_cap, double* flops,
+                           double* bytes);
+DMME_API int dmme_unet_forward_profiled(const dmme_plan* plan, const void* packed, const float* x, const int64_t* t,
+                               int t_len, float* y, void* workspace, const float* drop_masks, void* stream,
+                               float* op_ms);
+
 /* Copy an intermediate activation (the output of module `name`, e.g. "down_layers.3",
  * "input_conv", "condition") out of the workspace as fp32 NCHW for parity tests.
  * numel_cap guards the destination size. */
@@ -124,10 +137,12 @@ DMME_API int dmme_randn(float* out, int64_t numel, uint64_t seed, uint64_t offse
 
 /* forward noising: replaces forward_process(...).sample() and the target re-derivation
  * of DDPM.training_step (equations/ddpm/ddpm.py:36-41, diffusion_models/ddpm.py:72-79):
- *   mean = sqrt(abar[t_n]) x0 ; std = sqrt(1-abar[t_n]) ; x_t = mean + std z ;
- *   target = (x_t - mean)/std   (optional).  abar: device fp32 table indexed by t. */
-DMME_API int dmme_q_sample(const float* x0, const float* z, const float* alpha_bar, const int64_t* t, int B,
-                  int64_t chw, float* x_t, float* target, void* stream);
+ *   mean = sqrt_abar[t_n] x0 ; std = sqrt_1m_abar[t_n] ; x_t = mean + std z ;
+ *   target = (x_t - mean)/std   (optional).
+ * sqrt_abar / sqrt_1m_abar: device fp32 tables indexed by t holding sqrt(abar_t) and
+ * sqrt(1 - abar_t), evaluated on the host with the reference's fp32 torch ops. */
+DMME_API int dmme_q_sample(const float* x0, const float* z, const float* sqrt_abar, const float* sqrt_1m_abar,
+                  const int64_t* t, int B, int64_t chw, float* x_t, float* target, void* stream);
 
 /* one DDPM reverse update, in place on x: replaces DDPM.sampling_step after the model
  * call (diffusion_models/ddpm.py:99-110, equations/ddpm/ddpm.py:65-71):

@@ -1,0 +1,70 @@
+"""CPU: the C-ABI library loads and exports every symbol include/dmme_hip.h declares; the
+ctypes prototypes list exactly that set; host-only entry points behave (no GPU compute)."""
+
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "dmme_hip.h")).read()
+    return sorted(set(re.findall(r"DMME_API[^;(]*?\b(dmme_\w+)\s*\(", text)))
+
+
+def test_header_declares_entry_points():
+    names = declared_symbols()
+    assert len(names) >= 30
+    for must in ("dmme_unet_plan_create", "dmme_unet_forward", "dmme_q_sample", "dmme_ddpm_step", "dmme_ddim_step", "dmme_conv2d"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from dmme_amd import _lib
+
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    h = C.CDLL(_lib.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(h, name), f"{name} declared in include/dmme_hip.h but not exported"
+    assert sorted(_lib.PROTOTYPES) == declared_symbols()
+    assert _lib.lib().dmme_version() >= 100
+
+
+def test_plan_is_host_only_and_reports_errors():
+    from dmme_amd import _lib
+
+    lib = _lib.lib()
+    cfg = _lib.UNetCfg()
+    cfg.in_channels, cfg.pos_dim, cfg.emb_dim, cfg.num_groups, cfg.dropout = 3, 128, 512, 32, 0.1
+    cfg.num_depths, cfg.num_blocks, cfg.num_attention_depths = 4, 2, 1
+    for i, c in enumerate((128, 256, 256, 256)):
+        cfg.channels_per_depth[i] = c
+    cfg.attention_depths[0] = 2
+    h = C.c_void_p()
+    assert lib.dmme_unet_plan_create(C.byref(cfg), 128, 32, 32, _lib.BF16, -1, C.byref(h)) == 0
+    assert lib.dmme_unet_plan_num_params(h) == 305
+    assert lib.dmme_unet_plan_ref_numel(h) == 32_416_643 + 64  # parameters + the sinusoid buffer
+    assert lib.dmme_unet_plan_workspace_bytes(h) > 0 and lib.dmme_unet_plan_packed_bytes(h) > 2 * 32_416_643
+    assert lib.dmme_unet_plan_dropmask_numel(h) == 128 * 4736
+    n_ops = lib.dmme_unet_plan_num_ops(h)
+    assert n_ops == lib.dmme_unet_plan_num_launches(h) > 100
+    label = C.create_string_buffer(128)
+    fl, by = C.c_double(), C.c_double()
+    total = 0.0
+    for i in range(n_ops):
+        assert lib.dmme_unet_plan_op_info(h, i, label, 128, C.byref(fl), C.byref(by)) == 0
+        total += fl.value
+    # algorithmic FLOPs of one batch-128 forward: 128 x 9.809 GFLOP, time-MLP counted once
+    assert abs(total / 128 / 9.809e9 - 1) < 0.01
+    lib.dmme_unet_plan_destroy(h)
+    # invalid arguments come back as a status + message, never an exception / crash
+    cfg.num_groups = 7
+    assert lib.dmme_unet_plan_create(C.byref(cfg), 1, 32, 32, _lib.F32, -1, C.byref(h)) == -1
+    assert b"num_groups" in lib.dmme_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(-1, "x")
+    with pytest.raises(NotImplementedError):
+        _lib.check(-2, "x")

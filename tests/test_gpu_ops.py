@@ -21,14 +21,16 @@ def _bf(x):
 def _ref_conv(x1, w, b, x2, scale, shift, dmask, tproj, res, stride, upsample, pro_silu, out_silu, bf16):
     x = x1 if x2 is None else torch.cat([x1, x2], 1)
     q = _bf if bf16 else (lambda t: t)
-    x = q(x)
+    if x.shape[1] > 4:  # the 3-channel network input stays fp32 in both precisions
+        x = q(x)
     if scale is not None:
         x = x * scale[:, :, None, None] + shift[:, :, None, None]
     if pro_silu:
         x = F.silu(x)
     if dmask is not None:
         x = x * dmask[:, :, None, None]
-    x = q(x)
+    if x.shape[1] > 4:
+        x = q(x)
     if upsample:
         x = F.interpolate(x, scale_factor=2.0, mode="nearest")
     y = F.conv2d(x.double(), q(w).double(), b.double(), stride=stride, padding=w.shape[-1] // 2).float()
@@ -83,7 +85,7 @@ def test_conv(case, dtname):
     ref = _ref_conv(x1, w, b, x2, scale, shift, dmask, tproj, res, stride, up, pro, False, dtname == "bf16")
     cu = lambda t: None if t is None else t.cuda()
     outs = {}
-    for force_generic in (True, False):
+    for force_generic in (1, 2, 0):  # generic kernel, first-generation MFMA kernel, best (pipelined) kernel
         y = G.conv2d(dt, cu(x1), cu(w), cu(b), cu(x2), cu(scale), cu(shift), cu(dmask), cu(tproj), cu(res), stride, up, pro, False, force_generic)
         torch.cuda.synchronize()
         outs[force_generic] = y.cpu()

@@ -154,9 +154,10 @@ def test_sampler_kernels_bit_exact():
     ddpm = dmme_amd.DDPM(torch.nn.Identity(), T).cuda()
     got_xt = torch.empty_like(x0).cuda()
     got_tg = torch.empty_like(x0).cuda()
-    _lib.check(_lib.lib().dmme_q_sample(_lib.ptr(x0.cuda()), _lib.ptr(z.cuda()), _lib.ptr(ddpm.alpha_bar), _lib.ptr(t.cuda()), B, 3 * 32 * 32,
+    x0d, zd, td = x0.cuda(), z.cuda(), t.cuda()  # keep the device tensors alive across the raw-pointer call
+    _lib.check(_lib.lib().dmme_q_sample(_lib.ptr(x0d), _lib.ptr(zd), _lib.ptr(ddpm._sqrt_alpha_bar), _lib.ptr(ddpm._sqrt_one_minus_alpha_bar), _lib.ptr(td), B, 3 * 32 * 32,
                                         _lib.ptr(got_xt), _lib.ptr(got_tg), _lib.stream_ptr()))
-    assert torch.equal(got_xt.cpu(), xt)
+    np.testing.assert_allclose(got_xt.cpu().numpy(), xt.numpy(), rtol=0, atol=0)  # bit-exact
     np.testing.assert_allclose(got_tg.cpu().numpy(), target.numpy(), atol=1e-6, rtol=1e-6)
     eps = synth.normal(3, (B, 3, 32, 32))
     for step in (1000, 501, 2, 1):

@@ -1,0 +1,135 @@
+"""CPU: host-side mirror of the reference interface (no GPU compute): state_dict contract,
+schedules / tau tables against the reference's golden values, error behaviour, YAML runner,
+LR warm-up, helpers."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import dmme_amd
+from oracle import unet as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("cfg", [O.UNetConfig(), O.TINY, O.UNetConfig(dropout=0.0), O.UNetConfig(channels_per_depth=(32, 64), num_blocks=1, attention_depths=(1, 2))])
+def test_state_dict_contract_matches_reference_table(cfg):
+    net = dmme_amd.UNet(cfg.in_channels, cfg.pos_dim, cfg.emb_dim, cfg.num_groups, cfg.dropout, cfg.channels_per_depth, cfg.num_blocks, cfg.attention_depths)
+    table = O.param_table(cfg)  # pinned against the reference by make_golden.py (load_state_dict strict + key order)
+    sd = net.state_dict()
+    assert list(sd.keys()) == [k for k, _, _ in table]
+    assert [tuple(v.shape) for v in sd.values()] == [s for _, s, _ in table]
+    assert sum(p.numel() for p in net.parameters()) == sum(int(np.prod(s)) for _, s, r in table if r != "buffer")
+    assert [n for n, _ in net.named_buffers()] == ["condition.0.embeddings"]
+
+
+def test_load_state_dict_roundtrip_keeps_flat_views():
+    cfg = O.TINY
+    net = dmme_amd.UNet(cfg.in_channels, cfg.pos_dim, cfg.emb_dim, cfg.num_groups, cfg.dropout, cfg.channels_per_depth, cfg.num_blocks)
+    sd = O.make_state_dict(cfg, 3)
+    net.load_state_dict(sd, strict=True)
+    flat = net.flat_parameters()
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, sd[k])
+        assert flat.data_ptr() <= v.data_ptr() < flat.data_ptr() + 4 * flat.numel()
+    net.double().float()  # _apply moves tensors one by one; the module re-flattens afterwards
+    flat2 = net.flat_parameters()
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, sd[k]) and flat2.data_ptr() <= v.data_ptr() < flat2.data_ptr() + 4 * flat2.numel()
+    with pytest.raises(RuntimeError):
+        net.load_state_dict({k: v for k, v in list(sd.items())[:-1]}, strict=True)
+
+
+def test_default_init_statistics():
+    torch.manual_seed(0)
+    net = dmme_amd.UNet()
+    sd = net.state_dict()
+    w = sd["down_layers.0.conv1.2.weight"]
+    bound = 1 / np.sqrt(128 * 9)
+    assert w.abs().max() <= bound and w.abs().max() > 0.9 * bound and abs(w.mean()) < 1e-3
+    assert torch.all(sd["down_layers.0.conv1.0.weight"] == 1) and torch.all(sd["down_layers.0.conv1.0.bias"] == 0)
+    assert torch.all(sd["up_layers.8.attention.norm.weight"] == 1)
+    f = sd["condition.0.embeddings"]
+    assert f.shape == (1, 64) and f[0, 0] == 1 and abs(f[0, -1].item() - 1e-4) < 1e-9
+
+
+def test_forward_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    net = dmme_amd.UNet(pos_dim=4, emb_dim=8, num_groups=2, channels_per_depth=(4, 8), num_blocks=1)
+    with pytest.raises(dmme_amd._lib.DmmeError):
+        net(torch.zeros(1, 3, 8, 8), torch.tensor([1]))
+
+
+def test_ddpm_buffers_match_reference_golden(golden):
+    g = golden("schedules")
+    for T in (100, 1000):
+        d = dmme_amd.DDPM(torch.nn.Identity(), T)
+        assert d.beta.shape == (T + 1, 1, 1, 1)
+        assert np.array_equal(d.beta.reshape(-1).numpy(), g[f"sched_beta_{T}"])
+        assert np.array_equal(d.alpha.reshape(-1).numpy(), g[f"sched_alpha_{T}"])
+        assert np.array_equal(d.alpha_bar.reshape(-1).numpy(), g[f"sched_abar_{T}"])
+        assert d.state_dict() == {}  # schedules are non-persistent, like the reference
+    d = dmme_amd.DDPM(torch.nn.Identity(), 50, start=2.5e-5, end=0.005)
+    assert np.array_equal(d.alpha_bar.reshape(-1).numpy(), g["sched_abar_50_custom"])
+    # per-step scalars of the reverse update, same fp32 ops as reverse_process
+    b, a, ab = (torch.from_numpy(g[f"sched_{k}_1000"]) for k in ("beta", "alpha", "abar"))
+    d = dmme_amd.DDPM(torch.nn.Identity(), 1000)
+    # index 0 (t = 0) is never used: beta_0 / sqrt(1 - abar_0) is 0/0
+    assert d._c1 == (1 / torch.sqrt(a)).tolist() and d._c2[1:] == (b / torch.sqrt(1 - ab)).tolist()[1:] and d._sigma == torch.sqrt(b).tolist()
+
+
+def test_ddim_tau_matches_reference_golden(golden):
+    g = golden("schedules")
+    for T, S in ((1000, 50), (100, 5), (1000, 7)):
+        for sch in ("linear", "quadratic"):
+            d = dmme_amd.DDIM(torch.nn.Identity(), T, S, sch.upper() if S == 7 else sch)
+            assert np.array_equal(d.tau.numpy(), g[f"tau_{sch}_{T}_{S}"])
+    with pytest.raises(NotImplementedError):
+        dmme_amd.DDIM(torch.nn.Identity(), 100, 5, "cosine")
+    assert dmme_amd.DDIM(torch.nn.Identity()).tau[:4].tolist() == [0, 0, 2, 4]  # tau_0 = tau_1 = 0
+
+
+def test_helpers_match_reference_contracts():
+    torch.manual_seed(0)
+    t = dmme_amd.uniform_int(1, 100, 100000)
+    assert t.min() == 1 and t.max() == 99  # randint is high-exclusive: t = T never drawn
+    assert torch.equal(dmme_amd.pad(torch.tensor([1.0, 2.0])), torch.tensor([0.0, 1.0, 2.0]))
+    assert torch.equal(dmme_amd.pad(torch.tensor([1.0]), value=1), torch.tensor([1.0, 1.0]))
+    x = torch.rand(4, 3)
+    assert torch.equal(dmme_amd.norm(x), (x - 0.5) * 2) and torch.equal(dmme_amd.denorm(dmme_amd.norm(x) * 3), torch.clip((dmme_amd.norm(x) * 3 + 1) / 2, 0, 1))
+    assert dmme_amd.gaussian((2, 3)).shape == (2, 3) and dmme_amd.gaussian_like(x).shape == x.shape
+
+
+def test_warmup_lr_schedule():
+    p = torch.nn.Parameter(torch.zeros(2))
+    opt = torch.optim.Adam([p], lr=2e-4)
+    sched = dmme_amd.lr_scheduler.WarmupLR(opt, 5)
+    lrs = []
+    for _ in range(7):
+        lrs.append(opt.param_groups[0]["lr"])
+        p.grad = torch.ones(2)
+        opt.step()
+        sched.step()
+    # lr = base * min(1, (step_count + 1) / warmup), evaluated when the scheduler steps (reference warmup.py:10-19)
+    np.testing.assert_allclose(lrs, [2e-4 * v for v in (0.2, 0.4, 0.6, 0.8, 1, 1, 1)], rtol=1e-12)
+
+
+def test_lit_modules_and_yaml_runner():
+    from dmme_amd import trainer
+
+    for name, cls, dm in (("ddpm", dmme_amd.LitDDPM, dmme_amd.DDPM), ("ddim", dmme_amd.LitDDIM, dmme_amd.DDIM)):
+        conf = trainer.parse_config(os.path.join(ROOT, "configs", name, "cifar10.yaml"))
+        assert conf["batch_size"] == 128 and conf["max_steps"] == 800000 and conf["gradient_clip_val"] == 1.0 and conf["precision"] == "bf16"
+        module = trainer.build_module(conf)
+        assert isinstance(module, cls) and type(module.diffusion_model) is dm
+        assert module.lr == 2e-4 and module.warmup == 5000 and module.decay == 0.9999
+        assert module.diffusion_model.model.precision == "bf16"
+        keys = list(module.state_dict().keys())
+        assert keys[0] == "diffusion_model.model.condition.0.embeddings" and len(keys) == 305
+    opts, scheds = module.configure_optimizers()
+    assert opts[0].defaults["lr"] == 2e-4 and scheds[0]["interval"] == "step"
+    m2 = dmme_amd.LitDDIM(sample_steps=10, tau_schedule="linear", timesteps=100)
+    assert m2.diffusion_model.sub_timesteps == 10 and m2.diffusion_model.tau[-1] == 100

@@ -98,6 +98,101 @@ __device__ __forceinline__ uint4 prologue_vec<bf16>(uint4 raw, const float* sc, 
 }
 
 
+
+// Shared epilogue of the implicit-GEMM kernels.  acc layout (32x32 MFMA tile): lane = cout
+// column r, registers j = pixel rows (j&3) + 8*(j>>2) + 4*h -- a lane's values are 2 bytes wide
+// and 2*Cout bytes apart in the NHWC output, so storing them directly costs 64 narrow store
+// (and residual load) instructions per lane.  The common case (NHWC output in T, time-embedding
+// row uniform over the tile, no output SiLU) therefore transposes the tile through LDS:
+// accumulators (+ bias + time embedding) go to an fp32 [BM][BN] image, then every thread
+// handles whole 16-byte output vectors: one vector residual load, one vector store.
+// Everything else takes the general path straight from the registers.
+// `stage` must hold BM*BN floats and no wave may still be reading operand tiles from it.
+template <typename T, int BM, int BN, int MI, int NI, typename PixFn>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MI][NI], int co0, int wn0, int r, int h,
+                                              int wm0, int n0, int TN, PixFn pix_of, float* stage) {
+    constexpr int VEC = 16 / sizeof(T);
+    const bool uniform_t = !a.tproj || a.nt == 1 || TN == 1;
+    if (!a.out_silu && !a.out_nchw && uniform_t && (a.Cout % VEC) == 0) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int c = wn0 + ni * 32 + r, co = co0 + c;
+            float fold = 0.f;
+            if (co < a.Cout) {
+                fold = a.bias[co];
+                if (a.tproj) fold += a.tproj[(a.nt == 1 ? 0 : n0) * a.tproj_ld + co];
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int m = wm0 + mi * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+                    stage[m * BN + c] = acc[mi][ni][j] + fold;
+                }
+        }
+        __syncthreads();
+        constexpr int VPR = BN / VEC;  // vectors per pixel row of the tile
+        T* __restrict__ dst = (T*)a.dst;
+        const T* __restrict__ res = (const T*)a.res1;
+        for (int it = threadIdx.x; it < BM * VPR; it += 256) {
+            const int m = it / VPR, cg = it % VPR;
+            const int co = co0 + cg * VEC;
+            const int opix = pix_of(m);  // -1: pixel belongs to an image past the batch
+            if (opix < 0 || co >= a.Cout) continue;
+            const int off = opix * a.Cout + co;
+            const float* sp = stage + m * BN + cg * VEC;
+            if constexpr (sizeof(T) == 4) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(sp);
+                if (res) {
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(res + off);
+                    v += rv;
+                }
+                *reinterpret_cast<f32x4*>(dst + off) = v;
+            } else {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                if (res) {
+                    const bf16x8 rv = *reinterpret_cast<const bf16x8*>(res + off);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                }
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+                *reinterpret_cast<bf16x8*>(dst + off) = o;
+            }
+        }
+        return;
+    }
+    // general path (final NCHW conv, SiLU outputs, per-image time rows inside one tile)
+    // (fully unrolled: a runtime index into acc[][] would push the accumulators to scratch)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int co = co0 + wn0 + ni * 32 + r;
+        if (co >= a.Cout) continue;
+        const float bias = a.bias[co];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int m = wm0 + mi * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+                const int opix = pix_of(m);
+                if (opix < 0) continue;
+                const int hw = a.Hout * a.Wout;
+                const int n = opix / hw;
+                float v = acc[mi][ni][j] + bias;
+                if (a.tproj) v += a.tproj[(int64_t)(a.nt == 1 ? 0 : n) * a.tproj_ld + co];
+                if (a.res1) v += to_f(((const T*)a.res1)[(int64_t)opix * a.Cout + co]);
+                if (a.out_silu) v = silu_f(v);
+                if (a.out_nchw)
+                    ((float*)a.dst)[((int64_t)n * a.Cout + co) * hw + (opix - n * hw)] = v;
+                else
+                    ((T*)a.dst)[(int64_t)opix * a.Cout + co] = from_f<T>(v);
+            }
+        }
+    }
+}
+
 inline bool make_tile(const ConvArgs& a, int BM, int BN, ConvTile& g) {
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
     int TW = a.Wout < 16 ? a.Wout : 16;

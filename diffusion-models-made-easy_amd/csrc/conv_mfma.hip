@@ -123,37 +123,20 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a, ConvTile g) 
         }
     }
 
-    // ---- epilogue: lane holds column co (lane&31), rows (j&3) + 8*(j>>2) + 4*h ----
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int co = co0 + wn0 + ni * 32 + r;
-        if (co >= a.Cout) continue;
-        const float bias = a.bias[co];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int m = wm0 + mi * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
-                const int tx = m & mTW, ty = (m >> shTW) & mTH, tn = m >> (shTW + shTH);
-                const int n = n0 + tn;
-                if (n >= a.N) continue;
-                const int64_t opix = ((int64_t)n * a.Hout + oy0 + ty) * a.Wout + ox0 + tx;
-                float v = acc[mi][ni][j] + bias;
-                if (a.tproj) v += a.tproj[(int64_t)(a.nt == 1 ? 0 : n) * a.tproj_ld + co];
-                if (a.res1) v += to_f(((const T*)a.res1)[opix * a.Cout + co]);
-                if (a.out_silu) v = silu_f(v);
-                if (a.out_nchw)
-                    ((float*)a.dst)[(((int64_t)n * a.Cout + co) * a.Hout + oy0 + ty) * a.Wout + ox0 + tx] = v;
-                else
-                    ((T*)a.dst)[opix * a.Cout + co] = from_f<T>(v);
-            }
-        }
-    }
+    __syncthreads();  // operand tiles are dead: LDS becomes the output staging image
+    // ---- epilogue: + bias + time embedding + residual, store ----
+    auto pix_of = [&](int m) -> int {
+        const int tx = m & mTW, ty = (m >> shTW) & mTH, tn = m >> (shTW + shTH);
+        const int n = n0 + tn;
+        return n < a.N ? (n * a.Hout + oy0 + ty) * a.Wout + ox0 + tx : -1;
+    };
+    conv_epilogue<T, BM, BN, MI, NI>(a, acc, co0, wn0, r, h, wm0, n0, g.TN, pix_of, reinterpret_cast<float*>(lds));
 }
 
 bool conv_mfma_supported(int dtype, const ConvArgs& a) {
     const int KC = dtype == DMME_BF16 ? 64 : 32;
     if (a.in_nchw) return false;
+    if ((int64_t)a.N * a.Hout * a.Wout * a.Cout >= (1ll << 31)) return false;  // 32-bit offsets in the epilogue
     if (a.taps != 9 && a.taps != 1) return false;
     if (a.taps == 1 && (a.stride != 1 || a.up)) return false;
     if (a.stride != 1 && a.stride != 2) return false;
@@ -190,7 +173,9 @@ static int launch_sized(const ConvArgs& a, hipStream_t s) {
     const int pick = pick_tile(a, g);
     DMME_REQUIRE(pick >= 0, DMME_ERR_UNSUPPORTED, "conv_mfma: no tile fits (H=%d W=%d)", a.Hout, a.Wout);
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
-    const size_t lds = tile_lds(g, kCand[pick][1]);
+    size_t lds = tile_lds(g, kCand[pick][1]);
+    const size_t stage = (size_t)kCand[pick][0] * kCand[pick][1] * sizeof(float);  // epilogue staging image
+    if (lds < stage) lds = stage;
     switch (pick) {
         case 0: hipLaunchKernelGGL((conv_mfma_kernel<T, TAPS, 128, 128>), grid, dim3(256), lds, s, a, g); break;
         case 1: hipLaunchKernelGGL((conv_mfma_kernel<T, TAPS, 128, 64>), grid, dim3(256), lds, s, a, g); break;

@@ -199,36 +199,17 @@ __global__ void __launch_bounds__(256, 2) conv3x3_pipe_kernel(ConvArgs a, ConvTi
         }
     }
 
-    // ---- epilogue (as conv_mfma.hip): lane = cout column, registers = pixel rows ----
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int co = co0 + wn0 + ni * 32 + r;
-        if (co >= a.Cout) continue;
-        const float bias = a.bias[co];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int m = wm0 + mi * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
-                const int tx = m & mTW, ty = (m >> shTW) & mTH, tn = m >> (shTW + shTH);
-                const int n = n0 + tn;
-                if (n >= a.N) continue;
-                const int64_t opix = ((int64_t)n * a.Hout + oy0 + ty) * a.Wout + ox0 + tx;
-                float v = acc[mi][ni][j] + bias;
-                if (a.tproj) v += a.tproj[(int64_t)(a.nt == 1 ? 0 : n) * a.tproj_ld + co];
-                if (a.res1) v += to_f(((const T*)a.res1)[opix * a.Cout + co]);
-                if (a.out_silu) v = silu_f(v);
-                if (a.out_nchw)
-                    ((float*)a.dst)[(((int64_t)n * a.Cout + co) * a.Hout + oy0 + ty) * a.Wout + ox0 + tx] = v;
-                else
-                    ((T*)a.dst)[opix * a.Cout + co] = from_f<T>(v);
-            }
-        }
-    }
+    // ---- epilogue: + bias + time embedding + residual, store ----
+    auto pix_of = [&](int m) -> int {
+        const int tx = m & mTW, ty = (m >> shTW) & mTH, tn = m >> (shTW + shTH);
+        const int n = n0 + tn;
+        return n < a.N ? (n * a.Hout + oy0 + ty) * a.Wout + ox0 + tx : -1;
+    };
+    conv_epilogue<T, BM, BN, MI, NI>(a, acc, co0, wn0, r, h, wm0, n0, g.TN, pix_of, reinterpret_cast<float*>(lds));
 }
 
 static const int kPipeCand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
-static size_t pipe_lds(const ConvTile& g, int BN) { return (size_t)g.a_rows * ROW_DATA + (size_t)3 * BN * ROW_DATA; }
+static size_t pipe_lds(const ConvTile& g, int BN) { return (size_t)g.a_rows * ROW_DATA + (size_t)3 * BN * ROW_DATA; }  // >= BM*BN*4 for every candidate tile
 
 static int ilog2(int v) {
     int s = 0;

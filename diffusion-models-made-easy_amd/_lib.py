@@ -78,6 +78,12 @@ PROTOTYPES = {
     "dmme_unet_plan_num_ops": (_i, [_vp]),
     "dmme_unet_plan_op_info": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dmme_unet_forward_profiled": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dmme_unet_plan_packed_bwd_bytes": (_i64, [_vp]),
+    "dmme_unet_plan_bwd_workspace_bytes": (_i64, [_vp]),
+    "dmme_unet_pack_params_bwd": (_i, [_vp, _vp, _vp, _vp]),
+    "dmme_unet_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dmme_grad_norm": (_i, [_vp, _i64, _vp, _vp, _vp]),
+    "dmme_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _vp, _f, _f, _vp]),
     "dmme_unet_debug_read": (_i, [_vp, _vp, C.c_char_p, _vp, _i64, C.POINTER(_i64), _vp]),
     "dmme_dropout_masks": (_i, [_vp, _u64, _u64, _vp, _vp]),
     "dmme_randn": (_i, [_vp, _i64, _u64, _u64, _vp]),

@@ -1,4 +1,7 @@
-"""Autograd glue for the training path (the HIP backward is attached here)."""
+"""Autograd glue for the training path: torch.autograd only sees two opaque nodes (the UNet
+and the MSE loss); everything inside them is HIP (dmme_unet_forward / dmme_unet_backward /
+dmme_mse_loss).  Parameter gradients are accumulated by the library straight into the
+model's flat fp32 gradient buffer (every `param.grad` is a view of it)."""
 
 from __future__ import annotations
 
@@ -8,18 +11,46 @@ from torch import Tensor
 from . import _lib
 
 
+class _UNetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, anchor: Tensor, model, c: Tensor):
+        y, saved = model._forward_impl(x, c, want_ctx=True)
+        ctx.model = model
+        ctx.saved = saved
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        ctx.model._backward_impl(ctx.saved, dy)
+        ctx.saved = None
+        return None, None, None, None
+
+
 def unet_apply(model, x: Tensor, c: Tensor) -> Tensor:
-    raise NotImplementedError(
-        "the HIP backward of the UNet is not built yet: run the model under torch.no_grad() "
-        "(sampling / inference) or call .requires_grad_(False) on it"
-    )
+    """eps = UNet(x, c) with a HIP backward; `anchor` only ties the node into the graph."""
+    anchor = next(p for p in model.parameters() if p.requires_grad)
+    return _UNetFunction.apply(x, anchor, model, c)
+
+
+class _MSEFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eps: Tensor, target: Tensor):
+        e = eps.detach().to(torch.float32).contiguous()
+        tg = target.detach().to(torch.float32).contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=e.device)
+        scratch = torch.empty(1024, dtype=torch.float32, device=e.device)
+        d_eps = torch.empty_like(e) if eps.requires_grad else None
+        _lib.check(_lib.lib().dmme_mse_loss(_lib.ptr(e), _lib.ptr(tg), e.numel(), _lib.ptr(loss), _lib.ptr(d_eps), 1.0, _lib.ptr(scratch), _lib.stream_ptr()), "dmme_mse_loss")
+        ctx.d_eps = d_eps
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        d = ctx.d_eps
+        ctx.d_eps = None
+        return (d * grad_out if d is not None else None), None
 
 
 def mse_loss_apply(eps: Tensor, target: Tensor) -> Tensor:
-    """simple_loss (reference: equations/ddpm/losses.py:5-13) through dmme_mse_loss."""
-    e = eps.detach().to(torch.float32).contiguous()
-    tg = target.detach().to(torch.float32).contiguous()
-    loss = torch.empty(1, dtype=torch.float32, device=e.device)
-    scratch = torch.empty(1024, dtype=torch.float32, device=e.device)
-    _lib.check(_lib.lib().dmme_mse_loss(_lib.ptr(e), _lib.ptr(tg), e.numel(), _lib.ptr(loss), _lib.ptr(None), 1.0, _lib.ptr(scratch), _lib.stream_ptr()), "dmme_mse_loss")
-    return loss[0]
+    """simple_loss (reference: equations/ddpm/losses.py:5-13): mean((target - eps)^2) over all elements."""
+    return _MSEFunction.apply(eps, target)

@@ -103,7 +103,7 @@ struct ConvArgs {
     const void* src1;
     const void* src2;
     const void* w;      // [Cout][taps][Cin] T
-    const float* bias;  // [Cout]
+    const float* bias;  // [Cout] or null
     const float* scale; // [N][Cin] or null
     const float* shift;
     const float* dmask; // [N][Cin] or null
@@ -112,7 +112,7 @@ struct ConvArgs {
     const void* res2;   // NHWC T [.., Cout-R1] or null
     void* dst;
     int N, Hin, Win, C1, C2;
-    int up, stride, taps;
+    int up, stride, taps;  // up: 0 none, 1 nearest 2x (nn.Upsample), 2 zero-insertion 2x (data gradient of a stride-2 conv)
     int Hout, Wout, Cout;
     int pro_silu, out_silu;
     int nt, tproj_ld, R1;
@@ -133,14 +133,15 @@ bool conv_pipe_supported(int dtype, const ConvArgs& a);
 int launch_conv_pipe(int dtype, const ConvArgs& a, hipStream_t s);
 void conv_pipe_label(int dtype, const ConvArgs& a, char* buf, int cap);
 
+// mean_rstd (nullable): [N][groups][2] = {mean, rstd}, kept for the backward pass
 int launch_gn_generic(int dtype, const void* src1, const void* src2, int N, int HW, int C1, int C2, int groups,
-                      const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                      const float* gamma, const float* beta, float eps, float* scale, float* shift, float* mean_rstd,
                       hipStream_t s);
 bool gn_fast_supported(int dtype, int N, int HW, int C1, int C2, int groups);
 // partial: scratch of gn_fast_scratch_floats(...) floats
 size_t gn_fast_scratch_floats(int N, int HW, int C, int groups);
 int launch_gn_fast(int dtype, const void* src1, const void* src2, int N, int HW, int C1, int C2, int groups,
-                   const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                   const float* gamma, const float* beta, float eps, float* scale, float* shift, float* mean_rstd,
                    float* partial, hipStream_t s);
 
 int launch_attn_generic(int dtype, const void* qkv, int N, int S, int C, void* out, hipStream_t s);
@@ -161,7 +162,8 @@ struct PackItem {  // one chunk of the table-driven parameter re-pack
     int64_t dst_off;   // BYTE offset in the packed buffer
     int32_t cout, cin, taps;  // tensor geometry (cin*taps = row length)
     int32_t row0, rows;       // rows [row0, row0+rows) of this tensor handled by this item
-    int32_t as_f32;           // 1: keep fp32 (biases, gammas, freqs); 0: convert to dtype
+    int32_t as_f32;           // 1: keep fp32 (biases, gammas, freqs); 0: convert to dtype;
+                              // 2: transposed + tap-flipped copy [cin][taps-1-tap][cout] in dtype (data-gradient weights)
 };
 int launch_pack_table(int dtype, const PackItem* items_dev, int n_items, const float* ref_flat, void* packed,
                       hipStream_t s);
@@ -175,5 +177,22 @@ int launch_ddpm_step(float* x, const float* eps, const float* z, float c1, float
 int launch_ddim_step(float* x, const float* eps, float s1, float s2, int64_t numel, hipStream_t s);
 int launch_mse(const float* eps, const float* target, int64_t numel, float* loss, float* d_eps, float gscale,
                float* scratch, hipStream_t s);
+
+// ---- backward (kernels_bwd.hip) ----
+int launch_wgrad_generic(int dtype, const ConvArgs& a, const void* dY, float* dW, hipStream_t s);
+int launch_colsum(int dtype, const void* dY, int N, int HW, int C, float* rowsum, float* dbias, float* dtproj, int ld, int nt,
+                  hipStream_t s);
+int launch_gn_bwd_generic(int dtype, const void* dv, const void* x1, const void* x2, int N, int HW, int C1, int C2, int groups,
+                          const float* gamma, const float* mean_rstd, const float* scale, const float* shift, const float* dmask,
+                          int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, hipStream_t s);
+int launch_grad_acc(int dtype, const void* src, void* d1, void* d2, int C1, int C2, int acc1, int acc2, int pool, int N, int H, int W,
+                    hipStream_t s);
+int launch_attn_bwd_generic(int dtype, const void* qkv, const void* dO, int N, int S, int C, float* P, float* dS, void* dqkv, hipStream_t s);
+int launch_lin_dinput(int dtype, const float* dY, const void* W, int R, int O, int K, float* dX, hipStream_t s);
+int launch_lin_dweight(const float* dY, const float* X, int R, int O, int K, float* dW, float* dB, hipStream_t s);
+int launch_silu_bwd(float* dy, const float* z, int n, hipStream_t s);
+int launch_grad_norm(const float* g, int64_t n, float* norm_out, float* scratch, hipStream_t s);
+int launch_adam(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr, float b1, float b2, float eps, int step,
+                const float* norm, float max_norm, float ema_decay, hipStream_t s);
 
 }  // namespace dmme

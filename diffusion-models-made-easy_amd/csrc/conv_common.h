@@ -119,7 +119,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
             const int c = wn0 + ni * 32 + r, co = co0 + c;
             float fold = 0.f;
             if (co < a.Cout) {
-                fold = a.bias[co];
+                fold = a.bias ? a.bias[co] : 0.f;
                 if (a.tproj) fold += a.tproj[(a.nt == 1 ? 0 : n0) * a.tproj_ld + co];
             }
 #pragma unroll
@@ -170,7 +170,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
     for (int ni = 0; ni < NI; ++ni) {
         const int co = co0 + wn0 + ni * 32 + r;
         if (co >= a.Cout) continue;
-        const float bias = a.bias[co];
+        const float bias = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll

@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a, ConvTile g) 
             const int hy = rem / g.HWd, hx = rem % g.HWd;
             const int n = n0 + tn, iy = iy0 + hy, ix = ix0 + hx;
             uint4 val = make_uint4(0u, 0u, 0u, 0u);
-            if (n < a.N && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) {
+            if (n < a.N && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv && !(a.up == 2 && ((iy | ix) & 1))) {
                 const int sy = a.up ? (iy >> 1) : iy, sx = a.up ? (ix >> 1) : ix;
                 const int64_t pix = ((int64_t)n * a.Hin + sy) * a.Win + sx;
                 val = *reinterpret_cast<const uint4*>(sbase + pix * Cs + cs0 + cu * EPV);

@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_pipe_kernel(ConvArgs a, ConvTi
                 const int hy = rem / g.HWd, hx = rem - hy * g.HWd;
                 const int n = n0 + tn, iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
                 a_pix[i] = -1;
-                if (n < a.N && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) {
+                if (n < a.N && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv && !(a.up == 2 && ((iy | ix) & 1))) {
                     const int sy = a.up ? (iy >> 1) : iy, sx = a.up ? (ix >> 1) : ix;
                     a_pix[i] = (n * a.Hin + sy) * a.Win + sx;
                     a_ss[i] = n * Cin;

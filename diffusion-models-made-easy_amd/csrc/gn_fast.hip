@@ -103,7 +103,8 @@ __global__ void __launch_bounds__(256) gn_partial_kernel(const T* __restrict__ s
 __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ partial, int N, int nchunks, int groups,
                                                           int C, int chunk_cnt, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps,
-                                                          float* __restrict__ scale, float* __restrict__ shift) {
+                                                          float* __restrict__ scale, float* __restrict__ shift,
+                                                          float* __restrict__ mean_rstd) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * groups) return;
     const int n = i / groups, g = i % groups, cg = C / groups;
@@ -118,6 +119,10 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restric
         na = tot;
     }
     const float rstd = 1.0f / sqrtf(m2 / na + eps);
+    if (mean_rstd) {
+        mean_rstd[(int64_t)i * 2] = mean;
+        mean_rstd[(int64_t)i * 2 + 1] = rstd;
+    }
     for (int j = 0; j < cg; ++j) {
         const int c = g * cg + j;
         const float a = rstd * gamma[c];
@@ -162,8 +167,8 @@ size_t gn_fast_scratch_floats(int N, int HW, int C, int groups) {
 }
 
 int launch_gn_fast(int dtype, const void* src1, const void* src2, int N, int HW, int C1, int C2, int groups,
-                   const float* gamma, const float* beta, float eps, float* scale, float* shift, float* partial,
-                   hipStream_t s) {
+                   const float* gamma, const float* beta, float eps, float* scale, float* shift, float* mean_rstd,
+                   float* partial, hipStream_t s) {
     int chunk_px, nsweeps, nchunks;
     DMME_REQUIRE(gn_geometry(dtype, HW, C1, C2, groups, chunk_px, nsweeps, nchunks), DMME_ERR_UNSUPPORTED,
                  "gn_fast: unsupported geometry");
@@ -178,7 +183,7 @@ int launch_gn_fast(int dtype, const void* src1, const void* src2, int N, int HW,
     DMME_CHECK_LAUNCH();
     const int tot = N * groups;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, partial, N, nchunks, groups, C,
-                       chunk_px * (C / groups), gamma, beta, eps, scale, shift);
+                       chunk_px * (C / groups), gamma, beta, eps, scale, shift, mean_rstd);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }

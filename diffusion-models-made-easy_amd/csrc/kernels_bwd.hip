@@ -1,0 +1,470 @@
+// Backward kernels of the training step (shape-generic versions).
+//
+// Data-gradient of every convolution is NOT here: it is the forward implicit-GEMM kernel
+// run on dY with transposed + tap-flipped weights (plan.hip).  This file holds what has no
+// forward twin: weight gradients, bias / time-embedding column sums, GroupNorm(+SiLU
+// +Dropout2d) backward, attention backward, gradient accumulation (channel split of
+// torch.cat, 2x2 sum-pool of nn.Upsample), the small linears of the time MLP.
+// Reference math: torch autograd of models/ddpm.py:118-133 (ResBlock), :54-75 (Attention).
+#include "common.h"
+
+namespace dmme {
+
+__device__ __forceinline__ float silu_grad(float u) {
+    const float s = 1.0f / (1.0f + expf(-u));
+    return s * (1.0f + u * (1.0f - s));
+}
+
+// ------------------------------------------------------------------ weight gradient (generic)
+// dW[co][ci][kh][kw] += sum_{n,oy,ox} dY[n,oy,ox,co] * v[n, oy*s-pad+kh, ox*s-pad+kw, ci]
+// with v = act(x) recomputed through the forward prologue.  One thread per weight element.
+template <typename T>
+__global__ void __launch_bounds__(256) wgrad_generic_kernel(ConvArgs a, const T* __restrict__ dY, float* __restrict__ dW) {
+    const int Cin = a.C1 + a.C2;
+    const int64_t total = (int64_t)a.Cout * a.taps * Cin;
+    const int Hv = a.up ? 2 * a.Hin : a.Hin, Wv = a.up ? 2 * a.Win : a.Win;
+    const int k = a.taps == 9 ? 3 : 1, pad = a.taps == 9 ? 1 : 0;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(idx % Cin);
+        const int tap = (int)((idx / Cin) % a.taps);
+        const int co = (int)(idx / ((int64_t)Cin * a.taps));
+        const int kh = tap / k, kw = tap % k;
+        float acc = 0.f;
+        for (int n = 0; n < a.N; ++n) {
+            float sc = 1.f, sh = 0.f, dm = 1.f;
+            if (a.scale) {
+                sc = a.scale[(int64_t)n * Cin + ci];
+                sh = a.shift[(int64_t)n * Cin + ci];
+            }
+            if (a.dmask) dm = a.dmask[(int64_t)n * Cin + ci];
+            for (int oy = 0; oy < a.Hout; ++oy) {
+                const int iy = oy * a.stride - pad + kh;
+                if (iy < 0 || iy >= Hv) continue;
+                const int sy = a.up ? (iy >> 1) : iy;
+                for (int ox = 0; ox < a.Wout; ++ox) {
+                    const int ix = ox * a.stride - pad + kw;
+                    if (ix < 0 || ix >= Wv) continue;
+                    const int sx = a.up ? (ix >> 1) : ix;
+                    float v;
+                    if (a.in_nchw)
+                        v = ((const float*)a.src1)[(((int64_t)n * a.C1 + ci) * a.Hin + sy) * a.Win + sx];
+                    else {
+                        const int64_t pix = ((int64_t)n * a.Hin + sy) * a.Win + sx;
+                        v = ci < a.C1 ? to_f(((const T*)a.src1)[pix * a.C1 + ci]) : to_f(((const T*)a.src2)[pix * a.C2 + (ci - a.C1)]);
+                    }
+                    if (a.scale) v = fmaf(v, sc, sh);
+                    if (a.pro_silu) v = silu_f(v);
+                    if (a.dmask) v *= dm;
+                    if (!a.in_nchw) v = to_f(from_f<T>(v));
+                    acc = fmaf(to_f(dY[(((int64_t)n * a.Hout + oy) * a.Wout + ox) * a.Cout + co]), v, acc);
+                }
+            }
+        }
+        dW[((int64_t)co * Cin + ci) * a.taps + tap] += acc;
+    }
+}
+
+int launch_wgrad_generic(int dtype, const ConvArgs& a, const void* dY, float* dW, hipStream_t s) {
+    const int64_t total = (int64_t)a.Cout * a.taps * (a.C1 + a.C2);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (dtype == DMME_BF16)
+        hipLaunchKernelGGL(wgrad_generic_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, s, a, (const bf16*)dY, dW);
+    else
+        hipLaunchKernelGGL(wgrad_generic_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, a, (const float*)dY, dW);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+// ------------------------------------------------------------------ column sums of dY
+// rowsum[n][c] = sum over the image's pixels of dY[n, :, c]  (coalesced over c)
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ dY, int HW, int C, float* __restrict__ rowsum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = blockIdx.y;
+    if (c >= C) return;
+    const T* p = dY + (int64_t)n * HW * C + c;
+    float acc = 0.f;
+    for (int i = 0; i < HW; ++i) acc += to_f(p[(int64_t)i * C]);
+    rowsum[(int64_t)n * C + c] = acc;
+}
+// dbias[c] += sum_n rowsum[n][c];  d_tproj rows: per image (nt == N) or the single broadcast row
+__global__ void __launch_bounds__(256) bias_tproj_kernel(const float* __restrict__ rowsum, int N, int C, float* __restrict__ dbias,
+                                                         float* __restrict__ dtproj, int ld, int nt) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float tot = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float v = rowsum[(int64_t)n * C + c];
+        tot += v;
+        if (dtproj && nt > 1) dtproj[(int64_t)n * ld + c] = v;
+    }
+    if (dbias) dbias[c] += tot;
+    if (dtproj && nt == 1) dtproj[c] = tot;
+}
+int launch_colsum(int dtype, const void* dY, int N, int HW, int C, float* rowsum, float* dbias, float* dtproj, int ld, int nt,
+                  hipStream_t s) {
+    dim3 grid((C + 255) / 256, N);
+    if (dtype == DMME_BF16)
+        hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dY, HW, C, rowsum);
+    else
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)dY, HW, C, rowsum);
+    DMME_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bias_tproj_kernel, dim3((C + 255) / 256), dim3(256), 0, s, rowsum, N, C, dbias, dtproj, ld, nt);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+// ------------------------------------------------------------------ GroupNorm (+SiLU+mask) backward
+// forward: u = gamma*xhat + beta (= x*scale + shift), v = silu(u)*mask (or v = u)
+// given dv:  du = dv*mask*silu'(u);  dgamma += sum du*xhat;  dbeta += sum du
+//            dx = rstd * (du*gamma - (S1 + xhat*S2)/cnt),  S1 = sum_g du*gamma, S2 = sum_g du*gamma*xhat
+// One workgroup per (n, group); handles groups straddling the two concatenated sources.
+template <typename T>
+__global__ void __launch_bounds__(256) gn_bwd_generic_kernel(const T* __restrict__ dv, const T* __restrict__ x1, const T* __restrict__ x2,
+                                                             int HW, int C1, int C2, int groups, const float* __restrict__ gamma,
+                                                             const float* __restrict__ mean_rstd, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, const float* __restrict__ dmask, int pro_silu,
+                                                             T* __restrict__ dx1, T* __restrict__ dx2, int acc1, int acc2,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int n = blockIdx.y, g = blockIdx.x;
+    const int C = C1 + C2, cg = C / groups;
+    float* dg_l = sm;            // cg
+    float* db_l = sm + cg;       // cg
+    float* red = sm + 2 * cg;    // 16
+    for (int j = threadIdx.x; j < 2 * cg; j += blockDim.x) sm[j] = 0.f;
+    __syncthreads();
+    const float mean = mean_rstd[((int64_t)n * groups + g) * 2], rstd = mean_rstd[((int64_t)n * groups + g) * 2 + 1];
+    const int64_t cnt = (int64_t)cg * HW;
+    auto elem = [&](int64_t e, float& du, float& xhat, int& c, int64_t& p) {
+        c = g * cg + (int)(e % cg);
+        p = (int64_t)n * HW + e / cg;
+        const float x = c < C1 ? to_f(x1[p * C1 + c]) : to_f(x2[p * C2 + (c - C1)]);
+        float d = to_f(dv[p * C + c]);
+        if (dmask) d *= dmask[(int64_t)n * C + c];
+        if (pro_silu) d *= silu_grad(fmaf(x, scale[(int64_t)n * C + c], shift[(int64_t)n * C + c]));
+        du = d;
+        xhat = (x - mean) * rstd;
+    };
+    float s1 = 0.f, s2 = 0.f;
+    for (int64_t e = threadIdx.x; e < cnt; e += blockDim.x) {
+        float du, xhat;
+        int c;
+        int64_t p;
+        elem(e, du, xhat, c, p);
+        const float gm = gamma[c];
+        s1 = fmaf(du, gm, s1);
+        s2 = fmaf(du * gm, xhat, s2);
+        atomicAdd(&dg_l[c - g * cg], du * xhat);
+        atomicAdd(&db_l[c - g * cg], du);
+    }
+    const float S1 = block_sum(s1, red);
+    const float S2 = block_sum(s2, red);
+    const float inv = 1.0f / (float)cnt;
+    for (int64_t e = threadIdx.x; e < cnt; e += blockDim.x) {
+        float du, xhat;
+        int c;
+        int64_t p;
+        elem(e, du, xhat, c, p);
+        const float dx = rstd * (du * gamma[c] - (S1 + xhat * S2) * inv);
+        if (c < C1) {
+            T* d = dx1 + p * C1 + c;
+            *d = from_f<T>(acc1 ? to_f(*d) + dx : dx);
+        } else {
+            T* d = dx2 + p * C2 + (c - C1);
+            *d = from_f<T>(acc2 ? to_f(*d) + dx : dx);
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < cg; j += blockDim.x) {
+        atomicAdd(&dgamma[g * cg + j], dg_l[j]);
+        atomicAdd(&dbeta[g * cg + j], db_l[j]);
+    }
+}
+
+int launch_gn_bwd_generic(int dtype, const void* dv, const void* x1, const void* x2, int N, int HW, int C1, int C2, int groups,
+                          const float* gamma, const float* mean_rstd, const float* scale, const float* shift, const float* dmask,
+                          int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, hipStream_t s) {
+    const int cg = (C1 + C2) / groups;
+    const size_t lds = (size_t)(2 * cg + 16) * sizeof(float);
+    dim3 grid(groups, N);
+    if (dtype == DMME_BF16)
+        hipLaunchKernelGGL(gn_bwd_generic_kernel<bf16>, grid, dim3(256), lds, s, (const bf16*)dv, (const bf16*)x1, (const bf16*)x2, HW, C1, C2,
+                           groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, (bf16*)dx1, (bf16*)dx2, acc1, acc2, dgamma, dbeta);
+    else
+        hipLaunchKernelGGL(gn_bwd_generic_kernel<float>, grid, dim3(256), lds, s, (const float*)dv, (const float*)x1, (const float*)x2, HW, C1,
+                           C2, groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, (float*)dx1, (float*)dx2, acc1, acc2, dgamma, dbeta);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+// ------------------------------------------------------------------ gradient accumulation
+// dst1[.., :C1] (+)= src[.., :C1], dst2[.., :C2] (+)= src[.., C1:]; with pool = 1 the source is
+// 2H x 2W and each destination pixel receives the sum of its 2x2 block (nn.Upsample backward).
+template <typename T>
+__global__ void __launch_bounds__(256) grad_acc_kernel(const T* __restrict__ src, T* __restrict__ d1, T* __restrict__ d2, int C1, int C2,
+                                                       int acc1, int acc2, int pool, int H, int W, int64_t total) {
+    const int C = C1 + C2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t p = i / C;  // n*H*W + y*W + x  (destination pixel)
+        float v;
+        if (pool) {
+            const int x = (int)(p % W), y = (int)((p / W) % H);
+            const int64_t n = p / ((int64_t)W * H);
+            const int64_t b = ((n * 2 * H + 2 * y) * 2 * W + 2 * x) * C + c;
+            v = to_f(src[b]) + to_f(src[b + C]) + to_f(src[b + (int64_t)2 * W * C]) + to_f(src[b + (int64_t)2 * W * C + C]);
+        } else {
+            v = to_f(src[i]);
+        }
+        if (c < C1) {
+            T* d = d1 + p * C1 + c;
+            *d = from_f<T>(acc1 ? to_f(*d) + v : v);
+        } else {
+            T* d = d2 + p * C2 + (c - C1);
+            *d = from_f<T>(acc2 ? to_f(*d) + v : v);
+        }
+    }
+}
+int launch_grad_acc(int dtype, const void* src, void* d1, void* d2, int C1, int C2, int acc1, int acc2, int pool, int N, int H, int W,
+                    hipStream_t s) {
+    const int64_t total = (int64_t)N * H * W * (C1 + C2);
+    if (total == 0) return DMME_OK;
+    int64_t b = (total + 255) / 256;
+    if (b > 16384) b = 16384;
+    if (dtype == DMME_BF16)
+        hipLaunchKernelGGL(grad_acc_kernel<bf16>, dim3((unsigned)b), dim3(256), 0, s, (const bf16*)src, (bf16*)d1, (bf16*)d2, C1, C2, acc1, acc2, pool,
+                           H, W, total);
+    else
+        hipLaunchKernelGGL(grad_acc_kernel<float>, dim3((unsigned)b), dim3(256), 0, s, (const float*)src, (float*)d1, (float*)d2, C1, C2, acc1, acc2,
+                           pool, H, W, total);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+// ------------------------------------------------------------------ attention backward (generic)
+// pass A (one workgroup per query row): recompute p_i, dP_i = dO_i V^T, dS_i = p_i (dP_i - <p_i, dP_i>),
+//   keep P and dS (fp32, [N][S][S]) and write dQ_i = scale * dS_i K.
+// pass B (one workgroup per key row): dK_j = scale * dS[:, j]^T Q,  dV_j = P[:, j]^T dO.
+template <typename T>
+__global__ void __launch_bounds__(256) attn_bwd_rows_kernel(const T* __restrict__ qkv, const T* __restrict__ dO, int S, int C,
+                                                            float* __restrict__ P, float* __restrict__ dS, T* __restrict__ dqkv) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* qs = sm;            // C
+    float* dos = sm + C;       // C
+    float* ps = sm + 2 * C;    // S
+    float* ds = ps + S;        // S
+    float* red = ds + S;       // 16
+    const int n = blockIdx.y, i = blockIdx.x;
+    const T* base = qkv + (int64_t)n * S * 3 * C;
+    const float kscale = powf((float)C, -0.5f);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        qs[c] = to_f(base[(int64_t)i * 3 * C + c]);
+        dos[c] = to_f(dO[((int64_t)n * S + i) * C + c]);
+    }
+    __syncthreads();
+    float lmax = -INFINITY;
+    for (int j = threadIdx.x; j < S; j += blockDim.x) {
+        const T* kr = base + (int64_t)j * 3 * C + C;
+        const T* vr = base + (int64_t)j * 3 * C + 2 * C;
+        float sacc = 0.f, dacc = 0.f;
+        for (int c = 0; c < C; ++c) {
+            sacc = fmaf(qs[c], to_f(kr[c]) * kscale, sacc);
+            dacc = fmaf(dos[c], to_f(vr[c]), dacc);
+        }
+        ps[j] = sacc;
+        ds[j] = dacc;
+        lmax = fmaxf(lmax, sacc);
+    }
+    const float m = block_max(lmax, red);
+    float lsum = 0.f;
+    for (int j = threadIdx.x; j < S; j += blockDim.x) {
+        const float e = expf(ps[j] - m);
+        ps[j] = e;
+        lsum += e;
+    }
+    const float inv = 1.0f / block_sum(lsum, red);
+    float ldel = 0.f;
+    for (int j = threadIdx.x; j < S; j += blockDim.x) {
+        const float p = ps[j] * inv;
+        ps[j] = p;
+        ldel = fmaf(p, ds[j], ldel);
+    }
+    const float delta = block_sum(ldel, red);
+    float* Prow = P + ((int64_t)n * S + i) * S;
+    float* dSrow = dS + ((int64_t)n * S + i) * S;
+    for (int j = threadIdx.x; j < S; j += blockDim.x) {
+        const float v = ps[j] * (ds[j] - delta);
+        ds[j] = v;
+        Prow[j] = ps[j];
+        dSrow[j] = v;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc = 0.f;
+        for (int j = 0; j < S; ++j) acc = fmaf(ds[j], to_f(base[(int64_t)j * 3 * C + C + c]), acc);
+        dqkv[((int64_t)n * S + i) * 3 * C + c] = from_f<T>(acc * kscale);
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) attn_bwd_cols_kernel(const T* __restrict__ qkv, const T* __restrict__ dO, int S, int C,
+                                                            const float* __restrict__ P, const float* __restrict__ dS, T* __restrict__ dqkv) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* pc = sm;       // S : P[:, j]
+    float* dc = sm + S;   // S : dS[:, j]
+    const int n = blockIdx.y, j = blockIdx.x;
+    const T* base = qkv + (int64_t)n * S * 3 * C;
+    const float kscale = powf((float)C, -0.5f);
+    for (int i = threadIdx.x; i < S; i += blockDim.x) {
+        pc[i] = P[((int64_t)n * S + i) * S + j];
+        dc[i] = dS[((int64_t)n * S + i) * S + j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float dk = 0.f, dvv = 0.f;
+        for (int i = 0; i < S; ++i) {
+            dk = fmaf(dc[i], to_f(base[(int64_t)i * 3 * C + c]), dk);
+            dvv = fmaf(pc[i], to_f(dO[((int64_t)n * S + i) * C + c]), dvv);
+        }
+        dqkv[((int64_t)n * S + j) * 3 * C + C + c] = from_f<T>(dk * kscale);
+        dqkv[((int64_t)n * S + j) * 3 * C + 2 * C + c] = from_f<T>(dvv);
+    }
+}
+int launch_attn_bwd_generic(int dtype, const void* qkv, const void* dO, int N, int S, int C, float* P, float* dS, void* dqkv, hipStream_t s) {
+    const size_t ldsA = (size_t)(2 * C + 2 * S + 16) * sizeof(float), ldsB = (size_t)(2 * S) * sizeof(float);
+    DMME_REQUIRE(ldsA <= 64 * 1024, DMME_ERR_UNSUPPORTED, "attention backward: C+S too large (%d+%d)", C, S);
+    dim3 grid(S, N);
+    if (dtype == DMME_BF16) {
+        hipLaunchKernelGGL(attn_bwd_rows_kernel<bf16>, grid, dim3(256), ldsA, s, (const bf16*)qkv, (const bf16*)dO, S, C, P, dS, (bf16*)dqkv);
+        DMME_CHECK_LAUNCH();
+        hipLaunchKernelGGL(attn_bwd_cols_kernel<bf16>, grid, dim3(256), ldsB, s, (const bf16*)qkv, (const bf16*)dO, S, C, P, dS, (bf16*)dqkv);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_rows_kernel<float>, grid, dim3(256), ldsA, s, (const float*)qkv, (const float*)dO, S, C, P, dS, (float*)dqkv);
+        DMME_CHECK_LAUNCH();
+        hipLaunchKernelGGL(attn_bwd_cols_kernel<float>, grid, dim3(256), ldsB, s, (const float*)qkv, (const float*)dO, S, C, P, dS, (float*)dqkv);
+    }
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+// ------------------------------------------------------------------ small linears (time MLP) backward
+// dX[r][k] = sum_o dY[r][o] W[o][k]      (fp32 activations, weights in T)
+template <typename T>
+__global__ void __launch_bounds__(256) lin_dinput_kernel(const float* __restrict__ dY, const T* __restrict__ W, int R, int O, int K, float* __restrict__ dX) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= R * K) return;
+    const int r = idx / K, k = idx % K;
+    float acc = 0.f;
+    for (int o = 0; o < O; ++o) acc = fmaf(dY[(int64_t)r * O + o], to_f(W[(int64_t)o * K + k]), acc);
+    dX[idx] = acc;
+}
+// dW[o][k] += sum_r dY[r][o] X[r][k];  dB[o] += sum_r dY[r][o]
+__global__ void __launch_bounds__(256) lin_dweight_kernel(const float* __restrict__ dY, const float* __restrict__ X, int R, int O, int K,
+                                                          float* __restrict__ dW, float* __restrict__ dB) {
+    const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)O * K) return;
+    const int o = (int)(idx / K), k = (int)(idx % K);
+    float acc = 0.f, b = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const float d = dY[(int64_t)r * O + o];
+        acc = fmaf(d, X[(int64_t)r * K + k], acc);
+        b += d;
+    }
+    dW[idx] += acc;
+    if (k == 0 && dB) dB[o] += b;
+}
+// dz = dy * silu'(z), in place on dy
+__global__ void __launch_bounds__(256) silu_bwd_kernel(float* __restrict__ dy, const float* __restrict__ z, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dy[i] *= silu_grad(z[i]);
+}
+int launch_lin_dinput(int dtype, const float* dY, const void* W, int R, int O, int K, float* dX, hipStream_t s) {
+    const int total = R * K;
+    if (dtype == DMME_BF16)
+        hipLaunchKernelGGL(lin_dinput_kernel<bf16>, dim3((total + 255) / 256), dim3(256), 0, s, dY, (const bf16*)W, R, O, K, dX);
+    else
+        hipLaunchKernelGGL(lin_dinput_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, s, dY, (const float*)W, R, O, K, dX);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+int launch_lin_dweight(const float* dY, const float* X, int R, int O, int K, float* dW, float* dB, hipStream_t s) {
+    const int64_t total = (int64_t)O * K;
+    hipLaunchKernelGGL(lin_dweight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dY, X, R, O, K, dW, dB);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+int launch_silu_bwd(float* dy, const float* z, int n, hipStream_t s) {
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dy, z, n);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+// ------------------------------------------------------------------ optimiser tail
+// sum of squares of a flat fp32 buffer -> partial[blockIdx] (finalised by the consumer)
+__global__ void __launch_bounds__(256) sumsq_partial_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ partial) {
+    __shared__ float red[16];
+    float acc = 0.f;
+    for (int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
+        if (i + 3 < n) {
+            const float4 v = *reinterpret_cast<const float4*>(g + i);
+            acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        } else {
+            for (int64_t j = i; j < n; ++j) acc += g[j] * g[j];
+        }
+    }
+    const float tot = block_sum(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(256) sumsq_final_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+    __shared__ float red[16];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += partial[i];
+    const float tot = block_sum(acc, red);
+    if (threadIdx.x == 0) out[0] = sqrtf(tot);
+}
+int launch_grad_norm(const float* g, int64_t n, float* norm_out, float* scratch, hipStream_t s) {
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(1024), dim3(256), 0, s, g, n, scratch);
+    DMME_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, scratch, 1024, norm_out);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+// clip-by-global-norm + Adam (+ EMA) over flat fp32 buffers, one pass:
+//   g *= min(1, max_norm / (norm + 1e-6))                       (torch.nn.utils.clip_grad_norm_)
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2
+//   p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)                 (torch.optim.Adam, no weight decay)
+//   ema = d ema + (1-d) p                                        (callbacks/ema.py:169-176)
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, float* __restrict__ ema, int64_t n, float lr, float b1, float b2,
+                                                   float eps, float bc1, float bc2_sqrt, const float* __restrict__ norm, float max_norm,
+                                                   float ema_decay) {
+    float clip = 1.0f;
+    if (norm && max_norm > 0.f) {
+        const float c = max_norm / (norm[0] + 1e-6f);
+        clip = c < 1.0f ? c : 1.0f;
+    }
+    const float step = lr / bc1;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * clip;
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float pi = p[i] - step * mi / (sqrtf(vi) / bc2_sqrt + eps);
+        p[i] = pi;
+        if (ema) ema[i] = ema_decay * ema[i] + (1.0f - ema_decay) * pi;
+    }
+}
+int launch_adam(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr, float b1, float b2, float eps, int step,
+                const float* norm, float max_norm, float ema_decay, hipStream_t s) {
+    const float bc1 = 1.0f - powf(b1, (float)step), bc2s = sqrtf(1.0f - powf(b2, (float)step));
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, ema, n, lr, b1, b2, eps, bc1, bc2s, norm, max_norm, ema_decay);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+}  // namespace dmme

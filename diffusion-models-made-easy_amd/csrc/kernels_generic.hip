@@ -31,10 +31,12 @@ __global__ void __launch_bounds__(256) conv_generic_kernel(ConvArgs a) {
         for (int kh = 0; kh < k; ++kh) {
             const int iy = oh * a.stride - pad + kh;
             if (iy < 0 || iy >= Hv) continue;
+            if (a.up == 2 && (iy & 1)) continue;  // zero-insertion: only even rows / columns carry data
             const int sy = a.up ? (iy >> 1) : iy;
             for (int kw = 0; kw < k; ++kw) {
                 const int ix = ow * a.stride - pad + kw;
                 if (ix < 0 || ix >= Wv) continue;
+                if (a.up == 2 && (ix & 1)) continue;
                 const int sx = a.up ? (ix >> 1) : ix;
                 const T* wt = w + (kh * k + kw) * Cin;
                 const int64_t pix = ((int64_t)n * a.Hin + sy) * a.Win + sx;
@@ -54,7 +56,7 @@ __global__ void __launch_bounds__(256) conv_generic_kernel(ConvArgs a) {
                 }
             }
         }
-        acc += a.bias[co];
+        if (a.bias) acc += a.bias[co];
         if (a.tproj) acc += a.tproj[(int64_t)(a.nt == 1 ? 0 : n) * a.tproj_ld + co];
         const int64_t opix = ((int64_t)n * a.Hout + oh) * a.Wout + ow;
         if (a.res1) {
@@ -159,7 +161,8 @@ int launch_conv_generic(int dtype, const ConvArgs& a, hipStream_t s) {
 template <typename T>
 __global__ void __launch_bounds__(256) gn_generic_kernel(const T* __restrict__ s1, const T* __restrict__ s2, int HW,
                                                          int C1, int C2, int groups, const float* gamma,
-                                                         const float* beta, float eps, float* scale, float* shift) {
+                                                         const float* beta, float eps, float* scale, float* shift,
+                                                         float* mean_rstd) {
     __shared__ float red[16];
     const int n = blockIdx.y, g = blockIdx.x;
     const int C = C1 + C2, cg = C / groups;
@@ -179,6 +182,10 @@ __global__ void __launch_bounds__(256) gn_generic_kernel(const T* __restrict__ s
     }
     const float var = block_sum(q, red) / (float)cnt;
     const float rstd = 1.0f / sqrtf(var + eps);
+    if (mean_rstd && threadIdx.x == 0) {
+        mean_rstd[((int64_t)n * groups + g) * 2] = mean;
+        mean_rstd[((int64_t)n * groups + g) * 2 + 1] = rstd;
+    }
     for (int j = threadIdx.x; j < cg; j += blockDim.x) {
         const int c = g * cg + j;
         const float a = rstd * gamma[c];
@@ -188,15 +195,15 @@ __global__ void __launch_bounds__(256) gn_generic_kernel(const T* __restrict__ s
 }
 
 int launch_gn_generic(int dtype, const void* src1, const void* src2, int N, int HW, int C1, int C2, int groups,
-                      const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                      const float* gamma, const float* beta, float eps, float* scale, float* shift, float* mean_rstd,
                       hipStream_t s) {
     dim3 grid(groups, N);
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(gn_generic_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)src1, (const bf16*)src2, HW,
-                           C1, C2, groups, gamma, beta, eps, scale, shift);
+                           C1, C2, groups, gamma, beta, eps, scale, shift, mean_rstd);
     else
         hipLaunchKernelGGL(gn_generic_kernel<float>, grid, dim3(256), 0, s, (const float*)src1, (const float*)src2,
-                           HW, C1, C2, groups, gamma, beta, eps, scale, shift);
+                           HW, C1, C2, groups, gamma, beta, eps, scale, shift, mean_rstd);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }
@@ -376,9 +383,19 @@ __global__ void __launch_bounds__(256) pack_table_kernel(const PackItem* items, 
     const int64_t total = (int64_t)it.rows * row;
     const float* src = ref + it.src_off;
     const int64_t e0 = (int64_t)it.row0 * row;
-    if (it.as_f32) {
+    if (it.as_f32 == 1) {
         float* dst = (float*)(packed + it.dst_off);
         for (int64_t e = threadIdx.x; e < total; e += blockDim.x) dst[e0 + e] = src[e0 + e];
+    } else if (it.as_f32 == 2) {
+        // data-gradient copy: dst[ci][taps-1-tap][co]; this item covers source rows (couts) [row0, row0+rows)
+        T* dst = (T*)(packed + it.dst_off);
+        for (int64_t e = threadIdx.x; e < total; e += blockDim.x) {
+            const int64_t g = e0 + e;                      // reference-layout index: (co*cin + ci)*taps + tap
+            const int tap = (int)(g % it.taps);
+            const int64_t q = g / it.taps;
+            const int ci = (int)(q % it.cin), co = (int)(q / it.cin);
+            dst[((int64_t)ci * it.taps + (it.taps - 1 - tap)) * it.cout + co] = from_f<T>(src[g]);
+        }
     } else {
         T* dst = (T*)(packed + it.dst_off);
         for (int64_t e = threadIdx.x; e < total; e += blockDim.x) {

@@ -28,6 +28,7 @@ struct Param {
     int64_t shape[4] = {1, 1, 1, 1};
     int64_t ref_off = 0;     // elements, fp32 reference-layout flat buffer
     int64_t packed_off = 0;  // bytes
+    int64_t packed_bwd_off = -1;  // bytes in the data-gradient weight buffer (conv weights only)
     bool is_buffer = false;
     bool as_f32 = true;      // stays fp32 in the packed buffer (bias / gamma / beta / freqs)
     int cout = 1, cin = 1, taps = 1;
@@ -48,7 +49,7 @@ struct Op {
     int lin_K = 0, lin_N = 0, lin_w = -1, lin_b = -1, lin_silu = 0;
     // OP_GN
     int gn_src1 = -1, gn_src2 = -1, gn_gamma = -1, gn_beta = -1;
-    int64_t gn_scale = 0, gn_shift = 0;
+    int64_t gn_scale = 0, gn_shift = 0, gn_mr = 0;  // workspace offsets: scale/shift [N][C], {mean, rstd} [N][G][2]
     // OP_CONV
     int src1 = -1, src2 = -1;  // tensor ids; -2: network input (NCHW fp32)
     int w = -1, b = -1;
@@ -82,6 +83,16 @@ struct dmme_plan {
     PackItem* items_dev = nullptr;
     int n_items = 0;
     int n_launches = 0;
+    // ---- training (backward) ----
+    struct TBlock { int tw, tb, col, cout; };
+    std::vector<TBlock> tblocks;           // per-ResBlock time projection parameters
+    int p_l1w = -1, p_l1b = -1, p_l2w = -1, p_l2b = -1;
+    int64_t packed_bwd_bytes = 0, bws_bytes = 0;
+    std::vector<int64_t> gt_off;           // gradient buffer of every forward tensor
+    int64_t bws_tmp = 0, bws_dy = 0, bws_rowsum = 0, bws_dtproj = 0, bws_dtemb = 0, bws_dh1 = 0, bws_z = 0, bws_attP = 0,
+            bws_attdS = 0;
+    PackItem* items_bwd_dev = nullptr;
+    int n_items_bwd = 0;
 };
 
 namespace {
@@ -209,6 +220,7 @@ int build_plan(dmme_plan* P) {
     int l1w, l1b, l2w, l2b, icw, icb, ogw, ogb, ocw, ocb;
     bld.lin("condition.1", c.pos_dim, c.emb_dim, l1w, l1b);
     bld.lin("condition.3", c.emb_dim, c.emb_dim, l2w, l2b);
+    P->p_l1w = l1w; P->p_l1b = l1b; P->p_l2w = l2w; P->p_l2b = l2b;
     bld.conv("input_conv", c.in_channels, chans[0], 3, icw, icb);
     for (auto* seq : {&down, &up, &mid})
         for (auto& n : *seq) {
@@ -230,6 +242,7 @@ int build_plan(dmme_plan* P) {
             if (n.kind == 0) {
                 n.tproj_col = tcols;
                 tcols += n.cout;
+                P->tblocks.push_back({n.tw, n.tb, n.tproj_col, n.cout});
             }
     P->tproj_cols = tcols;
     int64_t cur = 0;
@@ -256,6 +269,15 @@ int build_plan(dmme_plan* P) {
         }
     }
     P->packed_bytes = cur;
+    {   // transposed + tap-flipped conv weights for the data-gradient convolutions
+        int64_t bc = 0;
+        for (Param& p : P->params)
+            if (p.ndim == 4) {
+                p.packed_bwd_off = bc;
+                bc = align_up(bc + p.numel() * es, 256);
+            }
+        P->packed_bwd_bytes = bc;
+    }
 
     // ---- workspace + op list ----
     int64_t ws = 0;
@@ -308,6 +330,7 @@ int build_plan(dmme_plan* P) {
         const int C = t1.C + (s2 >= 0 ? P->tensors[s2].C : 0);
         o.gn_scale = ws_alloc((int64_t)B * C * 4);
         o.gn_shift = ws_alloc((int64_t)B * C * 4);
+        o.gn_mr = ws_alloc((int64_t)B * c.num_groups * 2 * 4);
         const size_t part = gn_fast_scratch_floats(B, t1.H * t1.W, C, c.num_groups);
         if (part > gn_part_max) gn_part_max = part;
         ops.push_back(o);
@@ -428,6 +451,46 @@ int build_plan(dmme_plan* P) {
     P->ws_gnpart = ws_alloc((int64_t)(gn_part_max ? gn_part_max : 1) * 4);
     P->ws_bytes = ws;
     P->n_launches = (int)ops.size();
+
+    // ---- backward workspace: one gradient buffer per forward tensor + temporaries ----
+    {
+        int64_t bw = 0;
+        auto balloc = [&](int64_t bytes) {
+            const int64_t o = bw;
+            bw = align_up(bw + bytes, 256);
+            return o;
+        };
+        int64_t tmp_max = 0, att_max = 0;
+        int cmax = c.in_channels;
+        for (const Tensor& t : P->tensors) {
+            P->gt_off.push_back(balloc((int64_t)B * t.H * t.W * t.C * es));
+            if (t.C > cmax) cmax = t.C;
+        }
+        for (const Op& o : ops) {
+            if (o.kind == OP_CONV && o.src1 >= 0) {
+                const Tensor& t1 = P->tensors[o.src1];
+                const int Cin = t1.C + (o.src2 >= 0 ? P->tensors[o.src2].C : 0);
+                const int64_t up = o.up ? 4 : 1;
+                const int64_t b = (int64_t)B * t1.H * t1.W * up * Cin * es;
+                if (b > tmp_max) tmp_max = b;
+            }
+            if (o.kind == OP_ATTN) {
+                const Tensor& q = P->tensors[o.at_qkv];
+                const int64_t b = (int64_t)B * q.H * q.W * q.H * q.W * 4;
+                if (b > att_max) att_max = b;
+            }
+        }
+        P->bws_tmp = balloc(tmp_max);
+        P->bws_dy = balloc((int64_t)B * P->H * P->W * c.in_channels * es);
+        P->bws_rowsum = balloc((int64_t)B * cmax * 3 * 4);  // qkv convs have 3*C outputs
+        P->bws_dtproj = balloc((int64_t)B * tcols * 4);
+        P->bws_dtemb = balloc((int64_t)B * c.emb_dim * 4);
+        P->bws_dh1 = balloc((int64_t)B * c.emb_dim * 4);
+        P->bws_z = balloc((int64_t)B * c.emb_dim * 4);
+        P->bws_attP = balloc(att_max);
+        P->bws_attdS = balloc(att_max);
+        P->bws_bytes = bw;
+    }
     return DMME_OK;
 }
 
@@ -451,6 +514,35 @@ int build_pack_items(dmme_plan* P, std::vector<PackItem>& items) {
         }
     }
     return DMME_OK;
+}
+
+int build_pack_items_bwd(dmme_plan* P, std::vector<PackItem>& items) {
+    const int64_t CHUNK = 16384;
+    for (const Param& p : P->params) {
+        if (p.packed_bwd_off < 0) continue;
+        const int64_t row = (int64_t)p.cin * p.taps;
+        int64_t rows_per = CHUNK / row;
+        if (rows_per < 1) rows_per = 1;
+        for (int64_t r0 = 0; r0 < p.cout; r0 += rows_per) {
+            PackItem it;
+            it.src_off = p.ref_off;
+            it.dst_off = p.packed_bwd_off;
+            it.cout = p.cout;
+            it.cin = p.cin;
+            it.taps = p.taps;
+            it.row0 = (int32_t)r0;
+            it.rows = (int32_t)((p.cout - r0) < rows_per ? (p.cout - r0) : rows_per);
+            it.as_f32 = 2;
+            items.push_back(it);
+        }
+    }
+    return DMME_OK;
+}
+
+int run_any_conv(int dtype, const ConvArgs& a, hipStream_t s) {
+    if (conv_pipe_supported(dtype, a)) return launch_conv_pipe(dtype, a, s);
+    if (conv_mfma_supported(dtype, a)) return launch_conv_mfma(dtype, a, s);
+    return launch_conv_generic(dtype, a, s);
 }
 
 // fill the device-side descriptor of a conv op
@@ -534,9 +626,9 @@ int run_op(const dmme_plan* P, const Op& o, const char* pk, const float* x, cons
             float* sh = (float*)(ws + o.gn_shift);
             if (gn_fast_supported(P->dtype, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups))
                 return launch_gn_fast(P->dtype, s1, s2, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups, gam, bet, 1e-5f, sc,
-                                      sh, (float*)(ws + P->ws_gnpart), s);
+                                      sh, (float*)(ws + o.gn_mr), (float*)(ws + P->ws_gnpart), s);
             return launch_gn_generic(P->dtype, s1, s2, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups, gam, bet, 1e-5f,
-                                     sc, sh, s);
+                                     sc, sh, (float*)(ws + o.gn_mr), s);
         }
         case OP_CONV: {
             ConvArgs a{};
@@ -650,6 +742,11 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
         hipError_t e = hipSetDevice(device);
         if (e == hipSuccess) e = hipMalloc((void**)&P->items_dev, items.size() * sizeof(PackItem));
         if (e == hipSuccess) e = hipMemcpy(P->items_dev, items.data(), items.size() * sizeof(PackItem), hipMemcpyHostToDevice);
+        std::vector<PackItem> bitems;
+        build_pack_items_bwd(P, bitems);
+        P->n_items_bwd = (int)bitems.size();
+        if (e == hipSuccess) e = hipMalloc((void**)&P->items_bwd_dev, bitems.size() * sizeof(PackItem));
+        if (e == hipSuccess) e = hipMemcpy(P->items_bwd_dev, bitems.data(), bitems.size() * sizeof(PackItem), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             set_error("plan_create: device table setup failed: %s", hipGetErrorString(e));
             delete P;
@@ -663,6 +760,7 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
 DMME_API void dmme_unet_plan_destroy(dmme_plan* plan) {
     if (!plan) return;
     if (plan->items_dev) (void)hipFree(plan->items_dev);
+    if (plan->items_bwd_dev) (void)hipFree(plan->items_bwd_dev);
     delete plan;
 }
 
@@ -744,6 +842,153 @@ DMME_API int dmme_unet_forward_profiled(const dmme_plan* plan, const void* packe
     for (auto& e : ev) (void)hipEventDestroy(e);
     if (rc == DMME_ERR_HIP) set_error("forward_profiled: HIP event error");
     return rc;
+}
+
+// ---------------------------------------------------------------- training: backward + optimiser
+DMME_API int64_t dmme_unet_plan_packed_bwd_bytes(const dmme_plan* plan) { return plan ? plan->packed_bwd_bytes : 0; }
+DMME_API int64_t dmme_unet_plan_bwd_workspace_bytes(const dmme_plan* plan) { return plan ? plan->bws_bytes : 0; }
+
+DMME_API int dmme_unet_pack_params_bwd(const dmme_plan* plan, const float* ref_flat, void* packed_bwd, void* stream) {
+    DMME_REQUIRE(plan && ref_flat && packed_bwd, DMME_ERR_INVALID, "pack_params_bwd: null argument");
+    DMME_REQUIRE(plan->items_bwd_dev, DMME_ERR_INVALID, "pack_params_bwd: plan was created without a device");
+    return launch_pack_table(plan->dtype, plan->items_bwd_dev, plan->n_items_bwd, ref_flat, packed_bwd, (hipStream_t)stream);
+}
+
+DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const void* packed_bwd, const float* x,
+                                const int64_t* t, int t_len, const float* d_y, void* workspace, void* bwd_workspace,
+                                const float* drop_masks, float* grad_flat, void* stream) {
+    DMME_REQUIRE(plan && packed && packed_bwd && x && t && d_y && workspace && bwd_workspace && grad_flat, DMME_ERR_INVALID,
+                 "unet_backward: null argument");
+    DMME_REQUIRE(t_len == 1 || t_len == plan->B, DMME_ERR_INVALID, "unet_backward: bad t_len %d", t_len);
+    const dmme_plan* P = plan;
+    hipStream_t s = (hipStream_t)stream;
+    const char* pk = (const char*)packed;
+    const char* pkb = (const char*)packed_bwd;
+    char* ws = (char*)workspace;
+    char* bws = (char*)bwd_workspace;
+    const int B = P->B, dt = P->dtype, nt = t_len, G = P->cfg.num_groups;
+    std::vector<char> written(P->tensors.size(), 0);
+    auto gptr = [&](int id) -> char* { return bws + P->gt_off[id]; };
+    auto claim = [&](int id) -> int {  // 0: first contribution (write), 1: accumulate
+        const int acc = written[id];
+        written[id] = 1;
+        return acc;
+    };
+    float* rowsum = (float*)(bws + P->bws_rowsum);
+    float* dtproj = (float*)(bws + P->bws_dtproj);
+    char* tmp = bws + P->bws_tmp;
+    int rc = launch_nchw_to_nhwc(dt, d_y, B, P->cfg.in_channels, P->H * P->W, bws + P->bws_dy, s);
+    if (rc != DMME_OK) return rc;
+
+    for (int oi = (int)P->ops.size() - 1; oi >= 0 && rc == DMME_OK; --oi) {
+        const Op& o = P->ops[oi];
+        if (o.kind == OP_ATTN) {
+            const Tensor& q = P->tensors[o.at_qkv];
+            const int S = q.H * q.W, C = q.C / 3;
+            DMME_REQUIRE(written[o.at_out], DMME_ERR_INVALID, "backward: attention output has no gradient");
+            rc = launch_attn_bwd_generic(dt, ws + q.off, gptr(o.at_out), B, S, C, (float*)(bws + P->bws_attP),
+                                         (float*)(bws + P->bws_attdS), gptr(o.at_qkv), s);
+            written[o.at_qkv] = 1;
+            continue;
+        }
+        if (o.kind != OP_CONV) continue;
+        ConvArgs a{};
+        fill_conv(P, o, pk, x, nullptr, ws, drop_masks, nt, a);
+        const char* dy = o.dst == -2 ? bws + P->bws_dy : gptr(o.dst);
+        if (o.dst != -2) DMME_REQUIRE(written[o.dst], DMME_ERR_INVALID, "backward: tensor %d has no gradient", o.dst);
+        const int Cin = a.C1 + a.C2;
+        // 1. bias and time-embedding-row gradients (column sums of dY)
+        rc = launch_colsum(dt, dy, B, a.Hout * a.Wout, a.Cout, rowsum, grad_flat + P->params[o.b].ref_off,
+                           o.tproj_col >= 0 ? dtproj + o.tproj_col : nullptr, P->tproj_cols, nt, s);
+        if (rc != DMME_OK) break;
+        // 2. weight gradient (reference layout, accumulated)
+        rc = launch_wgrad_generic(dt, a, dy, grad_flat + P->params[o.w].ref_off, s);
+        if (rc != DMME_OK) break;
+        // 3. data gradient: the forward kernel on dY with transposed, tap-flipped weights
+        if (o.src1 >= 0) {
+            ConvArgs d{};
+            d.src1 = dy;
+            d.C1 = a.Cout;
+            d.N = B;
+            d.Hin = a.Hout;
+            d.Win = a.Wout;
+            d.up = o.stride == 2 ? 2 : 0;
+            d.stride = 1;
+            d.taps = o.taps;
+            d.Hout = d.up ? 2 * d.Hin : d.Hin;
+            d.Wout = d.up ? 2 * d.Win : d.Win;
+            d.Cout = Cin;
+            d.w = pkb + P->params[o.w].packed_bwd_off;
+            d.dst = tmp;
+            rc = run_any_conv(dt, d, s);
+            if (rc != DMME_OK) break;
+            const Tensor& t1 = P->tensors[o.src1];
+            char* g1 = gptr(o.src1);
+            char* g2 = o.src2 >= 0 ? gptr(o.src2) : nullptr;
+            const int acc1 = claim(o.src1), acc2 = o.src2 >= 0 ? claim(o.src2) : 0;
+            if (o.gn >= 0) {
+                const Op& gop = P->ops[o.gn];
+                rc = launch_gn_bwd_generic(dt, tmp, a.src1, a.src2, B, t1.H * t1.W, a.C1, a.C2, G,
+                                           (const float*)(pk + P->params[gop.gn_gamma].packed_off), (const float*)(ws + gop.gn_mr),
+                                           a.scale, a.shift, a.dmask, a.pro_silu, g1, g2, acc1, acc2,
+                                           grad_flat + P->params[gop.gn_gamma].ref_off, grad_flat + P->params[gop.gn_beta].ref_off, s);
+            } else {
+                rc = launch_grad_acc(dt, tmp, g1, g2, a.C1, a.C2, acc1, acc2, o.up == 1 ? 1 : 0, B, t1.H, t1.W, s);
+            }
+            if (rc != DMME_OK) break;
+        }
+        // 4. residual branch: d(res) += dY
+        if (o.res1 >= 0) {
+            const int R1 = P->tensors[o.res1].C;
+            const int acc1 = claim(o.res1), acc2 = o.res2 >= 0 ? claim(o.res2) : 0;
+            rc = launch_grad_acc(dt, dy, gptr(o.res1), o.res2 >= 0 ? gptr(o.res2) : nullptr, R1, a.Cout - R1, acc1, acc2, 0, B,
+                                 a.Hout, a.Wout, s);
+        }
+    }
+    if (rc != DMME_OK) return rc;
+
+    // ---- time MLP backward (models/ddpm.py:211-217 and the per-block Linear at :101-104) ----
+    const int emb = P->cfg.emb_dim, pos = P->cfg.pos_dim, tc = P->tproj_cols;
+    const float* temb = (const float*)(ws + P->ws_temb);
+    const float* h1 = (const float*)(ws + P->ws_th1);
+    const float* esin = (const float*)(ws + P->ws_tsin);
+    float* dtemb = (float*)(bws + P->bws_dtemb);
+    float* dh1 = (float*)(bws + P->bws_dh1);
+    float* z = (float*)(bws + P->bws_z);
+    for (const auto& tb : P->tblocks) {
+        // dW_block[o][k] += sum_r dtproj[r][col+o] temb[r][k]: gather the block's columns through rowsum scratch
+        // (dtproj is [nt][tc]; the generic kernel wants a dense [nt][cout] matrix)
+        DMME_CHECK_HIP(hipMemcpy2DAsync(rowsum, (size_t)tb.cout * 4, dtproj + tb.col, (size_t)tc * 4, (size_t)tb.cout * 4, (size_t)nt,
+                                        hipMemcpyDeviceToDevice, s));
+        rc = launch_lin_dweight(rowsum, temb, nt, tb.cout, emb, grad_flat + P->params[tb.tw].ref_off,
+                                grad_flat + P->params[tb.tb].ref_off, s);
+        if (rc != DMME_OK) return rc;
+    }
+    rc = launch_lin_dinput(dt, dtproj, pk + P->tproj_w_off, nt, tc, emb, dtemb, s);
+    if (rc != DMME_OK) return rc;
+    // temb = silu(z2), z2 = h1 W2^T + b2
+    rc = launch_linear_wave(dt, h1, nt, emb, pk + P->params[P->p_l2w].packed_off, (const float*)(pk + P->params[P->p_l2b].packed_off), emb, 0, z, s);
+    if (rc == DMME_OK) rc = launch_silu_bwd(dtemb, z, nt * emb, s);
+    if (rc == DMME_OK) rc = launch_lin_dweight(dtemb, h1, nt, emb, emb, grad_flat + P->params[P->p_l2w].ref_off, grad_flat + P->params[P->p_l2b].ref_off, s);
+    if (rc == DMME_OK) rc = launch_lin_dinput(dt, dtemb, pk + P->params[P->p_l2w].packed_off, nt, emb, emb, dh1, s);
+    // h1 = silu(z1), z1 = e W1^T + b1
+    if (rc == DMME_OK) rc = launch_linear_wave(dt, esin, nt, pos, pk + P->params[P->p_l1w].packed_off, (const float*)(pk + P->params[P->p_l1b].packed_off), emb, 0, z, s);
+    if (rc == DMME_OK) rc = launch_silu_bwd(dh1, z, nt * emb, s);
+    if (rc == DMME_OK) rc = launch_lin_dweight(dh1, esin, nt, emb, pos, grad_flat + P->params[P->p_l1w].ref_off, grad_flat + P->params[P->p_l1b].ref_off, s);
+    return rc;
+}
+
+DMME_API int dmme_grad_norm(const float* grad, int64_t numel, float* norm_out, float* scratch, void* stream) {
+    DMME_REQUIRE(grad && norm_out && scratch && numel > 0, DMME_ERR_INVALID, "grad_norm: bad argument");
+    return launch_grad_norm(grad, numel, norm_out, scratch, (hipStream_t)stream);
+}
+
+DMME_API int dmme_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema, int64_t numel, float lr,
+                            float beta1, float beta2, float eps, int step, const float* grad_norm, float max_norm, float ema_decay,
+                            void* stream) {
+    DMME_REQUIRE(param && grad && exp_avg && exp_avg_sq && numel > 0 && step >= 1, DMME_ERR_INVALID, "adam_step: bad argument");
+    return launch_adam(param, grad, exp_avg, exp_avg_sq, ema, numel, lr, beta1, beta2, eps, step, grad_norm, max_norm, ema_decay,
+                       (hipStream_t)stream);
 }
 
 DMME_API int dmme_unet_debug_read(const dmme_plan* plan, const void* workspace, const char* name, float* dst,
@@ -831,9 +1076,10 @@ DMME_API int dmme_groupnorm_scale_shift(int dtype, const void* src1, const void*
     DMME_REQUIRE(groups > 0 && (C1 + C2) % groups == 0, DMME_ERR_INVALID, "groupnorm: %d channels not divisible by %d groups",
                  C1 + C2, groups);
     if (!force_generic && partial_scratch && gn_fast_supported(dtype, N, HW, C1, C2, groups))
-        return launch_gn_fast(dtype, src1, src2, N, HW, C1, C2, groups, gamma, beta, eps, scale, shift, partial_scratch,
-                              (hipStream_t)stream);
-    return launch_gn_generic(dtype, src1, src2, N, HW, C1, C2, groups, gamma, beta, eps, scale, shift, (hipStream_t)stream);
+        return launch_gn_fast(dtype, src1, src2, N, HW, C1, C2, groups, gamma, beta, eps, scale, shift, nullptr,
+                              partial_scratch, (hipStream_t)stream);
+    return launch_gn_generic(dtype, src1, src2, N, HW, C1, C2, groups, gamma, beta, eps, scale, shift, nullptr,
+                             (hipStream_t)stream);
 }
 
 DMME_API int dmme_attention(int dtype, const void* qkv, int N, int S, int C, void* out, int force_generic, void* stream) {

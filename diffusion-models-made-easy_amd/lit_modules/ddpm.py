@@ -65,6 +65,6 @@ class LitDDPM(_Base):
         """Adam(lr) + per-step linear warm-up (reference: lit_modules/ddpm.py:127-135)"""
         from ..optim import FusedAdam
 
-        optimizer = FusedAdam(self.diffusion_model.parameters(), lr=self.lr)
+        optimizer = FusedAdam(self.diffusion_model.parameters(), lr=self.lr, ema_decay=self.decay)
         scheduler = {"scheduler": WarmupLR(optimizer, self.warmup), "interval": "step", "frequency": 1}
         return [optimizer], [scheduler]

@@ -10,6 +10,7 @@ the C ABI.  There is no PyTorch math on the device and no CPU fallback."""
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Dict, Optional, Sequence, Tuple
 
 import torch
@@ -98,6 +99,8 @@ class UNet(nn.Module):
         self._plans: Dict[Tuple, _Plan] = {}
         self._injected_masks: Optional[Tensor] = None
         self._mask_calls = 0
+        self._param_epoch = 0  # bumped by optimisers that update the flat buffer through raw pointers
+        self._flat_grad: Optional[Tensor] = None
 
         # parameter table from the C++ plan (host only: device = -1)
         table_plan = _Plan(self._cfg, 1, 32, 32, _lib.F32, -1)
@@ -157,7 +160,9 @@ class UNet(nn.Module):
             if is_buf:
                 mod.register_buffer(parts[-1], view)  # persistent, like the reference (:336)
             else:
-                mod.register_parameter(parts[-1], nn.Parameter(view))
+                par = nn.Parameter(view)
+                par._dmme_owner = weakref.ref(self)
+                mod.register_parameter(parts[-1], par)
             self._views.append((mod, parts[-1], off, n, shape, is_buf))
 
     def _current(self, mod, leaf, is_buf) -> Tensor:
@@ -224,7 +229,7 @@ class UNet(nn.Module):
 
     def _packed_for(self, plan: _Plan) -> Tensor:
         flat = self._ensure_flat()
-        ver = (flat.data_ptr(), flat._version)
+        ver = (flat.data_ptr(), flat._version, self._param_epoch)
         if plan.packed_version != ver:
             _lib.check(plan.lib.dmme_unet_pack_params(plan.h, _lib.ptr(flat), _lib.ptr(plan.packed), _lib.stream_ptr()), "dmme_unet_pack_params")
             plan.packed_version = ver
@@ -254,7 +259,57 @@ class UNet(nn.Module):
             return unet_apply(self, x, c)
         return self._forward_impl(x, c)
 
-    def _forward_impl(self, x: Tensor, c: Tensor, keep: bool = False) -> Tensor:
+    def mark_params_updated(self):
+        """call after writing the flat parameter buffer through a raw pointer (fused optimiser)"""
+        self._param_epoch += 1
+
+    # ------------------------------------------------------------------ gradients
+    def flat_grad(self) -> Tensor:
+        """fp32 gradient buffer in the flat parameter layout; every param.grad is a view of it.
+        (Re)created zeroed when absent, on another device, or after zero_grad(set_to_none=True)."""
+        flat = self._ensure_flat()
+        g = self._flat_grad
+        fresh = g is None or g.device != flat.device or g.numel() != flat.numel()
+        if fresh:
+            g = torch.zeros_like(flat)
+            self._flat_grad = g
+        rebind = fresh
+        if not rebind:
+            for mod, leaf, off, n, shape, is_buf in self._views:
+                if not is_buf and mod._parameters[leaf].grad is None:
+                    rebind = True
+                    break
+            if rebind:
+                g.zero_()
+        if rebind:
+            for mod, leaf, off, n, shape, is_buf in self._views:
+                if not is_buf:
+                    mod._parameters[leaf].grad = g[off : off + n].view(shape)
+        return g
+
+    def _backward_impl(self, saved, dy: Tensor):
+        plan, xin, t, masks = saved
+        lib = plan.lib
+        dev = xin.device
+        if getattr(plan, "bws", None) is None:
+            plan.bws = torch.empty(int(lib.dmme_unet_plan_bwd_workspace_bytes(plan.h)), dtype=torch.uint8, device=dev)
+            plan.packed_bwd = torch.empty(int(lib.dmme_unet_plan_packed_bwd_bytes(plan.h)), dtype=torch.uint8, device=dev)
+            plan.packed_bwd_version = None
+        flat = self._ensure_flat()
+        packed = self._packed_for(plan)
+        ver = (flat.data_ptr(), flat._version, self._param_epoch)
+        if plan.packed_bwd_version != ver:
+            _lib.check(lib.dmme_unet_pack_params_bwd(plan.h, _lib.ptr(flat), _lib.ptr(plan.packed_bwd), _lib.stream_ptr()), "dmme_unet_pack_params_bwd")
+            plan.packed_bwd_version = ver
+        g = self.flat_grad()
+        d = dy.detach().to(torch.float32).contiguous()
+        _lib.check(
+            lib.dmme_unet_backward(plan.h, _lib.ptr(packed), _lib.ptr(plan.packed_bwd), _lib.ptr(xin), _lib.ptr(t), int(t.numel()), _lib.ptr(d),
+                                   _lib.ptr(plan.workspace), _lib.ptr(plan.bws), _lib.ptr(masks), _lib.ptr(g), _lib.stream_ptr()),
+            "dmme_unet_backward",
+        )
+
+    def _forward_impl(self, x: Tensor, c: Tensor, want_ctx: bool = False):
         B, _, H, W = x.shape
         plan = self._plan_for(B, H, W, x.device)
         packed = self._packed_for(plan)
@@ -279,6 +334,8 @@ class UNet(nn.Module):
             "dmme_unet_forward",
         )
         self._last_plan = plan
+        if want_ctx:
+            return y, (plan, xin, t, masks)
         return y
 
     def debug_activation(self, name: str) -> Tensor:

@@ -1,0 +1,50 @@
+"""Plain training loop behind `python -m dmme_amd.trainer fit` (stands in for pl.Trainer.fit on
+the keys of configs/ddpm/cifar10.yaml that touch the hot path).  Synthetic CIFAR10-shaped data:
+x_0 = 2 U[0,1) - 1 (there is no dataset in the image; the input pipeline is out of scope)."""
+
+from __future__ import annotations
+
+import json
+import time
+
+import torch
+
+from . import distributed as D
+from .common.noise import gaussian
+
+
+def synthetic_batch(batch_size: int, device, shape=(3, 32, 32)):
+    return torch.rand((batch_size, *shape), device=device) * 2 - 1
+
+
+def train_step(module, optimizer, scheduler, x0, clip=None):
+    """one optimisation step: loss -> HIP backward -> (DP mean all-reduce) -> clip+Adam(+EMA) -> LR step"""
+    loss = module.training_step((x0,), 0)
+    loss.backward()
+    model = module.diffusion_model.model
+    D.allreduce_mean_flat(model.flat_grad())
+    optimizer.step()
+    if scheduler is not None:
+        scheduler.step()
+    optimizer.zero_grad()
+    return loss
+
+
+def fit(module, batch_size=128, max_steps=100, clip=None, log_every=50):
+    dev = next(module.parameters()).device
+    module.train()
+    opts, scheds = module.configure_optimizers()
+    opt = opts[0]
+    if clip:
+        for g in opt.param_groups:
+            g["max_grad_norm"] = float(clip)
+    sched = scheds[0]["scheduler"] if scheds else None
+    t0 = time.perf_counter()
+    for step in range(max_steps):
+        x0 = synthetic_batch(batch_size, dev)
+        loss = train_step(module, opt, sched, x0, clip)
+        if (step + 1) % log_every == 0 or step + 1 == max_steps:
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            print(json.dumps({"step": step + 1, "train/loss": round(float(loss), 5), "images_per_s": round((step + 1) * batch_size / dt, 1)}), flush=True)
+    return module

@@ -119,6 +119,27 @@ DMME_API int dmme_unet_forward_profiled(const dmme_plan* plan, const void* packe
                                int t_len, float* y, void* workspace, const float* drop_masks, void* stream,
                                float* op_ms);
 
+/* ---- training: replaces loss.backward() through the UNet + the optimiser side of the step ----
+ * dmme_unet_backward: given d_y = dL/d(eps) (NCHW fp32) and the workspace left by the matching
+ * dmme_unet_forward call (same x, t, drop_masks), ACCUMULATES dL/d(parameters) into grad_flat
+ * (fp32, reference state_dict order and layouts, like the flat parameter buffer).
+ * packed_bwd holds transposed, tap-flipped conv weights (dmme_unet_pack_params_bwd) for the
+ * data-gradient convolutions. Replaces torch autograd of models/ddpm.py:281-316. */
+DMME_API int64_t dmme_unet_plan_packed_bwd_bytes(const dmme_plan* plan);
+DMME_API int64_t dmme_unet_plan_bwd_workspace_bytes(const dmme_plan* plan);
+DMME_API int dmme_unet_pack_params_bwd(const dmme_plan* plan, const float* ref_flat, void* packed_bwd, void* stream);
+DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const void* packed_bwd, const float* x,
+                       const int64_t* t, int t_len, const float* d_y, void* workspace, void* bwd_workspace,
+                       const float* drop_masks, float* grad_flat, void* stream);
+/* global L2 norm of a flat fp32 gradient buffer (clip_grad_norm_; scratch: 1024 floats) */
+DMME_API int dmme_grad_norm(const float* grad, int64_t numel, float* norm_out, float* scratch, void* stream);
+/* one fused pass: clip by global norm (max_norm <= 0: off) -> Adam (torch.optim.Adam, no weight
+ * decay; reference lit_modules/ddpm.py:130) -> optional EMA (reference callbacks/ema.py:169-176;
+ * ema may be NULL).  `step` is 1-based; grad_norm is the device scalar of dmme_grad_norm. */
+DMME_API int dmme_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema, int64_t numel,
+                   float lr, float beta1, float beta2, float eps, int step, const float* grad_norm, float max_norm,
+                   float ema_decay, void* stream);
+
 /* Copy an intermediate activation (the output of module `name`, e.g. "down_layers.3",
  * "input_conv", "condition") out of the workspace as fp32 NCHW for parity tests.
  * numel_cap guards the destination size. */

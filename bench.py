@@ -37,7 +37,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--precision", default="bf16")
-    ap.add_argument("--mode", default="sample", choices=["sample", "ddim"])
+    ap.add_argument("--mode", default="sample", choices=["sample", "ddim", "train"])
+    ap.add_argument("--train-steps", type=int, default=8, help="training steps timed for train_images_per_s (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -143,6 +144,41 @@ def cpu_baseline_leg(batch_ref):
             "sample": f"{done} DDPM steps of batch {Bc}, fp32, oracle UNet + update, {dt:.1f} s"}
 
 
+def train_leg(dmme_amd, dev, B, precision, steps, warmup, dist):
+    """training images/s: q_sample -> UNet fwd (train mode, Dropout2d on) -> MSE -> HIP backward -> (RCCL mean
+    all-reduce of the flat gradient) -> fused clip(1.0)+Adam+EMA -> warm-up LR step; per-GPU batch B."""
+    from dmme_amd.train_loop import synthetic_batch, train_step
+
+    lit = dmme_amd.LitDDPM(model=dmme_amd.UNet(precision=precision)).to(dev)
+    lit.train()
+    opts, scheds = lit.configure_optimizers()
+    opt, sched = opts[0], scheds[0]["scheduler"]
+    for g in opt.param_groups:
+        g["max_grad_norm"] = 1.0
+    x0 = synthetic_batch(B, dev)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(warmup):
+        loss = train_step(lit, opt, sched, x0)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = train_step(lit, opt, sched, x0)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(loss).all(), "non-finite training loss"
+    return dt, float(loss)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -164,6 +200,20 @@ def main():
 
     torch.manual_seed(1337 + rank)
     B, T = args.batch, 1000
+    if args.mode == "train":
+        dt, loss = train_leg(dmme_amd, dev, B, args.precision, args.steps, args.warmup, dist)
+        if rank == 0:
+            print(json.dumps({
+                "metric": METRIC, "value": round(world * args.steps * B / dt, 2),
+                "unit": "training images/s (q_sample + UNet fwd/bwd + grad all-reduce + clip + Adam + EMA), summed over GPUs",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+                "config": {"workload": f"DDPM CIFAR10 32x32 training step, default UNet, batch {B} per GPU, dropout 0.1", "global_batch": B * world,
+                           "parallelism": f"dp{world} (RCCL mean all-reduce of the flat fp32 gradient)"}, "final_loss": round(loss, 5)}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     model = dmme_amd.UNet(precision=args.precision).to(dev).eval()
     if args.mode == "ddim":
         proc = dmme_amd.DDIM(model, T, 50).to(dev)
@@ -226,6 +276,11 @@ def main():
         "train_images_per_s": None,
         "launches_per_step": int(model._last_plan.lib.dmme_unet_plan_num_launches(model._last_plan.h)) + 2,
     }
+    if args.train_steps > 0:
+        del x
+        dt_tr, _ = train_leg(dmme_amd, dev, B, args.precision, args.train_steps, 2, dist)
+        out["train_images_per_s"] = round(world * args.train_steps * B / dt_tr, 1)
+        out["train_ms_per_step"] = round(1e3 * dt_tr / args.train_steps, 2)
     if rank == 0:
         if not args.no_roofline:
             xin = dmme_amd.gaussian((B, 3, 32, 32), device=dev)

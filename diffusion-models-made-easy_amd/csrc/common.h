@@ -180,6 +180,9 @@ int launch_mse(const float* eps, const float* target, int64_t numel, float* loss
 
 // ---- backward (kernels_bwd.hip) ----
 int launch_wgrad_generic(int dtype, const ConvArgs& a, const void* dY, float* dW, hipStream_t s);
+// MFMA weight gradient (wgrad_mfma.hip); scratch: Cout*taps*Cin floats
+bool wgrad_mfma_supported(int dtype, const ConvArgs& a);
+int launch_wgrad_mfma(int dtype, const ConvArgs& a, const void* dY, float* scratch, float* dW, hipStream_t s);
 int launch_colsum(int dtype, const void* dY, int N, int HW, int C, float* rowsum, float* dbias, float* dtproj, int ld, int nt,
                   hipStream_t s);
 int launch_gn_bwd_generic(int dtype, const void* dv, const void* x1, const void* x2, int N, int HW, int C1, int C2, int groups,

@@ -19,48 +19,50 @@ __device__ __forceinline__ float silu_grad(float u) {
 // dW[co][ci][kh][kw] += sum_{n,oy,ox} dY[n,oy,ox,co] * v[n, oy*s-pad+kh, ox*s-pad+kw, ci]
 // with v = act(x) recomputed through the forward prologue.  One thread per weight element.
 template <typename T>
-__global__ void __launch_bounds__(256) wgrad_generic_kernel(ConvArgs a, const T* __restrict__ dY, float* __restrict__ dW) {
+__global__ void __launch_bounds__(256) wgrad_generic_kernel(ConvArgs a, const T* __restrict__ dY, float* __restrict__ dW, int rows_per_chunk) {
     const int Cin = a.C1 + a.C2;
     const int64_t total = (int64_t)a.Cout * a.taps * Cin;
     const int Hv = a.up ? 2 * a.Hin : a.Hin, Wv = a.up ? 2 * a.Win : a.Win;
     const int k = a.taps == 9 ? 3 : 1, pad = a.taps == 9 ? 1 : 0;
+    // blockIdx.y selects a chunk of (n, oy) output rows; partial sums are merged with atomics
+    const int row_begin = blockIdx.y * rows_per_chunk;
+    const int row_end = min(row_begin + rows_per_chunk, a.N * a.Hout);
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int ci = (int)(idx % Cin);
         const int tap = (int)((idx / Cin) % a.taps);
         const int co = (int)(idx / ((int64_t)Cin * a.taps));
         const int kh = tap / k, kw = tap % k;
         float acc = 0.f;
-        for (int n = 0; n < a.N; ++n) {
+        for (int row = row_begin; row < row_end; ++row) {
+            const int n = row / a.Hout, oy = row % a.Hout;
+            const int iy = oy * a.stride - pad + kh;
+            if (iy < 0 || iy >= Hv) continue;
+            const int sy = a.up ? (iy >> 1) : iy;
             float sc = 1.f, sh = 0.f, dm = 1.f;
             if (a.scale) {
                 sc = a.scale[(int64_t)n * Cin + ci];
                 sh = a.shift[(int64_t)n * Cin + ci];
             }
             if (a.dmask) dm = a.dmask[(int64_t)n * Cin + ci];
-            for (int oy = 0; oy < a.Hout; ++oy) {
-                const int iy = oy * a.stride - pad + kh;
-                if (iy < 0 || iy >= Hv) continue;
-                const int sy = a.up ? (iy >> 1) : iy;
-                for (int ox = 0; ox < a.Wout; ++ox) {
-                    const int ix = ox * a.stride - pad + kw;
-                    if (ix < 0 || ix >= Wv) continue;
-                    const int sx = a.up ? (ix >> 1) : ix;
-                    float v;
-                    if (a.in_nchw)
-                        v = ((const float*)a.src1)[(((int64_t)n * a.C1 + ci) * a.Hin + sy) * a.Win + sx];
-                    else {
-                        const int64_t pix = ((int64_t)n * a.Hin + sy) * a.Win + sx;
-                        v = ci < a.C1 ? to_f(((const T*)a.src1)[pix * a.C1 + ci]) : to_f(((const T*)a.src2)[pix * a.C2 + (ci - a.C1)]);
-                    }
-                    if (a.scale) v = fmaf(v, sc, sh);
-                    if (a.pro_silu) v = silu_f(v);
-                    if (a.dmask) v *= dm;
-                    if (!a.in_nchw) v = to_f(from_f<T>(v));
-                    acc = fmaf(to_f(dY[(((int64_t)n * a.Hout + oy) * a.Wout + ox) * a.Cout + co]), v, acc);
+            for (int ox = 0; ox < a.Wout; ++ox) {
+                const int ix = ox * a.stride - pad + kw;
+                if (ix < 0 || ix >= Wv) continue;
+                const int sx = a.up ? (ix >> 1) : ix;
+                float v;
+                if (a.in_nchw)
+                    v = ((const float*)a.src1)[(((int64_t)n * a.C1 + ci) * a.Hin + sy) * a.Win + sx];
+                else {
+                    const int64_t pix = ((int64_t)n * a.Hin + sy) * a.Win + sx;
+                    v = ci < a.C1 ? to_f(((const T*)a.src1)[pix * a.C1 + ci]) : to_f(((const T*)a.src2)[pix * a.C2 + (ci - a.C1)]);
                 }
+                if (a.scale) v = fmaf(v, sc, sh);
+                if (a.pro_silu) v = silu_f(v);
+                if (a.dmask) v *= dm;
+                if (!a.in_nchw) v = to_f(from_f<T>(v));
+                acc = fmaf(to_f(dY[(((int64_t)n * a.Hout + oy) * a.Wout + ox) * a.Cout + co]), v, acc);
             }
         }
-        dW[((int64_t)co * Cin + ci) * a.taps + tap] += acc;
+        atomicAdd(&dW[((int64_t)co * Cin + ci) * a.taps + tap], acc);
     }
 }
 
@@ -68,10 +70,18 @@ int launch_wgrad_generic(int dtype, const ConvArgs& a, const void* dY, float* dW
     const int64_t total = (int64_t)a.Cout * a.taps * (a.C1 + a.C2);
     int64_t blocks = (total + 255) / 256;
     if (blocks > 65536) blocks = 65536;
+    // split the pixel loop so that small-weight convs (first / last layer) still fill the GPU
+    const int rows = a.N * a.Hout;
+    int chunks = (int)((4096 + blocks - 1) / blocks);
+    if (chunks > rows) chunks = rows;
+    if (chunks < 1) chunks = 1;
+    const int rpc = (rows + chunks - 1) / chunks;
+    chunks = (rows + rpc - 1) / rpc;
+    dim3 grid((unsigned)blocks, (unsigned)chunks);
     if (dtype == DMME_BF16)
-        hipLaunchKernelGGL(wgrad_generic_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, s, a, (const bf16*)dY, dW);
+        hipLaunchKernelGGL(wgrad_generic_kernel<bf16>, grid, dim3(256), 0, s, a, (const bf16*)dY, dW, rpc);
     else
-        hipLaunchKernelGGL(wgrad_generic_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, a, (const float*)dY, dW);
+        hipLaunchKernelGGL(wgrad_generic_kernel<float>, grid, dim3(256), 0, s, a, (const float*)dY, dW, rpc);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }

@@ -89,6 +89,7 @@ struct dmme_plan {
     int p_l1w = -1, p_l1b = -1, p_l2w = -1, p_l2b = -1;
     int64_t packed_bwd_bytes = 0, bws_bytes = 0;
     std::vector<int64_t> gt_off;           // gradient buffer of every forward tensor
+    int64_t bws_wscratch = 0;
     int64_t bws_tmp = 0, bws_dy = 0, bws_rowsum = 0, bws_dtproj = 0, bws_dtemb = 0, bws_dh1 = 0, bws_z = 0, bws_attP = 0,
             bws_attdS = 0;
     PackItem* items_bwd_dev = nullptr;
@@ -479,6 +480,12 @@ int build_plan(dmme_plan* P) {
                 const int64_t b = (int64_t)B * q.H * q.W * q.H * q.W * 4;
                 if (b > att_max) att_max = b;
             }
+        }
+        {
+            int64_t wmax = 0;
+            for (const Param& p : P->params)
+                if (p.ndim == 4 && p.numel() > wmax) wmax = p.numel();
+            P->bws_wscratch = balloc(wmax * 4);
         }
         P->bws_tmp = balloc(tmp_max);
         P->bws_dy = balloc((int64_t)B * P->H * P->W * c.in_channels * es);
@@ -902,7 +909,10 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
                            o.tproj_col >= 0 ? dtproj + o.tproj_col : nullptr, P->tproj_cols, nt, s);
         if (rc != DMME_OK) break;
         // 2. weight gradient (reference layout, accumulated)
-        rc = launch_wgrad_generic(dt, a, dy, grad_flat + P->params[o.w].ref_off, s);
+        if (wgrad_mfma_supported(dt, a))
+            rc = launch_wgrad_mfma(dt, a, dy, (float*)(bws + P->bws_wscratch), grad_flat + P->params[o.w].ref_off, s);
+        else
+            rc = launch_wgrad_generic(dt, a, dy, grad_flat + P->params[o.w].ref_off, s);
         if (rc != DMME_OK) break;
         // 3. data gradient: the forward kernel on dY with transposed, tap-flipped weights
         if (o.src1 >= 0) {

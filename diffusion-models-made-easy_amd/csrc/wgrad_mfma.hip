@@ -1,0 +1,246 @@
+// Weight gradient of the 3x3 / 1x1 convolutions on the matrix cores.
+//
+//   dW[co][tap][ci] = sum over pixels p of  dY[p][co] * v[p*stride + tap][ci],   v = act(x)
+//
+// i.e. a GEMM whose reduction dimension is the PIXEL index: M = Cout, N = Cin, K = N*H*W.
+// Both operands are NHWC, so K is the strided dimension of both; the fragments are therefore
+// read TRANSPOSED out of row-major [pixel][channel] LDS tiles:
+//   bf16: ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group, two reads per
+//         32x32x16 fragment) for dY^T (A operand) and for the shifted activation tile (B);
+//   fp32: v_mfma_f32_32x32x2_f32 takes one element per lane with the channel on the lane,
+//         so plain ds_read_b32 of the same tiles already is the transposed view.
+// One workgroup = 128 couts x 64 cins x one kernel ROW (3 taps: the three kw shifts reuse the
+// dY fragments) x a strided subset of the 64-pixel tiles; the activation halo rows of that
+// kernel row are staged with the forward prologue (GroupNorm affine + SiLU + Dropout2d mask)
+// applied on the way, exactly like the forward kernel.  Partial sums go out with fp32
+// atomics into a packed [co][tap][ci] image (ci contiguous across lanes: full-rate
+// atomics); a small kernel folds it into the reference-layout gradient buffer.
+#include <stdio.h>
+
+#include "conv_common.h"
+
+namespace dmme {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int WG_CO = 128, WG_CI = 64, WG_PX = 64;
+
+template <typename T>
+struct WgGeom {
+    // LDS row pitches chosen so the 4 rows of a transposed read land on disjoint bank ranges
+    static constexpr int DY_PITCH = sizeof(T) == 2 ? 320 : 512;  // 128 couts
+    static constexpr int V_PITCH = sizeof(T) == 2 ? 192 : 256;   // 64 cins
+};
+
+template <typename T, int KW>
+__global__ void __launch_bounds__(256) wgrad_mfma_kernel(ConvArgs a, ConvTile g, const T* __restrict__ dY, float* __restrict__ dWp,
+                                                         int nsplit, int shTW, int shTH) {
+    constexpr int EPV = Frag<T>::EPV;
+    constexpr int DYP = WgGeom<T>::DY_PITCH, VP = WgGeom<T>::V_PITCH;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* ldsY = lds;                 // [64 px][128 co]
+    char* ldsV = lds + WG_PX * DYP;   // [TN*TH rows x HWd px][64 ci]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wco = (wave >> 1) * 64, wci = (wave & 1) * 32;
+    const int r = lane & 31, h = lane >> 5;
+    const int Cin = a.C1 + a.C2;
+    const int n_ci = Cin / WG_CI, n_co = (a.Cout + WG_CO - 1) / WG_CO, n_kh = KW == 3 ? 3 : 1;
+    int b = blockIdx.x;
+    const int split = b % nsplit; b /= nsplit;
+    const int kh = b % n_kh; b /= n_kh;
+    const int cit = b % n_ci; b /= n_ci;
+    const int cot = b;
+    (void)n_co;
+    const int co0 = cot * WG_CO, ci0 = cit * WG_CI;
+    const int PAD = KW == 3 ? 1 : 0;
+    const int Hv = a.up ? 2 * a.Hin : a.Hin, Wv = a.up ? 2 * a.Win : a.Win;
+    const int mTW = (1 << shTW) - 1, mTH = (1 << shTH) - 1;
+    const int v_rows = g.TN * g.TH * g.HWd;  // halo pixels of ONE kernel row
+    const bool second = ci0 >= a.C1;
+    const T* sbase = second ? (const T*)a.src2 : (const T*)a.src1;
+    const int Cs = second ? a.C2 : a.C1, cs0 = second ? ci0 - a.C1 : ci0;
+
+    f32x16 acc[KW][2];
+#pragma unroll
+    for (int k = 0; k < KW; ++k)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[k][mi][j] = 0.f;
+
+    // transposed-read lane roles (bf16): 16-lane group gq, lane i = 4*q + p inside it
+    const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g1 = (lane >> 4) & 1;
+
+    for (int tile = split; tile < g.tiles_m; tile += nsplit) {
+        const int tx_blk = tile % g.tiles_x, ty_blk = (tile / g.tiles_x) % g.tiles_y;
+        const int n0 = (tile / (g.tiles_x * g.tiles_y)) * g.TN;
+        const int oy0 = ty_blk << shTH, ox0 = tx_blk << shTW;
+        __syncthreads();
+        // ---- stage dY tile: 64 pixels x 128 couts ----
+        for (int u = tid; u < WG_PX * (WG_CO / EPV); u += 256) {
+            const int m = u / (WG_CO / EPV), cu = u % (WG_CO / EPV);
+            const int tx = m & mTW, ty = (m >> shTW) & mTH, tn = m >> (shTW + shTH);
+            const int n = n0 + tn, co = co0 + cu * EPV;
+            uint4 val = make_uint4(0u, 0u, 0u, 0u);
+            if (n < a.N && co < a.Cout)
+                val = *reinterpret_cast<const uint4*>(dY + (((int64_t)n * a.Hout + oy0 + ty) * a.Wout + ox0 + tx) * a.Cout + co);
+            *reinterpret_cast<uint4*>(ldsY + m * DYP + cu * 16) = val;
+        }
+        // ---- stage the activation rows of this kernel row: (tn, ty) x HWd pixels x 64 cins, prologue applied ----
+        for (int u = tid; u < v_rows * (WG_CI / EPV); u += 256) {
+            const int row = u / (WG_CI / EPV), cu = u % (WG_CI / EPV);
+            const int hx = row % g.HWd, ty = (row / g.HWd) & mTH, tn = row / (g.HWd << shTH);
+            const int n = n0 + tn, iy = (oy0 + ty) * a.stride - PAD + kh, ix = ox0 * a.stride - PAD + hx;
+            uint4 val = make_uint4(0u, 0u, 0u, 0u);
+            if (n < a.N && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) {
+                const int sy = a.up ? (iy >> 1) : iy, sx = a.up ? (ix >> 1) : ix;
+                val = *reinterpret_cast<const uint4*>(sbase + (((int64_t)n * a.Hin + sy) * a.Win + sx) * Cs + cs0 + cu * EPV);
+                const int64_t so = (int64_t)n * Cin + ci0 + cu * EPV;
+                val = prologue_vec<T>(val, a.scale ? a.scale + so : nullptr, a.scale ? a.shift + so : nullptr,
+                                      a.dmask ? a.dmask + so : nullptr, a.pro_silu);
+            }
+            *reinterpret_cast<uint4*>(ldsV + row * VP + cu * 16) = val;
+        }
+        __syncthreads();
+        if constexpr (sizeof(T) == 2) {
+            // ---- bf16: k-steps of 16 pixels; lane half h owns pixels 8h..8h+7 of the step (two 4-pixel blocks) ----
+#pragma unroll
+            for (int ks = 0; ks < WG_PX / 16; ++ks) {
+                s16x8 af[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    const int colb = (wco + mi * 32 + 16 * tr_g1 + 4 * tr_p) * 2;
+                    const char* p0 = ldsY + (16 * ks + 8 * h + tr_q) * DYP + colb;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 4 * DYP));
+                    af[mi][0] = lo[0]; af[mi][1] = lo[1]; af[mi][2] = lo[2]; af[mi][3] = lo[3];
+                    af[mi][4] = hi[0]; af[mi][5] = hi[1]; af[mi][6] = hi[2]; af[mi][7] = hi[3];
+                }
+                // halo row of the first pixel of each 4-pixel block (blocks never straddle a tile row: 4 | TW)
+                int vrow[2];
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int m = 16 * ks + 8 * h + 4 * half + tr_q;
+                    const int tx = m & mTW, tyn = m >> shTW;  // tyn = tn*TH + ty
+                    vrow[half] = tyn * g.HWd + tx * a.stride;
+                }
+#pragma unroll
+                for (int kw = 0; kw < KW; ++kw) {
+                    const int colb = (wci + 16 * tr_g1 + 4 * tr_p) * 2;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ldsV + (vrow[0] + kw) * VP + colb));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ldsV + (vrow[1] + kw) * VP + colb));
+                    s16x8 bfr;
+                    bfr[0] = lo[0]; bfr[1] = lo[1]; bfr[2] = lo[2]; bfr[3] = lo[3];
+                    bfr[4] = hi[0]; bfr[5] = hi[1]; bfr[6] = hi[2]; bfr[7] = hi[3];
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+                        acc[kw][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mi]), __builtin_bit_cast(bf16x8, bfr),
+                                                                               acc[kw][mi], 0, 0, 0);
+                }
+            }
+        } else {
+            // ---- fp32: k-steps of 2 pixels; lane half h owns pixel 2*ks + h; channel on the lane ----
+#pragma unroll 4
+            for (int ks = 0; ks < WG_PX / 2; ++ks) {
+                const int m = 2 * ks + h;
+                const int tx = m & mTW, tyn = m >> shTW;
+                const int vrow = tyn * g.HWd + tx * a.stride;
+                float af[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) af[mi] = *reinterpret_cast<const float*>(ldsY + m * DYP + (wco + mi * 32 + r) * 4);
+#pragma unroll
+                for (int kw = 0; kw < KW; ++kw) {
+                    const float bv = *reinterpret_cast<const float*>(ldsV + (vrow + kw) * VP + (wci + r) * 4);
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) acc[kw][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bv, acc[kw][mi], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- partial sums out: D[row = co][col = ci]; lane = ci column, registers = co rows ----
+    const int ci = ci0 + wci + r;
+#pragma unroll
+    for (int kw = 0; kw < KW; ++kw) {
+        const int tap = kh * KW + kw;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int co = co0 + wco + mi * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+                if (co < a.Cout) atomicAdd(dWp + ((int64_t)co * a.taps + tap) * Cin + ci, acc[kw][mi][j]);
+            }
+        }
+    }
+}
+
+// dW_ref[(co*Cin + ci)*taps + tap] += dWp[(co*taps + tap)*Cin + ci]
+__global__ void __launch_bounds__(256) wgrad_unpack_kernel(const float* __restrict__ dWp, float* __restrict__ dW, int Cin, int taps, int64_t total) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int tap = (int)(e % taps);
+        const int64_t q = e / taps;
+        const int ci = (int)(q % Cin);
+        const int64_t co = q / Cin;
+        dW[e] += dWp[(co * taps + tap) * Cin + ci];
+    }
+}
+
+static bool wg_tile(const ConvArgs& a, ConvTile& g) {
+    if (!make_tile(a, WG_PX, 64, g)) return false;
+    if (g.TW < 4) return false;  // 4-pixel transposed-read blocks must stay inside one tile row
+    return true;
+}
+
+bool wgrad_mfma_supported(int dtype, const ConvArgs& a) {
+    const int KC = dtype == DMME_BF16 ? 64 : 32;
+    (void)KC;
+    if (a.in_nchw) return false;
+    if (a.taps != 9 && a.taps != 1) return false;
+    if (a.taps == 1 && (a.stride != 1 || a.up)) return false;
+    if (a.up == 2) return false;
+    if (a.C1 % WG_CI || a.C2 % WG_CI || a.C1 == 0) return false;
+    if (a.Cout % 32) return false;
+    ConvTile g;
+    if (!wg_tile(a, g)) return false;
+    const size_t lds = (size_t)WG_PX * (dtype == DMME_BF16 ? 320 : 512) + (size_t)g.TN * g.TH * g.HWd * (dtype == DMME_BF16 ? 192 : 256);
+    return lds <= 64 * 1024;
+}
+
+size_t wgrad_scratch_floats(const ConvArgs& a) { return (size_t)a.Cout * a.taps * (a.C1 + a.C2); }
+
+template <typename T>
+static int launch_wgrad_t(const ConvArgs& a, const void* dY, float* dWp, float* dW, hipStream_t s) {
+    ConvTile g{};
+    DMME_REQUIRE(wg_tile(a, g), DMME_ERR_UNSUPPORTED, "wgrad_mfma: no tile");
+    const int Cin = a.C1 + a.C2;
+    const int n_ci = Cin / WG_CI, n_co = (a.Cout + WG_CO - 1) / WG_CO, n_kh = a.taps == 9 ? 3 : 1;
+    const int base = n_ci * n_co * n_kh;
+    int nsplit = 768 / base;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > g.tiles_m) nsplit = g.tiles_m;
+    const int64_t total = (int64_t)a.Cout * a.taps * Cin;
+    DMME_CHECK_HIP(hipMemsetAsync(dWp, 0, (size_t)total * sizeof(float), s));
+    int shTW = 0, shTH = 0;
+    while ((1 << shTW) < g.TW) ++shTW;
+    while ((1 << shTH) < g.TH) ++shTH;
+    const size_t lds = (size_t)WG_PX * WgGeom<T>::DY_PITCH + (size_t)g.TN * g.TH * g.HWd * WgGeom<T>::V_PITCH;
+    const dim3 grid((unsigned)(base * nsplit));
+    if (a.taps == 9)
+        hipLaunchKernelGGL((wgrad_mfma_kernel<T, 3>), grid, dim3(256), lds, s, a, g, (const T*)dY, dWp, nsplit, shTW, shTH);
+    else
+        hipLaunchKernelGGL((wgrad_mfma_kernel<T, 1>), grid, dim3(256), lds, s, a, g, (const T*)dY, dWp, nsplit, shTW, shTH);
+    DMME_CHECK_LAUNCH();
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad_unpack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dWp, dW, Cin, a.taps, total);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+int launch_wgrad_mfma(int dtype, const ConvArgs& a, const void* dY, float* scratch, float* dW, hipStream_t s) {
+    DMME_REQUIRE(wgrad_mfma_supported(dtype, a), DMME_ERR_UNSUPPORTED, "wgrad_mfma: unsupported shape");
+    return dtype == DMME_BF16 ? launch_wgrad_t<bf16>(a, dY, scratch, dW, s) : launch_wgrad_t<float>(a, dY, scratch, dW, s);
+}
+
+}  // namespace dmme

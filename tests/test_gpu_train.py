@@ -156,3 +156,24 @@ def test_train_loop_tiny_matches_oracle_two_steps():
         np.testing.assert_allclose(loss.item(), want.item(), rtol=2e-5)
     for k, p in net.named_parameters():
         np.testing.assert_allclose(p.detach().cpu().numpy(), sd[k].detach().numpy(), atol=3e-5, rtol=1e-4, err_msg=k)
+
+
+def test_bf16_train_step_close_to_fp32():
+    """bf16 compute path (MFMA wgrad with transposed LDS reads): gradients track the fp32 path."""
+    import dmme_amd
+
+    cfg = O.UNetConfig(channels_per_depth=(64, 128), num_blocks=1, attention_depths=(2,), emb_dim=128, pos_dim=32)
+    grads = {}
+    for prec in ("fp32", "bf16"):
+        net = _build(cfg, 3, prec).eval()
+        ddpm = dmme_amd.DDPM(net, 1000).cuda()
+        loss = ddpm.training_step(synth.uniform(1, (4, 3, 32, 32)).cuda(), t=torch.tensor([5, 300, 700, 999]).cuda(), noise=synth.normal(2, (4, 3, 32, 32)).cuda())
+        loss.backward()
+        grads[prec] = {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()}
+    worst = 0.0
+    for k in grads["fp32"]:
+        a, b = grads["fp32"][k], grads["bf16"][k]
+        rel = ((a - b).norm() / (a.norm() + 1e-12)).item()
+        worst = max(worst, rel)
+        assert rel < 0.08, (k, rel)
+    print("worst relative gradient error bf16 vs fp32:", worst)

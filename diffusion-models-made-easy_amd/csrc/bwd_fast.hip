@@ -1,0 +1,320 @@
+// Coalesced, HBM-bound backward helpers for NHWC tensors (16-byte loads, every element read
+// once per pass): per-(image, channel) column sums of dY (bias / time-embedding gradients) and
+// the GroupNorm(+SiLU+Dropout2d) backward split into
+//   pass A  per-(n, c) sums  A = sum_p du,  B = sum_p du*xhat            (du = dv*mask*silu'(u))
+//   finalize S1[n,g] = sum_{c in g} gamma_c A,  S2 = sum gamma_c B;  dgamma_c += sum_n B, dbeta_c += sum_n A
+//   pass B  dx = rstd * (du*gamma - (S1 + xhat*S2)/cnt)                  (elementwise)
+// The group sums follow from the channel sums, so no per-group reduction over pixels is needed.
+#include "common.h"
+
+namespace dmme {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T>
+__device__ __forceinline__ void load_vec(const T* p, float (&v)[16 / sizeof(T)]) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(p);
+    if constexpr (sizeof(T) == 4) {
+        const float4 f = __builtin_bit_cast(float4, raw);
+        v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+    } else {
+        const bf16x8 b = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)b[j];
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store_vec(T* p, const float (&v)[16 / sizeof(T)]) {
+    if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        bf16x8 b;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = (bf16)v[j];
+        *reinterpret_cast<bf16x8*>(p) = b;
+    }
+}
+
+__device__ __forceinline__ float silu_grad_f(float u) {
+    const float s = 1.0f / (1.0f + expf(-u));
+    return s * (1.0f + u * (1.0f - s));
+}
+
+// geometry shared by the kernels: a workgroup owns `chunk_px` pixels of one image, thread -> fixed
+// 16-byte channel slot (tid % VPP) and pixel row phase (tid / VPP)
+static bool vec_geometry(int dtype, int HW, int C, int& chunk_px, int& nchunks) {
+    const int EPV = dtype == DMME_BF16 ? 8 : 4;
+    if (C % EPV) return false;
+    const int VPP = C / EPV;
+    if (VPP > 256 || 256 % VPP) return false;
+    const int ppw = 256 / VPP;
+    if (HW % ppw) return false;
+    int sweeps = HW / ppw;
+    if (sweeps > 16) sweeps = 16;
+    while (sweeps > 1 && (HW / ppw) % sweeps) --sweeps;
+    chunk_px = sweeps * ppw;
+    nchunks = HW / chunk_px;
+    return true;
+}
+
+// ------------------------------------------------------------------ column sums
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_vec_kernel(const T* __restrict__ dY, int HW, int C, int chunk_px, float* __restrict__ rowsum) {
+    constexpr int EPV = 16 / sizeof(T);
+    __shared__ float red[256 * EPV];
+    const int tid = threadIdx.x, VPP = C / EPV, slot = tid % VPP, prow = tid / VPP, ppw = 256 / VPP;
+    const int n = blockIdx.y;
+    const int64_t p0 = (int64_t)n * HW + (int64_t)blockIdx.x * chunk_px;
+    float acc[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) acc[j] = 0.f;
+    for (int p = prow; p < chunk_px; p += ppw) {
+        float v[EPV];
+        load_vec<T>(dY + (p0 + p) * C + slot * EPV, v);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) acc[j] += v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) red[tid * EPV + j] = acc[j];
+    __syncthreads();
+    if (tid < VPP) {
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+            float s = 0.f;
+            for (int r = 0; r < ppw; ++r) s += red[(r * VPP + tid) * EPV + j];
+            atomicAdd(&rowsum[(int64_t)n * C + tid * EPV + j], s);
+        }
+    }
+}
+
+// dbias[c] += sum_n rowsum[n][c];  d_tproj rows (per image, or the single broadcast row)
+__global__ void __launch_bounds__(256) bias_tproj_fast_kernel(const float* __restrict__ rowsum, int N, int C, float* __restrict__ dbias,
+                                                              float* __restrict__ dtproj, int ld, int nt) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    int n = 0;
+    for (; n + 3 < N; n += 4) {
+        const float a = rowsum[(int64_t)n * C + c], b = rowsum[(int64_t)(n + 1) * C + c], d = rowsum[(int64_t)(n + 2) * C + c],
+                    e = rowsum[(int64_t)(n + 3) * C + c];
+        t0 += a; t1 += b; t2 += d; t3 += e;
+        if (dtproj && nt > 1) {
+            dtproj[(int64_t)n * ld + c] = a;
+            dtproj[(int64_t)(n + 1) * ld + c] = b;
+            dtproj[(int64_t)(n + 2) * ld + c] = d;
+            dtproj[(int64_t)(n + 3) * ld + c] = e;
+        }
+    }
+    for (; n < N; ++n) {
+        const float a = rowsum[(int64_t)n * C + c];
+        t0 += a;
+        if (dtproj && nt > 1) dtproj[(int64_t)n * ld + c] = a;
+    }
+    const float tot = (t0 + t1) + (t2 + t3);
+    if (dbias) dbias[c] += tot;
+    if (dtproj && nt == 1) dtproj[c] = tot;
+}
+
+bool colsum_fast_supported(int dtype, int HW, int C) {
+    int a, b;
+    return vec_geometry(dtype, HW, C, a, b);
+}
+
+int launch_colsum_fast(int dtype, const void* dY, int N, int HW, int C, float* rowsum, float* dbias, float* dtproj, int ld, int nt,
+                       hipStream_t s) {
+    int chunk_px, nchunks;
+    DMME_REQUIRE(vec_geometry(dtype, HW, C, chunk_px, nchunks), DMME_ERR_UNSUPPORTED, "colsum_fast: unsupported geometry");
+    DMME_CHECK_HIP(hipMemsetAsync(rowsum, 0, (size_t)N * C * sizeof(float), s));
+    dim3 grid(nchunks, N);
+    if (dtype == DMME_BF16)
+        hipLaunchKernelGGL(colsum_vec_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dY, HW, C, chunk_px, rowsum);
+    else
+        hipLaunchKernelGGL(colsum_vec_kernel<float>, grid, dim3(256), 0, s, (const float*)dY, HW, C, chunk_px, rowsum);
+    DMME_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bias_tproj_fast_kernel, dim3((C + 255) / 256), dim3(256), 0, s, rowsum, N, C, dbias, dtproj, ld, nt);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+// ------------------------------------------------------------------ GroupNorm backward, pass A
+template <typename T>
+__global__ void __launch_bounds__(256) gn_bwd_sums_kernel(const T* __restrict__ dv, const T* __restrict__ x1, const T* __restrict__ x2, int HW,
+                                                          int C1, int C2, int groups, const float* __restrict__ mean_rstd,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          const float* __restrict__ dmask, int pro_silu, int chunk_px,
+                                                          float* __restrict__ AB /* [N][C][2] */) {
+    constexpr int EPV = 16 / sizeof(T);
+    __shared__ float red[256 * EPV * 2];
+    const int C = C1 + C2, tid = threadIdx.x, VPP = C / EPV, slot = tid % VPP, prow = tid / VPP, ppw = 256 / VPP;
+    const int n = blockIdx.y, c0 = slot * EPV, cg = C / groups;
+    const bool second = c0 >= C1;
+    const T* xs = second ? x2 : x1;
+    const int Cs = second ? C2 : C1, cs0 = second ? c0 - C1 : c0;
+    const int64_t p0 = (int64_t)n * HW + (int64_t)blockIdx.x * chunk_px;
+    float sc[EPV], sh[EPV], dm[EPV], mu[EPV], rs[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+        const int c = c0 + j;
+        sc[j] = scale[(int64_t)n * C + c];
+        sh[j] = shift[(int64_t)n * C + c];
+        dm[j] = dmask ? dmask[(int64_t)n * C + c] : 1.0f;
+        mu[j] = mean_rstd[((int64_t)n * groups + c / cg) * 2];
+        rs[j] = mean_rstd[((int64_t)n * groups + c / cg) * 2 + 1];
+    }
+    float a[EPV], b[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) a[j] = b[j] = 0.f;
+    for (int p = prow; p < chunk_px; p += ppw) {
+        float d[EPV], xv[EPV];
+        load_vec<T>(dv + (p0 + p) * C + c0, d);
+        load_vec<T>(xs + (p0 + p) * Cs + cs0, xv);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+            float du = d[j] * dm[j];
+            if (pro_silu) du *= silu_grad_f(fmaf(xv[j], sc[j], sh[j]));
+            a[j] += du;
+            b[j] = fmaf(du, (xv[j] - mu[j]) * rs[j], b[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+        red[(tid * EPV + j) * 2] = a[j];
+        red[(tid * EPV + j) * 2 + 1] = b[j];
+    }
+    __syncthreads();
+    if (tid < VPP) {
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+            float sa = 0.f, sb = 0.f;
+            for (int r = 0; r < ppw; ++r) {
+                sa += red[((r * VPP + tid) * EPV + j) * 2];
+                sb += red[((r * VPP + tid) * EPV + j) * 2 + 1];
+            }
+            atomicAdd(&AB[((int64_t)n * C + tid * EPV + j) * 2], sa);
+            atomicAdd(&AB[((int64_t)n * C + tid * EPV + j) * 2 + 1], sb);
+        }
+    }
+}
+
+// finalize: S[n][g] = {sum gamma A, sum gamma B};  dgamma_c += sum_n B, dbeta_c += sum_n A
+__global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __restrict__ AB, int N, int C, int groups,
+                                                              const float* __restrict__ gamma, float* __restrict__ S,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int cg = C / groups;
+    if (i < N * groups) {
+        const int n = i / groups, g = i % groups;
+        float s1 = 0.f, s2 = 0.f;
+        for (int j = 0; j < cg; ++j) {
+            const int c = g * cg + j;
+            s1 = fmaf(gamma[c], AB[((int64_t)n * C + c) * 2], s1);
+            s2 = fmaf(gamma[c], AB[((int64_t)n * C + c) * 2 + 1], s2);
+        }
+        S[(int64_t)i * 2] = s1;
+        S[(int64_t)i * 2 + 1] = s2;
+    }
+    if (i < C) {
+        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+        int n = 0;
+        for (; n + 1 < N; n += 2) {
+            a0 += AB[((int64_t)n * C + i) * 2];
+            b0 += AB[((int64_t)n * C + i) * 2 + 1];
+            a1 += AB[((int64_t)(n + 1) * C + i) * 2];
+            b1 += AB[((int64_t)(n + 1) * C + i) * 2 + 1];
+        }
+        if (n < N) {
+            a0 += AB[((int64_t)n * C + i) * 2];
+            b0 += AB[((int64_t)n * C + i) * 2 + 1];
+        }
+        dbeta[i] += a0 + a1;
+        dgamma[i] += b0 + b1;
+    }
+}
+
+// pass B: dx, split over the two concatenated destinations, write or accumulate
+template <typename T>
+__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__ dv, const T* __restrict__ x1, const T* __restrict__ x2, int HW,
+                                                           int C1, int C2, int groups, const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean_rstd, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ dmask, int pro_silu,
+                                                           const float* __restrict__ S, int chunk_px, T* __restrict__ dx1, T* __restrict__ dx2,
+                                                           int acc1, int acc2) {
+    constexpr int EPV = 16 / sizeof(T);
+    const int C = C1 + C2, tid = threadIdx.x, VPP = C / EPV, slot = tid % VPP, prow = tid / VPP, ppw = 256 / VPP;
+    const int n = blockIdx.y, c0 = slot * EPV, cg = C / groups;
+    const bool second = c0 >= C1;
+    const T* xs = second ? x2 : x1;
+    T* dst = second ? dx2 : dx1;
+    const int acc = second ? acc2 : acc1;
+    const int Cs = second ? C2 : C1, cs0 = second ? c0 - C1 : c0;
+    const int64_t p0 = (int64_t)n * HW + (int64_t)blockIdx.x * chunk_px;
+    const float inv = 1.0f / (float)((int64_t)cg * HW);
+    float sc[EPV], sh[EPV], dm[EPV], mu[EPV], rs[EPV], gm[EPV], k1[EPV], k2[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+        const int c = c0 + j, g = c / cg;
+        sc[j] = scale[(int64_t)n * C + c];
+        sh[j] = shift[(int64_t)n * C + c];
+        dm[j] = dmask ? dmask[(int64_t)n * C + c] : 1.0f;
+        mu[j] = mean_rstd[((int64_t)n * groups + g) * 2];
+        rs[j] = mean_rstd[((int64_t)n * groups + g) * 2 + 1];
+        gm[j] = gamma[c];
+        k1[j] = S[((int64_t)n * groups + g) * 2] * inv;
+        k2[j] = S[((int64_t)n * groups + g) * 2 + 1] * inv;
+    }
+    for (int p = prow; p < chunk_px; p += ppw) {
+        float d[EPV], xv[EPV], o[EPV];
+        load_vec<T>(dv + (p0 + p) * C + c0, d);
+        load_vec<T>(xs + (p0 + p) * Cs + cs0, xv);
+        if (acc) load_vec<T>(dst + (p0 + p) * Cs + cs0, o);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+            float du = d[j] * dm[j];
+            if (pro_silu) du *= silu_grad_f(fmaf(xv[j], sc[j], sh[j]));
+            const float xhat = (xv[j] - mu[j]) * rs[j];
+            const float dx = rs[j] * (du * gm[j] - (k1[j] + xhat * k2[j]));
+            o[j] = acc ? o[j] + dx : dx;
+        }
+        store_vec<T>(dst + (p0 + p) * Cs + cs0, o);
+    }
+}
+
+bool gn_bwd_fast_supported(int dtype, int HW, int C1, int C2) {
+    const int EPV = dtype == DMME_BF16 ? 8 : 4;
+    int a, b;
+    return (C1 % EPV) == 0 && vec_geometry(dtype, HW, C1 + C2, a, b);
+}
+
+// scratch: N*C*2 + N*groups*2 floats
+int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2, int N, int HW, int C1, int C2, int groups,
+                       const float* gamma, const float* mean_rstd, const float* scale, const float* shift, const float* dmask,
+                       int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, float* scratch,
+                       hipStream_t s) {
+    int chunk_px, nchunks;
+    const int C = C1 + C2;
+    DMME_REQUIRE(vec_geometry(dtype, HW, C, chunk_px, nchunks), DMME_ERR_UNSUPPORTED, "gn_bwd_fast: unsupported geometry");
+    float* AB = scratch;
+    float* S = scratch + (size_t)N * C * 2;
+    DMME_CHECK_HIP(hipMemsetAsync(AB, 0, (size_t)N * C * 2 * sizeof(float), s));
+    dim3 grid(nchunks, N);
+    if (dtype == DMME_BF16)
+        hipLaunchKernelGGL(gn_bwd_sums_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dv, (const bf16*)x1, (const bf16*)x2, HW, C1, C2, groups,
+                           mean_rstd, scale, shift, dmask, pro_silu, chunk_px, AB);
+    else
+        hipLaunchKernelGGL(gn_bwd_sums_kernel<float>, grid, dim3(256), 0, s, (const float*)dv, (const float*)x1, (const float*)x2, HW, C1, C2,
+                           groups, mean_rstd, scale, shift, dmask, pro_silu, chunk_px, AB);
+    DMME_CHECK_LAUNCH();
+    const int tot = N * groups > C ? N * groups : C;
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, AB, N, C, groups, gamma, S, dgamma, dbeta);
+    DMME_CHECK_LAUNCH();
+    if (dtype == DMME_BF16)
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dv, (const bf16*)x1, (const bf16*)x2, HW, C1, C2, groups,
+                           gamma, mean_rstd, scale, shift, dmask, pro_silu, S, chunk_px, (bf16*)dx1, (bf16*)dx2, acc1, acc2);
+    else
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)dv, (const float*)x1, (const float*)x2, HW, C1, C2,
+                           groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, S, chunk_px, (float*)dx1, (float*)dx2, acc1, acc2);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+}  // namespace dmme

@@ -188,6 +188,15 @@ int launch_colsum(int dtype, const void* dY, int N, int HW, int C, float* rowsum
 int launch_gn_bwd_generic(int dtype, const void* dv, const void* x1, const void* x2, int N, int HW, int C1, int C2, int groups,
                           const float* gamma, const float* mean_rstd, const float* scale, const float* shift, const float* dmask,
                           int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, hipStream_t s);
+// coalesced vector versions (bwd_fast.hip)
+bool colsum_fast_supported(int dtype, int HW, int C);
+int launch_colsum_fast(int dtype, const void* dY, int N, int HW, int C, float* rowsum, float* dbias, float* dtproj, int ld, int nt,
+                       hipStream_t s);
+bool gn_bwd_fast_supported(int dtype, int HW, int C1, int C2);
+int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2, int N, int HW, int C1, int C2, int groups,
+                       const float* gamma, const float* mean_rstd, const float* scale, const float* shift, const float* dmask,
+                       int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, float* scratch,
+                       hipStream_t s);
 int launch_grad_acc(int dtype, const void* src, void* d1, void* d2, int C1, int C2, int acc1, int acc2, int pool, int N, int H, int W,
                     hipStream_t s);
 int launch_attn_bwd_generic(int dtype, const void* qkv, const void* dO, int N, int S, int C, float* P, float* dS, void* dqkv, hipStream_t s);

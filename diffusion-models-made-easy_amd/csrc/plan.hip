@@ -89,7 +89,7 @@ struct dmme_plan {
     int p_l1w = -1, p_l1b = -1, p_l2w = -1, p_l2b = -1;
     int64_t packed_bwd_bytes = 0, bws_bytes = 0;
     std::vector<int64_t> gt_off;           // gradient buffer of every forward tensor
-    int64_t bws_wscratch = 0;
+    int64_t bws_wscratch = 0, bws_gnscratch = 0;
     int64_t bws_tmp = 0, bws_dy = 0, bws_rowsum = 0, bws_dtproj = 0, bws_dtemb = 0, bws_dh1 = 0, bws_z = 0, bws_attP = 0,
             bws_attdS = 0;
     PackItem* items_bwd_dev = nullptr;
@@ -487,6 +487,7 @@ int build_plan(dmme_plan* P) {
                 if (p.ndim == 4 && p.numel() > wmax) wmax = p.numel();
             P->bws_wscratch = balloc(wmax * 4);
         }
+        P->bws_gnscratch = balloc(((int64_t)B * 2 * cmax * 2 + (int64_t)B * c.num_groups * 2) * 4);
         P->bws_tmp = balloc(tmp_max);
         P->bws_dy = balloc((int64_t)B * P->H * P->W * c.in_channels * es);
         P->bws_rowsum = balloc((int64_t)B * cmax * 3 * 4);  // qkv convs have 3*C outputs
@@ -905,8 +906,12 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
         if (o.dst != -2) DMME_REQUIRE(written[o.dst], DMME_ERR_INVALID, "backward: tensor %d has no gradient", o.dst);
         const int Cin = a.C1 + a.C2;
         // 1. bias and time-embedding-row gradients (column sums of dY)
-        rc = launch_colsum(dt, dy, B, a.Hout * a.Wout, a.Cout, rowsum, grad_flat + P->params[o.b].ref_off,
-                           o.tproj_col >= 0 ? dtproj + o.tproj_col : nullptr, P->tproj_cols, nt, s);
+        if (colsum_fast_supported(dt, a.Hout * a.Wout, a.Cout))
+            rc = launch_colsum_fast(dt, dy, B, a.Hout * a.Wout, a.Cout, rowsum, grad_flat + P->params[o.b].ref_off,
+                                    o.tproj_col >= 0 ? dtproj + o.tproj_col : nullptr, P->tproj_cols, nt, s);
+        else
+            rc = launch_colsum(dt, dy, B, a.Hout * a.Wout, a.Cout, rowsum, grad_flat + P->params[o.b].ref_off,
+                               o.tproj_col >= 0 ? dtproj + o.tproj_col : nullptr, P->tproj_cols, nt, s);
         if (rc != DMME_OK) break;
         // 2. weight gradient (reference layout, accumulated)
         if (wgrad_mfma_supported(dt, a))
@@ -938,6 +943,12 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
             const int acc1 = claim(o.src1), acc2 = o.src2 >= 0 ? claim(o.src2) : 0;
             if (o.gn >= 0) {
                 const Op& gop = P->ops[o.gn];
+                if (gn_bwd_fast_supported(dt, t1.H * t1.W, a.C1, a.C2))
+                    rc = launch_gn_bwd_fast(dt, tmp, a.src1, a.src2, B, t1.H * t1.W, a.C1, a.C2, G,
+                                            (const float*)(pk + P->params[gop.gn_gamma].packed_off), (const float*)(ws + gop.gn_mr), a.scale,
+                                            a.shift, a.dmask, a.pro_silu, g1, g2, acc1, acc2, grad_flat + P->params[gop.gn_gamma].ref_off,
+                                            grad_flat + P->params[gop.gn_beta].ref_off, (float*)(bws + P->bws_gnscratch), s);
+                else
                 rc = launch_gn_bwd_generic(dt, tmp, a.src1, a.src2, B, t1.H * t1.W, a.C1, a.C2, G,
                                            (const float*)(pk + P->params[gop.gn_gamma].packed_off), (const float*)(ws + gop.gn_mr),
                                            a.scale, a.shift, a.dmask, a.pro_silu, g1, g2, acc1, acc2,

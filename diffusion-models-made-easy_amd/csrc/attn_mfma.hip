@@ -27,7 +27,7 @@ constexpr int AT_KT = 32;  // keys per tile
 constexpr int AT_QB = 128; // queries per workgroup
 
 template <int C>
-__global__ void __launch_bounds__(256) attn_mfma_kernel(const bf16* __restrict__ qkv, int S, bf16* __restrict__ out) {
+__global__ void __launch_bounds__(256) attn_mfma_kernel(const bf16* __restrict__ qkv, int S, bf16* __restrict__ out, float* __restrict__ lse) {
     constexpr int KSTEPS = C / 16;   // k-steps of the QK^T product
     constexpr int CT = C / 32;       // 32-channel tiles of the output
     constexpr int KP = C * 2 + 16;   // K tile row pitch (bytes)
@@ -123,7 +123,10 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const bf16* __restrict__
         }
     }
     // ---- normalise and store: lane = query, registers = channels (j&3) + 8 (j>>2) + 4 h ----
-    const float inv = 1.0f / (l + __shfl_xor(l, 32, 64));
+    const float ltot = l + __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / ltot;
+    // log2-domain log-sum-exp of the scaled scores, kept for the backward pass: p = exp2(s*c1 - lse)
+    if (lse && h == 0) lse[(int64_t)n * S + q_row] = m + log2f(ltot);
     bf16* orow = out + ((int64_t)n * S + q_row) * C;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
@@ -143,15 +146,215 @@ bool attn_mfma_supported(int dtype, int N, int S, int C) {
     return dtype == DMME_BF16 && (C == 128 || C == 256) && S >= AT_QB && S % AT_QB == 0;
 }
 
-int launch_attn_mfma(int dtype, const void* qkv, int N, int S, int C, void* out, hipStream_t s) {
+int launch_attn_mfma(int dtype, const void* qkv, int N, int S, int C, void* out, float* lse, hipStream_t s) {
     DMME_REQUIRE(attn_mfma_supported(dtype, N, S, C), DMME_ERR_UNSUPPORTED, "attn_mfma: unsupported shape S=%d C=%d", S, C);
     const dim3 grid((unsigned)(N * (S / AT_QB)));
     if (C == 256)
-        hipLaunchKernelGGL(attn_mfma_kernel<256>, grid, dim3(256), 0, s, (const bf16*)qkv, S, (bf16*)out);
+        hipLaunchKernelGGL(attn_mfma_kernel<256>, grid, dim3(256), 0, s, (const bf16*)qkv, S, (bf16*)out, lse);
     else
-        hipLaunchKernelGGL(attn_mfma_kernel<128>, grid, dim3(256), 0, s, (const bf16*)qkv, S, (bf16*)out);
+        hipLaunchKernelGGL(attn_mfma_kernel<128>, grid, dim3(256), 0, s, (const bf16*)qkv, S, (bf16*)out, lse);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
+}
+
+// =====================================================================================
+// Backward.  With P = softmax(Q K^T s) (s = C^-0.5), O = P V and dO given:
+//   dV = P^T dO,  dP = dO V^T,  dS = P o (dP - delta),  delta_i = <dO_i, O_i>,
+//   dQ = s dS K,  dK = s dS^T Q.
+// Kernel 1 (attn_bwd_scores) recomputes the transposed score tiles S^T = K Q^T and dP^T = V dO^T
+// on the matrix cores with the query on the lane (as in the forward kernel), so the softmax
+// row terms (saved log-sum-exp, delta) are per-lane scalars, and writes P and dS (bf16,
+// [N][S][S], row = query).  The three remaining products are plain per-image GEMMs
+// (attn_bgemm): dV = P^T dO and dK = s dS^T Q contract over the ROW index of two row-major
+// matrices (both fragments via transposed LDS reads), dQ = s dS K is a row-major A times a
+// transposed-read B.
+template <int C>
+__global__ void __launch_bounds__(256) attn_bwd_scores_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ O,
+                                                              const bf16* __restrict__ dO, const float* __restrict__ lse, int S,
+                                                              bf16* __restrict__ P, bf16* __restrict__ dS) {
+    constexpr int KSTEPS = C / 16;
+    constexpr int KP = C * 2 + 16;
+    __shared__ __attribute__((aligned(16))) char lds[2 * AT_KT * KP];
+    char* ldsK = lds;
+    char* ldsV = lds + AT_KT * KP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int qblocks = S / AT_QB;
+    const int n = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;
+    const bf16* base = qkv + (int64_t)n * S * 3 * C;
+    const int q_row = qb * AT_QB + wave * 32 + r;
+    uint4 qf[KSTEPS], dof[KSTEPS];
+    float dpart = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+        qf[ks] = *reinterpret_cast<const uint4*>(base + (int64_t)q_row * 3 * C + ks * 16 + h * 8);
+        dof[ks] = *reinterpret_cast<const uint4*>(dO + ((int64_t)n * S + q_row) * C + ks * 16 + h * 8);
+        const uint4 ov = *reinterpret_cast<const uint4*>(O + ((int64_t)n * S + q_row) * C + ks * 16 + h * 8);
+        const bf16x8 a = __builtin_bit_cast(bf16x8, dof[ks]), b = __builtin_bit_cast(bf16x8, ov);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dpart = fmaf((float)a[j], (float)b[j], dpart);
+    }
+    const float delta = dpart + __shfl_xor(dpart, 32, 64);
+    const float L = lse[(int64_t)n * S + q_row];
+    const float c1 = 1.4426950408889634f / sqrtf((float)C);
+    bf16* Prow = P + ((int64_t)n * S + q_row) * S;
+    bf16* dSrow = dS + ((int64_t)n * S + q_row) * S;
+
+    for (int k0 = 0; k0 < S; k0 += AT_KT) {
+        __syncthreads();
+        for (int u = tid; u < AT_KT * (C / 8); u += 256) {
+            const int row = u / (C / 8), cu = u % (C / 8);
+            const bf16* src = base + (int64_t)(k0 + row) * 3 * C + cu * 8;
+            *reinterpret_cast<uint4*>(ldsK + row * KP + cu * 16) = *reinterpret_cast<const uint4*>(src + C);
+            *reinterpret_cast<uint4*>(ldsV + row * KP + cu * 16) = *reinterpret_cast<const uint4*>(src + 2 * C);
+        }
+        __syncthreads();
+        f32x16 st, dp;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) st[j] = dp[j] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const uint4 kf = *reinterpret_cast<const uint4*>(ldsK + r * KP + ks * 32 + h * 16);
+            const uint4 vf = *reinterpret_cast<const uint4*>(ldsV + r * KP + ks * 32 + h * 16);
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[ks]), st, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, dof[ks]), dp, 0, 0, 0);
+        }
+        // registers j <-> key k0 + (j&3) + 8*(j>>2) + 4*h : four consecutive keys per register quad
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int jg = 0; jg < 4; ++jg) {
+            bf16x4 pv, dv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float p = exp2f(fmaf(st[jg * 4 + e], c1, -L));
+                pv[e] = (bf16)p;
+                dv[e] = (bf16)(p * (dp[jg * 4 + e] - delta));
+            }
+            *reinterpret_cast<bf16x4*>(Prow + k0 + 8 * jg + 4 * h) = pv;
+            *reinterpret_cast<bf16x4*>(dSrow + k0 + 8 * jg + 4 * h) = dv;
+        }
+    }
+}
+
+// per-image GEMM  out[m][n] = alpha * sum_k A(m,k) B(k,n),  M = K = S, N = C (bf16 in, fp32 accumulate)
+//   TRANS_A = 1: A(m,k) = X[k][m]  (X row-major [S][S], ldx = S)      -- dV, dK
+//   TRANS_A = 0: A(m,k) = X[m][k]                                      -- dQ
+//   B(k,n) = Y[k][n] (row-major, ldy), fragments by transposed LDS reads.
+// One workgroup = one image x 64 rows of the output; 4 waves split the C columns.
+template <int C, int TRANS_A>
+__global__ void __launch_bounds__(256) attn_bgemm_kernel(const bf16* __restrict__ X, int ldx, int64_t x_img, const bf16* __restrict__ Y, int ldy,
+                                                         int64_t y_img, int S, float alpha, bf16* __restrict__ out, int ldo, int64_t o_img) {
+    constexpr int WN = C / 4;        // columns per wave
+    constexpr int NI = WN / 32;      // 32-column tiles per wave
+    constexpr int YP = C * 2 + 64;   // Y tile pitch: 4 rows of a transposed read on disjoint banks
+    constexpr int XP_T = 64 * 2 + 64;  // X tile [32 k][64 m] for transposed reads
+    constexpr int XP_N = 32 * 2 + 16;  // X tile [64 m][32 k] for row reads
+    __shared__ __attribute__((aligned(16))) char lds[32 * YP + (TRANS_A ? 32 * XP_T : 64 * XP_N)];
+    char* ldsY = lds;
+    char* ldsX = lds + 32 * YP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int mblocks = S / 64;
+    const int n = blockIdx.x / mblocks, m0 = (blockIdx.x % mblocks) * 64;
+    const bf16* Xi = X + n * x_img;
+    const bf16* Yi = Y + n * y_img;
+    const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g1 = (lane >> 4) & 1;
+    f32x16 acc[2][NI];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.f;
+
+    for (int k0 = 0; k0 < S; k0 += 32) {
+        __syncthreads();
+        for (int u = tid; u < 32 * (C / 8); u += 256) {
+            const int row = u / (C / 8), cu = u % (C / 8);
+            *reinterpret_cast<uint4*>(ldsY + row * YP + cu * 16) = *reinterpret_cast<const uint4*>(Yi + (int64_t)(k0 + row) * ldy + cu * 8);
+        }
+        if (TRANS_A) {
+            // X[k0 + row][m0 .. m0+63]
+            for (int u = tid; u < 32 * 8; u += 256) {
+                const int row = u >> 3, cu = u & 7;
+                *reinterpret_cast<uint4*>(ldsX + row * XP_T + cu * 16) = *reinterpret_cast<const uint4*>(Xi + (int64_t)(k0 + row) * ldx + m0 + cu * 8);
+            }
+        } else {
+            // X[m0 + row][k0 .. k0+31]
+            for (int u = tid; u < 64 * 4; u += 256) {
+                const int row = u >> 2, cu = u & 3;
+                *reinterpret_cast<uint4*>(ldsX + row * XP_N + cu * 16) = *reinterpret_cast<const uint4*>(Xi + (int64_t)(m0 + row) * ldx + k0 + cu * 8);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            s16x8 af[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                if (TRANS_A) {
+                    const char* p0 = ldsX + (16 * ks + 8 * h + tr_q) * XP_T + (mi * 32 + 16 * tr_g1 + 4 * tr_p) * 2;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 4 * XP_T));
+                    af[mi][0] = lo[0]; af[mi][1] = lo[1]; af[mi][2] = lo[2]; af[mi][3] = lo[3];
+                    af[mi][4] = hi[0]; af[mi][5] = hi[1]; af[mi][6] = hi[2]; af[mi][7] = hi[3];
+                } else {
+                    af[mi] = __builtin_bit_cast(s16x8, *reinterpret_cast<const uint4*>(ldsX + (mi * 32 + r) * XP_N + ks * 32 + h * 16));
+                }
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const char* p0 = ldsY + (16 * ks + 8 * h + tr_q) * YP + (wave * WN + ni * 32 + 16 * tr_g1 + 4 * tr_p) * 2;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 4 * YP));
+                s16x8 bfr;
+                bfr[0] = lo[0]; bfr[1] = lo[1]; bfr[2] = lo[2]; bfr[3] = lo[3];
+                bfr[4] = hi[0]; bfr[5] = hi[1]; bfr[6] = hi[2]; bfr[7] = hi[3];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mi]), __builtin_bit_cast(bf16x8, bfr), acc[mi][ni], 0, 0, 0);
+            }
+        }
+    }
+    bf16* Oi = out + n * o_img;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int m = m0 + mi * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+                Oi[(int64_t)m * ldo + wave * WN + ni * 32 + r] = (bf16)(acc[mi][ni][j] * alpha);
+            }
+}
+
+bool attn_bwd_mfma_supported(int dtype, int N, int S, int C) { return attn_mfma_supported(dtype, N, S, C) && S % 64 == 0; }
+
+template <int C>
+static int launch_attn_bwd_t(const bf16* qkv, const bf16* O, const bf16* dO, const float* lse, int N, int S, bf16* P, bf16* dS, bf16* dqkv,
+                             hipStream_t s) {
+    hipLaunchKernelGGL(attn_bwd_scores_kernel<C>, dim3((unsigned)(N * (S / AT_QB))), dim3(256), 0, s, qkv, O, dO, lse, S, P, dS);
+    DMME_CHECK_LAUNCH();
+    const dim3 grid((unsigned)(N * (S / 64)));
+    const float scale = 1.0f / sqrtf((float)C);
+    const int64_t qi = (int64_t)S * 3 * C, oi = (int64_t)S * C, pi = (int64_t)S * S;
+    // dV = P^T dO ; dK = s dS^T Q ; dQ = s dS K
+    hipLaunchKernelGGL((attn_bgemm_kernel<C, 1>), grid, dim3(256), 0, s, P, S, pi, dO, C, oi, S, 1.0f, dqkv + 2 * C, 3 * C, qi);
+    DMME_CHECK_LAUNCH();
+    hipLaunchKernelGGL((attn_bgemm_kernel<C, 1>), grid, dim3(256), 0, s, dS, S, pi, qkv, 3 * C, qi, S, scale, dqkv + C, 3 * C, qi);
+    DMME_CHECK_LAUNCH();
+    hipLaunchKernelGGL((attn_bgemm_kernel<C, 0>), grid, dim3(256), 0, s, dS, S, pi, qkv + C, 3 * C, qi, S, scale, dqkv, 3 * C, qi);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+// P, dS: N*S*S bf16 each
+int launch_attn_bwd_mfma(int dtype, const void* qkv, const void* O, const void* dO, const float* lse, int N, int S, int C, void* P, void* dS,
+                         void* dqkv, hipStream_t s) {
+    DMME_REQUIRE(attn_bwd_mfma_supported(dtype, N, S, C), DMME_ERR_UNSUPPORTED, "attn_bwd_mfma: unsupported shape");
+    if (C == 256)
+        return launch_attn_bwd_t<256>((const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, N, S, (bf16*)P, (bf16*)dS, (bf16*)dqkv, s);
+    return launch_attn_bwd_t<128>((const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, N, S, (bf16*)P, (bf16*)dS, (bf16*)dqkv, s);
 }
 
 }  // namespace dmme

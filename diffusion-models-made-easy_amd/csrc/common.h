@@ -146,7 +146,11 @@ int launch_gn_fast(int dtype, const void* src1, const void* src2, int N, int HW,
 
 int launch_attn_generic(int dtype, const void* qkv, int N, int S, int C, void* out, hipStream_t s);
 bool attn_mfma_supported(int dtype, int N, int S, int C);
-int launch_attn_mfma(int dtype, const void* qkv, int N, int S, int C, void* out, hipStream_t s);
+// lse (nullable): [N][S] log2-domain log-sum-exp of the scaled scores, kept for the backward pass
+int launch_attn_mfma(int dtype, const void* qkv, int N, int S, int C, void* out, float* lse, hipStream_t s);
+bool attn_bwd_mfma_supported(int dtype, int N, int S, int C);
+int launch_attn_bwd_mfma(int dtype, const void* qkv, const void* O, const void* dO, const float* lse, int N, int S, int C, void* P, void* dS,
+                         void* dqkv, hipStream_t s);
 
 int launch_time_sinusoid(const int64_t* t, int nt, const float* freqs, int half, float* out, hipStream_t s);
 // out[nt][Nout] = act(in[nt][K] . W[Nout][K]^T + b); in/out fp32, W in dtype

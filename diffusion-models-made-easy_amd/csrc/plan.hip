@@ -62,6 +62,7 @@ struct Op {
     int up = 0, stride = 1, taps = 9;
     // OP_ATTN
     int at_qkv = -1, at_out = -1;
+    int64_t at_lse = 0;  // workspace offset of the forward's log-sum-exp [N][S]
 };
 
 }  // namespace dmme
@@ -392,6 +393,7 @@ int build_plan(dmme_plan* P) {
             at.kind = OP_ATTN;
             at.at_qkv = q.dst;
             at.at_out = new_tensor(n.cout, h, w);
+            at.at_lse = ws_alloc((int64_t)B * h * w * 4);
             ops.push_back(at);
             Op pr{};
             pr.kind = OP_CONV;
@@ -649,7 +651,7 @@ int run_op(const dmme_plan* P, const Op& o, const char* pk, const float* x, cons
             const Tensor& q = P->tensors[o.at_qkv];
             const int S = q.H * q.W, C = q.C / 3;
             if (attn_mfma_supported(P->dtype, P->B, S, C))
-                return launch_attn_mfma(P->dtype, ws + q.off, P->B, S, C, ws + P->tensors[o.at_out].off, s);
+                return launch_attn_mfma(P->dtype, ws + q.off, P->B, S, C, ws + P->tensors[o.at_out].off, (float*)(ws + o.at_lse), s);
             return launch_attn_generic(P->dtype, ws + q.off, P->B, S, C, ws + P->tensors[o.at_out].off, s);
         }
     }
@@ -894,8 +896,12 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
             const Tensor& q = P->tensors[o.at_qkv];
             const int S = q.H * q.W, C = q.C / 3;
             DMME_REQUIRE(written[o.at_out], DMME_ERR_INVALID, "backward: attention output has no gradient");
-            rc = launch_attn_bwd_generic(dt, ws + q.off, gptr(o.at_out), B, S, C, (float*)(bws + P->bws_attP),
-                                         (float*)(bws + P->bws_attdS), gptr(o.at_qkv), s);
+            if (attn_bwd_mfma_supported(dt, B, S, C))
+                rc = launch_attn_bwd_mfma(dt, ws + q.off, ws + P->tensors[o.at_out].off, gptr(o.at_out), (const float*)(ws + o.at_lse), B, S, C,
+                                          bws + P->bws_attP, bws + P->bws_attdS, gptr(o.at_qkv), s);
+            else
+                rc = launch_attn_bwd_generic(dt, ws + q.off, gptr(o.at_out), B, S, C, (float*)(bws + P->bws_attP),
+                                             (float*)(bws + P->bws_attdS), gptr(o.at_qkv), s);
             written[o.at_qkv] = 1;
             continue;
         }
@@ -1105,7 +1111,7 @@ DMME_API int dmme_groupnorm_scale_shift(int dtype, const void* src1, const void*
 
 DMME_API int dmme_attention(int dtype, const void* qkv, int N, int S, int C, void* out, int force_generic, void* stream) {
     DMME_REQUIRE(qkv && out && N > 0 && S > 0 && C > 0, DMME_ERR_INVALID, "attention: bad argument");
-    if (!force_generic && attn_mfma_supported(dtype, N, S, C)) return launch_attn_mfma(dtype, qkv, N, S, C, out, (hipStream_t)stream);
+    if (!force_generic && attn_mfma_supported(dtype, N, S, C)) return launch_attn_mfma(dtype, qkv, N, S, C, out, nullptr, (hipStream_t)stream);
     return launch_attn_generic(dtype, qkv, N, S, C, out, (hipStream_t)stream);
 }
 

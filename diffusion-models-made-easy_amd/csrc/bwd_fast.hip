@@ -42,33 +42,34 @@ __device__ __forceinline__ float silu_grad_f(float u) {
 
 // geometry shared by the kernels: a workgroup owns `chunk_px` pixels of one image, thread -> fixed
 // 16-byte channel slot (tid % VPP) and pixel row phase (tid / VPP)
-static bool vec_geometry(int dtype, int HW, int C, int& chunk_px, int& nchunks) {
+static bool vec_geometry(int dtype, int HW, int C, int& chunk_px, int& nchunks, int& ppw_out) {
     const int EPV = dtype == DMME_BF16 ? 8 : 4;
     if (C % EPV) return false;
     const int VPP = C / EPV;
-    if (VPP > 256 || 256 % VPP) return false;
-    const int ppw = 256 / VPP;
-    if (HW % ppw) return false;
+    if (VPP > 256) return false;
+    int ppw = 256 / VPP;  // threads beyond ppw*VPP idle when VPP does not divide 256 (e.g. 768 channels)
+    while (ppw > 1 && HW % ppw) --ppw;
     int sweeps = HW / ppw;
     if (sweeps > 16) sweeps = 16;
     while (sweeps > 1 && (HW / ppw) % sweeps) --sweeps;
     chunk_px = sweeps * ppw;
     nchunks = HW / chunk_px;
+    ppw_out = ppw;
     return true;
 }
 
 // ------------------------------------------------------------------ column sums
 template <typename T>
-__global__ void __launch_bounds__(256) colsum_vec_kernel(const T* __restrict__ dY, int HW, int C, int chunk_px, float* __restrict__ rowsum) {
+__global__ void __launch_bounds__(256) colsum_vec_kernel(const T* __restrict__ dY, int HW, int C, int chunk_px, int ppw, float* __restrict__ rowsum) {
     constexpr int EPV = 16 / sizeof(T);
     __shared__ float red[256 * EPV];
-    const int tid = threadIdx.x, VPP = C / EPV, slot = tid % VPP, prow = tid / VPP, ppw = 256 / VPP;
+    const int tid = threadIdx.x, VPP = C / EPV, slot = tid % VPP, prow = tid / VPP;
     const int n = blockIdx.y;
     const int64_t p0 = (int64_t)n * HW + (int64_t)blockIdx.x * chunk_px;
     float acc[EPV];
 #pragma unroll
     for (int j = 0; j < EPV; ++j) acc[j] = 0.f;
-    for (int p = prow; p < chunk_px; p += ppw) {
+    for (int p = prow; p < chunk_px && prow < ppw; p += ppw) {
         float v[EPV];
         load_vec<T>(dY + (p0 + p) * C + slot * EPV, v);
 #pragma unroll
@@ -87,51 +88,47 @@ __global__ void __launch_bounds__(256) colsum_vec_kernel(const T* __restrict__ d
     }
 }
 
-// dbias[c] += sum_n rowsum[n][c];  d_tproj rows (per image, or the single broadcast row)
+// dbias[c] += sum_n rowsum[n][c];  d_tproj rows (per image, or the single broadcast row); 32 channels per
+// workgroup, the batch split 8 ways and combined through LDS
 __global__ void __launch_bounds__(256) bias_tproj_fast_kernel(const float* __restrict__ rowsum, int N, int C, float* __restrict__ dbias,
                                                               float* __restrict__ dtproj, int ld, int nt) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-    int n = 0;
-    for (; n + 3 < N; n += 4) {
-        const float a = rowsum[(int64_t)n * C + c], b = rowsum[(int64_t)(n + 1) * C + c], d = rowsum[(int64_t)(n + 2) * C + c],
-                    e = rowsum[(int64_t)(n + 3) * C + c];
-        t0 += a; t1 += b; t2 += d; t3 += e;
-        if (dtproj && nt > 1) {
-            dtproj[(int64_t)n * ld + c] = a;
-            dtproj[(int64_t)(n + 1) * ld + c] = b;
-            dtproj[(int64_t)(n + 2) * ld + c] = d;
-            dtproj[(int64_t)(n + 3) * ld + c] = e;
+    __shared__ float red[8][33];
+    const int cl = threadIdx.x & 31, seg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float acc = 0.f;
+    if (c < C)
+        for (int n = seg; n < N; n += 8) {
+            const float v = rowsum[(int64_t)n * C + c];
+            acc += v;
+            if (dtproj && nt > 1) dtproj[(int64_t)n * ld + c] = v;
         }
+    red[seg][cl] = acc;
+    __syncthreads();
+    if (seg == 0 && c < C) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tot += red[k][cl];
+        if (dbias) dbias[c] += tot;
+        if (dtproj && nt == 1) dtproj[c] = tot;
     }
-    for (; n < N; ++n) {
-        const float a = rowsum[(int64_t)n * C + c];
-        t0 += a;
-        if (dtproj && nt > 1) dtproj[(int64_t)n * ld + c] = a;
-    }
-    const float tot = (t0 + t1) + (t2 + t3);
-    if (dbias) dbias[c] += tot;
-    if (dtproj && nt == 1) dtproj[c] = tot;
 }
 
 bool colsum_fast_supported(int dtype, int HW, int C) {
-    int a, b;
-    return vec_geometry(dtype, HW, C, a, b);
+    int a, b, c;
+    return vec_geometry(dtype, HW, C, a, b, c);
 }
 
 int launch_colsum_fast(int dtype, const void* dY, int N, int HW, int C, float* rowsum, float* dbias, float* dtproj, int ld, int nt,
                        hipStream_t s) {
-    int chunk_px, nchunks;
-    DMME_REQUIRE(vec_geometry(dtype, HW, C, chunk_px, nchunks), DMME_ERR_UNSUPPORTED, "colsum_fast: unsupported geometry");
-    DMME_CHECK_HIP(hipMemsetAsync(rowsum, 0, (size_t)N * C * sizeof(float), s));
+    int chunk_px, nchunks, ppw;
+    DMME_REQUIRE(vec_geometry(dtype, HW, C, chunk_px, nchunks, ppw), DMME_ERR_UNSUPPORTED, "colsum_fast: unsupported geometry");
     dim3 grid(nchunks, N);
     if (dtype == DMME_BF16)
-        hipLaunchKernelGGL(colsum_vec_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dY, HW, C, chunk_px, rowsum);
+        hipLaunchKernelGGL(colsum_vec_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dY, HW, C, chunk_px, ppw, rowsum);
     else
-        hipLaunchKernelGGL(colsum_vec_kernel<float>, grid, dim3(256), 0, s, (const float*)dY, HW, C, chunk_px, rowsum);
+        hipLaunchKernelGGL(colsum_vec_kernel<float>, grid, dim3(256), 0, s, (const float*)dY, HW, C, chunk_px, ppw, rowsum);
     DMME_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bias_tproj_fast_kernel, dim3((C + 255) / 256), dim3(256), 0, s, rowsum, N, C, dbias, dtproj, ld, nt);
+    hipLaunchKernelGGL(bias_tproj_fast_kernel, dim3((C + 31) / 32), dim3(256), 0, s, rowsum, N, C, dbias, dtproj, ld, nt);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }
@@ -141,11 +138,11 @@ template <typename T>
 __global__ void __launch_bounds__(256) gn_bwd_sums_kernel(const T* __restrict__ dv, const T* __restrict__ x1, const T* __restrict__ x2, int HW,
                                                           int C1, int C2, int groups, const float* __restrict__ mean_rstd,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
-                                                          const float* __restrict__ dmask, int pro_silu, int chunk_px,
+                                                          const float* __restrict__ dmask, int pro_silu, int chunk_px, int ppw,
                                                           float* __restrict__ AB /* [N][C][2] */) {
     constexpr int EPV = 16 / sizeof(T);
     __shared__ float red[256 * EPV * 2];
-    const int C = C1 + C2, tid = threadIdx.x, VPP = C / EPV, slot = tid % VPP, prow = tid / VPP, ppw = 256 / VPP;
+    const int C = C1 + C2, tid = threadIdx.x, VPP = C / EPV, slot = tid % VPP, prow = tid / VPP;
     const int n = blockIdx.y, c0 = slot * EPV, cg = C / groups;
     const bool second = c0 >= C1;
     const T* xs = second ? x2 : x1;
@@ -164,7 +161,7 @@ __global__ void __launch_bounds__(256) gn_bwd_sums_kernel(const T* __restrict__ 
     float a[EPV], b[EPV];
 #pragma unroll
     for (int j = 0; j < EPV; ++j) a[j] = b[j] = 0.f;
-    for (int p = prow; p < chunk_px; p += ppw) {
+    for (int p = prow; p < chunk_px && prow < ppw; p += ppw) {
         float d[EPV], xv[EPV];
         load_vec<T>(dv + (p0 + p) * C + c0, d);
         load_vec<T>(xs + (p0 + p) * Cs + cs0, xv);
@@ -196,13 +193,15 @@ __global__ void __launch_bounds__(256) gn_bwd_sums_kernel(const T* __restrict__ 
     }
 }
 
-// finalize: S[n][g] = {sum gamma A, sum gamma B};  dgamma_c += sum_n B, dbeta_c += sum_n A
-__global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __restrict__ AB, int N, int C, int groups,
+// finalize: blocks [0, nb_s): S[n][g] = {sum gamma A, sum gamma B};
+//           remaining blocks: 32 channels each, dgamma_c += sum_n B, dbeta_c += sum_n A (8-way split over n + LDS)
+__global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __restrict__ AB, int N, int C, int groups, int nb_s,
                                                               const float* __restrict__ gamma, float* __restrict__ S,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int cg = C / groups;
-    if (i < N * groups) {
+    if ((int)blockIdx.x < nb_s) {
+        const int i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= N * groups) return;
         const int n = i / groups, g = i % groups;
         float s1 = 0.f, s2 = 0.f;
         for (int j = 0; j < cg; ++j) {
@@ -212,22 +211,29 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __res
         }
         S[(int64_t)i * 2] = s1;
         S[(int64_t)i * 2 + 1] = s2;
+        return;
     }
-    if (i < C) {
-        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
-        int n = 0;
-        for (; n + 1 < N; n += 2) {
-            a0 += AB[((int64_t)n * C + i) * 2];
-            b0 += AB[((int64_t)n * C + i) * 2 + 1];
-            a1 += AB[((int64_t)(n + 1) * C + i) * 2];
-            b1 += AB[((int64_t)(n + 1) * C + i) * 2 + 1];
+    __shared__ float ra[8][33], rb[8][33];
+    const int cl = threadIdx.x & 31, seg = threadIdx.x >> 5;
+    const int c = ((int)blockIdx.x - nb_s) * 32 + cl;
+    float a = 0.f, b = 0.f;
+    if (c < C)
+        for (int n = seg; n < N; n += 8) {
+            a += AB[((int64_t)n * C + c) * 2];
+            b += AB[((int64_t)n * C + c) * 2 + 1];
         }
-        if (n < N) {
-            a0 += AB[((int64_t)n * C + i) * 2];
-            b0 += AB[((int64_t)n * C + i) * 2 + 1];
+    ra[seg][cl] = a;
+    rb[seg][cl] = b;
+    __syncthreads();
+    if (seg == 0 && c < C) {
+        float ta = 0.f, tb = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            ta += ra[k][cl];
+            tb += rb[k][cl];
         }
-        dbeta[i] += a0 + a1;
-        dgamma[i] += b0 + b1;
+        dbeta[c] += ta;
+        dgamma[c] += tb;
     }
 }
 
@@ -237,10 +243,11 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
                                                            int C1, int C2, int groups, const float* __restrict__ gamma,
                                                            const float* __restrict__ mean_rstd, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ dmask, int pro_silu,
-                                                           const float* __restrict__ S, int chunk_px, T* __restrict__ dx1, T* __restrict__ dx2,
+                                                           const float* __restrict__ S, int chunk_px, int ppw, T* __restrict__ dx1, T* __restrict__ dx2,
                                                            int acc1, int acc2) {
     constexpr int EPV = 16 / sizeof(T);
-    const int C = C1 + C2, tid = threadIdx.x, VPP = C / EPV, slot = tid % VPP, prow = tid / VPP, ppw = 256 / VPP;
+    const int C = C1 + C2, tid = threadIdx.x, VPP = C / EPV, slot = tid % VPP, prow = tid / VPP;
+    if (prow >= ppw) return;
     const int n = blockIdx.y, c0 = slot * EPV, cg = C / groups;
     const bool second = c0 >= C1;
     const T* xs = second ? x2 : x1;
@@ -281,38 +288,35 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
 
 bool gn_bwd_fast_supported(int dtype, int HW, int C1, int C2) {
     const int EPV = dtype == DMME_BF16 ? 8 : 4;
-    int a, b;
-    return (C1 % EPV) == 0 && vec_geometry(dtype, HW, C1 + C2, a, b);
+    int a, b, c;
+    return (C1 % EPV) == 0 && vec_geometry(dtype, HW, C1 + C2, a, b, c);
 }
 
-// scratch: N*C*2 + N*groups*2 floats
+// AB: N*C*2 floats, zero on entry;  S: N*groups*2 floats of scratch
 int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2, int N, int HW, int C1, int C2, int groups,
                        const float* gamma, const float* mean_rstd, const float* scale, const float* shift, const float* dmask,
-                       int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, float* scratch,
+                       int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, float* AB, float* S,
                        hipStream_t s) {
-    int chunk_px, nchunks;
+    int chunk_px, nchunks, ppw;
     const int C = C1 + C2;
-    DMME_REQUIRE(vec_geometry(dtype, HW, C, chunk_px, nchunks), DMME_ERR_UNSUPPORTED, "gn_bwd_fast: unsupported geometry");
-    float* AB = scratch;
-    float* S = scratch + (size_t)N * C * 2;
-    DMME_CHECK_HIP(hipMemsetAsync(AB, 0, (size_t)N * C * 2 * sizeof(float), s));
+    DMME_REQUIRE(vec_geometry(dtype, HW, C, chunk_px, nchunks, ppw), DMME_ERR_UNSUPPORTED, "gn_bwd_fast: unsupported geometry");
     dim3 grid(nchunks, N);
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(gn_bwd_sums_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dv, (const bf16*)x1, (const bf16*)x2, HW, C1, C2, groups,
-                           mean_rstd, scale, shift, dmask, pro_silu, chunk_px, AB);
+                           mean_rstd, scale, shift, dmask, pro_silu, chunk_px, ppw, AB);
     else
         hipLaunchKernelGGL(gn_bwd_sums_kernel<float>, grid, dim3(256), 0, s, (const float*)dv, (const float*)x1, (const float*)x2, HW, C1, C2,
-                           groups, mean_rstd, scale, shift, dmask, pro_silu, chunk_px, AB);
+                           groups, mean_rstd, scale, shift, dmask, pro_silu, chunk_px, ppw, AB);
     DMME_CHECK_LAUNCH();
-    const int tot = N * groups > C ? N * groups : C;
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, AB, N, C, groups, gamma, S, dgamma, dbeta);
+    const int nb_s = (N * groups + 255) / 256;
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(nb_s + (C + 31) / 32), dim3(256), 0, s, AB, N, C, groups, nb_s, gamma, S, dgamma, dbeta);
     DMME_CHECK_LAUNCH();
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dv, (const bf16*)x1, (const bf16*)x2, HW, C1, C2, groups,
-                           gamma, mean_rstd, scale, shift, dmask, pro_silu, S, chunk_px, (bf16*)dx1, (bf16*)dx2, acc1, acc2);
+                           gamma, mean_rstd, scale, shift, dmask, pro_silu, S, chunk_px, ppw, (bf16*)dx1, (bf16*)dx2, acc1, acc2);
     else
         hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)dv, (const float*)x1, (const float*)x2, HW, C1, C2,
-                           groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, S, chunk_px, (float*)dx1, (float*)dx2, acc1, acc2);
+                           groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, S, chunk_px, ppw, (float*)dx1, (float*)dx2, acc1, acc2);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }

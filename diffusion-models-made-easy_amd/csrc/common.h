@@ -184,9 +184,14 @@ int launch_mse(const float* eps, const float* target, int64_t numel, float* loss
 
 // ---- backward (kernels_bwd.hip) ----
 int launch_wgrad_generic(int dtype, const ConvArgs& a, const void* dY, float* dW, hipStream_t s);
-// MFMA weight gradient (wgrad_mfma.hip); scratch: Cout*taps*Cin floats
+// first / last layer weight gradients (few input or output channels)
+bool wgrad_small_supported(int dtype, const ConvArgs& a);
+int launch_wgrad_small(int dtype, const ConvArgs& a, const void* dY, float* dW, hipStream_t s);
+// MFMA weight gradient (wgrad_mfma.hip): atomically accumulates into a zero-initialised packed-layout image
 bool wgrad_mfma_supported(int dtype, const ConvArgs& a);
-int launch_wgrad_mfma(int dtype, const ConvArgs& a, const void* dY, float* scratch, float* dW, hipStream_t s);
+int launch_wgrad_mfma(int dtype, const ConvArgs& a, const void* dY, float* dWp, hipStream_t s);
+struct PackItem;
+int launch_wgrad_unpack(const PackItem* items_dev, int n_items, const float* image, float* grad_flat, hipStream_t s);
 int launch_colsum(int dtype, const void* dY, int N, int HW, int C, float* rowsum, float* dbias, float* dtproj, int ld, int nt,
                   hipStream_t s);
 int launch_gn_bwd_generic(int dtype, const void* dv, const void* x1, const void* x2, int N, int HW, int C1, int C2, int groups,
@@ -194,19 +199,24 @@ int launch_gn_bwd_generic(int dtype, const void* dv, const void* x1, const void*
                           int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, hipStream_t s);
 // coalesced vector versions (bwd_fast.hip)
 bool colsum_fast_supported(int dtype, int HW, int C);
+// rowsum must be zero on entry (the backward pass clears all its accumulation scratch with one memset)
 int launch_colsum_fast(int dtype, const void* dY, int N, int HW, int C, float* rowsum, float* dbias, float* dtproj, int ld, int nt,
                        hipStream_t s);
 bool gn_bwd_fast_supported(int dtype, int HW, int C1, int C2);
 int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2, int N, int HW, int C1, int C2, int groups,
                        const float* gamma, const float* mean_rstd, const float* scale, const float* shift, const float* dmask,
-                       int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, float* scratch,
-                       hipStream_t s);
+                       int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, float* AB_zeroed,
+                       float* S_scratch, hipStream_t s);
 int launch_grad_acc(int dtype, const void* src, void* d1, void* d2, int C1, int C2, int acc1, int acc2, int pool, int N, int H, int W,
                     hipStream_t s);
 int launch_attn_bwd_generic(int dtype, const void* qkv, const void* dO, int N, int S, int C, float* P, float* dS, void* dqkv, hipStream_t s);
 int launch_lin_dinput(int dtype, const float* dY, const void* W, int R, int O, int K, float* dX, hipStream_t s);
 int launch_lin_dweight(const float* dY, const float* X, int R, int O, int K, float* dW, float* dB, hipStream_t s);
 int launch_silu_bwd(float* dy, const float* z, int n, hipStream_t s);
+// small fp32 GEMMs (small_gemm.hip): mode 0 NT (forward linear), 1 NN (input gradient), 2 TN (weight gradient, accumulating)
+int launch_small_gemm(int dtype, int mode, const float* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias, int out_silu,
+                      float* C, int ldc, hipStream_t s);
+int launch_nsum(const float* Mx, int N, int C, int64_t stride, int estride, float* out, hipStream_t s);
 int launch_grad_norm(const float* g, int64_t n, float* norm_out, float* scratch, hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr, float b1, float b2, float eps, int step,
                 const float* norm, float max_norm, float ema_decay, hipStream_t s);

@@ -86,6 +86,117 @@ int launch_wgrad_generic(int dtype, const ConvArgs& a, const void* dY, float* dW
     return DMME_OK;
 }
 
+// ------------------------------------------------------------------ weight gradient, few output channels
+// Cout <= 4 (the network's last conv): one workgroup per chunk of output rows, thread <-> (tap, 16-byte
+// cin vector) holding Cout*EPV accumulators; the activation vector is recomputed through the prologue.
+template <typename T>
+__global__ void __launch_bounds__(256) wgrad_cout_small_kernel(ConvArgs a, const T* __restrict__ dY, float* __restrict__ dW, int rows_per_chunk) {
+    constexpr int EPV = 16 / sizeof(T);
+    const int Cin = a.C1;  // single source, Cin % EPV == 0
+    const int vpt = Cin / EPV;                 // vectors per tap
+    const int slot = threadIdx.x;              // (tap, vector)
+    if (slot >= 9 * vpt) return;
+    const int tap = slot / vpt, cv = slot % vpt, kh = tap / 3, kw = tap % 3, c0 = cv * EPV;
+    float acc[4][EPV];
+#pragma unroll
+    for (int co = 0; co < 4; ++co)
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) acc[co][j] = 0.f;
+    const int row_begin = blockIdx.x * rows_per_chunk, row_end = min(row_begin + rows_per_chunk, a.N * a.Hout);
+    for (int row = row_begin; row < row_end; ++row) {
+        const int n = row / a.Hout, oy = row % a.Hout, iy = oy - 1 + kh;
+        if (iy < 0 || iy >= a.Hin) continue;
+        float sc[EPV], sh[EPV];
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+            sc[j] = a.scale ? a.scale[(int64_t)n * Cin + c0 + j] : 1.f;
+            sh[j] = a.scale ? a.shift[(int64_t)n * Cin + c0 + j] : 0.f;
+        }
+        for (int ox = 0; ox < a.Wout; ++ox) {
+            const int ix = ox - 1 + kw;
+            if (ix < 0 || ix >= a.Win) continue;
+            const T* xp = (const T*)a.src1 + (((int64_t)n * a.Hin + iy) * a.Win + ix) * Cin + c0;
+            float v[EPV];
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) {
+                float t = fmaf(to_f(xp[j]), sc[j], sh[j]);
+                if (a.pro_silu) t = silu_f(t);
+                v[j] = to_f(from_f<T>(t));
+            }
+            const T* dp = dY + (((int64_t)n * a.Hout + oy) * a.Wout + ox) * a.Cout;
+#pragma unroll
+            for (int co = 0; co < 4; ++co) {
+                if (co >= a.Cout) break;
+                const float d = to_f(dp[co]);
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) acc[co][j] = fmaf(d, v[j], acc[co][j]);
+            }
+        }
+    }
+    for (int co = 0; co < a.Cout && co < 4; ++co)
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) atomicAdd(&dW[((int64_t)co * Cin + c0 + j) * 9 + tap], acc[co][j]);
+}
+
+// Cin <= 4 on the NCHW fp32 network input (the first conv): thread <-> cout with 9*Cin accumulators;
+// the 9*Cin input values of a pixel are wave-uniform loads.
+template <typename T>
+__global__ void __launch_bounds__(256) wgrad_cin_small_kernel(ConvArgs a, const T* __restrict__ dY, float* __restrict__ dW, int rows_per_chunk) {
+    const int Cin = a.C1, co = threadIdx.x;
+    if (co >= a.Cout) return;
+    float acc[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) acc[k] = 0.f;
+    const int row_begin = blockIdx.x * rows_per_chunk, row_end = min(row_begin + rows_per_chunk, a.N * a.Hout);
+    const float* x = (const float*)a.src1;
+    for (int row = row_begin; row < row_end; ++row) {
+        const int n = row / a.Hout, oy = row % a.Hout;
+        for (int ox = 0; ox < a.Wout; ++ox) {
+            const float d = to_f(dY[(((int64_t)n * a.Hout + oy) * a.Wout + ox) * a.Cout + co]);
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) {
+                if (ci >= Cin) break;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int iy = oy - 1 + tap / 3, ix = ox - 1 + tap % 3;
+                    float v = 0.f;
+                    if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) v = x[(((int64_t)n * Cin + ci) * a.Hin + iy) * a.Win + ix];
+                    acc[ci * 9 + tap] = fmaf(d, v, acc[ci * 9 + tap]);
+                }
+            }
+        }
+    }
+    for (int ci = 0; ci < Cin && ci < 4; ++ci)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) atomicAdd(&dW[((int64_t)co * Cin + ci) * 9 + tap], acc[ci * 9 + tap]);
+}
+
+bool wgrad_small_supported(int dtype, const ConvArgs& a) {
+    const int EPV = dtype == DMME_BF16 ? 8 : 4;
+    if (a.taps != 9 || a.stride != 1 || a.up || a.C2 || a.dmask) return false;
+    if (a.in_nchw) return a.C1 <= 4 && a.Cout <= 256 && !a.scale && !a.pro_silu;
+    return a.Cout <= 4 && a.C1 % EPV == 0 && 9 * (a.C1 / EPV) <= 256;
+}
+int launch_wgrad_small(int dtype, const ConvArgs& a, const void* dY, float* dW, hipStream_t s) {
+    const int rows = a.N * a.Hout;
+    int chunks = rows < 2048 ? rows : 2048;
+    const int rpc = (rows + chunks - 1) / chunks;
+    chunks = (rows + rpc - 1) / rpc;
+    if (a.in_nchw) {
+        if (dtype == DMME_BF16)
+            hipLaunchKernelGGL(wgrad_cin_small_kernel<bf16>, dim3(chunks), dim3(256), 0, s, a, (const bf16*)dY, dW, rpc);
+        else
+            hipLaunchKernelGGL(wgrad_cin_small_kernel<float>, dim3(chunks), dim3(256), 0, s, a, (const float*)dY, dW, rpc);
+    } else {
+        if (dtype == DMME_BF16)
+            hipLaunchKernelGGL(wgrad_cout_small_kernel<bf16>, dim3(chunks), dim3(256), 0, s, a, (const bf16*)dY, dW, rpc);
+        else
+            hipLaunchKernelGGL(wgrad_cout_small_kernel<float>, dim3(chunks), dim3(256), 0, s, a, (const float*)dY, dW, rpc);
+    }
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
 // ------------------------------------------------------------------ column sums of dY
 // rowsum[n][c] = sum over the image's pixels of dY[n, :, c]  (coalesced over c)
 template <typename T>

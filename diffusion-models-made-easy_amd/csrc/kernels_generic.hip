@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(256) conv_in_kernel(ConvArgs a, int px_per_blo
         const int ox = (int)(p % a.Wout), oy = (int)((p / a.Wout) % a.Hout), n = (int)(p / ((int64_t)a.Wout * a.Hout));
         float acc[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = a.bias[cg + j];
+        for (int j = 0; j < 8; ++j) acc[j] = a.bias ? a.bias[cg + j] : 0.f;
         for (int kh = 0; kh < 3; ++kh) {
             const int iy = oy - 1 + kh;
             if (iy < 0 || iy >= a.Hin) continue;
@@ -106,7 +106,8 @@ __global__ void __launch_bounds__(256) conv_in_kernel(ConvArgs a, int px_per_blo
                 const int ix = ox - 1 + kw;
                 if (ix < 0 || ix >= a.Win) continue;
                 for (int ci = 0; ci < Cin; ++ci) {
-                    const float v = ((const float*)a.src1)[(((int64_t)n * Cin + ci) * a.Hin + iy) * a.Win + ix];
+                    const float v = a.in_nchw ? ((const float*)a.src1)[(((int64_t)n * Cin + ci) * a.Hin + iy) * a.Win + ix]
+                                              : to_f(((const T*)a.src1)[(((int64_t)n * a.Hin + iy) * a.Win + ix) * Cin + ci]);
                     const float* wr = wl + ((kh * 3 + kw) * Cin + ci) * Cout + cg;
                     const float4 w0 = *reinterpret_cast<const float4*>(wr), w1 = *reinterpret_cast<const float4*>(wr + 4);
                     acc[0] = fmaf(v, w0.x, acc[0]); acc[1] = fmaf(v, w0.y, acc[1]);
@@ -123,7 +124,7 @@ __global__ void __launch_bounds__(256) conv_in_kernel(ConvArgs a, int px_per_blo
 }
 
 static bool conv_in_supported(const ConvArgs& a) {
-    return a.in_nchw && !a.out_nchw && a.taps == 9 && a.stride == 1 && !a.up && a.C2 == 0 && a.C1 <= 4 && !a.scale &&
+    return !a.out_nchw && a.taps == 9 && a.stride == 1 && !a.up && a.C2 == 0 && a.C1 <= 4 && !a.scale &&
            !a.pro_silu && !a.dmask && !a.tproj && !a.res1 && !a.out_silu && a.Cout % 8 == 0 && a.Cout <= 2048 &&
            256 % (a.Cout / 8) == 0 && (size_t)9 * a.C1 * a.Cout * 4 <= 48 * 1024;
 }

@@ -29,6 +29,7 @@ struct Param {
     int64_t ref_off = 0;     // elements, fp32 reference-layout flat buffer
     int64_t packed_off = 0;  // bytes
     int64_t packed_bwd_off = -1;  // bytes in the data-gradient weight buffer (conv weights only)
+    int64_t wp_off = -1;          // float offset of this conv weight in the packed-layout gradient image
     bool is_buffer = false;
     bool as_f32 = true;      // stays fp32 in the packed buffer (bias / gamma / beta / freqs)
     int cout = 1, cin = 1, taps = 1;
@@ -49,6 +50,7 @@ struct Op {
     int lin_K = 0, lin_N = 0, lin_w = -1, lin_b = -1, lin_silu = 0;
     // OP_GN
     int gn_src1 = -1, gn_src2 = -1, gn_gamma = -1, gn_beta = -1;
+    int64_t b_rowsum = 0, b_ab = 0;  // backward scratch (bytes in the zeroed region): column sums of dY, GroupNorm channel sums
     int64_t gn_scale = 0, gn_shift = 0, gn_mr = 0;  // workspace offsets: scale/shift [N][C], {mean, rstd} [N][G][2]
     // OP_CONV
     int src1 = -1, src2 = -1;  // tensor ids; -2: network input (NCHW fp32)
@@ -90,7 +92,9 @@ struct dmme_plan {
     int p_l1w = -1, p_l1b = -1, p_l2w = -1, p_l2b = -1;
     int64_t packed_bwd_bytes = 0, bws_bytes = 0;
     std::vector<int64_t> gt_off;           // gradient buffer of every forward tensor
-    int64_t bws_wscratch = 0, bws_gnscratch = 0;
+    int64_t bws_zero = 0, bws_zero_bytes = 0, bws_wimage = 0, bws_gnS = 0;  // region cleared once per backward
+    PackItem* items_unpack_dev = nullptr;
+    int n_items_unpack = 0;
     int64_t bws_tmp = 0, bws_dy = 0, bws_rowsum = 0, bws_dtproj = 0, bws_dtemb = 0, bws_dh1 = 0, bws_z = 0, bws_attP = 0,
             bws_attdS = 0;
     PackItem* items_bwd_dev = nullptr;
@@ -483,13 +487,28 @@ int build_plan(dmme_plan* P) {
                 if (b > att_max) att_max = b;
             }
         }
-        {
-            int64_t wmax = 0;
-            for (const Param& p : P->params)
-                if (p.ndim == 4 && p.numel() > wmax) wmax = p.numel();
-            P->bws_wscratch = balloc(wmax * 4);
+        {   // accumulation scratch, one contiguous region cleared by a single memset per backward:
+            // packed-layout weight-gradient image, per-conv column sums, per-GroupNorm channel sums
+            P->bws_zero = bw;
+            int64_t wfl = 0;
+            for (Param& p : P->params)
+                if (p.ndim == 4) {
+                    p.wp_off = wfl;
+                    wfl += (p.numel() + 63) / 64 * 64;
+                }
+            P->bws_wimage = balloc(wfl * 4);
+            for (Op& o : P->ops) {
+                if (o.kind != OP_CONV) continue;
+                o.b_rowsum = balloc((int64_t)B * P->params[o.w].cout * 4);
+                if (o.gn >= 0) {
+                    const Op& gop = P->ops[o.gn];
+                    const int C = P->tensors[gop.gn_src1].C + (gop.gn_src2 >= 0 ? P->tensors[gop.gn_src2].C : 0);
+                    o.b_ab = balloc((int64_t)B * C * 2 * 4);
+                }
+            }
+            P->bws_zero_bytes = bw - P->bws_zero;
+            P->bws_gnS = balloc((int64_t)B * c.num_groups * 2 * 4);
         }
-        P->bws_gnscratch = balloc(((int64_t)B * 2 * cmax * 2 + (int64_t)B * c.num_groups * 2) * 4);
         P->bws_tmp = balloc(tmp_max);
         P->bws_dy = balloc((int64_t)B * P->H * P->W * c.in_channels * es);
         P->bws_rowsum = balloc((int64_t)B * cmax * 3 * 4);  // qkv convs have 3*C outputs
@@ -543,6 +562,29 @@ int build_pack_items_bwd(dmme_plan* P, std::vector<PackItem>& items) {
             it.row0 = (int32_t)r0;
             it.rows = (int32_t)((p.cout - r0) < rows_per ? (p.cout - r0) : rows_per);
             it.as_f32 = 2;
+            items.push_back(it);
+        }
+    }
+    return DMME_OK;
+}
+
+int build_unpack_items(dmme_plan* P, std::vector<PackItem>& items) {
+    const int64_t CHUNK = 16384;
+    for (const Param& p : P->params) {
+        if (p.wp_off < 0) continue;
+        const int64_t row = (int64_t)p.cin * p.taps;
+        int64_t rows_per = CHUNK / row;
+        if (rows_per < 1) rows_per = 1;
+        for (int64_t r0 = 0; r0 < p.cout; r0 += rows_per) {
+            PackItem it;
+            it.src_off = p.ref_off;  // destination: reference-layout gradient (float offset)
+            it.dst_off = p.wp_off;   // source: packed-layout image (float offset)
+            it.cout = p.cout;
+            it.cin = p.cin;
+            it.taps = p.taps;
+            it.row0 = (int32_t)r0;
+            it.rows = (int32_t)((p.cout - r0) < rows_per ? (p.cout - r0) : rows_per);
+            it.as_f32 = 0;
             items.push_back(it);
         }
     }
@@ -622,6 +664,9 @@ int run_op(const dmme_plan* P, const Op& o, const char* pk, const float* x, cons
         case OP_LINEAR: {
             const char* w = o.lin_w >= 0 ? pk + P->params[o.lin_w].packed_off : pk + P->tproj_w_off;
             const float* b = (const float*)(o.lin_b >= 0 ? pk + P->params[o.lin_b].packed_off : pk + P->tproj_b_off);
+            if (nt > 4)
+                return launch_small_gemm(P->dtype, 0, (const float*)(ws + o.lin_in), o.lin_K, w, o.lin_K, nt, o.lin_N, o.lin_K, b, o.lin_silu,
+                                         (float*)(ws + o.lin_out), o.lin_N, s);
             return launch_linear_wave(P->dtype, (const float*)(ws + o.lin_in), nt, o.lin_K, w, b, o.lin_N, o.lin_silu,
                                       (float*)(ws + o.lin_out), s);
         }
@@ -757,6 +802,11 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
         P->n_items_bwd = (int)bitems.size();
         if (e == hipSuccess) e = hipMalloc((void**)&P->items_bwd_dev, bitems.size() * sizeof(PackItem));
         if (e == hipSuccess) e = hipMemcpy(P->items_bwd_dev, bitems.data(), bitems.size() * sizeof(PackItem), hipMemcpyHostToDevice);
+        std::vector<PackItem> uitems;
+        build_unpack_items(P, uitems);
+        P->n_items_unpack = (int)uitems.size();
+        if (e == hipSuccess) e = hipMalloc((void**)&P->items_unpack_dev, uitems.size() * sizeof(PackItem));
+        if (e == hipSuccess) e = hipMemcpy(P->items_unpack_dev, uitems.data(), uitems.size() * sizeof(PackItem), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             set_error("plan_create: device table setup failed: %s", hipGetErrorString(e));
             delete P;
@@ -771,6 +821,7 @@ DMME_API void dmme_unet_plan_destroy(dmme_plan* plan) {
     if (!plan) return;
     if (plan->items_dev) (void)hipFree(plan->items_dev);
     if (plan->items_bwd_dev) (void)hipFree(plan->items_bwd_dev);
+    if (plan->items_unpack_dev) (void)hipFree(plan->items_unpack_dev);
     delete plan;
 }
 
@@ -884,7 +935,8 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
         written[id] = 1;
         return acc;
     };
-    float* rowsum = (float*)(bws + P->bws_rowsum);
+    DMME_CHECK_HIP(hipMemsetAsync(bws + P->bws_zero, 0, (size_t)P->bws_zero_bytes, s));
+    float* wimage = (float*)(bws + P->bws_wimage);
     float* dtproj = (float*)(bws + P->bws_dtproj);
     char* tmp = bws + P->bws_tmp;
     int rc = launch_nchw_to_nhwc(dt, d_y, B, P->cfg.in_channels, P->H * P->W, bws + P->bws_dy, s);
@@ -911,6 +963,7 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
         const char* dy = o.dst == -2 ? bws + P->bws_dy : gptr(o.dst);
         if (o.dst != -2) DMME_REQUIRE(written[o.dst], DMME_ERR_INVALID, "backward: tensor %d has no gradient", o.dst);
         const int Cin = a.C1 + a.C2;
+        float* rowsum = (float*)(bws + o.b_rowsum);
         // 1. bias and time-embedding-row gradients (column sums of dY)
         if (colsum_fast_supported(dt, a.Hout * a.Wout, a.Cout))
             rc = launch_colsum_fast(dt, dy, B, a.Hout * a.Wout, a.Cout, rowsum, grad_flat + P->params[o.b].ref_off,
@@ -921,7 +974,9 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
         if (rc != DMME_OK) break;
         // 2. weight gradient (reference layout, accumulated)
         if (wgrad_mfma_supported(dt, a))
-            rc = launch_wgrad_mfma(dt, a, dy, (float*)(bws + P->bws_wscratch), grad_flat + P->params[o.w].ref_off, s);
+            rc = launch_wgrad_mfma(dt, a, dy, wimage + P->params[o.w].wp_off, s);
+        else if (wgrad_small_supported(dt, a))
+            rc = launch_wgrad_small(dt, a, dy, grad_flat + P->params[o.w].ref_off, s);
         else
             rc = launch_wgrad_generic(dt, a, dy, grad_flat + P->params[o.w].ref_off, s);
         if (rc != DMME_OK) break;
@@ -953,7 +1008,7 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
                     rc = launch_gn_bwd_fast(dt, tmp, a.src1, a.src2, B, t1.H * t1.W, a.C1, a.C2, G,
                                             (const float*)(pk + P->params[gop.gn_gamma].packed_off), (const float*)(ws + gop.gn_mr), a.scale,
                                             a.shift, a.dmask, a.pro_silu, g1, g2, acc1, acc2, grad_flat + P->params[gop.gn_gamma].ref_off,
-                                            grad_flat + P->params[gop.gn_beta].ref_off, (float*)(bws + P->bws_gnscratch), s);
+                                            grad_flat + P->params[gop.gn_beta].ref_off, (float*)(bws + o.b_ab), (float*)(bws + P->bws_gnS), s);
                 else
                 rc = launch_gn_bwd_generic(dt, tmp, a.src1, a.src2, B, t1.H * t1.W, a.C1, a.C2, G,
                                            (const float*)(pk + P->params[gop.gn_gamma].packed_off), (const float*)(ws + gop.gn_mr),
@@ -973,6 +1028,9 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
         }
     }
     if (rc != DMME_OK) return rc;
+    // fold the packed-layout weight-gradient image into the reference-layout gradients (one launch)
+    rc = launch_wgrad_unpack(P->items_unpack_dev, P->n_items_unpack, wimage, grad_flat, s);
+    if (rc != DMME_OK) return rc;
 
     // ---- time MLP backward (models/ddpm.py:211-217 and the per-block Linear at :101-104) ----
     const int emb = P->cfg.emb_dim, pos = P->cfg.pos_dim, tc = P->tproj_cols;
@@ -983,25 +1041,26 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
     float* dh1 = (float*)(bws + P->bws_dh1);
     float* z = (float*)(bws + P->bws_z);
     for (const auto& tb : P->tblocks) {
-        // dW_block[o][k] += sum_r dtproj[r][col+o] temb[r][k]: gather the block's columns through rowsum scratch
-        // (dtproj is [nt][tc]; the generic kernel wants a dense [nt][cout] matrix)
-        DMME_CHECK_HIP(hipMemcpy2DAsync(rowsum, (size_t)tb.cout * 4, dtproj + tb.col, (size_t)tc * 4, (size_t)tb.cout * 4, (size_t)nt,
-                                        hipMemcpyDeviceToDevice, s));
-        rc = launch_lin_dweight(rowsum, temb, nt, tb.cout, emb, grad_flat + P->params[tb.tw].ref_off,
-                                grad_flat + P->params[tb.tb].ref_off, s);
+        // dW_block[o][k] += sum_r dtproj[r][col+o] temb[r][k];  db_block[o] += sum_r dtproj[r][col+o]
+        rc = launch_small_gemm(dt, 2, dtproj + tb.col, tc, temb, emb, tb.cout, emb, nt, nullptr, 0, grad_flat + P->params[tb.tw].ref_off, emb, s);
+        if (rc == DMME_OK) rc = launch_nsum(dtproj + tb.col, nt, tb.cout, tc, 1, grad_flat + P->params[tb.tb].ref_off, s);
         if (rc != DMME_OK) return rc;
     }
-    rc = launch_lin_dinput(dt, dtproj, pk + P->tproj_w_off, nt, tc, emb, dtemb, s);
+    const float* W2 = (const float*)nullptr;
+    (void)W2;
+    rc = launch_small_gemm(dt, 1, dtproj, tc, pk + P->tproj_w_off, emb, nt, emb, tc, nullptr, 0, dtemb, emb, s);
     if (rc != DMME_OK) return rc;
     // temb = silu(z2), z2 = h1 W2^T + b2
-    rc = launch_linear_wave(dt, h1, nt, emb, pk + P->params[P->p_l2w].packed_off, (const float*)(pk + P->params[P->p_l2b].packed_off), emb, 0, z, s);
+    rc = launch_small_gemm(dt, 0, h1, emb, pk + P->params[P->p_l2w].packed_off, emb, nt, emb, emb, (const float*)(pk + P->params[P->p_l2b].packed_off), 0, z, emb, s);
     if (rc == DMME_OK) rc = launch_silu_bwd(dtemb, z, nt * emb, s);
-    if (rc == DMME_OK) rc = launch_lin_dweight(dtemb, h1, nt, emb, emb, grad_flat + P->params[P->p_l2w].ref_off, grad_flat + P->params[P->p_l2b].ref_off, s);
-    if (rc == DMME_OK) rc = launch_lin_dinput(dt, dtemb, pk + P->params[P->p_l2w].packed_off, nt, emb, emb, dh1, s);
+    if (rc == DMME_OK) rc = launch_small_gemm(dt, 2, dtemb, emb, h1, emb, emb, emb, nt, nullptr, 0, grad_flat + P->params[P->p_l2w].ref_off, emb, s);
+    if (rc == DMME_OK) rc = launch_nsum(dtemb, nt, emb, emb, 1, grad_flat + P->params[P->p_l2b].ref_off, s);
+    if (rc == DMME_OK) rc = launch_small_gemm(dt, 1, dtemb, emb, pk + P->params[P->p_l2w].packed_off, emb, nt, emb, emb, nullptr, 0, dh1, emb, s);
     // h1 = silu(z1), z1 = e W1^T + b1
-    if (rc == DMME_OK) rc = launch_linear_wave(dt, esin, nt, pos, pk + P->params[P->p_l1w].packed_off, (const float*)(pk + P->params[P->p_l1b].packed_off), emb, 0, z, s);
+    if (rc == DMME_OK) rc = launch_small_gemm(dt, 0, esin, pos, pk + P->params[P->p_l1w].packed_off, pos, nt, emb, pos, (const float*)(pk + P->params[P->p_l1b].packed_off), 0, z, emb, s);
     if (rc == DMME_OK) rc = launch_silu_bwd(dh1, z, nt * emb, s);
-    if (rc == DMME_OK) rc = launch_lin_dweight(dh1, esin, nt, emb, pos, grad_flat + P->params[P->p_l1w].ref_off, grad_flat + P->params[P->p_l1b].ref_off, s);
+    if (rc == DMME_OK) rc = launch_small_gemm(dt, 2, dh1, emb, esin, pos, emb, pos, nt, nullptr, 0, grad_flat + P->params[P->p_l1w].ref_off, pos, s);
+    if (rc == DMME_OK) rc = launch_nsum(dh1, nt, emb, emb, 1, grad_flat + P->params[P->p_l1b].ref_off, s);
     return rc;
 }
 

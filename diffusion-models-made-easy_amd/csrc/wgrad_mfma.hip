@@ -175,17 +175,6 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(ConvArgs a, ConvTile g,
     }
 }
 
-// dW_ref[(co*Cin + ci)*taps + tap] += dWp[(co*taps + tap)*Cin + ci]
-__global__ void __launch_bounds__(256) wgrad_unpack_kernel(const float* __restrict__ dWp, float* __restrict__ dW, int Cin, int taps, int64_t total) {
-    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int tap = (int)(e % taps);
-        const int64_t q = e / taps;
-        const int ci = (int)(q % Cin);
-        const int64_t co = q / Cin;
-        dW[e] += dWp[(co * taps + tap) * Cin + ci];
-    }
-}
-
 static bool wg_tile(const ConvArgs& a, ConvTile& g) {
     if (!make_tile(a, WG_PX, 64, g)) return false;
     if (g.TW < 4) return false;  // 4-pixel transposed-read blocks must stay inside one tile row
@@ -207,10 +196,8 @@ bool wgrad_mfma_supported(int dtype, const ConvArgs& a) {
     return lds <= 64 * 1024;
 }
 
-size_t wgrad_scratch_floats(const ConvArgs& a) { return (size_t)a.Cout * a.taps * (a.C1 + a.C2); }
-
 template <typename T>
-static int launch_wgrad_t(const ConvArgs& a, const void* dY, float* dWp, float* dW, hipStream_t s) {
+static int launch_wgrad_t(const ConvArgs& a, const void* dY, float* dWp, hipStream_t s) {
     ConvTile g{};
     DMME_REQUIRE(wg_tile(a, g), DMME_ERR_UNSUPPORTED, "wgrad_mfma: no tile");
     const int Cin = a.C1 + a.C2;
@@ -219,8 +206,6 @@ static int launch_wgrad_t(const ConvArgs& a, const void* dY, float* dWp, float* 
     int nsplit = 768 / base;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > g.tiles_m) nsplit = g.tiles_m;
-    const int64_t total = (int64_t)a.Cout * a.taps * Cin;
-    DMME_CHECK_HIP(hipMemsetAsync(dWp, 0, (size_t)total * sizeof(float), s));
     int shTW = 0, shTH = 0;
     while ((1 << shTW) < g.TW) ++shTW;
     while ((1 << shTH) < g.TH) ++shTH;
@@ -231,16 +216,38 @@ static int launch_wgrad_t(const ConvArgs& a, const void* dY, float* dWp, float* 
     else
         hipLaunchKernelGGL((wgrad_mfma_kernel<T, 1>), grid, dim3(256), lds, s, a, g, (const T*)dY, dWp, nsplit, shTW, shTH);
     DMME_CHECK_LAUNCH();
-    int64_t blocks = (total + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(wgrad_unpack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dWp, dW, Cin, a.taps, total);
-    DMME_CHECK_LAUNCH();
     return DMME_OK;
 }
 
-int launch_wgrad_mfma(int dtype, const ConvArgs& a, const void* dY, float* scratch, float* dW, hipStream_t s) {
+// dWp: this conv's slice of the zero-initialised packed-layout gradient image ([co][tap][ci] fp32); partial
+// sums are added atomically.  launch_wgrad_unpack folds the whole image into the reference-layout gradients.
+int launch_wgrad_mfma(int dtype, const ConvArgs& a, const void* dY, float* dWp, hipStream_t s) {
     DMME_REQUIRE(wgrad_mfma_supported(dtype, a), DMME_ERR_UNSUPPORTED, "wgrad_mfma: unsupported shape");
-    return dtype == DMME_BF16 ? launch_wgrad_t<bf16>(a, dY, scratch, dW, s) : launch_wgrad_t<float>(a, dY, scratch, dW, s);
+    return dtype == DMME_BF16 ? launch_wgrad_t<bf16>(a, dY, dWp, s) : launch_wgrad_t<float>(a, dY, dWp, s);
+}
+
+// table-driven: one workgroup per item (a run of cout rows of one conv weight)
+__global__ void __launch_bounds__(256) wgrad_unpack_table_kernel(const PackItem* __restrict__ items, const float* __restrict__ image,
+                                                                 float* __restrict__ grad_flat) {
+    const PackItem it = items[blockIdx.x];
+    const int64_t row = (int64_t)it.cin * it.taps;
+    const int64_t total = (int64_t)it.rows * row, e0 = (int64_t)it.row0 * row;
+    const float* src = image + it.dst_off;   // float offset of this weight's packed image
+    float* dst = grad_flat + it.src_off;     // float offset of the reference-layout gradient
+    for (int64_t e = threadIdx.x; e < total; e += blockDim.x) {
+        const int64_t g = e0 + e;            // reference index (co*cin + ci)*taps + tap
+        const int tap = (int)(g % it.taps);
+        const int64_t q = g / it.taps;
+        const int ci = (int)(q % it.cin);
+        const int64_t co = q / it.cin;
+        dst[g] += src[(co * it.taps + tap) * it.cin + ci];
+    }
+}
+int launch_wgrad_unpack(const PackItem* items_dev, int n_items, const float* image, float* grad_flat, hipStream_t s) {
+    if (n_items == 0) return DMME_OK;
+    hipLaunchKernelGGL(wgrad_unpack_table_kernel, dim3(n_items), dim3(256), 0, s, items_dev, image, grad_flat);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
 }
 
 }  // namespace dmme

@@ -93,7 +93,7 @@ def roofline_leg(model, x, t_dev, precision):
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(name)
+            traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
         except Exception:  # noqa: BLE001
             traffic = None
     if g["flops"] > 0:

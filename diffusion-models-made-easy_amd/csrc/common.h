@@ -117,6 +117,10 @@ struct ConvArgs {
     int pro_silu, out_silu;
     int nt, tproj_ld, R1;
     int in_nchw, out_nchw;
+    // fused GroupNorm statistics of the OUTPUT tensor (null: off): per (image, spatial tile, group) {mean, M2}
+    // partials, [N][gn_tiles][Cout/gn_cg][2], written by the LDS-staged epilogue; merged by gn_finalize_parts
+    float* gn_part;
+    int gn_cg, gn_tiles;
 };
 
 // ---- kernel launchers (defined in the .hip files) ------------------------------------
@@ -132,6 +136,12 @@ void conv_mfma_label(int dtype, const ConvArgs& a, char* buf, int cap);
 bool conv_pipe_supported(int dtype, const ConvArgs& a);
 int launch_conv_pipe(int dtype, const ConvArgs& a, hipStream_t s);
 void conv_pipe_label(int dtype, const ConvArgs& a, char* buf, int cap);
+// can the kernel that would run this conv also emit GroupNorm partials of its output (group size cg)?
+// on success: tiles = spatial tiles per image, px = pixels per tile (the partial's element count is px*cg)
+bool conv_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px);
+// merge producer partials of one or two (concatenated) tensors into scale/shift (+ mean/rstd)
+int launch_gn_finalize_parts(const float* part1, int tiles1, int cnt1, int C1, const float* part2, int tiles2, int cnt2, int C2, int N, int groups,
+                             const float* gamma, const float* beta, float eps, float* scale, float* shift, float* mean_rstd, hipStream_t s);
 
 // mean_rstd (nullable): [N][groups][2] = {mean, rstd}, kept for the backward pass
 int launch_gn_generic(int dtype, const void* src1, const void* src2, int N, int HW, int C1, int C2, int groups,

@@ -1,5 +1,7 @@
 // Pieces shared by the implicit-GEMM convolution kernels (conv_mfma.hip, conv_pipe.hip).
 #pragma once
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dmme {
@@ -110,7 +112,7 @@ __device__ __forceinline__ uint4 prologue_vec<bf16>(uint4 raw, const float* sc, 
 // `stage` must hold BM*BN floats and no wave may still be reading operand tiles from it.
 template <typename T, int BM, int BN, int MI, int NI, typename PixFn>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MI][NI], int co0, int wn0, int r, int h,
-                                              int wm0, int n0, int TN, PixFn pix_of, float* stage) {
+                                              int wm0, int n0, int TN, PixFn pix_of, float* stage, int tile_s) {
     constexpr int VEC = 16 / sizeof(T);
     const bool uniform_t = !a.tproj || a.nt == 1 || TN == 1;
     if (!a.out_silu && !a.out_nchw && uniform_t && (a.Cout % VEC) == 0) {
@@ -134,6 +136,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
         constexpr int VPR = BN / VEC;  // vectors per pixel row of the tile
         T* __restrict__ dst = (T*)a.dst;
         const T* __restrict__ res = (const T*)a.res1;
+        // fused GroupNorm partials: every thread owns ONE 16-byte channel vector (256 % VPR == 0), so it keeps
+        // running sum / sum of squares of the values it stores (two halves of the vector separately)
+        float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
+        int cnt_items = 0;
         for (int it = threadIdx.x; it < BM * VPR; it += 256) {
             const int m = it / VPR, cg = it % VPR;
             const int co = co0 + cg * VEC;
@@ -141,6 +147,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
             if (opix < 0 || co >= a.Cout) continue;
             const int off = opix * a.Cout + co;
             const float* sp = stage + m * BN + cg * VEC;
+            ++cnt_items;
             if constexpr (sizeof(T) == 4) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(sp);
                 if (res) {
@@ -148,6 +155,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                     v += rv;
                 }
                 *reinterpret_cast<f32x4*>(dst + off) = v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s1a += v[e];
+                    s2a = fmaf(v[e], v[e], s2a);
+                }
             } else {
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
                 float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -160,6 +172,59 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
                 *reinterpret_cast<bf16x8*>(dst + off) = o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {  // statistics of the values the consumer reads back (bf16-rounded)
+                    const float x0 = (float)o[e], x1 = (float)o[4 + e];
+                    s1a += x0;
+                    s2a = fmaf(x0, x0, s2a);
+                    s1b += x1;
+                    s2b = fmaf(x1, x1, s2b);
+                }
+            }
+        }
+        if (a.gn_part) {
+            // per-thread (mean, M2) from <= 64 values (negligible cancellation), exchanged through LDS and merged
+            // with Chan's formula by one thread per group.  TN == 1: the tile is one image.
+            const int cgs = a.gn_cg;
+            const bool split = cgs < VEC;            // bf16, 4-channel groups: the two vector halves are two groups
+            constexpr int HALF = VEC > 4 ? 4 : VEC;
+            float cntA = (float)(cnt_items * HALF), cntB = cntA;
+            if (!split && VEC > 4) {                 // whole vector inside one group: merge the halves first
+                s1a += s1b;
+                s2a += s2b;
+                cntA *= 2.f;
+            }
+            const float meanA = s1a / cntA, m2A = s2a - s1a * meanA;
+            const float meanB = s1b / cntB, m2B = s2b - s1b * meanB;
+            __syncthreads();  // all reads of the staged tile are done: reuse it for the exchange
+            stage[threadIdx.x * 4] = meanA;
+            stage[threadIdx.x * 4 + 1] = m2A;
+            stage[threadIdx.x * 4 + 2] = meanB;
+            stage[threadIdx.x * 4 + 3] = m2B;
+            __syncthreads();
+            const int GT = BN / cgs;  // groups in this cout tile
+            if ((int)threadIdx.x < GT) {
+                const int g = threadIdx.x;
+                constexpr int R = 256 / VPR;  // pixel-row phases sharing one channel vector
+                int v_first, v_count, sub;
+                if (split) {
+                    v_first = g >> 1; v_count = 1; sub = g & 1;
+                } else {
+                    v_count = cgs / VEC; v_first = g * v_count; sub = 0;
+                }
+                float na = 0.f, mean = 0.f, M2 = 0.f;
+                for (int vv = 0; vv < v_count; ++vv)
+                    for (int rr = 0; rr < R; ++rr) {
+                        const float* q = stage + (rr * VPR + v_first + vv) * 4 + 2 * sub;
+                        const float delta = q[0] - mean, tot = na + cntA;
+                        mean += delta * (cntA / tot);
+                        M2 += q[1] + delta * delta * (na * cntA / tot);
+                        na = tot;
+                    }
+                const int G = a.Cout / cgs;
+                float* o = a.gn_part + (((int64_t)n0 * a.gn_tiles + tile_s) * G + (co0 / cgs + g)) * 2;
+                o[0] = mean;
+                o[1] = M2;
             }
         }
         return;
@@ -191,6 +256,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
             }
         }
     }
+}
+
+// tile-selection threshold: smallest workgroup count a tile shape must still produce (tunable for experiments)
+inline int min_wgs() {
+    static int v = [] { const char* e = getenv("DMME_MIN_WGS"); return e ? atoi(e) : 512; }();
+    return v;
+}
+
+// fused statistics need: the staged fast epilogue, one image per tile, whole cout tiles, 16-byte group slices
+inline bool stats_tile_ok(const ConvArgs& a, const ConvTile& g, int BN, int cg, int vec) {
+    return g.TN == 1 && !a.out_silu && !a.out_nchw && a.Cout % BN == 0 && a.Cout % vec == 0 && (cg % vec == 0 || (vec == 8 && cg == 4)) && BN % cg == 0 &&
+           (!a.tproj || a.nt == 1 || g.TN == 1);
 }
 
 inline bool make_tile(const ConvArgs& a, int BM, int BN, ConvTile& g) {

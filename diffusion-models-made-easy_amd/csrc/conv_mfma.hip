@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a, ConvTile g) 
         const int n = n0 + tn;
         return n < a.N ? (n * a.Hout + oy0 + ty) * a.Wout + ox0 + tx : -1;
     };
-    conv_epilogue<T, BM, BN, MI, NI>(a, acc, co0, wn0, r, h, wm0, n0, g.TN, pix_of, reinterpret_cast<float*>(lds));
+    conv_epilogue<T, BM, BN, MI, NI>(a, acc, co0, wn0, r, h, wm0, n0, g.TN, pix_of, reinterpret_cast<float*>(lds), ty_blk * g.tiles_x + tx_blk);
 }
 
 bool conv_mfma_supported(int dtype, const ConvArgs& a) {
@@ -162,7 +162,7 @@ static int pick_tile(const ConvArgs& a, ConvTile& g) {
         if (a.Cout <= 64 && kCand[i][1] > 64) continue;
         pick = i;
         g = t;
-        if ((int64_t)t.tiles_m * t.tiles_n >= 512) break;
+        if ((int64_t)t.tiles_m * t.tiles_n >= min_wgs()) break;
     }
     return pick;
 }
@@ -183,6 +183,20 @@ static int launch_sized(const ConvArgs& a, hipStream_t s) {
     }
     DMME_CHECK_LAUNCH();
     return DMME_OK;
+}
+
+bool conv_pipe_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px);
+
+bool conv_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px) {
+    if (conv_pipe_supported(dtype, a)) return conv_pipe_stats_query(dtype, a, cg, tiles, px);
+    if (!conv_mfma_supported(dtype, a)) return false;
+    ConvTile g{};
+    const int pick = pick_tile(a, g);
+    if (pick < 0) return false;
+    if (!stats_tile_ok(a, g, kCand[pick][1], cg, dtype == DMME_BF16 ? 8 : 4)) return false;
+    *tiles = g.tiles_x * g.tiles_y;
+    *px = kCand[pick][0];
+    return true;
 }
 
 void conv_mfma_label(int dtype, const ConvArgs& a, char* buf, int cap) {

@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_pipe_kernel(ConvArgs a, ConvTi
         const int n = n0 + tn;
         return n < a.N ? (n * a.Hout + oy0 + ty) * a.Wout + ox0 + tx : -1;
     };
-    conv_epilogue<T, BM, BN, MI, NI>(a, acc, co0, wn0, r, h, wm0, n0, g.TN, pix_of, reinterpret_cast<float*>(lds));
+    conv_epilogue<T, BM, BN, MI, NI>(a, acc, co0, wn0, r, h, wm0, n0, g.TN, pix_of, reinterpret_cast<float*>(lds), ty_blk * g.tiles_x + tx_blk);
 }
 
 static const int kPipeCand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
@@ -227,7 +227,7 @@ static int pipe_pick(const ConvArgs& a, ConvTile& g) {
         if (a.Cout <= 64 && kPipeCand[i][1] > 64) continue;
         pick = i;
         g = t;
-        if ((int64_t)t.tiles_m * t.tiles_n >= 512) break;
+        if ((int64_t)t.tiles_m * t.tiles_n >= min_wgs()) break;
     }
     return pick;
 }
@@ -279,6 +279,16 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
 int launch_conv_pipe(int dtype, const ConvArgs& a, hipStream_t s) {
     DMME_REQUIRE(conv_pipe_supported(dtype, a), DMME_ERR_UNSUPPORTED, "conv_pipe: unsupported shape");
     return dtype == DMME_BF16 ? launch_pipe_t<bf16>(a, s) : launch_pipe_t<float>(a, s);
+}
+
+bool conv_pipe_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px) {
+    ConvTile g{};
+    const int pick = pipe_pick(a, g);
+    if (pick < 0) return false;
+    if (!stats_tile_ok(a, g, kPipeCand[pick][1], cg, dtype == DMME_BF16 ? 8 : 4)) return false;
+    *tiles = g.tiles_x * g.tiles_y;
+    *px = kPipeCand[pick][0];
+    return true;
 }
 
 void conv_pipe_label(int dtype, const ConvArgs& a, char* buf, int cap) {

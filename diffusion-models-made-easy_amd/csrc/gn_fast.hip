@@ -131,6 +131,56 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restric
     }
 }
 
+// Merge the per-tile {mean, M2} partials emitted by the producing convolutions (conv_common.h, fused
+// statistics) of one tensor, or of the two tensors of a channel concat, into scale/shift (+ mean/rstd).
+// A consumer group of cg = (C1+C2)/groups channels is a whole number of producer groups (C_i/groups each)
+// of exactly one source; every partial of source i covers cnt_i elements.
+__global__ void __launch_bounds__(256) gn_finalize_parts_kernel(const float* __restrict__ p1, int t1, int cnt1, int C1,
+                                                                const float* __restrict__ p2, int t2, int cnt2, int C2, int N, int groups,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                                float* __restrict__ scale, float* __restrict__ shift,
+                                                                float* __restrict__ mean_rstd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * groups) return;
+    const int n = i / groups, g = i % groups, C = C1 + C2, cg = C / groups;
+    const int c_first = g * cg;
+    const bool second = c_first >= C1;
+    const float* p = second ? p2 : p1;
+    const int tiles = second ? t2 : t1, cs = second ? C2 : C1;
+    const float m = (float)(second ? cnt2 : cnt1);
+    const int fg = cs / groups;                          // producer (fine) group size
+    const int f0 = (second ? c_first - C1 : c_first) / fg, nf = cg / fg;
+    float na = 0.f, mean = 0.f, m2 = 0.f;
+    for (int t = 0; t < tiles; ++t)
+        for (int f = 0; f < nf; ++f) {
+            const float* q = p + (((int64_t)n * tiles + t) * groups + f0 + f) * 2;
+            const float delta = q[0] - mean, tot = na + m;
+            mean += delta * (m / tot);
+            m2 += q[1] + delta * delta * (na * m / tot);
+            na = tot;
+        }
+    const float rstd = 1.0f / sqrtf(m2 / na + eps);
+    if (mean_rstd) {
+        mean_rstd[(int64_t)i * 2] = mean;
+        mean_rstd[(int64_t)i * 2 + 1] = rstd;
+    }
+    for (int j = 0; j < cg; ++j) {
+        const int c = c_first + j;
+        const float a = rstd * gamma[c];
+        scale[(int64_t)n * C + c] = a;
+        shift[(int64_t)n * C + c] = beta[c] - mean * a;
+    }
+}
+
+int launch_gn_finalize_parts(const float* part1, int tiles1, int cnt1, int C1, const float* part2, int tiles2, int cnt2, int C2, int N, int groups,
+                             const float* gamma, const float* beta, float eps, float* scale, float* shift, float* mean_rstd, hipStream_t s) {
+    const int tot = N * groups;
+    hipLaunchKernelGGL(gn_finalize_parts_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, part1, tiles1, cnt1, C1, part2, tiles2, cnt2, C2, N,
+                       groups, gamma, beta, eps, scale, shift, mean_rstd);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
 static bool gn_geometry(int dtype, int HW, int C1, int C2, int groups, int& chunk_px, int& nsweeps, int& nchunks) {
     const int EPV = dtype == DMME_BF16 ? 8 : 4;
     const int C = C1 + C2;

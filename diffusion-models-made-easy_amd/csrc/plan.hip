@@ -1,6 +1,7 @@
 // Host side of libdmme_hip: the UNet execution plan (layer graph, parameter table,
 // packed-weight layout, workspace layout, launch sequence) and the extern "C" API.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -39,6 +40,9 @@ struct Param {
 struct Tensor {  // an activation in the workspace, NHWC in the compute dtype
     int64_t off = 0;
     int C = 0, H = 0, W = 0;
+    // GroupNorm partials emitted by the producing conv's epilogue (-1: none): [B][tiles][G][2] floats
+    int64_t stats_off = -1;
+    int stats_tiles = 0, stats_cnt = 0;
 };
 
 enum OpKind { OP_SINUS, OP_LINEAR, OP_GN, OP_CONV, OP_ATTN };
@@ -651,8 +655,57 @@ void fill_conv(const dmme_plan* P, const Op& o, const char* packed, const float*
         a.dst = y;
         a.out_nchw = 1;
     } else {
-        a.dst = ws + P->tensors[o.dst].off;
+        const Tensor& td = P->tensors[o.dst];
+        a.dst = ws + td.off;
+        if (td.stats_off >= 0) {
+            a.gn_part = (float*)(ws + td.stats_off);
+            a.gn_cg = td.C / P->cfg.num_groups;
+            a.gn_tiles = td.stats_tiles;
+        }
     }
+}
+
+// can this GroupNorm be finalised from the partials its producers emitted?
+bool gn_from_parts(const dmme_plan* P, const Op& o) {
+    const Tensor& t1 = P->tensors[o.gn_src1];
+    if (t1.stats_off < 0) return false;
+    const int G = P->cfg.num_groups;
+    int C = t1.C;
+    if (o.gn_src2 >= 0) {
+        const Tensor& t2 = P->tensors[o.gn_src2];
+        if (t2.stats_off < 0) return false;
+        C += t2.C;
+        const int cg = C / G;
+        if (t1.C % cg || cg % (t1.C / G) || cg % (t2.C / G)) return false;
+    }
+    return true;
+}
+
+// decide which conv outputs carry fused GroupNorm partials (needs the launch-time tile choice) and give them room
+void assign_stats(dmme_plan* P) {
+    std::vector<char> wanted(P->tensors.size(), 0);
+    for (const Op& o : P->ops)
+        if (o.kind == OP_GN) {
+            wanted[o.gn_src1] = 1;
+            if (o.gn_src2 >= 0) wanted[o.gn_src2] = 1;
+        }
+    const int G = P->cfg.num_groups;
+    int64_t ws = P->ws_bytes;
+    for (const Op& o : P->ops) {
+        if (o.kind != OP_CONV || o.dst < 0 || !wanted[o.dst]) continue;
+        Tensor& td = P->tensors[o.dst];
+        if (td.C % G) continue;
+        ConvArgs a{};
+        fill_conv(P, o, (const char*)4096, (const float*)4096, (float*)4096, (char*)4096, nullptr, 1, a);
+        a.nt = o.tproj_col >= 0 ? P->B : 0;  // training adds one time-embedding row per image
+        int tiles = 0, px = 0;
+        if (!conv_stats_query(P->dtype, a, td.C / G, &tiles, &px)) continue;
+        td.stats_tiles = tiles;
+        td.stats_cnt = px * (td.C / G);
+        td.stats_off = ws;
+        ws = align_up(ws + (int64_t)P->B * tiles * G * 2 * 4, 256);
+    }
+    P->ws_bytes = ws;
 }
 
 int run_op(const dmme_plan* P, const Op& o, const char* pk, const float* x, const int64_t* t, int nt, float* y,
@@ -679,6 +732,13 @@ int run_op(const dmme_plan* P, const Op& o, const char* pk, const float* x, cons
             const float* bet = (const float*)(pk + P->params[o.gn_beta].packed_off);
             float* sc = (float*)(ws + o.gn_scale);
             float* sh = (float*)(ws + o.gn_shift);
+            if (gn_from_parts(P, o)) {
+                const Tensor* t2 = o.gn_src2 >= 0 ? &P->tensors[o.gn_src2] : nullptr;
+                return launch_gn_finalize_parts((const float*)(ws + t1.stats_off), t1.stats_tiles, t1.stats_cnt, t1.C,
+                                                t2 ? (const float*)(ws + t2->stats_off) : nullptr, t2 ? t2->stats_tiles : 0,
+                                                t2 ? t2->stats_cnt : 0, C2, P->B, P->cfg.num_groups, gam, bet, 1e-5f, sc, sh,
+                                                (float*)(ws + o.gn_mr), s);
+            }
             if (gn_fast_supported(P->dtype, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups))
                 return launch_gn_fast(P->dtype, s1, s2, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups, gam, bet, 1e-5f, sc,
                                       sh, (float*)(ws + o.gn_mr), (float*)(ws + P->ws_gnpart), s);
@@ -723,8 +783,13 @@ void op_account(const dmme_plan* P, const Op& o, char* label, int cap, double* f
             const Tensor& t1 = P->tensors[o.gn_src1];
             const int C = t1.C + (o.gn_src2 >= 0 ? P->tensors[o.gn_src2].C : 0);
             const bool fast = gn_fast_supported(P->dtype, P->B, t1.H * t1.W, t1.C, C - t1.C, P->cfg.num_groups);
-            snprintf(label, cap, fast ? "gn_partial_kernel<%s>" : "gn_generic_kernel<%s>", tn);
-            *bytes = B * t1.H * t1.W * C * es + 2.0 * B * C * 4;
+            if (gn_from_parts(P, o)) {
+                snprintf(label, cap, "gn_finalize_parts_kernel");
+                *bytes = 2.0 * B * C * 4;
+            } else {
+                snprintf(label, cap, fast ? "gn_partial_kernel<%s>" : "gn_generic_kernel<%s>", tn);
+                *bytes = B * t1.H * t1.W * C * es + 2.0 * B * C * 4;
+            }
             break;
         }
         case OP_CONV: {
@@ -790,6 +855,7 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
         delete P;
         return rc;
     }
+    if (!getenv("DMME_NO_FUSED_GN")) assign_stats(P);
     if (device >= 0) {
         std::vector<PackItem> items;
         build_pack_items(P, items);

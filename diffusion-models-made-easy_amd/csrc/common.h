@@ -136,6 +136,11 @@ void conv_mfma_label(int dtype, const ConvArgs& a, char* buf, int cap);
 bool conv_pipe_supported(int dtype, const ConvArgs& a);
 int launch_conv_pipe(int dtype, const ConvArgs& a, hipStream_t s);
 void conv_pipe_label(int dtype, const ConvArgs& a, char* buf, int cap);
+// software-pipelined 1x1 variant (conv1x1_pipe.hip); preferred for taps == 1
+bool conv1x1_pipe_supported(int dtype, const ConvArgs& a);
+int launch_conv1x1_pipe(int dtype, const ConvArgs& a, hipStream_t s);
+void conv1x1_pipe_label(int dtype, const ConvArgs& a, char* buf, int cap);
+bool conv1x1_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px);
 // can the kernel that would run this conv also emit GroupNorm partials of its output (group size cg)?
 // on success: tiles = spatial tiles per image, px = pixels per tile (the partial's element count is px*cg)
 bool conv_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px);

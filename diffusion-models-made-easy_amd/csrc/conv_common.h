@@ -19,6 +19,7 @@ struct ConvTile {  // host-computed geometry, passed by value
     int tiles_x, tiles_y; // tiles per image
     int tiles_m, tiles_n;
     int a_rows;           // TN*HH*HWd
+    unsigned magic_px, magic_w;  // ceil(2^32 / (HH*HWd)), ceil(2^32 / HWd): exact x/d by __umulhi for x*d < 2^32
 };
 
 template <typename T>
@@ -272,7 +273,9 @@ inline bool stats_tile_ok(const ConvArgs& a, const ConvTile& g, int BN, int cg, 
 
 inline bool make_tile(const ConvArgs& a, int BM, int BN, ConvTile& g) {
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-    int TW = a.Wout < 16 ? a.Wout : 16;
+    // 32-wide tiles when the image is at least 32 wide: the 32 pixels of an MFMA row tile are then consecutive halo
+    // rows, which the XOR swizzle keeps conflict-free (a 16-wide tile wraps to the next pixel row mid-fragment)
+    int TW = a.Wout < 16 ? a.Wout : ((a.Wout % 32 == 0 && BM >= 128 && a.stride == 1) ? 32 : 16);
     if (!pow2(TW) || a.Wout % TW) return false;
     if (BM % TW) return false;
     int TH = BM / TW;
@@ -290,6 +293,8 @@ inline bool make_tile(const ConvArgs& a, int BM, int BN, ConvTile& g) {
     g.tiles_m = g.tiles_x * g.tiles_y * ((a.N + g.TN - 1) / g.TN);
     g.tiles_n = (a.Cout + BN - 1) / BN;
     g.a_rows = g.TN * g.HH * g.HWd;
+    g.magic_px = (unsigned)((0x100000000ull + (unsigned)(g.HH * g.HWd) - 1) / (unsigned)(g.HH * g.HWd));
+    g.magic_w = (unsigned)((0x100000000ull + (unsigned)g.HWd - 1) / (unsigned)g.HWd);
     return true;
 }
 

@@ -188,6 +188,7 @@ static int launch_sized(const ConvArgs& a, hipStream_t s) {
 bool conv_pipe_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px);
 
 bool conv_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px) {
+    if (conv1x1_pipe_supported(dtype, a)) return conv1x1_stats_query(dtype, a, cg, tiles, px);
     if (conv_pipe_supported(dtype, a)) return conv_pipe_stats_query(dtype, a, cg, tiles, px);
     if (!conv_mfma_supported(dtype, a)) return false;
     ConvTile g{};

@@ -19,12 +19,14 @@
 
 namespace dmme {
 
-constexpr int PIPE_UA = 8;  // halo 16-byte units a thread may own (a_rows * 8 <= 2048)
 
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * ROW_DATA + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <typename T, int BM, int BN>
-__global__ void __launch_bounds__(256, 2) conv3x3_pipe_kernel(ConvArgs a, ConvTile g, int shTW, int shTH) {
+// GT: taps staged per barrier interval (3 = one kernel row, 9 = the whole 3x3 filter: fewer, longer intervals for
+//     layers whose per-interval matrix work is too short to hide a global-load round trip);
+// UA: halo 16-byte units a thread may own (a_rows * 8 <= 256 * UA).
+template <typename T, int BM, int BN, int GT, int PIPE_UA>
+__global__ void __launch_bounds__(256, GT == 9 ? 1 : 2) conv3x3_pipe_kernel(ConvArgs a, ConvTile g, int shTW, int shTH) {
     constexpr int KC = Frag<T>::KC, EPV = Frag<T>::EPV;
     constexpr int MI = BM / 64, NI = BN / 64;
     constexpr int UB = BN / 32;  // filter units per thread per tap
@@ -57,9 +59,9 @@ __global__ void __launch_bounds__(256, 2) conv3x3_pipe_kernel(ConvArgs a, ConvTi
             a_pix[i] = -2;
             a_ss[i] = 0;
             if (row < g.a_rows) {
-                const int tn = row / halo_px, rem = row - tn * halo_px;
-                const int hy = rem / g.HWd, hx = rem - hy * g.HWd;
-                const int n = n0 + tn, iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+                const int tn = (int)__umulhi((unsigned)row, g.magic_px), rem = row - tn * halo_px;
+                const int hy = (int)__umulhi((unsigned)rem, g.magic_w), hx = rem - hy * g.HWd;
+                const int n = n0 + tn, iy = oy0 * a.stride - 1 + hy, ix = ox0 * a.stride - 1 + hx;
                 a_pix[i] = -1;
                 if (n < a.N && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv && !(a.up == 2 && ((iy | ix) & 1))) {
                     const int sy = a.up ? (iy >> 1) : iy, sx = a.up ? (ix >> 1) : ix;
@@ -81,7 +83,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_pipe_kernel(ConvArgs a, ConvTi
     for (int mi = 0; mi < MI; ++mi) {
         const int m = wm0 + mi * 32 + r;
         const int tx = m & mTW, ty = (m >> shTW) & mTH, tn = m >> (shTW + shTH);
-        a_row[mi] = (tn * g.HH + ty) * g.HWd + tx;
+        a_row[mi] = (tn * g.HH + ty * a.stride) * g.HWd + tx * a.stride;
     }
     int b_base[NI], b_swz[NI];
 #pragma unroll
@@ -100,7 +102,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_pipe_kernel(ConvArgs a, ConvTi
             for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.f;
 
     uint4 areg[PIPE_UA];
-    uint4 breg[3][UB];
+    uint4 breg[GT][UB];
     const T* wbase = (const T*)a.w;
 
     auto load_A = [&](int c0) {
@@ -128,16 +130,16 @@ __global__ void __launch_bounds__(256, 2) conv3x3_pipe_kernel(ConvArgs a, ConvTi
     };
     auto load_B = [&](int c0, int grp) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < GT; ++j)
 #pragma unroll
             for (int k = 0; k < UB; ++k) {
                 breg[j][k] = make_uint4(0u, 0u, 0u, 0u);
-                if (b_off[k] >= 0) breg[j][k] = *reinterpret_cast<const uint4*>(wbase + b_off[k] + (grp * 3 + j) * Cin + c0);
+                if (b_off[k] >= 0) breg[j][k] = *reinterpret_cast<const uint4*>(wbase + b_off[k] + (grp * GT + j) * Cin + c0);
             }
     };
     auto store_B = [&]() {
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < GT; ++j)
 #pragma unroll
             for (int k = 0; k < UB; ++k)
                 *reinterpret_cast<uint4*>(ldsB + j * BN * ROW_DATA + swz_off(urow + 32 * k, cu)) = breg[j][k];
@@ -151,22 +153,24 @@ __global__ void __launch_bounds__(256, 2) conv3x3_pipe_kernel(ConvArgs a, ConvTi
     __syncthreads();
 
     const int nchunks = Cin / KC;
+    constexpr int NG = 9 / GT;  // groups per Cin chunk
 #pragma unroll 1
     for (int ch = 0; ch < nchunks; ++ch) {
 #pragma unroll 1
-        for (int grp = 0; grp < 3; ++grp) {
+        for (int grp = 0; grp < NG; ++grp) {
             // issue the next group's loads before the matrix work
-            const bool last_grp = grp == 2;
+            const bool last_grp = grp == NG - 1;
             const bool more = !(last_grp && ch == nchunks - 1);
             const int nc0 = (last_grp ? ch + 1 : ch) * KC;
             if (more) {
                 load_B(nc0, last_grp ? 0 : grp + 1);
                 if (last_grp) load_A(nc0);
             }
-            // ---- 3 taps x KC of matrix work out of LDS ----
+            // ---- GT taps x KC of matrix work out of LDS ----
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int tap_off = grp * g.HWd + j;
+            for (int j = 0; j < GT; ++j) {
+                const int tap = grp * GT + j;
+                const int tap_off = (tap / 3) * g.HWd + (tap % 3);
                 int abase[MI], aswz[MI];
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
@@ -208,8 +212,11 @@ __global__ void __launch_bounds__(256, 2) conv3x3_pipe_kernel(ConvArgs a, ConvTi
     conv_epilogue<T, BM, BN, MI, NI>(a, acc, co0, wn0, r, h, wm0, n0, g.TN, pix_of, reinterpret_cast<float*>(lds), ty_blk * g.tiles_x + tx_blk);
 }
 
-static const int kPipeCand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
-static size_t pipe_lds(const ConvTile& g, int BN) { return (size_t)g.a_rows * ROW_DATA + (size_t)3 * BN * ROW_DATA; }  // >= BM*BN*4 for every candidate tile
+// candidate kernels: {BM, BN, GT}; the 9-tap variant serves layers with too little work per interval
+// (few workgroups or stride 2) and owns a larger LDS footprint
+static const int kPipeCand[4][3] = {{128, 128, 3}, {128, 64, 3}, {64, 64, 3}, {64, 64, 9}};
+static const int kPipeUA[4] = {8, 8, 8, 10};
+static size_t pipe_lds(const ConvTile& g, int BN, int GT) { return (size_t)g.a_rows * ROW_DATA + (size_t)GT * BN * ROW_DATA; }  // >= BM*BN*4 always
 
 static int ilog2(int v) {
     int s = 0;
@@ -217,24 +224,39 @@ static int ilog2(int v) {
     return s;
 }
 
+static bool pipe_fits(const ConvArgs& a, int i, ConvTile& t) {
+    if (!make_tile(a, kPipeCand[i][0], kPipeCand[i][1], t)) return false;
+    if (t.a_rows * 8 > 256 * kPipeUA[i]) return false;
+    if (pipe_lds(t, kPipeCand[i][1], kPipeCand[i][2]) > (kPipeCand[i][2] == 9 ? 128 : 80) * 1024) return false;
+    if (a.Cout <= 64 && kPipeCand[i][1] > 64) return false;
+    return true;
+}
+
 static int pipe_pick(const ConvArgs& a, ConvTile& g) {
     int pick = -1;
-    for (int i = 0; i < 3; ++i) {
+    if (a.stride == 1)
+        for (int i = 0; i < 3; ++i) {
+            ConvTile t;
+            if (!pipe_fits(a, i, t)) continue;
+            pick = i;
+            g = t;
+            if ((int64_t)t.tiles_m * t.tiles_n >= min_wgs()) break;
+        }
+    // fewer workgroups than two per CU (or stride 2): nothing overlaps a load round trip but this workgroup's own
+    // matrix work, so stage the whole 3x3 filter per interval
+    if (pick < 0 || (pick == 2 && (int64_t)g.tiles_m * g.tiles_n < 2 * 256)) {
         ConvTile t;
-        if (!make_tile(a, kPipeCand[i][0], kPipeCand[i][1], t)) continue;
-        if (t.a_rows * 8 > 256 * PIPE_UA) continue;
-        if (pipe_lds(t, kPipeCand[i][1]) > 80 * 1024) continue;
-        if (a.Cout <= 64 && kPipeCand[i][1] > 64) continue;
-        pick = i;
-        g = t;
-        if ((int64_t)t.tiles_m * t.tiles_n >= min_wgs()) break;
+        if (pipe_fits(a, 3, t)) {
+            pick = 3;
+            g = t;
+        }
     }
     return pick;
 }
 
 bool conv_pipe_supported(int dtype, const ConvArgs& a) {
     if (!conv_mfma_supported(dtype, a)) return false;
-    if (a.taps != 9 || a.stride != 1) return false;
+    if (a.taps != 9 || (a.stride != 1 && a.stride != 2)) return false;
     if ((int64_t)a.Cout * 9 * (a.C1 + a.C2) >= (1ll << 31)) return false;
     if ((int64_t)a.N * a.Hin * a.Win >= (1ll << 31)) return false;
     ConvTile g;
@@ -253,24 +275,25 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
     const int pick = pipe_pick(a, g);
     DMME_REQUIRE(pick >= 0, DMME_ERR_UNSUPPORTED, "conv_pipe: no tile fits");
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
-    const size_t lds = pipe_lds(g, kPipeCand[pick][1]);
+    const size_t lds = pipe_lds(g, kPipeCand[pick][1], kPipeCand[pick][2]);
     const int shTW = ilog2(g.TW), shTH = ilog2(g.TH);
-    static bool attr_done[3] = {false, false, false};
+    static bool attr_done[4] = {false, false, false, false};
     int rc = DMME_OK;
+#define DMME_PIPE_CASE(IDX, BM_, BN_, GT_, UA_, LIM)                                                                          \
+    case IDX:                                                                                                                 \
+        if (!attr_done[IDX]) {                                                                                                \
+            rc = set_lds_limit(conv3x3_pipe_kernel<T, BM_, BN_, GT_, UA_>, (LIM) * 1024);                                     \
+            attr_done[IDX] = rc == DMME_OK;                                                                                   \
+        }                                                                                                                     \
+        if (rc == DMME_OK) hipLaunchKernelGGL((conv3x3_pipe_kernel<T, BM_, BN_, GT_, UA_>), grid, dim3(256), lds, s, a, g, shTW, shTH); \
+        break;
     switch (pick) {
-        case 0:
-            if (!attr_done[0]) { rc = set_lds_limit(conv3x3_pipe_kernel<T, 128, 128>, 80 * 1024); attr_done[0] = rc == DMME_OK; }
-            if (rc == DMME_OK) hipLaunchKernelGGL((conv3x3_pipe_kernel<T, 128, 128>), grid, dim3(256), lds, s, a, g, shTW, shTH);
-            break;
-        case 1:
-            if (!attr_done[1]) { rc = set_lds_limit(conv3x3_pipe_kernel<T, 128, 64>, 80 * 1024); attr_done[1] = rc == DMME_OK; }
-            if (rc == DMME_OK) hipLaunchKernelGGL((conv3x3_pipe_kernel<T, 128, 64>), grid, dim3(256), lds, s, a, g, shTW, shTH);
-            break;
-        default:
-            if (!attr_done[2]) { rc = set_lds_limit(conv3x3_pipe_kernel<T, 64, 64>, 80 * 1024); attr_done[2] = rc == DMME_OK; }
-            if (rc == DMME_OK) hipLaunchKernelGGL((conv3x3_pipe_kernel<T, 64, 64>), grid, dim3(256), lds, s, a, g, shTW, shTH);
-            break;
+        DMME_PIPE_CASE(0, 128, 128, 3, 8, 80)
+        DMME_PIPE_CASE(1, 128, 64, 3, 8, 80)
+        DMME_PIPE_CASE(2, 64, 64, 3, 8, 80)
+        DMME_PIPE_CASE(3, 64, 64, 9, 10, 128)
     }
+#undef DMME_PIPE_CASE
     if (rc != DMME_OK) return rc;
     DMME_CHECK_LAUNCH();
     return DMME_OK;
@@ -294,8 +317,9 @@ bool conv_pipe_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int
 void conv_pipe_label(int dtype, const ConvArgs& a, char* buf, int cap) {
     ConvTile g{};
     const int pick = pipe_pick(a, g);
-    snprintf(buf, (size_t)cap, "conv3x3_pipe_kernel<%s,%d,%d>", dtype == DMME_BF16 ? "bf16" : "float",
-             pick >= 0 ? kPipeCand[pick][0] : 0, pick >= 0 ? kPipeCand[pick][1] : 0);
+    snprintf(buf, (size_t)cap, "conv3x3_pipe_kernel<%s,%d,%d,%d,%d>", dtype == DMME_BF16 ? "bf16" : "float",
+             pick >= 0 ? kPipeCand[pick][0] : 0, pick >= 0 ? kPipeCand[pick][1] : 0, pick >= 0 ? kPipeCand[pick][2] : 0,
+             pick >= 0 ? kPipeUA[pick] : 0);
 }
 
 }  // namespace dmme

@@ -596,6 +596,7 @@ int build_unpack_items(dmme_plan* P, std::vector<PackItem>& items) {
 }
 
 int run_any_conv(int dtype, const ConvArgs& a, hipStream_t s) {
+    if (conv1x1_pipe_supported(dtype, a)) return launch_conv1x1_pipe(dtype, a, s);
     if (conv_pipe_supported(dtype, a)) return launch_conv_pipe(dtype, a, s);
     if (conv_mfma_supported(dtype, a)) return launch_conv_mfma(dtype, a, s);
     return launch_conv_generic(dtype, a, s);
@@ -748,9 +749,7 @@ int run_op(const dmme_plan* P, const Op& o, const char* pk, const float* x, cons
         case OP_CONV: {
             ConvArgs a{};
             fill_conv(P, o, pk, x, y, ws, drop_masks, nt, a);
-            if (conv_pipe_supported(P->dtype, a)) return launch_conv_pipe(P->dtype, a, s);
-            if (conv_mfma_supported(P->dtype, a)) return launch_conv_mfma(P->dtype, a, s);
-            return launch_conv_generic(P->dtype, a, s);
+            return run_any_conv(P->dtype, a, s);
         }
         case OP_ATTN: {
             const Tensor& q = P->tensors[o.at_qkv];
@@ -795,7 +794,9 @@ void op_account(const dmme_plan* P, const Op& o, char* label, int cap, double* f
         case OP_CONV: {
             ConvArgs a{};
             fill_conv(P, o, (const char*)4096, (const float*)4096, (float*)4096, (char*)4096, nullptr, 1, a);
-            if (conv_pipe_supported(P->dtype, a))
+            if (conv1x1_pipe_supported(P->dtype, a))
+                conv1x1_pipe_label(P->dtype, a, label, cap);
+            else if (conv_pipe_supported(P->dtype, a))
                 conv_pipe_label(P->dtype, a, label, cap);
             else if (conv_mfma_supported(P->dtype, a))
                 conv_mfma_label(P->dtype, a, label, cap);
@@ -1215,6 +1216,7 @@ DMME_API int dmme_conv2d(const dmme_conv_desc* d, const void* src1, const void* 
     a.pro_silu = d->pro_silu; a.out_silu = d->out_silu; a.nt = d->nt; a.tproj_ld = d->tproj_ld;
     a.in_nchw = d->in_nchw; a.out_nchw = d->out_nchw;
     if (d->force_generic == 2 && conv_mfma_supported(d->dtype, a)) return launch_conv_mfma(d->dtype, a, (hipStream_t)stream);
+    if (!d->force_generic && conv1x1_pipe_supported(d->dtype, a)) return launch_conv1x1_pipe(d->dtype, a, (hipStream_t)stream);
     if (!d->force_generic && conv_pipe_supported(d->dtype, a)) return launch_conv_pipe(d->dtype, a, (hipStream_t)stream);
     if (!d->force_generic && conv_mfma_supported(d->dtype, a)) return launch_conv_mfma(d->dtype, a, (hipStream_t)stream);
     return launch_conv_generic(d->dtype, a, (hipStream_t)stream);

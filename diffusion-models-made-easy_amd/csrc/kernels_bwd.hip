@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) wgrad_cout_small_kernel(ConvArgs a, const
 #pragma unroll
             for (int j = 0; j < EPV; ++j) {
                 float t = fmaf(to_f(xp[j]), sc[j], sh[j]);
-                if (a.pro_silu) t = silu_f(t);
+                if (a.pro_silu) t = sizeof(T) == 2 ? silu_fast(t) : silu_f(t);  // same SiLU flavour as the forward prologue
                 v[j] = to_f(from_f<T>(t));
             }
             const T* dp = dY + (((int64_t)n * a.Hout + oy) * a.Wout + ox) * a.Cout;
@@ -140,13 +140,14 @@ __global__ void __launch_bounds__(256) wgrad_cout_small_kernel(ConvArgs a, const
 
 // Cin <= 4 on the NCHW fp32 network input (the first conv): thread <-> cout with 9*Cin accumulators;
 // the 9*Cin input values of a pixel are wave-uniform loads.
-template <typename T>
+template <typename T, int CIN>
 __global__ void __launch_bounds__(256) wgrad_cin_small_kernel(ConvArgs a, const T* __restrict__ dY, float* __restrict__ dW, int rows_per_chunk) {
-    const int Cin = a.C1, co = threadIdx.x;
+    constexpr int Cin = CIN;
+    const int co = threadIdx.x;
     if (co >= a.Cout) return;
-    float acc[36];
+    float acc[CIN * 9];
 #pragma unroll
-    for (int k = 0; k < 36; ++k) acc[k] = 0.f;
+    for (int k = 0; k < CIN * 9; ++k) acc[k] = 0.f;
     const int row_begin = blockIdx.x * rows_per_chunk, row_end = min(row_begin + rows_per_chunk, a.N * a.Hout);
     const float* x = (const float*)a.src1;
     for (int row = row_begin; row < row_end; ++row) {
@@ -154,8 +155,7 @@ __global__ void __launch_bounds__(256) wgrad_cin_small_kernel(ConvArgs a, const 
         for (int ox = 0; ox < a.Wout; ++ox) {
             const float d = to_f(dY[(((int64_t)n * a.Hout + oy) * a.Wout + ox) * a.Cout + co]);
 #pragma unroll
-            for (int ci = 0; ci < 4; ++ci) {
-                if (ci >= Cin) break;
+            for (int ci = 0; ci < CIN; ++ci) {
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     const int iy = oy - 1 + tap / 3, ix = ox - 1 + tap % 3;
@@ -166,7 +166,8 @@ __global__ void __launch_bounds__(256) wgrad_cin_small_kernel(ConvArgs a, const 
             }
         }
     }
-    for (int ci = 0; ci < Cin && ci < 4; ++ci)
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) atomicAdd(&dW[((int64_t)co * Cin + ci) * 9 + tap], acc[ci * 9 + tap]);
 }
@@ -179,14 +180,17 @@ bool wgrad_small_supported(int dtype, const ConvArgs& a) {
 }
 int launch_wgrad_small(int dtype, const ConvArgs& a, const void* dY, float* dW, hipStream_t s) {
     const int rows = a.N * a.Hout;
-    int chunks = rows < 2048 ? rows : 2048;
+    int chunks = rows < 256 ? rows : 256;  // few, long chunks: every chunk ends in one atomic per weight element (contended addresses)
     const int rpc = (rows + chunks - 1) / chunks;
     chunks = (rows + rpc - 1) / rpc;
     if (a.in_nchw) {
-        if (dtype == DMME_BF16)
-            hipLaunchKernelGGL(wgrad_cin_small_kernel<bf16>, dim3(chunks), dim3(256), 0, s, a, (const bf16*)dY, dW, rpc);
-        else
-            hipLaunchKernelGGL(wgrad_cin_small_kernel<float>, dim3(chunks), dim3(256), 0, s, a, (const float*)dY, dW, rpc);
+#define DMME_WCIN(TT, CC) hipLaunchKernelGGL((wgrad_cin_small_kernel<TT, CC>), dim3(chunks), dim3(256), 0, s, a, (const TT*)dY, dW, rpc)
+        if (dtype == DMME_BF16) {
+            switch (a.C1) { case 1: DMME_WCIN(bf16, 1); break; case 2: DMME_WCIN(bf16, 2); break; case 3: DMME_WCIN(bf16, 3); break; default: DMME_WCIN(bf16, 4); }
+        } else {
+            switch (a.C1) { case 1: DMME_WCIN(float, 1); break; case 2: DMME_WCIN(float, 2); break; case 3: DMME_WCIN(float, 3); break; default: DMME_WCIN(float, 4); }
+        }
+#undef DMME_WCIN
     } else {
         if (dtype == DMME_BF16)
             hipLaunchKernelGGL(wgrad_cout_small_kernel<bf16>, dim3(chunks), dim3(256), 0, s, a, (const bf16*)dY, dW, rpc);

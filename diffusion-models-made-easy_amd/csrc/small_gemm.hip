@@ -12,7 +12,7 @@ enum { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
 
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256) small_gemm_kernel(const float* __restrict__ A, int lda, const void* __restrict__ Bv, int ldb, int M, int N,
-                                                         int K, const float* __restrict__ bias, int out_silu, float* __restrict__ Cm, int ldc) {
+                                                         int K, const float* __restrict__ bias, int out_silu, float* __restrict__ Cm, int ldc, int ksplit) {
     __shared__ float As[16][64 + 4];
     __shared__ float Bs[16][64 + 4];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
@@ -22,7 +22,8 @@ __global__ void __launch_bounds__(256) small_gemm_kernel(const float* __restrict
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-    for (int k0 = 0; k0 < K; k0 += 16) {
+    // split-K: blockIdx.z owns every ksplit-th K step and adds its partial product atomically (C zeroed by the caller)
+    for (int k0 = blockIdx.z * 16; k0 < K; k0 += 16 * ksplit) {
         // stage A tile as As[k][m], B tile as Bs[k][n]
         for (int u = tid; u < 16 * 64; u += 256) {
             int kk, mm;
@@ -74,6 +75,8 @@ __global__ void __launch_bounds__(256) small_gemm_kernel(const float* __restrict
             float v = acc[i][j];
             if (MODE == GEMM_TN) {
                 Cm[(int64_t)m * ldc + n] += v;
+            } else if (ksplit > 1) {
+                atomicAdd(&Cm[(int64_t)m * ldc + n], v);
             } else {
                 if (bias) v += bias[n];
                 if (out_silu) v = silu_f(v);
@@ -85,8 +88,16 @@ __global__ void __launch_bounds__(256) small_gemm_kernel(const float* __restrict
 
 int launch_small_gemm(int dtype, int mode, const float* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias, int out_silu,
                       float* C, int ldc, hipStream_t s) {
-    dim3 grid((N + 63) / 64, (M + 63) / 64);
-#define DMME_SG(TT, MM) hipLaunchKernelGGL((small_gemm_kernel<TT, MM>), grid, dim3(256), 0, s, A, lda, B, ldb, M, N, K, bias, out_silu, C, ldc)
+    int ksplit = 1;
+    const int wgs = ((N + 63) / 64) * ((M + 63) / 64);
+    if (mode == GEMM_NN && !bias && !out_silu && wgs < 128 && K >= 1024) {  // few output tiles, long K: split the reduction
+        ksplit = 256 / wgs;
+        if (ksplit > K / 64) ksplit = K / 64;
+        if (ksplit < 1) ksplit = 1;
+    }
+    if (ksplit > 1) DMME_CHECK_HIP(hipMemsetAsync(C, 0, (size_t)M * ldc * sizeof(float), s));
+    dim3 grid((N + 63) / 64, (M + 63) / 64, ksplit);
+#define DMME_SG(TT, MM) hipLaunchKernelGGL((small_gemm_kernel<TT, MM>), grid, dim3(256), 0, s, A, lda, B, ldb, M, N, K, bias, out_silu, C, ldc, ksplit)
     if (mode == GEMM_TN) {
         DMME_SG(float, GEMM_TN);
     } else if (dtype == DMME_BF16) {

@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--mode", default="sample", choices=["sample", "ddim", "train"])
     ap.add_argument("--train-steps", type=int, default=8, help="training steps timed for train_images_per_s (0: skip)")
+    ap.add_argument("--graph", action="store_true", help="replay the UNet forward from a hipGraph (small-batch sampling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -176,7 +177,7 @@ def train_leg(dmme_amd, dev, B, precision, steps, warmup, dist):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert torch.isfinite(loss).all(), "non-finite training loss"
-    return dt, float(loss)
+    return dt, float(loss.detach())
 
 
 def main():
@@ -223,15 +224,23 @@ def main():
     all_t = torch.arange(0, T + 1, device=dev).unsqueeze(1)
     tau = proc._tau_host if args.mode == "ddim" else None
 
+    t_buf = all_t[T].clone()
+
+    def fwd(tt):
+        if args.graph:
+            t_buf.copy_(tt)
+            return model.graphed_forward(x, t_buf)
+        return model(x, tt)
+
     def one_step(k):
         with torch.no_grad():
             if args.mode == "ddim":
                 i = 50 - (k % 50)
-                eps = model(x, all_t[tau[i]])
+                eps = fwd(all_t[tau[i]])
                 proc._ddim_update(x, eps, i)
             else:
                 t = T - (k % T)
-                eps = model(x, all_t[t])
+                eps = fwd(all_t[t])
                 proc._reverse_update(x, eps, t, None)
 
     def fence():
@@ -275,6 +284,7 @@ def main():
         "image_steps_per_s": round(world * args.steps * B / elapsed, 1),
         "train_images_per_s": None,
         "launches_per_step": int(model._last_plan.lib.dmme_unet_plan_num_launches(model._last_plan.h)) + 2,
+        "hip_graph": bool(args.graph and not getattr(model, "_graph_disabled", False)),
     }
     if args.train_steps > 0:
         del x

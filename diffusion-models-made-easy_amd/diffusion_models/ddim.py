@@ -59,7 +59,14 @@ class DDIM(DDPM):
         x = gaussian(img_size, device=dev)
         if self._tau_dev is None or self._tau_dev.device != dev:
             self._tau_dev = self.tau.to(dev).unsqueeze(1)
+        # small batches are launch/latency bound: replay the forward from a hipGraph (no gain at B >= 128)
+        graphed = hasattr(self.model, "graphed_forward") and not self.model.training and int(img_size[0]) <= 64
+        t_buf = self._tau_dev[self.sub_timesteps].clone() if graphed else None
         for i in range(self.sub_timesteps, 0, -1):
-            eps = self.model(x, self._tau_dev[i])
+            if graphed:
+                t_buf.copy_(self._tau_dev[i])
+                eps = self.model.graphed_forward(x, t_buf)
+            else:
+                eps = self.model(x, self._tau_dev[i])
             self._ddim_update(x, eps, i)
         return x

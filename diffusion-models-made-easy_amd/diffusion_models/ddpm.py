@@ -96,8 +96,15 @@ class DDPM(nn.Module):
         x_t = gaussian(img_size, device=dev)
         if self._all_t is None or self._all_t.device != dev or self._all_t.numel() != self.timesteps + 1:
             self._all_t = torch.arange(0, self.timesteps + 1, device=dev).unsqueeze(1)
+        # small batches are launch/latency bound: replay the forward from a hipGraph (no gain at B >= 128)
+        graphed = hasattr(self.model, "graphed_forward") and not self.model.training and int(img_size[0]) <= 64
+        t_buf = self._all_t[self.timesteps].clone() if graphed else None
         for t in range(self.timesteps, 0, -1):
-            eps = self.model(x_t, self._all_t[t])
+            if graphed:  # one hipGraph replay per step instead of ~160 launches (small batches are launch-bound)
+                t_buf.copy_(self._all_t[t])
+                eps = self.model.graphed_forward(x_t, t_buf)
+            else:
+                eps = self.model(x_t, self._all_t[t])
             self._reverse_update(x_t, eps, t, None)
         return x_t
 

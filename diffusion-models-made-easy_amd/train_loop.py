@@ -46,5 +46,5 @@ def fit(module, batch_size=128, max_steps=100, clip=None, log_every=50):
         if (step + 1) % log_every == 0 or step + 1 == max_steps:
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            print(json.dumps({"step": step + 1, "train/loss": round(float(loss), 5), "images_per_s": round((step + 1) * batch_size / dt, 1)}), flush=True)
+            print(json.dumps({"step": step + 1, "train/loss": round(float(loss.detach()), 5), "images_per_s": round((step + 1) * batch_size / dt, 1)}), flush=True)
     return module

@@ -231,3 +231,18 @@ def test_reference_error_behaviour(tiny32):
     with pytest.raises(RuntimeError):
         with torch.no_grad():
             net(torch.zeros(3, 3, 32, 32, device="cuda"), torch.tensor([1, 2], device="cuda"))
+
+
+def test_graphed_forward_matches_eager(tiny32):
+    """hipGraph replay of the forward (sampling loops) returns the eager result, also after in-place updates of x / t."""
+    net, _ = tiny32
+    x = synth.normal(3, (2, 3, 32, 32)).cuda()
+    t = torch.tensor([77], device="cuda")
+    with torch.no_grad():
+        for step in range(3):
+            want = net(x, t).clone()
+            got = net.graphed_forward(x, t).clone()
+            assert torch.equal(got, want), f"step {step}"
+            x.mul_(0.9).add_(0.05)
+            t.fill_(50 - step)
+    assert getattr(net, "_graph", None) is not None or getattr(net, "_graph_disabled", False)

@@ -35,8 +35,13 @@ __device__ __forceinline__ void store_vec(T* p, const float (&v)[16 / sizeof(T)]
     }
 }
 
+template <typename T>
 __device__ __forceinline__ float silu_grad_f(float u) {
-    const float s = 1.0f / (1.0f + expf(-u));
+    float s;
+    if constexpr (sizeof(T) == 2)
+        s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * u));  // bf16 tensors: hardware exp / rcp
+    else
+        s = 1.0f / (1.0f + expf(-u));
     return s * (1.0f + u * (1.0f - s));
 }
 
@@ -168,7 +173,7 @@ __global__ void __launch_bounds__(256) gn_bwd_sums_kernel(const T* __restrict__ 
 #pragma unroll
         for (int j = 0; j < EPV; ++j) {
             float du = d[j] * dm[j];
-            if (pro_silu) du *= silu_grad_f(fmaf(xv[j], sc[j], sh[j]));
+            if (pro_silu) du *= silu_grad_f<T>(fmaf(xv[j], sc[j], sh[j]));
             a[j] += du;
             b[j] = fmaf(du, (xv[j] - mu[j]) * rs[j], b[j]);
         }
@@ -277,13 +282,52 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
         for (int j = 0; j < EPV; ++j) {
             float du = d[j] * dm[j];
-            if (pro_silu) du *= silu_grad_f(fmaf(xv[j], sc[j], sh[j]));
+            if (pro_silu) du *= silu_grad_f<T>(fmaf(xv[j], sc[j], sh[j]));
             const float xhat = (xv[j] - mu[j]) * rs[j];
             const float dx = rs[j] * (du * gm[j] - (k1[j] + xhat * k2[j]));
             o[j] = acc ? o[j] + dx : dx;
         }
         store_vec<T>(dst + (p0 + p) * Cs + cs0, o);
     }
+}
+
+// dst1[.., :C1] (+)= src[.., :C1], dst2[.., :C2] (+)= src[.., C1:]  with 16-byte accesses
+template <typename T>
+__global__ void __launch_bounds__(256) grad_acc_vec_kernel(const T* __restrict__ src, T* __restrict__ d1, T* __restrict__ d2, int C1, int C2,
+                                                           int acc1, int acc2, int64_t nvec) {
+    constexpr int EPV = 16 / sizeof(T);
+    const int C = C1 + C2, VPP = C / EPV;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / VPP;
+        const int c0 = (int)(i % VPP) * EPV;
+        float v[EPV], o[EPV];
+        load_vec<T>(src + p * C + c0, v);
+        const bool second = c0 >= C1;
+        T* dst = second ? d2 + p * C2 + (c0 - C1) : d1 + p * C1 + c0;
+        if (second ? acc2 : acc1) {
+            load_vec<T>(dst, o);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) v[j] += o[j];
+        }
+        store_vec<T>(dst, v);
+    }
+}
+bool grad_acc_fast_supported(int dtype, int C1, int C2, int pool) {
+    const int EPV = dtype == DMME_BF16 ? 8 : 4;
+    return !pool && C1 % EPV == 0 && C2 % EPV == 0;
+}
+int launch_grad_acc_fast(int dtype, const void* src, void* d1, void* d2, int C1, int C2, int acc1, int acc2, int64_t npix, hipStream_t s) {
+    const int EPV = dtype == DMME_BF16 ? 8 : 4;
+    const int64_t nvec = npix * ((C1 + C2) / EPV);
+    if (nvec == 0) return DMME_OK;
+    int64_t blocks = (nvec + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (dtype == DMME_BF16)
+        hipLaunchKernelGGL(grad_acc_vec_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16*)src, (bf16*)d1, (bf16*)d2, C1, C2, acc1, acc2, nvec);
+    else
+        hipLaunchKernelGGL(grad_acc_vec_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)src, (float*)d1, (float*)d2, C1, C2, acc1, acc2, nvec);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
 }
 
 bool gn_bwd_fast_supported(int dtype, int HW, int C1, int C2) {

@@ -222,6 +222,8 @@ int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2
                        const float* gamma, const float* mean_rstd, const float* scale, const float* shift, const float* dmask,
                        int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, float* AB_zeroed,
                        float* S_scratch, hipStream_t s);
+bool grad_acc_fast_supported(int dtype, int C1, int C2, int pool);
+int launch_grad_acc_fast(int dtype, const void* src, void* d1, void* d2, int C1, int C2, int acc1, int acc2, int64_t npix, hipStream_t s);
 int launch_grad_acc(int dtype, const void* src, void* d1, void* d2, int C1, int C2, int acc1, int acc2, int pool, int N, int H, int W,
                     hipStream_t s);
 int launch_attn_bwd_generic(int dtype, const void* qkv, const void* dO, int N, int S, int C, float* P, float* dS, void* dqkv, hipStream_t s);

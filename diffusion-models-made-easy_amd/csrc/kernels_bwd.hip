@@ -354,6 +354,7 @@ __global__ void __launch_bounds__(256) grad_acc_kernel(const T* __restrict__ src
 }
 int launch_grad_acc(int dtype, const void* src, void* d1, void* d2, int C1, int C2, int acc1, int acc2, int pool, int N, int H, int W,
                     hipStream_t s) {
+    if (grad_acc_fast_supported(dtype, C1, C2, pool)) return launch_grad_acc_fast(dtype, src, d1, d2, C1, C2, acc1, acc2, (int64_t)N * H * W, s);
     const int64_t total = (int64_t)N * H * W * (C1 + C2);
     if (total == 0) return DMME_OK;
     int64_t b = (total + 255) / 256;

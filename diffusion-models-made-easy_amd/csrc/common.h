@@ -206,6 +206,33 @@ int launch_wgrad_small(int dtype, const ConvArgs& a, const void* dY, float* dW, 
 bool wgrad_mfma_supported(int dtype, const ConvArgs& a);
 int launch_wgrad_mfma(int dtype, const ConvArgs& a, const void* dY, float* dWp, hipStream_t s);
 struct PackItem;
+struct ConvTile {  // host-computed geometry, passed by value
+    int TW, TH, TN;       // output tile: TN images x TH x TW pixels (product = BM)
+    int HH, HWd;          // halo extent in (virtual) input space
+    int tiles_x, tiles_y; // tiles per image
+    int tiles_m, tiles_n;
+    int a_rows;           // TN*HH*HWd
+    unsigned magic_px, magic_w;  // ceil(2^32 / (HH*HWd)), ceil(2^32 / HWd): exact x/d by __umulhi for x*d < 2^32
+};
+
+// grouped (deferred) 3x3 weight gradients: plan-time tables, one launch per backward (wgrad_mfma.hip)
+struct WgLayer {
+    int64_t src1_off, src2_off;    // bytes into the forward workspace (src2: -1 none)
+    int64_t scale_off, shift_off;  // bytes into the forward workspace (-1: no GroupNorm prologue)
+    int64_t dmask_off;             // floats into the drop-mask buffer (-1: none)
+    int64_t dy_off;                // bytes into the backward workspace: gradient of the conv output
+    int64_t dw_off;                // floats into the packed weight-gradient image
+    int N, Hin, Win, C1, C2, up, Hout, Wout, Cout, pro_silu;
+    int shTW, shTH;
+    ConvTile g;
+};
+struct WgJob {
+    int layer, cot, cit, tile0, ntiles;
+};
+// fills the geometry fields of L when the conv qualifies (offsets are the caller's)
+bool wgrad_group_layer(int dtype, const ConvArgs& a, WgLayer& L);
+int launch_wgrad_group(int dtype, const WgLayer* layers_dev, const WgJob* jobs_dev, int njobs, const void* ws, const void* bws,
+                       const float* drop_masks, float* wimage, hipStream_t s);
 int launch_wgrad_unpack(const PackItem* items_dev, int n_items, const float* image, float* grad_flat, hipStream_t s);
 int launch_colsum(int dtype, const void* dY, int N, int HW, int C, float* rowsum, float* dbias, float* dtproj, int ld, int nt,
                   hipStream_t s);

@@ -13,15 +13,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int ROW_DATA = 128;          // data bytes per LDS row (one Cin chunk of one pixel / cout)
 constexpr int ROW_PITCH = ROW_DATA + 16;  // padded pitch
 
-struct ConvTile {  // host-computed geometry, passed by value
-    int TW, TH, TN;       // output tile: TN images x TH x TW pixels (product = BM)
-    int HH, HWd;          // halo extent in (virtual) input space
-    int tiles_x, tiles_y; // tiles per image
-    int tiles_m, tiles_n;
-    int a_rows;           // TN*HH*HWd
-    unsigned magic_px, magic_w;  // ceil(2^32 / (HH*HWd)), ceil(2^32 / HWd): exact x/d by __umulhi for x*d < 2^32
-};
-
 template <typename T>
 struct Frag;
 template <>

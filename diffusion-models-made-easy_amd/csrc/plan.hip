@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -66,6 +67,7 @@ struct Op {
     int res1 = -1, res2 = -1;
     int dst = -1;              // tensor id; -2: network output (NCHW fp32)
     int up = 0, stride = 1, taps = 9;
+    int wg_layer = -1;         // index into the grouped weight-gradient table (-1: per-layer kernels)
     // OP_ATTN
     int at_qkv = -1, at_out = -1;
     int64_t at_lse = 0;  // workspace offset of the forward's log-sum-exp [N][S]
@@ -103,6 +105,11 @@ struct dmme_plan {
             bws_attdS = 0;
     PackItem* items_bwd_dev = nullptr;
     int n_items_bwd = 0;
+    // grouped weight gradients (one launch per backward)
+    std::vector<WgLayer> wg_layers;
+    std::vector<WgJob> wg_jobs;
+    WgLayer* wg_layers_dev = nullptr;
+    WgJob* wg_jobs_dev = nullptr;
 };
 
 namespace {
@@ -666,6 +673,44 @@ void fill_conv(const dmme_plan* P, const Op& o, const char* packed, const float*
     }
 }
 
+// Grouped weight gradients: every 3x3 stride-1 conv the all-taps MFMA kernel supports is taken out of the per-layer
+// sequence; its (cout tile, cin tile) pairs are cut into jobs of at most `q` consecutive 64-pixel tiles, longest first.
+void build_wgrad_group(dmme_plan* P) {
+    if (P->dtype != DMME_BF16 || getenv("DMME_NO_WGRAD_GROUP")) return;
+    const int q = getenv("DMME_WG_Q") ? atoi(getenv("DMME_WG_Q")) : 128;
+    for (int oi = (int)P->ops.size() - 1; oi >= 0; --oi) {
+        Op& o = P->ops[oi];
+        if (o.kind != OP_CONV || o.src1 < 0 || o.dst < 0) continue;
+        ConvArgs a{};
+        fill_conv(P, o, nullptr, nullptr, nullptr, nullptr, nullptr, 1, a);
+        WgLayer L{};
+        if (!wgrad_mfma_supported(P->dtype, a) || !wgrad_group_layer(P->dtype, a, L)) continue;
+        L.src1_off = P->tensors[o.src1].off;
+        L.src2_off = o.src2 >= 0 ? P->tensors[o.src2].off : -1;
+        L.scale_off = o.gn >= 0 ? P->ops[o.gn].gn_scale : -1;
+        L.shift_off = o.gn >= 0 ? P->ops[o.gn].gn_shift : -1;
+        L.dmask_off = o.dmask_off;
+        L.dy_off = P->gt_off[o.dst];
+        L.dw_off = P->params[o.w].wp_off;
+        o.wg_layer = (int)P->wg_layers.size();
+        P->wg_layers.push_back(L);
+        const int n_co = (L.Cout + 63) / 64, n_ci = (L.C1 + L.C2) / 64;
+        const int ns = (L.g.tiles_m + q - 1) / q;
+        for (int cot = 0; cot < n_co; ++cot)
+            for (int cit = 0; cit < n_ci; ++cit)
+                for (int sp = 0; sp < ns; ++sp) {
+                    WgJob j{};
+                    j.layer = o.wg_layer;
+                    j.cot = cot;
+                    j.cit = cit;
+                    j.tile0 = (int)((int64_t)L.g.tiles_m * sp / ns);
+                    j.ntiles = (int)((int64_t)L.g.tiles_m * (sp + 1) / ns) - j.tile0;
+                    if (j.ntiles > 0) P->wg_jobs.push_back(j);
+                }
+    }
+    std::stable_sort(P->wg_jobs.begin(), P->wg_jobs.end(), [](const WgJob& x, const WgJob& y) { return x.ntiles > y.ntiles; });
+}
+
 // can this GroupNorm be finalised from the partials its producers emitted?
 bool gn_from_parts(const dmme_plan* P, const Op& o) {
     const Tensor& t1 = P->tensors[o.gn_src1];
@@ -857,6 +902,7 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
         return rc;
     }
     if (!getenv("DMME_NO_FUSED_GN")) assign_stats(P);
+    if (device >= 0) build_wgrad_group(P);
     if (device >= 0) {
         std::vector<PackItem> items;
         build_pack_items(P, items);
@@ -874,6 +920,12 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
         P->n_items_unpack = (int)uitems.size();
         if (e == hipSuccess) e = hipMalloc((void**)&P->items_unpack_dev, uitems.size() * sizeof(PackItem));
         if (e == hipSuccess) e = hipMemcpy(P->items_unpack_dev, uitems.data(), uitems.size() * sizeof(PackItem), hipMemcpyHostToDevice);
+        if (!P->wg_jobs.empty()) {
+            if (e == hipSuccess) e = hipMalloc((void**)&P->wg_layers_dev, P->wg_layers.size() * sizeof(WgLayer));
+            if (e == hipSuccess) e = hipMemcpy(P->wg_layers_dev, P->wg_layers.data(), P->wg_layers.size() * sizeof(WgLayer), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMalloc((void**)&P->wg_jobs_dev, P->wg_jobs.size() * sizeof(WgJob));
+            if (e == hipSuccess) e = hipMemcpy(P->wg_jobs_dev, P->wg_jobs.data(), P->wg_jobs.size() * sizeof(WgJob), hipMemcpyHostToDevice);
+        }
         if (e != hipSuccess) {
             set_error("plan_create: device table setup failed: %s", hipGetErrorString(e));
             delete P;
@@ -889,6 +941,8 @@ DMME_API void dmme_unet_plan_destroy(dmme_plan* plan) {
     if (plan->items_dev) (void)hipFree(plan->items_dev);
     if (plan->items_bwd_dev) (void)hipFree(plan->items_bwd_dev);
     if (plan->items_unpack_dev) (void)hipFree(plan->items_unpack_dev);
+    if (plan->wg_layers_dev) (void)hipFree(plan->wg_layers_dev);
+    if (plan->wg_jobs_dev) (void)hipFree(plan->wg_jobs_dev);
     delete plan;
 }
 
@@ -1039,8 +1093,10 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
             rc = launch_colsum(dt, dy, B, a.Hout * a.Wout, a.Cout, rowsum, grad_flat + P->params[o.b].ref_off,
                                o.tproj_col >= 0 ? dtproj + o.tproj_col : nullptr, P->tproj_cols, nt, s);
         if (rc != DMME_OK) break;
-        // 2. weight gradient (reference layout, accumulated)
-        if (wgrad_mfma_supported(dt, a))
+        // 2. weight gradient: deferred to the grouped launch below, or per layer (packed image / reference layout)
+        if (o.wg_layer >= 0 && P->wg_jobs_dev)
+            rc = DMME_OK;
+        else if (wgrad_mfma_supported(dt, a))
             rc = launch_wgrad_mfma(dt, a, dy, wimage + P->params[o.w].wp_off, s);
         else if (wgrad_small_supported(dt, a))
             rc = launch_wgrad_small(dt, a, dy, grad_flat + P->params[o.w].ref_off, s);
@@ -1095,6 +1151,11 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
         }
     }
     if (rc != DMME_OK) return rc;
+    // all deferred 3x3 weight gradients in one launch: every dY and forward activation is still in its workspace
+    if (P->wg_jobs_dev) {
+        rc = launch_wgrad_group(dt, P->wg_layers_dev, P->wg_jobs_dev, (int)P->wg_jobs.size(), ws, bws, drop_masks, wimage, s);
+        if (rc != DMME_OK) return rc;
+    }
     // fold the packed-layout weight-gradient image into the reference-layout gradients (one launch)
     rc = launch_wgrad_unpack(P->items_unpack_dev, P->n_items_unpack, wimage, grad_flat, s);
     if (rc != DMME_OK) return rc;

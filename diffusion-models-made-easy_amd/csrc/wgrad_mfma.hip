@@ -16,6 +16,7 @@
 // atomics into a packed [co][tap][ci] image (ci contiguous across lanes: full-rate
 // atomics); a small kernel folds it into the reference-layout gradient buffer.
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "conv_common.h"
 
@@ -175,6 +176,155 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(ConvArgs a, ConvTile g,
     }
 }
 
+
+// ---- grouped all-nine-taps weight gradient (3x3, stride 1, bf16) ---------------------------------------------
+// Split-K weight gradients pay for their parallelism in atomics: every workgroup ends with one atomic per output it
+// owns, and a layer launched alone needs hundreds of pixel splits to fill 256 CUs (measured: ~65 us of atomics per
+// layer, more than the MFMA time of most layers).  The backward therefore DEFERS these weight gradients - every dY
+// and every forward activation stays in its workspace - and runs them all in ONE launch over a plan-time job table:
+// ~50 layers supply the parallelism, each job owns a long contiguous run of pixel tiles, and the atomic count drops
+// by more than an order of magnitude.
+// One job = 64 couts x 64 cins x ALL 9 taps (4 waves 2x2, wave tile 32 co x 32 ci, 9 accumulators) over `ntiles`
+// 64-pixel tiles.  The raw dY / input vectors of the next tile are prefetched into registers while the MFMAs of the
+// current one run; the GN-affine/SiLU/dropout prologue is applied when they are written to LDS.
+template <typename T>
+__global__ void __launch_bounds__(256, 2) wgrad9_group_kernel(const WgLayer* __restrict__ layers, const WgJob* __restrict__ jobs,
+                                                              const char* __restrict__ ws, const char* __restrict__ bws,
+                                                              const float* __restrict__ drop_masks, float* __restrict__ wimage) {
+    static_assert(sizeof(T) == 2, "grouped weight gradient is bf16 only");
+    constexpr int EPV = 8, CO = 64, CI = 64, DYP = 192, VP = WgGeom<T>::V_PITCH;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* ldsY = lds;                 // [64 px][64 co]
+    char* ldsV = lds + WG_PX * DYP;   // [halo px][64 ci]
+    const WgJob job = jobs[blockIdx.x];
+    const WgLayer& L = layers[job.layer];
+    const ConvTile g = L.g;
+    const int shTW = L.shTW, shTH = L.shTH;
+    const int N = L.N, Hin = L.Hin, Win = L.Win, C1 = L.C1, C2 = L.C2, up = L.up, Hout = L.Hout, Wout = L.Wout, Cout = L.Cout;
+    const int pro_silu = L.pro_silu;
+    const T* dY = (const T*)(bws + L.dy_off);
+    float* dWp = wimage + L.dw_off;
+    const float* scale = L.scale_off >= 0 ? (const float*)(ws + L.scale_off) : nullptr;
+    const float* shift = L.scale_off >= 0 ? (const float*)(ws + L.shift_off) : nullptr;
+    const float* dmask = (drop_masks && L.dmask_off >= 0) ? drop_masks + L.dmask_off : nullptr;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;
+    const int r = lane & 31, h = lane >> 5;
+    const int Cin = C1 + C2;
+    const int co0 = job.cot * CO, ci0 = job.cit * CI;
+    const int Hv = up ? 2 * Hin : Hin, Wv = up ? 2 * Win : Win;
+    const int mTW = (1 << shTW) - 1, mTH = (1 << shTH) - 1;
+    const int halo_px = g.HH * g.HWd;
+    const bool second = ci0 >= C1;
+    const T* sbase = (const T*)(ws + (second ? L.src2_off : L.src1_off));
+    const int Cs = second ? C2 : C1, cs0 = second ? ci0 - C1 : ci0;
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[k][j] = 0.f;
+    const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g1 = (lane >> 4) & 1;
+
+    constexpr int UY = WG_PX * (CO / EPV) / 256;   // dY vectors per thread
+    constexpr int UV = 5;                          // halo vectors per thread (a_rows <= 160)
+    uint4 ry[UY], rv[UV];
+    unsigned vmask = 0;                            // bit k: halo vector k is inside the image (else zero padding)
+    int n0_cur = 0;
+    auto issue = [&](int tile) {
+        const int tx_blk = tile % g.tiles_x, ty_blk = (tile / g.tiles_x) % g.tiles_y;
+        const int n0 = (tile / (g.tiles_x * g.tiles_y)) * g.TN;
+        const int oy0 = ty_blk << shTH, ox0 = tx_blk << shTW;
+        n0_cur = n0;
+        vmask = 0;
+#pragma unroll
+        for (int k = 0; k < UY; ++k) {
+            const int u = tid + 256 * k;
+            const int m = u / (CO / EPV), cu = u % (CO / EPV);
+            const int tx = m & mTW, ty = (m >> shTW) & mTH, tn = m >> (shTW + shTH);
+            const int n = n0 + tn, co = co0 + cu * EPV;
+            ry[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (n < N && co < Cout)
+                ry[k] = *reinterpret_cast<const uint4*>(dY + (((int64_t)n * Hout + oy0 + ty) * Wout + ox0 + tx) * Cout + co);
+        }
+#pragma unroll
+        for (int k = 0; k < UV; ++k) {
+            const int u = tid + 256 * k;
+            const int row = u / (CI / EPV), cu = u % (CI / EPV);
+            const int tn = (int)__umulhi((unsigned)row, g.magic_px), rem = row - tn * halo_px;
+            const int hy = (int)__umulhi((unsigned)rem, g.magic_w), hx = rem - hy * g.HWd;
+            const int n = n0 + tn, iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+            rv[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (row < g.a_rows && n < N && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) {
+                const int sy = up ? (iy >> 1) : iy, sx = up ? (ix >> 1) : ix;
+                rv[k] = *reinterpret_cast<const uint4*>(sbase + (((int64_t)n * Hin + sy) * Win + sx) * Cs + cs0 + cu * EPV);
+                vmask |= 1u << k;
+            }
+        }
+    };
+    const int tile_end = job.tile0 + job.ntiles;
+    issue(job.tile0);
+    for (int tile = job.tile0; tile < tile_end; ++tile) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < UY; ++k) {
+            const int u = tid + 256 * k;
+            *reinterpret_cast<uint4*>(ldsY + (u / (CO / EPV)) * DYP + (u % (CO / EPV)) * 16) = ry[k];
+        }
+#pragma unroll
+        for (int k = 0; k < UV; ++k) {
+            const int u = tid + 256 * k;
+            const int row = u / (CI / EPV), cu = u % (CI / EPV);
+            uint4 val = rv[k];
+            if (vmask & (1u << k)) {
+                const int n = n0_cur + (int)__umulhi((unsigned)row, g.magic_px);
+                const int64_t so = (int64_t)n * Cin + ci0 + cu * EPV;
+                val = prologue_vec<T>(val, scale ? scale + so : nullptr, scale ? shift + so : nullptr, dmask ? dmask + so : nullptr, pro_silu);
+            }
+            if (row < g.a_rows) *reinterpret_cast<uint4*>(ldsV + row * VP + cu * 16) = val;
+        }
+        __syncthreads();
+        if (tile + 1 < tile_end) issue(tile + 1);
+#pragma unroll 1
+        for (int ks = 0; ks < WG_PX / 16; ++ks) {
+            s16x8 af;
+            {
+                const char* p0 = ldsY + (16 * ks + 8 * h + tr_q) * DYP + (wco + 16 * tr_g1 + 4 * tr_p) * 2;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 4 * DYP));
+                af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3];
+                af[4] = hi[0]; af[5] = hi[1]; af[6] = hi[2]; af[7] = hi[3];
+            }
+            int vrow[2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int m = 16 * ks + 8 * h + 4 * half + tr_q;
+                const int tx = m & mTW, ty = (m >> shTW) & mTH, tn = m >> (shTW + shTH);
+                vrow[half] = (tn * g.HH + ty) * g.HWd + tx;
+            }
+            const int colb = (wci + 16 * tr_g1 + 4 * tr_p) * 2;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int toff = (tap / 3) * g.HWd + (tap % 3);
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ldsV + (vrow[0] + toff) * VP + colb));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ldsV + (vrow[1] + toff) * VP + colb));
+                s16x8 bfr;
+                bfr[0] = lo[0]; bfr[1] = lo[1]; bfr[2] = lo[2]; bfr[3] = lo[3];
+                bfr[4] = hi[0]; bfr[5] = hi[1]; bfr[6] = hi[2]; bfr[7] = hi[3];
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bfr), acc[tap], 0, 0, 0);
+            }
+        }
+    }
+    const int ci = ci0 + wci + r;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int co = co0 + wco + (j & 3) + 8 * (j >> 2) + 4 * h;
+            if (co < Cout) atomicAdd(dWp + ((int64_t)co * 9 + tap) * Cin + ci, acc[tap][j]);
+        }
+}
+
 static bool wg_tile(const ConvArgs& a, ConvTile& g) {
     if (!make_tile(a, WG_PX, 64, g)) return false;
     if (g.TW < 4) return false;  // 4-pixel transposed-read blocks must stay inside one tile row
@@ -246,6 +396,33 @@ __global__ void __launch_bounds__(256) wgrad_unpack_table_kernel(const PackItem*
 int launch_wgrad_unpack(const PackItem* items_dev, int n_items, const float* image, float* grad_flat, hipStream_t s) {
     if (n_items == 0) return DMME_OK;
     hipLaunchKernelGGL(wgrad_unpack_table_kernel, dim3(n_items), dim3(256), 0, s, items_dev, image, grad_flat);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+bool wgrad_group_layer(int dtype, const ConvArgs& a, WgLayer& L) {
+    if (dtype != DMME_BF16 || a.taps != 9 || a.stride != 1 || a.in_nchw) return false;
+    const int Cin = a.C1 + a.C2;
+    if (Cin % 64 || a.C1 % 64 || a.Cout % 8) return false;
+    ConvTile g{};
+    if (!make_tile(a, WG_PX, 64, g) || g.TW < 4 || g.a_rows > 160) return false;
+    L.g = g;
+    L.shTW = L.shTH = 0;
+    while ((1 << L.shTW) < g.TW) ++L.shTW;
+    while ((1 << L.shTH) < g.TH) ++L.shTH;
+    if ((1 << L.shTW) != g.TW || (1 << L.shTH) != g.TH) return false;
+    L.N = a.N; L.Hin = a.Hin; L.Win = a.Win; L.C1 = a.C1; L.C2 = a.C2; L.up = a.up;
+    L.Hout = a.Hout; L.Wout = a.Wout; L.Cout = a.Cout; L.pro_silu = a.pro_silu;
+    return true;
+}
+
+int launch_wgrad_group(int dtype, const WgLayer* layers_dev, const WgJob* jobs_dev, int njobs, const void* ws, const void* bws,
+                       const float* drop_masks, float* wimage, hipStream_t s) {
+    DMME_REQUIRE(dtype == DMME_BF16, DMME_ERR_UNSUPPORTED, "grouped weight gradient is bf16 only");
+    if (njobs <= 0) return DMME_OK;
+    const size_t lds = (size_t)WG_PX * 192 + (size_t)160 * WgGeom<bf16>::V_PITCH;
+    hipLaunchKernelGGL((wgrad9_group_kernel<bf16>), dim3((unsigned)njobs), dim3(256), lds, s, layers_dev, jobs_dev, (const char*)ws,
+                       (const char*)bws, drop_masks, wimage);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }

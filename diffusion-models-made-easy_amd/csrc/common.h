@@ -180,7 +180,8 @@ struct PackItem {  // one chunk of the table-driven parameter re-pack
     int64_t src_off;   // element offset in the fp32 reference-layout flat buffer
     int64_t dst_off;   // BYTE offset in the packed buffer
     int32_t cout, cin, taps;  // tensor geometry (cin*taps = row length)
-    int32_t row0, rows;       // rows [row0, row0+rows) of this tensor handled by this item
+    int32_t row0, rows;       // rows (couts) [row0, row0+rows) of this tensor handled by this item
+    int32_t ci0, nci;         // cin range [ci0, ci0+nci) handled by this item (re-pack items; rows*nci*taps <= 8192)
     int32_t as_f32;           // 1: keep fp32 (biases, gammas, freqs); 0: convert to dtype;
                               // 2: transposed + tap-flipped copy [cin][taps-1-tap][cout] in dtype (data-gradient weights)
 };
@@ -261,6 +262,10 @@ int launch_silu_bwd(float* dy, const float* z, int n, hipStream_t s);
 int launch_small_gemm(int dtype, int mode, const float* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias, int out_silu,
                       float* C, int ldc, hipStream_t s);
 int launch_nsum(const float* Mx, int N, int C, int64_t stride, int estride, float* out, hipStream_t s);
+// one launch for a set of Linear layers: per-64-row-tile (gemm) / per-32-column (sum) output bases, in floats
+int launch_small_gemm_tn_tiled(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc,
+                               const int64_t* mtile_off, hipStream_t s);
+int launch_nsum_tiled(const float* Mx, int N, int C, int64_t stride, int estride, float* out, const int64_t* ctile_off, hipStream_t s);
 int launch_grad_norm(const float* g, int64_t n, float* norm_out, float* scratch, hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr, float b1, float b2, float eps, int step,
                 const float* norm, float max_norm, float ema_decay, hipStream_t s);

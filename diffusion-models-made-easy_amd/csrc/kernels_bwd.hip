@@ -6,6 +6,8 @@
 // +Dropout2d) backward, attention backward, gradient accumulation (channel split of
 // torch.cat, 2x2 sum-pool of nn.Upsample), the small linears of the time MLP.
 // Reference math: torch autograd of models/ddpm.py:118-133 (ResBlock), :54-75 (Attention).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dmme {
@@ -172,13 +174,133 @@ __global__ void __launch_bounds__(256) wgrad_cin_small_kernel(ConvArgs a, const 
         for (int tap = 0; tap < 9; ++tap) atomicAdd(&dW[((int64_t)co * Cin + ci) * 9 + tap], acc[ci * 9 + tap]);
 }
 
+// Thin 3x3 weight gradients (first conv: Cin <= 3 on the NCHW fp32 input; last conv: Cout <= 3), stride 1:
+//   out[k][c] = sum_p wide[p][c] * coef[p][k],   k = g*9 + tap,  g < G <= 3
+// first conv: wide = dY [p][Cout],            coef[p][ci*9+tap] = x[n][ci][y-1+kh][x-1+kw]
+// last conv:  wide = prologue(input) [q][Cin], coef[q][co*9+tap] = dY[n][y+1-kh][x+1-kw][co]   (substituting q = p + tap)
+// so the wide NHWC tensor is read exactly once, without a halo.  A workgroup stages the 27 coefficients of 256
+// pixels in LDS, thread <-> (4 channels, pixel lane) keeps 4 x 27 accumulators, the pixel lanes are merged through
+// LDS and each workgroup ends with one atomic per weight element.
+template <typename T, bool FIRST>
+__global__ void __launch_bounds__(256) wgrad_thin_kernel(ConvArgs a, const T* __restrict__ dY, float* __restrict__ dW, int tiles_total) {
+    constexpr int PX = 256, KP = 28;
+    __shared__ __attribute__((aligned(16))) float lds[256 * 9 * 4];  // coef [PX][KP] (28 KB), then the merge buffer [lanes][9][Cw] (36 KB)
+    const int Cw = FIRST ? a.Cout : a.C1, G = FIRST ? a.C1 : a.Cout, K = G * 9;
+    const int H = a.Hout, W = a.Wout, HW = H * W;
+    const int64_t total = (int64_t)a.N * HW;
+    const int vecs = Cw / 4, lanes_p = 256 / vecs;
+    const int tid = threadIdx.x, vec = tid % vecs, pl = tid / vecs;
+    const T* wide = FIRST ? dY : (const T*)a.src1;
+    const float* xin = (const float*)a.src1;
+    float acc[4][27];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 27; ++k) acc[j][k] = 0.f;
+    for (int tile = blockIdx.x; tile < tiles_total; tile += gridDim.x) {
+        const int64_t p0 = (int64_t)tile * PX;
+        __syncthreads();
+        for (int e = tid; e < PX * 27; e += 256) {
+            const int pi = e % PX, k = e / PX;
+            const int64_t p = p0 + pi;
+            float v = 0.f;
+            if (p < total && k < K) {
+                const int n = (int)(p / HW), rem = (int)(p - (int64_t)n * HW), y = rem / W, x = rem - y * W;
+                const int g = k / 9, tap = k - g * 9, kh = tap / 3, kw = tap - kh * 3;
+                const int sy = FIRST ? y - 1 + kh : y + 1 - kh, sx = FIRST ? x - 1 + kw : x + 1 - kw;
+                if (sy >= 0 && sy < H && sx >= 0 && sx < W)
+                    v = FIRST ? xin[(((int64_t)n * G + g) * H + sy) * W + sx] : to_f(dY[(((int64_t)n * H + sy) * W + sx) * G + g]);
+            }
+            lds[pi * KP + k] = v;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int pi = pl; pi < PX; pi += lanes_p) {
+            const int64_t p = p0 + pi;
+            if (p >= total) break;
+            float v[4];
+            if constexpr (sizeof(T) == 2) {
+                const uint2 raw = *reinterpret_cast<const uint2*>(wide + p * Cw + 4 * vec);
+                v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
+                v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
+            } else {
+                const float4 raw = *reinterpret_cast<const float4*>(wide + p * Cw + 4 * vec);
+                v[0] = raw.x; v[1] = raw.y; v[2] = raw.z; v[3] = raw.w;
+            }
+            if constexpr (!FIRST) {
+                if (a.scale) {
+                    const int64_t so = (p / HW) * Cw + 4 * vec;
+                    const float4 sc = *reinterpret_cast<const float4*>(a.scale + so), sh = *reinterpret_cast<const float4*>(a.shift + so);
+                    v[0] = fmaf(v[0], sc.x, sh.x); v[1] = fmaf(v[1], sc.y, sh.y); v[2] = fmaf(v[2], sc.z, sh.z); v[3] = fmaf(v[3], sc.w, sh.w);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (a.pro_silu) v[j] = sizeof(T) == 2 ? silu_fast(v[j]) : silu_f(v[j]);  // same SiLU flavour as the forward prologue
+                    v[j] = to_f(from_f<T>(v[j]));
+                }
+            }
+            const float4* cp = reinterpret_cast<const float4*>(lds + pi * KP);
+#pragma unroll
+            for (int k4 = 0; k4 < 7; ++k4) {
+                const float4 c = cp[k4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[j][4 * k4] = fmaf(v[j], c.x, acc[j][4 * k4]);
+                    if (4 * k4 + 1 < 27) acc[j][4 * k4 + 1] = fmaf(v[j], c.y, acc[j][4 * k4 + 1]);
+                    if (4 * k4 + 2 < 27) acc[j][4 * k4 + 2] = fmaf(v[j], c.z, acc[j][4 * k4 + 2]);
+                    if (4 * k4 + 3 < 27) acc[j][4 * k4 + 3] = fmaf(v[j], c.w, acc[j][4 * k4 + 3]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        if (g >= G) break;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            *reinterpret_cast<float4*>(lds + ((int64_t)pl * 9 + t) * Cw + 4 * vec) =
+                make_float4(acc[0][g * 9 + t], acc[1][g * 9 + t], acc[2][g * 9 + t], acc[3][g * 9 + t]);
+        __syncthreads();
+        for (int e = tid; e < 9 * Cw; e += 256) {
+            const int t = e / Cw, c = e - t * Cw;
+            float sum = 0.f;
+            for (int l = 0; l < lanes_p; ++l) sum += lds[(l * 9 + t) * Cw + c];
+            const int64_t idx = FIRST ? ((int64_t)c * G + g) * 9 + t : ((int64_t)g * Cw + c) * 9 + t;
+            atomicAdd(dW + idx, sum);
+        }
+    }
+}
+
+static bool wgrad_thin_supported(const ConvArgs& a) {
+    if (a.taps != 9 || a.stride != 1 || a.up || a.C2 || a.dmask || a.Hout != a.Hin || a.Wout != a.Win) return false;
+    const int Cw = a.in_nchw ? a.Cout : a.C1, G = a.in_nchw ? a.C1 : a.Cout;
+    if (G > 3 || Cw % 4 || Cw / 4 > 256 || 256 % (Cw / 4)) return false;
+    if (a.in_nchw) return !a.scale && !a.pro_silu;
+    return true;
+}
+
 bool wgrad_small_supported(int dtype, const ConvArgs& a) {
+    if (wgrad_thin_supported(a)) return true;
     const int EPV = dtype == DMME_BF16 ? 8 : 4;
     if (a.taps != 9 || a.stride != 1 || a.up || a.C2 || a.dmask) return false;
     if (a.in_nchw) return a.C1 <= 4 && a.Cout <= 256 && !a.scale && !a.pro_silu;
     return a.Cout <= 4 && a.C1 % EPV == 0 && 9 * (a.C1 / EPV) <= 256;
 }
 int launch_wgrad_small(int dtype, const ConvArgs& a, const void* dY, float* dW, hipStream_t s) {
+    if (wgrad_thin_supported(a) && !getenv("DMME_NO_WGRAD_THIN")) {
+        const int64_t total = (int64_t)a.N * a.Hout * a.Wout;
+        const int tiles = (int)((total + 255) / 256), grid = tiles < 512 ? tiles : 512;
+#define DMME_WTHIN(TT, FF) hipLaunchKernelGGL((wgrad_thin_kernel<TT, FF>), dim3(grid), dim3(256), 0, s, a, (const TT*)dY, dW, tiles)
+        if (dtype == DMME_BF16) {
+            if (a.in_nchw) DMME_WTHIN(bf16, true); else DMME_WTHIN(bf16, false);
+        } else {
+            if (a.in_nchw) DMME_WTHIN(float, true); else DMME_WTHIN(float, false);
+        }
+#undef DMME_WTHIN
+        DMME_CHECK_LAUNCH();
+        return DMME_OK;
+    }
     const int rows = a.N * a.Hout;
     int chunks = rows < 256 ? rows : 256;  // few, long chunks: every chunk ends in one atomic per weight element (contended addresses)
     const int rpc = (rows + chunks - 1) / chunks;

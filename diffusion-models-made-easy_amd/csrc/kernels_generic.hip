@@ -376,34 +376,38 @@ int launch_pack_weight(int dtype, const float* src, int Cout, int Cin, int taps,
     return DMME_OK;
 }
 
-// table-driven: one workgroup per PackItem (a run of rows of one tensor)
+// table-driven: one workgroup per PackItem = a (cout range) x (cin range) sub-block of one tensor, at most 8192
+// elements.  The sub-block is read with contiguous runs of nci*taps floats per cout into LDS and written back in the
+// packed order ([cout][tap][cin], or [cin][taps-1-tap][cout] for the data-gradient copy) with contiguous runs too.
 template <typename T>
 __global__ void __launch_bounds__(256) pack_table_kernel(const PackItem* items, const float* ref, char* packed) {
+    __shared__ float tile[8192 + 256];
     const PackItem it = items[blockIdx.x];
-    const int64_t row = (int64_t)it.cin * it.taps;
-    const int64_t total = (int64_t)it.rows * row;
     const float* src = ref + it.src_off;
-    const int64_t e0 = (int64_t)it.row0 * row;
     if (it.as_f32 == 1) {
         float* dst = (float*)(packed + it.dst_off);
-        for (int64_t e = threadIdx.x; e < total; e += blockDim.x) dst[e0 + e] = src[e0 + e];
-    } else if (it.as_f32 == 2) {
-        // data-gradient copy: dst[ci][taps-1-tap][co]; this item covers source rows (couts) [row0, row0+rows)
-        T* dst = (T*)(packed + it.dst_off);
-        for (int64_t e = threadIdx.x; e < total; e += blockDim.x) {
-            const int64_t g = e0 + e;                      // reference-layout index: (co*cin + ci)*taps + tap
-            const int tap = (int)(g % it.taps);
-            const int64_t q = g / it.taps;
-            const int ci = (int)(q % it.cin), co = (int)(q / it.cin);
-            dst[((int64_t)ci * it.taps + (it.taps - 1 - tap)) * it.cout + co] = from_f<T>(src[g]);
+        const int row = it.cin * it.taps, total = it.rows * row, e0 = it.row0 * row;
+        for (int e = threadIdx.x; e < total; e += blockDim.x) dst[e0 + e] = src[e0 + e];
+        return;
+    }
+    const int taps = it.taps, nci = it.nci, seg = nci * taps;  // contiguous source run per cout
+    const int pitch = seg | 1;                                  // odd pitch: conflict-free column reads
+    const int total = it.rows * seg;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int co = e / seg, rem = e - co * seg;
+        tile[co * pitch + rem] = src[((int64_t)(it.row0 + co) * it.cin + it.ci0) * taps + rem];
+    }
+    __syncthreads();
+    T* dst = (T*)(packed + it.dst_off);
+    if (it.as_f32 == 2) {  // dst[ci][taps-1-tap][co]: runs of `rows` couts
+        for (int e = threadIdx.x; e < total; e += blockDim.x) {
+            const int co = e % it.rows, q = e / it.rows, tap = q % taps, cil = q / taps;
+            dst[((int64_t)(it.ci0 + cil) * taps + (taps - 1 - tap)) * it.cout + it.row0 + co] = from_f<T>(tile[co * pitch + cil * taps + tap]);
         }
-    } else {
-        T* dst = (T*)(packed + it.dst_off);
-        for (int64_t e = threadIdx.x; e < total; e += blockDim.x) {
-            const int64_t g = e0 + e;
-            const int64_t r = g / row, rem = g % row;
-            const int tap = (int)(rem / it.cin), ci = (int)(rem % it.cin);
-            dst[g] = from_f<T>(src[(r * it.cin + ci) * it.taps + tap]);
+    } else {               // dst[co][tap][ci]: runs of nci cins
+        for (int e = threadIdx.x; e < total; e += blockDim.x) {
+            const int cil = e % nci, q = e / nci, tap = q % taps, co = q / taps;
+            dst[((int64_t)(it.row0 + co) * taps + tap) * it.cin + it.ci0 + cil] = from_f<T>(tile[co * pitch + cil * taps + tap]);
         }
     }
 }

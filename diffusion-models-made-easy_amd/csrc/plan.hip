@@ -110,6 +110,10 @@ struct dmme_plan {
     std::vector<WgJob> wg_jobs;
     WgLayer* wg_layers_dev = nullptr;
     WgJob* wg_jobs_dev = nullptr;
+    // batched time-projection gradients: destination (float offset into grad_flat) of every 64-row tile of
+    // dtproj^T temb, then of every 32-column tile of the bias sums
+    int64_t* tp_tiles_dev = nullptr;
+    int tp_n64 = 0;
 };
 
 namespace {
@@ -534,48 +538,52 @@ int build_plan(dmme_plan* P) {
     return DMME_OK;
 }
 
-int build_pack_items(dmme_plan* P, std::vector<PackItem>& items) {
-    const int64_t CHUNK = 16384;
-    for (const Param& p : P->params) {
-        const int64_t row = (int64_t)p.cin * p.taps;
-        int64_t rows_per = CHUNK / row;
-        if (rows_per < 1) rows_per = 1;
-        for (int64_t r0 = 0; r0 < p.cout; r0 += rows_per) {
+// re-pack items: (cout range) x (cin range) sub-blocks of at most 8192 elements (the LDS tile of pack_table_kernel).
+// wide_co: prefer long cout runs (the transposed data-gradient layout writes runs of couts), else long cin runs.
+static void push_pack_items(const Param& p, int64_t dst_off, int as_f32, bool wide_co, std::vector<PackItem>& items) {
+    const int LIMIT = 8192;
+    int nco, nci;
+    if (as_f32 == 1) {
+        nci = p.cin;
+        nco = LIMIT / (p.cin * p.taps);
+        if (nco < 1) nco = 1;
+    } else if (wide_co) {
+        nco = p.cout < 64 ? p.cout : 64;
+        nci = LIMIT / (nco * p.taps);
+        if (nci > p.cin) nci = p.cin;
+        if (nci < 1) nci = 1;
+    } else {
+        nci = p.cin;
+        if (nci * p.taps > LIMIT) nci = LIMIT / p.taps;
+        nco = LIMIT / (nci * p.taps);
+        if (nco < 1) nco = 1;
+    }
+    if (as_f32 != 1 && nco > 256) nco = 256;  // the odd LDS pitch adds one float per cout: keep that within the tile's slack
+    for (int r0 = 0; r0 < p.cout; r0 += nco)
+        for (int c0 = 0; c0 < p.cin; c0 += nci) {
             PackItem it;
             it.src_off = p.ref_off;
-            it.dst_off = p.packed_off;
+            it.dst_off = dst_off;
             it.cout = p.cout;
             it.cin = p.cin;
             it.taps = p.taps;
-            it.row0 = (int32_t)r0;
-            it.rows = (int32_t)((p.cout - r0) < rows_per ? (p.cout - r0) : rows_per);
-            it.as_f32 = p.as_f32 ? 1 : 0;
+            it.row0 = r0;
+            it.rows = p.cout - r0 < nco ? p.cout - r0 : nco;
+            it.ci0 = c0;
+            it.nci = p.cin - c0 < nci ? p.cin - c0 : nci;
+            it.as_f32 = as_f32;
             items.push_back(it);
         }
-    }
+}
+
+int build_pack_items(dmme_plan* P, std::vector<PackItem>& items) {
+    for (const Param& p : P->params) push_pack_items(p, p.packed_off, p.as_f32 ? 1 : 0, false, items);
     return DMME_OK;
 }
 
 int build_pack_items_bwd(dmme_plan* P, std::vector<PackItem>& items) {
-    const int64_t CHUNK = 16384;
-    for (const Param& p : P->params) {
-        if (p.packed_bwd_off < 0) continue;
-        const int64_t row = (int64_t)p.cin * p.taps;
-        int64_t rows_per = CHUNK / row;
-        if (rows_per < 1) rows_per = 1;
-        for (int64_t r0 = 0; r0 < p.cout; r0 += rows_per) {
-            PackItem it;
-            it.src_off = p.ref_off;
-            it.dst_off = p.packed_bwd_off;
-            it.cout = p.cout;
-            it.cin = p.cin;
-            it.taps = p.taps;
-            it.row0 = (int32_t)r0;
-            it.rows = (int32_t)((p.cout - r0) < rows_per ? (p.cout - r0) : rows_per);
-            it.as_f32 = 2;
-            items.push_back(it);
-        }
-    }
+    for (const Param& p : P->params)
+        if (p.packed_bwd_off >= 0) push_pack_items(p, p.packed_bwd_off, 2, true, items);
     return DMME_OK;
 }
 
@@ -595,6 +603,8 @@ int build_unpack_items(dmme_plan* P, std::vector<PackItem>& items) {
             it.taps = p.taps;
             it.row0 = (int32_t)r0;
             it.rows = (int32_t)((p.cout - r0) < rows_per ? (p.cout - r0) : rows_per);
+            it.ci0 = 0;
+            it.nci = p.cin;
             it.as_f32 = 0;
             items.push_back(it);
         }
@@ -677,7 +687,9 @@ void fill_conv(const dmme_plan* P, const Op& o, const char* packed, const float*
 // sequence; its (cout tile, cin tile) pairs are cut into jobs of at most `q` consecutive 64-pixel tiles, longest first.
 void build_wgrad_group(dmme_plan* P) {
     if (P->dtype != DMME_BF16 || getenv("DMME_NO_WGRAD_GROUP")) return;
-    const int q = getenv("DMME_WG_Q") ? atoi(getenv("DMME_WG_Q")) : 128;
+    const int q = getenv("DMME_WG_Q") ? atoi(getenv("DMME_WG_Q")) : 64;
+    struct Grp { int layer, n_co, n_ci, tile0, ntiles; };
+    std::vector<Grp> groups;
     for (int oi = (int)P->ops.size() - 1; oi >= 0; --oi) {
         Op& o = P->ops[oi];
         if (o.kind != OP_CONV || o.src1 < 0 || o.dst < 0) continue;
@@ -696,19 +708,47 @@ void build_wgrad_group(dmme_plan* P) {
         P->wg_layers.push_back(L);
         const int n_co = (L.Cout + 63) / 64, n_ci = (L.C1 + L.C2) / 64;
         const int ns = (L.g.tiles_m + q - 1) / q;
-        for (int cot = 0; cot < n_co; ++cot)
-            for (int cit = 0; cit < n_ci; ++cit)
-                for (int sp = 0; sp < ns; ++sp) {
-                    WgJob j{};
-                    j.layer = o.wg_layer;
-                    j.cot = cot;
-                    j.cit = cit;
-                    j.tile0 = (int)((int64_t)L.g.tiles_m * sp / ns);
-                    j.ntiles = (int)((int64_t)L.g.tiles_m * (sp + 1) / ns) - j.tile0;
-                    if (j.ntiles > 0) P->wg_jobs.push_back(j);
-                }
+        for (int sp = 0; sp < ns; ++sp) {
+            Grp gr{};
+            gr.layer = o.wg_layer;
+            gr.n_co = n_co;
+            gr.n_ci = n_ci;
+            gr.tile0 = (int)((int64_t)L.g.tiles_m * sp / ns);
+            gr.ntiles = (int)((int64_t)L.g.tiles_m * (sp + 1) / ns) - gr.tile0;
+            if (gr.ntiles > 0) groups.push_back(gr);
+        }
     }
-    std::stable_sort(P->wg_jobs.begin(), P->wg_jobs.end(), [](const WgJob& x, const WgJob& y) { return x.ntiles > y.ntiles; });
+    // All (cout tile, cin tile) jobs of one pixel range read the same dY and activation tiles: they go to ONE XCD
+    // (consecutive positions of its round-robin slice of the grid, blockIdx % 8), so the re-reads hit that XCD's L2
+    // instead of HBM.  Groups are placed longest first on the least-loaded XCD; short slices are padded with empty jobs.
+    std::stable_sort(groups.begin(), groups.end(), [](const Grp& x, const Grp& y) { return x.ntiles > y.ntiles; });
+    const int NX = 8;
+    std::vector<WgJob> lists[NX];
+    int64_t load[NX] = {0};
+    for (const Grp& gr : groups) {
+        int best = 0;
+        for (int x = 1; x < NX; ++x)
+            if (load[x] < load[best]) best = x;
+        for (int cot = 0; cot < gr.n_co; ++cot)
+            for (int cit = 0; cit < gr.n_ci; ++cit) {
+                WgJob j{};
+                j.layer = gr.layer;
+                j.cot = cot;
+                j.cit = cit;
+                j.tile0 = gr.tile0;
+                j.ntiles = gr.ntiles;
+                lists[best].push_back(j);
+            }
+        load[best] += (int64_t)gr.ntiles * gr.n_co * gr.n_ci;
+    }
+    size_t longest = 0;
+    for (int x = 0; x < NX; ++x) longest = std::max(longest, lists[x].size());
+    for (size_t pos = 0; pos < longest; ++pos)
+        for (int x = 0; x < NX; ++x) {
+            WgJob j{};
+            if (pos < lists[x].size()) j = lists[x][pos];
+            P->wg_jobs.push_back(j);
+        }
 }
 
 // can this GroupNorm be finalised from the partials its producers emitted?
@@ -920,6 +960,24 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
         P->n_items_unpack = (int)uitems.size();
         if (e == hipSuccess) e = hipMalloc((void**)&P->items_unpack_dev, uitems.size() * sizeof(PackItem));
         if (e == hipSuccess) e = hipMemcpy(P->items_unpack_dev, uitems.data(), uitems.size() * sizeof(PackItem), hipMemcpyHostToDevice);
+        {
+            bool ok = !P->tblocks.empty() && P->tproj_cols % 64 == 0;
+            for (const auto& tb : P->tblocks) ok = ok && tb.cout % 64 == 0 && tb.col % 64 == 0;
+            if (ok) {
+                std::vector<int64_t> tiles(P->tproj_cols / 64 + P->tproj_cols / 32, -1);
+                const int n64 = P->tproj_cols / 64;
+                for (const auto& tb : P->tblocks) {
+                    for (int r = 0; r < tb.cout; r += 64) tiles[(tb.col + r) / 64] = P->params[tb.tw].ref_off + (int64_t)r * P->cfg.emb_dim;
+                    for (int r = 0; r < tb.cout; r += 32) tiles[n64 + (tb.col + r) / 32] = P->params[tb.tb].ref_off + r;
+                }
+                for (int64_t v : tiles) ok = ok && v >= 0;
+                if (ok) {
+                    if (e == hipSuccess) e = hipMalloc((void**)&P->tp_tiles_dev, tiles.size() * sizeof(int64_t));
+                    if (e == hipSuccess) e = hipMemcpy(P->tp_tiles_dev, tiles.data(), tiles.size() * sizeof(int64_t), hipMemcpyHostToDevice);
+                    P->tp_n64 = n64;
+                }
+            }
+        }
         if (!P->wg_jobs.empty()) {
             if (e == hipSuccess) e = hipMalloc((void**)&P->wg_layers_dev, P->wg_layers.size() * sizeof(WgLayer));
             if (e == hipSuccess) e = hipMemcpy(P->wg_layers_dev, P->wg_layers.data(), P->wg_layers.size() * sizeof(WgLayer), hipMemcpyHostToDevice);
@@ -943,6 +1001,7 @@ DMME_API void dmme_unet_plan_destroy(dmme_plan* plan) {
     if (plan->items_unpack_dev) (void)hipFree(plan->items_unpack_dev);
     if (plan->wg_layers_dev) (void)hipFree(plan->wg_layers_dev);
     if (plan->wg_jobs_dev) (void)hipFree(plan->wg_jobs_dev);
+    if (plan->tp_tiles_dev) (void)hipFree(plan->tp_tiles_dev);
     delete plan;
 }
 
@@ -1168,6 +1227,11 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
     float* dtemb = (float*)(bws + P->bws_dtemb);
     float* dh1 = (float*)(bws + P->bws_dh1);
     float* z = (float*)(bws + P->bws_z);
+    if (P->tp_tiles_dev) {  // every block's dW / db in one launch each
+        rc = launch_small_gemm_tn_tiled(dtproj, tc, temb, emb, tc, emb, nt, grad_flat, emb, P->tp_tiles_dev, s);
+        if (rc == DMME_OK) rc = launch_nsum_tiled(dtproj, nt, tc, tc, 1, grad_flat, P->tp_tiles_dev + P->tp_n64, s);
+        if (rc != DMME_OK) return rc;
+    } else
     for (const auto& tb : P->tblocks) {
         // dW_block[o][k] += sum_r dtproj[r][col+o] temb[r][k];  db_block[o] += sum_r dtproj[r][col+o]
         rc = launch_small_gemm(dt, 2, dtproj + tb.col, tc, temb, emb, tb.cout, emb, nt, nullptr, 0, grad_flat + P->params[tb.tw].ref_off, emb, s);

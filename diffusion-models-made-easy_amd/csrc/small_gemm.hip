@@ -12,7 +12,8 @@ enum { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
 
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256) small_gemm_kernel(const float* __restrict__ A, int lda, const void* __restrict__ Bv, int ldb, int M, int N,
-                                                         int K, const float* __restrict__ bias, int out_silu, float* __restrict__ Cm, int ldc, int ksplit) {
+                                                         int K, const float* __restrict__ bias, int out_silu, float* __restrict__ Cm, int ldc, int ksplit,
+                                                         const int64_t* __restrict__ mtile_off) {
     __shared__ float As[16][64 + 4];
     __shared__ float Bs[16][64 + 4];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
@@ -74,7 +75,9 @@ __global__ void __launch_bounds__(256) small_gemm_kernel(const float* __restrict
             if (n >= N) continue;
             float v = acc[i][j];
             if (MODE == GEMM_TN) {
-                Cm[(int64_t)m * ldc + n] += v;
+                // scattered output: each 64-row tile of C has its own base (several Linear layers in one launch)
+                float* crow = mtile_off ? Cm + mtile_off[blockIdx.y] + (int64_t)(ty * 4 + i) * ldc : Cm + (int64_t)m * ldc;
+                crow[n] += v;
             } else if (ksplit > 1) {
                 atomicAdd(&Cm[(int64_t)m * ldc + n], v);
             } else {
@@ -97,7 +100,7 @@ int launch_small_gemm(int dtype, int mode, const float* A, int lda, const void* 
     }
     if (ksplit > 1) DMME_CHECK_HIP(hipMemsetAsync(C, 0, (size_t)M * ldc * sizeof(float), s));
     dim3 grid((N + 63) / 64, (M + 63) / 64, ksplit);
-#define DMME_SG(TT, MM) hipLaunchKernelGGL((small_gemm_kernel<TT, MM>), grid, dim3(256), 0, s, A, lda, B, ldb, M, N, K, bias, out_silu, C, ldc, ksplit)
+#define DMME_SG(TT, MM) hipLaunchKernelGGL((small_gemm_kernel<TT, MM>), grid, dim3(256), 0, s, A, lda, B, ldb, M, N, K, bias, out_silu, C, ldc, ksplit, (const int64_t*)nullptr)
     if (mode == GEMM_TN) {
         DMME_SG(float, GEMM_TN);
     } else if (dtype == DMME_BF16) {
@@ -110,8 +113,20 @@ int launch_small_gemm(int dtype, int mode, const float* A, int lda, const void* 
     return DMME_OK;
 }
 
+// C[tile(m)][n] += sum_k A[k][m] * B[k][n] with a per-64-row-tile output base: the weight gradients of all the
+// per-ResBlock time projections (models/ddpm.py:101-104) in one launch
+int launch_small_gemm_tn_tiled(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc,
+                               const int64_t* mtile_off, hipStream_t s) {
+    dim3 grid((N + 63) / 64, (M + 63) / 64, 1);
+    hipLaunchKernelGGL((small_gemm_kernel<float, GEMM_TN>), grid, dim3(256), 0, s, A, lda, (const void*)B, ldb, M, N, K, (const float*)nullptr, 0, C, ldc,
+                       1, mtile_off);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
 // out[c] += sum_n M[n*stride + c*estride]   (bias-type reductions over the batch), one workgroup per 32 columns
-__global__ void __launch_bounds__(256) nsum_kernel(const float* __restrict__ Mx, int N, int C, int64_t stride, int estride, float* __restrict__ out) {
+__global__ void __launch_bounds__(256) nsum_kernel(const float* __restrict__ Mx, int N, int C, int64_t stride, int estride, float* __restrict__ out,
+                                                   const int64_t* __restrict__ ctile_off) {
     __shared__ float red[8][33];
     const int cl = threadIdx.x & 31, seg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
@@ -124,11 +139,18 @@ __global__ void __launch_bounds__(256) nsum_kernel(const float* __restrict__ Mx,
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += red[k][cl];
-        out[c] += t;
+        if (ctile_off) out[ctile_off[blockIdx.x] + cl] += t;  // per-32-column destination (several bias vectors in one launch)
+        else out[c] += t;
     }
 }
 int launch_nsum(const float* Mx, int N, int C, int64_t stride, int estride, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(nsum_kernel, dim3((C + 31) / 32), dim3(256), 0, s, Mx, N, C, stride, estride, out);
+    hipLaunchKernelGGL(nsum_kernel, dim3((C + 31) / 32), dim3(256), 0, s, Mx, N, C, stride, estride, out, (const int64_t*)nullptr);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+int launch_nsum_tiled(const float* Mx, int N, int C, int64_t stride, int estride, float* out, const int64_t* ctile_off, hipStream_t s) {
+    hipLaunchKernelGGL(nsum_kernel, dim3((C + 31) / 32), dim3(256), 0, s, Mx, N, C, stride, estride, out, ctile_off);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }

@@ -197,6 +197,7 @@ __global__ void __launch_bounds__(256, 2) wgrad9_group_kernel(const WgLayer* __r
     char* ldsY = lds;                 // [64 px][64 co]
     char* ldsV = lds + WG_PX * DYP;   // [halo px][64 ci]
     const WgJob job = jobs[blockIdx.x];
+    if (job.ntiles <= 0) return;  // padding of a short XCD slice
     const WgLayer& L = layers[job.layer];
     const ConvTile g = L.g;
     const int shTW = L.shTW, shTH = L.shTH;

@@ -185,9 +185,8 @@ template <typename T, bool FIRST>
 __global__ void __launch_bounds__(256) wgrad_thin_kernel(ConvArgs a, const T* __restrict__ dY, float* __restrict__ dW, int tiles_total) {
     constexpr int PX = 256, KP = 28;
     __shared__ __attribute__((aligned(16))) float lds[256 * 9 * 4];  // coef [PX][KP] (28 KB), then the merge buffer [lanes][9][Cw] (36 KB)
-    const int Cw = FIRST ? a.Cout : a.C1, G = FIRST ? a.C1 : a.Cout, K = G * 9;
+    const int Cw = FIRST ? a.Cout : a.C1, G = FIRST ? a.C1 : a.Cout;
     const int H = a.Hout, W = a.Wout, HW = H * W;
-    const int64_t total = (int64_t)a.N * HW;
     const int vecs = Cw / 4, lanes_p = 256 / vecs;
     const int tid = threadIdx.x, vec = tid % vecs, pl = tid / vecs;
     const T* wide = FIRST ? dY : (const T*)a.src1;
@@ -197,46 +196,64 @@ __global__ void __launch_bounds__(256) wgrad_thin_kernel(ConvArgs a, const T* __
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int k = 0; k < 27; ++k) acc[j][k] = 0.f;
+    const int total = a.N * HW;  // < 2^31 (checked by the launcher)
     for (int tile = blockIdx.x; tile < tiles_total; tile += gridDim.x) {
-        const int64_t p0 = (int64_t)tile * PX;
+        const int p0 = tile * PX;
         __syncthreads();
-        for (int e = tid; e < PX * 27; e += 256) {
-            const int pi = e % PX, k = e / PX;
-            const int64_t p = p0 + pi;
-            float v = 0.f;
-            if (p < total && k < K) {
-                const int n = (int)(p / HW), rem = (int)(p - (int64_t)n * HW), y = rem / W, x = rem - y * W;
-                const int g = k / 9, tap = k - g * 9, kh = tap / 3, kw = tap - kh * 3;
+        {   // thread <-> pixel: its 27 coefficients are 27 independent gathers
+            const int p = p0 + tid;
+            const int n = p / HW, rem = p - n * HW, y = rem / W, x = rem - y * W;
+            float cv[27];
+#pragma unroll
+            for (int k = 0; k < 27; ++k) {
+                const int g = k / 9, tap = k % 9, kh = tap / 3, kw = tap % 3;
                 const int sy = FIRST ? y - 1 + kh : y + 1 - kh, sx = FIRST ? x - 1 + kw : x + 1 - kw;
-                if (sy >= 0 && sy < H && sx >= 0 && sx < W)
+                float v = 0.f;
+                if (p < total && g < G && sy >= 0 && sy < H && sx >= 0 && sx < W)
                     v = FIRST ? xin[(((int64_t)n * G + g) * H + sy) * W + sx] : to_f(dY[(((int64_t)n * H + sy) * W + sx) * G + g]);
+                cv[k] = v;
             }
-            lds[pi * KP + k] = v;
+#pragma unroll
+            for (int k = 0; k < 27; ++k) lds[tid * KP + k] = cv[k];
         }
         __syncthreads();
-#pragma unroll 2
+        // GroupNorm scale/shift of this thread's 4 channels: per tile when the tile lies in one image, else per pixel
+        const int n_first = p0 / HW;
+        const bool one_image = (min(p0 + PX, total) - 1) / HW == n_first;
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (!FIRST) {
+            if (a.scale && one_image) {
+                const int64_t so = (int64_t)n_first * Cw + 4 * vec;
+                sc = *reinterpret_cast<const float4*>(a.scale + so);
+                sh = *reinterpret_cast<const float4*>(a.shift + so);
+            }
+        }
+#pragma unroll 4
         for (int pi = pl; pi < PX; pi += lanes_p) {
-            const int64_t p = p0 + pi;
-            if (p >= total) break;
-            float v[4];
+            const int p = p0 + pi;
+            const bool in = p < total;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
             if constexpr (sizeof(T) == 2) {
-                const uint2 raw = *reinterpret_cast<const uint2*>(wide + p * Cw + 4 * vec);
+                uint2 raw = make_uint2(0u, 0u);
+                if (in) raw = *reinterpret_cast<const uint2*>(wide + (int64_t)p * Cw + 4 * vec);
                 v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
                 v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
             } else {
-                const float4 raw = *reinterpret_cast<const float4*>(wide + p * Cw + 4 * vec);
+                float4 raw = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (in) raw = *reinterpret_cast<const float4*>(wide + (int64_t)p * Cw + 4 * vec);
                 v[0] = raw.x; v[1] = raw.y; v[2] = raw.z; v[3] = raw.w;
             }
             if constexpr (!FIRST) {
-                if (a.scale) {
-                    const int64_t so = (p / HW) * Cw + 4 * vec;
-                    const float4 sc = *reinterpret_cast<const float4*>(a.scale + so), sh = *reinterpret_cast<const float4*>(a.shift + so);
-                    v[0] = fmaf(v[0], sc.x, sh.x); v[1] = fmaf(v[1], sc.y, sh.y); v[2] = fmaf(v[2], sc.z, sh.z); v[3] = fmaf(v[3], sc.w, sh.w);
+                if (a.scale && !one_image && in) {
+                    const int64_t so = (int64_t)(p / HW) * Cw + 4 * vec;
+                    sc = *reinterpret_cast<const float4*>(a.scale + so);
+                    sh = *reinterpret_cast<const float4*>(a.shift + so);
                 }
+                v[0] = fmaf(v[0], sc.x, sh.x); v[1] = fmaf(v[1], sc.y, sh.y); v[2] = fmaf(v[2], sc.z, sh.z); v[3] = fmaf(v[3], sc.w, sh.w);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (a.pro_silu) v[j] = sizeof(T) == 2 ? silu_fast(v[j]) : silu_f(v[j]);  // same SiLU flavour as the forward prologue
-                    v[j] = to_f(from_f<T>(v[j]));
+                    v[j] = in ? to_f(from_f<T>(v[j])) : 0.f;
                 }
             }
             const float4* cp = reinterpret_cast<const float4*>(lds + pi * KP);
@@ -262,8 +279,10 @@ __global__ void __launch_bounds__(256) wgrad_thin_kernel(ConvArgs a, const T* __
             *reinterpret_cast<float4*>(lds + ((int64_t)pl * 9 + t) * Cw + 4 * vec) =
                 make_float4(acc[0][g * 9 + t], acc[1][g * 9 + t], acc[2][g * 9 + t], acc[3][g * 9 + t]);
         __syncthreads();
+        // every workgroup adds into the same few KB: lanes walk the destination in address order (c-major, tap-minor),
+        // so one wave instruction touches 2 (last conv) or ~7 (first conv) cache lines instead of one per lane
         for (int e = tid; e < 9 * Cw; e += 256) {
-            const int t = e / Cw, c = e - t * Cw;
+            const int c = e / 9, t = e - c * 9;
             float sum = 0.f;
             for (int l = 0; l < lanes_p; ++l) sum += lds[(l * 9 + t) * Cw + c];
             const int64_t idx = FIRST ? ((int64_t)c * G + g) * 9 + t : ((int64_t)g * Cw + c) * 9 + t;
@@ -276,6 +295,7 @@ static bool wgrad_thin_supported(const ConvArgs& a) {
     if (a.taps != 9 || a.stride != 1 || a.up || a.C2 || a.dmask || a.Hout != a.Hin || a.Wout != a.Win) return false;
     const int Cw = a.in_nchw ? a.Cout : a.C1, G = a.in_nchw ? a.C1 : a.Cout;
     if (G > 3 || Cw % 4 || Cw / 4 > 256 || 256 % (Cw / 4)) return false;
+    if ((int64_t)a.N * a.Hout * a.Wout * (Cw > 27 ? Cw : 27) >= (1ll << 31)) return false;
     if (a.in_nchw) return !a.scale && !a.pro_silu;
     return true;
 }
@@ -290,7 +310,7 @@ bool wgrad_small_supported(int dtype, const ConvArgs& a) {
 int launch_wgrad_small(int dtype, const ConvArgs& a, const void* dY, float* dW, hipStream_t s) {
     if (wgrad_thin_supported(a) && !getenv("DMME_NO_WGRAD_THIN")) {
         const int64_t total = (int64_t)a.N * a.Hout * a.Wout;
-        const int tiles = (int)((total + 255) / 256), grid = tiles < 512 ? tiles : 512;
+        const int tiles = (int)((total + 255) / 256), grid = tiles < 256 ? tiles : 256;  // few workgroups: they all end in atomics on the same addresses
 #define DMME_WTHIN(TT, FF) hipLaunchKernelGGL((wgrad_thin_kernel<TT, FF>), dim3(grid), dim3(256), 0, s, a, (const TT*)dY, dW, tiles)
         if (dtype == DMME_BF16) {
             if (a.in_nchw) DMME_WTHIN(bf16, true); else DMME_WTHIN(bf16, false);

@@ -67,7 +67,7 @@ struct Op {
     int res1 = -1, res2 = -1;
     int dst = -1;              // tensor id; -2: network output (NCHW fp32)
     int up = 0, stride = 1, taps = 9;
-    int wg_layer = -1;         // index into the grouped weight-gradient table (-1: per-layer kernels)
+    int wg_layer = -1;         // index into the grouped weight-gradient table of its kernel size (-1: per-layer kernels)
     // OP_ATTN
     int at_qkv = -1, at_out = -1;
     int64_t at_lse = 0;  // workspace offset of the forward's log-sum-exp [N][S]
@@ -106,10 +106,13 @@ struct dmme_plan {
     PackItem* items_bwd_dev = nullptr;
     int n_items_bwd = 0;
     // grouped weight gradients (one launch per backward)
-    std::vector<WgLayer> wg_layers;
-    std::vector<WgJob> wg_jobs;
-    WgLayer* wg_layers_dev = nullptr;
-    WgJob* wg_jobs_dev = nullptr;
+    struct WgGroup {
+        int taps = 0;
+        std::vector<WgLayer> layers;
+        std::vector<WgJob> jobs;
+        WgLayer* layers_dev = nullptr;
+        WgJob* jobs_dev = nullptr;
+    } wg[2];  // 3x3, 1x1
     // batched time-projection gradients: destination (float offset into grad_flat) of every 64-row tile of
     // dtproj^T temb, then of every 32-column tile of the bias sums
     int64_t* tp_tiles_dev = nullptr;
@@ -685,18 +688,20 @@ void fill_conv(const dmme_plan* P, const Op& o, const char* packed, const float*
 
 // Grouped weight gradients: every 3x3 stride-1 conv the all-taps MFMA kernel supports is taken out of the per-layer
 // sequence; its (cout tile, cin tile) pairs are cut into jobs of at most `q` consecutive 64-pixel tiles, longest first.
-void build_wgrad_group(dmme_plan* P) {
+void build_wgrad_group(dmme_plan* P, dmme_plan::WgGroup& G, int taps) {
+    G.taps = taps;
     if (P->dtype != DMME_BF16 || getenv("DMME_NO_WGRAD_GROUP")) return;
-    const int q = getenv("DMME_WG_Q") ? atoi(getenv("DMME_WG_Q")) : 64;
+    const int q = taps == 9 ? (getenv("DMME_WG_Q") ? atoi(getenv("DMME_WG_Q")) : 64) : (getenv("DMME_WG_Q1") ? atoi(getenv("DMME_WG_Q1")) : 64);
     struct Grp { int layer, n_co, n_ci, tile0, ntiles; };
     std::vector<Grp> groups;
     for (int oi = (int)P->ops.size() - 1; oi >= 0; --oi) {
         Op& o = P->ops[oi];
-        if (o.kind != OP_CONV || o.src1 < 0 || o.dst < 0) continue;
+        if (o.kind != OP_CONV || o.src1 < 0 || o.dst < 0 || o.taps != taps) continue;
         ConvArgs a{};
         fill_conv(P, o, nullptr, nullptr, nullptr, nullptr, nullptr, 1, a);
         WgLayer L{};
-        if (!wgrad_mfma_supported(P->dtype, a) || !wgrad_group_layer(P->dtype, a, L)) continue;
+        int CO = 0, CI = 0;
+        if (!wgrad_mfma_supported(P->dtype, a) || !wgrad_group_layer(P->dtype, a, L, &CO, &CI)) continue;
         L.src1_off = P->tensors[o.src1].off;
         L.src2_off = o.src2 >= 0 ? P->tensors[o.src2].off : -1;
         L.scale_off = o.gn >= 0 ? P->ops[o.gn].gn_scale : -1;
@@ -704,9 +709,9 @@ void build_wgrad_group(dmme_plan* P) {
         L.dmask_off = o.dmask_off;
         L.dy_off = P->gt_off[o.dst];
         L.dw_off = P->params[o.w].wp_off;
-        o.wg_layer = (int)P->wg_layers.size();
-        P->wg_layers.push_back(L);
-        const int n_co = (L.Cout + 63) / 64, n_ci = (L.C1 + L.C2) / 64;
+        o.wg_layer = (int)G.layers.size();
+        G.layers.push_back(L);
+        const int n_co = (L.Cout + CO - 1) / CO, n_ci = (L.C1 + L.C2) / CI;
         const int ns = (L.g.tiles_m + q - 1) / q;
         for (int sp = 0; sp < ns; ++sp) {
             Grp gr{};
@@ -747,7 +752,7 @@ void build_wgrad_group(dmme_plan* P) {
         for (int x = 0; x < NX; ++x) {
             WgJob j{};
             if (pos < lists[x].size()) j = lists[x][pos];
-            P->wg_jobs.push_back(j);
+            G.jobs.push_back(j);
         }
 }
 
@@ -942,7 +947,10 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
         return rc;
     }
     if (!getenv("DMME_NO_FUSED_GN")) assign_stats(P);
-    if (device >= 0) build_wgrad_group(P);
+    if (device >= 0) {
+        build_wgrad_group(P, P->wg[0], 9);
+        build_wgrad_group(P, P->wg[1], 1);
+    }
     if (device >= 0) {
         std::vector<PackItem> items;
         build_pack_items(P, items);
@@ -978,11 +986,12 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
                 }
             }
         }
-        if (!P->wg_jobs.empty()) {
-            if (e == hipSuccess) e = hipMalloc((void**)&P->wg_layers_dev, P->wg_layers.size() * sizeof(WgLayer));
-            if (e == hipSuccess) e = hipMemcpy(P->wg_layers_dev, P->wg_layers.data(), P->wg_layers.size() * sizeof(WgLayer), hipMemcpyHostToDevice);
-            if (e == hipSuccess) e = hipMalloc((void**)&P->wg_jobs_dev, P->wg_jobs.size() * sizeof(WgJob));
-            if (e == hipSuccess) e = hipMemcpy(P->wg_jobs_dev, P->wg_jobs.data(), P->wg_jobs.size() * sizeof(WgJob), hipMemcpyHostToDevice);
+        for (auto& G : P->wg) {
+            if (G.jobs.empty()) continue;
+            if (e == hipSuccess) e = hipMalloc((void**)&G.layers_dev, G.layers.size() * sizeof(WgLayer));
+            if (e == hipSuccess) e = hipMemcpy(G.layers_dev, G.layers.data(), G.layers.size() * sizeof(WgLayer), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMalloc((void**)&G.jobs_dev, G.jobs.size() * sizeof(WgJob));
+            if (e == hipSuccess) e = hipMemcpy(G.jobs_dev, G.jobs.data(), G.jobs.size() * sizeof(WgJob), hipMemcpyHostToDevice);
         }
         if (e != hipSuccess) {
             set_error("plan_create: device table setup failed: %s", hipGetErrorString(e));
@@ -999,8 +1008,10 @@ DMME_API void dmme_unet_plan_destroy(dmme_plan* plan) {
     if (plan->items_dev) (void)hipFree(plan->items_dev);
     if (plan->items_bwd_dev) (void)hipFree(plan->items_bwd_dev);
     if (plan->items_unpack_dev) (void)hipFree(plan->items_unpack_dev);
-    if (plan->wg_layers_dev) (void)hipFree(plan->wg_layers_dev);
-    if (plan->wg_jobs_dev) (void)hipFree(plan->wg_jobs_dev);
+    for (auto& G : plan->wg) {
+        if (G.layers_dev) (void)hipFree(G.layers_dev);
+        if (G.jobs_dev) (void)hipFree(G.jobs_dev);
+    }
     if (plan->tp_tiles_dev) (void)hipFree(plan->tp_tiles_dev);
     delete plan;
 }
@@ -1153,7 +1164,7 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
                                o.tproj_col >= 0 ? dtproj + o.tproj_col : nullptr, P->tproj_cols, nt, s);
         if (rc != DMME_OK) break;
         // 2. weight gradient: deferred to the grouped launch below, or per layer (packed image / reference layout)
-        if (o.wg_layer >= 0 && P->wg_jobs_dev)
+        if (o.wg_layer >= 0 && P->wg[o.taps == 9 ? 0 : 1].jobs_dev)
             rc = DMME_OK;
         else if (wgrad_mfma_supported(dt, a))
             rc = launch_wgrad_mfma(dt, a, dy, wimage + P->params[o.w].wp_off, s);
@@ -1210,9 +1221,10 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
         }
     }
     if (rc != DMME_OK) return rc;
-    // all deferred 3x3 weight gradients in one launch: every dY and forward activation is still in its workspace
-    if (P->wg_jobs_dev) {
-        rc = launch_wgrad_group(dt, P->wg_layers_dev, P->wg_jobs_dev, (int)P->wg_jobs.size(), ws, bws, drop_masks, wimage, s);
+    // all deferred 3x3 (then 1x1) weight gradients in one launch each: every dY and forward activation is still in its workspace
+    for (const auto& G : P->wg) {
+        if (!G.jobs_dev) continue;
+        rc = launch_wgrad_group(dt, G.taps, G.layers_dev, G.jobs_dev, (int)G.jobs.size(), ws, bws, drop_masks, wimage, s);
         if (rc != DMME_OK) return rc;
     }
     // fold the packed-layout weight-gradient image into the reference-layout gradients (one launch)

@@ -177,25 +177,41 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(ConvArgs a, ConvTile g,
 }
 
 
-// ---- grouped all-nine-taps weight gradient (3x3, stride 1, bf16) ---------------------------------------------
+// ---- grouped weight gradients (3x3 and 1x1, stride 1, bf16) --------------------------------------------------
 // Split-K weight gradients pay for their parallelism in atomics: every workgroup ends with one atomic per output it
 // owns, and a layer launched alone needs hundreds of pixel splits to fill 256 CUs (measured: ~65 us of atomics per
 // layer, more than the MFMA time of most layers).  The backward therefore DEFERS these weight gradients - every dY
-// and every forward activation stays in its workspace - and runs them all in ONE launch over a plan-time job table:
-// ~50 layers supply the parallelism, each job owns a long contiguous run of pixel tiles, and the atomic count drops
-// by more than an order of magnitude.
-// One job = 64 couts x 64 cins x ALL 9 taps (4 waves 2x2, wave tile 32 co x 32 ci, 9 accumulators) over `ntiles`
-// 64-pixel tiles.  The raw dY / input vectors of the next tile are prefetched into registers while the MFMAs of the
-// current one run; the GN-affine/SiLU/dropout prologue is applied when they are written to LDS.
-template <typename T>
-__global__ void __launch_bounds__(256, 2) wgrad9_group_kernel(const WgLayer* __restrict__ layers, const WgJob* __restrict__ jobs,
-                                                              const char* __restrict__ ws, const char* __restrict__ bws,
-                                                              const float* __restrict__ drop_masks, float* __restrict__ wimage) {
+// and every forward activation stays in its workspace - and runs them in ONE launch per kernel size over a plan-time
+// job table: ~50 layers supply the parallelism, each job owns a long contiguous run of pixel tiles, and the atomic
+// count drops by more than an order of magnitude.
+// One job = (64*WM) couts x (64*WN) cins x all TAPS taps (4 waves 2x2, wave tile 32*WM co x 32*WN ci) over `ntiles`
+// 64-pixel tiles: <9,1,1> for 3x3 (144 accumulator registers), <1,2,2> for 1x1.  The raw dY / input vectors of the
+// next tile are prefetched into registers while the MFMAs of the current one run; the GN-affine/SiLU/dropout
+// prologue is applied when they are written to LDS.
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+template <int TAPS, int WM, int WN>
+struct WgGroupGeom {
+    static constexpr int CO = 64 * WM, CI = 64 * WN;
+    static constexpr int DYP = CO * 2 + 64, VP = CI * 2 + 64;  // pitches: the 4 rows of a transposed read on disjoint banks
+    static constexpr int MAX_ROWS = TAPS == 9 ? 160 : 64;     // halo rows of one 64-pixel tile
+    static constexpr int UY = WG_PX * (CO / 8) / 256;          // dY vectors per thread
+    static constexpr int UV = (MAX_ROWS * (CI / 8) + 255) / 256;  // input vectors per thread
+    static constexpr size_t LDS = (size_t)WG_PX * DYP + (size_t)MAX_ROWS * VP;
+};
+
+template <typename T, int TAPS, int WM, int WN>
+__global__ void __launch_bounds__(256, 2) wgrad_group_kernel(const WgLayer* __restrict__ layers, const WgJob* __restrict__ jobs,
+                                                             const char* __restrict__ ws, const char* __restrict__ bws,
+                                                             const float* __restrict__ drop_masks, float* __restrict__ wimage) {
     static_assert(sizeof(T) == 2, "grouped weight gradient is bf16 only");
-    constexpr int EPV = 8, CO = 64, CI = 64, DYP = 192, VP = WgGeom<T>::V_PITCH;
+    using GG = WgGroupGeom<TAPS, WM, WN>;
+    constexpr int EPV = 8, CO = GG::CO, CI = GG::CI, DYP = GG::DYP, VP = GG::VP, UY = GG::UY, UV = GG::UV;
+    constexpr int PAD = TAPS == 9 ? 1 : 0;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    char* ldsY = lds;                 // [64 px][64 co]
-    char* ldsV = lds + WG_PX * DYP;   // [halo px][64 ci]
+    lds_char* ldsY = (lds_char*)lds;      // [64 px][CO]
+    lds_char* ldsV = ldsY + WG_PX * DYP;  // [halo px][CI]
     const WgJob job = jobs[blockIdx.x];
     if (job.ntiles <= 0) return;  // padding of a short XCD slice
     const WgLayer& L = layers[job.layer];
@@ -210,7 +226,7 @@ __global__ void __launch_bounds__(256, 2) wgrad9_group_kernel(const WgLayer* __r
     const float* dmask = (drop_masks && L.dmask_off >= 0) ? drop_masks + L.dmask_off : nullptr;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;
+    const int wco = (wave >> 1) * 32 * WM, wci = (wave & 1) * 32 * WN;
     const int r = lane & 31, h = lane >> 5;
     const int Cin = C1 + C2;
     const int co0 = job.cot * CO, ci0 = job.cit * CI;
@@ -220,15 +236,27 @@ __global__ void __launch_bounds__(256, 2) wgrad9_group_kernel(const WgLayer* __r
     const bool second = ci0 >= C1;
     const T* sbase = (const T*)(ws + (second ? L.src2_off : L.src1_off));
     const int Cs = second ? C2 : C1, cs0 = second ? ci0 - C1 : ci0;
-    f32x16 acc[9];
+    f32x16 acc[TAPS][WM][WN];
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
+    for (int k = 0; k < TAPS; ++k)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[k][j] = 0.f;
+        for (int a = 0; a < WM; ++a)
+#pragma unroll
+            for (int b = 0; b < WN; ++b)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[k][a][b][j] = 0.f;
     const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g1 = (lane >> 4) & 1;
+    // LDS byte offsets of this lane's fragment rows for k-step 0 (pixel 8h + tr_q); pixel bits 2 (second half of the
+    // fragment) and 4-5 (k-step) add the uniform offsets L.half_off / L.ks_off (bit fields of tx, ty, tn do not carry)
+    const int a_base = (8 * h + tr_q) * DYP + (wco + 16 * tr_g1 + 4 * tr_p) * 2;
+    int b_base;
+    {
+        const int m = 8 * h + tr_q;
+        const int tx = m & mTW, ty = (m >> shTW) & mTH, tn = m >> (shTW + shTH);
+        b_base = ((tn * g.HH + ty) * g.HWd + tx) * VP + (wci + 16 * tr_g1 + 4 * tr_p) * 2;
+    }
+    const int row_b = g.HWd * VP;
 
-    constexpr int UY = WG_PX * (CO / EPV) / 256;   // dY vectors per thread
-    constexpr int UV = 5;                          // halo vectors per thread (a_rows <= 160)
     uint4 ry[UY], rv[UV];
     unsigned vmask = 0;                            // bit k: halo vector k is inside the image (else zero padding)
     int n0_cur = 0;
@@ -254,7 +282,7 @@ __global__ void __launch_bounds__(256, 2) wgrad9_group_kernel(const WgLayer* __r
             const int row = u / (CI / EPV), cu = u % (CI / EPV);
             const int tn = (int)__umulhi((unsigned)row, g.magic_px), rem = row - tn * halo_px;
             const int hy = (int)__umulhi((unsigned)rem, g.magic_w), hx = rem - hy * g.HWd;
-            const int n = n0 + tn, iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+            const int n = n0 + tn, iy = oy0 - PAD + hy, ix = ox0 - PAD + hx;
             rv[k] = make_uint4(0u, 0u, 0u, 0u);
             if (row < g.a_rows && n < N && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) {
                 const int sy = up ? (iy >> 1) : iy, sx = up ? (ix >> 1) : ix;
@@ -270,7 +298,7 @@ __global__ void __launch_bounds__(256, 2) wgrad9_group_kernel(const WgLayer* __r
 #pragma unroll
         for (int k = 0; k < UY; ++k) {
             const int u = tid + 256 * k;
-            *reinterpret_cast<uint4*>(ldsY + (u / (CO / EPV)) * DYP + (u % (CO / EPV)) * 16) = ry[k];
+            *reinterpret_cast<uint4*>(lds + (u / (CO / EPV)) * DYP + (u % (CO / EPV)) * 16) = ry[k];
         }
 #pragma unroll
         for (int k = 0; k < UV; ++k) {
@@ -282,48 +310,53 @@ __global__ void __launch_bounds__(256, 2) wgrad9_group_kernel(const WgLayer* __r
                 const int64_t so = (int64_t)n * Cin + ci0 + cu * EPV;
                 val = prologue_vec<T>(val, scale ? scale + so : nullptr, scale ? shift + so : nullptr, dmask ? dmask + so : nullptr, pro_silu);
             }
-            if (row < g.a_rows) *reinterpret_cast<uint4*>(ldsV + row * VP + cu * 16) = val;
+            if (row < g.a_rows) *reinterpret_cast<uint4*>(lds + WG_PX * DYP + row * VP + cu * 16) = val;
         }
         __syncthreads();
         if (tile + 1 < tile_end) issue(tile + 1);
-#pragma unroll 1
+#pragma unroll TAPS == 9 ? 1 : 4
         for (int ks = 0; ks < WG_PX / 16; ++ks) {
-            s16x8 af;
-            {
-                const char* p0 = ldsY + (16 * ks + 8 * h + tr_q) * DYP + (wco + 16 * tr_g1 + 4 * tr_p) * 2;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 4 * DYP));
-                af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3];
-                af[4] = hi[0]; af[5] = hi[1]; af[6] = hi[2]; af[7] = hi[3];
-            }
-            int vrow[2];
+            s16x8 af[WM];
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int m = 16 * ks + 8 * h + 4 * half + tr_q;
-                const int tx = m & mTW, ty = (m >> shTW) & mTH, tn = m >> (shTW + shTH);
-                vrow[half] = (tn * g.HH + ty) * g.HWd + tx;
+            for (int a = 0; a < WM; ++a) {
+                lds_char* p0 = ldsY + a_base + 16 * ks * DYP + a * 64;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * DYP));
+                af[a][0] = lo[0]; af[a][1] = lo[1]; af[a][2] = lo[2]; af[a][3] = lo[3];
+                af[a][4] = hi[0]; af[a][5] = hi[1]; af[a][6] = hi[2]; af[a][7] = hi[3];
             }
-            const int colb = (wci + 16 * tr_g1 + 4 * tr_p) * 2;
+            const int ks_b = b_base + L.ks_off[ks];
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int toff = (tap / 3) * g.HWd + (tap % 3);
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ldsV + (vrow[0] + toff) * VP + colb));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ldsV + (vrow[1] + toff) * VP + colb));
-                s16x8 bfr;
-                bfr[0] = lo[0]; bfr[1] = lo[1]; bfr[2] = lo[2]; bfr[3] = lo[3];
-                bfr[4] = hi[0]; bfr[5] = hi[1]; bfr[6] = hi[2]; bfr[7] = hi[3];
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bfr), acc[tap], 0, 0, 0);
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int t_b = ks_b + (tap / 3) * row_b;
+#pragma unroll
+                for (int b = 0; b < WN; ++b) {
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ldsV + t_b + (tap % 3) * VP + b * 64));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ldsV + t_b + L.half_off + (tap % 3) * VP + b * 64));
+                    s16x8 bfr;
+                    bfr[0] = lo[0]; bfr[1] = lo[1]; bfr[2] = lo[2]; bfr[3] = lo[3];
+                    bfr[4] = hi[0]; bfr[5] = hi[1]; bfr[6] = hi[2]; bfr[7] = hi[3];
+#pragma unroll
+                    for (int a = 0; a < WM; ++a)
+                        acc[tap][a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[a]), __builtin_bit_cast(bf16x8, bfr),
+                                                                               acc[tap][a][b], 0, 0, 0);
+                }
             }
         }
     }
-    const int ci = ci0 + wci + r;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int tap = 0; tap < TAPS; ++tap)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int co = co0 + wco + (j & 3) + 8 * (j >> 2) + 4 * h;
-            if (co < Cout) atomicAdd(dWp + ((int64_t)co * 9 + tap) * Cin + ci, acc[tap][j]);
-        }
+        for (int a = 0; a < WM; ++a)
+#pragma unroll
+            for (int b = 0; b < WN; ++b) {
+                const int ci = ci0 + wci + 32 * b + r;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int co = co0 + wco + 32 * a + (j & 3) + 8 * (j >> 2) + 4 * h;
+                    if (co < Cout) atomicAdd(dWp + ((int64_t)co * TAPS + tap) * Cin + ci, acc[tap][a][b][j]);
+                }
+            }
 }
 
 static bool wg_tile(const ConvArgs& a, ConvTile& g) {
@@ -401,29 +434,48 @@ int launch_wgrad_unpack(const PackItem* items_dev, int n_items, const float* ima
     return DMME_OK;
 }
 
-bool wgrad_group_layer(int dtype, const ConvArgs& a, WgLayer& L) {
-    if (dtype != DMME_BF16 || a.taps != 9 || a.stride != 1 || a.in_nchw) return false;
+bool wgrad_group_layer(int dtype, const ConvArgs& a, WgLayer& L, int* co_tile, int* ci_tile) {
+    if (dtype != DMME_BF16 || (a.taps != 9 && a.taps != 1) || a.stride != 1 || a.in_nchw || a.up == 2) return false;
+    if (a.taps == 1 && a.up) return false;
+    const int CO = a.taps == 9 ? 64 : 128, CI = a.taps == 9 ? 64 : 128;
     const int Cin = a.C1 + a.C2;
-    if (Cin % 64 || a.C1 % 64 || a.Cout % 8) return false;
+    if (Cin % CI || a.C1 % CI || a.Cout % 8) return false;
     ConvTile g{};
-    if (!make_tile(a, WG_PX, 64, g) || g.TW < 4 || g.a_rows > 160) return false;
+    if (!make_tile(a, WG_PX, 64, g) || g.TW < 4 || g.a_rows > (a.taps == 9 ? 160 : 64) || a.N % g.TN) return false;
     L.g = g;
     L.shTW = L.shTH = 0;
     while ((1 << L.shTW) < g.TW) ++L.shTW;
     while ((1 << L.shTH) < g.TH) ++L.shTH;
     if ((1 << L.shTW) != g.TW || (1 << L.shTH) != g.TH) return false;
+    const int VP = CI * 2 + 64;
+    auto row_of = [&](int m) {  // halo row of tile pixel m (tap 0)
+        const int tx = m & (g.TW - 1), ty = (m >> L.shTW) & (g.TH - 1), tn = m >> (L.shTW + L.shTH);
+        return (tn * g.HH + ty) * g.HWd + tx;
+    };
+    for (int ks = 0; ks < 4; ++ks) L.ks_off[ks] = row_of(16 * ks) * VP;
+    L.half_off = row_of(4) * VP;
     L.N = a.N; L.Hin = a.Hin; L.Win = a.Win; L.C1 = a.C1; L.C2 = a.C2; L.up = a.up;
     L.Hout = a.Hout; L.Wout = a.Wout; L.Cout = a.Cout; L.pro_silu = a.pro_silu;
+    *co_tile = CO;
+    *ci_tile = CI;
     return true;
 }
 
-int launch_wgrad_group(int dtype, const WgLayer* layers_dev, const WgJob* jobs_dev, int njobs, const void* ws, const void* bws,
+int launch_wgrad_group(int dtype, int taps, const WgLayer* layers_dev, const WgJob* jobs_dev, int njobs, const void* ws, const void* bws,
                        const float* drop_masks, float* wimage, hipStream_t s) {
-    DMME_REQUIRE(dtype == DMME_BF16, DMME_ERR_UNSUPPORTED, "grouped weight gradient is bf16 only");
+    DMME_REQUIRE(dtype == DMME_BF16 && (taps == 9 || taps == 1), DMME_ERR_UNSUPPORTED, "grouped weight gradient: bf16, 3x3 or 1x1 only");
     if (njobs <= 0) return DMME_OK;
-    const size_t lds = (size_t)WG_PX * 192 + (size_t)160 * WgGeom<bf16>::V_PITCH;
-    hipLaunchKernelGGL((wgrad9_group_kernel<bf16>), dim3((unsigned)njobs), dim3(256), lds, s, layers_dev, jobs_dev, (const char*)ws,
-                       (const char*)bws, drop_masks, wimage);
+    if (taps == 9) {
+        constexpr size_t lds = WgGroupGeom<9, 1, 1>::LDS;
+        static_assert(lds <= 64 * 1024, "LDS tile");
+        hipLaunchKernelGGL((wgrad_group_kernel<bf16, 9, 1, 1>), dim3((unsigned)njobs), dim3(256), lds, s, layers_dev, jobs_dev, (const char*)ws,
+                           (const char*)bws, drop_masks, wimage);
+    } else {
+        constexpr size_t lds = WgGroupGeom<1, 2, 2>::LDS;
+        static_assert(lds <= 64 * 1024, "LDS tile");
+        hipLaunchKernelGGL((wgrad_group_kernel<bf16, 1, 2, 2>), dim3((unsigned)njobs), dim3(256), lds, s, layers_dev, jobs_dev, (const char*)ws,
+                           (const char*)bws, drop_masks, wimage);
+    }
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }

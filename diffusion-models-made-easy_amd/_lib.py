@@ -101,6 +101,7 @@ PROTOTYPES = {
     "dmme_event_record": (_i, [_vp, _vp]),
     "dmme_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(_f)]),
     "dmme_event_destroy": (_i, [_vp]),
+    "dmme_debug_set_stamps": (_i, [_vp]),
 }
 
 

@@ -121,6 +121,8 @@ struct ConvArgs {
     // partials, [N][gn_tiles][Cout/gn_cg][2], written by the LDS-staged epilogue; merged by gn_finalize_parts
     float* gn_part;
     int gn_cg, gn_tiles;
+    // diagnostic (null: off): per-phase cycle stamps of a few workgroups, [slot][64] (dmme_debug_set_stamps)
+    long long* stamps;
 };
 
 // ---- kernel launchers (defined in the .hip files) ------------------------------------

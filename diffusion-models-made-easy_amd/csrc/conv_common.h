@@ -102,123 +102,166 @@ __device__ __forceinline__ uint4 prologue_vec<bf16>(uint4 raw, const float* sc, 
 // handles whole 16-byte output vectors: one vector residual load, one vector store.
 // Everything else takes the general path straight from the registers.
 // `stage` must hold BM*BN floats and no wave may still be reading operand tiles from it.
-template <typename T, int BM, int BN, int MI, int NI, typename PixFn>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MI][NI], int co0, int wn0, int r, int h,
-                                              int wm0, int n0, int TN, PixFn pix_of, float* stage, int tile_s) {
+// The staged fast epilogue in two parts, so a wave without accumulators (wave-specialised kernels) can join the store loop:
+// conv_epilogue_stage: accumulators (+ bias + time embedding) -> fp32 [BM][BN] image in LDS      (no barrier)
+// conv_epilogue_store: after a barrier - every thread handles whole 16-byte output vectors; NT = threads taking part
+template <typename T>
+__device__ __forceinline__ bool conv_epilogue_is_staged(const ConvArgs& a, int TN) {
     constexpr int VEC = 16 / sizeof(T);
     const bool uniform_t = !a.tproj || a.nt == 1 || TN == 1;
-    if (!a.out_silu && !a.out_nchw && uniform_t && (a.Cout % VEC) == 0) {
+    return !a.out_silu && !a.out_nchw && uniform_t && (a.Cout % VEC) == 0;
+}
+template <typename T, int BN, int MI, int NI>
+__device__ __forceinline__ void conv_epilogue_stage(const ConvArgs& a, f32x16 (&acc)[MI][NI], int co0, int wn0, int r, int h, int wm0, int n0,
+                                                    float* stage) {
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int c = wn0 + ni * 32 + r, co = co0 + c;
-            float fold = 0.f;
-            if (co < a.Cout) {
-                fold = a.bias ? a.bias[co] : 0.f;
-                if (a.tproj) fold += a.tproj[(a.nt == 1 ? 0 : n0) * a.tproj_ld + co];
+    for (int ni = 0; ni < NI; ++ni) {
+        const int c = wn0 + ni * 32 + r, co = co0 + c;
+        float fold = 0.f;
+        if (co < a.Cout) {
+            fold = a.bias ? a.bias[co] : 0.f;
+            if (a.tproj) fold += a.tproj[(a.nt == 1 ? 0 : n0) * a.tproj_ld + co];
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int m = wm0 + mi * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+                stage[m * BN + c] = acc[mi][ni][j] + fold;
             }
+    }
+}
+template <typename T, int BM, int BN, int NT, typename PixFn>
+__device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, int co0, int n0, PixFn pix_of, float* stage, int tile_s) {
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int VPR = BN / VEC;  // vectors per pixel row of the tile
+    T* __restrict__ dst = (T*)a.dst;
+    const T* __restrict__ res = (const T*)a.res1;
+    // fused GroupNorm partials: every thread owns ONE 16-byte channel vector (NT % VPR == 0), so it keeps
+    // running sum / sum of squares of the values it stores (two halves of the vector separately)
+    float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
+    int cnt_items = 0;
+    for (int it = threadIdx.x; it < BM * VPR; it += NT) {
+        const int m = it / VPR, cg = it % VPR;
+        const int co = co0 + cg * VEC;
+        const int opix = pix_of(m);  // -1: pixel belongs to an image past the batch
+        if (opix < 0 || co >= a.Cout) continue;
+        const int off = opix * a.Cout + co;
+        const float* sp = stage + m * BN + cg * VEC;
+        ++cnt_items;
+        if constexpr (sizeof(T) == 4) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(sp);
+            if (res) {
+                const f32x4 rv = *reinterpret_cast<const f32x4*>(res + off);
+                v += rv;
+            }
+            *reinterpret_cast<f32x4*>(dst + off) = v;
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+            for (int e = 0; e < 4; ++e) {
+                s1a += v[e];
+                s2a = fmaf(v[e], v[e], s2a);
+            }
+        } else {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            if (res) {
+                const bf16x8 rv = *reinterpret_cast<const bf16x8*>(res + off);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int m = wm0 + mi * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
-                    stage[m * BN + c] = acc[mi][ni][j] + fold;
-                }
+                for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+            *reinterpret_cast<bf16x8*>(dst + off) = o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {  // statistics of the values the consumer reads back (bf16-rounded)
+                const float x0 = (float)o[e], x1 = (float)o[4 + e];
+                s1a += x0;
+                s2a = fmaf(x0, x0, s2a);
+                s1b += x1;
+                s2b = fmaf(x1, x1, s2b);
+            }
+        }
+    }
+    if (a.gn_part) {
+        // per-thread (mean, M2) from <= 64 values (negligible cancellation), exchanged through LDS and merged
+        // with Chan's formula by one thread per group.  TN == 1: the tile is one image.
+        const int cgs = a.gn_cg;
+        const bool split = cgs < VEC;            // bf16, 4-channel groups: the two vector halves are two groups
+        constexpr int HALF = VEC > 4 ? 4 : VEC;
+        float cntA = (float)(cnt_items * HALF), cntB = cntA;
+        if (!split && VEC > 4) {                 // whole vector inside one group: merge the halves first
+            s1a += s1b;
+            s2a += s2b;
+            cntA *= 2.f;
+        }
+        float meanA = s1a / cntA, m2A = s2a - s1a * meanA;
+        float meanB = s1b / cntB, m2B = s2b - s1b * meanB;
+        // Lanes VPR apart in a wave own the same channel vector (every thread stored the same number of items): merge them
+        // pairwise with shuffles - equal counts make Chan's formula mean = (m1 + m2) / 2, M2 = M2a + M2b + (m1 - m2)^2 n / 2 -
+        // then one entry per (wave, channel vector) goes through LDS and one thread per group merges those few.
+        constexpr int LPW = VPR < 64 ? VPR : 64;  // distinct channel vectors among a wave's lanes
+        float cnt = cntA;                         // (cntB == cntA whenever the B half is used)
+#pragma unroll
+        for (int off = LPW; off < 64; off <<= 1) {
+            const float oA = __shfl_xor(meanA, off, 64), oA2 = __shfl_xor(m2A, off, 64);
+            const float oB = __shfl_xor(meanB, off, 64), oB2 = __shfl_xor(m2B, off, 64);
+            const float dA = oA - meanA, dB = oB - meanB;
+            m2A += oA2 + dA * dA * (0.5f * cnt);
+            m2B += oB2 + dB * dB * (0.5f * cnt);
+            meanA = 0.5f * (meanA + oA);
+            meanB = 0.5f * (meanB + oB);
+            cnt *= 2.f;
+        }
+        __syncthreads();  // all reads of the staged tile are done: reuse it for the exchange
+        const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+        if (ln < LPW) {
+            float* q = stage + (wv * LPW + ln) * 4;
+            q[0] = meanA;
+            q[1] = m2A;
+            q[2] = meanB;
+            q[3] = m2B;
         }
         __syncthreads();
-        constexpr int VPR = BN / VEC;  // vectors per pixel row of the tile
-        T* __restrict__ dst = (T*)a.dst;
-        const T* __restrict__ res = (const T*)a.res1;
-        // fused GroupNorm partials: every thread owns ONE 16-byte channel vector (256 % VPR == 0), so it keeps
-        // running sum / sum of squares of the values it stores (two halves of the vector separately)
-        float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
-        int cnt_items = 0;
-        for (int it = threadIdx.x; it < BM * VPR; it += 256) {
-            const int m = it / VPR, cg = it % VPR;
-            const int co = co0 + cg * VEC;
-            const int opix = pix_of(m);  // -1: pixel belongs to an image past the batch
-            if (opix < 0 || co >= a.Cout) continue;
-            const int off = opix * a.Cout + co;
-            const float* sp = stage + m * BN + cg * VEC;
-            ++cnt_items;
-            if constexpr (sizeof(T) == 4) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(sp);
-                if (res) {
-                    const f32x4 rv = *reinterpret_cast<const f32x4*>(res + off);
-                    v += rv;
-                }
-                *reinterpret_cast<f32x4*>(dst + off) = v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    s1a += v[e];
-                    s2a = fmaf(v[e], v[e], s2a);
-                }
+        const int GT = BN / cgs;  // groups in this cout tile
+        if ((int)threadIdx.x < GT) {
+            const int g = threadIdx.x;
+            // entries of channel vector v: one per wave when VPR <= 64 (wave w, lane v), else the waves w with
+            // (w * 64) % VPR == v - v % 64 ... only VPR <= 64 occurs (BN <= 128 couts, 16-byte vectors of >= 4 elements)
+            static_assert(VPR <= 64, "conv_epilogue_store: more channel vectors than lanes");
+            constexpr int NW = NT / 64;
+            int v_first, v_count, sub;
+            if (split) {
+                v_first = g >> 1; v_count = 1; sub = g & 1;
             } else {
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
-                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                if (res) {
-                    const bf16x8 rv = *reinterpret_cast<const bf16x8*>(res + off);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
-                }
-                bf16x8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-                *reinterpret_cast<bf16x8*>(dst + off) = o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {  // statistics of the values the consumer reads back (bf16-rounded)
-                    const float x0 = (float)o[e], x1 = (float)o[4 + e];
-                    s1a += x0;
-                    s2a = fmaf(x0, x0, s2a);
-                    s1b += x1;
-                    s2b = fmaf(x1, x1, s2b);
-                }
+                v_count = cgs / VEC; v_first = g * v_count; sub = 0;
             }
+            float na = 0.f, mean = 0.f, M2 = 0.f;
+            for (int vv = 0; vv < v_count; ++vv)
+                for (int w = 0; w < NW; ++w) {
+                    const float* q = stage + (w * LPW + v_first + vv) * 4 + 2 * sub;
+                    const float delta = q[0] - mean, tot = na + cnt;
+                    const float rt = __builtin_amdgcn_rcpf(tot);
+                    mean += delta * (cnt * rt);
+                    M2 += q[1] + delta * delta * (na * cnt * rt);
+                    na = tot;
+                }
+            const int G = a.Cout / cgs;
+            float* o = a.gn_part + (((int64_t)n0 * a.gn_tiles + tile_s) * G + (co0 / cgs + g)) * 2;
+            o[0] = mean;
+            o[1] = M2;
         }
-        if (a.gn_part) {
-            // per-thread (mean, M2) from <= 64 values (negligible cancellation), exchanged through LDS and merged
-            // with Chan's formula by one thread per group.  TN == 1: the tile is one image.
-            const int cgs = a.gn_cg;
-            const bool split = cgs < VEC;            // bf16, 4-channel groups: the two vector halves are two groups
-            constexpr int HALF = VEC > 4 ? 4 : VEC;
-            float cntA = (float)(cnt_items * HALF), cntB = cntA;
-            if (!split && VEC > 4) {                 // whole vector inside one group: merge the halves first
-                s1a += s1b;
-                s2a += s2b;
-                cntA *= 2.f;
-            }
-            const float meanA = s1a / cntA, m2A = s2a - s1a * meanA;
-            const float meanB = s1b / cntB, m2B = s2b - s1b * meanB;
-            __syncthreads();  // all reads of the staged tile are done: reuse it for the exchange
-            stage[threadIdx.x * 4] = meanA;
-            stage[threadIdx.x * 4 + 1] = m2A;
-            stage[threadIdx.x * 4 + 2] = meanB;
-            stage[threadIdx.x * 4 + 3] = m2B;
-            __syncthreads();
-            const int GT = BN / cgs;  // groups in this cout tile
-            if ((int)threadIdx.x < GT) {
-                const int g = threadIdx.x;
-                constexpr int R = 256 / VPR;  // pixel-row phases sharing one channel vector
-                int v_first, v_count, sub;
-                if (split) {
-                    v_first = g >> 1; v_count = 1; sub = g & 1;
-                } else {
-                    v_count = cgs / VEC; v_first = g * v_count; sub = 0;
-                }
-                float na = 0.f, mean = 0.f, M2 = 0.f;
-                for (int vv = 0; vv < v_count; ++vv)
-                    for (int rr = 0; rr < R; ++rr) {
-                        const float* q = stage + (rr * VPR + v_first + vv) * 4 + 2 * sub;
-                        const float delta = q[0] - mean, tot = na + cntA;
-                        mean += delta * (cntA / tot);
-                        M2 += q[1] + delta * delta * (na * cntA / tot);
-                        na = tot;
-                    }
-                const int G = a.Cout / cgs;
-                float* o = a.gn_part + (((int64_t)n0 * a.gn_tiles + tile_s) * G + (co0 / cgs + g)) * 2;
-                o[0] = mean;
-                o[1] = M2;
-            }
-        }
+    }
+}
+
+// NT: threads of the workgroup that run the store loop (and the barriers)
+template <typename T, int BM, int BN, int MI, int NI, int NT = 256, typename PixFn>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MI][NI], int co0, int wn0, int r, int h,
+                                              int wm0, int n0, int TN, PixFn pix_of, float* stage, int tile_s) {
+    if (conv_epilogue_is_staged<T>(a, TN)) {
+        conv_epilogue_stage<T, BN, MI, NI>(a, acc, co0, wn0, r, h, wm0, n0, stage);
+        __syncthreads();
+        conv_epilogue_store<T, BM, BN, NT>(a, co0, n0, pix_of, stage, tile_s);
         return;
     }
     // general path (final NCHW conv, SiLU outputs, per-image time rows inside one tile)
@@ -248,6 +291,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
             }
         }
     }
+}
+
+// number of __syncthreads() the epilogue above executes (for the waves of a workgroup that do not take part in it)
+template <typename T>
+__device__ __forceinline__ int conv_epilogue_syncs(const ConvArgs& a, int TN) {
+    constexpr int VEC = 16 / sizeof(T);
+    const bool uniform_t = !a.tproj || a.nt == 1 || TN == 1;
+    if (!a.out_silu && !a.out_nchw && uniform_t && (a.Cout % VEC) == 0) return a.gn_part ? 3 : 1;
+    return 0;
 }
 
 // tile-selection threshold: smallest workgroup count a tile shape must still produce (tunable for experiments)

@@ -212,6 +212,366 @@ __global__ void __launch_bounds__(256, GT == 9 ? 1 : 2) conv3x3_pipe_kernel(Conv
     conv_epilogue<T, BM, BN, MI, NI>(a, acc, co0, wn0, r, h, wm0, n0, g.TN, pix_of, reinterpret_cast<float*>(lds), ty_blk * g.tiles_x + tx_blk);
 }
 
+// Device-pass-only instructions behind small helpers: the host pass of hipcc parses kernel bodies too, and it knows neither
+// the gfx950 LDS-DMA builtin nor these s_waitcnt forms (an error there silently drops the kernel's host stub).
+typedef __attribute__((address_space(3))) char lds_c;
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_byte_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(gsrc, (lds_c*)(size_t)lds_byte_addr, 16, 0, 0);
+#else
+    (void)gsrc;
+    (void)lds_byte_addr;
+#endif
+}
+template <int N>
+__device__ __forceinline__ void wait_vm_keep() {  // retire all but the N youngest vector-memory operations; all LDS operations
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
+
+struct WsTile { int n0, oy0, ox0, co0, ts; };
+__device__ __forceinline__ WsTile ws_tile_of(const ConvTile& g, int shTW, int shTH, int kt, int bn) {
+    const int t = (int)blockIdx.x + kt * (int)gridDim.x;
+    const int tile_n = t % g.tiles_n, tile_m = t / g.tiles_n;
+    const int tiles_img = g.tiles_x * g.tiles_y;
+    WsTile r;
+    const int sp = tile_m % tiles_img;
+    r.n0 = tile_m / tiles_img;
+    r.oy0 = (sp / g.tiles_x) << shTH;
+    r.ox0 = (sp % g.tiles_x) << shTW;
+    r.co0 = tile_n * bn;
+    r.ts = sp;
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-specialised, persistent 256-pixel x 128-cout kernel (bf16, one image per tile, an even number of 64-channel
+// chunks).  In-kernel cycle stamps of the kernel above showed a workgroup spending under half of its life in MFMA
+// phases: the GroupNorm/SiLU prologue, the filter staging, the first loads (an all-CU HBM burst, ~10k cycles) and the
+// barriers all sit BETWEEN the matrix phases of the same four waves, and per MFMA it moves too many bytes: every
+// 128x128 tile re-reads all filters (L2 -> CU sustains ~15 B/clk/CU) and VGPR-sourced LDS stores run at ~79 B/clk.
+// Here a workgroup is 8 waves, one per CU, looping over its tiles:
+//   waves 0-3  consumers: nothing but LDS fragment reads and MFMAs - 128 pixels x 64 couts each (8 MFMAs per 6
+//              fragment reads, explicitly double-buffered: one MFMA wave per SIMD must hide the LDS latency itself);
+//   waves 4-7  producers: ONE continuous stream over all the workgroup's tiles - the filter tap of the next stage by
+//              LDS-DMA (global_load_lds_dwordx4, swizzle on the source address), the next chunk's halo a chunk ahead
+//              through registers with the GN-affine / SiLU / dropout math, spread over the chunk's nine stages; the
+//              first chunk and tap of the next tile are therefore in LDS before the current tile's epilogue starts.
+// One barrier per stage (a stage = one filter tap of one 64-channel chunk).  Scale / shift / mask of a tile's image sit
+// in LDS (double-buffered by tile), so the producers' math never waits on a global load behind the prefetch.  Every
+// producer load is unconditional (clamped addresses, padding zeroed by a select), so the loads in flight can be counted:
+// the stage barrier is a raw s_barrier behind `s_waitcnt vmcnt(N)` that retires the DMA but not the halo prefetch.
+// LDS only fits with single-tap stages:
+//   [A0 | R0 | R1 | R2 | A1] + parameters:  A = halo of one 64-channel chunk (double-buffered by chunk), R = ring of
+//   filter taps (128 couts x 64 channels = 16 KB, filled by LDS-DMA one stage ahead; slot = stage % 3).
+// A tile ends on slot R2 and buffer A1 (9 stages per chunk, even chunk count) while the next tile's first tap / chunk
+// are already in R0 / A0, so R1|R2|A1 (>= 64 KB) stages the epilogue: two passes of 128 pixels.
+template <int PIPE_UA>
+__global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTile g, int shTW, int shTH, int ntiles) {
+    using T = bf16;
+    constexpr int KC = 64, EPV = 8, BN = 128, MI = 4, NI = 2, UB = BN / 32;  // BM = 256
+    constexpr int R_BYTES = BN * ROW_DATA;  // one tap
+    static_assert(PIPE_UA == 11, "unit schedule below is written out for 11 units over 9 stages");
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int a_bytes = g.a_rows * ROW_DATA;
+    const int Cin = a.C1 + a.C2;
+    const int offA1 = a_bytes + 3 * R_BYTES, offR = a_bytes;
+    float* par_base = reinterpret_cast<float*>(lds + 2 * a_bytes + 3 * R_BYTES);  // [2][3][Cin]: scale, shift, mask
+#define WS_BUFA(p) (lds + (((p) & 1) ? offA1 : 0))
+#define WS_RING(slot) (lds + offR + (slot) * R_BYTES)
+#define WS_PAR(kt) (par_base + ((kt) & 1) * 3 * Cin)
+#define WS_TILE(kt) ws_tile_of(g, shTW, shTH, (kt), BN)
+    typedef WsTile TileXY;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool producer = wave >= 4;
+    const int nchunks = Cin / KC;
+    const int K = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;  // tiles of this workgroup
+    const bool has_pro = a.scale || a.pro_silu || a.dmask;
+    {
+        float* par = WS_PAR(0);
+        const int n0 = WS_TILE(0).n0;
+        for (int c = tid; c < Cin; c += 512) {
+            const int so = n0 * Cin + c;
+            par[c] = a.scale ? a.scale[so] : 1.f;
+            par[Cin + c] = a.scale ? a.shift[so] : 0.f;
+            par[2 * Cin + c] = a.dmask ? a.dmask[so] : 1.f;
+        }
+    }
+    __syncthreads();
+    const int mTW = (1 << shTW) - 1, mTH = (1 << shTH) - 1;
+    const bool estamp = tid == 0 && blockIdx.x == 0;  // diagnostic stamps of the epilogue passes (consumer wave 0, workgroup 0)
+    int e_i = 0;
+    // tile epilogue, 128 pixels per pass through R1|R2|A1: the consumer waves owning the pass's rows stage their
+    // accumulators, then ALL 512 threads (the producers are between tiles) run the store loop
+#define WS_ESTAMP() { if (estamp && a.stamps && e_i < 24) a.stamps[64 + e_i++] = (long long)clock64(); }
+#define WS2_EPILOGUE(TT, STAGE_STMT)                                                                              \
+    {                                                                                                                              \
+        float* stage = reinterpret_cast<float*>(WS_RING(1));                                                                       \
+        _Pragma("unroll 1") for (int p = 0; p < 2; ++p) {                                                                          \
+            auto pix_of = [&](int m) -> int {                                                                                      \
+                const int mm = m + 128 * p;                                                                                        \
+                const int tx = mm & mTW, ty = (mm >> shTW) & mTH;                                                                  \
+                return ((TT).n0 * a.Hout + (TT).oy0 + ty) * a.Wout + (TT).ox0 + tx;                                                \
+            };                                                                                                                     \
+            WS_ESTAMP()                                                                                                            \
+            STAGE_STMT                                                                                                             \
+            WS_ESTAMP()                                                                                                            \
+            __syncthreads();                                                                                                       \
+            WS_ESTAMP()                                                                                                            \
+            conv_epilogue_store<T, 128, BN, 512>(a, (TT).co0, (TT).n0, pix_of, stage, 2 * (TT).ts + p);                             \
+            WS_ESTAMP()                                                                                                            \
+            __syncthreads(); /* everyone is done with the staging area */                                                          \
+        }                                                                                                                          \
+    }
+
+    if (producer) {
+        const int ptid = tid & 255, cu = ptid & 7, urow = ptid >> 3, pw = ptid >> 6;
+        const int Hv = a.up ? 2 * a.Hin : a.Hin, Wv = a.up ? 2 * a.Win : a.Win;
+        int a_pix[PIPE_UA], a_sw[PIPE_UA];
+        unsigned b_vo[UB];
+#pragma unroll
+        for (int i = 0; i < PIPE_UA; ++i) a_sw[i] = swz_off(urow + 32 * i, cu);
+#pragma unroll
+        for (int k4 = 0; k4 < UB; ++k4) b_vo[k4] = (unsigned)(((urow + 32 * k4) * 9 * Cin + (cu ^ ((urow >> 1) & 7)) * EPV) * 2);
+        auto set_pix = [&](int i, const TileXY& t) __attribute__((always_inline)) {
+            const int row = urow + 32 * i;
+            const int hy = (int)__umulhi((unsigned)row, g.magic_w), hx = row - hy * g.HWd;
+            const int iy = t.oy0 - 1 + hy, ix = t.ox0 - 1 + hx;
+            const bool in = iy >= 0 && iy < Hv && ix >= 0 && ix < Wv && !(a.up == 2 && ((iy | ix) & 1));
+            const int sy = a.up ? (iy >> 1) : iy, sx = a.up ? (ix >> 1) : ix;
+            a_pix[i] = row >= g.a_rows ? -2 : in ? (t.n0 * a.Hin + sy) * a.Win + sx : -1;
+        };
+        const char* wbase = (const char*)a.w;
+        u32x4 areg[PIPE_UA];
+        f32x4 ps0, ps1, ph0, ph1, pm0, pm1;
+        auto load_par = [&](const float* par, int c0) __attribute__((always_inline)) {
+            const float* p = par + c0 + cu * EPV;
+            ps0 = *reinterpret_cast<const f32x4*>(p); ps1 = *reinterpret_cast<const f32x4*>(p + 4);
+            ph0 = *reinterpret_cast<const f32x4*>(p + Cin); ph1 = *reinterpret_cast<const f32x4*>(p + Cin + 4);
+            pm0 = *reinterpret_cast<const f32x4*>(p + 2 * Cin); pm1 = *reinterpret_cast<const f32x4*>(p + 2 * Cin + 4);
+        };
+        auto load_A = [&](int i, int c0) __attribute__((always_inline)) {
+            const bool second = c0 >= a.C1;
+            const char* sbase = (const char*)(second ? a.src2 : a.src1) + (size_t)((second ? c0 - a.C1 : c0) * 2);
+            const int Cs = second ? a.C2 : a.C1;
+            const int px = a_pix[i] < 0 ? 0 : a_pix[i];
+            areg[i] = *reinterpret_cast<const u32x4*>(sbase + (size_t)((unsigned)(px * Cs + cu * EPV) * 2u));
+        };
+        auto store_A = [&](int i, char* dstA) __attribute__((always_inline)) {
+            u32x4 val = areg[i];
+            if (has_pro) {
+                const bf16x8 x = __builtin_bit_cast(bf16x8, val);
+                bf16x8 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v0 = fmaf((float)x[q], ps0[q], ph0[q]), v1 = fmaf((float)x[4 + q], ps1[q], ph1[q]);
+                    if (a.pro_silu) {
+                        v0 = silu_fast(v0);
+                        v1 = silu_fast(v1);
+                    }
+                    o[q] = (bf16)(v0 * pm0[q]);
+                    o[4 + q] = (bf16)(v1 * pm1[q]);
+                }
+                val = __builtin_bit_cast(u32x4, o);
+            }
+            const u32x4 zero = {0u, 0u, 0u, 0u};
+            if (a_pix[i] < 0) val = zero;
+            if (a_pix[i] != -2) *reinterpret_cast<u32x4*>(dstA + a_sw[i]) = val;
+        };
+        // one filter tap (cout tile co0, chunk c, tap t) -> ring slot: UB DMA instructions per wave
+        auto dma_tap = [&](char* dstR, int co0, int c, int t) __attribute__((always_inline)) {
+            const unsigned lbase = (unsigned)(size_t)(lds_c*)dstR + (unsigned)(pw * 8 * ROW_DATA);
+            const char* ub = wbase + ((size_t)co0 * 9 * Cin + (size_t)t * Cin + (size_t)c * KC) * 2;
+#pragma unroll
+            for (int k4 = 0; k4 < UB; ++k4) {
+                const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)(lbase + (unsigned)(32 * k4 * ROW_DATA)));
+                glds16(ub + b_vo[k4], l);
+            }
+        };
+        TileXY tcur = WS_TILE(0), tnext = WS_TILE(K > 1 ? 1 : 0);
+        {   // preamble: chunk 0 halo + tap 0 of the first tile; chunk 1 halo in flight
+#pragma unroll
+            for (int i = 0; i < PIPE_UA; ++i) {
+                set_pix(i, tcur);
+                load_A(i, 0);
+            }
+            dma_tap(WS_RING(0), tcur.co0, 0, 0);
+            load_par(WS_PAR(0), 0);
+#pragma unroll
+            for (int i = 0; i < PIPE_UA; ++i) store_A(i, WS_BUFA(0));
+#pragma unroll
+            for (int i = 0; i < PIPE_UA; ++i) load_A(i, KC);  // nchunks >= 2
+        }
+        __syncthreads();
+        int kt = 0, cc = 0, cg = 0;
+#define WS_A_UNIT(i)                          \
+    {                                         \
+        if (do_store) store_A((i), dstA);     \
+        if (new_tile) set_pix((i), tnn);      \
+        load_A((i), lc * KC);                 \
+    }
+        // stage TP = tap TP of chunk (kt, cc): DMA of the next stage's tap, 1-2 halo units of the next chunk, barrier
+#define WS_PSTAGE(TP)                                                                                                   \
+    {                                                                                                                   \
+        const bool last_c = cc + 1 == nchunks;                                                                          \
+        const bool have_n = !(last_c && kt + 1 == K);                                                                   \
+        const int nk = have_n ? (last_c ? kt + 1 : kt) : kt, nc = have_n ? (last_c ? 0 : cc + 1) : cc;                  \
+        const bool last_n = nc + 1 == nchunks;                                                                          \
+        const bool have_l = have_n && !(last_n && nk + 1 == K);                                                         \
+        const int lk = have_l ? (last_n ? nk + 1 : nk) : nk, lc = have_l ? (last_n ? 0 : nc + 1) : nc;                  \
+        if ((TP) < 8) dma_tap(WS_RING(((TP) + 1) % 3), tcur.co0, cc, (TP) + 1);                                         \
+        else dma_tap(WS_RING(0), nk == kt ? tcur.co0 : tnext.co0, nc, 0);                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        {                                                                                                               \
+            const bool do_store = have_n;                                                                               \
+            char* dstA = WS_BUFA(cg + 1);                                                                               \
+            const bool new_tile = have_l && lc == 0;                                                                    \
+            const TileXY tnn = lk == kt ? tcur : tnext;                                                                 \
+            if ((TP) == 0) { load_par(WS_PAR(nk), nc* KC); WS_A_UNIT(0) WS_A_UNIT(1) }                                  \
+            else if ((TP) == 8) { WS_A_UNIT(9) WS_A_UNIT(10) }                                                          \
+            else { WS_A_UNIT((TP) + 1) }                                                                                \
+        }                                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        wait_vm_keep<((TP) == 0 || (TP) == 8) ? 2 : 1>(); /* retire the DMA, leave this stage's halo loads in flight */ \
+        __builtin_amdgcn_s_barrier();                                                                                   \
+        if ((TP) == 8) {                                                                                                \
+            ++cg;                                                                                                       \
+            if (++cc == nchunks) { /* tile done: its epilogue (store loop shared with the consumers), then on */        \
+                WS2_EPILOGUE(tcur, ;)                                                                                   \
+                cc = 0;                                                                                                 \
+                ++kt;                                                                                                   \
+                tcur = tnext;                                                                                           \
+                tnext = WS_TILE(kt + 1 < K ? kt + 1 : kt);                                                              \
+            }                                                                                                           \
+        }                                                                                                               \
+    }
+        const int GCH = K * nchunks;
+        for (int ch = 0; ch < GCH; ++ch) {
+            WS_PSTAGE(0) WS_PSTAGE(1) WS_PSTAGE(2) WS_PSTAGE(3) WS_PSTAGE(4) WS_PSTAGE(5) WS_PSTAGE(6) WS_PSTAGE(7) WS_PSTAGE(8)
+        }
+#undef WS_PSTAGE
+#undef WS_A_UNIT
+        return;
+    }
+
+    // ---- consumers: wave tile 128 pixels x 64 couts ----
+    const int wm0 = (wave >> 1) * 128, wn0 = (wave & 1) * 64;
+    const int r = lane & 31, h = lane >> 5;
+    int a_row[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = wm0 + mi * 32 + r;
+        const int tx = m & mTW, ty = (m >> shTW) & mTH;
+        a_row[mi] = ty * g.HWd + tx;
+    }
+    int b_base[NI], b_swz[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int row = wn0 + ni * 32 + r;
+        b_base[ni] = row * ROW_DATA;
+        b_swz[ni] = (row >> 1) & 7;
+    }
+    // diagnostic cycle stamps (a.stamps null: off): consumer wave 0 of workgroup 0, [arrive, leave] of every barrier
+    int stamp_i = 0;
+    const bool stamping = a.stamps && tid == 0 && blockIdx.x == 0;
+#define WS_STAMP() { if (stamping && stamp_i < 64) a.stamps[stamp_i++] = (long long)clock64(); }
+    WS_STAMP()
+    __syncthreads();  // preamble tiles are in LDS
+    WS_STAMP()
+    int cg = 0;
+    for (int kt = 0; kt < K; ++kt) {
+        const TileXY t = WS_TILE(kt);
+        f32x16 acc[MI][NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.f;
+        float pr[6];  // parameters of the next tile's image (see the 128x128 kernel)
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+            const int idx = tid + 256 * e, arr = idx / Cin, c = idx - arr * Cin;
+            pr[e] = 0.f;
+            if (kt + 1 < K && idx < 3 * Cin) {
+                const int so = WS_TILE(kt + 1).n0 * Cin + c;
+                pr[e] = arr == 0 ? (a.scale ? a.scale[so] : 1.f) : arr == 1 ? (a.scale ? a.shift[so] : 0.f) : (a.dmask ? a.dmask[so] : 1.f);
+            }
+        }
+        for (int c = 0; c < nchunks; ++c, ++cg) {
+            const char* ldsA = WS_BUFA(cg);
+#pragma unroll 3
+            for (int tp = 0; tp < 9; ++tp) {
+                const char* ldsR = WS_RING(tp % 3);
+                const int tap_off = (tp / 3) * g.HWd + (tp % 3);
+                int abase[MI], aswz[MI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int row = a_row[mi] + tap_off;
+                    abase[mi] = row * ROW_DATA;
+                    aswz[mi] = (row >> 1) & 7;
+                }
+                uint4 af[2][MI], bfr[2][NI];
+#define WS_FRAGS(SET, KG)                                                                                                         \
+    {                                                                                                                             \
+        const int cidx = (KG) * 2 + h;                                                                                            \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) af[SET][mi] = *reinterpret_cast<const uint4*>(ldsA + abase[mi] + ((cidx ^ aswz[mi]) << 4)); \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) bfr[SET][ni] = *reinterpret_cast<const uint4*>(ldsR + b_base[ni] + ((cidx ^ b_swz[ni]) << 4)); \
+        __builtin_amdgcn_sched_barrier(0);                                                                                        \
+    }
+#define WS_MMAS(SET)                                                                                  \
+    {                                                                                                 \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                             \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_group(af[SET][mi], bfr[SET][ni], acc[mi][ni], (T*)nullptr); \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    }
+                WS_FRAGS(0, 0) WS_FRAGS(1, 1) WS_MMAS(0) WS_FRAGS(0, 2) WS_MMAS(1) WS_FRAGS(1, 3) WS_MMAS(0) WS_MMAS(1)
+#undef WS_FRAGS
+#undef WS_MMAS
+                if (c == 0 && tp == 0 && kt + 1 < K) {
+                    float* parn = WS_PAR(kt + 1);
+#pragma unroll
+                    for (int e = 0; e < 6; ++e)
+                        if (tid + 256 * e < 3 * Cin) parn[tid + 256 * e] = pr[e];
+                }
+                WS_STAMP()
+                __syncthreads();
+                WS_STAMP()
+            }
+        }
+        // the last stage read R2 and A1: R1|R2|A1 stages the epilogue
+        WS2_EPILOGUE(t, if ((wave >> 1) == p) (conv_epilogue_stage<T, BN, MI, NI>(a, acc, t.co0, wn0, r, h, 0, t.n0, stage));)
+        WS_STAMP()
+    }
+#undef WS_STAMP
+#undef WS2_EPILOGUE
+#undef WS_ESTAMP
+#undef WS_BUFA
+#undef WS_RING
+#undef WS_PAR
+#undef WS_TILE
+}
+
+static size_t ws2_lds(const ConvArgs& a, const ConvTile& g) { return 2 * (size_t)g.a_rows * ROW_DATA + 3 * (size_t)128 * ROW_DATA + (size_t)2 * 3 * (a.C1 + a.C2) * 4; }
+
+// the wave-specialised kernel applies (else 0): its tile goes to g
+static int ws_pick(const ConvArgs& a, ConvTile& g) {
+    static const int ws_min_tiles = getenv("DMME_WS_MIN") ? atoi(getenv("DMME_WS_MIN")) : 256;
+    const int Cin = a.C1 + a.C2, nch = Cin / 64;
+    if (a.taps != 9 || a.stride != 1 || Cin % 64 || nch < 2 || nch % 2 || Cin > 512 || a.out_silu || a.out_nchw || a.in_nchw || a.Cout % 128) return 0;
+    ConvTile t;
+    // staging area R1|R2|A1 must hold 128 x 128 floats; the halo must fit 11 units per producer lane
+    if (make_tile(a, 256, 128, t) && t.TN == 1 && t.a_rows <= 352 && ws2_lds(a, t) <= 160 * 1024 && (size_t)t.a_rows * ROW_DATA + 2 * 128 * ROW_DATA >= 64 * 1024 &&
+        t.tiles_m * t.tiles_n >= ws_min_tiles) {
+        g = t;
+        return 3;
+    }
+    return 0;
+}
+
 // candidate kernels: {BM, BN, GT}; the 9-tap variant serves layers with too little work per interval
 // (few workgroups or stride 2) and owns a larger LDS footprint
 static const int kPipeCand[4][3] = {{128, 128, 3}, {128, 64, 3}, {64, 64, 3}, {64, 64, 9}};
@@ -275,6 +635,24 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
     const int pick = pipe_pick(a, g);
     DMME_REQUIRE(pick >= 0, DMME_ERR_UNSUPPORTED, "conv_pipe: no tile fits");
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
+    if constexpr (sizeof(T) == 2) {
+        static const bool ws_off = getenv("DMME_NO_WS") != nullptr;
+        ConvTile gw{};
+        const int ws = ws_off ? 0 : ws_pick(a, gw);
+        if (ws) {
+            static bool ws_attr = false;
+            if (!ws_attr) {
+                const int rc0 = set_lds_limit(conv3x3_ws2_kernel<11>, 160 * 1024);
+                if (rc0 != DMME_OK) return rc0;
+                ws_attr = true;
+            }
+            const int ntiles = gw.tiles_m * gw.tiles_n;
+            const dim3 wgrid((unsigned)(ntiles < 256 ? ntiles : 256));
+            hipLaunchKernelGGL((conv3x3_ws2_kernel<11>), wgrid, dim3(512), ws2_lds(a, gw), s, a, gw, ilog2(gw.TW), ilog2(gw.TH), ntiles);
+            DMME_CHECK_LAUNCH();
+            return DMME_OK;
+        }
+    }
     const size_t lds = pipe_lds(g, kPipeCand[pick][1], kPipeCand[pick][2]);
     const int shTW = ilog2(g.TW), shTH = ilog2(g.TH);
     static bool attr_done[4] = {false, false, false, false};
@@ -305,6 +683,16 @@ int launch_conv_pipe(int dtype, const ConvArgs& a, hipStream_t s) {
 }
 
 bool conv_pipe_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px) {
+    if (dtype == DMME_BF16 && !getenv("DMME_NO_WS")) {  // the wave-specialised kernel's tile, when it will run this conv
+        ConvTile gw{};
+        const int ws = ws_pick(a, gw);
+        if (ws) {
+            if (!stats_tile_ok(a, gw, 128, cg, 8)) return false;
+            *tiles = gw.tiles_x * gw.tiles_y * 2;  // one partial per 128-pixel epilogue pass
+            *px = 128;
+            return true;
+        }
+    }
     ConvTile g{};
     const int pick = pipe_pick(a, g);
     if (pick < 0) return false;
@@ -315,6 +703,14 @@ bool conv_pipe_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int
 }
 
 void conv_pipe_label(int dtype, const ConvArgs& a, char* buf, int cap) {
+    if (dtype == DMME_BF16 && !getenv("DMME_NO_WS")) {
+        ConvTile gw{};
+        const int ws = ws_pick(a, gw);
+        if (ws) {
+            snprintf(buf, (size_t)cap, "conv3x3_ws2_kernel<11>");
+            return;
+        }
+    }
     ConvTile g{};
     const int pick = pipe_pick(a, g);
     snprintf(buf, (size_t)cap, "conv3x3_pipe_kernel<%s,%d,%d,%d,%d>", dtype == DMME_BF16 ? "bf16" : "float",

@@ -1336,6 +1336,12 @@ DMME_API int dmme_mse_loss(const float* eps, const float* target, int64_t numel,
     return launch_mse(eps, target, numel, loss, d_eps, grad_scale, scratch, (hipStream_t)stream);
 }
 
+static long long* g_stamps = nullptr;
+DMME_API int dmme_debug_set_stamps(void* buf) {
+    g_stamps = (long long*)buf;
+    return DMME_OK;
+}
+
 DMME_API int dmme_conv2d(const dmme_conv_desc* d, const void* src1, const void* src2, const void* weight, const float* bias,
                 const float* scale, const float* shift, const float* dmask, const float* tproj, const void* res1,
                 const void* res2, int R1, void* dst, void* stream) {
@@ -1352,6 +1358,7 @@ DMME_API int dmme_conv2d(const dmme_conv_desc* d, const void* src1, const void* 
     a.Hout = Hv / a.stride; a.Wout = Wv / a.stride; a.Cout = d->Cout;
     a.pro_silu = d->pro_silu; a.out_silu = d->out_silu; a.nt = d->nt; a.tproj_ld = d->tproj_ld;
     a.in_nchw = d->in_nchw; a.out_nchw = d->out_nchw;
+    a.stamps = g_stamps;
     if (d->force_generic == 2 && conv_mfma_supported(d->dtype, a)) return launch_conv_mfma(d->dtype, a, (hipStream_t)stream);
     if (!d->force_generic && conv1x1_pipe_supported(d->dtype, a)) return launch_conv1x1_pipe(d->dtype, a, (hipStream_t)stream);
     if (!d->force_generic && conv_pipe_supported(d->dtype, a)) return launch_conv_pipe(d->dtype, a, (hipStream_t)stream);

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Per-stage cycle stamps of the wave-specialised conv kernel (consumer wave 0 and producer wave 4 of two workgroups).
+usage: python tools/stamp_ws.py 32x128x128 [gn]"""
+import ctypes as C, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dmme_amd import _lib
+shp = sys.argv[1] if len(sys.argv) > 1 else "32x128x128"
+gn = len(sys.argv) > 2 and sys.argv[2] == "gn"
+hw, cin, cout = (int(v) for v in shp.split("x"))
+B = 128
+dev = torch.device("cuda:0")
+lib = _lib.lib()
+x = torch.randn(B, hw, hw, cin, device=dev).to(torch.bfloat16)
+w = (torch.randn(cout, 9, cin, device=dev) * 0.05).to(torch.bfloat16)
+b = torch.randn(cout, device=dev)
+scale = torch.rand(B, cin, device=dev) + 0.5
+shift = torch.randn(B, cin, device=dev) * 0.1
+out = torch.empty(B, hw, hw, cout, device=dev, dtype=torch.bfloat16)
+d = _lib.ConvDesc()
+d.dtype, d.N, d.Hin, d.Win, d.C1, d.C2 = _lib.BF16, B, hw, hw, cin, 0
+d.upsample, d.stride, d.taps, d.Cout = 0, 1, 9, cout
+d.pro_silu = int(gn)
+d.out_silu = d.nt = d.tproj_ld = d.in_nchw = d.out_nchw = d.force_generic = 0
+st = _lib.stream_ptr()
+sc, sh = (scale, shift) if gn else (None, None)
+def run():
+    _lib.check(lib.dmme_conv2d(C.byref(d), _lib.ptr(x), None, _lib.ptr(w), _lib.ptr(b), _lib.ptr(sc), _lib.ptr(sh), None, None, None, None, cout,
+                               _lib.ptr(out), st), "conv")
+for _ in range(3): run()
+stamps = torch.zeros(8 * 64 + 4096 * 4, dtype=torch.int64, device=dev)
+_lib.check(lib.dmme_debug_set_stamps(_lib.ptr(stamps)))
+run()
+torch.cuda.synchronize()
+_lib.check(lib.dmme_debug_set_stamps(None))
+v = [int(t) for t in stamps.cpu()[:64] if int(t) != 0]
+rel = [t - v[0] for t in v]
+d = [rel[i + 1] - rel[i] for i in range(len(rel) - 1)]
+print("stamps", len(v), "total", rel[-1])
+print("wait preamble", d[0])
+print("work per stage:", d[1::2][:30])
+print("wait per stage:", d[2::2][:30])
+
+e = [int(t) for t in stamps.cpu()[64:88] if int(t) != 0]
+print("epilogue stamps (pass start, after conv_epilogue, after barrier) deltas:", [e[i + 1] - e[i] for i in range(len(e) - 1)])

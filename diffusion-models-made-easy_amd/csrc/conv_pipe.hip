@@ -290,16 +290,22 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
     const int nchunks = Cin / KC;
     const int K = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;  // tiles of this workgroup
     const bool has_pro = a.scale || a.pro_silu || a.dmask;
-    {
-        float* par = WS_PAR(0);
-        const int n0 = WS_TILE(0).n0;
-        for (int c = tid; c < Cin; c += 512) {
-            const int so = n0 * Cin + c;
-            par[c] = a.scale ? a.scale[so] : 1.f;
-            par[Cin + c] = a.scale ? a.shift[so] : 0.f;
-            par[2 * Cin + c] = a.dmask ? a.dmask[so] : 1.f;
-        }
+    // scale / shift / mask of tile kt's image -> parameter buffer kt & 1 (all 512 threads).  Tiles 0 and 1 here; tile kt + 2
+    // at the end of tile kt's epilogue (the producers' last use of that buffer - tile kt's last chunk - is behind them,
+    // their first use for tile kt + 2 is nine stages before tile kt + 1 ends)
+#define WS_FILL_PAR(KT)                                                   \
+    {                                                                     \
+        float* par = WS_PAR(KT);                                          \
+        const int pn0 = WS_TILE(KT).n0;                                   \
+        for (int c = tid; c < Cin; c += 512) {                            \
+            const int so = pn0 * Cin + c;                                 \
+            par[c] = a.scale ? a.scale[so] : 1.f;                         \
+            par[Cin + c] = a.scale ? a.shift[so] : 0.f;                   \
+            par[2 * Cin + c] = a.dmask ? a.dmask[so] : 1.f;               \
+        }                                                                 \
     }
+    WS_FILL_PAR(0)
+    if (K > 1) WS_FILL_PAR(1)
     __syncthreads();
     const int mTW = (1 << shTW) - 1, mTH = (1 << shTH) - 1;
     const bool estamp = tid == 0 && blockIdx.x == 0;  // diagnostic stamps of the epilogue passes (consumer wave 0, workgroup 0)
@@ -307,7 +313,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
     // tile epilogue, 128 pixels per pass through R1|R2|A1: the consumer waves owning the pass's rows stage their
     // accumulators, then ALL 512 threads (the producers are between tiles) run the store loop
 #define WS_ESTAMP() { if (estamp && a.stamps && e_i < 24) a.stamps[64 + e_i++] = (long long)clock64(); }
-#define WS2_EPILOGUE(TT, STAGE_STMT)                                                                              \
+#define WS2_EPILOGUE(TT, KT, STAGE_STMT)                                                                              \
     {                                                                                                                              \
         float* stage = reinterpret_cast<float*>(WS_RING(1));                                                                       \
         _Pragma("unroll 1") for (int p = 0; p < 2; ++p) {                                                                          \
@@ -325,6 +331,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             WS_ESTAMP()                                                                                                            \
             __syncthreads(); /* everyone is done with the staging area */                                                          \
         }                                                                                                                          \
+        if ((KT) + 2 < K) WS_FILL_PAR((KT) + 2)                                                                                    \
     }
 
     if (producer) {
@@ -440,7 +447,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         if ((TP) == 8) {                                                                                                \
             ++cg;                                                                                                       \
             if (++cc == nchunks) { /* tile done: its epilogue (store loop shared with the consumers), then on */        \
-                WS2_EPILOGUE(tcur, ;)                                                                                   \
+                WS2_EPILOGUE(tcur, kt, ;)                                                                                   \
                 cc = 0;                                                                                                 \
                 ++kt;                                                                                                   \
                 tcur = tnext;                                                                                           \
@@ -491,16 +498,6 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.f;
-        float pr[6];  // parameters of the next tile's image (see the 128x128 kernel)
-#pragma unroll
-        for (int e = 0; e < 6; ++e) {
-            const int idx = tid + 256 * e, arr = idx / Cin, c = idx - arr * Cin;
-            pr[e] = 0.f;
-            if (kt + 1 < K && idx < 3 * Cin) {
-                const int so = WS_TILE(kt + 1).n0 * Cin + c;
-                pr[e] = arr == 0 ? (a.scale ? a.scale[so] : 1.f) : arr == 1 ? (a.scale ? a.shift[so] : 0.f) : (a.dmask ? a.dmask[so] : 1.f);
-            }
-        }
         for (int c = 0; c < nchunks; ++c, ++cg) {
             const char* ldsA = WS_BUFA(cg);
 #pragma unroll 3
@@ -531,23 +528,18 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
                 WS_FRAGS(0, 0) WS_FRAGS(1, 1) WS_MMAS(0) WS_FRAGS(0, 2) WS_MMAS(1) WS_FRAGS(1, 3) WS_MMAS(0) WS_MMAS(1)
 #undef WS_FRAGS
 #undef WS_MMAS
-                if (c == 0 && tp == 0 && kt + 1 < K) {
-                    float* parn = WS_PAR(kt + 1);
-#pragma unroll
-                    for (int e = 0; e < 6; ++e)
-                        if (tid + 256 * e < 3 * Cin) parn[tid + 256 * e] = pr[e];
-                }
                 WS_STAMP()
                 __syncthreads();
                 WS_STAMP()
             }
         }
         // the last stage read R2 and A1: R1|R2|A1 stages the epilogue
-        WS2_EPILOGUE(t, if ((wave >> 1) == p) (conv_epilogue_stage<T, BN, MI, NI>(a, acc, t.co0, wn0, r, h, 0, t.n0, stage));)
+        WS2_EPILOGUE(t, kt, if ((wave >> 1) == p) (conv_epilogue_stage<T, BN, MI, NI>(a, acc, t.co0, wn0, r, h, 0, t.n0, stage));)
         WS_STAMP()
     }
 #undef WS_STAMP
 #undef WS2_EPILOGUE
+#undef WS_FILL_PAR
 #undef WS_ESTAMP
 #undef WS_BUFA
 #undef WS_RING

@@ -2,6 +2,8 @@
 // MFMA kernels do not cover (3-channel input/output convs, odd test configurations)
 // and as a second, structurally independent implementation for parity tests.
 // Also: time embedding, small linears, layout converters, the parameter re-packer.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dmme {
@@ -123,15 +125,107 @@ __global__ void __launch_bounds__(256) conv_in_kernel(ConvArgs a, int px_per_blo
     }
 }
 
+// First conv on the matrix cores: Cin <= 3 NCHW fp32 input, K = 9 * Cin <= 28 as 14 steps of v_mfma_f32_32x32x2f32
+// (the input stays fp32: same numerics as the scalar kernel above).  D[cout][pixel] = W[cout][k] . X[k][pixel]: the
+// weights are the row operand (held in registers for the wave's lifetime), 32 consecutive pixels the columns, so a
+// lane ends up with 4 consecutive couts of ITS pixel per register group: 8-byte (bf16) NHWC stores.
+typedef float f32x16_g __attribute__((ext_vector_type(16)));
+template <typename T, int CT>  // CT: 32-cout tiles per wave (Cout = 32 * CT)
+__global__ void __launch_bounds__(256) conv_in_mfma_kernel(ConvArgs a, int nblocks) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int Cin = a.C1, K = 9 * Cin;
+    float wreg[CT][14];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int j = 0; j < 14; ++j) {
+            const int k = 2 * j + h;
+            wreg[ct][j] = k < K ? to_f(((const T*)a.w)[(int64_t)(ct * 32 + r) * K + k]) : 0.f;
+        }
+    const int HW = a.Hout * a.Wout;
+    for (int blk = blockIdx.x * 4 + (threadIdx.x >> 6); blk < nblocks; blk += gridDim.x * 4) {
+        const int p = blk * 32 + r;  // this lane's pixel (column); N*H*W is a multiple of 32
+        const int n = p / HW, rem = p - n * HW, oy = rem / a.Wout, ox = rem - oy * a.Wout;
+        float xv[14];
+#pragma unroll
+        for (int j = 0; j < 14; ++j) {
+            const int k = 2 * j + h, tap = k / Cin, ci = k - tap * Cin;
+            const int iy = oy - 1 + tap / 3, ix = ox - 1 + tap % 3;
+            xv[j] = (k < K && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) ? ((const float*)a.src1)[(((int64_t)n * Cin + ci) * a.Hin + iy) * a.Win + ix] : 0.f;
+        }
+        constexpr int PITCH = CT * 32 + 4;  // bf16 elements per staged pixel row (+8 bytes: rows on different banks)
+        __shared__ __attribute__((aligned(16))) unsigned short stage_in[4][32 * PITCH];
+        unsigned short* st = stage_in[threadIdx.x >> 6];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            f32x16_g acc;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = a.bias ? a.bias[ct * 32 + (j & 3) + 8 * (j >> 2) + 4 * h] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 14; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[ct][j], xv[j], acc, 0, 0, 0);
+            if constexpr (sizeof(T) == 2) {
+                // bf16: the wave's 32 pixels x (32 * CT) couts go through LDS so every global store writes whole pixel rows
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    typedef __bf16 bf16x4_g __attribute__((ext_vector_type(4)));
+                    bf16x4_g v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (__bf16)acc[4 * gq + e];
+                    *reinterpret_cast<bf16x4_g*>(st + r * PITCH + ct * 32 + 8 * gq + 4 * h) = v;
+                }
+            } else {
+                T* o = (T*)a.dst + (int64_t)p * a.Cout + ct * 32 + 4 * h;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    *reinterpret_cast<float4*>(o + 8 * gq) = make_float4(acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]);
+            }
+        }
+        if constexpr (sizeof(T) == 2) {
+            __builtin_amdgcn_wave_barrier();  // same wave: LDS operations complete in order
+            constexpr int VPR = CT * 4;       // 16-byte vectors per pixel row
+#pragma unroll
+            for (int q = 0; q < 32 * VPR / 64; ++q) {
+                const int it = lane + 64 * q, px = it / VPR, sg = it % VPR;
+                const uint2 lo = *reinterpret_cast<const uint2*>(st + px * PITCH + sg * 8), hi = *reinterpret_cast<const uint2*>(st + px * PITCH + sg * 8 + 4);
+                *reinterpret_cast<uint4*>((T*)a.dst + (int64_t)(blk * 32 + px) * a.Cout + sg * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+static bool conv_in_mfma_supported(const ConvArgs& a) {
+    return a.in_nchw && !a.out_nchw && a.taps == 9 && a.stride == 1 && !a.up && a.C2 == 0 && a.C1 <= 3 && !a.scale && !a.pro_silu && !a.dmask &&
+           !a.tproj && !a.res1 && !a.out_silu && !a.gn_part && (a.Cout == 128 || a.Cout == 64 || a.Cout == 32) &&
+           ((int64_t)a.N * a.Hout * a.Wout) % 32 == 0 && (int64_t)a.N * a.Hout * a.Wout * a.Cout < (1ll << 31) && !getenv("DMME_NO_CONV_IN_MFMA");
+}
+
 static bool conv_in_supported(const ConvArgs& a) {
     return !a.out_nchw && a.taps == 9 && a.stride == 1 && !a.up && a.C2 == 0 && a.C1 <= 4 && !a.scale &&
            !a.pro_silu && !a.dmask && !a.tproj && !a.res1 && !a.out_silu && a.Cout % 8 == 0 && a.Cout <= 2048 &&
            256 % (a.Cout / 8) == 0 && (size_t)9 * a.C1 * a.Cout * 4 <= 48 * 1024;
 }
 
-const char* conv_generic_kernel_name(const ConvArgs& a) { return conv_in_supported(a) ? "conv_in_kernel" : "conv_generic_kernel"; }
+const char* conv_generic_kernel_name(const ConvArgs& a) {
+    return conv_in_mfma_supported(a) ? "conv_in_mfma_kernel" : conv_in_supported(a) ? "conv_in_kernel" : "conv_generic_kernel";
+}
 
 int launch_conv_generic(int dtype, const ConvArgs& a, hipStream_t s) {
+    if (conv_in_mfma_supported(a)) {
+        const int nblocks = (int)((int64_t)a.N * a.Hout * a.Wout / 32);
+        static const int cin_grid = getenv("DMME_CIN_GRID") ? atoi(getenv("DMME_CIN_GRID")) : 512;
+        unsigned grid = (unsigned)((nblocks + 3) / 4);  // persistent waves: the filter registers are loaded once per wave
+        if ((int)grid > cin_grid) grid = (unsigned)cin_grid;
+#define DMME_CIN(TT, CT) hipLaunchKernelGGL((conv_in_mfma_kernel<TT, CT>), dim3(grid), dim3(256), 0, s, a, nblocks)
+        if (dtype == DMME_BF16) {
+            if (a.Cout == 128) DMME_CIN(bf16, 4); else if (a.Cout == 64) DMME_CIN(bf16, 2); else DMME_CIN(bf16, 1);
+        } else {
+            if (a.Cout == 128) DMME_CIN(float, 4); else if (a.Cout == 64) DMME_CIN(float, 2); else DMME_CIN(float, 1);
+        }
+#undef DMME_CIN
+        DMME_CHECK_LAUNCH();
+        return DMME_OK;
+    }
     if (conv_in_supported(a)) {
         const int64_t npix = (int64_t)a.N * a.Hout * a.Wout;
         const int ppb = 256 / (a.Cout / 8) * 8;  // 8 passes per block

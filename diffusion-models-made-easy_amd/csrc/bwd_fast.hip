@@ -133,7 +133,41 @@ int launch_colsum_fast(int dtype, const void* dY, int N, int HW, int C, float* r
     else
         hipLaunchKernelGGL(colsum_vec_kernel<float>, grid, dim3(256), 0, s, (const float*)dY, HW, C, chunk_px, ppw, rowsum);
     DMME_CHECK_LAUNCH();
+    if (!dbias && !dtproj) return DMME_OK;  // the caller reduces rowsum later (launch_bias_tproj_group)
     hipLaunchKernelGGL(bias_tproj_fast_kernel, dim3((C + 31) / 32), dim3(256), 0, s, rowsum, N, C, dbias, dtproj, ld, nt);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+// the same reduction for MANY convs in one launch: one workgroup per (conv, 32-channel block) job
+__global__ void __launch_bounds__(256) bias_tproj_group_kernel(const BiasJob* __restrict__ jobs, const char* __restrict__ bws, float* __restrict__ grad_flat,
+                                                               float* __restrict__ dtproj, int N, int ld, int nt) {
+    __shared__ float red[8][33];
+    const BiasJob jb = jobs[blockIdx.x];
+    const float* rowsum = reinterpret_cast<const float*>(bws + jb.rowsum_off);
+    const int cl = threadIdx.x & 31, seg = threadIdx.x >> 5;
+    const int c = jb.cblock * 32 + cl, C = jb.C;
+    float* dt = jb.tcol >= 0 ? dtproj + jb.tcol : nullptr;
+    float acc = 0.f;
+    if (c < C)
+        for (int n = seg; n < N; n += 8) {
+            const float v = rowsum[(int64_t)n * C + c];
+            acc += v;
+            if (dt && nt > 1) dt[(int64_t)n * ld + c] = v;
+        }
+    red[seg][cl] = acc;
+    __syncthreads();
+    if (seg == 0 && c < C) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tot += red[k][cl];
+        grad_flat[jb.dbias_off + c] += tot;
+        if (dt && nt == 1) dt[c] = tot;
+    }
+}
+int launch_bias_tproj_group(const BiasJob* jobs_dev, int njobs, const void* bws, float* grad_flat, float* dtproj, int N, int ld, int nt, hipStream_t s) {
+    if (njobs <= 0) return DMME_OK;
+    hipLaunchKernelGGL(bias_tproj_group_kernel, dim3((unsigned)njobs), dim3(256), 0, s, jobs_dev, (const char*)bws, grad_flat, dtproj, N, ld, nt);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }

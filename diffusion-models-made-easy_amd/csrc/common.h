@@ -247,6 +247,14 @@ int launch_gn_bwd_generic(int dtype, const void* dv, const void* x1, const void*
 // coalesced vector versions (bwd_fast.hip)
 bool colsum_fast_supported(int dtype, int HW, int C);
 // rowsum must be zero on entry (the backward pass clears all its accumulation scratch with one memset)
+// deferred bias / time-projection reductions of many convs (plan-time table, one launch per backward)
+struct BiasJob {
+    int64_t rowsum_off;  // bytes into the backward workspace: this conv's [N][C] column sums
+    int64_t dbias_off;   // floats into grad_flat
+    int C, cblock, tcol; // channels, 32-channel block of this job, column of the conv's time-projection rows (-1: none)
+};
+int launch_bias_tproj_group(const BiasJob* jobs_dev, int njobs, const void* bws, float* grad_flat, float* dtproj, int N, int ld, int nt, hipStream_t s);
+// dbias == dtproj == nullptr: only the [N][C] column sums (the caller reduces them later with launch_bias_tproj_group)
 int launch_colsum_fast(int dtype, const void* dY, int N, int HW, int C, float* rowsum, float* dbias, float* dtproj, int ld, int nt,
                        hipStream_t s);
 bool gn_bwd_fast_supported(int dtype, int HW, int C1, int C2);

@@ -68,6 +68,7 @@ struct Op {
     int dst = -1;              // tensor id; -2: network output (NCHW fp32)
     int up = 0, stride = 1, taps = 9;
     int wg_layer = -1;         // index into the grouped weight-gradient table of its kernel size (-1: per-layer kernels)
+    int bias_deferred = 0;     // its bias / time-projection reduction runs in the grouped launch
     // OP_ATTN
     int at_qkv = -1, at_out = -1;
     int64_t at_lse = 0;  // workspace offset of the forward's log-sum-exp [N][S]
@@ -117,6 +118,9 @@ struct dmme_plan {
     // dtproj^T temb, then of every 32-column tile of the bias sums
     int64_t* tp_tiles_dev = nullptr;
     int tp_n64 = 0;
+    // deferred bias / time-projection reductions (one launch per backward)
+    std::vector<BiasJob> bias_jobs;
+    BiasJob* bias_jobs_dev = nullptr;
 };
 
 namespace {
@@ -950,6 +954,23 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
     if (device >= 0) {
         build_wgrad_group(P, P->wg[0], 9);
         build_wgrad_group(P, P->wg[1], 1);
+        if (!getenv("DMME_NO_BIAS_GROUP"))
+            for (Op& o : P->ops) {
+                if (o.kind != OP_CONV) continue;
+                ConvArgs a{};
+                fill_conv(P, o, nullptr, nullptr, nullptr, nullptr, nullptr, 1, a);
+                if (!colsum_fast_supported(P->dtype, a.Hout * a.Wout, a.Cout)) continue;
+                o.bias_deferred = 1;
+                for (int cb = 0; cb < (a.Cout + 31) / 32; ++cb) {
+                    BiasJob j{};
+                    j.rowsum_off = o.b_rowsum;
+                    j.dbias_off = P->params[o.b].ref_off;
+                    j.C = a.Cout;
+                    j.cblock = cb;
+                    j.tcol = o.tproj_col;
+                    P->bias_jobs.push_back(j);
+                }
+            }
     }
     if (device >= 0) {
         std::vector<PackItem> items;
@@ -986,6 +1007,10 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
                 }
             }
         }
+        if (!P->bias_jobs.empty()) {
+            if (e == hipSuccess) e = hipMalloc((void**)&P->bias_jobs_dev, P->bias_jobs.size() * sizeof(BiasJob));
+            if (e == hipSuccess) e = hipMemcpy(P->bias_jobs_dev, P->bias_jobs.data(), P->bias_jobs.size() * sizeof(BiasJob), hipMemcpyHostToDevice);
+        }
         for (auto& G : P->wg) {
             if (G.jobs.empty()) continue;
             if (e == hipSuccess) e = hipMalloc((void**)&G.layers_dev, G.layers.size() * sizeof(WgLayer));
@@ -1013,6 +1038,7 @@ DMME_API void dmme_unet_plan_destroy(dmme_plan* plan) {
         if (G.jobs_dev) (void)hipFree(G.jobs_dev);
     }
     if (plan->tp_tiles_dev) (void)hipFree(plan->tp_tiles_dev);
+    if (plan->bias_jobs_dev) (void)hipFree(plan->bias_jobs_dev);
     delete plan;
 }
 
@@ -1156,7 +1182,9 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
         const int Cin = a.C1 + a.C2;
         float* rowsum = (float*)(bws + o.b_rowsum);
         // 1. bias and time-embedding-row gradients (column sums of dY)
-        if (colsum_fast_supported(dt, a.Hout * a.Wout, a.Cout))
+        if (o.bias_deferred && P->bias_jobs_dev)
+            rc = launch_colsum_fast(dt, dy, B, a.Hout * a.Wout, a.Cout, rowsum, nullptr, nullptr, P->tproj_cols, nt, s);
+        else if (colsum_fast_supported(dt, a.Hout * a.Wout, a.Cout))
             rc = launch_colsum_fast(dt, dy, B, a.Hout * a.Wout, a.Cout, rowsum, grad_flat + P->params[o.b].ref_off,
                                     o.tproj_col >= 0 ? dtproj + o.tproj_col : nullptr, P->tproj_cols, nt, s);
         else
@@ -1221,6 +1249,11 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
         }
     }
     if (rc != DMME_OK) return rc;
+    // bias and time-embedding-row gradients of every conv from its column sums: one launch
+    if (P->bias_jobs_dev) {
+        rc = launch_bias_tproj_group(P->bias_jobs_dev, (int)P->bias_jobs.size(), bws, grad_flat, dtproj, B, P->tproj_cols, nt, s);
+        if (rc != DMME_OK) return rc;
+    }
     // all deferred 3x3 (then 1x1) weight gradients in one launch each: every dY and forward activation is still in its workspace
     for (const auto& G : P->wg) {
         if (!G.jobs_dev) continue;

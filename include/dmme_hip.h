@@ -225,8 +225,9 @@ DMME_API int dmme_nhwc_to_nchw(int dtype, const void* src, int N, int C, int HW,
 /* reference-layout fp32 weight (Cout, Cin, k, k) -> packed [Cout][k*k][Cin] in dtype */
 DMME_API int dmme_pack_weight(int dtype, const float* src, int Cout, int Cin, int taps, void* dst, void* stream);
 
-/* diagnostic: device buffer of [8][64] int64 that the pipelined conv kernels launched through dmme_conv2d fill with
- * shader-clock stamps of their phases (workgroups 0, 1, grid/2, grid-1 -> slots 0..3); NULL switches it off. */
+/* diagnostic: device buffer of >= 128 int64 that the wave-specialised conv kernel launched through dmme_conv2d fills
+ * with shader-clock stamps of consumer wave 0 of workgroup 0: [0..63] arrive / leave of every stage barrier,
+ * [64..87] the epilogue passes (tools/stamp_ws.py); NULL switches it off. */
 DMME_API int dmme_debug_set_stamps(void* buf);
 
 /* timing helper: records a HIP event pair around nothing; used by bench.py to time

@@ -553,7 +553,7 @@ static size_t ws2_lds(const ConvArgs& a, const ConvTile& g) { return 2 * (size_t
 static int ws_pick(const ConvArgs& a, ConvTile& g) {
     static const int ws_min_tiles = getenv("DMME_WS_MIN") ? atoi(getenv("DMME_WS_MIN")) : 256;
     const int Cin = a.C1 + a.C2, nch = Cin / 64;
-    if (a.taps != 9 || a.stride != 1 || Cin % 64 || nch < 2 || nch % 2 || Cin > 512 || a.out_silu || a.out_nchw || a.in_nchw || a.Cout % 128) return 0;
+    if (a.taps != 9 || a.stride != 1 || Cin % 64 || a.C1 % 64 || nch < 2 || nch % 2 || Cin > 512 || a.out_silu || a.out_nchw || a.in_nchw || a.Cout % 128) return 0;
     ConvTile t;
     // staging area R1|R2|A1 must hold 128 x 128 floats; the halo must fit 11 units per producer lane
     if (make_tile(a, 256, 128, t) && t.TN == 1 && t.a_rows <= 352 && ws2_lds(a, t) <= 160 * 1024 && (size_t)t.a_rows * ROW_DATA + 2 * 128 * ROW_DATA >= 64 * 1024 &&

@@ -59,6 +59,11 @@ CASES = [
     ("tiny_odd", 3, 12, 0, 8, 6, 3, 1, False, True, 3, False),
     ("tiny_cat", 2, 8, 4, 16, 4, 3, 1, False, True, 1, False),
     ("linear_as_conv", 128, 512, 0, 1, 4736, 1, 1, False, False, 0, False),
+    # >= 256 tiles of 256 pixels x 128 couts: the wave-specialised persistent kernel (bf16)
+    ("ws_rb128_32", 64, 128, 0, 32, 128, 3, 1, False, True, 64, True),
+    ("ws_cat256_32", 64, 128, 128, 32, 128, 3, 1, False, True, 1, False),
+    ("ws_up256_16", 32, 256, 0, 16, 256, 3, 1, True, False, 0, False),
+    ("ws_plain256_16", 128, 256, 0, 16, 256, 3, 1, False, False, 0, False),
 ]
 
 

@@ -111,7 +111,8 @@ __device__ __forceinline__ bool conv_epilogue_is_staged(const ConvArgs& a, int T
     const bool uniform_t = !a.tproj || a.nt == 1 || TN == 1;
     return !a.out_silu && !a.out_nchw && uniform_t && (a.Cout % VEC) == 0;
 }
-template <typename T, int BN, int MI, int NI>
+// MSTRIDE: staged rows between a wave's consecutive 32-row accumulator tiles (32: contiguous rows)
+template <typename T, int BN, int MI, int NI, int MSTRIDE = 32>
 __device__ __forceinline__ void conv_epilogue_stage(const ConvArgs& a, f32x16 (&acc)[MI][NI], int co0, int wn0, int r, int h, int wm0, int n0,
                                                     float* stage) {
 #pragma unroll
@@ -126,13 +127,26 @@ __device__ __forceinline__ void conv_epilogue_stage(const ConvArgs& a, f32x16 (&
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const int m = wm0 + mi * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+                const int m = wm0 + mi * MSTRIDE + (j & 3) + 8 * (j >> 2) + 4 * h;
                 stage[m * BN + c] = acc[mi][ni][j] + fold;
             }
     }
 }
+// residual vectors of this thread's items, loaded BEFORE the staging barrier (whole cout tiles, every pixel valid)
 template <typename T, int BM, int BN, int NT, typename PixFn>
-__device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, int co0, int n0, PixFn pix_of, float* stage, int tile_s) {
+__device__ __forceinline__ void conv_epilogue_res_prefetch(const ConvArgs& a, int co0, PixFn pix_of, uint4 (&pre)[BM * (BN / (16 / (int)sizeof(T))) / NT]) {
+    constexpr int VEC = 16 / sizeof(T), VPR = BN / VEC, ITEMS = BM * VPR / NT;
+    const T* __restrict__ res = (const T*)a.res1;
+#pragma unroll
+    for (int q = 0; q < ITEMS; ++q) {
+        const int it = threadIdx.x + q * NT, m = it / VPR, cg = it % VPR;
+        pre[q] = make_uint4(0u, 0u, 0u, 0u);
+        if (res) pre[q] = *reinterpret_cast<const uint4*>(res + pix_of(m) * a.Cout + co0 + cg * VEC);
+    }
+}
+template <typename T, int BM, int BN, int NT, typename PixFn>
+__device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, int co0, int n0, PixFn pix_of, float* stage, int tile_s,
+                                                    const uint4* pre = nullptr) {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int VPR = BN / VEC;  // vectors per pixel row of the tile
     T* __restrict__ dst = (T*)a.dst;
@@ -141,18 +155,18 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, int co0, 
     // running sum / sum of squares of the values it stores (two halves of the vector separately)
     float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
     int cnt_items = 0;
-    for (int it = threadIdx.x; it < BM * VPR; it += NT) {
+    auto item = [&](int it, const uint4* pv) __attribute__((always_inline)) {
         const int m = it / VPR, cg = it % VPR;
         const int co = co0 + cg * VEC;
         const int opix = pix_of(m);  // -1: pixel belongs to an image past the batch
-        if (opix < 0 || co >= a.Cout) continue;
+        if (opix < 0 || co >= a.Cout) return;
         const int off = opix * a.Cout + co;
         const float* sp = stage + m * BN + cg * VEC;
         ++cnt_items;
         if constexpr (sizeof(T) == 4) {
             f32x4 v = *reinterpret_cast<const f32x4*>(sp);
             if (res) {
-                const f32x4 rv = *reinterpret_cast<const f32x4*>(res + off);
+                const f32x4 rv = pv ? __builtin_bit_cast(f32x4, *pv) : *reinterpret_cast<const f32x4*>(res + off);
                 v += rv;
             }
             *reinterpret_cast<f32x4*>(dst + off) = v;
@@ -165,7 +179,7 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, int co0, 
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             if (res) {
-                const bf16x8 rv = *reinterpret_cast<const bf16x8*>(res + off);
+                const bf16x8 rv = pv ? __builtin_bit_cast(bf16x8, *pv) : *reinterpret_cast<const bf16x8*>(res + off);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
             }
@@ -182,6 +196,13 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, int co0, 
                 s2b = fmaf(x1, x1, s2b);
             }
         }
+    };
+    if (pre) {
+        constexpr int ITEMS = BM * VPR / NT;
+#pragma unroll
+        for (int q = 0; q < ITEMS; ++q) item(threadIdx.x + q * NT, pre + q);
+    } else {
+        for (int it = threadIdx.x; it < BM * VPR; it += NT) item(it, nullptr);
     }
     if (a.gn_part) {
         // per-thread (mean, M2) from <= 64 values (negligible cancellation), exchanged through LDS and merged

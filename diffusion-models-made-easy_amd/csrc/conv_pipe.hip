@@ -313,27 +313,34 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
     // tile epilogue, 128 pixels per pass through R1|R2|A1: the consumer waves owning the pass's rows stage their
     // accumulators, then ALL 512 threads (the producers are between tiles) run the store loop
 #define WS_ESTAMP() { if (estamp && a.stamps && e_i < 24) a.stamps[64 + e_i++] = (long long)clock64(); }
-#define WS2_EPILOGUE(TT, KT, STAGE_STMT)                                                                              \
+#define WS2_PASS(TT, P, STAGE_STMT)                                                                                                \
+    {                                                                                                                              \
+        constexpr int p = (P);                                                                                                     \
+        auto pix_of = [&](int m) -> int {                                                                                          \
+            const int mm = m + 128 * p;                                                                                            \
+            const int tx = mm & mTW, ty = (mm >> shTW) & mTH;                                                                      \
+            return ((TT).n0 * a.Hout + (TT).oy0 + ty) * a.Wout + (TT).ox0 + tx;                                                    \
+        };                                                                                                                         \
+        uint4 rpre[128 * (BN / 8) / 512];                                                                                          \
+        conv_epilogue_res_prefetch<T, 128, BN, 512>(a, (TT).co0, pix_of, rpre); /* in flight across the staging barrier */         \
+        WS_ESTAMP()                                                                                                                \
+        STAGE_STMT                                                                                                                 \
+        WS_ESTAMP()                                                                                                                \
+        __syncthreads();                                                                                                           \
+        WS_ESTAMP()                                                                                                                \
+        conv_epilogue_store<T, 128, BN, 512>(a, (TT).co0, (TT).n0, pix_of, stage, 2 * (TT).ts + p, rpre);                          \
+        WS_ESTAMP()                                                                                                                \
+        __syncthreads(); /* everyone is done with the staging area */                                                              \
+    }
+    // consumer wave-row wr owns the 32-pixel blocks {wr, wr + 2, wr + 4, wr + 6} of the tile, so both wave-rows hold two
+    // blocks of either epilogue pass and all four consumer waves stage at once
+#define WS2_EPILOGUE(TT, KT, STAGE0, STAGE1)                                                                                       \
     {                                                                                                                              \
         float* stage = reinterpret_cast<float*>(WS_RING(1));                                                                       \
-        _Pragma("unroll 1") for (int p = 0; p < 2; ++p) {                                                                          \
-            auto pix_of = [&](int m) -> int {                                                                                      \
-                const int mm = m + 128 * p;                                                                                        \
-                const int tx = mm & mTW, ty = (mm >> shTW) & mTH;                                                                  \
-                return ((TT).n0 * a.Hout + (TT).oy0 + ty) * a.Wout + (TT).ox0 + tx;                                                \
-            };                                                                                                                     \
-            WS_ESTAMP()                                                                                                            \
-            STAGE_STMT                                                                                                             \
-            WS_ESTAMP()                                                                                                            \
-            __syncthreads();                                                                                                       \
-            WS_ESTAMP()                                                                                                            \
-            conv_epilogue_store<T, 128, BN, 512>(a, (TT).co0, (TT).n0, pix_of, stage, 2 * (TT).ts + p);                             \
-            WS_ESTAMP()                                                                                                            \
-            __syncthreads(); /* everyone is done with the staging area */                                                          \
-        }                                                                                                                          \
+        WS2_PASS(TT, 0, STAGE0)                                                                                                    \
+        WS2_PASS(TT, 1, STAGE1)                                                                                                    \
         if ((KT) + 2 < K) WS_FILL_PAR((KT) + 2)                                                                                    \
     }
-
     if (producer) {
         const int ptid = tid & 255, cu = ptid & 7, urow = ptid >> 3, pw = ptid >> 6;
         const int Hv = a.up ? 2 * a.Hin : a.Hin, Wv = a.up ? 2 * a.Win : a.Win;
@@ -447,7 +454,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         if ((TP) == 8) {                                                                                                \
             ++cg;                                                                                                       \
             if (++cc == nchunks) { /* tile done: its epilogue (store loop shared with the consumers), then on */        \
-                WS2_EPILOGUE(tcur, kt, ;)                                                                                   \
+                WS2_EPILOGUE(tcur, kt, ;, ;)                                                                                   \
                 cc = 0;                                                                                                 \
                 ++kt;                                                                                                   \
                 tcur = tnext;                                                                                           \
@@ -465,12 +472,12 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
     }
 
     // ---- consumers: wave tile 128 pixels x 64 couts ----
-    const int wm0 = (wave >> 1) * 128, wn0 = (wave & 1) * 64;
+    const int wrow = wave >> 1, wn0 = (wave & 1) * 64;
     const int r = lane & 31, h = lane >> 5;
     int a_row[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        const int m = wm0 + mi * 32 + r;
+        const int m = (2 * mi + wrow) * 32 + r;  // interleaved 32-pixel blocks (see the epilogue)
         const int tx = m & mTW, ty = (m >> shTW) & mTH;
         a_row[mi] = ty * g.HWd + tx;
     }
@@ -534,11 +541,13 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             }
         }
         // the last stage read R2 and A1: R1|R2|A1 stages the epilogue
-        WS2_EPILOGUE(t, kt, if ((wave >> 1) == p) (conv_epilogue_stage<T, BN, MI, NI>(a, acc, t.co0, wn0, r, h, 0, t.n0, stage));)
+        WS2_EPILOGUE(t, kt, (conv_epilogue_stage<T, BN, 2, NI, 64>(a, reinterpret_cast<f32x16(&)[2][NI]>(acc[0]), t.co0, wn0, r, h, wrow * 32, t.n0, stage));,
+                     (conv_epilogue_stage<T, BN, 2, NI, 64>(a, reinterpret_cast<f32x16(&)[2][NI]>(acc[2]), t.co0, wn0, r, h, wrow * 32, t.n0, stage));)
         WS_STAMP()
     }
 #undef WS_STAMP
 #undef WS2_EPILOGUE
+#undef WS2_PASS
 #undef WS_FILL_PAR
 #undef WS_ESTAMP
 #undef WS_BUFA

@@ -576,7 +576,7 @@ static int ws_pick(const ConvArgs& a, ConvTile& g) {
 // candidate kernels: {BM, BN, GT}; the 9-tap variant serves layers with too little work per interval
 // (few workgroups or stride 2) and owns a larger LDS footprint
 static const int kPipeCand[4][3] = {{128, 128, 3}, {128, 64, 3}, {64, 64, 3}, {64, 64, 9}};
-static const int kPipeUA[4] = {8, 8, 8, 10};
+static const int kPipeUA[4] = {8, 8, 8, 11};
 static size_t pipe_lds(const ConvTile& g, int BN, int GT) { return (size_t)g.a_rows * ROW_DATA + (size_t)GT * BN * ROW_DATA; }  // >= BM*BN*4 always
 
 static int ilog2(int v) {
@@ -670,7 +670,7 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
         DMME_PIPE_CASE(0, 128, 128, 3, 8, 80)
         DMME_PIPE_CASE(1, 128, 64, 3, 8, 80)
         DMME_PIPE_CASE(2, 64, 64, 3, 8, 80)
-        DMME_PIPE_CASE(3, 64, 64, 9, 10, 128)
+        DMME_PIPE_CASE(3, 64, 64, 9, 11, 128)
     }
 #undef DMME_PIPE_CASE
     if (rc != DMME_OK) return rc;

@@ -6,11 +6,26 @@
 //
 // Replaces the statistics half of nn.GroupNorm (models/ddpm.py:17-18); the apply half
 // is fused into the prologue of the convolution that consumes it (conv_mfma.hip).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dmme {
 
 constexpr int GN_MAX_SWEEPS = 8;
+
+template <typename T>
+__device__ __forceinline__ void load_vec_gn(const T* p, float (&v)[16 / sizeof(T)]) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(p);
+    if constexpr (sizeof(T) == 4) {
+        v[0] = __uint_as_float(raw.x); v[1] = __uint_as_float(raw.y); v[2] = __uint_as_float(raw.z); v[3] = __uint_as_float(raw.w);
+    } else {
+        v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
+        v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
+        v[4] = __uint_as_float(raw.z << 16); v[5] = __uint_as_float(raw.z & 0xffff0000u);
+        v[6] = __uint_as_float(raw.w << 16); v[7] = __uint_as_float(raw.w & 0xffff0000u);
+    }
+}
 
 template <typename T>
 __global__ void __launch_bounds__(256) gn_partial_kernel(const T* __restrict__ s1, const T* __restrict__ s2, int HW,
@@ -181,6 +196,100 @@ int launch_gn_finalize_parts(const float* part1, int tiles1, int cnt1, int C1, c
     return DMME_OK;
 }
 
+// Small feature maps (<= 64 pixels, the 8x8 and 4x4 levels: their convs tile several images together and cannot fuse
+// the statistics): ONE workgroup per image does the whole norm - channel sums through LDS atomics, group means, a second
+// pass for the centred squares (the image is <= 64 KB: L2 hits), then scale / shift for every channel.  One launch
+// instead of two, and no partial buffer.
+template <typename T>
+__global__ void __launch_bounds__(256) gn_small_kernel(const T* __restrict__ s1, const T* __restrict__ s2, int HW, int C1, int C2, int groups,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                       float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_rstd) {
+    constexpr int EPV = 16 / sizeof(T);
+    __shared__ float csum[512], gmean[64], grstd[64];
+    __shared__ float part[256 * EPV];  // [pixel phase][channel]: fixed-order (bit-reproducible) reduction over the phases
+    const int C = C1 + C2, cg = C / groups, n = blockIdx.x, tid = threadIdx.x;
+    const int VPP = C / EPV, ppw = 256 / VPP, slot = tid % VPP, prow = tid / VPP;
+    const int c0 = slot * EPV;
+    const bool second = c0 >= C1;
+    const T* src = second ? s2 + (int64_t)n * HW * C2 + (c0 - C1) : s1 + (int64_t)n * HW * C1 + c0;
+    const int Cs = second ? C2 : C1;
+    const bool active = prow < ppw;
+    float acc[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) acc[j] = 0.f;
+    if (active)
+        for (int p = prow; p < HW; p += ppw) {
+            float v[EPV];
+            load_vec_gn<T>(src + (int64_t)p * Cs, v);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) acc[j] += v[j];
+        }
+    if (active)
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) part[prow * C + c0 + j] = acc[j];
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int q = 0; q < ppw; ++q) s += part[q * C + c];
+        csum[c] = s;
+    }
+    __syncthreads();
+    const float inv_cnt = 1.f / (float)(HW * cg);
+    if (tid < groups) {
+        float s = 0.f;
+        for (int j = 0; j < cg; ++j) s += csum[tid * cg + j];
+        gmean[tid] = s * inv_cnt;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) acc[j] = 0.f;
+    if (active) {
+        float mu[EPV];
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) mu[j] = gmean[(c0 + j) / cg];
+        for (int p = prow; p < HW; p += ppw) {
+            float v[EPV];
+            load_vec_gn<T>(src + (int64_t)p * Cs, v);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) {
+                const float d = v[j] - mu[j];
+                acc[j] = fmaf(d, d, acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) part[prow * C + c0 + j] = acc[j];
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int q = 0; q < ppw; ++q) s += part[q * C + c];
+        csum[c] = s;
+    }
+    __syncthreads();
+    if (tid < groups) {
+        float s = 0.f;
+        for (int j = 0; j < cg; ++j) s += csum[tid * cg + j];
+        const float rstd = 1.0f / sqrtf(s * inv_cnt + eps);
+        grstd[tid] = rstd;
+        if (mean_rstd) {
+            mean_rstd[((int64_t)n * groups + tid) * 2] = gmean[tid];
+            mean_rstd[((int64_t)n * groups + tid) * 2 + 1] = rstd;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int gq = c / cg;
+        const float a = grstd[gq] * gamma[c];
+        scale[(int64_t)n * C + c] = a;
+        shift[(int64_t)n * C + c] = beta[c] - gmean[gq] * a;
+    }
+}
+
+static bool gn_small_supported(int dtype, int HW, int C1, int C2, int groups) {
+    const int EPV = dtype == DMME_BF16 ? 8 : 4, C = C1 + C2;
+    return HW <= 64 && C <= 512 && groups <= 64 && C % groups == 0 && C1 % EPV == 0 && C2 % EPV == 0 && C / EPV <= 256 && !getenv("DMME_NO_GN_SMALL");
+}
+
 static bool gn_geometry(int dtype, int HW, int C1, int C2, int groups, int& chunk_px, int& nsweeps, int& nchunks) {
     const int EPV = dtype == DMME_BF16 ? 8 : 4;
     const int C = C1 + C2;
@@ -199,6 +308,7 @@ static bool gn_geometry(int dtype, int HW, int C1, int C2, int groups, int& chun
 }
 
 bool gn_fast_supported(int dtype, int N, int HW, int C1, int C2, int groups) {
+    if (gn_small_supported(dtype, HW, C1, C2, groups)) return true;
     int a, b, c;
     (void)N;
     return gn_geometry(dtype, HW, C1, C2, groups, a, b, c);
@@ -219,6 +329,16 @@ size_t gn_fast_scratch_floats(int N, int HW, int C, int groups) {
 int launch_gn_fast(int dtype, const void* src1, const void* src2, int N, int HW, int C1, int C2, int groups,
                    const float* gamma, const float* beta, float eps, float* scale, float* shift, float* mean_rstd,
                    float* partial, hipStream_t s) {
+    if (gn_small_supported(dtype, HW, C1, C2, groups)) {
+        if (dtype == DMME_BF16)
+            hipLaunchKernelGGL(gn_small_kernel<bf16>, dim3(N), dim3(256), 0, s, (const bf16*)src1, (const bf16*)src2, HW, C1, C2, groups, gamma, beta,
+                               eps, scale, shift, mean_rstd);
+        else
+            hipLaunchKernelGGL(gn_small_kernel<float>, dim3(N), dim3(256), 0, s, (const float*)src1, (const float*)src2, HW, C1, C2, groups, gamma,
+                               beta, eps, scale, shift, mean_rstd);
+        DMME_CHECK_LAUNCH();
+        return DMME_OK;
+    }
     int chunk_px, nsweeps, nchunks;
     DMME_REQUIRE(gn_geometry(dtype, HW, C1, C2, groups, chunk_px, nsweeps, nchunks), DMME_ERR_UNSUPPORTED,
                  "gn_fast: unsupported geometry");

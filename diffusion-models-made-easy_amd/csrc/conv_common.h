@@ -13,6 +13,28 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int ROW_DATA = 128;          // data bytes per LDS row (one Cin chunk of one pixel / cout)
 constexpr int ROW_PITCH = ROW_DATA + 16;  // padded pitch
 
+// LDS rows are 128 B (one 64-channel bf16 chunk); 16-byte piece `chunk` of row `row` lives at piece chunk ^ (row>>1)&7
+__device__ __forceinline__ int swz_off(int row, int chunk) { return row * ROW_DATA + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// Device-pass-only instructions behind small helpers: the host pass of hipcc parses kernel bodies too, and it knows neither
+// the gfx950 LDS-DMA builtin nor these s_waitcnt forms (an error there silently drops the kernel's host stub).
+typedef __attribute__((address_space(3))) char lds_c;
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_byte_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(gsrc, (lds_c*)(size_t)lds_byte_addr, 16, 0, 0);
+#else
+    (void)gsrc;
+    (void)lds_byte_addr;
+#endif
+}
+template <int N>
+__device__ __forceinline__ void wait_vm_keep() {  // retire all but the N youngest vector-memory operations; all LDS operations
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
+
 template <typename T>
 struct Frag;
 template <>

@@ -20,7 +20,6 @@
 namespace dmme {
 
 
-__device__ __forceinline__ int swz_off(int row, int chunk) { return row * ROW_DATA + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 // GT: taps staged per barrier interval (3 = one kernel row, 9 = the whole 3x3 filter: fewer, longer intervals for
 //     layers whose per-interval matrix work is too short to hide a global-load round trip);
@@ -210,25 +209,6 @@ __global__ void __launch_bounds__(256, GT == 9 ? 1 : 2) conv3x3_pipe_kernel(Conv
         return n < a.N ? (n * a.Hout + oy0 + ty) * a.Wout + ox0 + tx : -1;
     };
     conv_epilogue<T, BM, BN, MI, NI>(a, acc, co0, wn0, r, h, wm0, n0, g.TN, pix_of, reinterpret_cast<float*>(lds), ty_blk * g.tiles_x + tx_blk);
-}
-
-// Device-pass-only instructions behind small helpers: the host pass of hipcc parses kernel bodies too, and it knows neither
-// the gfx950 LDS-DMA builtin nor these s_waitcnt forms (an error there silently drops the kernel's host stub).
-typedef __attribute__((address_space(3))) char lds_c;
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_byte_addr) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_global_load_lds(gsrc, (lds_c*)(size_t)lds_byte_addr, 16, 0, 0);
-#else
-    (void)gsrc;
-    (void)lds_byte_addr;
-#endif
-}
-template <int N>
-__device__ __forceinline__ void wait_vm_keep() {  // retire all but the N youngest vector-memory operations; all LDS operations
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
 }
 
 struct WsTile { int n0, oy0, ox0, co0, ts; };

@@ -5,6 +5,8 @@
 //   finalize S1[n,g] = sum_{c in g} gamma_c A,  S2 = sum gamma_c B;  dgamma_c += sum_n B, dbeta_c += sum_n A
 //   pass B  dx = rstd * (du*gamma - (S1 + xhat*S2)/cnt)                  (elementwise)
 // The group sums follow from the channel sums, so no per-group reduction over pixels is needed.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dmme {
@@ -364,6 +366,116 @@ int launch_grad_acc_fast(int dtype, const void* src, void* d1, void* d2, int C1,
     return DMME_OK;
 }
 
+// Small feature maps (<= 64 pixels): ONE workgroup per image does the whole GroupNorm(+SiLU+Dropout2d) backward - channel
+// sums A, B in LDS (fixed-order reduction), the group sums, then a second pass over the (L2-resident) image for dx; the
+// batch sums of dgamma / dbeta go out as one atomic per channel per image.  One launch instead of three.
+template <typename T>
+__global__ void __launch_bounds__(256) gn_bwd_small_kernel(const T* __restrict__ dv, const T* __restrict__ x1, const T* __restrict__ x2, int HW, int C1,
+                                                           int C2, int groups, const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ dmask, int pro_silu, T* __restrict__ dx1, T* __restrict__ dx2,
+                                                           int acc1, int acc2, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    constexpr int EPV = 16 / sizeof(T);
+    __shared__ float red[256 * EPV * 2];
+    __shared__ float chA[512], chB[512], gS1[64], gS2[64];
+    const int C = C1 + C2, tid = threadIdx.x, VPP = C / EPV, ppw = 256 / VPP, slot = tid % VPP, prow = tid / VPP;
+    const int n = blockIdx.x, c0 = slot * EPV, cg = C / groups;
+    const bool active = prow < ppw;
+    const bool second = c0 >= C1;
+    const T* xs = second ? x2 : x1;
+    T* dst = second ? dx2 : dx1;
+    const int acc = second ? acc2 : acc1;
+    const int Cs = second ? C2 : C1, cs0 = second ? c0 - C1 : c0;
+    const int64_t p0 = (int64_t)n * HW;
+    float sc[EPV], sh[EPV], dm[EPV], mu[EPV], rs[EPV], gm[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+        const int c = active ? c0 + j : 0, g = c / cg;
+        sc[j] = scale[(int64_t)n * C + c];
+        sh[j] = shift[(int64_t)n * C + c];
+        dm[j] = dmask ? dmask[(int64_t)n * C + c] : 1.0f;
+        mu[j] = mean_rstd[((int64_t)n * groups + g) * 2];
+        rs[j] = mean_rstd[((int64_t)n * groups + g) * 2 + 1];
+        gm[j] = gamma[c];
+    }
+    float a[EPV], bq[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) a[j] = bq[j] = 0.f;
+    if (active)
+        for (int p = prow; p < HW; p += ppw) {
+            float d[EPV], xv[EPV];
+            load_vec<T>(dv + (p0 + p) * C + c0, d);
+            load_vec<T>(xs + (p0 + p) * Cs + cs0, xv);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) {
+                float du = d[j] * dm[j];
+                if (pro_silu) du *= silu_grad_f<T>(fmaf(xv[j], sc[j], sh[j]));
+                a[j] += du;
+                bq[j] = fmaf(du, (xv[j] - mu[j]) * rs[j], bq[j]);
+            }
+        }
+    if (active)
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+            red[(tid * EPV + j) * 2] = a[j];
+            red[(tid * EPV + j) * 2 + 1] = bq[j];
+        }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int v = c / EPV, j = c % EPV;
+        float sa = 0.f, sb = 0.f;
+        for (int r = 0; r < ppw; ++r) {
+            sa += red[((r * VPP + v) * EPV + j) * 2];
+            sb += red[((r * VPP + v) * EPV + j) * 2 + 1];
+        }
+        chA[c] = sa;
+        chB[c] = sb;
+        atomicAdd(&dbeta[c], sa);
+        atomicAdd(&dgamma[c], sb);
+    }
+    __syncthreads();
+    if (tid < groups) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int j = 0; j < cg; ++j) {
+            const int c = tid * cg + j;
+            s1 = fmaf(gamma[c], chA[c], s1);
+            s2 = fmaf(gamma[c], chB[c], s2);
+        }
+        gS1[tid] = s1;
+        gS2[tid] = s2;
+    }
+    __syncthreads();
+    if (!active) return;
+    const float inv = 1.0f / (float)((int64_t)cg * HW);
+    float k1[EPV], k2[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+        const int g = (c0 + j) / cg;
+        k1[j] = gS1[g] * inv;
+        k2[j] = gS2[g] * inv;
+    }
+    for (int p = prow; p < HW; p += ppw) {
+        float d[EPV], xv[EPV], o[EPV];
+        load_vec<T>(dv + (p0 + p) * C + c0, d);
+        load_vec<T>(xs + (p0 + p) * Cs + cs0, xv);
+        if (acc) load_vec<T>(dst + (p0 + p) * Cs + cs0, o);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+            float du = d[j] * dm[j];
+            if (pro_silu) du *= silu_grad_f<T>(fmaf(xv[j], sc[j], sh[j]));
+            const float xhat = (xv[j] - mu[j]) * rs[j];
+            const float dx = rs[j] * (du * gm[j] - (k1[j] + xhat * k2[j]));
+            o[j] = acc ? o[j] + dx : dx;
+        }
+        store_vec<T>(dst + (p0 + p) * Cs + cs0, o);
+    }
+}
+
+static bool gn_bwd_small_supported(int dtype, int HW, int C1, int C2, int groups) {
+    const int EPV = dtype == DMME_BF16 ? 8 : 4, C = C1 + C2;
+    return HW <= 64 && C <= 512 && groups <= 64 && C % groups == 0 && C1 % EPV == 0 && C2 % EPV == 0 && C / EPV <= 256 && !getenv("DMME_NO_GN_SMALL");
+}
+
 bool gn_bwd_fast_supported(int dtype, int HW, int C1, int C2) {
     const int EPV = dtype == DMME_BF16 ? 8 : 4;
     int a, b, c;
@@ -375,6 +487,16 @@ int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2
                        const float* gamma, const float* mean_rstd, const float* scale, const float* shift, const float* dmask,
                        int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, float* AB, float* S,
                        hipStream_t s) {
+    if (gn_bwd_small_supported(dtype, HW, C1, C2, groups)) {
+        if (dtype == DMME_BF16)
+            hipLaunchKernelGGL(gn_bwd_small_kernel<bf16>, dim3(N), dim3(256), 0, s, (const bf16*)dv, (const bf16*)x1, (const bf16*)x2, HW, C1, C2, groups,
+                               gamma, mean_rstd, scale, shift, dmask, pro_silu, (bf16*)dx1, (bf16*)dx2, acc1, acc2, dgamma, dbeta);
+        else
+            hipLaunchKernelGGL(gn_bwd_small_kernel<float>, dim3(N), dim3(256), 0, s, (const float*)dv, (const float*)x1, (const float*)x2, HW, C1, C2,
+                               groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, (float*)dx1, (float*)dx2, acc1, acc2, dgamma, dbeta);
+        DMME_CHECK_LAUNCH();
+        return DMME_OK;
+    }
     int chunk_px, nchunks, ppw;
     const int C = C1 + C2;
     DMME_REQUIRE(vec_geometry(dtype, HW, C, chunk_px, nchunks, ppw), DMME_ERR_UNSUPPORTED, "gn_bwd_fast: unsupported geometry");

@@ -369,10 +369,34 @@ __global__ void __launch_bounds__(256) bias_tproj_kernel(const float* __restrict
     if (dbias) dbias[c] += tot;
     if (dtproj && nt == 1) dtproj[c] = tot;
 }
+// few channels (the 3-channel output conv): one workgroup per image, threads over the pixels, LDS reduction per channel
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_thin_kernel(const T* __restrict__ dY, int HW, int C, float* __restrict__ rowsum) {
+    __shared__ float red[256];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    for (int c = 0; c < C; ++c) {
+        float acc = 0.f;
+        for (int p = tid; p < HW; p += 256) acc += to_f(dY[((int64_t)n * HW + p) * C + c]);
+        red[tid] = acc;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) red[tid] += red[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) rowsum[(int64_t)n * C + c] = red[0];
+        __syncthreads();
+    }
+}
+
 int launch_colsum(int dtype, const void* dY, int N, int HW, int C, float* rowsum, float* dbias, float* dtproj, int ld, int nt,
                   hipStream_t s) {
     dim3 grid((C + 255) / 256, N);
-    if (dtype == DMME_BF16)
+    if (C <= 8 && HW >= 256) {
+        if (dtype == DMME_BF16)
+            hipLaunchKernelGGL(colsum_thin_kernel<bf16>, dim3(N), dim3(256), 0, s, (const bf16*)dY, HW, C, rowsum);
+        else
+            hipLaunchKernelGGL(colsum_thin_kernel<float>, dim3(N), dim3(256), 0, s, (const float*)dY, HW, C, rowsum);
+    } else if (dtype == DMME_BF16)
         hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dY, HW, C, rowsum);
     else
         hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)dY, HW, C, rowsum);

@@ -7,6 +7,8 @@ dmme_adam_step): clip -> Adam -> EMA.  Works on the parameters of dmme_amd UNets
 
 from __future__ import annotations
 
+import contextlib
+
 import torch
 
 from . import _lib
@@ -68,3 +70,24 @@ class FusedAdam(torch.optim.Optimizer):
     def ema_parameters(self, model):
         st = self._flat_state.get(id(model))
         return None if st is None else st["ema"]
+
+    @contextlib.contextmanager
+    def swap_ema(self, model):
+        """Evaluate / sample with the EMA weights: inside the block the model's flat parameter buffer holds the EMA
+        copy, the live weights come back on exit (the reference's EMA callback swaps them the same way around
+        validation and image generation, callbacks/ema.py:298-308).  Two flat-buffer copies each way; the packed
+        kernel-layout weights are rebuilt on the next forward because the buffer's version changed."""
+        ema = self.ema_parameters(model)
+        if ema is None:
+            raise RuntimeError("swap_ema: no EMA copy yet (ema_decay == 0 or no optimiser step taken)")
+        flat = model.flat_parameters()
+        with torch.no_grad():
+            live = flat.clone()
+            flat.copy_(ema)
+            model.mark_params_updated()
+        try:
+            yield model
+        finally:
+            with torch.no_grad():
+                flat.copy_(live)
+                model.mark_params_updated()

@@ -177,3 +177,41 @@ def test_bf16_train_step_close_to_fp32():
         worst = max(worst, rel)
         assert rel < 0.08, (k, rel)
     print("worst relative gradient error bf16 vs fp32:", worst)
+
+
+def test_swap_ema_weights_for_sampling():
+    """EMA copy follows ema = d*ema + (1-d)*p after every step; swap_ema puts it in the model for evaluation and
+    restores the live weights afterwards (forward outputs follow the swap: the packed weights are rebuilt)."""
+    import dmme_amd
+    from dmme_amd.optim import FusedAdam
+
+    torch.manual_seed(3)
+    from oracle import unet as O
+
+    cfg = O.TINY
+    model = dmme_amd.UNet(cfg.in_channels, cfg.pos_dim, cfg.emb_dim, cfg.num_groups, 0.0, cfg.channels_per_depth, cfg.num_blocks,
+                          cfg.attention_depths, precision="fp32").cuda()
+    model.eval()
+    opt = FusedAdam(model.parameters(), lr=1e-2, ema_decay=0.5)
+    x = torch.randn(2, cfg.in_channels, 8, 8, device="cuda")
+    t = torch.tensor([5], device="cuda")
+    p0 = model.flat_parameters().clone()
+    for _ in range(2):
+        model.train()
+        loss = (model(x, t) ** 2).mean()
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+    model.eval()
+    p2 = model.flat_parameters().clone()
+    ema = opt.ema_parameters(model).clone()
+    assert not torch.equal(p2, p0) and not torch.equal(ema, p2)
+    with torch.no_grad():
+        y_live = model(x, t).clone()
+        with opt.swap_ema(model):
+            assert torch.equal(model.flat_parameters(), ema)
+            y_ema = model(x, t).clone()
+        assert torch.equal(model.flat_parameters(), p2)
+        y_back = model(x, t).clone()
+    assert torch.equal(y_live, y_back)
+    assert not torch.equal(y_live, y_ema)

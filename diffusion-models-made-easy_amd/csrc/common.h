@@ -128,6 +128,7 @@ struct ConvArgs {
 // ---- kernel launchers (defined in the .hip files) ------------------------------------
 int launch_conv_generic(int dtype, const ConvArgs& a, hipStream_t s);
 const char* conv_generic_kernel_name(const ConvArgs& a);
+bool conv_in_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px);
 // returns DMME_ERR_UNSUPPORTED (without setting the error) when the shape is outside
 // the MFMA kernel's domain, so callers can fall back to the generic kernel.
 bool conv_mfma_supported(int dtype, const ConvArgs& a);

@@ -190,7 +190,7 @@ bool conv_pipe_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int
 bool conv_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px) {
     if (conv1x1_pipe_supported(dtype, a)) return conv1x1_stats_query(dtype, a, cg, tiles, px);
     if (conv_pipe_supported(dtype, a)) return conv_pipe_stats_query(dtype, a, cg, tiles, px);
-    if (!conv_mfma_supported(dtype, a)) return false;
+    if (!conv_mfma_supported(dtype, a)) return conv_in_stats_query(dtype, a, cg, tiles, px);
     ConvTile g{};
     const int pick = pick_tile(a, g);
     if (pick < 0) return false;

@@ -172,6 +172,28 @@ __global__ void __launch_bounds__(256) conv_in_mfma_kernel(ConvArgs a, int nbloc
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = (__bf16)acc[4 * gq + e];
                     *reinterpret_cast<bf16x4_g*>(st + r * PITCH + ct * 32 + 8 * gq + 4 * h) = v;
+                    if (a.gn_part) {
+                        // fused GroupNorm partial (groups of 4 channels = this register group): {mean, M2} of the 32 pixels x
+                        // 4 stored (bf16-rounded) values, reduced over the 32 lanes of this half-wave
+                        float s = 0.f, ss = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float x = (float)v[e];
+                            s += x;
+                            ss = fmaf(x, x, ss);
+                        }
+#pragma unroll
+                        for (int o = 1; o < 32; o <<= 1) {
+                            s += __shfl_xor(s, o, 64);
+                            ss += __shfl_xor(ss, o, 64);
+                        }
+                        if (r == 0) {
+                            const float mean = s * (1.f / 128.f);
+                            float* po = a.gn_part + (((int64_t)n * a.gn_tiles + (rem >> 5)) * (a.Cout / 4) + ct * 8 + 2 * gq + h) * 2;
+                            po[0] = mean;
+                            po[1] = ss - s * mean;
+                        }
+                    }
                 }
             } else {
                 T* o = (T*)a.dst + (int64_t)p * a.Cout + ct * 32 + 4 * h;
@@ -196,8 +218,17 @@ __global__ void __launch_bounds__(256) conv_in_mfma_kernel(ConvArgs a, int nbloc
 
 static bool conv_in_mfma_supported(const ConvArgs& a) {
     return a.in_nchw && !a.out_nchw && a.taps == 9 && a.stride == 1 && !a.up && a.C2 == 0 && a.C1 <= 3 && !a.scale && !a.pro_silu && !a.dmask &&
-           !a.tproj && !a.res1 && !a.out_silu && !a.gn_part && (a.Cout == 128 || a.Cout == 64 || a.Cout == 32) &&
+           !a.tproj && !a.res1 && !a.out_silu && (a.Cout == 128 || a.Cout == 64 || a.Cout == 32) &&
+           (!a.gn_part || (a.gn_cg == 4 && (a.Hout * a.Wout) % 32 == 0)) &&
            ((int64_t)a.N * a.Hout * a.Wout) % 32 == 0 && (int64_t)a.N * a.Hout * a.Wout * a.Cout < (1ll << 31) && !getenv("DMME_NO_CONV_IN_MFMA");
+}
+
+// the first-conv kernel can emit GroupNorm partials of its output: one per 32-pixel block, groups of exactly 4 channels
+bool conv_in_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px) {
+    if (dtype != DMME_BF16 || cg != 4 || !conv_in_mfma_supported(a) || (a.Hout * a.Wout) % 32) return false;
+    *tiles = a.Hout * a.Wout / 32;
+    *px = 32;
+    return true;
 }
 
 static bool conv_in_supported(const ConvArgs& a) {
@@ -225,7 +256,7 @@ int launch_conv_generic(int dtype, const ConvArgs& a, hipStream_t s) {
         DMME_CHECK_LAUNCH();
         return DMME_OK;
     }
-    if (conv_in_supported(a)) {
+    if (conv_in_supported(a) && !a.gn_part) {
         const int64_t npix = (int64_t)a.N * a.Hout * a.Wout;
         const int ppb = 256 / (a.Cout / 8) * 8;  // 8 passes per block
         const unsigned blocks = (unsigned)((npix + ppb - 1) / ppb);

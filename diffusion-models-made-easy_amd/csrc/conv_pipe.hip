@@ -253,10 +253,11 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
     using T = bf16;
     constexpr int KC = 64, EPV = 8, BN = 128, MI = 4, NI = 2, UB = BN / 32;  // BM = 256
     constexpr int R_BYTES = BN * ROW_DATA;  // one tap
+    constexpr int A_PITCH = ROW_DATA + 16;  // halo rows are padded, not swizzled: fragment reads use immediate offsets from one base
     static_assert(PIPE_UA == 11, "unit schedule below is written out for 11 units over 9 stages");
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int a_bytes = g.a_rows * ROW_DATA;
+    const int a_bytes = g.a_rows * A_PITCH;
     const int Cin = a.C1 + a.C2;
     const int offA1 = a_bytes + 3 * R_BYTES, offR = a_bytes;
     float* par_base = reinterpret_cast<float*>(lds + 2 * a_bytes + 3 * R_BYTES);  // [2][3][Cin]: scale, shift, mask
@@ -327,7 +328,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         int a_pix[PIPE_UA], a_sw[PIPE_UA];
         unsigned b_vo[UB];
 #pragma unroll
-        for (int i = 0; i < PIPE_UA; ++i) a_sw[i] = swz_off(urow + 32 * i, cu);
+        for (int i = 0; i < PIPE_UA; ++i) a_sw[i] = (urow + 32 * i) * A_PITCH + cu * 16;
 #pragma unroll
         for (int k4 = 0; k4 < UB; ++k4) b_vo[k4] = (unsigned)(((urow + 32 * k4) * 9 * Cin + (cu ^ ((urow >> 1) & 7)) * EPV) * 2);
         auto set_pix = [&](int i, const TileXY& t) __attribute__((always_inline)) {
@@ -460,14 +461,14 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
     for (int mi = 0; mi < MI; ++mi) {
         const int m = (2 * mi + wrow) * 32 + r;  // interleaved 32-pixel blocks (see the epilogue)
         const int tx = m & mTW, ty = (m >> shTW) & mTH;
-        a_row[mi] = ty * g.HWd + tx;
+        a_row[mi] = (ty * g.HWd + tx) * A_PITCH + h * 16;  // byte offset of this lane's fragment row (tap 0, k-group 0)
     }
-    int b_base[NI], b_swz[NI];
+    int b_off[NI][4];  // byte offset of this lane's filter fragment per k-group (the ring stays XOR-swizzled: the DMA writes lane-linear)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int row = wn0 + ni * 32 + r;
-        b_base[ni] = row * ROW_DATA;
-        b_swz[ni] = (row >> 1) & 7;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) b_off[ni][kg] = row * ROW_DATA + (((kg * 2 + h) ^ ((row >> 1) & 7)) << 4);
     }
     // diagnostic cycle stamps (a.stamps null: off): consumer wave 0 of workgroup 0, [arrive, leave] of every barrier
     int stamp_i = 0;
@@ -491,20 +492,15 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
 #pragma unroll 3
             for (int tp = 0; tp < 9; ++tp) {
                 const char* ldsR = WS_RING(tp % 3);
-                const int tap_off = (tp / 3) * g.HWd + (tp % 3);
-                int abase[MI], aswz[MI];
+                const int tap_b = ((tp / 3) * g.HWd + (tp % 3)) * A_PITCH;
+                const char* pa[MI];
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    const int row = a_row[mi] + tap_off;
-                    abase[mi] = row * ROW_DATA;
-                    aswz[mi] = (row >> 1) & 7;
-                }
+                for (int mi = 0; mi < MI; ++mi) pa[mi] = ldsA + a_row[mi] + tap_b;
                 uint4 af[2][MI], bfr[2][NI];
 #define WS_FRAGS(SET, KG)                                                                                                         \
     {                                                                                                                             \
-        const int cidx = (KG) * 2 + h;                                                                                            \
-        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) af[SET][mi] = *reinterpret_cast<const uint4*>(ldsA + abase[mi] + ((cidx ^ aswz[mi]) << 4)); \
-        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) bfr[SET][ni] = *reinterpret_cast<const uint4*>(ldsR + b_base[ni] + ((cidx ^ b_swz[ni]) << 4)); \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) af[SET][mi] = *reinterpret_cast<const uint4*>(pa[mi] + (KG) * 32);      \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) bfr[SET][ni] = *reinterpret_cast<const uint4*>(ldsR + b_off[ni][KG]);   \
         __builtin_amdgcn_sched_barrier(0);                                                                                        \
     }
 #define WS_MMAS(SET)                                                                                  \
@@ -537,7 +533,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
 #undef WS_TILE
 }
 
-static size_t ws2_lds(const ConvArgs& a, const ConvTile& g) { return 2 * (size_t)g.a_rows * ROW_DATA + 3 * (size_t)128 * ROW_DATA + (size_t)2 * 3 * (a.C1 + a.C2) * 4; }
+static size_t ws2_lds(const ConvArgs& a, const ConvTile& g) { return 2 * (size_t)g.a_rows * (ROW_DATA + 16) + 3 * (size_t)128 * ROW_DATA + (size_t)2 * 3 * (a.C1 + a.C2) * 4; }
 
 // the wave-specialised kernel applies (else 0): its tile goes to g
 static int ws_pick(const ConvArgs& a, ConvTile& g) {

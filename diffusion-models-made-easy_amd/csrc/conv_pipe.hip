@@ -408,6 +408,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         if (new_tile) set_pix((i), tnn);      \
         load_A((i), lc * KC);                 \
     }
+#define WS_A_ARRIVED(i) { asm volatile("" : "+v"(areg[i][0]), "+v"(areg[i][1]), "+v"(areg[i][2]), "+v"(areg[i][3])); }
         // stage TP = tap TP of chunk (kt, cc): DMA of the next stage's tap, 1-2 halo units of the next chunk, barrier
 #define WS_PSTAGE(TP)                                                                                                   \
     {                                                                                                                   \
@@ -417,6 +418,13 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         const bool last_n = nc + 1 == nchunks;                                                                          \
         const bool have_l = have_n && !(last_n && nk + 1 == K);                                                         \
         const int lk = have_l ? (last_n ? nk + 1 : nk) : nk, lc = have_l ? (last_n ? 0 : nc + 1) : nc;                  \
+        /* hipcc waits vmcnt(0) at the first use of an ordinary load's result while an LDS-DMA is in flight: take this  \
+           stage's halo registers as arrived BEFORE the DMA is issued (counted wait here), so the math below runs under  \
+           the DMA instead of behind it */                                                                              \
+        if ((TP) == 0) { WS_A_ARRIVED(0) WS_A_ARRIVED(1) }                                                              \
+        else if ((TP) == 8) { WS_A_ARRIVED(9) WS_A_ARRIVED(10) }                                                        \
+        else { WS_A_ARRIVED((TP) + 1) }                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
         if ((TP) < 8) dma_tap(WS_RING(((TP) + 1) % 3), tcur.co0, cc, (TP) + 1);                                         \
         else dma_tap(WS_RING(0), nk == kt ? tcur.co0 : tnext.co0, nc, 0);                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
@@ -449,6 +457,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         }
 #undef WS_PSTAGE
 #undef WS_A_UNIT
+#undef WS_A_ARRIVED
         return;
     }
 

@@ -39,8 +39,8 @@ def main():
         d.out_silu = d.nt = d.tproj_ld = d.in_nchw = d.out_nchw = d.force_generic = 0
         flops = 2.0 * B * hw * hw * cin * cout * args.taps
         for var in args.variants.split(","):
-            d.pro_silu = 1 if var == "gn" else 0
-            sc, sh = (scale, shift) if var == "gn" else (None, None)
+            d.pro_silu = 1 if var == "gn" else 0  # "aff": GroupNorm affine without SiLU
+            sc, sh = (scale, shift) if var in ("gn", "aff") else (None, None)
             st = _lib.stream_ptr()
 
             def run():

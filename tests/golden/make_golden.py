@@ -35,6 +35,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
 from oracle import unet as O  # noqa: E402
+from oracle import iddpm as OI  # noqa: E402
 from oracle import synth  # noqa: E402
 
 REF = "/root/reference/src/dmme"
@@ -59,10 +60,11 @@ def import_reference():
     eq = importlib.import_module("dmme.equations")
     dm = importlib.import_module("dmme.diffusion_models")
     mm = importlib.import_module("dmme.models.ddpm")
-    return d, eq, dm, mm
+    mi = importlib.import_module("dmme.models.iddpm")
+    return d, eq, dm, mm, mi
 
 
-dmme, eq, dm, mm = import_reference()
+dmme, eq, dm, mm, mi = import_reference()
 torch.distributions.Distribution.set_default_validate_args(False)
 torch.set_num_threads(8)
 
@@ -339,6 +341,186 @@ def gen_traj(out):
                     out[f"traj_ddim_{sch}_{T_}_{S_}_i{i}"] = x.numpy()
 
 
+# ---------------------------------------------------------------------------- Improved DDPM
+
+
+def ref_iunet(cfg: OI.IUNetConfig, seed: int):
+    net = mi.UNet(
+        in_channels=cfg.in_channels,
+        pos_dim=cfg.pos_dim,
+        emb_dim=cfg.emb_dim,
+        num_groups=cfg.num_groups,
+        dropout=cfg.dropout,
+        channels_per_depth=cfg.channels_per_depth,
+        num_blocks=cfg.num_blocks,
+        attention_depths=cfg.attention_depths,
+    )
+    sd = OI.make_state_dict(cfg, seed)
+    assert list(net.state_dict().keys()) == [k for k, _, _ in OI.param_table(cfg)], "iddpm param_table order mismatch"
+    net.load_state_dict(sd, strict=True)
+    return net, sd
+
+
+def gen_iddpm_unet(out):
+    for tag, cfg, seed in (("tiny", OI.TINY, 31), ("attn", OI.TINY_ATTN, 32)):
+        net, _ = ref_iunet(cfg, seed)
+        net.eval()
+        out[f"{tag}_seed"] = np.int64(seed)
+        case = 0
+        for B in (1, 3):
+            for tshape in ("one", "per"):
+                x = synth.normal(700 + case, (B, 3, 32, 32))
+                t = synth.randint(720 + case, 1, 100, 1 if tshape == "one" else B)
+                with torch.no_grad():
+                    y = net(x, t)
+                out[f"{tag}_case{case}_B"] = np.int64(B)
+                out[f"{tag}_case{case}_xseed"] = np.int64(700 + case)
+                out[f"{tag}_case{case}_t"] = t.numpy()
+                out[f"{tag}_case{case}_y"] = y.numpy()
+                case += 1
+        out[f"{tag}_ncases"] = np.int64(case)
+        # per-module activations at B = 2 (the head merge mixes the two samples)
+        x = synth.normal(750, (2, 3, 32, 32))
+        t = torch.tensor([7, 93])
+        acts, hs = hook_outputs(net)
+        with torch.no_grad():
+            y = net(x, t)
+        for h in hs:
+            h.remove()
+        out[f"{tag}_acts_xseed"] = np.int64(750)
+        out[f"{tag}_acts_t"] = t.numpy()
+        out[f"{tag}_acts_y"] = y.numpy()
+        for k, v in acts.items():
+            out[f"{tag}_act::{k}"] = v.numpy()
+        # train mode, injected Dropout2d masks
+        B = 3
+        masks = OI.make_drop_masks(cfg, B, 760)
+        x = synth.normal(761, (B, 3, 32, 32))
+        t = torch.tensor([3, 50, 99])
+        net.train(True)
+        with torch.no_grad(), InjectDropout([masks[k] for k in OI.res_block_names(cfg)]) as dr:
+            y = net(x, t)
+            assert dr.k == len(OI.res_block_names(cfg))
+        out[f"{tag}_train_meta"] = np.array([B, 760, 761], dtype=np.int64)
+        out[f"{tag}_train_t"] = t.numpy()
+        out[f"{tag}_train_y"] = y.numpy()
+    # default-size network (36.2 M parameters): digests only
+    cfg, seed = OI.IUNetConfig(), 41
+    net, _ = ref_iunet(cfg, seed)
+    net.eval()
+    out["full_seed"] = np.int64(seed)
+    out["full_nparams"] = np.int64(sum(p.numel() for p in net.parameters()))
+    x = synth.normal(770, (2, 3, 32, 32))
+    out["full_xseed"] = np.int64(770)
+    acts, hs = hook_outputs(net)
+    with torch.no_grad():
+        y1 = net(x, torch.tensor([500]))
+    for h in hs:
+        h.remove()
+    out["full_t_one"] = np.array([500], dtype=np.int64)
+    out["full_y_one"] = y1.numpy()
+    for k, v in acts.items():
+        out[f"full_actdigest::{k}"] = synth.digest(v)
+    # one multi-head attention block alone at real width: C = 256, S = 64, B = 3
+    at = mi.MultiHeadAttention(256, 32, 4)
+    full_sd = OI.make_state_dict(cfg, seed)
+    pre = "down_layers.3.attention."
+    at.load_state_dict({k[len(pre):]: v for k, v in full_sd.items() if k.startswith(pre)})
+    x = synth.normal(771, (3, 256, 8, 8))
+    with torch.no_grad():
+        out["layer_mha256_y"] = at(x).numpy()
+
+
+def gen_iddpm_process(out):
+    dummy = torch.nn.Identity()
+    for T in (100, 1000, 4000):
+        d = dm.IDDPM(dummy, timesteps=T)
+        out[f"cos_beta_{T}"] = d.beta.reshape(-1).numpy()
+        out[f"cos_alpha_{T}"] = d.alpha.reshape(-1).numpy()
+        out[f"cos_abar_{T}"] = d.alpha_bar.reshape(-1).numpy()
+    d = dm.IDDPM(dummy, timesteps=4000, schedule="linear", start=2.5e-5, end=0.005)  # configs/iddpm/cifar10.yaml:78-81
+    out["lin_beta_4000"] = d.beta.reshape(-1).numpy()
+    out["lin_abar_4000"] = d.alpha_bar.reshape(-1).numpy()
+    try:
+        dm.IDDPM(dummy, schedule="sqrt")
+        out["bad_schedule_raises"] = np.int64(0)
+    except NotImplementedError:
+        out["bad_schedule_raises"] = np.int64(1)
+    # equations on synthetic tensors
+    v = synth.uniform(800, (4, 3, 8, 8), -0.5, 1.5)
+    bt = torch.tensor([0.02, 1e-4, 0.3, 0.999]).reshape(4, 1, 1, 1)
+    btt = torch.tensor([0.01, 0.0, 0.2, 0.5]).reshape(4, 1, 1, 1)
+    out["interp_var"] = eq.iddpm.interpolate_variance(v, bt, btt).numpy()
+
+    # training_step on the tiny network: hybrid loss + every gradient (a t == 1 row included)
+    cfg, seed, T, B = OI.TINY, 31, 100, 4
+    x0 = synth.uniform(810, (B, 3, 32, 32))
+    z = synth.normal(812, (B, 3, 32, 32))
+    t = torch.tensor([1, 57, 99, 2])
+    out["train_meta"] = np.array([seed, T, B, 810, 812, 813], dtype=np.int64)
+    out["train_t"] = t.numpy()
+    for sched in ("cosine", "linear"):
+        for mode in ("eval", "train"):
+            net, _ = ref_iunet(cfg, seed)
+            net.train(mode == "train")
+            idd = dm.IDDPM(net, timesteps=T, schedule=sched)
+            masks = OI.make_drop_masks(cfg, B, 813)
+            order = OI.res_block_names(cfg)
+            orig_ui = dmme.uniform_int
+            dmme.uniform_int = lambda lo, hi, count=1, device=None: t
+            try:
+                with InjectNormal([z]), InjectDropout([masks[k] for k in order]):
+                    loss = idd.training_step(x0)
+            finally:
+                dmme.uniform_int = orig_ui
+            loss.backward()
+            out[f"train_{sched}_{mode}_loss"] = loss.detach().numpy()
+            if sched == "cosine":
+                for k, p in net.named_parameters():
+                    out[f"train_{mode}_grad::{k}"] = p.grad.numpy()
+    # the two loss terms by themselves, and the gradient w.r.t. the raw network output, on synthetic tensors
+    idd = dm.IDDPM(dummy, timesteps=T)
+    mo = (0.5 * synth.normal(820, (B, 6, 32, 32))).requires_grad_(True)
+    x_t = synth.normal(821, (B, 3, 32, 32))
+    bt, at_, abt, abp = idd.beta[t], idd.alpha[t], idd.alpha_bar[t], idd.alpha_bar[t - 1]
+    eps_, v_ = mo.chunk(2, dim=1)
+    var = eq.iddpm.interpolate_variance(v_, bt, (1 - abp) / (1 - abt) * bt)
+    vlb = eq.iddpm.loss_vlb(eps_, var, x_t, t, x0, bt, at_, abt, abp)
+    vlb.backward()
+    out["vlb_meta"] = np.array([820, 821], dtype=np.int64)
+    out["vlb_value"] = vlb.detach().numpy()
+    out["vlb_dout"] = mo.grad.numpy()
+    net, _ = ref_iunet(cfg, seed)
+    net.eval()
+    idd_v = dm.IDDPM(net, timesteps=T, loss_type="vlb")
+    idd_s = dm.IDDPM(net, timesteps=T, loss_type="simple")
+    orig_ui = dmme.uniform_int
+    dmme.uniform_int = lambda lo, hi, count=1, device=None: t
+    try:
+        with InjectNormal([z]), torch.no_grad():
+            out["train_vlb_only_loss"] = idd_v.training_step(x0).numpy()
+        with InjectNormal([z]), torch.no_grad():
+            out["train_simple_returns_none"] = np.int64(idd_s.training_step(x0) is None)
+    finally:
+        dmme.uniform_int = orig_ui
+
+    # sampling: 100-step cosine chain on the tiny network, injected noise
+    Bs = 2
+    shape = (Bs, 3, 32, 32)
+    x_T = synth.normal(830, shape)
+    zs = [synth.normal(2000 + k, shape) for k in range(T)]
+    out["traj_meta"] = np.array([seed, T, Bs, 830, 2000], dtype=np.int64)
+    for sched in ("cosine", "linear"):
+        idd = dm.IDDPM(net, timesteps=T, schedule=sched)
+        all_t = torch.arange(0, T + 1).unsqueeze(1)
+        x = x_T
+        with torch.no_grad(), InjectNormal(zs):
+            for k in range(T):
+                x = idd.sampling_step(x, all_t[T - k])
+                if k in (0, 1, 9, 49, 97, 98, 99):
+                    out[f"traj_{sched}_step{k}"] = x.numpy()
+
+
 def main():
     torch.manual_seed(0)
     groups = {
@@ -348,6 +530,8 @@ def main():
         "schedules": gen_schedules,
         "train_tiny": gen_train,
         "traj_tiny": gen_traj,
+        "iddpm_unet": gen_iddpm_unet,
+        "iddpm_process": gen_iddpm_process,
     }
     only = sys.argv[1:]
     for name, fn in groups.items():

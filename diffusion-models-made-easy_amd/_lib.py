@@ -33,6 +33,8 @@ class UNetCfg(C.Structure):
         ("num_blocks", C.c_int),
         ("num_attention_depths", C.c_int),
         ("attention_depths", C.c_int * 8),
+        ("arch", C.c_int),
+        ("num_heads", C.c_int),
     ]
 
 
@@ -72,6 +74,7 @@ PROTOTYPES = {
     "dmme_unet_plan_packed_bytes": (_i64, [_vp]),
     "dmme_unet_plan_workspace_bytes": (_i64, [_vp]),
     "dmme_unet_plan_dropmask_numel": (_i64, [_vp]),
+    "dmme_unet_plan_out_channels": (_i, [_vp]),
     "dmme_unet_plan_num_launches": (_i, [_vp]),
     "dmme_unet_pack_params": (_i, [_vp, _vp, _vp, _vp]),
     "dmme_unet_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),

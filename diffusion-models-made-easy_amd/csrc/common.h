@@ -163,6 +163,12 @@ int launch_gn_fast(int dtype, const void* src1, const void* src2, int N, int HW,
                    float* partial, hipStream_t s);
 
 int launch_attn_generic(int dtype, const void* qkv, int N, int S, int C, void* out, hipStream_t s);
+// multi-head attention as the reference ships it (models/iddpm.py:35-47): head h owns qkv channels [h*3d, (h+1)*3d) split
+// (q | k | v), K scaled by C^-0.5, and row b*heads + h of the result lands at batch (b*heads + h) % N, head (b*heads + h) / N
+int launch_attn_heads(int dtype, const void* qkv, int N, int S, int C, int heads, void* out, hipStream_t s);
+int launch_attn_heads_bwd(int dtype, const void* qkv, const void* dO, int N, int S, int C, int heads, float* P, float* dS, void* dqkv, hipStream_t s);
+// scale-shift conditioning folded into a GroupNorm's per-(n, c) scale / shift: sc *= 1 + t_scale, sh = sh * (1 + t_scale) + t_shift
+int launch_gn_modulate(float* scale, float* shift, const float* t_shift, const float* t_scale, int ld, int nt, int N, int C, hipStream_t s);
 bool attn_mfma_supported(int dtype, int N, int S, int C);
 // lse (nullable): [N][S] log2-domain log-sum-exp of the scaled scores, kept for the backward pass
 int launch_attn_mfma(int dtype, const void* qkv, int N, int S, int C, void* out, float* lse, hipStream_t s);

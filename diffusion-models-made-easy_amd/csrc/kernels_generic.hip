@@ -334,23 +334,27 @@ int launch_gn_generic(int dtype, const void* src1, const void* src2, int N, int 
 }
 
 // ------------------------------------------------------------------ generic attention
-// One workgroup per (query token, image).  scores in LDS (S floats) + q (C floats).
+// One workgroup per (query token, image x head).  scores in LDS (S floats) + q (d floats).
+// Head view (heads > 1, models/iddpm.py:35-47): head h of image b reads the qkv channels [h*3d, (h+1)*3d) as (q | k | v),
+// d = C / heads; K is scaled by C^-0.5 (the full width); result row i = b*heads + h is stored as image i % N, head i / N
+// (the reference's "(b head)" split read back as "(head b)").  heads == 1 is the DDPM single-head block (models/ddpm.py:54-63).
 template <typename T>
-__global__ void __launch_bounds__(256) attn_generic_kernel(const T* __restrict__ qkv, int S, int C, T* __restrict__ out) {
+__global__ void __launch_bounds__(256) attn_generic_kernel(const T* __restrict__ qkv, int S, int C, int heads, int N, T* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* qs = sm;       // C
-    float* ps = sm + C;   // S
+    const int d = C / heads;
+    float* qs = sm;       // d
+    float* ps = sm + d;   // S
     float* red = ps + S;  // 16
-    const int n = blockIdx.y, i = blockIdx.x;
-    const T* base = qkv + (int64_t)n * S * 3 * C;
+    const int bh = blockIdx.y, n = bh / heads, hd = bh % heads, i = blockIdx.x;
+    const T* base = qkv + (int64_t)n * S * 3 * C + (int64_t)hd * 3 * d;
     const float kscale = powf((float)C, -0.5f);
-    for (int c = threadIdx.x; c < C; c += blockDim.x) qs[c] = to_f(base[(int64_t)i * 3 * C + c]);
+    for (int c = threadIdx.x; c < d; c += blockDim.x) qs[c] = to_f(base[(int64_t)i * 3 * C + c]);
     __syncthreads();
     float lmax = -INFINITY;
     for (int j = threadIdx.x; j < S; j += blockDim.x) {
-        const T* kr = base + (int64_t)j * 3 * C + C;
+        const T* kr = base + (int64_t)j * 3 * C + d;
         float acc = 0.f;
-        for (int c = 0; c < C; ++c) acc = fmaf(qs[c], to_f(from_f<T>(to_f(kr[c]) * kscale)), acc);
+        for (int c = 0; c < d; ++c) acc = fmaf(qs[c], to_f(from_f<T>(to_f(kr[c]) * kscale)), acc);
         ps[j] = acc;
         lmax = fmaxf(lmax, acc);
     }
@@ -364,21 +368,43 @@ __global__ void __launch_bounds__(256) attn_generic_kernel(const T* __restrict__
     const float tot = block_sum(lsum, red);
     __syncthreads();
     const float inv = 1.0f / tot;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int on = bh % N, oh = bh / N;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
         float acc = 0.f;
-        for (int j = 0; j < S; ++j) acc = fmaf(to_f(from_f<T>(ps[j] * inv)), to_f(base[(int64_t)j * 3 * C + 2 * C + c]), acc);
-        out[((int64_t)n * S + i) * C + c] = from_f<T>(acc);
+        for (int j = 0; j < S; ++j) acc = fmaf(to_f(from_f<T>(ps[j] * inv)), to_f(base[(int64_t)j * 3 * C + 2 * d + c]), acc);
+        out[((int64_t)on * S + i) * C + oh * d + c] = from_f<T>(acc);
     }
 }
 
-int launch_attn_generic(int dtype, const void* qkv, int N, int S, int C, void* out, hipStream_t s) {
-    const size_t lds = (size_t)(C + S + 16) * sizeof(float);
-    DMME_REQUIRE(lds <= 64 * 1024, DMME_ERR_UNSUPPORTED, "attention generic: C+S too large (%d+%d)", C, S);
-    dim3 grid(S, N);
+int launch_attn_heads(int dtype, const void* qkv, int N, int S, int C, int heads, void* out, hipStream_t s) {
+    DMME_REQUIRE(heads >= 1 && C % heads == 0, DMME_ERR_INVALID, "attention: width %d not divisible by %d heads", C, heads);
+    const size_t lds = (size_t)(C / heads + S + 16) * sizeof(float);
+    DMME_REQUIRE(lds <= 64 * 1024, DMME_ERR_UNSUPPORTED, "attention generic: d+S too large (%d+%d)", C / heads, S);
+    dim3 grid(S, N * heads);
     if (dtype == DMME_BF16)
-        hipLaunchKernelGGL(attn_generic_kernel<bf16>, grid, dim3(256), lds, s, (const bf16*)qkv, S, C, (bf16*)out);
+        hipLaunchKernelGGL(attn_generic_kernel<bf16>, grid, dim3(256), lds, s, (const bf16*)qkv, S, C, heads, N, (bf16*)out);
     else
-        hipLaunchKernelGGL(attn_generic_kernel<float>, grid, dim3(256), lds, s, (const float*)qkv, S, C, (float*)out);
+        hipLaunchKernelGGL(attn_generic_kernel<float>, grid, dim3(256), lds, s, (const float*)qkv, S, C, heads, N, (float*)out);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+int launch_attn_generic(int dtype, const void* qkv, int N, int S, int C, void* out, hipStream_t s) {
+    return launch_attn_heads(dtype, qkv, N, S, C, 1, out, s);
+}
+
+// scale-shift conditioning of iddpm.ResBlock (models/iddpm.py:117-118) folded into the GroupNorm's per-(n, c) affine:
+// GN(h) * (1 + t_scale) + t_shift = h * (sc * (1 + t_scale)) + (sh * (1 + t_scale) + t_shift).  t rows: nt == 1 broadcasts.
+__global__ void gn_modulate_kernel(float* __restrict__ scale, float* __restrict__ shift, const float* __restrict__ t_shift,
+                                   const float* __restrict__ t_scale, int ld, int nt, int N, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i % C, r = nt == 1 ? 0 : n;
+    const float m = 1.0f + t_scale[(int64_t)r * ld + c];
+    scale[i] = scale[i] * m;
+    shift[i] = fmaf(shift[i], m, t_shift[(int64_t)r * ld + c]);
+}
+int launch_gn_modulate(float* scale, float* shift, const float* t_shift, const float* t_scale, int ld, int nt, int N, int C, hipStream_t s) {
+    hipLaunchKernelGGL(gn_modulate_kernel, dim3((N * C + 255) / 256), dim3(256), 0, s, scale, shift, t_shift, t_scale, ld, nt, N, C);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }

@@ -57,6 +57,9 @@ struct Op {
     int gn_src1 = -1, gn_src2 = -1, gn_gamma = -1, gn_beta = -1;
     int64_t b_rowsum = 0, b_ab = 0;  // backward scratch (bytes in the zeroed region): column sums of dY, GroupNorm channel sums
     int64_t gn_scale = 0, gn_shift = 0, gn_mr = 0;  // workspace offsets: scale/shift [N][C], {mean, rstd} [N][G][2]
+    // scale-shift conditioning (iddpm.ResBlock, models/iddpm.py:117-118): columns of tproj holding (shift | scale), -1: none.
+    // The GroupNorm output becomes GN(h) * (scale + 1) + shift, folded into the per-(n, c) scale / shift the consumer applies.
+    int gn_mod_col = -1, gn_mod_C = 0;
     // OP_CONV
     int src1 = -1, src2 = -1;  // tensor ids; -2: network input (NCHW fp32)
     int w = -1, b = -1;
@@ -70,7 +73,7 @@ struct Op {
     int wg_layer = -1;         // index into the grouped weight-gradient table of its kernel size (-1: per-layer kernels)
     int bias_deferred = 0;     // its bias / time-projection reduction runs in the grouped launch
     // OP_ATTN
-    int at_qkv = -1, at_out = -1;
+    int at_qkv = -1, at_out = -1, at_heads = 1;
     int64_t at_lse = 0;  // workspace offset of the forward's log-sum-exp [N][S]
 };
 
@@ -81,6 +84,7 @@ using namespace dmme;
 struct dmme_plan {
     dmme_unet_cfg cfg;
     int B, H, W, dtype, device;
+    int out_channels = 0;  // in_channels (DDPM) or 2 * in_channels (IDDPM: eps, v)
     std::vector<Param> params;
     std::vector<Tensor> tensors;
     std::vector<Op> ops;
@@ -173,6 +177,22 @@ struct Builder {
     void res_params(Node& n) {
         const dmme_unet_cfg& c = P->cfg;
         const std::string& p = n.prefix;
+        if (c.arch == DMME_ARCH_IDDPM) {
+            // iddpm.ResBlock.__init__ registration order (models/iddpm.py:85-104): conv1 (built with p = 0: conv at index 2),
+            // norm, condition (Linear emb -> 2 c_out), conv2 = norm_act_drop_conv(...)[1:] (the slice keeps the keys 1..3)
+            gn(p + ".conv1.0", n.cin, n.gn1w, n.gn1b);
+            conv(p + ".conv1.2", n.cin, n.cout, 3, n.c1w, n.c1b);
+            gn(p + ".norm", n.cout, n.gn2w, n.gn2b);
+            lin(p + ".condition.0", c.emb_dim, 2 * n.cout, n.tw, n.tb);
+            conv(p + (c.dropout > 0 ? ".conv2.3" : ".conv2.2"), n.cout, n.cout, 3, n.c2w, n.c2b);
+            if (n.cin != n.cout) conv(p + ".residual", n.cin, n.cout, 1, n.rw, n.rb);
+            if (n.attn) {
+                gn(p + ".attention.norm", n.cout, n.anw, n.anb);
+                conv(p + ".attention.qkv_proj", n.cout, 3 * n.cout, 1, n.qw, n.qb);
+                conv(p + ".attention.proj", n.cout, n.cout, 1, n.pw, n.pb);
+            }
+            return;
+        }
         gn(p + ".conv1.0", n.cin, n.gn1w, n.gn1b);
         conv(p + ".conv1.2", n.cin, n.cout, 3, n.c1w, n.c1b);
         lin(p + ".condition.0", c.emb_dim, n.cout, n.tw, n.tb);
@@ -240,6 +260,11 @@ int build_plan(dmme_plan* P) {
     const int top = chans[L - 1];
     mid.push_back(Node{0, "middle_layers.0", top, top, true});
     mid.push_back(Node{0, "middle_layers.1", top, top, false});
+    if (c.arch == DMME_ARCH_IDDPM)  // MultiHeadAttention asserts dim % num_heads == 0 (models/iddpm.py:26)
+        for (auto* seq : {&down, &up, &mid})
+            for (auto& n : *seq)
+                DMME_REQUIRE(!n.attn || n.cout % c.num_heads == 0, DMME_ERR_INVALID, "%s: attention width %d not divisible by num_heads=%d",
+                             n.prefix.c_str(), n.cout, c.num_heads);
 
     // ---- parameter table in nn.Module registration order ----
     Builder bld{P};
@@ -260,7 +285,8 @@ int build_plan(dmme_plan* P) {
                 bld.conv(n.prefix + ".conv", n.cin, n.cout, 3, n.cw, n.cb);
         }
     bld.gn("output_conv.0", chans[0], ogw, ogb);
-    bld.conv("output_conv.2", chans[0], c.in_channels, 3, ocw, ocb);
+    P->out_channels = c.arch == DMME_ARCH_IDDPM ? 2 * c.in_channels : c.in_channels;
+    bld.conv("output_conv.2", chans[0], P->out_channels, 3, ocw, ocb);
     P->ref_numel = bld.ref_cursor;
 
     // ---- packed layout: the per-block time projections form one [sumCout][emb] matrix ----
@@ -268,9 +294,10 @@ int build_plan(dmme_plan* P) {
     for (auto* seq : {&down, &up, &mid})
         for (auto& n : *seq)
             if (n.kind == 0) {
+                const int width = c.arch == DMME_ARCH_IDDPM ? 2 * n.cout : n.cout;  // (shift | scale) for the scale-shift blocks
                 n.tproj_col = tcols;
-                tcols += n.cout;
-                P->tblocks.push_back({n.tw, n.tb, n.tproj_col, n.cout});
+                tcols += width;
+                P->tblocks.push_back({n.tw, n.tb, n.tproj_col, width});
             }
     P->tproj_cols = tcols;
     int64_t cur = 0;
@@ -380,15 +407,20 @@ int build_plan(dmme_plan* P) {
     auto emit_res = [&](const Node& n, int x1, int x2) {
         const Tensor tx = P->tensors[x1];
         const int h = tx.H, w = tx.W;
+        const bool iddpm = P->cfg.arch == DMME_ARCH_IDDPM;
         const int g1 = emit_gn(x1, x2, n.gn1w, n.gn1b);
         Op c1{};
         c1.kind = OP_CONV;
         c1.src1 = x1; c1.src2 = x2; c1.w = n.c1w; c1.b = n.c1b; c1.gn = g1; c1.pro_silu = 1;
-        c1.tproj_col = n.tproj_col; c1.taps = 9;
+        c1.tproj_col = iddpm ? -1 : n.tproj_col; c1.taps = 9;  // DDPM: h += Linear(t_emb) in the epilogue (models/ddpm.py:129)
         c1.dst = new_tensor(n.cout, h, w);
         ops.push_back(c1);
         const int hmid = c1.dst;
         const int g2 = emit_gn(hmid, -1, n.gn2w, n.gn2b);
+        if (iddpm) {  // h = norm(h) * (scale + 1) + shift (models/iddpm.py:117-118)
+            ops[g2].gn_mod_col = n.tproj_col;
+            ops[g2].gn_mod_C = n.cout;
+        }
         int r1 = x1, r2 = x2;
         if (n.cin != n.cout) {
             Op rc{};
@@ -418,6 +450,7 @@ int build_plan(dmme_plan* P) {
             Op at{};
             at.kind = OP_ATTN;
             at.at_qkv = q.dst;
+            at.at_heads = iddpm ? P->cfg.num_heads : 1;
             at.at_out = new_tensor(n.cout, h, w);
             at.at_lse = ws_alloc((int64_t)B * h * w * 4);
             ops.push_back(at);
@@ -505,7 +538,7 @@ int build_plan(dmme_plan* P) {
             }
             if (o.kind == OP_ATTN) {
                 const Tensor& q = P->tensors[o.at_qkv];
-                const int64_t b = (int64_t)B * q.H * q.W * q.H * q.W * 4;
+                const int64_t b = (int64_t)B * o.at_heads * q.H * q.W * q.H * q.W * 4;
                 if (b > att_max) att_max = b;
             }
         }
@@ -532,7 +565,7 @@ int build_plan(dmme_plan* P) {
             P->bws_gnS = balloc((int64_t)B * c.num_groups * 2 * 4);
         }
         P->bws_tmp = balloc(tmp_max);
-        P->bws_dy = balloc((int64_t)B * P->H * P->W * c.in_channels * es);
+        P->bws_dy = balloc((int64_t)B * P->H * P->W * P->out_channels * es);
         P->bws_rowsum = balloc((int64_t)B * cmax * 3 * 4);  // qkv convs have 3*C outputs
         P->bws_dtproj = balloc((int64_t)B * tcols * 4);
         P->bws_dtemb = balloc((int64_t)B * c.emb_dim * 4);
@@ -803,6 +836,30 @@ void assign_stats(dmme_plan* P) {
     P->ws_bytes = ws;
 }
 
+// GroupNorm statistics folded with the affine into per-(n, c) scale / shift for the consuming conv's prologue
+int run_gn(const dmme_plan* P, const Op& o, const char* pk, char* ws, hipStream_t s) {
+    const Tensor& t1 = P->tensors[o.gn_src1];
+    const void* s1 = ws + t1.off;
+    const void* s2 = o.gn_src2 >= 0 ? ws + P->tensors[o.gn_src2].off : nullptr;
+    const int C2 = o.gn_src2 >= 0 ? P->tensors[o.gn_src2].C : 0;
+    const float* gam = (const float*)(pk + P->params[o.gn_gamma].packed_off);
+    const float* bet = (const float*)(pk + P->params[o.gn_beta].packed_off);
+    float* sc = (float*)(ws + o.gn_scale);
+    float* sh = (float*)(ws + o.gn_shift);
+    if (gn_from_parts(P, o)) {
+        const Tensor* t2 = o.gn_src2 >= 0 ? &P->tensors[o.gn_src2] : nullptr;
+        return launch_gn_finalize_parts((const float*)(ws + t1.stats_off), t1.stats_tiles, t1.stats_cnt, t1.C,
+                                        t2 ? (const float*)(ws + t2->stats_off) : nullptr, t2 ? t2->stats_tiles : 0,
+                                        t2 ? t2->stats_cnt : 0, C2, P->B, P->cfg.num_groups, gam, bet, 1e-5f, sc, sh,
+                                        (float*)(ws + o.gn_mr), s);
+    }
+    if (gn_fast_supported(P->dtype, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups))
+        return launch_gn_fast(P->dtype, s1, s2, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups, gam, bet, 1e-5f, sc, sh,
+                              (float*)(ws + o.gn_mr), (float*)(ws + P->ws_gnpart), s);
+    return launch_gn_generic(P->dtype, s1, s2, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups, gam, bet, 1e-5f, sc, sh,
+                             (float*)(ws + o.gn_mr), s);
+}
+
 int run_op(const dmme_plan* P, const Op& o, const char* pk, const float* x, const int64_t* t, int nt, float* y,
            char* ws, const float* drop_masks, hipStream_t s) {
     switch (o.kind) {
@@ -819,26 +876,11 @@ int run_op(const dmme_plan* P, const Op& o, const char* pk, const float* x, cons
                                       (float*)(ws + o.lin_out), s);
         }
         case OP_GN: {
-            const Tensor& t1 = P->tensors[o.gn_src1];
-            const void* s1 = ws + t1.off;
-            const void* s2 = o.gn_src2 >= 0 ? ws + P->tensors[o.gn_src2].off : nullptr;
-            const int C2 = o.gn_src2 >= 0 ? P->tensors[o.gn_src2].C : 0;
-            const float* gam = (const float*)(pk + P->params[o.gn_gamma].packed_off);
-            const float* bet = (const float*)(pk + P->params[o.gn_beta].packed_off);
-            float* sc = (float*)(ws + o.gn_scale);
-            float* sh = (float*)(ws + o.gn_shift);
-            if (gn_from_parts(P, o)) {
-                const Tensor* t2 = o.gn_src2 >= 0 ? &P->tensors[o.gn_src2] : nullptr;
-                return launch_gn_finalize_parts((const float*)(ws + t1.stats_off), t1.stats_tiles, t1.stats_cnt, t1.C,
-                                                t2 ? (const float*)(ws + t2->stats_off) : nullptr, t2 ? t2->stats_tiles : 0,
-                                                t2 ? t2->stats_cnt : 0, C2, P->B, P->cfg.num_groups, gam, bet, 1e-5f, sc, sh,
-                                                (float*)(ws + o.gn_mr), s);
-            }
-            if (gn_fast_supported(P->dtype, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups))
-                return launch_gn_fast(P->dtype, s1, s2, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups, gam, bet, 1e-5f, sc,
-                                      sh, (float*)(ws + o.gn_mr), (float*)(ws + P->ws_gnpart), s);
-            return launch_gn_generic(P->dtype, s1, s2, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups, gam, bet, 1e-5f,
-                                     sc, sh, (float*)(ws + o.gn_mr), s);
+            const int rc = run_gn(P, o, pk, ws, s);
+            if (rc != DMME_OK || o.gn_mod_col < 0) return rc;
+            const float* tp = (const float*)(ws + P->ws_tproj) + o.gn_mod_col;
+            return launch_gn_modulate((float*)(ws + o.gn_scale), (float*)(ws + o.gn_shift), tp, tp + o.gn_mod_C, P->tproj_cols, nt, P->B,
+                                      o.gn_mod_C, s);
         }
         case OP_CONV: {
             ConvArgs a{};
@@ -848,6 +890,8 @@ int run_op(const dmme_plan* P, const Op& o, const char* pk, const float* x, cons
         case OP_ATTN: {
             const Tensor& q = P->tensors[o.at_qkv];
             const int S = q.H * q.W, C = q.C / 3;
+            if (o.at_heads > 1)
+                return launch_attn_heads(P->dtype, ws + q.off, P->B, S, C, o.at_heads, ws + P->tensors[o.at_out].off, s);
             if (attn_mfma_supported(P->dtype, P->B, S, C))
                 return launch_attn_mfma(P->dtype, ws + q.off, P->B, S, C, ws + P->tensors[o.at_out].off, (float*)(ws + o.at_lse), s);
             return launch_attn_generic(P->dtype, ws + q.off, P->B, S, C, ws + P->tensors[o.at_out].off, s);
@@ -855,7 +899,6 @@ int run_op(const dmme_plan* P, const Op& o, const char* pk, const float* x, cons
     }
     return DMME_OK;
 }
-
 // kernel label + algorithmic flops / bytes of one op (bench.py's roofline accounting)
 void op_account(const dmme_plan* P, const Op& o, char* label, int cap, double* flops, double* bytes) {
     const double es = (double)dtype_size(P->dtype);
@@ -905,7 +948,10 @@ void op_account(const dmme_plan* P, const Op& o, char* label, int cap, double* f
         case OP_ATTN: {
             const Tensor& q = P->tensors[o.at_qkv];
             const double S = q.H * q.W, C = q.C / 3;
-            snprintf(label, cap, attn_mfma_supported(P->dtype, P->B, (int)S, (int)C) ? "attn_mfma_kernel<%s>" : "attn_generic_kernel<%s>", tn);
+            if (o.at_heads > 1)
+                snprintf(label, cap, "attn_heads_kernel<%s>", tn);
+            else
+                snprintf(label, cap, attn_mfma_supported(P->dtype, P->B, (int)S, (int)C) ? "attn_mfma_kernel<%s>" : "attn_generic_kernel<%s>", tn);
             *flops = 4.0 * B * S * S * C;
             *bytes = B * S * 4.0 * C * es;
             break;
@@ -934,6 +980,10 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
                  "plan_create: bad depth/blocks");
     DMME_REQUIRE(cfg->num_attention_depths >= 0 && cfg->num_attention_depths <= 8, DMME_ERR_INVALID, "bad attention_depths");
     DMME_REQUIRE(cfg->pos_dim >= 4 && cfg->pos_dim % 2 == 0, DMME_ERR_INVALID, "pos_dim must be even and >= 4");
+    DMME_REQUIRE(cfg->arch == DMME_ARCH_DDPM || cfg->arch == DMME_ARCH_IDDPM, DMME_ERR_INVALID, "plan_create: unknown arch %d", cfg->arch);
+    if (cfg->arch == DMME_ARCH_IDDPM) {
+        DMME_REQUIRE(cfg->num_heads >= 1, DMME_ERR_INVALID, "plan_create: num_heads must be >= 1");
+    }
     for (int d = 0; d < cfg->num_depths; ++d)
         DMME_REQUIRE(cfg->channels_per_depth[d] > 0 && cfg->channels_per_depth[d] % cfg->num_groups == 0,
                      DMME_ERR_INVALID, "channels_per_depth[%d]=%d not divisible by num_groups=%d", d,
@@ -1064,6 +1114,7 @@ DMME_API int64_t dmme_unet_plan_ref_numel(const dmme_plan* plan) { return plan ?
 DMME_API int64_t dmme_unet_plan_packed_bytes(const dmme_plan* plan) { return plan ? plan->packed_bytes : 0; }
 DMME_API int64_t dmme_unet_plan_workspace_bytes(const dmme_plan* plan) { return plan ? plan->ws_bytes : 0; }
 DMME_API int64_t dmme_unet_plan_dropmask_numel(const dmme_plan* plan) { return plan ? plan->dropmask_numel : 0; }
+DMME_API int dmme_unet_plan_out_channels(const dmme_plan* plan) { return plan ? plan->out_channels : 0; }
 DMME_API int dmme_unet_plan_num_launches(const dmme_plan* plan) { return plan ? plan->n_launches : 0; }
 
 DMME_API int dmme_unet_pack_params(const dmme_plan* plan, const float* ref_flat, void* packed, void* stream) {
@@ -1156,7 +1207,7 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
     float* wimage = (float*)(bws + P->bws_wimage);
     float* dtproj = (float*)(bws + P->bws_dtproj);
     char* tmp = bws + P->bws_tmp;
-    int rc = launch_nchw_to_nhwc(dt, d_y, B, P->cfg.in_channels, P->H * P->W, bws + P->bws_dy, s);
+    int rc = launch_nchw_to_nhwc(dt, d_y, B, P->out_channels, P->H * P->W, bws + P->bws_dy, s);
     if (rc != DMME_OK) return rc;
 
     for (int oi = (int)P->ops.size() - 1; oi >= 0 && rc == DMME_OK; --oi) {

@@ -23,8 +23,9 @@ class _Scope(nn.Module):
     """Parameter container used to reproduce the reference's dotted state_dict keys."""
 
 
-def _cfg_struct(in_channels, pos_dim, emb_dim, num_groups, dropout, channels_per_depth, num_blocks, attention_depths):
+def _cfg_struct(in_channels, pos_dim, emb_dim, num_groups, dropout, channels_per_depth, num_blocks, attention_depths, arch=0, num_heads=1):
     cfg = _lib.UNetCfg()
+    cfg.arch, cfg.num_heads = int(arch), int(num_heads)
     cfg.in_channels, cfg.pos_dim, cfg.emb_dim, cfg.num_groups = in_channels, pos_dim, emb_dim, num_groups
     cfg.dropout = float(dropout)
     if not 1 <= len(channels_per_depth) <= 8 or len(attention_depths) > 8:
@@ -89,13 +90,16 @@ class UNet(nn.Module):
         num_blocks: int = 2,
         attention_depths: Sequence[int] = (2,),
         precision: str = "fp32",
+        _arch: int = 0,
+        _num_heads: int = 1,
     ):
         super().__init__()
         self.in_channels = in_channels
+        self.out_channels = 2 * in_channels if _arch == 1 else in_channels
         self.dropout = float(dropout)
         self.precision = precision
         self._dtype = _lib.dtype_code(precision)
-        self._cfg = _cfg_struct(in_channels, pos_dim, emb_dim, num_groups, dropout, tuple(channels_per_depth), num_blocks, tuple(attention_depths))
+        self._cfg = _cfg_struct(in_channels, pos_dim, emb_dim, num_groups, dropout, tuple(channels_per_depth), num_blocks, tuple(attention_depths), _arch, _num_heads)
         self._plans: Dict[Tuple, _Plan] = {}
         self._injected_masks: Optional[Tensor] = None
         self._mask_calls = 0
@@ -315,7 +319,7 @@ class UNet(nn.Module):
         packed = self._packed_for(plan)
         xin = x.detach().to(torch.float32).contiguous()
         t = c.detach().reshape(-1).to(device=x.device, dtype=torch.int64).contiguous()
-        y = torch.empty_like(xin)
+        y = torch.empty((B, self.out_channels, H, W), dtype=torch.float32, device=x.device)
         masks = None
         if self.training and self.dropout > 0:
             if self._injected_masks is not None:

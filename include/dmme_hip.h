@@ -52,7 +52,14 @@ typedef enum {
 
 typedef enum { DMME_F32 = 0, DMME_BF16 = 1 } dmme_dtype;
 
-/* Constructor arguments of the reference UNet (src/dmme/models/ddpm.py:190-200). */
+/* Which of the reference's two UNets the plan builds. */
+typedef enum {
+    DMME_ARCH_DDPM = 0,  /* dmme.models.ddpm.UNet (src/dmme/models/ddpm.py:176-316): eps only */
+    DMME_ARCH_IDDPM = 1  /* dmme.models.iddpm.UNet (src/dmme/models/iddpm.py:125-265): scale-shift ResBlocks,
+                            multi-head attention, 2*in_channels outputs (eps, v) */
+} dmme_unet_arch;
+
+/* Constructor arguments of the reference UNet (src/dmme/models/ddpm.py:190-200, models/iddpm.py:139-149). */
 typedef struct {
     int in_channels;
     int pos_dim;
@@ -64,6 +71,9 @@ typedef struct {
     int num_blocks;
     int num_attention_depths;
     int attention_depths[8];
+    int arch;      /* dmme_unet_arch */
+    int num_heads; /* DMME_ARCH_IDDPM: heads of MultiHeadAttention (the reference hard-codes 4, models/iddpm.py:82);
+                      ignored (1) for DMME_ARCH_DDPM */
 } dmme_unet_cfg;
 
 typedef struct dmme_plan dmme_plan;
@@ -92,6 +102,8 @@ DMME_API int64_t dmme_unet_plan_workspace_bytes(const dmme_plan* plan);
 /* floats in a full set of Dropout2d multipliers: sum over ResBlocks of B*Cout, laid out
  * block after block (graph order: down, middle, up), each [B][Cout]. */
 DMME_API int64_t dmme_unet_plan_dropmask_numel(const dmme_plan* plan);
+/* channels of the network output: in_channels (DDPM) or 2*in_channels (IDDPM: eps and v stacked) */
+DMME_API int dmme_unet_plan_out_channels(const dmme_plan* plan);
 /* number of kernel launches one forward issues (for launch-overhead accounting) */
 DMME_API int dmme_unet_plan_num_launches(const dmme_plan* plan);
 
@@ -100,7 +112,8 @@ DMME_API int dmme_unet_plan_num_launches(const dmme_plan* plan);
 DMME_API int dmme_unet_pack_params(const dmme_plan* plan, const float* ref_flat, void* packed, void* stream);
 
 /* ---- UNet forward: replaces UNet.forward (models/ddpm.py:281-316) -------------------
- * y = eps_theta(x, t).  x, y: (B, C, H, W) fp32 NCHW.  t: int64[t_len], t_len in {1, B}.
+ * y = eps_theta(x, t).  x: (B, C, H, W), y: (B, dmme_unet_plan_out_channels(), H, W), fp32 NCHW.
+ * t: int64[t_len], t_len in {1, B}.  DMME_ARCH_IDDPM: iddpm.UNet.forward (models/iddpm.py:232-265).
  * drop_masks: NULL for eval(); else the Dropout2d multipliers (0 or 1/(1-p)) laid out
  * as dmme_unet_plan_dropmask_numel() describes (nn.Dropout2d, models/ddpm.py:29). */
 DMME_API int dmme_unet_forward(const dmme_plan* plan, const void* packed, const float* x, const int64_t* t, int t_len,

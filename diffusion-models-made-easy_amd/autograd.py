@@ -54,3 +54,32 @@ class _MSEFunction(torch.autograd.Function):
 def mse_loss_apply(eps: Tensor, target: Tensor) -> Tensor:
     """simple_loss (reference: equations/ddpm/losses.py:5-13): mean((target - eps)^2) over all elements."""
     return _MSEFunction.apply(eps, target)
+
+
+class _IDDPMLossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model_out: Tensor, x_t: Tensor, x_0: Tensor, target: Tensor, t: Tensor, coef: Tensor, w_simple: float, w_vlb: float):
+        o = model_out.detach().to(torch.float32).contiguous()
+        B = o.size(0)
+        loss = torch.empty(3, dtype=torch.float32, device=o.device)
+        scratch = torch.empty(1024, dtype=torch.float32, device=o.device)
+        d_out = torch.empty_like(o) if model_out.requires_grad else None
+        _lib.check(
+            _lib.lib().dmme_iddpm_loss(_lib.ptr(o), _lib.ptr(x_t), _lib.ptr(x_0), _lib.ptr(target), _lib.ptr(t), _lib.ptr(coef), B, x_t[0].numel(),
+                                       w_simple, w_vlb, _lib.ptr(loss), _lib.ptr(d_out), 1.0, _lib.ptr(scratch), _lib.stream_ptr()),
+            "dmme_iddpm_loss",
+        )
+        ctx.d_out = d_out
+        ctx.parts = loss
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        d = ctx.d_out
+        ctx.d_out = None
+        return (d * grad_out if d is not None else None), None, None, None, None, None, None, None
+
+
+def iddpm_loss_apply(model_out: Tensor, x_t: Tensor, x_0: Tensor, target: Tensor, t: Tensor, coef: Tensor, w_simple: float, w_vlb: float) -> Tensor:
+    """w_simple * L_simple + w_vlb * L_vlb (reference: diffusion_models/iddpm.py:92-116, equations/iddpm/losses.py:40-98)."""
+    return _IDDPMLossFunction.apply(model_out, x_t, x_0, target, t, coef.to(device=model_out.device, dtype=torch.float32).contiguous(), w_simple, w_vlb)

@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(256) gn_bwd_sums_kernel(const T* __restrict__ 
 //           remaining blocks: 32 channels each, dgamma_c += sum_n B, dbeta_c += sum_n A (8-way split over n + LDS)
 __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __restrict__ AB, int N, int C, int groups, int nb_s,
                                                               const float* __restrict__ gamma, float* __restrict__ S,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, GnMod mod) {
     const int cg = C / groups;
     if ((int)blockIdx.x < nb_s) {
         const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -247,8 +247,9 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __res
         float s1 = 0.f, s2 = 0.f;
         for (int j = 0; j < cg; ++j) {
             const int c = g * cg + j;
-            s1 = fmaf(gamma[c], AB[((int64_t)n * C + c) * 2], s1);
-            s2 = fmaf(gamma[c], AB[((int64_t)n * C + c) * 2 + 1], s2);
+            const float gm = gamma[c] * mod.mul(n, c);
+            s1 = fmaf(gm, AB[((int64_t)n * C + c) * 2], s1);
+            s2 = fmaf(gm, AB[((int64_t)n * C + c) * 2 + 1], s2);
         }
         S[(int64_t)i * 2] = s1;
         S[(int64_t)i * 2 + 1] = s2;
@@ -260,8 +261,10 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __res
     float a = 0.f, b = 0.f;
     if (c < C)
         for (int n = seg; n < N; n += 8) {
-            a += AB[((int64_t)n * C + c) * 2];
-            b += AB[((int64_t)n * C + c) * 2 + 1];
+            const float an = AB[((int64_t)n * C + c) * 2], bn = AB[((int64_t)n * C + c) * 2 + 1], m = mod.mul(n, c);
+            a = fmaf(an, m, a);
+            b = fmaf(bn, m, b);
+            mod.emit(n, c, an, bn, gamma[c]);
         }
     ra[seg][cl] = a;
     rb[seg][cl] = b;
@@ -285,7 +288,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ mean_rstd, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ dmask, int pro_silu,
                                                            const float* __restrict__ S, int chunk_px, int ppw, T* __restrict__ dx1, T* __restrict__ dx2,
-                                                           int acc1, int acc2) {
+                                                           int acc1, int acc2, GnMod mod) {
     constexpr int EPV = 16 / sizeof(T);
     const int C = C1 + C2, tid = threadIdx.x, VPP = C / EPV, slot = tid % VPP, prow = tid / VPP;
     if (prow >= ppw) return;
@@ -306,7 +309,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
         dm[j] = dmask ? dmask[(int64_t)n * C + c] : 1.0f;
         mu[j] = mean_rstd[((int64_t)n * groups + g) * 2];
         rs[j] = mean_rstd[((int64_t)n * groups + g) * 2 + 1];
-        gm[j] = gamma[c];
+        gm[j] = gamma[c] * mod.mul(n, c);
         k1[j] = S[((int64_t)n * groups + g) * 2] * inv;
         k2[j] = S[((int64_t)n * groups + g) * 2 + 1] * inv;
     }
@@ -485,9 +488,9 @@ bool gn_bwd_fast_supported(int dtype, int HW, int C1, int C2) {
 // AB: N*C*2 floats, zero on entry;  S: N*groups*2 floats of scratch
 int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2, int N, int HW, int C1, int C2, int groups,
                        const float* gamma, const float* mean_rstd, const float* scale, const float* shift, const float* dmask,
-                       int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, float* AB, float* S,
+                       int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, float* AB, float* S, GnMod mod,
                        hipStream_t s) {
-    if (gn_bwd_small_supported(dtype, HW, C1, C2, groups)) {
+    if (!mod.t_scale && gn_bwd_small_supported(dtype, HW, C1, C2, groups)) {
         if (dtype == DMME_BF16)
             hipLaunchKernelGGL(gn_bwd_small_kernel<bf16>, dim3(N), dim3(256), 0, s, (const bf16*)dv, (const bf16*)x1, (const bf16*)x2, HW, C1, C2, groups,
                                gamma, mean_rstd, scale, shift, dmask, pro_silu, (bf16*)dx1, (bf16*)dx2, acc1, acc2, dgamma, dbeta);
@@ -509,14 +512,14 @@ int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2
                            groups, mean_rstd, scale, shift, dmask, pro_silu, chunk_px, ppw, AB);
     DMME_CHECK_LAUNCH();
     const int nb_s = (N * groups + 255) / 256;
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(nb_s + (C + 31) / 32), dim3(256), 0, s, AB, N, C, groups, nb_s, gamma, S, dgamma, dbeta);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(nb_s + (C + 31) / 32), dim3(256), 0, s, AB, N, C, groups, nb_s, gamma, S, dgamma, dbeta, mod);
     DMME_CHECK_LAUNCH();
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dv, (const bf16*)x1, (const bf16*)x2, HW, C1, C2, groups,
-                           gamma, mean_rstd, scale, shift, dmask, pro_silu, S, chunk_px, ppw, (bf16*)dx1, (bf16*)dx2, acc1, acc2);
+                           gamma, mean_rstd, scale, shift, dmask, pro_silu, S, chunk_px, ppw, (bf16*)dx1, (bf16*)dx2, acc1, acc2, mod);
     else
         hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)dv, (const float*)x1, (const float*)x2, HW, C1, C2,
-                           groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, S, chunk_px, ppw, (float*)dx1, (float*)dx2, acc1, acc2);
+                           groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, S, chunk_px, ppw, (float*)dx1, (float*)dx2, acc1, acc2, mod);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }

@@ -204,6 +204,10 @@ int launch_q_sample(const float* x0, const float* z, const float* sqrt_abar, con
 int launch_ddpm_step(float* x, const float* eps, const float* z, float c1, float c2, float sigma, int add_noise,
                      int64_t numel, hipStream_t s);
 int launch_ddim_step(float* x, const float* eps, float s1, float s2, int64_t numel, hipStream_t s);
+int launch_iddpm_step(float* x, const float* out, const float* z, float c1, float c2, float log_beta, float log_beta_tilde, int add_noise,
+                      int B, int64_t chw, hipStream_t s);
+int launch_iddpm_loss(const float* out, const float* x_t, const float* x_0, const float* target, const int64_t* t, const float* coef, int B,
+                      int64_t chw, float w_simple, float w_vlb, float* loss, float* d_out, float gscale, float* scratch, hipStream_t s);
 int launch_mse(const float* eps, const float* target, int64_t numel, float* loss, float* d_eps, float gscale,
                float* scratch, hipStream_t s);
 
@@ -248,9 +252,34 @@ int launch_wgrad_group(int dtype, int taps, const WgLayer* layers_dev, const WgJ
 int launch_wgrad_unpack(const PackItem* items_dev, int n_items, const float* image, float* grad_flat, hipStream_t s);
 int launch_colsum(int dtype, const void* dY, int N, int HW, int C, float* rowsum, float* dbias, float* dtproj, int ld, int nt,
                   hipStream_t s);
+// Scale-shift conditioning of a GroupNorm in the backward pass (iddpm.ResBlock, models/iddpm.py:117-118):
+// y = GN(x) * (1 + t_scale[r][c]) + t_shift[r][c], r = n (nt == N) or 0 (nt == 1).  The GroupNorm backward then runs with the
+// effective gamma_c * (1 + t_scale) and also emits d t_shift = A, d t_scale = gamma_c B + beta_c A (A = sum du, B = sum du xhat).
+// t_scale == nullptr: plain GroupNorm.  d_* rows are assigned when nt == N and atomically accumulated (zeroed buffer) when nt == 1.
+struct GnMod {
+    const float* t_scale = nullptr;
+    const float* beta = nullptr;
+    float* d_shift = nullptr;
+    float* d_scale = nullptr;
+    int ld = 0, nt = 0;
+#if defined(__HIPCC__)
+    __device__ __forceinline__ float mul(int n, int c) const { return t_scale ? 1.0f + t_scale[(int64_t)(nt == 1 ? 0 : n) * ld + c] : 1.0f; }
+    __device__ __forceinline__ void emit(int n, int c, float A, float B, float gamma_c) const {
+        if (!t_scale) return;
+        const float ds = fmaf(gamma_c, B, beta[c] * A);
+        if (nt == 1) {
+            atomicAdd(&d_shift[c], A);
+            atomicAdd(&d_scale[c], ds);
+        } else {
+            d_shift[(int64_t)n * ld + c] = A;
+            d_scale[(int64_t)n * ld + c] = ds;
+        }
+    }
+#endif
+};
 int launch_gn_bwd_generic(int dtype, const void* dv, const void* x1, const void* x2, int N, int HW, int C1, int C2, int groups,
                           const float* gamma, const float* mean_rstd, const float* scale, const float* shift, const float* dmask,
-                          int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, hipStream_t s);
+                          int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, GnMod mod, hipStream_t s);
 // coalesced vector versions (bwd_fast.hip)
 bool colsum_fast_supported(int dtype, int HW, int C);
 // rowsum must be zero on entry (the backward pass clears all its accumulation scratch with one memset)
@@ -268,7 +297,7 @@ bool gn_bwd_fast_supported(int dtype, int HW, int C1, int C2);
 int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2, int N, int HW, int C1, int C2, int groups,
                        const float* gamma, const float* mean_rstd, const float* scale, const float* shift, const float* dmask,
                        int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, float* AB_zeroed,
-                       float* S_scratch, hipStream_t s);
+                       float* S_scratch, GnMod mod, hipStream_t s);
 bool grad_acc_fast_supported(int dtype, int C1, int C2, int pool);
 int launch_grad_acc_fast(int dtype, const void* src, void* d1, void* d2, int C1, int C2, int acc1, int acc2, int64_t npix, hipStream_t s);
 int launch_grad_acc(int dtype, const void* src, void* d1, void* d2, int C1, int C2, int acc1, int acc2, int pool, int N, int H, int W,

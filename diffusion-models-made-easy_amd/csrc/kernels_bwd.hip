@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(256) gn_bwd_generic_kernel(const T* __restrict
                                                              const float* __restrict__ mean_rstd, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, const float* __restrict__ dmask, int pro_silu,
                                                              T* __restrict__ dx1, T* __restrict__ dx2, int acc1, int acc2,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, GnMod mod) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int n = blockIdx.y, g = blockIdx.x;
     const int C = C1 + C2, cg = C / groups;
@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(256) gn_bwd_generic_kernel(const T* __restrict
         int c;
         int64_t p;
         elem(e, du, xhat, c, p);
-        const float gm = gamma[c];
+        const float gm = gamma[c] * mod.mul(n, c);
         s1 = fmaf(du, gm, s1);
         s2 = fmaf(du * gm, xhat, s2);
         atomicAdd(&dg_l[c - g * cg], du * xhat);
@@ -458,7 +458,7 @@ __global__ void __launch_bounds__(256) gn_bwd_generic_kernel(const T* __restrict
         int c;
         int64_t p;
         elem(e, du, xhat, c, p);
-        const float dx = rstd * (du * gamma[c] - (S1 + xhat * S2) * inv);
+        const float dx = rstd * (du * gamma[c] * mod.mul(n, c) - (S1 + xhat * S2) * inv);
         if (c < C1) {
             T* d = dx1 + p * C1 + c;
             *d = from_f<T>(acc1 ? to_f(*d) + dx : dx);
@@ -469,23 +469,26 @@ __global__ void __launch_bounds__(256) gn_bwd_generic_kernel(const T* __restrict
     }
     __syncthreads();
     for (int j = threadIdx.x; j < cg; j += blockDim.x) {
-        atomicAdd(&dgamma[g * cg + j], dg_l[j]);
-        atomicAdd(&dbeta[g * cg + j], db_l[j]);
+        const int c = g * cg + j;
+        const float m = mod.mul(n, c);
+        atomicAdd(&dgamma[c], dg_l[j] * m);
+        atomicAdd(&dbeta[c], db_l[j] * m);
+        mod.emit(n, c, db_l[j], dg_l[j], gamma[c]);
     }
 }
 
 int launch_gn_bwd_generic(int dtype, const void* dv, const void* x1, const void* x2, int N, int HW, int C1, int C2, int groups,
                           const float* gamma, const float* mean_rstd, const float* scale, const float* shift, const float* dmask,
-                          int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, hipStream_t s) {
+                          int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, GnMod mod, hipStream_t s) {
     const int cg = (C1 + C2) / groups;
     const size_t lds = (size_t)(2 * cg + 16) * sizeof(float);
     dim3 grid(groups, N);
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(gn_bwd_generic_kernel<bf16>, grid, dim3(256), lds, s, (const bf16*)dv, (const bf16*)x1, (const bf16*)x2, HW, C1, C2,
-                           groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, (bf16*)dx1, (bf16*)dx2, acc1, acc2, dgamma, dbeta);
+                           groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, (bf16*)dx1, (bf16*)dx2, acc1, acc2, dgamma, dbeta, mod);
     else
         hipLaunchKernelGGL(gn_bwd_generic_kernel<float>, grid, dim3(256), lds, s, (const float*)dv, (const float*)x1, (const float*)x2, HW, C1,
-                           C2, groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, (float*)dx1, (float*)dx2, acc1, acc2, dgamma, dbeta);
+                           C2, groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, (float*)dx1, (float*)dx2, acc1, acc2, dgamma, dbeta, mod);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }
@@ -537,31 +540,36 @@ int launch_grad_acc(int dtype, const void* src, void* d1, void* d2, int C1, int 
 
 // ------------------------------------------------------------------ attention backward (generic)
 // pass A (one workgroup per query row): recompute p_i, dP_i = dO_i V^T, dS_i = p_i (dP_i - <p_i, dP_i>),
-//   keep P and dS (fp32, [N][S][S]) and write dQ_i = scale * dS_i K.
+//   keep P and dS (fp32, [N*heads][S][S]) and write dQ_i = scale * dS_i K.
 // pass B (one workgroup per key row): dK_j = scale * dS[:, j]^T Q,  dV_j = P[:, j]^T dO.
+// Head view as in attn_generic_kernel: (image n, head hd) reads qkv channels [hd*3d, (hd+1)*3d); its output row bh = n*heads + hd
+// was stored at image bh % N, head bh / N, so that is where its dO comes from (models/iddpm.py:38-46).
 template <typename T>
-__global__ void __launch_bounds__(256) attn_bwd_rows_kernel(const T* __restrict__ qkv, const T* __restrict__ dO, int S, int C,
+__global__ void __launch_bounds__(256) attn_bwd_rows_kernel(const T* __restrict__ qkv, const T* __restrict__ dO, int S, int C, int heads, int N,
                                                             float* __restrict__ P, float* __restrict__ dS, T* __restrict__ dqkv) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* qs = sm;            // C
-    float* dos = sm + C;       // C
-    float* ps = sm + 2 * C;    // S
+    const int d = C / heads;
+    float* qs = sm;            // d
+    float* dos = sm + d;       // d
+    float* ps = sm + 2 * d;    // S
     float* ds = ps + S;        // S
     float* red = ds + S;       // 16
-    const int n = blockIdx.y, i = blockIdx.x;
-    const T* base = qkv + (int64_t)n * S * 3 * C;
+    const int bh = blockIdx.y, n = bh / heads, hd = bh % heads, i = blockIdx.x;
+    const int64_t hoff = (int64_t)n * S * 3 * C + (int64_t)hd * 3 * d;
+    const T* base = qkv + hoff;
+    const T* dob = dO + (int64_t)(bh % N) * S * C + (int64_t)(bh / N) * d;
     const float kscale = powf((float)C, -0.5f);
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
         qs[c] = to_f(base[(int64_t)i * 3 * C + c]);
-        dos[c] = to_f(dO[((int64_t)n * S + i) * C + c]);
+        dos[c] = to_f(dob[(int64_t)i * C + c]);
     }
     __syncthreads();
     float lmax = -INFINITY;
     for (int j = threadIdx.x; j < S; j += blockDim.x) {
-        const T* kr = base + (int64_t)j * 3 * C + C;
-        const T* vr = base + (int64_t)j * 3 * C + 2 * C;
+        const T* kr = base + (int64_t)j * 3 * C + d;
+        const T* vr = base + (int64_t)j * 3 * C + 2 * d;
         float sacc = 0.f, dacc = 0.f;
-        for (int c = 0; c < C; ++c) {
+        for (int c = 0; c < d; ++c) {
             sacc = fmaf(qs[c], to_f(kr[c]) * kscale, sacc);
             dacc = fmaf(dos[c], to_f(vr[c]), dacc);
         }
@@ -584,8 +592,8 @@ __global__ void __launch_bounds__(256) attn_bwd_rows_kernel(const T* __restrict_
         ldel = fmaf(p, ds[j], ldel);
     }
     const float delta = block_sum(ldel, red);
-    float* Prow = P + ((int64_t)n * S + i) * S;
-    float* dSrow = dS + ((int64_t)n * S + i) * S;
+    float* Prow = P + ((int64_t)bh * S + i) * S;
+    float* dSrow = dS + ((int64_t)bh * S + i) * S;
     for (int j = threadIdx.x; j < S; j += blockDim.x) {
         const float v = ps[j] * (ds[j] - delta);
         ds[j] = v;
@@ -593,51 +601,59 @@ __global__ void __launch_bounds__(256) attn_bwd_rows_kernel(const T* __restrict_
         dSrow[j] = v;
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
         float acc = 0.f;
-        for (int j = 0; j < S; ++j) acc = fmaf(ds[j], to_f(base[(int64_t)j * 3 * C + C + c]), acc);
-        dqkv[((int64_t)n * S + i) * 3 * C + c] = from_f<T>(acc * kscale);
+        for (int j = 0; j < S; ++j) acc = fmaf(ds[j], to_f(base[(int64_t)j * 3 * C + d + c]), acc);
+        dqkv[hoff + (int64_t)i * 3 * C + c] = from_f<T>(acc * kscale);
     }
 }
 template <typename T>
-__global__ void __launch_bounds__(256) attn_bwd_cols_kernel(const T* __restrict__ qkv, const T* __restrict__ dO, int S, int C,
+__global__ void __launch_bounds__(256) attn_bwd_cols_kernel(const T* __restrict__ qkv, const T* __restrict__ dO, int S, int C, int heads, int N,
                                                             const float* __restrict__ P, const float* __restrict__ dS, T* __restrict__ dqkv) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int d = C / heads;
     float* pc = sm;       // S : P[:, j]
     float* dc = sm + S;   // S : dS[:, j]
-    const int n = blockIdx.y, j = blockIdx.x;
-    const T* base = qkv + (int64_t)n * S * 3 * C;
+    const int bh = blockIdx.y, n = bh / heads, hd = bh % heads, j = blockIdx.x;
+    const int64_t hoff = (int64_t)n * S * 3 * C + (int64_t)hd * 3 * d;
+    const T* base = qkv + hoff;
+    const T* dob = dO + (int64_t)(bh % N) * S * C + (int64_t)(bh / N) * d;
     const float kscale = powf((float)C, -0.5f);
     for (int i = threadIdx.x; i < S; i += blockDim.x) {
-        pc[i] = P[((int64_t)n * S + i) * S + j];
-        dc[i] = dS[((int64_t)n * S + i) * S + j];
+        pc[i] = P[((int64_t)bh * S + i) * S + j];
+        dc[i] = dS[((int64_t)bh * S + i) * S + j];
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
         float dk = 0.f, dvv = 0.f;
         for (int i = 0; i < S; ++i) {
             dk = fmaf(dc[i], to_f(base[(int64_t)i * 3 * C + c]), dk);
-            dvv = fmaf(pc[i], to_f(dO[((int64_t)n * S + i) * C + c]), dvv);
+            dvv = fmaf(pc[i], to_f(dob[(int64_t)i * C + c]), dvv);
         }
-        dqkv[((int64_t)n * S + j) * 3 * C + C + c] = from_f<T>(dk * kscale);
-        dqkv[((int64_t)n * S + j) * 3 * C + 2 * C + c] = from_f<T>(dvv);
+        dqkv[hoff + (int64_t)j * 3 * C + d + c] = from_f<T>(dk * kscale);
+        dqkv[hoff + (int64_t)j * 3 * C + 2 * d + c] = from_f<T>(dvv);
     }
 }
-int launch_attn_bwd_generic(int dtype, const void* qkv, const void* dO, int N, int S, int C, float* P, float* dS, void* dqkv, hipStream_t s) {
-    const size_t ldsA = (size_t)(2 * C + 2 * S + 16) * sizeof(float), ldsB = (size_t)(2 * S) * sizeof(float);
-    DMME_REQUIRE(ldsA <= 64 * 1024, DMME_ERR_UNSUPPORTED, "attention backward: C+S too large (%d+%d)", C, S);
-    dim3 grid(S, N);
+int launch_attn_heads_bwd(int dtype, const void* qkv, const void* dO, int N, int S, int C, int heads, float* P, float* dS, void* dqkv, hipStream_t s) {
+    DMME_REQUIRE(heads >= 1 && C % heads == 0, DMME_ERR_INVALID, "attention backward: width %d not divisible by %d heads", C, heads);
+    const int d = C / heads;
+    const size_t ldsA = (size_t)(2 * d + 2 * S + 16) * sizeof(float), ldsB = (size_t)(2 * S) * sizeof(float);
+    DMME_REQUIRE(ldsA <= 64 * 1024, DMME_ERR_UNSUPPORTED, "attention backward: d+S too large (%d+%d)", d, S);
+    dim3 grid(S, N * heads);
     if (dtype == DMME_BF16) {
-        hipLaunchKernelGGL(attn_bwd_rows_kernel<bf16>, grid, dim3(256), ldsA, s, (const bf16*)qkv, (const bf16*)dO, S, C, P, dS, (bf16*)dqkv);
+        hipLaunchKernelGGL(attn_bwd_rows_kernel<bf16>, grid, dim3(256), ldsA, s, (const bf16*)qkv, (const bf16*)dO, S, C, heads, N, P, dS, (bf16*)dqkv);
         DMME_CHECK_LAUNCH();
-        hipLaunchKernelGGL(attn_bwd_cols_kernel<bf16>, grid, dim3(256), ldsB, s, (const bf16*)qkv, (const bf16*)dO, S, C, P, dS, (bf16*)dqkv);
+        hipLaunchKernelGGL(attn_bwd_cols_kernel<bf16>, grid, dim3(256), ldsB, s, (const bf16*)qkv, (const bf16*)dO, S, C, heads, N, P, dS, (bf16*)dqkv);
     } else {
-        hipLaunchKernelGGL(attn_bwd_rows_kernel<float>, grid, dim3(256), ldsA, s, (const float*)qkv, (const float*)dO, S, C, P, dS, (float*)dqkv);
+        hipLaunchKernelGGL(attn_bwd_rows_kernel<float>, grid, dim3(256), ldsA, s, (const float*)qkv, (const float*)dO, S, C, heads, N, P, dS, (float*)dqkv);
         DMME_CHECK_LAUNCH();
-        hipLaunchKernelGGL(attn_bwd_cols_kernel<float>, grid, dim3(256), ldsB, s, (const float*)qkv, (const float*)dO, S, C, P, dS, (float*)dqkv);
+        hipLaunchKernelGGL(attn_bwd_cols_kernel<float>, grid, dim3(256), ldsB, s, (const float*)qkv, (const float*)dO, S, C, heads, N, P, dS, (float*)dqkv);
     }
     DMME_CHECK_LAUNCH();
     return DMME_OK;
+}
+int launch_attn_bwd_generic(int dtype, const void* qkv, const void* dO, int N, int S, int C, float* P, float* dS, void* dqkv, hipStream_t s) {
+    return launch_attn_heads_bwd(dtype, qkv, dO, N, S, C, 1, P, dS, dqkv, s);
 }
 
 // ------------------------------------------------------------------ small linears (time MLP) backward

@@ -205,4 +205,120 @@ int launch_mse(const float* eps, const float* target, int64_t numel, float* loss
     return DMME_OK;
 }
 
+// ------------------------------------------------------------------ Improved DDPM (learned variance)
+// network output (B, 2C, H, W): channels [0, C) = eps, [C, 2C) = v (diffusion_models/iddpm.py:159).
+// Sigma = exp(v log beta_t + (1 - v) log max(beta~_t, 1e-12)) (equations/iddpm/losses.py:34-37).
+__device__ __forceinline__ float iddpm_std(float v, float log_beta, float log_beta_tilde) {
+    return sqrtf(expf(__fadd_rn(__fmul_rn(v, log_beta), __fmul_rn(__fsub_rn(1.0f, v), log_beta_tilde))));
+}
+__global__ void __launch_bounds__(256) iddpm_step_kernel(float* __restrict__ x, const float* __restrict__ out, const float* __restrict__ z,
+                                                         float c1, float c2, float log_beta, float log_beta_tilde, int add_noise,
+                                                         int64_t chw, int64_t total) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / chw, r = i - b * chw;
+        const float e = out[b * 2 * chw + r];
+        const float m = __fmul_rn(c1, __fsub_rn(x[i], __fmul_rn(c2, e)));
+        if (add_noise) {
+            const float sd = iddpm_std(out[b * 2 * chw + chw + r], log_beta, log_beta_tilde);
+            x[i] = __fadd_rn(m, __fmul_rn(sd, z[i]));
+        } else {
+            x[i] = m;
+        }
+    }
+}
+int launch_iddpm_step(float* x, const float* out, const float* z, float c1, float c2, float log_beta, float log_beta_tilde,
+                      int add_noise, int B, int64_t chw, hipStream_t s) {
+    const int64_t total = (int64_t)B * chw;
+    if (total <= 0) return DMME_OK;
+    hipLaunchKernelGGL(iddpm_step_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, out, z, c1, c2, log_beta, log_beta_tilde, add_noise, chw,
+                       total);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+// Hybrid / VLB loss and its gradient w.r.t. the raw network output, one pass (diffusion_models/iddpm.py:62-116,
+// equations/iddpm/losses.py:9-98).  coef: per-timestep fp32 table, 8 floats per t:
+//   [0] 1/sqrt(alpha_t)  [1] beta_t/sqrt(1-abar_t)  [2] log beta_t  [3] log max(beta~_t, 1e-12)
+//   [4] sqrt(abar_{t-1}) beta_t/(1-abar_t)  [5] sqrt(alpha_t)(1-abar_{t-1})/(1-abar_t)  [6] sqrt(beta~_t)  [7] unused
+// L_vlb uses the predicted noise with a stop-gradient, so d/d(eps) comes from L_simple only and d/d(v) from L_vlb only.
+__global__ void __launch_bounds__(256) iddpm_loss_kernel(const float* __restrict__ out, const float* __restrict__ x_t, const float* __restrict__ x_0,
+                                                         const float* __restrict__ target, const int64_t* __restrict__ t,
+                                                         const float* __restrict__ coef, int64_t chw, int64_t total, float w_simple, float w_vlb,
+                                                         float gscale, float* __restrict__ d_out, float* __restrict__ partial) {
+    __shared__ float red[16];
+    float acc_s = 0.f, acc_v = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / chw, r = i - b * chw;
+        const int64_t tt = t[b];
+        const float* c = coef + tt * 8;
+        const float e = out[b * 2 * chw + r], v = out[b * 2 * chw + chw + r];
+        const float xt = x_t[i], x0 = x_0[i];
+        const float d = target[i] - e;
+        acc_s += d * d;
+        const float mean = c[0] * (xt - c[1] * e);
+        const float sd = iddpm_std(v, c[2], c[3]);
+        const float hl = 0.5f * (c[2] - c[3]);  // d(sd)/dv = sd * hl
+        float vlb, dv;
+        if (tt == 1) {  // discrete NLL of x_0 in bins of +-1/255 (losses.py:9-20)
+            const float ap = (x0 + 1.0f / 255.0f - mean) / sd, am = (x0 - 1.0f / 255.0f - mean) / sd;
+            const bool up = x0 < 1.0f, lo = x0 > -1.0f;
+            const float Fp = up ? 0.5f * (1.0f + erff(ap * 0.70710678118654752f)) : 1.0f;
+            const float Fm = lo ? 0.5f * (1.0f + erff(am * 0.70710678118654752f)) : 0.0f;
+            const float prob = Fp - Fm;
+            vlb = -logf(fmaxf(prob, 1e-12f));
+            const float pp = up ? 0.3989422804014327f * expf(-0.5f * ap * ap) * ap : 0.f;
+            const float pm = lo ? 0.3989422804014327f * expf(-0.5f * am * am) * am : 0.f;
+            dv = prob >= 1e-12f ? hl * (pp - pm) / prob : 0.f;  // -(1/prob) d(prob)/d(sd) * sd * hl, d Phi(a)/d sd = -phi(a) a / sd
+        } else {  // KL(q(x_{t-1} | x_t, x_0) || p_theta) (losses.py:23-31, torch kl_normal_normal)
+            const float qm = c[4] * x0 + c[5] * xt;
+            const float q = c[6] / sd, ratio = q * q;
+            const float u = (qm - mean) / sd, t1 = u * u;
+            vlb = 0.5f * (ratio + t1 - 1.0f - logf(ratio));
+            dv = hl * (1.0f - ratio - t1);
+        }
+        acc_v += vlb;
+        if (d_out) {
+            d_out[b * 2 * chw + r] = (-2.0f * d) * (w_simple * gscale);
+            d_out[b * 2 * chw + chw + r] = dv * (w_vlb * gscale);
+        }
+    }
+    const float ts = block_sum(acc_s, red);
+    __syncthreads();
+    const float tv = block_sum(acc_v, red);
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = ts;
+        partial[2 * blockIdx.x + 1] = tv;
+    }
+}
+__global__ void __launch_bounds__(256) iddpm_loss_final_kernel(const float* partial, int n, float inv_numel, float w_simple, float w_vlb,
+                                                               float* loss) {
+    __shared__ float red[16];
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        a += partial[2 * i];
+        b += partial[2 * i + 1];
+    }
+    const float ta = block_sum(a, red);
+    __syncthreads();
+    const float tb = block_sum(b, red);
+    if (threadIdx.x == 0) {
+        loss[1] = ta * inv_numel;  // L_simple
+        loss[2] = tb * inv_numel;  // L_vlb
+        loss[0] = w_simple * loss[1] + w_vlb * loss[2];
+    }
+}
+int launch_iddpm_loss(const float* out, const float* x_t, const float* x_0, const float* target, const int64_t* t, const float* coef, int B,
+                      int64_t chw, float w_simple, float w_vlb, float* loss, float* d_out, float gscale, float* scratch, hipStream_t s) {
+    const int64_t total = (int64_t)B * chw;
+    DMME_REQUIRE(total > 0, DMME_ERR_INVALID, "iddpm_loss: empty batch");
+    unsigned g = grid_for(total);
+    if (g > 512) g = 512;
+    hipLaunchKernelGGL(iddpm_loss_kernel, dim3(g), dim3(256), 0, s, out, x_t, x_0, target, t, coef, chw, total, w_simple, w_vlb,
+                       gscale / (float)total, d_out, scratch);
+    DMME_CHECK_LAUNCH();
+    hipLaunchKernelGGL(iddpm_loss_final_kernel, dim3(1), dim3(256), 0, s, scratch, (int)g, 1.0f / (float)total, w_simple, w_vlb, loss);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
 }  // namespace dmme

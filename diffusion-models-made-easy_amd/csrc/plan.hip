@@ -1209,6 +1209,8 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
     char* tmp = bws + P->bws_tmp;
     int rc = launch_nchw_to_nhwc(dt, d_y, B, P->out_channels, P->H * P->W, bws + P->bws_dy, s);
     if (rc != DMME_OK) return rc;
+    if (P->cfg.arch == DMME_ARCH_IDDPM && nt == 1)  // shared timestep row: the GroupNorm backward accumulates into it atomically
+        DMME_CHECK_HIP(hipMemsetAsync(dtproj, 0, (size_t)P->tproj_cols * 4, s));
 
     for (int oi = (int)P->ops.size() - 1; oi >= 0 && rc == DMME_OK; --oi) {
         const Op& o = P->ops[oi];
@@ -1216,7 +1218,10 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
             const Tensor& q = P->tensors[o.at_qkv];
             const int S = q.H * q.W, C = q.C / 3;
             DMME_REQUIRE(written[o.at_out], DMME_ERR_INVALID, "backward: attention output has no gradient");
-            if (attn_bwd_mfma_supported(dt, B, S, C))
+            if (o.at_heads > 1)
+                rc = launch_attn_heads_bwd(dt, ws + q.off, gptr(o.at_out), B, S, C, o.at_heads, (float*)(bws + P->bws_attP),
+                                           (float*)(bws + P->bws_attdS), gptr(o.at_qkv), s);
+            else if (attn_bwd_mfma_supported(dt, B, S, C))
                 rc = launch_attn_bwd_mfma(dt, ws + q.off, ws + P->tensors[o.at_out].off, gptr(o.at_out), (const float*)(ws + o.at_lse), B, S, C,
                                           bws + P->bws_attP, bws + P->bws_attdS, gptr(o.at_qkv), s);
             else
@@ -1276,16 +1281,25 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
             const int acc1 = claim(o.src1), acc2 = o.src2 >= 0 ? claim(o.src2) : 0;
             if (o.gn >= 0) {
                 const Op& gop = P->ops[o.gn];
+                GnMod mod{};
+                if (gop.gn_mod_col >= 0) {  // scale-shift conditioning: effective gamma + gradients of the (shift | scale) projection rows
+                    mod.t_scale = (const float*)(ws + P->ws_tproj) + gop.gn_mod_col + gop.gn_mod_C;
+                    mod.beta = (const float*)(pk + P->params[gop.gn_beta].packed_off);
+                    mod.d_shift = dtproj + gop.gn_mod_col;
+                    mod.d_scale = dtproj + gop.gn_mod_col + gop.gn_mod_C;
+                    mod.ld = P->tproj_cols;
+                    mod.nt = nt;
+                }
                 if (gn_bwd_fast_supported(dt, t1.H * t1.W, a.C1, a.C2))
                     rc = launch_gn_bwd_fast(dt, tmp, a.src1, a.src2, B, t1.H * t1.W, a.C1, a.C2, G,
                                             (const float*)(pk + P->params[gop.gn_gamma].packed_off), (const float*)(ws + gop.gn_mr), a.scale,
                                             a.shift, a.dmask, a.pro_silu, g1, g2, acc1, acc2, grad_flat + P->params[gop.gn_gamma].ref_off,
-                                            grad_flat + P->params[gop.gn_beta].ref_off, (float*)(bws + o.b_ab), (float*)(bws + P->bws_gnS), s);
+                                            grad_flat + P->params[gop.gn_beta].ref_off, (float*)(bws + o.b_ab), (float*)(bws + P->bws_gnS), mod, s);
                 else
                 rc = launch_gn_bwd_generic(dt, tmp, a.src1, a.src2, B, t1.H * t1.W, a.C1, a.C2, G,
                                            (const float*)(pk + P->params[gop.gn_gamma].packed_off), (const float*)(ws + gop.gn_mr),
                                            a.scale, a.shift, a.dmask, a.pro_silu, g1, g2, acc1, acc2,
-                                           grad_flat + P->params[gop.gn_gamma].ref_off, grad_flat + P->params[gop.gn_beta].ref_off, s);
+                                           grad_flat + P->params[gop.gn_gamma].ref_off, grad_flat + P->params[gop.gn_beta].ref_off, mod, s);
             } else {
                 rc = launch_grad_acc(dt, tmp, g1, g2, a.C1, a.C2, acc1, acc2, o.up == 1 ? 1 : 0, B, t1.H, t1.W, s);
             }
@@ -1412,6 +1426,21 @@ DMME_API int dmme_ddim_step(float* x, const float* eps, float sqrt_one_minus_aba
                    void* stream) {
     DMME_REQUIRE(x && eps, DMME_ERR_INVALID, "ddim_step: null argument");
     return launch_ddim_step(x, eps, sqrt_one_minus_abar, sqrt_abar_prev, numel, (hipStream_t)stream);
+}
+
+DMME_API int dmme_iddpm_step(float* x, const float* model_out, const float* z, float inv_sqrt_alpha, float eps_coef, float log_beta,
+                             float log_beta_tilde, int add_noise, int B, int64_t chw, void* stream) {
+    DMME_REQUIRE(x && model_out && (z || !add_noise) && B > 0 && chw > 0, DMME_ERR_INVALID, "iddpm_step: bad argument");
+    return launch_iddpm_step(x, model_out, z, inv_sqrt_alpha, eps_coef, log_beta, log_beta_tilde, add_noise, B, chw, (hipStream_t)stream);
+}
+
+DMME_API int dmme_iddpm_loss(const float* model_out, const float* x_t, const float* x_0, const float* target, const int64_t* t,
+                             const float* coef, int B, int64_t chw, float w_simple, float w_vlb, float* loss, float* d_out,
+                             float grad_scale, float* scratch, void* stream) {
+    DMME_REQUIRE(model_out && x_t && x_0 && target && t && coef && loss && scratch && B > 0 && chw > 0, DMME_ERR_INVALID,
+                 "iddpm_loss: bad argument");
+    return launch_iddpm_loss(model_out, x_t, x_0, target, t, coef, B, chw, w_simple, w_vlb, loss, d_out, grad_scale, scratch,
+                             (hipStream_t)stream);
 }
 
 DMME_API int dmme_mse_loss(const float* eps, const float* target, int64_t numel, float* loss, float* d_eps, float grad_scale,

@@ -1,1 +1,1 @@
-from . import ddpm, ddim  # noqa: F401
+from . import ddpm, ddim, iddpm  # noqa: F401

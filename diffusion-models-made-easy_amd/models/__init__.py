@@ -1,1 +1,1 @@
-from . import ddpm  # noqa: F401
+from . import ddpm, iddpm  # noqa: F401

@@ -197,6 +197,29 @@ DMME_API int dmme_ddim_step(float* x, const float* eps, float sqrt_one_minus_aba
 DMME_API int dmme_mse_loss(const float* eps, const float* target, int64_t numel, float* loss, float* d_eps,
                   float grad_scale, float* scratch, void* stream);
 
+/* ---- Improved DDPM (learned variance): model_out is (B, 2C, H, W), channels [0, C) = eps, [C, 2C) = v
+ * (IDDPM.forward_model, diffusion_models/iddpm.py:152-164); chw = C*H*W of ONE image of x. */
+
+/* one reverse update, in place on x: replaces IDDPM.sampling_step after the model call
+ * (diffusion_models/iddpm.py:118-150, equations/ddpm/ddpm.py:65-71, equations/iddpm/losses.py:34-37):
+ *   mean = inv_sqrt_alpha * (x - eps_coef * eps);  std = sqrt(exp(v log_beta + (1 - v) log_beta_tilde));
+ *   x = add_noise ? mean + std * z : mean.   log_beta_tilde = log(max(beta~_t, 1e-12)); add_noise = (t != 1). */
+DMME_API int dmme_iddpm_step(float* x, const float* model_out, const float* z, float inv_sqrt_alpha, float eps_coef, float log_beta,
+                    float log_beta_tilde, int add_noise, int B, int64_t chw, void* stream);
+
+/* hybrid / VLB training loss and its gradient w.r.t. model_out: replaces the loss side of IDDPM.training_step
+ * (diffusion_models/iddpm.py:92-116) = eq.ddpm.simple_loss + gamma * eq.iddpm.loss_vlb (equations/iddpm/losses.py:40-98,
+ * discrete NLL rows for t == 1, KL rows otherwise, stop-gradient on eps inside L_vlb).
+ *   loss[0] = w_simple * L_simple + w_vlb * L_vlb, loss[1] = L_simple, loss[2] = L_vlb   (3 floats);
+ *   d_out (optional, B x 2C x H x W) = grad_scale * d loss[0] / d model_out.
+ * t: int64[B] per-sample timesteps; coef: device fp32 table of 8 floats per timestep evaluated on the host with the
+ * reference's fp32 torch ops: {1/sqrt(alpha_t), beta_t/sqrt(1-abar_t), log beta_t, log max(beta~_t, 1e-12),
+ * sqrt(abar_{t-1}) beta_t/(1-abar_t), sqrt(alpha_t)(1-abar_{t-1})/(1-abar_t), sqrt(beta~_t), 0}.
+ * target: the noise re-derived by dmme_q_sample.  `scratch` needs 1024 floats. */
+DMME_API int dmme_iddpm_loss(const float* model_out, const float* x_t, const float* x_0, const float* target, const int64_t* t,
+                    const float* coef, int B, int64_t chw, float w_simple, float w_vlb, float* loss, float* d_out,
+                    float grad_scale, float* scratch, void* stream);
+
 /* ---- single-op entry points used by the unit parity tests ---------------------------
  * Activations here are NHWC in the compute dtype; weights in the packed layout
  * [Cout][taps][Cin]; they exercise exactly the kernels the plan launches.

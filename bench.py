@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--mode", default="sample", choices=["sample", "ddim", "train"])
+    ap.add_argument("--model", default="ddpm", choices=["ddpm", "iddpm64"],
+                    help="ddpm: BASELINE configs[1]/[2] (default UNet, 32x32); iddpm64: configs[3] (IDDPM ImageNet-64 UNet, attention at "
+                         "16x16/8x8, cosine schedule, T=4000; use --batch 32 for the 256-over-8-GPUs shard)")
     ap.add_argument("--train-steps", type=int, default=8, help="training steps timed for train_images_per_s (0: skip)")
     ap.add_argument("--graph", action="store_true", help="replay the UNet forward from a hipGraph (small-batch sampling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -92,7 +95,7 @@ def roofline_leg(model, x, t_dev, precision):
     name, g = order[0]
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath) and x.shape[0] == 128 and precision == "bf16":  # the PMC passes (tools/prof.sh) run this configuration only
+    if os.path.exists(tpath) and x.shape[0] == 128 and x.shape[-1] == 32 and precision == "bf16":  # the PMC passes (tools/prof.sh) run this configuration only
         try:
             traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
         except Exception:  # noqa: BLE001
@@ -145,18 +148,29 @@ def cpu_baseline_leg(batch_ref):
             "sample": f"{done} DDPM steps of batch {Bc}, fp32, oracle UNet + update, {dt:.1f} s"}
 
 
-def train_leg(dmme_amd, dev, B, precision, steps, warmup, dist):
+def workload(dmme_amd, name, precision):
+    """(UNet, image side, T, process class, Lit class, label) of a --model choice"""
+    if name == "iddpm64":
+        from dmme_amd.models import iddpm
+
+        return (iddpm.UNet(attention_depths=(3, 4), precision=precision), 64, 4000, dmme_amd.IDDPM, dmme_amd.LitIDDPM,
+                "IDDPM ImageNet-64 UNet (36,562,822 params, 4-head attention at 16x16/8x8, dropout 0.3), cosine schedule, T=4000")
+    return dmme_amd.UNet(precision=precision), 32, 1000, dmme_amd.DDPM, dmme_amd.LitDDPM, "default UNet (32,416,643 params, random init)"
+
+
+def train_leg(dmme_amd, dev, B, precision, steps, warmup, dist, model_name="ddpm"):
     """training images/s: q_sample -> UNet fwd (train mode, Dropout2d on) -> MSE -> HIP backward -> (RCCL mean
     all-reduce of the flat gradient) -> fused clip(1.0)+Adam+EMA -> warm-up LR step; per-GPU batch B."""
     from dmme_amd.train_loop import synthetic_batch, train_step
 
-    lit = dmme_amd.LitDDPM(model=dmme_amd.UNet(precision=precision)).to(dev)
+    net, side, T, _, lit_cls, _ = workload(dmme_amd, model_name, precision)
+    lit = lit_cls(model=net, timesteps=T).to(dev)
     lit.train()
     opts, scheds = lit.configure_optimizers()
     opt, sched = opts[0], scheds[0]["scheduler"]
     for g in opt.param_groups:
         g["max_grad_norm"] = 1.0
-    x0 = synthetic_batch(B, dev)
+    x0 = synthetic_batch(B, dev, (3, side, side))
 
     def fence():
         if dist is not None:
@@ -200,27 +214,30 @@ def main():
     import dmme_amd
 
     torch.manual_seed(1337 + rank)
-    B, T = args.batch, 1000
+    B = args.batch
+    model, side, T, proc_cls, _, label = workload(dmme_amd, args.model, args.precision)
     if args.mode == "train":
-        dt, loss = train_leg(dmme_amd, dev, B, args.precision, args.steps, args.warmup, dist)
+        del model
+        dt, loss = train_leg(dmme_amd, dev, B, args.precision, args.steps, args.warmup, dist, args.model)
         if rank == 0:
             print(json.dumps({
                 "metric": METRIC, "value": round(world * args.steps * B / dt, 2),
                 "unit": "training images/s (q_sample + UNet fwd/bwd + grad all-reduce + clip + Adam + EMA), summed over GPUs",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-                "config": {"workload": f"DDPM CIFAR10 32x32 training step, default UNet, batch {B} per GPU, dropout 0.1", "global_batch": B * world,
+                "config": {"workload": (f"DDPM CIFAR10 32x32 training step, default UNet, batch {B} per GPU, dropout 0.1" if args.model == "ddpm" else
+                                        f"{label}: hybrid-loss training step at 64x64, batch {B} per GPU"), "global_batch": B * world,
                            "parallelism": f"dp{world} (RCCL mean all-reduce of the flat fp32 gradient)"}, "final_loss": round(loss, 5)}), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
         return
-    model = dmme_amd.UNet(precision=args.precision).to(dev).eval()
+    model = model.to(dev).eval()
     if args.mode == "ddim":
         proc = dmme_amd.DDIM(model, T, 50).to(dev)
     else:
-        proc = dmme_amd.DDPM(model, T).to(dev)
-    x = dmme_amd.gaussian((B, 3, 32, 32), device=dev)
+        proc = proc_cls(model, T).to(dev)
+    x = dmme_amd.gaussian((B, 3, side, side), device=dev)
     all_t = torch.arange(0, T + 1, device=dev).unsqueeze(1)
     tau = proc._tau_host if args.mode == "ddim" else None
 
@@ -276,8 +293,8 @@ def main():
         "dtype": args.precision,
         "data": "synthetic",
         "config": {
-            "workload": f"{'DDIM 50-step (quadratic tau)' if args.mode == 'ddim' else 'DDPM T=1000'} sampling, CIFAR10 32x32, default UNet "
-                        f"(32,416,643 params, random init), batch {B} per GPU, t.shape=(1,)",
+            "workload": (f"{'DDIM 50-step (quadratic tau)' if args.mode == 'ddim' else 'DDPM T=1000'} sampling, CIFAR10 32x32, {label}, "
+                         f"batch {B} per GPU, t.shape=(1,)") if args.model == "ddpm" else f"{label}: learned-variance sampling at 64x64, batch {B} per GPU, t.shape=(1,)",
             "global_batch": B * world,
             "parallelism": f"dp{world} (independent chains per GPU, no data-path collective)",
         },
@@ -288,14 +305,14 @@ def main():
     }
     if args.train_steps > 0:
         del x
-        dt_tr, _ = train_leg(dmme_amd, dev, B, args.precision, args.train_steps, 2, dist)
+        dt_tr, _ = train_leg(dmme_amd, dev, B, args.precision, args.train_steps, 2, dist, args.model)
         out["train_images_per_s"] = round(world * args.train_steps * B / dt_tr, 1)
         out["train_ms_per_step"] = round(1e3 * dt_tr / args.train_steps, 2)
     if rank == 0:
         if not args.no_roofline:
-            xin = dmme_amd.gaussian((B, 3, 32, 32), device=dev)
+            xin = dmme_amd.gaussian((B, 3, side, side), device=dev)
             out["roofline"] = roofline_leg(model, xin, all_t[500], args.precision)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == "ddpm":
             out["cpu_baseline"] = cpu_baseline_leg(B)
         print(json.dumps(out), flush=True)
     if dist is not None:

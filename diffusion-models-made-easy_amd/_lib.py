@@ -99,6 +99,7 @@ PROTOTYPES = {
     "dmme_conv2d": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "dmme_groupnorm_scale_shift": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _i, _vp]),
     "dmme_attention": (_i, [_i, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "dmme_attention_heads": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "dmme_nchw_to_nhwc": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),
     "dmme_nhwc_to_nchw": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),
     "dmme_pack_weight": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),

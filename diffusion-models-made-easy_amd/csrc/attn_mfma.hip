@@ -24,10 +24,28 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int AT_KT = 32;  // keys per tile
-constexpr int AT_QB = 128; // queries per workgroup
 
-template <int C>
-__global__ void __launch_bounds__(256) attn_mfma_kernel(const bf16* __restrict__ qkv, int S, bf16* __restrict__ out, float* __restrict__ lse) {
+// Head view (multi-head blocks of the IDDPM UNet, models/iddpm.py:35-47; heads == 1 is the DDPM block): a "row" bh = n*heads + hd
+// reads the qkv channels [hd*3D, (hd+1)*3D) of image n as (q | k | v) and owns the output row block (image bh % N, head bh / N) --
+// the reference splits "(b head)" and merges "(head b)".  scale = Cfull^-0.5 (the full width, not the head width).
+struct AttnGeom {
+    int S, ld, Cfull, heads, N;
+    float scale;
+};
+template <int D>
+__device__ __forceinline__ int64_t at_qkv_off(const AttnGeom& g, int bh) {
+    return (int64_t)(bh / g.heads) * g.S * g.ld + (int64_t)(bh % g.heads) * 3 * D;
+}
+template <int D>
+__device__ __forceinline__ int64_t at_o_off(const AttnGeom& g, int bh) {
+    return (int64_t)(bh % g.N) * g.S * g.Cfull + (int64_t)(bh / g.N) * D;
+}
+
+// C = head width; NW wavefronts of 32 queries each per workgroup
+template <int C, int NW>
+__global__ void __launch_bounds__(64 * NW) attn_mfma_kernel(const bf16* __restrict__ qkv, AttnGeom g, bf16* __restrict__ out, float* __restrict__ lse) {
+    constexpr int AT_QB = 32 * NW, NT = 64 * NW;
+    const int S = g.S;
     constexpr int KSTEPS = C / 16;   // k-steps of the QK^T product
     constexpr int CT = C / 32;       // 32-channel tiles of the output
     constexpr int KP = C * 2 + 16;   // K tile row pitch (bytes)
@@ -39,15 +57,16 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const bf16* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int qblocks = S / AT_QB;
-    const int n = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;
-    const bf16* base = qkv + (int64_t)n * S * 3 * C;
+    const int n = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;  // n: the (image, head) row
+    const bf16* base = qkv + at_qkv_off<C>(g, n);
+    const int ld = g.ld;
     const int q_row = qb * AT_QB + wave * 32 + r;  // this lane's query
 
     // Q^T fragments (B operand): element j of k-step ks = Q[q_row][16 ks + 8 h + j]
     uint4 qf[KSTEPS];
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks)
-        qf[ks] = *reinterpret_cast<const uint4*>(base + (int64_t)q_row * 3 * C + ks * 16 + h * 8);
+        qf[ks] = *reinterpret_cast<const uint4*>(base + (int64_t)q_row * ld + ks * 16 + h * 8);
 
     f32x16 o[CT];
 #pragma unroll
@@ -55,7 +74,7 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const bf16* __restrict__
 #pragma unroll
         for (int j = 0; j < 16; ++j) o[ct][j] = 0.f;
     float m = -1e30f, l = 0.f;
-    const float c1 = 1.4426950408889634f / sqrtf((float)C);  // C^-0.5 * log2(e)
+    const float c1 = 1.4426950408889634f * g.scale;  // Cfull^-0.5 * log2(e)
 
     // transposed-read lane geometry: 16-lane group g, lane i = 4 q + p inside it
     const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g1 = (lane >> 4) & 1;
@@ -63,9 +82,9 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const bf16* __restrict__
     for (int k0 = 0; k0 < S; k0 += AT_KT) {
         __syncthreads();
         // ---- stage K and V tiles (32 keys x C) ----
-        for (int u = tid; u < AT_KT * (C / 8); u += 256) {
+        for (int u = tid; u < AT_KT * (C / 8); u += NT) {
             const int row = u / (C / 8), cu = u % (C / 8);
-            const bf16* src = base + (int64_t)(k0 + row) * 3 * C + cu * 8;
+            const bf16* src = base + (int64_t)(k0 + row) * ld + cu * 8;
             *reinterpret_cast<uint4*>(ldsK + row * KP + cu * 16) = *reinterpret_cast<const uint4*>(src + C);
             *reinterpret_cast<uint4*>(ldsV + row * VP + cu * 16) = *reinterpret_cast<const uint4*>(src + 2 * C);
         }
@@ -127,7 +146,7 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const bf16* __restrict__
     const float inv = 1.0f / ltot;
     // log2-domain log-sum-exp of the scaled scores, kept for the backward pass: p = exp2(s*c1 - lse)
     if (lse && h == 0) lse[(int64_t)n * S + q_row] = m + log2f(ltot);
-    bf16* orow = out + ((int64_t)n * S + q_row) * C;
+    bf16* orow = out + at_o_off<C>(g, n) + (int64_t)q_row * g.Cfull;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
@@ -141,20 +160,37 @@ __global__ void __launch_bounds__(256) attn_mfma_kernel(const bf16* __restrict__
     }
 }
 
-bool attn_mfma_supported(int dtype, int N, int S, int C) {
+bool attn_mfma_supported(int dtype, int N, int S, int C) { return attn_heads_mfma_supported(dtype, N, S, C, 1); }
+// head width 64 / 128 / 256; 128-query workgroups, or 64-query ones for the 8x8 maps
+bool attn_heads_mfma_supported(int dtype, int N, int S, int C, int heads) {
     (void)N;
-    return dtype == DMME_BF16 && (C == 128 || C == 256) && S >= AT_QB && S % AT_QB == 0;
+    if (dtype != DMME_BF16 || heads < 1 || C % heads) return false;
+    const int D = C / heads;
+    return (D == 64 || D == 128 || D == 256) && S >= 64 && S % 64 == 0 && (S % 128 == 0 || S == 64);
 }
+static AttnGeom attn_geom(int N, int S, int C, int heads) { return AttnGeom{S, 3 * C, C, heads, N, 1.0f / sqrtf((float)C)}; }
 
-int launch_attn_mfma(int dtype, const void* qkv, int N, int S, int C, void* out, float* lse, hipStream_t s) {
-    DMME_REQUIRE(attn_mfma_supported(dtype, N, S, C), DMME_ERR_UNSUPPORTED, "attn_mfma: unsupported shape S=%d C=%d", S, C);
-    const dim3 grid((unsigned)(N * (S / AT_QB)));
-    if (C == 256)
-        hipLaunchKernelGGL(attn_mfma_kernel<256>, grid, dim3(256), 0, s, (const bf16*)qkv, S, (bf16*)out, lse);
+template <int D>
+static int launch_attn_fwd_t(const bf16* qkv, const AttnGeom& g, bf16* out, float* lse, hipStream_t s) {
+    const int rows = g.N * g.heads;
+    if (g.S % 128 == 0)
+        hipLaunchKernelGGL((attn_mfma_kernel<D, 4>), dim3((unsigned)(rows * (g.S / 128))), dim3(256), 0, s, qkv, g, out, lse);
     else
-        hipLaunchKernelGGL(attn_mfma_kernel<128>, grid, dim3(256), 0, s, (const bf16*)qkv, S, (bf16*)out, lse);
+        hipLaunchKernelGGL((attn_mfma_kernel<D, 2>), dim3((unsigned)(rows * (g.S / 64))), dim3(128), 0, s, qkv, g, out, lse);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
+}
+int launch_attn_heads_mfma(int dtype, const void* qkv, int N, int S, int C, int heads, void* out, float* lse, hipStream_t s) {
+    DMME_REQUIRE(attn_heads_mfma_supported(dtype, N, S, C, heads), DMME_ERR_UNSUPPORTED, "attn_mfma: unsupported shape S=%d C=%d heads=%d", S, C, heads);
+    const AttnGeom g = attn_geom(N, S, C, heads);
+    switch (C / heads) {
+        case 256: return launch_attn_fwd_t<256>((const bf16*)qkv, g, (bf16*)out, lse, s);
+        case 128: return launch_attn_fwd_t<128>((const bf16*)qkv, g, (bf16*)out, lse, s);
+        default: return launch_attn_fwd_t<64>((const bf16*)qkv, g, (bf16*)out, lse, s);
+    }
+}
+int launch_attn_mfma(int dtype, const void* qkv, int N, int S, int C, void* out, float* lse, hipStream_t s) {
+    return launch_attn_heads_mfma(dtype, qkv, N, S, C, 1, out, lse, s);
 }
 
 // =====================================================================================
@@ -168,10 +204,12 @@ int launch_attn_mfma(int dtype, const void* qkv, int N, int S, int C, void* out,
 // (attn_bgemm): dV = P^T dO and dK = s dS^T Q contract over the ROW index of two row-major
 // matrices (both fragments via transposed LDS reads), dQ = s dS K is a row-major A times a
 // transposed-read B.
-template <int C>
-__global__ void __launch_bounds__(256) attn_bwd_scores_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ O,
-                                                              const bf16* __restrict__ dO, const float* __restrict__ lse, int S,
+template <int C, int NW>
+__global__ void __launch_bounds__(64 * NW) attn_bwd_scores_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ O,
+                                                              const bf16* __restrict__ dO, const float* __restrict__ lse, AttnGeom g,
                                                               bf16* __restrict__ P, bf16* __restrict__ dS) {
+    constexpr int AT_QB = 32 * NW, NT = 64 * NW;
+    const int S = g.S, ld = g.ld;
     constexpr int KSTEPS = C / 16;
     constexpr int KP = C * 2 + 16;
     __shared__ __attribute__((aligned(16))) char lds[2 * AT_KT * KP];
@@ -180,31 +218,32 @@ __global__ void __launch_bounds__(256) attn_bwd_scores_kernel(const bf16* __rest
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int qblocks = S / AT_QB;
-    const int n = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;
-    const bf16* base = qkv + (int64_t)n * S * 3 * C;
+    const int n = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;  // n: the (image, head) row
+    const bf16* base = qkv + at_qkv_off<C>(g, n);
+    const int64_t orow = at_o_off<C>(g, n);
     const int q_row = qb * AT_QB + wave * 32 + r;
     uint4 qf[KSTEPS], dof[KSTEPS];
     float dpart = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
-        qf[ks] = *reinterpret_cast<const uint4*>(base + (int64_t)q_row * 3 * C + ks * 16 + h * 8);
-        dof[ks] = *reinterpret_cast<const uint4*>(dO + ((int64_t)n * S + q_row) * C + ks * 16 + h * 8);
-        const uint4 ov = *reinterpret_cast<const uint4*>(O + ((int64_t)n * S + q_row) * C + ks * 16 + h * 8);
+        qf[ks] = *reinterpret_cast<const uint4*>(base + (int64_t)q_row * ld + ks * 16 + h * 8);
+        dof[ks] = *reinterpret_cast<const uint4*>(dO + orow + (int64_t)q_row * g.Cfull + ks * 16 + h * 8);
+        const uint4 ov = *reinterpret_cast<const uint4*>(O + orow + (int64_t)q_row * g.Cfull + ks * 16 + h * 8);
         const bf16x8 a = __builtin_bit_cast(bf16x8, dof[ks]), b = __builtin_bit_cast(bf16x8, ov);
 #pragma unroll
         for (int j = 0; j < 8; ++j) dpart = fmaf((float)a[j], (float)b[j], dpart);
     }
     const float delta = dpart + __shfl_xor(dpart, 32, 64);
     const float L = lse[(int64_t)n * S + q_row];
-    const float c1 = 1.4426950408889634f / sqrtf((float)C);
+    const float c1 = 1.4426950408889634f * g.scale;
     bf16* Prow = P + ((int64_t)n * S + q_row) * S;
     bf16* dSrow = dS + ((int64_t)n * S + q_row) * S;
 
     for (int k0 = 0; k0 < S; k0 += AT_KT) {
         __syncthreads();
-        for (int u = tid; u < AT_KT * (C / 8); u += 256) {
+        for (int u = tid; u < AT_KT * (C / 8); u += NT) {
             const int row = u / (C / 8), cu = u % (C / 8);
-            const bf16* src = base + (int64_t)(k0 + row) * 3 * C + cu * 8;
+            const bf16* src = base + (int64_t)(k0 + row) * ld + cu * 8;
             *reinterpret_cast<uint4*>(ldsK + row * KP + cu * 16) = *reinterpret_cast<const uint4*>(src + C);
             *reinterpret_cast<uint4*>(ldsV + row * KP + cu * 16) = *reinterpret_cast<const uint4*>(src + 2 * C);
         }
@@ -240,12 +279,17 @@ __global__ void __launch_bounds__(256) attn_bwd_scores_kernel(const bf16* __rest
 //   TRANS_A = 1: A(m,k) = X[k][m]  (X row-major [S][S], ldx = S)      -- dV, dK
 //   TRANS_A = 0: A(m,k) = X[m][k]                                      -- dQ
 //   B(k,n) = Y[k][n] (row-major, ldy), fragments by transposed LDS reads.
-// One workgroup = one image x 64 rows of the output; 4 waves split the C columns.
-template <int C, int TRANS_A>
-__global__ void __launch_bounds__(256) attn_bgemm_kernel(const bf16* __restrict__ X, int ldx, int64_t x_img, const bf16* __restrict__ Y, int ldy,
-                                                         int64_t y_img, int S, float alpha, bf16* __restrict__ out, int ldo, int64_t o_img) {
-    constexpr int WN = C / 4;        // columns per wave
-    constexpr int NI = WN / 32;      // 32-column tiles per wave
+// One workgroup = one (image, head) row x 64 rows of the output; the 4 waves split the C columns (C >= 128), or 2 x 2 over
+// (rows, columns) for C = 64.  Y and out are addressed through the head view: Y_O = 1 reads an output-layout tensor (dO),
+// else a qkv-layout one at column offset ycol; out is always qkv-layout (dqkv) at column offset ocol.
+template <int C, int TRANS_A, int Y_O>
+__global__ void __launch_bounds__(256) attn_bgemm_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Y, int ycol, AttnGeom g, float alpha,
+                                                         bf16* __restrict__ out, int ocol) {
+    constexpr int WM = C >= 128 ? 1 : 2;   // waves along the 64 output rows
+    constexpr int MI = 2 / WM;             // 32-row tiles per wave
+    constexpr int WN = C / (4 / WM);       // columns per wave
+    constexpr int NI = WN / 32;            // 32-column tiles per wave
+    const int S = g.S, ldx = S, ldy = Y_O ? g.Cfull : g.ld, ldo = g.ld;
     constexpr int YP = C * 2 + 64;   // Y tile pitch: 4 rows of a transposed read on disjoint banks
     constexpr int XP_T = 64 * 2 + 64;  // X tile [32 k][64 m] for transposed reads
     constexpr int XP_N = 32 * 2 + 16;  // X tile [64 m][32 k] for row reads
@@ -256,12 +300,13 @@ __global__ void __launch_bounds__(256) attn_bgemm_kernel(const bf16* __restrict_
     const int r = lane & 31, h = lane >> 5;
     const int mblocks = S / 64;
     const int n = blockIdx.x / mblocks, m0 = (blockIdx.x % mblocks) * 64;
-    const bf16* Xi = X + n * x_img;
-    const bf16* Yi = Y + n * y_img;
+    const int wm = WM == 1 ? 0 : wave >> 1, wn = WM == 1 ? wave : wave & 1;
+    const bf16* Xi = X + (int64_t)n * S * S;
+    const bf16* Yi = Y + (Y_O ? at_o_off<C>(g, n) : at_qkv_off<C>(g, n) + ycol);
     const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g1 = (lane >> 4) & 1;
-    f32x16 acc[2][NI];
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -289,72 +334,82 @@ __global__ void __launch_bounds__(256) attn_bgemm_kernel(const bf16* __restrict_
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            s16x8 af[2];
+            s16x8 af[MI];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
+            for (int mi = 0; mi < MI; ++mi) {
+                const int mt = wm * MI + mi;  // 32-row tile inside the 64-row block
                 if (TRANS_A) {
-                    const char* p0 = ldsX + (16 * ks + 8 * h + tr_q) * XP_T + (mi * 32 + 16 * tr_g1 + 4 * tr_p) * 2;
+                    const char* p0 = ldsX + (16 * ks + 8 * h + tr_q) * XP_T + (mt * 32 + 16 * tr_g1 + 4 * tr_p) * 2;
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 4 * XP_T));
                     af[mi][0] = lo[0]; af[mi][1] = lo[1]; af[mi][2] = lo[2]; af[mi][3] = lo[3];
                     af[mi][4] = hi[0]; af[mi][5] = hi[1]; af[mi][6] = hi[2]; af[mi][7] = hi[3];
                 } else {
-                    af[mi] = __builtin_bit_cast(s16x8, *reinterpret_cast<const uint4*>(ldsX + (mi * 32 + r) * XP_N + ks * 32 + h * 16));
+                    af[mi] = __builtin_bit_cast(s16x8, *reinterpret_cast<const uint4*>(ldsX + (mt * 32 + r) * XP_N + ks * 32 + h * 16));
                 }
             }
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                const char* p0 = ldsY + (16 * ks + 8 * h + tr_q) * YP + (wave * WN + ni * 32 + 16 * tr_g1 + 4 * tr_p) * 2;
+                const char* p0 = ldsY + (16 * ks + 8 * h + tr_q) * YP + (wn * WN + ni * 32 + 16 * tr_g1 + 4 * tr_p) * 2;
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 4 * YP));
                 s16x8 bfr;
                 bfr[0] = lo[0]; bfr[1] = lo[1]; bfr[2] = lo[2]; bfr[3] = lo[3];
                 bfr[4] = hi[0]; bfr[5] = hi[1]; bfr[6] = hi[2]; bfr[7] = hi[3];
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mi]), __builtin_bit_cast(bf16x8, bfr), acc[mi][ni], 0, 0, 0);
             }
         }
     }
-    bf16* Oi = out + n * o_img;
+    bf16* Oi = out + at_qkv_off<C>(g, n) + ocol;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const int m = m0 + mi * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
-                Oi[(int64_t)m * ldo + wave * WN + ni * 32 + r] = (bf16)(acc[mi][ni][j] * alpha);
+                const int m = m0 + (wm * MI + mi) * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+                Oi[(int64_t)m * ldo + wn * WN + ni * 32 + r] = (bf16)(acc[mi][ni][j] * alpha);
             }
 }
 
-bool attn_bwd_mfma_supported(int dtype, int N, int S, int C) { return attn_mfma_supported(dtype, N, S, C) && S % 64 == 0; }
+bool attn_bwd_mfma_supported(int dtype, int N, int S, int C) { return attn_heads_mfma_supported(dtype, N, S, C, 1); }
 
-template <int C>
-static int launch_attn_bwd_t(const bf16* qkv, const bf16* O, const bf16* dO, const float* lse, int N, int S, bf16* P, bf16* dS, bf16* dqkv,
+template <int D>
+static int launch_attn_bwd_t(const bf16* qkv, const bf16* O, const bf16* dO, const float* lse, const AttnGeom& g, bf16* P, bf16* dS, bf16* dqkv,
                              hipStream_t s) {
-    hipLaunchKernelGGL(attn_bwd_scores_kernel<C>, dim3((unsigned)(N * (S / AT_QB))), dim3(256), 0, s, qkv, O, dO, lse, S, P, dS);
+    const int rows = g.N * g.heads, S = g.S;
+    if (S % 128 == 0)
+        hipLaunchKernelGGL((attn_bwd_scores_kernel<D, 4>), dim3((unsigned)(rows * (S / 128))), dim3(256), 0, s, qkv, O, dO, lse, g, P, dS);
+    else
+        hipLaunchKernelGGL((attn_bwd_scores_kernel<D, 2>), dim3((unsigned)(rows * (S / 64))), dim3(128), 0, s, qkv, O, dO, lse, g, P, dS);
     DMME_CHECK_LAUNCH();
-    const dim3 grid((unsigned)(N * (S / 64)));
-    const float scale = 1.0f / sqrtf((float)C);
-    const int64_t qi = (int64_t)S * 3 * C, oi = (int64_t)S * C, pi = (int64_t)S * S;
+    const dim3 grid((unsigned)(rows * (S / 64)));
     // dV = P^T dO ; dK = s dS^T Q ; dQ = s dS K
-    hipLaunchKernelGGL((attn_bgemm_kernel<C, 1>), grid, dim3(256), 0, s, P, S, pi, dO, C, oi, S, 1.0f, dqkv + 2 * C, 3 * C, qi);
+    hipLaunchKernelGGL((attn_bgemm_kernel<D, 1, 1>), grid, dim3(256), 0, s, P, dO, 0, g, 1.0f, dqkv, 2 * D);
     DMME_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_bgemm_kernel<C, 1>), grid, dim3(256), 0, s, dS, S, pi, qkv, 3 * C, qi, S, scale, dqkv + C, 3 * C, qi);
+    hipLaunchKernelGGL((attn_bgemm_kernel<D, 1, 0>), grid, dim3(256), 0, s, dS, qkv, 0, g, g.scale, dqkv, D);
     DMME_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_bgemm_kernel<C, 0>), grid, dim3(256), 0, s, dS, S, pi, qkv + C, 3 * C, qi, S, scale, dqkv, 3 * C, qi);
+    hipLaunchKernelGGL((attn_bgemm_kernel<D, 0, 0>), grid, dim3(256), 0, s, dS, qkv, D, g, g.scale, dqkv, 0);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }
 
-// P, dS: N*S*S bf16 each
+// P, dS: N*heads*S*S bf16 each
+int launch_attn_heads_bwd_mfma(int dtype, const void* qkv, const void* O, const void* dO, const float* lse, int N, int S, int C, int heads, void* P,
+                               void* dS, void* dqkv, hipStream_t s) {
+    DMME_REQUIRE(attn_heads_mfma_supported(dtype, N, S, C, heads), DMME_ERR_UNSUPPORTED, "attn_bwd_mfma: unsupported shape");
+    const AttnGeom g = attn_geom(N, S, C, heads);
+    switch (C / heads) {
+        case 256: return launch_attn_bwd_t<256>((const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, g, (bf16*)P, (bf16*)dS, (bf16*)dqkv, s);
+        case 128: return launch_attn_bwd_t<128>((const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, g, (bf16*)P, (bf16*)dS, (bf16*)dqkv, s);
+        default: return launch_attn_bwd_t<64>((const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, g, (bf16*)P, (bf16*)dS, (bf16*)dqkv, s);
+    }
+}
 int launch_attn_bwd_mfma(int dtype, const void* qkv, const void* O, const void* dO, const float* lse, int N, int S, int C, void* P, void* dS,
                          void* dqkv, hipStream_t s) {
-    DMME_REQUIRE(attn_bwd_mfma_supported(dtype, N, S, C), DMME_ERR_UNSUPPORTED, "attn_bwd_mfma: unsupported shape");
-    if (C == 256)
-        return launch_attn_bwd_t<256>((const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, N, S, (bf16*)P, (bf16*)dS, (bf16*)dqkv, s);
-    return launch_attn_bwd_t<128>((const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, N, S, (bf16*)P, (bf16*)dS, (bf16*)dqkv, s);
+    return launch_attn_heads_bwd_mfma(dtype, qkv, O, dO, lse, N, S, C, 1, P, dS, dqkv, s);
 }
 
 }  // namespace dmme

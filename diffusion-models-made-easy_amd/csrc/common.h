@@ -149,7 +149,8 @@ bool conv1x1_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* 
 bool conv_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px);
 // merge producer partials of one or two (concatenated) tensors into scale/shift (+ mean/rstd)
 int launch_gn_finalize_parts(const float* part1, int tiles1, int cnt1, int C1, const float* part2, int tiles2, int cnt2, int C2, int N, int groups,
-                             const float* gamma, const float* beta, float eps, float* scale, float* shift, float* mean_rstd, hipStream_t s);
+                             const float* gamma, const float* beta, float eps, float* scale, float* shift, float* mean_rstd, const float* t_shift,
+                             const float* t_scale, int t_ld, int nt, hipStream_t s);
 
 // mean_rstd (nullable): [N][groups][2] = {mean, rstd}, kept for the backward pass
 int launch_gn_generic(int dtype, const void* src1, const void* src2, int N, int HW, int C1, int C2, int groups,
@@ -172,6 +173,10 @@ int launch_gn_modulate(float* scale, float* shift, const float* t_shift, const f
 bool attn_mfma_supported(int dtype, int N, int S, int C);
 // lse (nullable): [N][S] log2-domain log-sum-exp of the scaled scores, kept for the backward pass
 int launch_attn_mfma(int dtype, const void* qkv, int N, int S, int C, void* out, float* lse, hipStream_t s);
+bool attn_heads_mfma_supported(int dtype, int N, int S, int C, int heads);
+int launch_attn_heads_mfma(int dtype, const void* qkv, int N, int S, int C, int heads, void* out, float* lse, hipStream_t s);
+int launch_attn_heads_bwd_mfma(int dtype, const void* qkv, const void* O, const void* dO, const float* lse, int N, int S, int C, int heads, void* P,
+                               void* dS, void* dqkv, hipStream_t s);
 bool attn_bwd_mfma_supported(int dtype, int N, int S, int C);
 int launch_attn_bwd_mfma(int dtype, const void* qkv, const void* O, const void* dO, const float* lse, int N, int S, int C, void* P, void* dS,
                          void* dqkv, hipStream_t s);

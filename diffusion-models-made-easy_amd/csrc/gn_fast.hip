@@ -154,7 +154,8 @@ __global__ void __launch_bounds__(256) gn_finalize_parts_kernel(const float* __r
                                                                 const float* __restrict__ p2, int t2, int cnt2, int C2, int N, int groups,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                                 float* __restrict__ scale, float* __restrict__ shift,
-                                                                float* __restrict__ mean_rstd) {
+                                                                float* __restrict__ mean_rstd, const float* __restrict__ t_shift,
+                                                                const float* __restrict__ t_scale, int t_ld, int nt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * groups) return;
     const int n = i / groups, g = i % groups, C = C1 + C2, cg = C / groups;
@@ -181,17 +182,24 @@ __global__ void __launch_bounds__(256) gn_finalize_parts_kernel(const float* __r
     }
     for (int j = 0; j < cg; ++j) {
         const int c = c_first + j;
-        const float a = rstd * gamma[c];
+        float a = rstd * gamma[c], b = beta[c] - mean * a;
+        if (t_scale) {  // scale-shift conditioning folded in (same arithmetic as gn_modulate_kernel)
+            const int64_t r = (int64_t)(nt == 1 ? 0 : n) * t_ld + c;
+            const float mm = 1.0f + t_scale[r];
+            a = a * mm;
+            b = fmaf(b, mm, t_shift[r]);
+        }
         scale[(int64_t)n * C + c] = a;
-        shift[(int64_t)n * C + c] = beta[c] - mean * a;
+        shift[(int64_t)n * C + c] = b;
     }
 }
 
 int launch_gn_finalize_parts(const float* part1, int tiles1, int cnt1, int C1, const float* part2, int tiles2, int cnt2, int C2, int N, int groups,
-                             const float* gamma, const float* beta, float eps, float* scale, float* shift, float* mean_rstd, hipStream_t s) {
+                             const float* gamma, const float* beta, float eps, float* scale, float* shift, float* mean_rstd, const float* t_shift,
+                             const float* t_scale, int t_ld, int nt, hipStream_t s) {
     const int tot = N * groups;
     hipLaunchKernelGGL(gn_finalize_parts_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, part1, tiles1, cnt1, C1, part2, tiles2, cnt2, C2, N,
-                       groups, gamma, beta, eps, scale, shift, mean_rstd);
+                       groups, gamma, beta, eps, scale, shift, mean_rstd, t_shift, t_scale, t_ld, nt);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }

@@ -452,7 +452,7 @@ int build_plan(dmme_plan* P) {
             at.at_qkv = q.dst;
             at.at_heads = iddpm ? P->cfg.num_heads : 1;
             at.at_out = new_tensor(n.cout, h, w);
-            at.at_lse = ws_alloc((int64_t)B * h * w * 4);
+            at.at_lse = ws_alloc((int64_t)B * at.at_heads * h * w * 4);
             ops.push_back(at);
             Op pr{};
             pr.kind = OP_CONV;
@@ -837,7 +837,11 @@ void assign_stats(dmme_plan* P) {
 }
 
 // GroupNorm statistics folded with the affine into per-(n, c) scale / shift for the consuming conv's prologue
-int run_gn(const dmme_plan* P, const Op& o, const char* pk, char* ws, hipStream_t s) {
+int run_gn(const dmme_plan* P, const Op& o, const char* pk, char* ws, int nt, hipStream_t s) {
+    // scale-shift conditioning (iddpm.ResBlock): (shift | scale) columns of the batched time projection
+    const float* tsh = o.gn_mod_col >= 0 ? (const float*)(ws + P->ws_tproj) + o.gn_mod_col : nullptr;
+    const float* tsc = tsh ? tsh + o.gn_mod_C : nullptr;
+    int rc;
     const Tensor& t1 = P->tensors[o.gn_src1];
     const void* s1 = ws + t1.off;
     const void* s2 = o.gn_src2 >= 0 ? ws + P->tensors[o.gn_src2].off : nullptr;
@@ -851,13 +855,16 @@ int run_gn(const dmme_plan* P, const Op& o, const char* pk, char* ws, hipStream_
         return launch_gn_finalize_parts((const float*)(ws + t1.stats_off), t1.stats_tiles, t1.stats_cnt, t1.C,
                                         t2 ? (const float*)(ws + t2->stats_off) : nullptr, t2 ? t2->stats_tiles : 0,
                                         t2 ? t2->stats_cnt : 0, C2, P->B, P->cfg.num_groups, gam, bet, 1e-5f, sc, sh,
-                                        (float*)(ws + o.gn_mr), s);
+                                        (float*)(ws + o.gn_mr), tsh, tsc, P->tproj_cols, nt, s);
     }
     if (gn_fast_supported(P->dtype, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups))
-        return launch_gn_fast(P->dtype, s1, s2, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups, gam, bet, 1e-5f, sc, sh,
-                              (float*)(ws + o.gn_mr), (float*)(ws + P->ws_gnpart), s);
-    return launch_gn_generic(P->dtype, s1, s2, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups, gam, bet, 1e-5f, sc, sh,
-                             (float*)(ws + o.gn_mr), s);
+        rc = launch_gn_fast(P->dtype, s1, s2, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups, gam, bet, 1e-5f, sc, sh,
+                            (float*)(ws + o.gn_mr), (float*)(ws + P->ws_gnpart), s);
+    else
+        rc = launch_gn_generic(P->dtype, s1, s2, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups, gam, bet, 1e-5f, sc, sh,
+                               (float*)(ws + o.gn_mr), s);
+    if (rc != DMME_OK || !tsh) return rc;
+    return launch_gn_modulate(sc, sh, tsh, tsc, P->tproj_cols, nt, P->B, o.gn_mod_C, s);
 }
 
 int run_op(const dmme_plan* P, const Op& o, const char* pk, const float* x, const int64_t* t, int nt, float* y,
@@ -875,13 +882,8 @@ int run_op(const dmme_plan* P, const Op& o, const char* pk, const float* x, cons
             return launch_linear_wave(P->dtype, (const float*)(ws + o.lin_in), nt, o.lin_K, w, b, o.lin_N, o.lin_silu,
                                       (float*)(ws + o.lin_out), s);
         }
-        case OP_GN: {
-            const int rc = run_gn(P, o, pk, ws, s);
-            if (rc != DMME_OK || o.gn_mod_col < 0) return rc;
-            const float* tp = (const float*)(ws + P->ws_tproj) + o.gn_mod_col;
-            return launch_gn_modulate((float*)(ws + o.gn_scale), (float*)(ws + o.gn_shift), tp, tp + o.gn_mod_C, P->tproj_cols, nt, P->B,
-                                      o.gn_mod_C, s);
-        }
+        case OP_GN:
+            return run_gn(P, o, pk, ws, nt, s);
         case OP_CONV: {
             ConvArgs a{};
             fill_conv(P, o, pk, x, y, ws, drop_masks, nt, a);
@@ -890,8 +892,11 @@ int run_op(const dmme_plan* P, const Op& o, const char* pk, const float* x, cons
         case OP_ATTN: {
             const Tensor& q = P->tensors[o.at_qkv];
             const int S = q.H * q.W, C = q.C / 3;
-            if (o.at_heads > 1)
+            if (o.at_heads > 1) {
+                if (attn_heads_mfma_supported(P->dtype, P->B, S, C, o.at_heads))
+                    return launch_attn_heads_mfma(P->dtype, ws + q.off, P->B, S, C, o.at_heads, ws + P->tensors[o.at_out].off, (float*)(ws + o.at_lse), s);
                 return launch_attn_heads(P->dtype, ws + q.off, P->B, S, C, o.at_heads, ws + P->tensors[o.at_out].off, s);
+            }
             if (attn_mfma_supported(P->dtype, P->B, S, C))
                 return launch_attn_mfma(P->dtype, ws + q.off, P->B, S, C, ws + P->tensors[o.at_out].off, (float*)(ws + o.at_lse), s);
             return launch_attn_generic(P->dtype, ws + q.off, P->B, S, C, ws + P->tensors[o.at_out].off, s);
@@ -949,7 +954,7 @@ void op_account(const dmme_plan* P, const Op& o, char* label, int cap, double* f
             const Tensor& q = P->tensors[o.at_qkv];
             const double S = q.H * q.W, C = q.C / 3;
             if (o.at_heads > 1)
-                snprintf(label, cap, "attn_heads_kernel<%s>", tn);
+                snprintf(label, cap, attn_heads_mfma_supported(P->dtype, P->B, (int)S, (int)C, o.at_heads) ? "attn_mfma_kernel<%s,heads>" : "attn_generic_kernel<%s,heads>", tn);
             else
                 snprintf(label, cap, attn_mfma_supported(P->dtype, P->B, (int)S, (int)C) ? "attn_mfma_kernel<%s>" : "attn_generic_kernel<%s>", tn);
             *flops = 4.0 * B * S * S * C;
@@ -1218,7 +1223,10 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
             const Tensor& q = P->tensors[o.at_qkv];
             const int S = q.H * q.W, C = q.C / 3;
             DMME_REQUIRE(written[o.at_out], DMME_ERR_INVALID, "backward: attention output has no gradient");
-            if (o.at_heads > 1)
+            if (o.at_heads > 1 && attn_heads_mfma_supported(dt, B, S, C, o.at_heads))
+                rc = launch_attn_heads_bwd_mfma(dt, ws + q.off, ws + P->tensors[o.at_out].off, gptr(o.at_out), (const float*)(ws + o.at_lse), B, S, C,
+                                                o.at_heads, bws + P->bws_attP, bws + P->bws_attdS, gptr(o.at_qkv), s);
+            else if (o.at_heads > 1)
                 rc = launch_attn_heads_bwd(dt, ws + q.off, gptr(o.at_out), B, S, C, o.at_heads, (float*)(bws + P->bws_attP),
                                            (float*)(bws + P->bws_attdS), gptr(o.at_qkv), s);
             else if (attn_bwd_mfma_supported(dt, B, S, C))
@@ -1497,6 +1505,13 @@ DMME_API int dmme_attention(int dtype, const void* qkv, int N, int S, int C, voi
     DMME_REQUIRE(qkv && out && N > 0 && S > 0 && C > 0, DMME_ERR_INVALID, "attention: bad argument");
     if (!force_generic && attn_mfma_supported(dtype, N, S, C)) return launch_attn_mfma(dtype, qkv, N, S, C, out, nullptr, (hipStream_t)stream);
     return launch_attn_generic(dtype, qkv, N, S, C, out, (hipStream_t)stream);
+}
+
+DMME_API int dmme_attention_heads(int dtype, const void* qkv, int N, int S, int C, int heads, void* out, int force_generic, void* stream) {
+    DMME_REQUIRE(qkv && out && N > 0 && S > 0 && C > 0 && heads > 0 && C % heads == 0, DMME_ERR_INVALID, "attention_heads: bad argument");
+    if (!force_generic && attn_heads_mfma_supported(dtype, N, S, C, heads))
+        return launch_attn_heads_mfma(dtype, qkv, N, S, C, heads, out, nullptr, (hipStream_t)stream);
+    return launch_attn_heads(dtype, qkv, N, S, C, heads, out, (hipStream_t)stream);
 }
 
 DMME_API int dmme_nchw_to_nhwc(int dtype, const float* src, int N, int C, int HW, void* dst, void* stream) {

@@ -255,6 +255,12 @@ DMME_API int dmme_groupnorm_scale_shift(int dtype, const void* src1, const void*
  * softmax(q (k*C^-0.5)^T) v   (Attention.forward_attention, models/ddpm.py:54-63). */
 DMME_API int dmme_attention(int dtype, const void* qkv, int N, int S, int C, void* out, int force_generic, void* stream);
 
+/* multi-head self-attention exactly as the reference ships it (MultiHeadAttention.forward_attention,
+ * models/iddpm.py:35-47): qkv [N][S][3C]; head h of image n reads channels [h*3d, (h+1)*3d) as (q | k | v), d = C/heads;
+ * K is scaled by C^-0.5; result row n*heads + h is written to out[(n*heads + h) % N][S][((n*heads + h) / N)*d ...]
+ * (the reference's "(b head)" split merged back as "(head b)").  heads = 1 equals dmme_attention. */
+DMME_API int dmme_attention_heads(int dtype, const void* qkv, int N, int S, int C, int heads, void* out, int force_generic, void* stream);
+
 /* NCHW fp32 <-> NHWC compute-dtype converters (test plumbing for the single-op calls) */
 DMME_API int dmme_nchw_to_nhwc(int dtype, const float* src, int N, int C, int HW, void* dst, void* stream);
 DMME_API int dmme_nhwc_to_nchw(int dtype, const void* src, int N, int C, int HW, float* dst, void* stream);

@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(256) wgrad_cin_small_kernel(ConvArgs a, const 
 // pixels in LDS, thread <-> (4 channels, pixel lane) keeps 4 x 27 accumulators, the pixel lanes are merged through
 // LDS and each workgroup ends with one atomic per weight element.
 template <typename T, bool FIRST>
-__global__ void __launch_bounds__(256) wgrad_thin_kernel(ConvArgs a, const T* __restrict__ dY, float* __restrict__ dW, int tiles_total) {
+__global__ void __launch_bounds__(256) wgrad_thin_kernel(ConvArgs a, const T* __restrict__ dY, float* __restrict__ dW, int tiles_total, int g0) {
     constexpr int PX = 256, KP = 28;
     __shared__ __attribute__((aligned(16))) float lds[256 * 9 * 4];  // coef [PX][KP] (28 KB), then the merge buffer [lanes][9][Cw] (36 KB)
     const int Cw = FIRST ? a.Cout : a.C1, G = FIRST ? a.C1 : a.Cout;
@@ -209,8 +209,8 @@ __global__ void __launch_bounds__(256) wgrad_thin_kernel(ConvArgs a, const T* __
                 const int g = k / 9, tap = k % 9, kh = tap / 3, kw = tap % 3;
                 const int sy = FIRST ? y - 1 + kh : y + 1 - kh, sx = FIRST ? x - 1 + kw : x + 1 - kw;
                 float v = 0.f;
-                if (p < total && g < G && sy >= 0 && sy < H && sx >= 0 && sx < W)
-                    v = FIRST ? xin[(((int64_t)n * G + g) * H + sy) * W + sx] : to_f(dY[(((int64_t)n * H + sy) * W + sx) * G + g]);
+                if (p < total && g0 + g < G && sy >= 0 && sy < H && sx >= 0 && sx < W)
+                    v = FIRST ? xin[(((int64_t)n * G + g0 + g) * H + sy) * W + sx] : to_f(dY[(((int64_t)n * H + sy) * W + sx) * G + g0 + g]);
                 cv[k] = v;
             }
 #pragma unroll
@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(256) wgrad_thin_kernel(ConvArgs a, const T* __
     }
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
-        if (g >= G) break;
+        if (g0 + g >= G) break;
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < 9; ++t)
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(256) wgrad_thin_kernel(ConvArgs a, const T* __
             const int c = e / 9, t = e - c * 9;
             float sum = 0.f;
             for (int l = 0; l < lanes_p; ++l) sum += lds[(l * 9 + t) * Cw + c];
-            const int64_t idx = FIRST ? ((int64_t)c * G + g) * 9 + t : ((int64_t)g * Cw + c) * 9 + t;
+            const int64_t idx = FIRST ? ((int64_t)c * G + g0 + g) * 9 + t : ((int64_t)(g0 + g) * Cw + c) * 9 + t;
             atomicAdd(dW + idx, sum);
         }
     }
@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(256) wgrad_thin_kernel(ConvArgs a, const T* __
 static bool wgrad_thin_supported(const ConvArgs& a) {
     if (a.taps != 9 || a.stride != 1 || a.up || a.C2 || a.dmask || a.Hout != a.Hin || a.Wout != a.Win) return false;
     const int Cw = a.in_nchw ? a.Cout : a.C1, G = a.in_nchw ? a.C1 : a.Cout;
-    if (G > 3 || Cw % 4 || Cw / 4 > 256 || 256 % (Cw / 4)) return false;
+    if (G > 6 || Cw % 4 || Cw / 4 > 256 || 256 % (Cw / 4)) return false;  // thin side: 3 channels per pass (6 = the IDDPM (eps, v) output)
     if ((int64_t)a.N * a.Hout * a.Wout * (Cw > 27 ? Cw : 27) >= (1ll << 31)) return false;
     if (a.in_nchw) return !a.scale && !a.pro_silu;
     return true;
@@ -311,14 +311,17 @@ int launch_wgrad_small(int dtype, const ConvArgs& a, const void* dY, float* dW, 
     if (wgrad_thin_supported(a) && !getenv("DMME_NO_WGRAD_THIN")) {
         const int64_t total = (int64_t)a.N * a.Hout * a.Wout;
         const int tiles = (int)((total + 255) / 256), grid = tiles < 256 ? tiles : 256;  // few workgroups: they all end in atomics on the same addresses
-#define DMME_WTHIN(TT, FF) hipLaunchKernelGGL((wgrad_thin_kernel<TT, FF>), dim3(grid), dim3(256), 0, s, a, (const TT*)dY, dW, tiles)
-        if (dtype == DMME_BF16) {
-            if (a.in_nchw) DMME_WTHIN(bf16, true); else DMME_WTHIN(bf16, false);
-        } else {
-            if (a.in_nchw) DMME_WTHIN(float, true); else DMME_WTHIN(float, false);
+#define DMME_WTHIN(TT, FF) hipLaunchKernelGGL((wgrad_thin_kernel<TT, FF>), dim3(grid), dim3(256), 0, s, a, (const TT*)dY, dW, tiles, g0)
+        const int G = a.in_nchw ? a.C1 : a.Cout;
+        for (int g0 = 0; g0 < G; g0 += 3) {
+            if (dtype == DMME_BF16) {
+                if (a.in_nchw) DMME_WTHIN(bf16, true); else DMME_WTHIN(bf16, false);
+            } else {
+                if (a.in_nchw) DMME_WTHIN(float, true); else DMME_WTHIN(float, false);
+            }
+            DMME_CHECK_LAUNCH();
         }
 #undef DMME_WTHIN
-        DMME_CHECK_LAUNCH();
         return DMME_OK;
     }
     const int rows = a.N * a.Hout;

@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) conv_generic_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------ first-layer convolution
-// 3x3 pad 1 stride 1 on the NCHW fp32 network input (Cin <= 4), NHWC T output: replaces
+// 3x3 pad 1 stride 1 on the NCHW fp32 network input (or a thin NHWC tensor; Cin <= 8), NHWC T output: replaces
 // UNet.input_conv (models/ddpm.py:219).  K = 9*Cin is far too small for MFMA; the op is
 // bound by the output write.  Each thread computes 8 consecutive couts of one pixel from
 // its 9*Cin inputs in registers; weights sit in LDS as [tap*Cin + ci][Cout] fp32.
@@ -232,7 +232,7 @@ bool conv_in_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* 
 }
 
 static bool conv_in_supported(const ConvArgs& a) {
-    return !a.out_nchw && a.taps == 9 && a.stride == 1 && !a.up && a.C2 == 0 && a.C1 <= 4 && !a.scale &&
+    return !a.out_nchw && a.taps == 9 && a.stride == 1 && !a.up && a.C2 == 0 && a.C1 <= 8 && !a.scale &&  // 6: data gradient of the IDDPM (eps, v) conv
            !a.pro_silu && !a.dmask && !a.tproj && !a.res1 && !a.out_silu && a.Cout % 8 == 0 && a.Cout <= 2048 &&
            256 % (a.Cout / 8) == 0 && (size_t)9 * a.C1 * a.Cout * 4 <= 48 * 1024;
 }

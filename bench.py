@@ -282,7 +282,7 @@ def main():
     out = {
         "metric": METRIC,
         "value": round(world * args.steps / elapsed, 3),
-        "unit": f"denoising steps/s (one step = UNet forward + {'DDIM' if args.mode == 'ddim' else 'DDPM'} update on a batch of {B}), summed over GPUs",
+        "unit": f"denoising steps/s (one step = UNet forward + {'DDIM' if args.mode == 'ddim' else 'IDDPM learned-variance' if args.model == 'iddpm64' else 'DDPM'} update on a batch of {B}), summed over GPUs",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,

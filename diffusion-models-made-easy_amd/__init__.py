@@ -8,9 +8,10 @@ __version__ = "0.1.0"
 from . import _lib  # noqa: F401
 from .common.noise import gaussian, gaussian_like, uniform_int, pad  # noqa: F401
 from .common.norm import denorm, norm  # noqa: F401
-from . import models, diffusion_models, equations, lit_modules, lr_scheduler  # noqa: F401
+from . import models, diffusion_models, equations, lit_modules, lr_scheduler, data_modules  # noqa: F401
+from .data_modules import CIFAR10  # noqa: F401
 from .diffusion_models import DDPM, DDIM, IDDPM  # noqa: F401
 from .lit_modules import LitDDPM, LitDDIM, LitIDDPM  # noqa: F401
 from .models.ddpm import UNet  # noqa: F401
 
-__all__ = ["gaussian", "gaussian_like", "uniform_int", "pad", "denorm", "norm", "UNet", "DDPM", "DDIM", "LitDDPM", "LitDDIM", "IDDPM", "LitIDDPM"]
+__all__ = ["gaussian", "gaussian_like", "uniform_int", "pad", "denorm", "norm", "UNet", "DDPM", "DDIM", "LitDDPM", "LitDDIM", "IDDPM", "LitIDDPM", "CIFAR10"]

@@ -94,6 +94,7 @@ PROTOTYPES = {
     "dmme_ddpm_step": (_i, [_vp, _vp, _vp, _f, _f, _f, _i, _i64, _vp]),
     "dmme_ddim_step": (_i, [_vp, _vp, _f, _f, _i64, _vp]),
     "dmme_mse_loss": (_i, [_vp, _vp, _i64, _vp, _vp, _f, _vp, _vp]),
+    "dmme_image_batch": (_i, [_vp, _i64, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "dmme_iddpm_step": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _i, _i, _i64, _vp]),
     "dmme_iddpm_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _f, _vp, _vp, _f, _vp, _vp]),
     "dmme_conv2d": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),

@@ -209,6 +209,7 @@ int launch_q_sample(const float* x0, const float* z, const float* sqrt_abar, con
 int launch_ddpm_step(float* x, const float* eps, const float* z, float c1, float c2, float sigma, int add_noise,
                      int64_t numel, hipStream_t s);
 int launch_ddim_step(float* x, const float* eps, float s1, float s2, int64_t numel, hipStream_t s);
+int launch_image_batch(const uint8_t* data, const int64_t* idx, const uint8_t* flip, int B, int C, int H, int W, float* out, hipStream_t s);
 int launch_iddpm_step(float* x, const float* out, const float* z, float c1, float c2, float log_beta, float log_beta_tilde, int add_noise,
                       int B, int64_t chw, hipStream_t s);
 int launch_iddpm_loss(const float* out, const float* x_t, const float* x_0, const float* target, const int64_t* t, const float* coef, int B,

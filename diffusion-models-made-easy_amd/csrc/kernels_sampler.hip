@@ -321,4 +321,40 @@ int launch_iddpm_loss(const float* out, const float* x_t, const float* x_0, cons
     return DMME_OK;
 }
 
+// ------------------------------------------------------------------ input pipeline: HBM-resident uint8 dataset -> training batch
+// out[b][c][y][x] = norm(ToTensor(flip_b(data[idx[b]])))[c][y][x]: torchvision's ToTensor (uint8 -> float / 255) followed by the
+// reference's norm, (x - 0.5) * 2 (src/dmme/common/norm.py:4-6), and RandomHorizontalFlip as a per-image bit
+// (data_modules/cifar10.py:33-44).  data: [n_images][C][H][W] uint8 (the CIFAR10 pickle's own layout).  One thread per 4 pixels.
+__global__ void __launch_bounds__(256) image_batch_kernel(const uint8_t* __restrict__ data, const int64_t* __restrict__ idx,
+                                                          const uint8_t* __restrict__ flip, int C, int H, int W, int64_t total4,
+                                                          float* __restrict__ out) {
+    const int W4 = W / 4;
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total4; q += (int64_t)gridDim.x * blockDim.x) {
+        const int x4 = (int)(q % W4);
+        int64_t r = q / W4;
+        const int y = (int)(r % H);
+        r /= H;
+        const int c = (int)(r % C), b = (int)(r / C);
+        const uint8_t* row = data + ((idx[b] * C + c) * H + y) * (int64_t)W;
+        const bool fl = flip && flip[b];
+        const uint32_t raw = *reinterpret_cast<const uint32_t*>(row + (fl ? W - 4 - 4 * x4 : 4 * x4));
+        float4 o;
+        float* ov = reinterpret_cast<float*>(&o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t u = (raw >> (8 * (fl ? 3 - j : j))) & 0xffu;
+            ov[j] = __fmul_rn(__fsub_rn(__fdiv_rn((float)u, 255.0f), 0.5f), 2.0f);
+        }
+        *reinterpret_cast<float4*>(out + (((int64_t)b * C + c) * H + y) * W + 4 * x4) = o;
+    }
+}
+int launch_image_batch(const uint8_t* data, const int64_t* idx, const uint8_t* flip, int B, int C, int H, int W, float* out, hipStream_t s) {
+    DMME_REQUIRE(W % 4 == 0, DMME_ERR_UNSUPPORTED, "image_batch: width %d is not a multiple of 4", W);
+    const int64_t total4 = (int64_t)B * C * H * (W / 4);
+    if (total4 <= 0) return DMME_OK;
+    hipLaunchKernelGGL(image_batch_kernel, dim3(grid_for(total4)), dim3(256), 0, s, data, idx, flip, C, H, W, total4, out);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
 }  // namespace dmme

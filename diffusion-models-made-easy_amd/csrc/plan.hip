@@ -1436,6 +1436,12 @@ DMME_API int dmme_ddim_step(float* x, const float* eps, float sqrt_one_minus_aba
     return launch_ddim_step(x, eps, sqrt_one_minus_abar, sqrt_abar_prev, numel, (hipStream_t)stream);
 }
 
+DMME_API int dmme_image_batch(const uint8_t* data, int64_t n_images, const int64_t* idx, const uint8_t* flip, int B, int C, int H, int W,
+                              float* out, void* stream) {
+    DMME_REQUIRE(data && idx && out && n_images > 0 && B > 0 && C > 0 && H > 0 && W > 0, DMME_ERR_INVALID, "image_batch: bad argument");
+    return launch_image_batch(data, idx, flip, B, C, H, W, out, (hipStream_t)stream);
+}
+
 DMME_API int dmme_iddpm_step(float* x, const float* model_out, const float* z, float inv_sqrt_alpha, float eps_coef, float log_beta,
                              float log_beta_tilde, int add_noise, int B, int64_t chw, void* stream) {
     DMME_REQUIRE(x && model_out && (z || !add_noise) && B > 0 && chw > 0, DMME_ERR_INVALID, "iddpm_step: bad argument");

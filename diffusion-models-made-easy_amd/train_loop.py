@@ -30,7 +30,7 @@ def train_step(module, optimizer, scheduler, x0, clip=None):
     return loss
 
 
-def fit(module, batch_size=128, max_steps=100, clip=None, log_every=50):
+def fit(module, batch_size=128, max_steps=100, clip=None, log_every=50, loader=None):
     dev = next(module.parameters()).device
     module.train()
     opts, scheds = module.configure_optimizers()
@@ -40,8 +40,16 @@ def fit(module, batch_size=128, max_steps=100, clip=None, log_every=50):
             g["max_grad_norm"] = float(clip)
     sched = scheds[0]["scheduler"] if scheds else None
     t0 = time.perf_counter()
+    batches = None
     for step in range(max_steps):
-        x0 = synthetic_batch(batch_size, dev)
+        if loader is None:
+            x0 = synthetic_batch(batch_size, dev)
+        else:  # epochs over the HBM-resident set: a fresh permutation each time the loader is exhausted
+            try:
+                x0 = next(batches)[0]
+            except (StopIteration, TypeError):
+                batches = iter(loader)
+                x0 = next(batches)[0]
         loss = train_step(module, opt, sched, x0, clip)
         if (step + 1) % log_every == 0 or step + 1 == max_steps:
             torch.cuda.synchronize()

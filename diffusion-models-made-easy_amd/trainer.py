@@ -6,7 +6,8 @@ same YAML with PyYAML, honours the keys that affect the hot path and ignores the
 Lightning-only ones (loggers, checkpoint callbacks, ...):
 
   model.class_path / init_args[.model.init_args]   -> dmme_amd.LitDDPM / LitDDIM (+ UNet overrides)
-  data.init_args.batch_size                         -> synthetic batches of that size
+  data.init_args.batch_size                         -> synthetic batches of that size (default), or with `--data config`
+                                                       the YAML's data module (dmme.CIFAR10: HBM-resident uint8 set, GPU flip + norm)
   trainer.max_steps, gradient_clip_val, precision, log_every_n_steps, devices
   seed_everything
 
@@ -30,6 +31,8 @@ import yaml
 def _resolve(class_path: str):
     """`dmme.X` in a reference YAML means this package's drop-in X."""
     mod, _, name = class_path.rpartition(".")
+    if class_path == "torchvision.transforms.RandomHorizontalFlip":  # the flip runs on the GPU inside dmme_image_batch
+        mod = "dmme_amd.data_modules"
     if mod == "dmme" or mod.startswith("dmme."):
         mod = "dmme_amd" + mod[4:]
     return getattr(importlib.import_module(mod), name)
@@ -52,6 +55,7 @@ def parse_config(path: str) -> Dict[str, Any]:
     precision = trainer.get("precision", 32)
     return {
         "model_spec": cfg["model"],
+        "data_spec": cfg.get("data"),
         "batch_size": int(data_args.get("batch_size", 128)),
         "max_steps": int(trainer.get("max_steps") or -1),
         "gradient_clip_val": trainer.get("gradient_clip_val"),
@@ -76,6 +80,8 @@ def main(argv=None):
     ap.add_argument("--config", required=True)
     ap.add_argument("--max-steps", type=int, default=None)
     ap.add_argument("--batch-size", type=int, default=None)
+    ap.add_argument("--data", default="synthetic", choices=["synthetic", "config"],
+                    help="fit: 'config' instantiates the YAML's data module (falls back to a random byte set when the CIFAR10 files are absent)")
     ap.add_argument("--num-images", type=int, default=16)
     ap.add_argument("--steps", type=int, default=None, help="sample: stop after this many denoising steps")
     args = ap.parse_args(argv)
@@ -105,7 +111,18 @@ def main(argv=None):
     from .train_loop import fit
 
     steps = args.max_steps if args.max_steps is not None else conf["max_steps"]
-    fit(module, batch_size=B, max_steps=steps, clip=conf["gradient_clip_val"], log_every=conf["log_every_n_steps"])
+    loader = None
+    if args.data == "config" and conf["data_spec"]:
+        dm = _instantiate(conf["data_spec"])
+        dm.batch_size = B
+        try:
+            dm.prepare_data()
+        except FileNotFoundError as e:
+            print(json.dumps({"data": "random bytes (dataset files absent)", "reason": str(e)[:160]}), flush=True)
+            dm.synthetic = True
+        dm.setup("fit")
+        loader = dm.train_dataloader()
+    fit(module, batch_size=B, max_steps=steps, clip=conf["gradient_clip_val"], log_every=conf["log_every_n_steps"], loader=loader)
     return 0
 
 

@@ -197,6 +197,15 @@ DMME_API int dmme_ddim_step(float* x, const float* eps, float sqrt_one_minus_aba
 DMME_API int dmme_mse_loss(const float* eps, const float* target, int64_t numel, float* loss, float* d_eps,
                   float grad_scale, float* scratch, void* stream);
 
+/* ---- input pipeline: training batch from an HBM-resident uint8 image set ---------------------------------------------
+ * Replaces the per-sample transform chain of the reference's data module (data_modules/cifar10.py:39-44:
+ * [RandomHorizontalFlip] -> torchvision ToTensor (uint8 / 255) -> norm, common/norm.py:4-6) plus the DataLoader's collate:
+ *   out[b] = (flip[b] ? hflip : id)(data[idx[b]]) / 255, then (x - 0.5) * 2, fp32 NCHW.
+ * data: [n_images][C][H][W] uint8 (the CIFAR10 python-pickle layout); idx: int64[B] (caller guarantees 0 <= idx < n_images);
+ * flip: uint8[B] or NULL (no augmentation, the reference's test set); W must be a multiple of 4. */
+DMME_API int dmme_image_batch(const uint8_t* data, int64_t n_images, const int64_t* idx, const uint8_t* flip, int B, int C, int H, int W,
+                     float* out, void* stream);
+
 /* ---- Improved DDPM (learned variance): model_out is (B, 2C, H, W), channels [0, C) = eps, [C, 2C) = v
  * (IDDPM.forward_model, diffusion_models/iddpm.py:152-164); chw = C*H*W of ONE image of x. */
 

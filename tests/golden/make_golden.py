@@ -521,6 +521,14 @@ def gen_iddpm_process(out):
                     out[f"traj_{sched}_step{k}"] = x.numpy()
 
 
+def gen_data(out):
+    """the reference's norm / denorm (common/norm.py) on every byte value as torchvision's ToTensor would hand it over"""
+    x = torch.arange(256, dtype=torch.float32).div(255)
+    out["norm_u8_table"] = dmme.norm(x).numpy()
+    out["denorm_of_norm"] = dmme.denorm(dmme.norm(x)).numpy()
+    out["denorm_clip"] = dmme.denorm(torch.tensor([-3.0, -1.0, 0.0, 0.25, 1.0, 7.0])).numpy()
+
+
 def main():
     torch.manual_seed(0)
     groups = {
@@ -532,6 +540,7 @@ def main():
         "traj_tiny": gen_traj,
         "iddpm_unet": gen_iddpm_unet,
         "iddpm_process": gen_iddpm_process,
+        "data": gen_data,
     }
     only = sys.argv[1:]
     for name, fn in groups.items():

@@ -91,3 +91,73 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.no_grad():
                 flat.copy_(live)
                 model.mark_params_updated()
+
+    # ------------------------------------------------------------------ checkpoint layout of the reference's EMAOptimizer
+    def _param_slices(self, model):
+        """(param, flat offset, numel) for every optimised parameter of `model`, in optimiser order"""
+        flat = model.flat_parameters()
+        base = flat.data_ptr()
+        out = []
+        for group in self.param_groups:
+            for p in group["params"]:
+                owner = p._dmme_owner()
+                if owner is model:
+                    out.append((p, (p.data_ptr() - base) // 4, p.numel()))
+        return out
+
+    def state_dict(self):
+        """Same layout as the reference's `EMAOptimizer.state_dict()` (callbacks/ema.py:339-359): {"opt": the wrapped
+        torch.optim.Adam's state_dict (per-parameter `step` / `exp_avg` / `exp_avg_sq`, loadable by a stock
+        torch.optim.Adam), "ema": tuple of per-parameter EMA tensors, "current_step", "decay", "every_n_steps", "device"}."""
+        g0 = self.param_groups[0]
+        state, ema, index = {}, [], 0
+        device = None
+        for m in self._owners:
+            st = self._flat_state.get(id(m))
+            flat = m.flat_parameters()
+            device = flat.device
+            for p, off, n in self._param_slices(m):
+                if st is not None:
+                    state[index] = {"step": torch.tensor(float(self._step_count)), "exp_avg": st["m"][off : off + n].view(p.shape).clone(),
+                                    "exp_avg_sq": st["v"][off : off + n].view(p.shape).clone()}
+                src = st["ema"] if st is not None and st["ema"] is not None else flat
+                ema.append(src[off : off + n].view(p.shape).clone())
+                index += 1
+        group = {"lr": g0["lr"], "betas": tuple(g0["betas"]), "eps": g0["eps"], "weight_decay": 0, "amsgrad": False, "maximize": False, "foreach": None,
+                 "capturable": False, "differentiable": False, "fused": None, "params": list(range(index))}
+        if "initial_lr" in g0:
+            group["initial_lr"] = g0["initial_lr"]
+        return {"opt": {"state": state, "param_groups": [group]}, "ema": tuple(ema), "current_step": self._step_count,
+                "decay": float(g0["ema_decay"] or 0.0), "every_n_steps": 1, "device": device,
+                "max_grad_norm": float(g0["max_grad_norm"] or 0.0)}
+
+    def load_state_dict(self, state_dict):
+        """accepts the layout above (written by this class or by the reference's EMAOptimizer around torch.optim.Adam)"""
+        opt = state_dict["opt"]
+        pg = opt["param_groups"][0]
+        for g in self.param_groups:
+            g["lr"], g["betas"], g["eps"] = pg["lr"], tuple(pg["betas"]), pg["eps"]
+            if "initial_lr" in pg:
+                g["initial_lr"] = pg["initial_lr"]
+            g["ema_decay"] = state_dict.get("decay", g["ema_decay"])
+            if "max_grad_norm" in state_dict:
+                g["max_grad_norm"] = state_dict["max_grad_norm"]
+        self._step_count = int(state_dict.get("current_step", 0))
+        ema_list = list(state_dict.get("ema") or [])
+        index = 0
+        with torch.no_grad():
+            for m in self._owners:
+                flat = m.flat_parameters()
+                decay = float(self.param_groups[0]["ema_decay"] or 0.0)
+                st = {"m": torch.zeros_like(flat), "v": torch.zeros_like(flat), "norm": torch.zeros(1, device=flat.device),
+                      "scratch": torch.empty(1024, device=flat.device), "ema": flat.clone() if (decay > 0 or ema_list) else None}
+                for p, off, n in self._param_slices(m):
+                    ps = opt["state"].get(index)
+                    if ps is not None:
+                        st["m"][off : off + n].copy_(ps["exp_avg"].reshape(-1))
+                        st["v"][off : off + n].copy_(ps["exp_avg_sq"].reshape(-1))
+                        self._step_count = max(self._step_count, int(float(ps["step"])))
+                    if ema_list:
+                        st["ema"][off : off + n].copy_(ema_list[index].reshape(-1))
+                    index += 1
+                self._flat_state[id(m)] = st

@@ -30,7 +30,7 @@ def train_step(module, optimizer, scheduler, x0, clip=None):
     return loss
 
 
-def fit(module, batch_size=128, max_steps=100, clip=None, log_every=50, loader=None):
+def fit(module, batch_size=128, max_steps=100, clip=None, log_every=50, loader=None, ckpt_path=None, save_path=None):
     dev = next(module.parameters()).device
     module.train()
     opts, scheds = module.configure_optimizers()
@@ -39,9 +39,14 @@ def fit(module, batch_size=128, max_steps=100, clip=None, log_every=50, loader=N
         for g in opt.param_groups:
             g["max_grad_norm"] = float(clip)
     sched = scheds[0]["scheduler"] if scheds else None
+    first = 0
+    if ckpt_path:
+        from .checkpoint import load_checkpoint
+
+        first = int(load_checkpoint(ckpt_path, module, opt, sched).get("global_step", 0))
     t0 = time.perf_counter()
     batches = None
-    for step in range(max_steps):
+    for step in range(first, max_steps):
         if loader is None:
             x0 = synthetic_batch(batch_size, dev)
         else:  # epochs over the HBM-resident set: a fresh permutation each time the loader is exhausted
@@ -54,5 +59,9 @@ def fit(module, batch_size=128, max_steps=100, clip=None, log_every=50, loader=N
         if (step + 1) % log_every == 0 or step + 1 == max_steps:
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            print(json.dumps({"step": step + 1, "train/loss": round(float(loss.detach()), 5), "images_per_s": round((step + 1) * batch_size / dt, 1)}), flush=True)
+            print(json.dumps({"step": step + 1, "train/loss": round(float(loss.detach()), 5), "images_per_s": round((step + 1 - first) * batch_size / dt, 1)}), flush=True)
+    if save_path and D.env_rank_world()[0] == 0:
+        from .checkpoint import save_checkpoint
+
+        save_checkpoint(save_path, module, opt, sched, global_step=max(max_steps, first))
     return module

@@ -63,6 +63,7 @@ def parse_config(path: str) -> Dict[str, Any]:
         "log_every_n_steps": int(trainer.get("log_every_n_steps") or 50),
         "devices": trainer.get("devices", 1),
         "seed": cfg.get("seed_everything", 1337),
+        "ckpt_path": cfg.get("ckpt_path"),
     }
 
 
@@ -82,6 +83,8 @@ def main(argv=None):
     ap.add_argument("--batch-size", type=int, default=None)
     ap.add_argument("--data", default="synthetic", choices=["synthetic", "config"],
                     help="fit: 'config' instantiates the YAML's data module (falls back to a random byte set when the CIFAR10 files are absent)")
+    ap.add_argument("--ckpt-path", default=None, help="resume / sample from a Lightning-layout checkpoint (the YAML's ckpt_path key)")
+    ap.add_argument("--save-checkpoint", default=None, help="fit: write a Lightning-layout checkpoint (weights, Adam moments, EMA copy) at the end")
     ap.add_argument("--num-images", type=int, default=16)
     ap.add_argument("--steps", type=int, default=None, help="sample: stop after this many denoising steps")
     args = ap.parse_args(argv)
@@ -92,7 +95,12 @@ def main(argv=None):
     module = build_module(conf).cuda()
     B = args.batch_size or conf["batch_size"]
 
+    ckpt_path = args.ckpt_path or conf.get("ckpt_path")
     if args.command == "sample":
+        if ckpt_path:
+            from .checkpoint import load_checkpoint
+
+            load_checkpoint(ckpt_path, module, strict=False)
         module.eval()
         dm = module.diffusion_model
         t0 = time.perf_counter()
@@ -122,7 +130,8 @@ def main(argv=None):
             dm.synthetic = True
         dm.setup("fit")
         loader = dm.train_dataloader()
-    fit(module, batch_size=B, max_steps=steps, clip=conf["gradient_clip_val"], log_every=conf["log_every_n_steps"], loader=loader)
+    fit(module, batch_size=B, max_steps=steps, clip=conf["gradient_clip_val"], log_every=conf["log_every_n_steps"], loader=loader,
+        ckpt_path=ckpt_path, save_path=args.save_checkpoint)
     return 0
 
 

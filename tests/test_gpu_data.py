@@ -82,6 +82,13 @@ def test_trainer_fit_with_the_yaml_data_module(tmp_path, capsys):
     }
     path = tmp_path / "cfg.yaml"
     path.write_text(yaml.safe_dump(cfg))
-    assert trainer.main(["fit", "--config", str(path), "--data", "config"]) == 0
+    ck = str(tmp_path / "last.ckpt")
+    assert trainer.main(["fit", "--config", str(path), "--data", "config", "--save-checkpoint", ck]) == 0
     lines = [json.loads(l) for l in capsys.readouterr().out.strip().splitlines()]
     assert lines[-1]["step"] == 4 and np.isfinite(lines[-1]["train/loss"])
+    # resume from the Lightning-layout checkpoint for two more steps, then sample from it
+    assert trainer.main(["fit", "--config", str(path), "--data", "config", "--ckpt-path", ck, "--max-steps", "6"]) == 0
+    lines = [json.loads(l) for l in capsys.readouterr().out.strip().splitlines()]
+    assert [l["step"] for l in lines] == [6]
+    assert trainer.main(["sample", "--config", str(path), "--ckpt-path", ck, "--num-images", "2", "--steps", "3"]) == 0
+    assert json.loads(capsys.readouterr().out.strip().splitlines()[-1])["finite"]

@@ -215,3 +215,64 @@ def test_swap_ema_weights_for_sampling():
         y_back = model(x, t).clone()
     assert torch.equal(y_live, y_back)
     assert not torch.equal(y_live, y_ema)
+
+
+def test_checkpoint_layout_round_trip_and_torch_adam_interop(tmp_path):
+    """The optimiser state is written in the reference's EMAOptimizer layout ({"opt", "ema", "current_step", ...},
+    callbacks/ema.py:339-359): a stock torch.optim.Adam loads "opt" and takes the same next step; a fresh model +
+    FusedAdam restored from the file continues bit-identically."""
+    import dmme_amd
+    from dmme_amd.checkpoint import load_checkpoint, save_checkpoint
+    from dmme_amd.optim import FusedAdam
+
+    cfg = O.TINY
+
+    def make():
+        lit = dmme_amd.LitDDPM(model=_build(cfg, 5), timesteps=100, warmup=3).cuda()
+        opts, scheds = lit.configure_optimizers()
+        return lit, opts[0], scheds[0]["scheduler"]
+
+    def set_grads(net, step):
+        net.flat_grad()
+        gen = torch.Generator().manual_seed(100 + step)
+        for _, p in net.named_parameters():
+            p.grad.copy_((torch.randn(p.shape, generator=gen) * 0.1).cuda())
+
+    lit, opt, sched = make()
+    net = lit.diffusion_model.model
+    for step in range(3):
+        set_grads(net, step)
+        opt.step()
+        sched.step()
+    path = str(tmp_path / "last.ckpt")
+    save_checkpoint(path, lit, opt, sched, global_step=3)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(ck) >= {"state_dict", "optimizer_states", "lr_schedulers", "global_step"}
+    assert all(k.startswith("diffusion_model.model.") for k in ck["state_dict"])
+    osd = ck["optimizer_states"][0]
+    assert set(osd) >= {"opt", "ema", "current_step", "decay", "every_n_steps", "device"}
+    assert osd["current_step"] == 3 and len(osd["ema"]) == len(list(net.parameters())) == len(osd["opt"]["state"])
+    # a stock Adam takes the same 4th step from the saved moments
+    ref_params = [p.detach().cpu().clone().requires_grad_(True) for p in net.parameters()]
+    ref_opt = torch.optim.Adam(ref_params, lr=1.0)
+    ref_opt.load_state_dict(osd["opt"])
+    set_grads(net, 3)
+    for rp, p in zip(ref_params, net.parameters()):
+        rp.grad = p.grad.detach().cpu().clone()
+    lr_now = opt.param_groups[0]["lr"]
+    assert ref_opt.param_groups[0]["lr"] == lr_now
+    ref_opt.step()
+    # restored copy continues identically
+    lit2, opt2, sched2 = make()
+    with torch.no_grad():
+        lit2.diffusion_model.model.flat_parameters().add_(1.0)  # make sure the weights really come from the file
+    load_checkpoint(path, lit2, opt2, sched2)
+    net2 = lit2.diffusion_model.model
+    set_grads(net2, 3)
+    opt.step()
+    opt2.step()
+    for rp, p, p2 in zip(ref_params, net.parameters(), net2.parameters()):
+        assert torch.equal(p, p2)
+        np.testing.assert_allclose(p.detach().cpu().numpy(), rp.detach().numpy(), rtol=0, atol=2e-7)
+    assert torch.equal(opt.ema_parameters(net), opt2.ema_parameters(net2))
+    assert sched2.state_dict()["last_epoch"] == sched.state_dict()["last_epoch"]

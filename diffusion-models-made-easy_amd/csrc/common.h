@@ -123,6 +123,11 @@ struct ConvArgs {
     int gn_cg, gn_tiles;
     // diagnostic (null: off): per-phase cycle stamps of a few workgroups, [slot][64] (dmme_debug_set_stamps)
     long long* stamps;
+    // split-K scratch (null: off): fp32 partial outputs [ksplit][N*Hout*Wout][Cout] of layers with too few output tiles to fill
+    // the chip (4x4 maps: 128 workgroups, each streaming every filter of its 64 couts); summed by conv_splitk_finish_kernel,
+    // which also applies bias / time row / residual.  splitk_cap: capacity in floats.
+    float* splitk;
+    int64_t splitk_cap;
 };
 
 // ---- kernel launchers (defined in the .hip files) ------------------------------------

@@ -25,11 +25,14 @@ namespace dmme {
 //     layers whose per-interval matrix work is too short to hide a global-load round trip);
 // UA: halo 16-byte units a thread may own (a_rows * 8 <= 256 * UA).
 template <typename T, int BM, int BN, int GT, int PIPE_UA>
-__global__ void __launch_bounds__(256, GT == 9 ? 1 : 2) conv3x3_pipe_kernel(ConvArgs a, ConvTile g, int shTW, int shTH) {
+__global__ void __launch_bounds__(256, GT == 9 ? 1 : 2) conv3x3_pipe_kernel(ConvArgs a, ConvTile g, int shTW, int shTH, int ksplit) {
     constexpr int KC = Frag<T>::KC, EPV = Frag<T>::EPV;
     constexpr int MI = BM / 64, NI = BN / 64;
     constexpr int UB = BN / 32;  // filter units per thread per tap
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    // diagnostic stamps (tools/stamp_pipe.py): wave 0 of workgroups 0 and 1 - entry, first tiles staged, main loop done, exit
+#define PIPE_STAMP(K) do { if (a.stamps && blockIdx.x < 2 && blockIdx.y == 0 && threadIdx.x == 0) a.stamps[blockIdx.x * 8 + (K)] = (long long)wall_clock64(); } while (0)
+    PIPE_STAMP(0);
     char* ldsA = lds;
     char* ldsB = lds + (size_t)g.a_rows * ROW_DATA;
 
@@ -46,6 +49,32 @@ __global__ void __launch_bounds__(256, GT == 9 ? 1 : 2) conv3x3_pipe_kernel(Conv
     const int Cin = a.C1 + a.C2;
     const int Hv = a.up ? 2 * a.Hin : a.Hin, Wv = a.up ? 2 * a.Win : a.Win;
     const int mTW = (1 << shTW) - 1, mTH = (1 << shTH) - 1;
+
+    // split-K (ksplit > 1): blockIdx.y owns a contiguous range of the Cin chunks and writes raw fp32 partial sums
+    const int nchunks_all = Cin / KC;
+    const int ch_begin = ksplit > 1 ? (int)blockIdx.y * nchunks_all / ksplit : 0;
+    const int nchunks = ksplit > 1 ? ((int)blockIdx.y + 1) * nchunks_all / ksplit : nchunks_all;
+
+    // the first filter group goes out before anything else: its round trip overlaps the halo descriptor arithmetic below
+    // (stamps: 3.1 us from kernel entry to the first load otherwise - instruction fetch of a cold kernel included)
+    int b_off[UB];  // element offset of (cout row, tap 0, cin 0) + this thread's 16-byte chunk; -1: past Cout
+#pragma unroll
+    for (int k = 0; k < UB; ++k) {
+        const int co = co0 + urow + 32 * k;
+        b_off[k] = co < a.Cout ? co * 9 * Cin + cu * EPV : -1;
+    }
+    uint4 breg[GT][UB];
+    const T* wbase = (const T*)a.w;
+    auto load_B = [&](int c0, int grp) {
+#pragma unroll
+        for (int j = 0; j < GT; ++j)
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                breg[j][k] = make_uint4(0u, 0u, 0u, 0u);
+                if (b_off[k] >= 0) breg[j][k] = *reinterpret_cast<const uint4*>(wbase + b_off[k] + (grp * GT + j) * Cin + c0);
+            }
+    };
+    load_B(ch_begin * KC, 0);
 
     // ---- chunk-invariant staging descriptors ----
     int a_pix[PIPE_UA];  // source pixel index, -1: zero (padding / past the batch), -2: no such unit
@@ -69,12 +98,6 @@ __global__ void __launch_bounds__(256, GT == 9 ? 1 : 2) conv3x3_pipe_kernel(Conv
                 }
             }
         }
-    }
-    int b_off[UB];  // element offset of (cout row, tap 0, cin 0) + this thread's 16-byte chunk; -1: past Cout
-#pragma unroll
-    for (int k = 0; k < UB; ++k) {
-        const int co = co0 + urow + 32 * k;
-        b_off[k] = co < a.Cout ? co * 9 * Cin + cu * EPV : -1;
     }
     // fragment read bases
     int a_row[MI];
@@ -101,8 +124,6 @@ __global__ void __launch_bounds__(256, GT == 9 ? 1 : 2) conv3x3_pipe_kernel(Conv
             for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.f;
 
     uint4 areg[PIPE_UA];
-    uint4 breg[GT][UB];
-    const T* wbase = (const T*)a.w;
 
     auto load_A = [&](int c0) {
         const bool second = c0 >= a.C1;
@@ -127,15 +148,6 @@ __global__ void __launch_bounds__(256, GT == 9 ? 1 : 2) conv3x3_pipe_kernel(Conv
             *reinterpret_cast<uint4*>(ldsA + swz_off(urow + 32 * i, cu)) = val;
         }
     };
-    auto load_B = [&](int c0, int grp) {
-#pragma unroll
-        for (int j = 0; j < GT; ++j)
-#pragma unroll
-            for (int k = 0; k < UB; ++k) {
-                breg[j][k] = make_uint4(0u, 0u, 0u, 0u);
-                if (b_off[k] >= 0) breg[j][k] = *reinterpret_cast<const uint4*>(wbase + b_off[k] + (grp * GT + j) * Cin + c0);
-            }
-    };
     auto store_B = [&]() {
 #pragma unroll
         for (int j = 0; j < GT; ++j)
@@ -144,17 +156,17 @@ __global__ void __launch_bounds__(256, GT == 9 ? 1 : 2) conv3x3_pipe_kernel(Conv
                 *reinterpret_cast<uint4*>(ldsB + j * BN * ROW_DATA + swz_off(urow + 32 * k, cu)) = breg[j][k];
     };
 
-    // ---- prologue: first halo chunk + first filter row ----
-    load_A(0);
-    load_B(0, 0);
-    store_A(0);
+    // ---- prologue: first halo chunk (the first filter group is already in flight) ----
+    load_A(ch_begin * KC);
+    PIPE_STAMP(1);
+    store_A(ch_begin * KC);
     store_B();
     __syncthreads();
+    PIPE_STAMP(2);
 
-    const int nchunks = Cin / KC;
     constexpr int NG = 9 / GT;  // groups per Cin chunk
 #pragma unroll 1
-    for (int ch = 0; ch < nchunks; ++ch) {
+    for (int ch = ch_begin; ch < nchunks; ++ch) {
 #pragma unroll 1
         for (int grp = 0; grp < NG; ++grp) {
             // issue the next group's loads before the matrix work
@@ -208,7 +220,69 @@ __global__ void __launch_bounds__(256, GT == 9 ? 1 : 2) conv3x3_pipe_kernel(Conv
         const int n = n0 + tn;
         return n < a.N ? (n * a.Hout + oy0 + ty) * a.Wout + ox0 + tx : -1;
     };
+    PIPE_STAMP(3);
+    if (ksplit > 1) {  // raw partial sums: lane = cout (coalesced 128-byte rows), register = pixel
+        float* part = a.splitk + (int64_t)blockIdx.y * a.N * a.Hout * a.Wout * a.Cout;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int co = co0 + wn0 + ni * 32 + r;
+            if (co >= a.Cout) continue;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int opix = pix_of(wm0 + mi * 32 + (j & 3) + 8 * (j >> 2) + 4 * h);
+                    if (opix >= 0) part[(int64_t)opix * a.Cout + co] = acc[mi][ni][j];
+                }
+        }
+        PIPE_STAMP(4);
+        return;
+    }
     conv_epilogue<T, BM, BN, MI, NI>(a, acc, co0, wn0, r, h, wm0, n0, g.TN, pix_of, reinterpret_cast<float*>(lds), ty_blk * g.tiles_x + tx_blk);
+    PIPE_STAMP(4);
+#undef PIPE_STAMP
+}
+
+// second half of a split-K convolution: sum the partial images, then the usual epilogue (bias, time-embedding row, residual)
+template <typename T>
+__global__ void __launch_bounds__(256) conv_splitk_finish_kernel(ConvArgs a, int ksplit, int64_t total4) {
+    const int C4 = a.Cout / 4, hw = a.Hout * a.Wout;
+    const int64_t slice = (int64_t)a.N * hw * a.Cout;
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total4; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = q / C4;
+        const int c = (int)(q - p * C4) * 4;
+        float4 v = *reinterpret_cast<const float4*>(a.splitk + p * a.Cout + c);
+        for (int z = 1; z < ksplit; ++z) {
+            const float4 u = *reinterpret_cast<const float4*>(a.splitk + z * slice + p * a.Cout + c);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        float f[4] = {v.x, v.y, v.z, v.w};
+        const int n = (int)(p / hw);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float fold = a.bias ? a.bias[c + j] : 0.f;
+            if (a.tproj) fold += a.tproj[(int64_t)(a.nt == 1 ? 0 : n) * a.tproj_ld + c + j];
+            f[j] += fold;
+            if (a.res1) f[j] += to_f(((const T*)a.res1)[p * a.Cout + c + j]);
+            ((T*)a.dst)[p * a.Cout + c + j] = from_f<T>(f[j]);
+        }
+    }
+}
+static int pipe_ksplit(const ConvArgs& a, const ConvTile& g, int pick, int KC) {
+    static const bool off = getenv("DMME_NO_SPLITK") != nullptr;
+    if (off || !a.splitk || pick != 3 || a.stride != 1 || a.gn_part || a.out_silu || a.out_nchw || a.res2 || a.Cout % 4) return 1;
+    const int64_t wgs = (int64_t)g.tiles_m * g.tiles_n;
+    if (wgs > 128) return 1;  // a full wave of workgroups already
+    // stamps (tools/stamp_pipe.py): these layers stream 92 KB per 64-channel chunk per workgroup through ONE CU's L2 port
+    // (~30 GB/s: 4.2 us per chunk against 0.55 us of MFMA) on half of the CUs, and a workgroup costs ~8 us before and after its
+    // chunk loop, so the split only pays while every workgroup still gets its own CU: fill the chip once, no further
+    int ks = (a.C1 + a.C2) / KC;
+    const int room = (int)(256 / wgs);
+    if (ks > room) ks = room;
+    if (ks > 4) ks = 4;
+    const int64_t out = (int64_t)a.N * a.Hout * a.Wout * a.Cout;
+    while (ks > 1 && ks * out > a.splitk_cap) --ks;
+    return ks < 1 ? 1 : ks;
 }
 
 struct WsTile { int n0, oy0, ox0, co0, ts; };
@@ -622,7 +696,8 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
     ConvTile g{};
     const int pick = pipe_pick(a, g);
     DMME_REQUIRE(pick >= 0, DMME_ERR_UNSUPPORTED, "conv_pipe: no tile fits");
-    const dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
+    const int ksplit = pipe_ksplit(a, g, pick, Frag<T>::KC);
+    const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)ksplit);
     if constexpr (sizeof(T) == 2) {
         static const bool ws_off = getenv("DMME_NO_WS") != nullptr;
         ConvTile gw{};
@@ -651,7 +726,7 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
             rc = set_lds_limit(conv3x3_pipe_kernel<T, BM_, BN_, GT_, UA_>, (LIM) * 1024);                                     \
             attr_done[IDX] = rc == DMME_OK;                                                                                   \
         }                                                                                                                     \
-        if (rc == DMME_OK) hipLaunchKernelGGL((conv3x3_pipe_kernel<T, BM_, BN_, GT_, UA_>), grid, dim3(256), lds, s, a, g, shTW, shTH); \
+        if (rc == DMME_OK) hipLaunchKernelGGL((conv3x3_pipe_kernel<T, BM_, BN_, GT_, UA_>), grid, dim3(256), lds, s, a, g, shTW, shTH, ksplit); \
         break;
     switch (pick) {
         DMME_PIPE_CASE(0, 128, 128, 3, 8, 80)
@@ -662,6 +737,11 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
 #undef DMME_PIPE_CASE
     if (rc != DMME_OK) return rc;
     DMME_CHECK_LAUNCH();
+    if (ksplit > 1) {
+        const int64_t total4 = (int64_t)a.N * a.Hout * a.Wout * (a.Cout / 4);
+        hipLaunchKernelGGL(conv_splitk_finish_kernel<T>, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, a, ksplit, total4);
+        DMME_CHECK_LAUNCH();
+    }
     return DMME_OK;
 }
 

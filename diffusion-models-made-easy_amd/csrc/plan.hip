@@ -91,6 +91,7 @@ struct dmme_plan {
     std::unordered_map<std::string, int> named;  // module name -> tensor id
     int64_t ref_numel = 0, packed_bytes = 0, ws_bytes = 0, dropmask_numel = 0;
     int64_t ws_tsin = 0, ws_th1 = 0, ws_temb = 0, ws_tproj = 0, ws_gnpart = 0;
+    int64_t ws_splitk = 0, splitk_floats = 0;  // split-K partial sums of the small-map convolutions (forward and data gradient)
     int tproj_cols = 0;
     int64_t tproj_w_off = 0, tproj_b_off = 0;  // packed byte offsets of the concatenated projection
     int freqs_param = -1;
@@ -511,6 +512,19 @@ int build_plan(dmme_plan* P) {
     }
     P->dropmask_numel = dmask_cursor;
     P->ws_gnpart = ws_alloc((int64_t)(gn_part_max ? gn_part_max : 1) * 4);
+    {   // up to 4 partial images of the widest small-map conv (either direction: its data gradient has Cin outputs)
+        int64_t mx = 0;
+        for (const Op& o : ops) {
+            if (o.kind != OP_CONV || o.taps != 9 || o.src1 < 0 || o.dst < 0) continue;
+            const Tensor &ti = P->tensors[o.src1], &to = P->tensors[o.dst];
+            if (to.H * to.W > 64 || o.stride != 1 || o.up) continue;
+            const int cin = ti.C + (o.src2 >= 0 ? P->tensors[o.src2].C : 0);
+            const int64_t v = (int64_t)B * to.H * to.W * (cin > to.C ? cin : to.C);
+            if (v > mx) mx = v;
+        }
+        P->splitk_floats = 4 * mx;
+        P->ws_splitk = ws_alloc(P->splitk_floats * 4 + 16);
+    }
     P->ws_bytes = ws;
     P->n_launches = (int)ops.size();
 
@@ -708,6 +722,10 @@ void fill_conv(const dmme_plan* P, const Op& o, const char* packed, const float*
         a.res1 = ws + P->tensors[o.res1].off;
         a.R1 = P->tensors[o.res1].C;
         if (o.res2 >= 0) a.res2 = ws + P->tensors[o.res2].off;
+    }
+    if (P->splitk_floats > 0 && ws) {
+        a.splitk = (float*)(ws + P->ws_splitk);
+        a.splitk_cap = P->splitk_floats;
     }
     if (o.dst == -2) {
         a.dst = y;
@@ -1281,6 +1299,10 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
             d.Cout = Cin;
             d.w = pkb + P->params[o.w].packed_bwd_off;
             d.dst = tmp;
+            if (P->splitk_floats > 0) {
+                d.splitk = (float*)(ws + P->ws_splitk);
+                d.splitk_cap = P->splitk_floats;
+            }
             rc = run_any_conv(dt, d, s);
             if (rc != DMME_OK) break;
             const Tensor& t1 = P->tensors[o.src1];

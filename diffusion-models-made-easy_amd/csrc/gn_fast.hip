@@ -150,6 +150,8 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restric
 // statistics) of one tensor, or of the two tensors of a channel concat, into scale/shift (+ mean/rstd).
 // A consumer group of cg = (C1+C2)/groups channels is a whole number of producer groups (C_i/groups each)
 // of exactly one source; every partial of source i covers cnt_i elements.
+template <bool BATCH, bool MOD>  // MOD: scale-shift conditioning folded in (IDDPM blocks).  BATCH: many partials per group (64x64 maps): break the load-latency chain; else the compact loop (a
+                       // kernel this small is dominated by its cold instruction fetch: the unrolled form costs 0.8 us more)
 __global__ void __launch_bounds__(256) gn_finalize_parts_kernel(const float* __restrict__ p1, int t1, int cnt1, int C1,
                                                                 const float* __restrict__ p2, int t2, int cnt2, int C2, int N, int groups,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
@@ -167,14 +169,36 @@ __global__ void __launch_bounds__(256) gn_finalize_parts_kernel(const float* __r
     const int fg = cs / groups;                          // producer (fine) group size
     const int f0 = (second ? c_first - C1 : c_first) / fg, nf = cg / fg;
     float na = 0.f, mean = 0.f, m2 = 0.f;
-    for (int t = 0; t < tiles; ++t)
-        for (int f = 0; f < nf; ++f) {
-            const float* q = p + (((int64_t)n * tiles + t) * groups + f0 + f) * 2;
-            const float delta = q[0] - mean, tot = na + m;
-            mean += delta * (m / tot);
-            m2 += q[1] + delta * delta * (na * m / tot);
-            na = tot;
+    // partials in (tile, fine group) order.  Eight independent loads are issued before their (serial) Chan merges, so the
+    // dependent chain costs one memory latency per eight partials instead of one per partial (64x64 maps: 32+ partials)
+    const int npart = tiles * nf;
+    if constexpr (!BATCH) {
+        for (int t = 0; t < tiles; ++t)
+            for (int f = 0; f < nf; ++f) {
+                const float* q = p + (((int64_t)n * tiles + t) * groups + f0 + f) * 2;
+                const float delta = q[0] - mean, tot = na + m;
+                mean += delta * (m / tot);
+                m2 += q[1] + delta * delta * (na * m / tot);
+                na = tot;
+            }
+    } else
+    for (int k0 = 0; k0 < npart; k0 += 8) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = min(k0 + u, npart - 1);
+            const int t = nf == 1 ? k : k / nf, f = nf == 1 ? 0 : k - t * nf;
+            v[u] = *reinterpret_cast<const float2*>(p + (((int64_t)n * tiles + t) * groups + f0 + f) * 2);
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + u < npart) {
+                const float delta = v[u].x - mean, tot = na + m;
+                mean += delta * (m / tot);
+                m2 += v[u].y + delta * delta * (na * m / tot);
+                na = tot;
+            }
+    }
     const float rstd = 1.0f / sqrtf(m2 / na + eps);
     if (mean_rstd) {
         mean_rstd[(int64_t)i * 2] = mean;
@@ -183,7 +207,7 @@ __global__ void __launch_bounds__(256) gn_finalize_parts_kernel(const float* __r
     for (int j = 0; j < cg; ++j) {
         const int c = c_first + j;
         float a = rstd * gamma[c], b = beta[c] - mean * a;
-        if (t_scale) {  // scale-shift conditioning folded in (same arithmetic as gn_modulate_kernel)
+        if constexpr (MOD) {  // scale-shift conditioning folded in (same arithmetic as gn_modulate_kernel)
             const int64_t r = (int64_t)(nt == 1 ? 0 : n) * t_ld + c;
             const float mm = 1.0f + t_scale[r];
             a = a * mm;
@@ -198,8 +222,16 @@ int launch_gn_finalize_parts(const float* part1, int tiles1, int cnt1, int C1, c
                              const float* gamma, const float* beta, float eps, float* scale, float* shift, float* mean_rstd, const float* t_shift,
                              const float* t_scale, int t_ld, int nt, hipStream_t s) {
     const int tot = N * groups;
-    hipLaunchKernelGGL(gn_finalize_parts_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, part1, tiles1, cnt1, C1, part2, tiles2, cnt2, C2, N,
-                       groups, gamma, beta, eps, scale, shift, mean_rstd, t_shift, t_scale, t_ld, nt);
+    const bool batch = (tiles1 > tiles2 ? tiles1 : tiles2) >= 16;
+#define DMME_GNF(BB, MM)                                                                                                                        \
+    hipLaunchKernelGGL((gn_finalize_parts_kernel<BB, MM>), dim3((tot + 255) / 256), dim3(256), 0, s, part1, tiles1, cnt1, C1, part2, tiles2, cnt2, C2, N, \
+                       groups, gamma, beta, eps, scale, shift, mean_rstd, t_shift, t_scale, t_ld, nt)
+    if (t_scale) {
+        if (batch) DMME_GNF(true, true); else DMME_GNF(false, true);
+    } else {
+        if (batch) DMME_GNF(true, false); else DMME_GNF(false, false);
+    }
+#undef DMME_GNF
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }

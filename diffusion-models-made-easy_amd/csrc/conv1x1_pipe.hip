@@ -16,7 +16,7 @@ namespace dmme {
 __device__ __forceinline__ int swz1(int row, int chunk) { return row * ROW_DATA + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 template <typename T, int BM, int BN>
-__global__ void __launch_bounds__(256, 2) conv1x1_pipe_kernel(ConvArgs a, int HW, int tiles_n) {
+__global__ void __launch_bounds__(256, 2) conv1x1_pipe_kernel(ConvArgs a, int HW, int tiles_n, int xcd_order) {
     constexpr int KC = Frag<T>::KC, EPV = Frag<T>::EPV;
     constexpr int MI = BM / 64, NI = BN / 64;
     constexpr int UA = BM / 32, UB = BN / 32;  // 16-byte units per thread per chunk
@@ -28,7 +28,15 @@ __global__ void __launch_bounds__(256, 2) conv1x1_pipe_kernel(ConvArgs a, int HW
     const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
     const int r = lane & 31, h = lane >> 5;
     const int cu = tid & 7, urow = tid >> 3;
-    const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
+    // The tiles_n cout tiles of one pixel tile read the same activations.  Workgroup L runs on XCD L % 8 and every XCD has its own
+    // L2, so in plain order those re-reads go to HBM once per XCD; xcd_order (pixel tiles a multiple of 8) gives the cout tiles of a
+    // pixel tile consecutive slots on ONE XCD (qkv: 6 tiles, 16.8 MB of activations fetched once instead of up to six times).
+    int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
+    if (xcd_order) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        tile_n = j % tiles_n;
+        tile_m = (j / tiles_n) * 8 + x;
+    }
     const int p0 = tile_m * BM, co0 = tile_n * BN;
     const int Cin = a.C1 + a.C2;
     const int Mtot = a.N * HW;
@@ -187,7 +195,10 @@ static int launch1_t(const ConvArgs& a, hipStream_t s) {
     const int BM = k1Cand[pick][0], BN = k1Cand[pick][1], HW = a.Hout * a.Wout;
     const int64_t M = (int64_t)a.N * HW;
     const int tiles_n = (a.Cout + BN - 1) / BN;
-    const dim3 grid((unsigned)(((M + BM - 1) / BM) * tiles_n));
+    const int64_t tiles_m = (M + BM - 1) / BM;
+    const dim3 grid((unsigned)(tiles_m * tiles_n));
+    static const bool xcd_off = getenv("DMME_NO_XCD_ORDER") != nullptr;
+    const int xcd_order = (!xcd_off && tiles_n > 1 && tiles_m % 8 == 0) ? 1 : 0;
     size_t lds = (size_t)2 * (BM + BN) * ROW_DATA;
     if (lds < (size_t)BM * BN * 4) lds = (size_t)BM * BN * 4;
     static bool attr_done[3] = {false, false, false};
@@ -200,7 +211,7 @@ static int launch1_t(const ConvArgs& a, hipStream_t s) {
             if (e != hipSuccess) rc = DMME_ERR_HIP;                                                                                   \
             attr_done[IDX] = rc == DMME_OK;                                                                                           \
         }                                                                                                                             \
-        if (rc == DMME_OK) hipLaunchKernelGGL((conv1x1_pipe_kernel<T, BM_, BN_>), grid, dim3(256), lds, s, a, HW, tiles_n);           \
+        if (rc == DMME_OK) hipLaunchKernelGGL((conv1x1_pipe_kernel<T, BM_, BN_>), grid, dim3(256), lds, s, a, HW, tiles_n, xcd_order); \
         break;
     switch (pick) {
         DMME_C1_CASE(0, 128, 128)

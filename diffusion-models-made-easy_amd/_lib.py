@@ -44,6 +44,9 @@ class ConvDesc(C.Structure):
         "nt", "tproj_ld", "in_nchw", "out_nchw", "force_generic")]  # 0: best kernel, 1: generic kernel, 2: first-generation MFMA kernel
 
 
+BUCKET_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int64, C.c_int64)  # dmme_bucket_fn
+
+
 class DmmeError(RuntimeError):
     pass
 
@@ -85,6 +88,8 @@ PROTOTYPES = {
     "dmme_unet_plan_bwd_workspace_bytes": (_i64, [_vp]),
     "dmme_unet_pack_params_bwd": (_i, [_vp, _vp, _vp, _vp]),
     "dmme_unet_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dmme_unet_backward_buckets": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, BUCKET_FN, _vp]),
+    "dmme_unet_plan_grad_buckets": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "dmme_grad_norm": (_i, [_vp, _i64, _vp, _vp, _vp]),
     "dmme_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _vp, _f, _f, _vp]),
     "dmme_unet_debug_read": (_i, [_vp, _vp, C.c_char_p, _vp, _i64, C.POINTER(_i64), _vp]),

@@ -119,6 +119,15 @@ struct dmme_plan {
         WgLayer* layers_dev = nullptr;
         WgJob* jobs_dev = nullptr;
     } wg[2];  // 3x3, 1x1
+    // Two-bucket backward (gradient all-reduce overlapped with backward): bucket 0 = the parameters backward finishes first
+    // (up_layers, middle_layers, output_conv: the contiguous tail of the flat buffer), bucket 1 = the rest.  Plan-time split of
+    // every deferred table at that boundary: [0] = bucket 0, [1] = bucket 1.
+    WgGroup wgb[2][2];
+    int op_split = 0;                 // first op (forward order) of bucket 0
+    int64_t bucket_off = 0;           // flat offset where bucket 0 starts
+    int bias_split = 0;               // bias_jobs[bias_split:] belong to bucket 0
+    int unpack_split = 0;             // items_unpack[unpack_split:] belong to bucket 0
+    int tcol_split = 0;               // time-projection columns [tcol_split, tproj_cols) belong to bucket 0
     // batched time-projection gradients: destination (float offset into grad_flat) of every 64-row tile of
     // dtproj^T temb, then of every 32-column tile of the bias sums
     int64_t* tp_tiles_dev = nullptr;
@@ -743,7 +752,7 @@ void fill_conv(const dmme_plan* P, const Op& o, const char* packed, const float*
 
 // Grouped weight gradients: every 3x3 stride-1 conv the all-taps MFMA kernel supports is taken out of the per-layer
 // sequence; its (cout tile, cin tile) pairs are cut into jobs of at most `q` consecutive 64-pixel tiles, longest first.
-void build_wgrad_group(dmme_plan* P, dmme_plan::WgGroup& G, int taps) {
+void build_wgrad_group(dmme_plan* P, dmme_plan::WgGroup& G, int taps, int op_lo = 0, int op_hi = 1 << 30) {
     G.taps = taps;
     if (P->dtype != DMME_BF16 || getenv("DMME_NO_WGRAD_GROUP")) return;
     const int q = taps == 9 ? (getenv("DMME_WG_Q") ? atoi(getenv("DMME_WG_Q")) : 64) : (getenv("DMME_WG_Q1") ? atoi(getenv("DMME_WG_Q1")) : 64);
@@ -751,7 +760,7 @@ void build_wgrad_group(dmme_plan* P, dmme_plan::WgGroup& G, int taps) {
     std::vector<Grp> groups;
     for (int oi = (int)P->ops.size() - 1; oi >= 0; --oi) {
         Op& o = P->ops[oi];
-        if (o.kind != OP_CONV || o.src1 < 0 || o.dst < 0 || o.taps != taps) continue;
+        if (o.kind != OP_CONV || o.src1 < 0 || o.dst < 0 || o.taps != taps || oi < op_lo || oi >= op_hi) continue;
         ConvArgs a{};
         fill_conv(P, o, nullptr, nullptr, nullptr, nullptr, nullptr, 1, a);
         WgLayer L{};
@@ -1025,6 +1034,35 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
     }
     if (!getenv("DMME_NO_FUSED_GN")) assign_stats(P);
     if (device >= 0) {
+        // bucket boundary: parameters from the first up_layers entry on are finished first by backward
+        P->op_split = (int)P->ops.size();
+        P->bucket_off = P->ref_numel;
+        for (const Param& pp : P->params)
+            if (pp.name.rfind("up_layers.", 0) == 0) {
+                P->bucket_off = pp.ref_off;
+                break;
+            }
+        for (int oi = 0; oi < (int)P->ops.size(); ++oi) {
+            const Op& o = P->ops[oi];
+            const int pi = o.kind == OP_CONV ? o.w : o.kind == OP_GN ? o.gn_gamma : -1;
+            if (pi >= 0 && P->params[pi].ref_off >= P->bucket_off) {
+                P->op_split = oi;
+                break;
+            }
+        }
+        for (int oi = P->op_split; oi < (int)P->ops.size(); ++oi) {  // the split must be clean: nothing of bucket 1 after it
+            const Op& o = P->ops[oi];
+            const int pi = o.kind == OP_CONV ? o.w : o.kind == OP_GN ? o.gn_gamma : -1;
+            if (pi >= 0 && P->params[pi].ref_off < P->bucket_off) P->op_split = -1;
+        }
+        P->tcol_split = P->tproj_cols;
+        for (const auto& tb : P->tblocks)
+            if (P->params[tb.tw].ref_off >= P->bucket_off && tb.col < P->tcol_split) P->tcol_split = tb.col;
+        for (const auto& tb : P->tblocks)
+            if ((P->params[tb.tw].ref_off >= P->bucket_off) != (tb.col >= P->tcol_split)) P->op_split = -1;
+        for (int b = 0; b < 2 && P->op_split > 0; ++b)  // before the "all" build: that one leaves the final Op::wg_layer values
+            for (int k = 0; k < 2; ++k)
+                build_wgrad_group(P, P->wgb[b][k], k == 0 ? 9 : 1, b == 0 ? P->op_split : 0, b == 0 ? 1 << 30 : P->op_split);
         build_wgrad_group(P, P->wg[0], 9);
         build_wgrad_group(P, P->wg[1], 1);
         if (!getenv("DMME_NO_BIAS_GROUP"))
@@ -1034,6 +1072,7 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
                 fill_conv(P, o, nullptr, nullptr, nullptr, nullptr, nullptr, 1, a);
                 if (!colsum_fast_supported(P->dtype, a.Hout * a.Wout, a.Cout)) continue;
                 o.bias_deferred = 1;
+                if ((int)(&o - P->ops.data()) < P->op_split) P->bias_split = (int)P->bias_jobs.size() + (a.Cout + 31) / 32;
                 for (int cb = 0; cb < (a.Cout + 31) / 32; ++cb) {
                     BiasJob j{};
                     j.rowsum_off = o.b_rowsum;
@@ -1084,13 +1123,21 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
             if (e == hipSuccess) e = hipMalloc((void**)&P->bias_jobs_dev, P->bias_jobs.size() * sizeof(BiasJob));
             if (e == hipSuccess) e = hipMemcpy(P->bias_jobs_dev, P->bias_jobs.data(), P->bias_jobs.size() * sizeof(BiasJob), hipMemcpyHostToDevice);
         }
-        for (auto& G : P->wg) {
-            if (G.jobs.empty()) continue;
-            if (e == hipSuccess) e = hipMalloc((void**)&G.layers_dev, G.layers.size() * sizeof(WgLayer));
-            if (e == hipSuccess) e = hipMemcpy(G.layers_dev, G.layers.data(), G.layers.size() * sizeof(WgLayer), hipMemcpyHostToDevice);
-            if (e == hipSuccess) e = hipMalloc((void**)&G.jobs_dev, G.jobs.size() * sizeof(WgJob));
-            if (e == hipSuccess) e = hipMemcpy(G.jobs_dev, G.jobs.data(), G.jobs.size() * sizeof(WgJob), hipMemcpyHostToDevice);
+        for (dmme_plan::WgGroup* G : {&P->wg[0], &P->wg[1], &P->wgb[0][0], &P->wgb[0][1], &P->wgb[1][0], &P->wgb[1][1]}) {
+            if (G->jobs.empty()) continue;
+            if (e == hipSuccess) e = hipMalloc((void**)&G->layers_dev, G->layers.size() * sizeof(WgLayer));
+            if (e == hipSuccess) e = hipMemcpy(G->layers_dev, G->layers.data(), G->layers.size() * sizeof(WgLayer), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMalloc((void**)&G->jobs_dev, G->jobs.size() * sizeof(WgJob));
+            if (e == hipSuccess) e = hipMemcpy(G->jobs_dev, G->jobs.data(), G->jobs.size() * sizeof(WgJob), hipMemcpyHostToDevice);
         }
+        P->unpack_split = (int)uitems.size();
+        for (int i = 0; i < (int)uitems.size(); ++i)
+            if (uitems[i].src_off >= P->bucket_off) {
+                P->unpack_split = i;
+                break;
+            }
+        for (int i = P->unpack_split; i < (int)uitems.size(); ++i)
+            if (uitems[i].src_off < P->bucket_off) P->op_split = -1;
         if (e != hipSuccess) {
             set_error("plan_create: device table setup failed: %s", hipGetErrorString(e));
             delete P;
@@ -1106,9 +1153,9 @@ DMME_API void dmme_unet_plan_destroy(dmme_plan* plan) {
     if (plan->items_dev) (void)hipFree(plan->items_dev);
     if (plan->items_bwd_dev) (void)hipFree(plan->items_bwd_dev);
     if (plan->items_unpack_dev) (void)hipFree(plan->items_unpack_dev);
-    for (auto& G : plan->wg) {
-        if (G.layers_dev) (void)hipFree(G.layers_dev);
-        if (G.jobs_dev) (void)hipFree(G.jobs_dev);
+    for (dmme_plan::WgGroup* G : {&plan->wg[0], &plan->wg[1], &plan->wgb[0][0], &plan->wgb[0][1], &plan->wgb[1][0], &plan->wgb[1][1]}) {
+        if (G->layers_dev) (void)hipFree(G->layers_dev);
+        if (G->jobs_dev) (void)hipFree(G->jobs_dev);
     }
     if (plan->tp_tiles_dev) (void)hipFree(plan->tp_tiles_dev);
     if (plan->bias_jobs_dev) (void)hipFree(plan->bias_jobs_dev);
@@ -1206,9 +1253,9 @@ DMME_API int dmme_unet_pack_params_bwd(const dmme_plan* plan, const float* ref_f
     return launch_pack_table(plan->dtype, plan->items_bwd_dev, plan->n_items_bwd, ref_flat, packed_bwd, (hipStream_t)stream);
 }
 
-DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const void* packed_bwd, const float* x,
-                                const int64_t* t, int t_len, const float* d_y, void* workspace, void* bwd_workspace,
-                                const float* drop_masks, float* grad_flat, void* stream) {
+static int backward_impl(const dmme_plan* plan, const void* packed, const void* packed_bwd, const float* x, const int64_t* t, int t_len,
+                         const float* d_y, void* workspace, void* bwd_workspace, const float* drop_masks, float* grad_flat, void* stream,
+                         dmme_bucket_fn ready, void* user) {
     DMME_REQUIRE(plan && packed && packed_bwd && x && t && d_y && workspace && bwd_workspace && grad_flat, DMME_ERR_INVALID,
                  "unet_backward: null argument");
     DMME_REQUIRE(t_len == 1 || t_len == plan->B, DMME_ERR_INVALID, "unet_backward: bad t_len %d", t_len);
@@ -1232,10 +1279,55 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
     char* tmp = bws + P->bws_tmp;
     int rc = launch_nchw_to_nhwc(dt, d_y, B, P->out_channels, P->H * P->W, bws + P->bws_dy, s);
     if (rc != DMME_OK) return rc;
+    const bool buckets = ready != nullptr && P->op_split > 0;  // two-bucket mode: deferred work flushed per bucket
+    const int emb = P->cfg.emb_dim, pos = P->cfg.pos_dim, tc = P->tproj_cols;
+    const float* temb = (const float*)(ws + P->ws_temb);
+    // deferred launches of one bucket (b = 0 / 1) or of everything (b = -1): bias + time rows, grouped weight gradients, unpack,
+    // the per-block time-projection weight gradients
+    auto flush = [&](int b) -> int {
+        int r = DMME_OK;
+        if (P->bias_jobs_dev) {
+            const int j0 = b == 0 ? P->bias_split : 0, j1 = b == 1 ? P->bias_split : (int)P->bias_jobs.size();
+            if (j1 > j0) r = launch_bias_tproj_group(P->bias_jobs_dev + j0, j1 - j0, bws, grad_flat, dtproj, B, tc, nt, s);
+            if (r != DMME_OK) return r;
+        }
+        for (int k = 0; k < 2; ++k) {
+            const dmme_plan::WgGroup& G = b < 0 ? P->wg[k] : P->wgb[b][k];
+            if (!G.jobs_dev) continue;
+            r = launch_wgrad_group(dt, G.taps, G.layers_dev, G.jobs_dev, (int)G.jobs.size(), ws, bws, drop_masks, wimage, s);
+            if (r != DMME_OK) return r;
+        }
+        {
+            const int i0 = b == 0 ? P->unpack_split : 0, i1 = b == 1 ? P->unpack_split : P->n_items_unpack;
+            if (i1 > i0) r = launch_wgrad_unpack(P->items_unpack_dev + i0, i1 - i0, wimage, grad_flat, s);
+            if (r != DMME_OK) return r;
+        }
+        const int c0 = b == 0 ? P->tcol_split : 0, c1 = b == 1 ? P->tcol_split : tc;
+        if (c1 > c0) {
+            if (P->tp_tiles_dev) {  // every block's dW / db in one launch each
+                r = launch_small_gemm_tn_tiled(dtproj + c0, tc, temb, emb, c1 - c0, emb, nt, grad_flat, emb, P->tp_tiles_dev + c0 / 64, s);
+                if (r == DMME_OK) r = launch_nsum_tiled(dtproj + c0, nt, c1 - c0, tc, 1, grad_flat, P->tp_tiles_dev + P->tp_n64 + c0 / 32, s);
+            } else {
+                for (const auto& tb : P->tblocks) {
+                    if (tb.col < c0 || tb.col >= c1) continue;
+                    // dW_block[o][k] += sum_r dtproj[r][col+o] temb[r][k];  db_block[o] += sum_r dtproj[r][col+o]
+                    r = launch_small_gemm(dt, 2, dtproj + tb.col, tc, temb, emb, tb.cout, emb, nt, nullptr, 0, grad_flat + P->params[tb.tw].ref_off, emb, s);
+                    if (r == DMME_OK) r = launch_nsum(dtproj + tb.col, nt, tb.cout, tc, 1, grad_flat + P->params[tb.tb].ref_off, s);
+                    if (r != DMME_OK) return r;
+                }
+            }
+        }
+        return r;
+    };
     if (P->cfg.arch == DMME_ARCH_IDDPM && nt == 1)  // shared timestep row: the GroupNorm backward accumulates into it atomically
         DMME_CHECK_HIP(hipMemsetAsync(dtproj, 0, (size_t)P->tproj_cols * 4, s));
 
     for (int oi = (int)P->ops.size() - 1; oi >= 0 && rc == DMME_OK; --oi) {
+        if (buckets && oi == P->op_split - 1) {  // every op of bucket 0 has run: finish its parameter gradients and hand it over
+            rc = flush(0);
+            if (rc != DMME_OK) break;
+            ready(user, 0, P->bucket_off, P->ref_numel - P->bucket_off);
+        }
         const Op& o = P->ops[oi];
         if (o.kind == OP_ATTN) {
             const Tensor& q = P->tensors[o.at_qkv];
@@ -1274,7 +1366,7 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
                                o.tproj_col >= 0 ? dtproj + o.tproj_col : nullptr, P->tproj_cols, nt, s);
         if (rc != DMME_OK) break;
         // 2. weight gradient: deferred to the grouped launch below, or per layer (packed image / reference layout)
-        if (o.wg_layer >= 0 && P->wg[o.taps == 9 ? 0 : 1].jobs_dev)
+        if (o.wg_layer >= 0 && (buckets ? P->wgb[oi >= P->op_split ? 0 : 1][o.taps == 9 ? 0 : 1].jobs_dev : P->wg[o.taps == 9 ? 0 : 1].jobs_dev))
             rc = DMME_OK;
         else if (wgrad_mfma_supported(dt, a))
             rc = launch_wgrad_mfma(dt, a, dy, wimage + P->params[o.w].wp_off, s);
@@ -1344,40 +1436,15 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
         }
     }
     if (rc != DMME_OK) return rc;
-    // bias and time-embedding-row gradients of every conv from its column sums: one launch
-    if (P->bias_jobs_dev) {
-        rc = launch_bias_tproj_group(P->bias_jobs_dev, (int)P->bias_jobs.size(), bws, grad_flat, dtproj, B, P->tproj_cols, nt, s);
-        if (rc != DMME_OK) return rc;
-    }
-    // all deferred 3x3 (then 1x1) weight gradients in one launch each: every dY and forward activation is still in its workspace
-    for (const auto& G : P->wg) {
-        if (!G.jobs_dev) continue;
-        rc = launch_wgrad_group(dt, G.taps, G.layers_dev, G.jobs_dev, (int)G.jobs.size(), ws, bws, drop_masks, wimage, s);
-        if (rc != DMME_OK) return rc;
-    }
-    // fold the packed-layout weight-gradient image into the reference-layout gradients (one launch)
-    rc = launch_wgrad_unpack(P->items_unpack_dev, P->n_items_unpack, wimage, grad_flat, s);
+    rc = flush(buckets ? 1 : -1);
     if (rc != DMME_OK) return rc;
 
     // ---- time MLP backward (models/ddpm.py:211-217 and the per-block Linear at :101-104) ----
-    const int emb = P->cfg.emb_dim, pos = P->cfg.pos_dim, tc = P->tproj_cols;
-    const float* temb = (const float*)(ws + P->ws_temb);
     const float* h1 = (const float*)(ws + P->ws_th1);
     const float* esin = (const float*)(ws + P->ws_tsin);
     float* dtemb = (float*)(bws + P->bws_dtemb);
     float* dh1 = (float*)(bws + P->bws_dh1);
     float* z = (float*)(bws + P->bws_z);
-    if (P->tp_tiles_dev) {  // every block's dW / db in one launch each
-        rc = launch_small_gemm_tn_tiled(dtproj, tc, temb, emb, tc, emb, nt, grad_flat, emb, P->tp_tiles_dev, s);
-        if (rc == DMME_OK) rc = launch_nsum_tiled(dtproj, nt, tc, tc, 1, grad_flat, P->tp_tiles_dev + P->tp_n64, s);
-        if (rc != DMME_OK) return rc;
-    } else
-    for (const auto& tb : P->tblocks) {
-        // dW_block[o][k] += sum_r dtproj[r][col+o] temb[r][k];  db_block[o] += sum_r dtproj[r][col+o]
-        rc = launch_small_gemm(dt, 2, dtproj + tb.col, tc, temb, emb, tb.cout, emb, nt, nullptr, 0, grad_flat + P->params[tb.tw].ref_off, emb, s);
-        if (rc == DMME_OK) rc = launch_nsum(dtproj + tb.col, nt, tb.cout, tc, 1, grad_flat + P->params[tb.tb].ref_off, s);
-        if (rc != DMME_OK) return rc;
-    }
     const float* W2 = (const float*)nullptr;
     (void)W2;
     rc = launch_small_gemm(dt, 1, dtproj, tc, pk + P->tproj_w_off, emb, nt, emb, tc, nullptr, 0, dtemb, emb, s);
@@ -1393,7 +1460,32 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
     if (rc == DMME_OK) rc = launch_silu_bwd(dh1, z, nt * emb, s);
     if (rc == DMME_OK) rc = launch_small_gemm(dt, 2, dh1, emb, esin, pos, emb, pos, nt, nullptr, 0, grad_flat + P->params[P->p_l1w].ref_off, pos, s);
     if (rc == DMME_OK) rc = launch_nsum(dh1, nt, emb, emb, 1, grad_flat + P->params[P->p_l1b].ref_off, s);
+    if (rc == DMME_OK && buckets) ready(user, 1, 0, P->bucket_off);
     return rc;
+}
+
+DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const void* packed_bwd, const float* x,
+                                const int64_t* t, int t_len, const float* d_y, void* workspace, void* bwd_workspace,
+                                const float* drop_masks, float* grad_flat, void* stream) {
+    return backward_impl(plan, packed, packed_bwd, x, t, t_len, d_y, workspace, bwd_workspace, drop_masks, grad_flat, stream, nullptr, nullptr);
+}
+
+DMME_API int dmme_unet_backward_buckets(const dmme_plan* plan, const void* packed, const void* packed_bwd, const float* x,
+                                        const int64_t* t, int t_len, const float* d_y, void* workspace, void* bwd_workspace,
+                                        const float* drop_masks, float* grad_flat, void* stream, dmme_bucket_fn ready, void* user) {
+    DMME_REQUIRE(ready, DMME_ERR_INVALID, "unet_backward_buckets: null callback");
+    return backward_impl(plan, packed, packed_bwd, x, t, t_len, d_y, workspace, bwd_workspace, drop_masks, grad_flat, stream, ready, user);
+}
+
+DMME_API int dmme_unet_plan_grad_buckets(const dmme_plan* plan, int64_t offsets[2], int64_t numels[2]) {
+    DMME_REQUIRE(plan && offsets && numels, DMME_ERR_INVALID, "grad_buckets: null argument");
+    if (plan->op_split <= 0) {  // no clean split for this configuration: one bucket
+        offsets[0] = 0; numels[0] = plan->ref_numel; offsets[1] = 0; numels[1] = 0;
+        return 1;
+    }
+    offsets[0] = plan->bucket_off; numels[0] = plan->ref_numel - plan->bucket_off;
+    offsets[1] = 0; numels[1] = plan->bucket_off;
+    return 2;
 }
 
 DMME_API int dmme_grad_norm(const float* grad, int64_t numel, float* norm_out, float* scratch, void* stream) {

@@ -65,3 +65,68 @@ def allreduce_mean_flat(flat_grad: torch.Tensor, bucket_elems: int = 8 << 20, as
         if async_op:
             handles.append(h)
     return handles
+
+
+class OverlappedGradReducer:
+    """Mean all-reduce of a dmme_amd UNet's flat gradient buffer, started bucket by bucket WHILE backward is still running.
+
+    `dmme_unet_backward_buckets` reports each gradient bucket as soon as the launches that write it are enqueued (first the
+    up / middle / output parameters - the tail of the flat buffer, ~2/3 of the bytes - then the rest).  For every report an event is
+    recorded on the compute stream and the bucket's all-reduce (RCCL; in slices of `bucket_elems` so the ring pipelines) is issued
+    on a side stream that waits for that event; the down path's backward keeps the compute stream busy meanwhile.  `finish()` makes
+    the compute stream wait for the side stream before the optimiser reads the gradients.  On CPU tensors (gloo tests) there are no
+    streams: the collectives run asynchronously and `finish()` waits on their handles."""
+
+    def __init__(self, model, bucket_elems: int = 8 << 20):
+        self.model = model
+        self.bucket_elems = bucket_elems
+        self.handles = []
+        self.reported = []
+        self._stream = None
+        model._bucket_hook = self.bucket_ready  # picked up by UNet._backward_impl
+
+    def active(self) -> bool:
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def bucket_ready(self, offset: int, numel: int, flat_grad: Optional[torch.Tensor] = None):
+        self.reported.append((offset, numel))
+        if not self.active():
+            return
+        flat = self.model.flat_grad() if flat_grad is None else flat_grad
+        world = dist.get_world_size()
+        view = flat[offset : offset + numel]
+        if view.is_cuda:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=view.device)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(view.device))
+            with torch.cuda.stream(self._stream):
+                self._stream.wait_event(ev)
+                self._reduce(view, world)
+        else:
+            self._reduce(view, world)
+
+    def _reduce(self, view: torch.Tensor, world: int):
+        view.div_(world)
+        for b, e in bucket_slices(view.numel(), self.bucket_elems):
+            self.handles.append(dist.all_reduce(view[b:e], op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self, flat_grad: Optional[torch.Tensor] = None) -> bool:
+        """True when the gradients were reduced here (the caller must then NOT reduce them again).  A step whose backward reported no
+        bucket (configuration without a clean split, or a non-bucketed backward) is reduced in one piece now."""
+        if not self.active():
+            self.reported.clear()
+            return False
+        flat = self.model.flat_grad() if flat_grad is None else flat_grad
+        covered = sum(n for _, n in self.reported)
+        if covered == 0:
+            self.bucket_ready(0, flat.numel(), flat)
+        elif covered != flat.numel():
+            raise RuntimeError(f"gradient buckets cover {covered} of {flat.numel()} elements")
+        for h in self.handles:
+            h.wait()  # CUDA: makes the current stream wait for the collective; gloo: blocks
+        if self._stream is not None:
+            torch.cuda.current_stream().wait_stream(self._stream)
+        self.handles.clear()
+        self.reported.clear()
+        return True

@@ -105,6 +105,7 @@ class UNet(nn.Module):
         self._mask_calls = 0
         self._param_epoch = 0  # bumped by optimisers that update the flat buffer through raw pointers
         self._flat_grad: Optional[Tensor] = None
+        self._bucket_hook = None  # callable(offset, numel): set by distributed.OverlappedGradReducer
 
         # parameter table from the C++ plan (host only: device = -1)
         table_plan = _Plan(self._cfg, 1, 32, 32, _lib.F32, -1)
@@ -307,6 +308,25 @@ class UNet(nn.Module):
             plan.packed_bwd_version = ver
         g = self.flat_grad()
         d = dy.detach().to(torch.float32).contiguous()
+        hook = self._bucket_hook
+        if hook is not None:  # two gradient buckets, each handed over as soon as its launches are enqueued (overlapped all-reduce)
+            errors = []
+
+            def ready(_user, _bucket, offset, numel):
+                try:
+                    hook(int(offset), int(numel))
+                except Exception as exc:  # noqa: BLE001 - never unwind through the C frames
+                    errors.append(exc)
+
+            cb = _lib.BUCKET_FN(ready)
+            _lib.check(
+                lib.dmme_unet_backward_buckets(plan.h, _lib.ptr(packed), _lib.ptr(plan.packed_bwd), _lib.ptr(xin), _lib.ptr(t), int(t.numel()), _lib.ptr(d),
+                                               _lib.ptr(plan.workspace), _lib.ptr(plan.bws), _lib.ptr(masks), _lib.ptr(g), _lib.stream_ptr(), cb, None),
+                "dmme_unet_backward_buckets",
+            )
+            if errors:
+                raise errors[0]
+            return
         _lib.check(
             lib.dmme_unet_backward(plan.h, _lib.ptr(packed), _lib.ptr(plan.packed_bwd), _lib.ptr(xin), _lib.ptr(t), int(t.numel()), _lib.ptr(d),
                                    _lib.ptr(plan.workspace), _lib.ptr(plan.bws), _lib.ptr(masks), _lib.ptr(g), _lib.stream_ptr()),

@@ -18,11 +18,16 @@ def synthetic_batch(batch_size: int, device, shape=(3, 32, 32)):
 
 
 def train_step(module, optimizer, scheduler, x0, clip=None):
-    """one optimisation step: loss -> HIP backward -> (DP mean all-reduce) -> clip+Adam(+EMA) -> LR step"""
+    """one optimisation step: loss -> HIP backward (data parallel: the gradient all-reduce of the first bucket runs on a side
+    stream under the rest of backward) -> clip+Adam(+EMA) -> LR step"""
+    model = module.diffusion_model.model
+    reducer = getattr(model, "_grad_reducer", None)
+    if reducer is None and D.dist.is_available() and D.dist.is_initialized() and D.dist.get_world_size() > 1:
+        reducer = model._grad_reducer = D.OverlappedGradReducer(model)
     loss = module.training_step((x0,), 0)
     loss.backward()
-    model = module.diffusion_model.model
-    D.allreduce_mean_flat(model.flat_grad())
+    if reducer is None or not reducer.finish():
+        D.allreduce_mean_flat(model.flat_grad())
     optimizer.step()
     if scheduler is not None:
         scheduler.step()

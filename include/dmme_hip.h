@@ -144,6 +144,19 @@ DMME_API int dmme_unet_pack_params_bwd(const dmme_plan* plan, const float* ref_f
 DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const void* packed_bwd, const float* x,
                        const int64_t* t, int t_len, const float* d_y, void* workspace, void* bwd_workspace,
                        const float* drop_masks, float* grad_flat, void* stream);
+/* Same backward in two gradient buckets, so a data-parallel caller can all-reduce the first while the second is still being
+ * computed (north star: "RCCL all-reduce of UNet grads over xGMI overlapped with backward"; the reference gets this from
+ * Lightning's DDP wrapper around `loss.backward()`).  Bucket 0 = the parameters backward finishes first (up_layers,
+ * middle_layers, output_conv: the contiguous tail of the flat buffer), bucket 1 = the rest (time MLP, input_conv,
+ * down_layers).  `ready(user, bucket, offset, numel)` is called on the calling thread as soon as every launch that writes
+ * grad_flat[offset, offset + numel) has been ENQUEUED on `stream` (record an event there; nothing has necessarily executed yet).
+ * Same results as dmme_unet_backward.  dmme_unet_plan_grad_buckets returns the number of buckets (1 when the configuration has
+ * no clean split, then `ready` is never called) and their ranges in hand-over order. */
+typedef void (*dmme_bucket_fn)(void* user, int bucket, int64_t offset, int64_t numel);
+DMME_API int dmme_unet_backward_buckets(const dmme_plan* plan, const void* packed, const void* packed_bwd, const float* x,
+                               const int64_t* t, int t_len, const float* d_y, void* workspace, void* bwd_workspace,
+                               const float* drop_masks, float* grad_flat, void* stream, dmme_bucket_fn ready, void* user);
+DMME_API int dmme_unet_plan_grad_buckets(const dmme_plan* plan, int64_t offsets[2], int64_t numels[2]);
 /* global L2 norm of a flat fp32 gradient buffer (clip_grad_norm_; scratch: 1024 floats) */
 DMME_API int dmme_grad_norm(const float* grad, int64_t numel, float* norm_out, float* scratch, void* stream);
 /* one fused pass: clip by global norm (max_norm <= 0: off) -> Adam (torch.optim.Adam, no weight

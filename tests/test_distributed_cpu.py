@@ -39,6 +39,30 @@ def _worker(rank, world, path):
         for h in hs:
             h.wait()
         assert torch.allclose(flat, full.mean(0), atol=1e-6)
+        # the overlapped form: buckets reported mid-backward (tail of the buffer first), reduced asynchronously, joined by finish()
+        class FakeModel:
+            def __init__(self, g):
+                self.g = g
+
+            def flat_grad(self):
+                return self.g
+
+        m = FakeModel(full[rank].clone())
+        red = D.OverlappedGradReducer(m, bucket_elems=256)
+        assert m._bucket_hook == red.bucket_ready
+        red.bucket_ready(600, 400)   # what dmme_unet_backward_buckets reports first
+        red.bucket_ready(0, 600)
+        assert red.finish() is True
+        assert torch.allclose(m.g, full.mean(0), atol=1e-6)
+        m.g.copy_(full[rank])        # a backward that reported nothing is reduced in one piece
+        assert red.finish() is True and torch.allclose(m.g, full.mean(0), atol=1e-6)
+        m.g.copy_(full[rank])
+        red.bucket_ready(600, 400)   # a partial report is an error, not a silent half-reduction
+        try:
+            red.finish()
+            raise AssertionError("expected RuntimeError")
+        except RuntimeError:
+            red.handles.clear(); red.reported.clear()
     finally:
         dist.destroy_process_group()
 

@@ -204,8 +204,14 @@ def main():
 
         if world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        # rehearsal on a box with fewer GPUs than ranks: DMME_DIST_BACKEND=gloo lets the ranks share devices (RCCL refuses that)
+        backend = os.environ.get("DMME_DIST_BACKEND", "nccl")
+        local = local % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -305,9 +311,12 @@ def main():
     }
     if args.train_steps > 0:
         del x
-        dt_tr, _ = train_leg(dmme_amd, dev, B, args.precision, args.train_steps, 2, dist, args.model)
-        out["train_images_per_s"] = round(world * args.train_steps * B / dt_tr, 1)
-        out["train_ms_per_step"] = round(1e3 * dt_tr / args.train_steps, 2)
+        try:  # secondary figure: a failure here must not cost the headline line
+            dt_tr, _ = train_leg(dmme_amd, dev, B, args.precision, args.train_steps, 2, dist, args.model)
+            out["train_images_per_s"] = round(world * args.train_steps * B / dt_tr, 1)
+            out["train_ms_per_step"] = round(1e3 * dt_tr / args.train_steps, 2)
+        except Exception as exc:  # noqa: BLE001
+            out["train_error"] = f"{type(exc).__name__}: {exc}"[:300]
     if rank == 0:
         if not args.no_roofline:
             xin = dmme_amd.gaussian((B, 3, side, side), device=dev)

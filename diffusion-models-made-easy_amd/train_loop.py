@@ -5,6 +5,7 @@ x_0 = 2 U[0,1) - 1 (there is no dataset in the image; the input pipeline is out 
 from __future__ import annotations
 
 import json
+import os
 import time
 
 import torch
@@ -22,7 +23,7 @@ def train_step(module, optimizer, scheduler, x0, clip=None):
     stream under the rest of backward) -> clip+Adam(+EMA) -> LR step"""
     model = module.diffusion_model.model
     reducer = getattr(model, "_grad_reducer", None)
-    if reducer is None and D.dist.is_available() and D.dist.is_initialized() and D.dist.get_world_size() > 1:
+    if reducer is None and not os.environ.get("DMME_NO_OVERLAP") and D.dist.is_available() and D.dist.is_initialized() and D.dist.get_world_size() > 1:
         reducer = model._grad_reducer = D.OverlappedGradReducer(model)
     loss = module.training_step((x0,), 0)
     loss.backward()

@@ -246,3 +246,34 @@ def test_graphed_forward_matches_eager(tiny32):
             x.mul_(0.9).add_(0.05)
             t.fill_(50 - step)
     assert getattr(net, "_graph", None) is not None or getattr(net, "_graph_disabled", False)
+
+
+def test_lsun_church_config_256x256_vs_oracle():
+    """configs/ddpm/lsun_church.yaml:78-90: six depths (128,128,256,256,512,512), attention on depth 5 only, dropout 0.0 (so the
+    conv2 key is `conv2.2`), 256x256 inputs, batch 2 - 97.7 M parameters.  Forward fp32 / bf16 against the oracle, and one training
+    step: the engine is not specialised to the CIFAR10 geometry."""
+    import dmme_amd
+
+    cfg = O.UNetConfig(dropout=0.0, channels_per_depth=(128, 128, 256, 256, 512, 512), attention_depths=(5,))
+    sd = O.make_state_dict(cfg, 77)
+    assert any(k.endswith("conv2.2.weight") for k in sd) and not any(".conv2.3." in k for k in sd)
+    x = synth.normal(1, (2, 3, 256, 256))
+    t = torch.tensor([10, 900])
+    want = O.unet_forward(sd, cfg, x, t)
+    for prec in ("fp32", "bf16"):
+        net = dmme_amd.UNet(dropout=0.0, channels_per_depth=cfg.channels_per_depth, attention_depths=cfg.attention_depths, precision=prec)
+        assert list(net.state_dict().keys()) == list(sd.keys())
+        net.load_state_dict(sd, strict=True)
+        net.cuda().eval()
+        with torch.no_grad():
+            got = net(x.cuda(), t.cuda()).cpu()
+        err = (got - want).abs()
+        if prec == "fp32":
+            assert float(err.max()) < FP32_ATOL
+        else:
+            assert float(err.pow(2).mean().sqrt() / want.pow(2).mean().sqrt()) < BF16_REL_RMS and float(err.max()) < BF16_MAX_ABS
+    net.train()
+    loss = dmme_amd.DDPM(net, 1000).cuda().training_step(synth.uniform(2, (2, 3, 256, 256)).cuda())
+    loss.backward()
+    g = net.flat_grad()
+    assert bool(torch.isfinite(loss)) and bool(torch.isfinite(g).all()) and float(g.norm()) > 0

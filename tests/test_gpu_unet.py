@@ -277,3 +277,46 @@ def test_lsun_church_config_256x256_vs_oracle():
     loss.backward()
     g = net.flat_grad()
     assert bool(torch.isfinite(loss)) and bool(torch.isfinite(g).all()) and float(g.norm()) > 0
+
+
+@pytest.mark.parametrize("B", [128, 512])
+def test_benchmark_batch_sizes_bf16_are_batch_consistent(golden, B):
+    """BASELINE configs[1] / [2] sizes in the benchmark precision: a batch built from 4 distinct images repeated B/4 times must give
+    the same row for the same image wherever it sits (every tile shape the large batches select, incl. the persistent kernel), and
+    those rows must agree with the B = 4 run (other tile shapes) and with the reference's golden rows."""
+    import dmme_amd
+
+    g = golden("unet_full")
+    cfg = O.UNetConfig()
+    net, _ = _build(cfg, int(g["full_seed"]), "bf16")
+    base = torch.cat([synth.normal(int(g["full_xseed"]), (2, 3, 32, 32)), synth.normal(8, (2, 3, 32, 32))])
+    t = torch.from_numpy(g["full_t_one"]).cuda()
+    with torch.no_grad():
+        small = net(base.cuda(), t).cpu()
+        big = net(base.repeat(B // 4, 1, 1, 1).cuda(), t).cpu()
+    rows = big.reshape(B // 4, 4, 3, 32, 32)
+    assert torch.equal(rows, rows[:1].expand_as(rows)), "the same image gave different rows at different batch positions"
+    scale = float(small.abs().max())
+    assert float((rows[0] - small).abs().max()) < 2e-2 * scale
+    err = (rows[0, :2] - torch.from_numpy(g["full_y_one"])).abs()
+    want = torch.from_numpy(g["full_y_one"])
+    assert float(err.pow(2).mean().sqrt() / want.pow(2).mean().sqrt()) < BF16_REL_RMS and float(err.max()) < BF16_MAX_ABS
+
+
+def test_ddim_chain_batch512_bf16_finite_and_reproducible():
+    """BASELINE configs[2]: the 50-step quadratic DDIM chain at batch 512 in bf16, twice from the same start."""
+    import dmme_amd
+
+    net, _ = _build(O.UNetConfig(), 21, "bf16")
+    ddim = dmme_amd.DDIM(net, 1000, 50).cuda()
+    x0 = synth.normal(5, (4, 3, 32, 32)).repeat(128, 1, 1, 1).cuda()
+    outs = []
+    with torch.no_grad():
+        for _ in range(2):
+            x = x0.clone()
+            for i in range(50, 0, -1):
+                x = ddim.sampling_step(x, torch.tensor([i], device="cuda"))
+            outs.append(x)
+    assert bool(torch.isfinite(outs[0]).all()) and torch.equal(outs[0], outs[1])
+    rows = outs[0].reshape(128, 4, 3, 32, 32)
+    assert torch.equal(rows, rows[:1].expand_as(rows))

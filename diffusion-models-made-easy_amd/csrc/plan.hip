@@ -1445,8 +1445,6 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
     float* dtemb = (float*)(bws + P->bws_dtemb);
     float* dh1 = (float*)(bws + P->bws_dh1);
     float* z = (float*)(bws + P->bws_z);
-    const float* W2 = (const float*)nullptr;
-    (void)W2;
     rc = launch_small_gemm(dt, 1, dtproj, tc, pk + P->tproj_w_off, emb, nt, emb, tc, nullptr, 0, dtemb, emb, s);
     if (rc != DMME_OK) return rc;
     // temb = silu(z2), z2 = h1 W2^T + b2

@@ -309,20 +309,37 @@ def main():
         "launches_per_step": int(model._last_plan.lib.dmme_unet_plan_num_launches(model._last_plan.h)) + 2,
         "hip_graph": bool(args.graph and not getattr(model, "_graph_disabled", False)),
     }
+    # rank 0: the per-kernel roofline of the measured forward and the CPU baseline, before the secondary training figure
+    if rank == 0:
+        if not args.no_roofline:
+            xin = dmme_amd.gaussian((B, 3, side, side), device=dev)
+            out["roofline"] = roofline_leg(model, xin, all_t[500], args.precision)
+            del xin
+        if world == 1 and not args.no_cpu_baseline and args.model == "ddpm":
+            out["cpu_baseline"] = cpu_baseline_leg(B)
     if args.train_steps > 0:
         del x
-        try:  # secondary figure: a failure here must not cost the headline line
+        # Secondary figure.  Neither an exception nor a stuck collective in it may cost the headline line: past the deadline every
+        # rank leaves through the watchdog, rank 0 printing the line it already has.
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["train_error"] = "training leg exceeded its deadline"
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(240.0, bail)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
             dt_tr, _ = train_leg(dmme_amd, dev, B, args.precision, args.train_steps, 2, dist, args.model)
             out["train_images_per_s"] = round(world * args.train_steps * B / dt_tr, 1)
             out["train_ms_per_step"] = round(1e3 * dt_tr / args.train_steps, 2)
         except Exception as exc:  # noqa: BLE001
             out["train_error"] = f"{type(exc).__name__}: {exc}"[:300]
+        watchdog.cancel()
     if rank == 0:
-        if not args.no_roofline:
-            xin = dmme_amd.gaussian((B, 3, side, side), device=dev)
-            out["roofline"] = roofline_leg(model, xin, all_t[500], args.precision)
-        if world == 1 and not args.no_cpu_baseline and args.model == "ddpm":
-            out["cpu_baseline"] = cpu_baseline_leg(B)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

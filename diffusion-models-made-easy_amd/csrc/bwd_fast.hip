@@ -95,6 +95,56 @@ __global__ void __launch_bounds__(256) colsum_vec_kernel(const T* __restrict__ d
     }
 }
 
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_group_kernel(const ColJob* __restrict__ jobs, char* __restrict__ bws) {
+    constexpr int EPV = 16 / sizeof(T);
+    __shared__ float red[256 * EPV];
+    const ColJob jb = jobs[blockIdx.x];
+    const T* dY = reinterpret_cast<const T*>(bws + jb.dy_off);
+    float* rowsum = reinterpret_cast<float*>(bws + jb.rowsum_off);
+    const int C = jb.C, ppw = jb.ppw, chunk_px = jb.chunk_px;
+    const int tid = threadIdx.x, VPP = C / EPV, slot = tid % VPP, prow = tid / VPP;
+    const int n = blockIdx.y;
+    const int64_t p0 = (int64_t)n * jb.HW + (int64_t)jb.chunk * chunk_px;
+    float acc[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) acc[j] = 0.f;
+    for (int p = prow; p < chunk_px && prow < ppw; p += ppw) {
+        float v[EPV];
+        load_vec<T>(dY + (p0 + p) * C + slot * EPV, v);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) acc[j] += v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) red[tid * EPV + j] = acc[j];
+    __syncthreads();
+    if (tid < VPP) {
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+            float sm = 0.f;
+            for (int r = 0; r < ppw; ++r) sm += red[(r * VPP + tid) * EPV + j];
+            atomicAdd(&rowsum[(int64_t)n * C + tid * EPV + j], sm);
+        }
+    }
+}
+int colsum_group_chunks(int dtype, int HW, int C, int* chunk_px, int* ppw) {
+    int cp, nc, pw;
+    if (!vec_geometry(dtype, HW, C, cp, nc, pw)) return 0;
+    *chunk_px = cp;
+    *ppw = pw;
+    return nc;
+}
+int launch_colsum_group(int dtype, const ColJob* jobs_dev, int njobs, void* bws, int N, hipStream_t s) {
+    if (njobs <= 0) return DMME_OK;
+    dim3 grid((unsigned)njobs, (unsigned)N);
+    if (dtype == DMME_BF16)
+        hipLaunchKernelGGL(colsum_group_kernel<bf16>, grid, dim3(256), 0, s, jobs_dev, (char*)bws);
+    else
+        hipLaunchKernelGGL(colsum_group_kernel<float>, grid, dim3(256), 0, s, jobs_dev, (char*)bws);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
 // dbias[c] += sum_n rowsum[n][c];  d_tproj rows (per image, or the single broadcast row); 32 channels per
 // workgroup, the batch split 8 ways and combined through LDS
 __global__ void __launch_bounds__(256) bias_tproj_fast_kernel(const float* __restrict__ rowsum, int N, int C, float* __restrict__ dbias,

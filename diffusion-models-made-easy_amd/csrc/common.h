@@ -301,6 +301,16 @@ struct BiasJob {
     int C, cblock, tcol; // channels, 32-channel block of this job, column of the conv's time-projection rows (-1: none)
 };
 int launch_bias_tproj_group(const BiasJob* jobs_dev, int njobs, const void* bws, float* grad_flat, float* dtproj, int N, int ld, int nt, hipStream_t s);
+// the [N][C] column sums of dY of MANY convs in one launch, deferred to the end of backward like the weight gradients (every dY is
+// still in its gradient buffer): a job is one pixel chunk of one conv, grid.y walks the images
+struct ColJob {
+    int64_t dy_off;      // bytes into the backward workspace
+    int64_t rowsum_off;  // bytes into the backward workspace (zeroed region)
+    int HW, C, chunk, chunk_px, ppw, pad;
+};
+// fills the job fields that depend on the geometry; returns the number of chunks (jobs) of this conv, 0: unsupported
+int colsum_group_chunks(int dtype, int HW, int C, int* chunk_px, int* ppw);
+int launch_colsum_group(int dtype, const ColJob* jobs_dev, int njobs, void* bws, int N, hipStream_t s);
 // dbias == dtproj == nullptr: only the [N][C] column sums (the caller reduces them later with launch_bias_tproj_group)
 int launch_colsum_fast(int dtype, const void* dY, int N, int HW, int C, float* rowsum, float* dbias, float* dtproj, int ld, int nt,
                        hipStream_t s);

@@ -135,6 +135,9 @@ struct dmme_plan {
     // deferred bias / time-projection reductions (one launch per backward)
     std::vector<BiasJob> bias_jobs;
     BiasJob* bias_jobs_dev = nullptr;
+    std::vector<ColJob> col_jobs;     // column sums of dY of every bias-deferred conv: one grouped launch per flush
+    ColJob* col_jobs_dev = nullptr;
+    int col_split = 0;                // col_jobs[col_split:] belong to bucket 0
 };
 
 namespace {
@@ -1073,6 +1076,19 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
                 if (!colsum_fast_supported(P->dtype, a.Hout * a.Wout, a.Cout)) continue;
                 o.bias_deferred = 1;
                 if ((int)(&o - P->ops.data()) < P->op_split) P->bias_split = (int)P->bias_jobs.size() + (a.Cout + 31) / 32;
+                if (!getenv("DMME_NO_COLSUM_GROUP")) {
+                    ColJob cj{};
+                    const int nch = colsum_group_chunks(P->dtype, a.Hout * a.Wout, a.Cout, &cj.chunk_px, &cj.ppw);
+                    cj.dy_off = o.dst == -2 ? P->bws_dy : P->gt_off[o.dst];
+                    cj.rowsum_off = o.b_rowsum;
+                    cj.HW = a.Hout * a.Wout;
+                    cj.C = a.Cout;
+                    for (int ch = 0; ch < nch; ++ch) {
+                        cj.chunk = ch;
+                        P->col_jobs.push_back(cj);
+                    }
+                    if ((int)(&o - P->ops.data()) < P->op_split) P->col_split = (int)P->col_jobs.size();
+                }
                 for (int cb = 0; cb < (a.Cout + 31) / 32; ++cb) {
                     BiasJob j{};
                     j.rowsum_off = o.b_rowsum;
@@ -1119,6 +1135,10 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
                 }
             }
         }
+        if (!P->col_jobs.empty()) {
+            if (e == hipSuccess) e = hipMalloc((void**)&P->col_jobs_dev, P->col_jobs.size() * sizeof(ColJob));
+            if (e == hipSuccess) e = hipMemcpy(P->col_jobs_dev, P->col_jobs.data(), P->col_jobs.size() * sizeof(ColJob), hipMemcpyHostToDevice);
+        }
         if (!P->bias_jobs.empty()) {
             if (e == hipSuccess) e = hipMalloc((void**)&P->bias_jobs_dev, P->bias_jobs.size() * sizeof(BiasJob));
             if (e == hipSuccess) e = hipMemcpy(P->bias_jobs_dev, P->bias_jobs.data(), P->bias_jobs.size() * sizeof(BiasJob), hipMemcpyHostToDevice);
@@ -1159,6 +1179,7 @@ DMME_API void dmme_unet_plan_destroy(dmme_plan* plan) {
     }
     if (plan->tp_tiles_dev) (void)hipFree(plan->tp_tiles_dev);
     if (plan->bias_jobs_dev) (void)hipFree(plan->bias_jobs_dev);
+    if (plan->col_jobs_dev) (void)hipFree(plan->col_jobs_dev);
     delete plan;
 }
 
@@ -1286,6 +1307,11 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
     // the per-block time-projection weight gradients
     auto flush = [&](int b) -> int {
         int r = DMME_OK;
+        if (P->bias_jobs_dev && P->col_jobs_dev) {
+            const int j0 = b == 0 ? P->col_split : 0, j1 = b == 1 ? P->col_split : (int)P->col_jobs.size();
+            if (j1 > j0) r = launch_colsum_group(dt, P->col_jobs_dev + j0, j1 - j0, bws, B, s);
+            if (r != DMME_OK) return r;
+        }
         if (P->bias_jobs_dev) {
             const int j0 = b == 0 ? P->bias_split : 0, j1 = b == 1 ? P->bias_split : (int)P->bias_jobs.size();
             if (j1 > j0) r = launch_bias_tproj_group(P->bias_jobs_dev + j0, j1 - j0, bws, grad_flat, dtproj, B, tc, nt, s);
@@ -1356,7 +1382,9 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
         const int Cin = a.C1 + a.C2;
         float* rowsum = (float*)(bws + o.b_rowsum);
         // 1. bias and time-embedding-row gradients (column sums of dY)
-        if (o.bias_deferred && P->bias_jobs_dev)
+        if (o.bias_deferred && P->bias_jobs_dev && P->col_jobs_dev)
+            rc = DMME_OK;  // its column sums come from the grouped launch of the flush
+        else if (o.bias_deferred && P->bias_jobs_dev)
             rc = launch_colsum_fast(dt, dy, B, a.Hout * a.Wout, a.Cout, rowsum, nullptr, nullptr, P->tproj_cols, nt, s);
         else if (colsum_fast_supported(dt, a.Hout * a.Wout, a.Cout))
             rc = launch_colsum_fast(dt, dy, B, a.Hout * a.Wout, a.Cout, rowsum, grad_flat + P->params[o.b].ref_off,

@@ -1,8 +1,8 @@
 """Random draws with the reference's names and contracts (src/dmme/common/noise.py:4-23).
 
 On a GPU device the normals come from the library's Philox4x32-10 kernel
-(dmme_randn); the stream is keyed on torch's seed so `torch.manual_seed` still makes
-runs reproducible.  Integer timesteps and CPU draws use torch (host plumbing)."""
+(dmme_randn); seed and offset come from torch's CUDA generator, so `torch.manual_seed`
+restarts the stream.  Integer timesteps and CPU draws use torch (host plumbing)."""
 
 from __future__ import annotations
 
@@ -10,14 +10,21 @@ import torch
 
 from .. import _lib
 
-_counter = {"n": 0}
+def philox_reserve(device: torch.device, numel: int):
+    """(seed, quad offset) of a fresh span of the device's Philox stream, taken from torch's own CUDA generator: its seed keys the
+    stream and its offset is advanced by what the span consumes, so `torch.manual_seed(s)` restarts the library's draws exactly
+    as it restarts torch's (the reference's randn / dropout draws come from that generator)."""
+    gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+    seed = gen.initial_seed() & 0xFFFFFFFFFFFFFFFF
+    off = int(gen.get_offset())
+    quads = (int(numel) + 3) // 4
+    gen.set_offset(off + 4 * quads)
+    return seed, off // 4
 
 
 def _philox_fill(out: torch.Tensor) -> torch.Tensor:
-    _counter["n"] += 1
-    seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
-    # a fresh 2^40-quad block of the counter space per call
-    _lib.check(_lib.lib().dmme_randn(_lib.ptr(out), out.numel(), seed, _counter["n"] << 40, _lib.stream_ptr()), "dmme_randn")
+    seed, off = philox_reserve(out.device, out.numel())
+    _lib.check(_lib.lib().dmme_randn(_lib.ptr(out), out.numel(), seed, off, _lib.stream_ptr()), "dmme_randn")
     return out
 
 

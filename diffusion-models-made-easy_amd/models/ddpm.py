@@ -350,9 +350,11 @@ class UNet(nn.Module):
                 if plan.masks is None:
                     plan.masks = torch.empty(plan.dropmask_numel, dtype=torch.float32, device=x.device)
                 masks = plan.masks
+                from ..common.noise import philox_reserve
+
                 self._mask_calls += 1
-                seed = (torch.initial_seed() & 0xFFFFFFFFFFFF) ^ 0x5DEECE66D
-                _lib.check(plan.lib.dmme_dropout_masks(plan.h, seed, self._mask_calls << 32, _lib.ptr(masks), _lib.stream_ptr()), "dmme_dropout_masks")
+                seed, off = philox_reserve(x.device, plan.dropmask_numel)  # torch's CUDA generator: manual_seed restarts the draws
+                _lib.check(plan.lib.dmme_dropout_masks(plan.h, seed ^ 0x5DEECE66D, off, _lib.ptr(masks), _lib.stream_ptr()), "dmme_dropout_masks")
         _lib.check(
             plan.lib.dmme_unet_forward(plan.h, _lib.ptr(packed), _lib.ptr(xin), _lib.ptr(t), int(t.numel()), _lib.ptr(y), _lib.ptr(plan.workspace), _lib.ptr(masks), _lib.stream_ptr()),
             "dmme_unet_forward",

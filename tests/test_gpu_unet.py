@@ -320,3 +320,18 @@ def test_ddim_chain_batch512_bf16_finite_and_reproducible():
     assert bool(torch.isfinite(outs[0]).all()) and torch.equal(outs[0], outs[1])
     rows = outs[0].reshape(128, 4, 3, 32, 32)
     assert torch.equal(rows, rows[:1].expand_as(rows))
+
+
+def test_full_chain_t1000_batch128_bf16_reproducible():
+    """BASELINE configs[1] end to end: DDPM.generate, all 1000 steps at batch 128 in bf16, twice from the same seed - finite and
+    bit-identical (140 launches x 1000 steps: a race anywhere in the step would show up as a difference)."""
+    import dmme_amd
+
+    net, _ = _build(O.UNetConfig(), 21, "bf16")
+    ddpm = dmme_amd.DDPM(net, 1000).cuda()
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(1234)
+        outs.append(ddpm.generate((128, 3, 32, 32)))
+    assert bool(torch.isfinite(outs[0]).all())
+    assert torch.equal(outs[0], outs[1])

@@ -338,6 +338,10 @@ class UNet(nn.Module):
         plan = self._plan_for(B, H, W, x.device)
         packed = self._packed_for(plan)
         xin = x.detach().to(torch.float32).contiguous()
+        if c.is_floating_point() and bool((c != c.round()).any()):
+            # the reference's sinusoid accepts any real t (models/ddpm.py:347); every caller passes integer timesteps and the C ABI
+            # takes int64 - refuse rather than truncate
+            raise NotImplementedError("fractional timesteps are not supported by the HIP path (integer t only)")
         t = c.detach().reshape(-1).to(device=x.device, dtype=torch.int64).contiguous()
         y = torch.empty((B, self.out_channels, H, W), dtype=torch.float32, device=x.device)
         masks = None

@@ -233,6 +233,18 @@ def test_reference_error_behaviour(tiny32):
             net(torch.zeros(3, 3, 32, 32, device="cuda"), torch.tensor([1, 2], device="cuda"))
 
 
+def test_float_timesteps(tiny32):
+    """integer-valued float timesteps are the same timesteps; fractional ones are refused, not truncated"""
+    net, _ = tiny32
+    x = synth.normal(3, (2, 3, 32, 32)).cuda()
+    with torch.no_grad():
+        a = net(x, torch.tensor([7, 93]).cuda())
+        b = net(x, torch.tensor([7.0, 93.0]).cuda())
+        assert torch.equal(a, b)
+        with pytest.raises(NotImplementedError):
+            net(x, torch.tensor([7.5, 93.0]).cuda())
+
+
 def test_graphed_forward_matches_eager(tiny32):
     """hipGraph replay of the forward (sampling loops) returns the eager result, also after in-place updates of x / t."""
     net, _ = tiny32

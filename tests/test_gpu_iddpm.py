@@ -100,6 +100,21 @@ def test_unet_full_bf16_vs_oracle():
     assert rel_rms < BF16_REL_RMS and float(err.max()) < BF16_MAX_ABS * max(1.0, float(want.abs().max())), (rel_rms, float(err.max()))
 
 
+def test_unet_64x64_config4_bf16_vs_oracle():
+    """BASELINE configs[3] geometry in the benchmark precision (MFMA head-view attention at S = 256 and S = 64, batch-mixing merge)."""
+    cfg = OI.IUNetConfig(attention_depths=(3, 4))
+    net, sd = _build(cfg, 43, "bf16")
+    B = 4
+    x = synth.normal(10, (B, 3, 64, 64))
+    t = torch.tensor([2500])
+    want = OI.unet_forward(sd, cfg, x, t)
+    with torch.no_grad():
+        got = net(x.cuda(), t.cuda()).cpu()
+    err = (got - want).abs()
+    rel_rms = float(err.pow(2).mean().sqrt() / want.pow(2).mean().sqrt())
+    assert rel_rms < BF16_REL_RMS and float(err.max()) < BF16_MAX_ABS * max(1.0, float(want.abs().max())), (rel_rms, float(err.max()))
+
+
 def test_unet_64x64_config4_fp32_vs_oracle():
     """BASELINE configs[3] geometry: attention_depths=(3, 4) at 64x64 (S = 256 and 64, d = 64), small batch."""
     cfg = OI.IUNetConfig(attention_depths=(3, 4))

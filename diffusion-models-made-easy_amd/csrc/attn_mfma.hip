@@ -79,16 +79,44 @@ __global__ void __launch_bounds__(64 * NW) attn_mfma_kernel(const bf16* __restri
     // transposed-read lane geometry: 16-lane group g, lane i = 4 q + p inside it
     const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g1 = (lane >> 4) & 1;
 
+    // 64-wide heads: K / V tiles go global -> registers -> LDS and the loads of tile k+1 are issued before the matrix work of tile k,
+    // so their round trip hides under it (14.2 -> 11.2 us).  Wider heads have no registers to spare for that (C = 256: 128
+    // accumulators + 64 of Q; with the prefetch 37 -> 60 us) and keep the direct global -> LDS staging.
+    constexpr bool PREFETCH = C <= 64;
+    constexpr int UNITS = AT_KT * (C / 8) / NT;
+    static_assert(UNITS >= 1 && UNITS * NT == AT_KT * (C / 8), "attn_mfma: tile does not split evenly over the threads");
+    uint4 kreg[UNITS], vreg[UNITS];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i) {
+            const int u = tid + i * NT, row = u / (C / 8), cu = u % (C / 8);
+            const bf16* src = base + (int64_t)(k0 + row) * ld + cu * 8;
+            kreg[i] = *reinterpret_cast<const uint4*>(src + C);
+            vreg[i] = *reinterpret_cast<const uint4*>(src + 2 * C);
+        }
+    };
+    if constexpr (PREFETCH) fetch(0);
     for (int k0 = 0; k0 < S; k0 += AT_KT) {
         __syncthreads();
         // ---- stage K and V tiles (32 keys x C) ----
-        for (int u = tid; u < AT_KT * (C / 8); u += NT) {
-            const int row = u / (C / 8), cu = u % (C / 8);
-            const bf16* src = base + (int64_t)(k0 + row) * ld + cu * 8;
-            *reinterpret_cast<uint4*>(ldsK + row * KP + cu * 16) = *reinterpret_cast<const uint4*>(src + C);
-            *reinterpret_cast<uint4*>(ldsV + row * VP + cu * 16) = *reinterpret_cast<const uint4*>(src + 2 * C);
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int i = 0; i < UNITS; ++i) {
+                const int u = tid + i * NT, row = u / (C / 8), cu = u % (C / 8);
+                *reinterpret_cast<uint4*>(ldsK + row * KP + cu * 16) = kreg[i];
+                *reinterpret_cast<uint4*>(ldsV + row * VP + cu * 16) = vreg[i];
+            }
+        } else {
+            for (int u = tid; u < AT_KT * (C / 8); u += NT) {
+                const int row = u / (C / 8), cu = u % (C / 8);
+                const bf16* src = base + (int64_t)(k0 + row) * ld + cu * 8;
+                *reinterpret_cast<uint4*>(ldsK + row * KP + cu * 16) = *reinterpret_cast<const uint4*>(src + C);
+                *reinterpret_cast<uint4*>(ldsV + row * VP + cu * 16) = *reinterpret_cast<const uint4*>(src + 2 * C);
+            }
         }
         __syncthreads();
+        if constexpr (PREFETCH)
+            if (k0 + AT_KT < S) fetch(k0 + AT_KT);
         // ---- S^T tile (32 keys x 32 queries) = K Q^T ----
         f32x16 st;
 #pragma unroll

@@ -322,3 +322,36 @@ def test_bucketed_backward_matches_and_reports_both_buckets(which):
     scale = float(want.abs().max())
     # fp32: only the order of the float atomics differs; bf16: the grouped weight-gradient launch is cut in two
     assert float((got - want).abs().max()) <= (1e-5 if which == "tiny_fp32" else 2e-3) * scale
+
+
+@pytest.mark.parametrize("which", ["ddpm", "iddpm"])
+def test_training_learns_bf16(which):
+    """End to end in the benchmark precision: 120 optimisation steps (HIP backward, fused clip + Adam + EMA, warm-up) on a small set of
+    smooth images bring the loss from ~1.1 to well under a fifth of that, for L_simple and for the hybrid loss."""
+    import dmme_amd
+    from dmme_amd.train_loop import train_step
+
+    torch.manual_seed(0)
+    if which == "ddpm":
+        lit = dmme_amd.LitDDPM(model=dmme_amd.UNet(precision="bf16"), warmup=50)
+    else:
+        from dmme_amd.models import iddpm
+
+        lit = dmme_amd.LitIDDPM(model=iddpm.UNet(precision="bf16"), warmup=50)
+    lit = lit.cuda()
+    lit.train()
+    opts, scheds = lit.configure_optimizers()
+    opt, sched = opts[0], scheds[0]["scheduler"]
+    for g in opt.param_groups:
+        g["max_grad_norm"] = 1.0
+    base = torch.nn.functional.interpolate(torch.rand(256, 3, 4, 4, device="cuda") * 2 - 1, size=32, mode="bilinear")
+    first = last = None
+    for step in range(120):
+        loss = float(train_step(lit, opt, sched, base[torch.randint(0, 256, (64,), device="cuda")]).detach())
+        assert loss == loss, f"NaN loss at step {step}"
+        if step == 0:
+            first = loss
+        last = loss
+    assert first > 0.8 and last < 0.2 * first, (first, last)
+    ema = opt.ema_parameters(lit.diffusion_model.model)
+    assert ema is not None and bool(torch.isfinite(ema).all())

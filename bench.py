@@ -309,14 +309,19 @@ def main():
         "launches_per_step": int(model._last_plan.lib.dmme_unet_plan_num_launches(model._last_plan.h)) + 2,
         "hip_graph": bool(args.graph and not getattr(model, "_graph_disabled", False)),
     }
-    # rank 0: the per-kernel roofline of the measured forward and the CPU baseline, before the secondary training figure
-    if rank == 0:
-        if not args.no_roofline:
-            xin = dmme_amd.gaussian((B, 3, side, side), device=dev)
-            out["roofline"] = roofline_leg(model, xin, all_t[500], args.precision)
-            del xin
-        if world == 1 and not args.no_cpu_baseline and args.model == "ddpm":
-            out["cpu_baseline"] = cpu_baseline_leg(B)
+    def rank0_legs():  # the per-kernel roofline of the measured forward and the CPU baseline
+        if rank == 0:
+            if not args.no_roofline:
+                xin = dmme_amd.gaussian((B, 3, side, side), device=dev)
+                out["roofline"] = roofline_leg(model, xin, all_t[500], args.precision)
+                del xin
+            if world == 1 and not args.no_cpu_baseline and args.model == "ddpm":
+                out["cpu_baseline"] = cpu_baseline_leg(B)
+
+    # several ranks: rank 0's legs first, so that a stuck collective in the training leg cannot cost them; one rank: after it (no
+    # collective to get stuck in, and the event-bracketed kernel times sit closer to rocprofv3's with the device in its training-leg state)
+    if world > 1 or args.train_steps <= 0:
+        rank0_legs()
     if args.train_steps > 0:
         del x
         # Secondary figure.  Neither an exception nor a stuck collective in it may cost the headline line: past the deadline every
@@ -339,6 +344,8 @@ def main():
         except Exception as exc:  # noqa: BLE001
             out["train_error"] = f"{type(exc).__name__}: {exc}"[:300]
         watchdog.cancel()
+        if world == 1:
+            rank0_legs()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -158,8 +158,11 @@ __global__ void __launch_bounds__(256) gn_finalize_parts_kernel(const float* __r
                                                                 float* __restrict__ scale, float* __restrict__ shift,
                                                                 float* __restrict__ mean_rstd, const float* __restrict__ t_shift,
                                                                 const float* __restrict__ t_scale, int t_ld, int nt) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * groups) return;
+    // BATCH: eight lanes share one (image, group): each merges every eighth partial, then three butterfly steps of Chan's formula
+    constexpr int LANES = BATCH ? 8 : 1;
+    const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = gi / LANES, sub = gi % LANES;
+    if (i >= N * groups) return;  // whole 8-lane teams leave together
     const int n = i / groups, g = i % groups, C = C1 + C2, cg = C / groups;
     const int c_first = g * cg;
     const bool second = c_first >= C1;
@@ -169,8 +172,7 @@ __global__ void __launch_bounds__(256) gn_finalize_parts_kernel(const float* __r
     const int fg = cs / groups;                          // producer (fine) group size
     const int f0 = (second ? c_first - C1 : c_first) / fg, nf = cg / fg;
     float na = 0.f, mean = 0.f, m2 = 0.f;
-    // partials in (tile, fine group) order.  Eight independent loads are issued before their (serial) Chan merges, so the
-    // dependent chain costs one memory latency per eight partials instead of one per partial (64x64 maps: 32+ partials)
+    // partials in (tile, fine group) order
     const int npart = tiles * nf;
     if constexpr (!BATCH) {
         for (int t = 0; t < tiles; ++t)
@@ -181,30 +183,33 @@ __global__ void __launch_bounds__(256) gn_finalize_parts_kernel(const float* __r
                 m2 += q[1] + delta * delta * (na * m / tot);
                 na = tot;
             }
-    } else
-    for (int k0 = 0; k0 < npart; k0 += 8) {
-        float2 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int k = min(k0 + u, npart - 1);
+    } else {
+        for (int k = sub; k < npart; k += LANES) {
             const int t = nf == 1 ? k : k / nf, f = nf == 1 ? 0 : k - t * nf;
-            v[u] = *reinterpret_cast<const float2*>(p + (((int64_t)n * tiles + t) * groups + f0 + f) * 2);
+            const float2 v = *reinterpret_cast<const float2*>(p + (((int64_t)n * tiles + t) * groups + f0 + f) * 2);
+            const float delta = v.x - mean, tot = na + m;
+            mean += delta * (m / tot);
+            m2 += v.y + delta * delta * (na * m / tot);
+            na = tot;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (k0 + u < npart) {
-                const float delta = v[u].x - mean, tot = na + m;
-                mean += delta * (m / tot);
-                m2 += v[u].y + delta * delta * (na * m / tot);
+        for (int off = 1; off < LANES; off <<= 1) {
+            const float nb = __shfl_xor(na, off, 64), mb = __shfl_xor(mean, off, 64), m2b = __shfl_xor(m2, off, 64);
+            const float tot = na + nb;
+            if (tot > 0.f) {
+                const float delta = mb - mean, w = nb / tot;
+                mean += delta * w;
+                m2 += m2b + delta * delta * (na * w);
                 na = tot;
             }
+        }
     }
     const float rstd = 1.0f / sqrtf(m2 / na + eps);
-    if (mean_rstd) {
+    if (mean_rstd && sub == 0) {
         mean_rstd[(int64_t)i * 2] = mean;
         mean_rstd[(int64_t)i * 2 + 1] = rstd;
     }
-    for (int j = 0; j < cg; ++j) {
+    for (int j = sub; j < cg; j += LANES) {
         const int c = c_first + j;
         float a = rstd * gamma[c], b = beta[c] - mean * a;
         if constexpr (MOD) {  // scale-shift conditioning folded in (same arithmetic as gn_modulate_kernel)
@@ -224,7 +229,7 @@ int launch_gn_finalize_parts(const float* part1, int tiles1, int cnt1, int C1, c
     const int tot = N * groups;
     const bool batch = (tiles1 > tiles2 ? tiles1 : tiles2) >= 16;
 #define DMME_GNF(BB, MM)                                                                                                                        \
-    hipLaunchKernelGGL((gn_finalize_parts_kernel<BB, MM>), dim3((tot + 255) / 256), dim3(256), 0, s, part1, tiles1, cnt1, C1, part2, tiles2, cnt2, C2, N, \
+    hipLaunchKernelGGL((gn_finalize_parts_kernel<BB, MM>), dim3((tot * ((BB) ? 8 : 1) + 255) / 256), dim3(256), 0, s, part1, tiles1, cnt1, C1, part2, tiles2, cnt2, C2, N, \
                        groups, gamma, beta, eps, scale, shift, mean_rstd, t_shift, t_scale, t_ld, nt)
     if (t_scale) {
         if (batch) DMME_GNF(true, true); else DMME_GNF(false, true);

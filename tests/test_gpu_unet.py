@@ -347,3 +347,23 @@ def test_full_chain_t1000_batch128_bf16_reproducible():
         outs.append(ddpm.generate((128, 3, 32, 32)))
     assert bool(torch.isfinite(outs[0]).all())
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_uneven_split_k_configuration(prec):
+    """192-channel deepest levels: the 4x4 / 8x8-map convolutions split Cin = 192 and 384 into uneven chunk ranges over blockIdx.y
+    (3 and 6 chunks of 64 in bf16, 6 and 12 of 32 in fp32) - against the oracle."""
+    import dmme_amd
+
+    cfg = O.UNetConfig(channels_per_depth=(64, 128, 192, 192), attention_depths=(3,))
+    net, sd = _build(cfg, 91, prec)
+    x = synth.normal(4, (8, 3, 32, 32))
+    t = torch.tensor([300])
+    want = O.unet_forward(sd, cfg, x, t)
+    with torch.no_grad():
+        got = net(x.cuda(), t.cuda()).cpu()
+    err = (got - want).abs()
+    if prec == "fp32":
+        assert float(err.max()) < FP32_ATOL
+    else:
+        assert float(err.pow(2).mean().sqrt() / want.pow(2).mean().sqrt()) < BF16_REL_RMS and float(err.max()) < BF16_MAX_ABS

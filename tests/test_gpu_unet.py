@@ -367,3 +367,20 @@ def test_uneven_split_k_configuration(prec):
         assert float(err.max()) < FP32_ATOL
     else:
         assert float(err.pow(2).mean().sqrt() / want.pow(2).mean().sqrt()) < BF16_REL_RMS and float(err.max()) < BF16_MAX_ABS
+
+
+@pytest.mark.parametrize("B", [1, 3, 5])
+def test_odd_batch_sizes_full_size_bf16(golden, B):
+    """batches that do not fill the multi-image tiles of the 8x8 / 4x4 levels (4 images per tile at 4x4): rows past the batch must be
+    neither read nor written; every row equals the same image run in a batch of 2 (rows are independent in the DDPM UNet)."""
+    g = golden("unet_full")
+    net, _ = _build(O.UNetConfig(), int(g["full_seed"]), "bf16")
+    base = synth.normal(int(g["full_xseed"]), (2, 3, 32, 32))
+    x = base[torch.arange(B) % 2]
+    t = torch.from_numpy(g["full_t_one"]).cuda()
+    with torch.no_grad():
+        pair = net(base.cuda(), t).cpu()
+        got = net(x.cuda(), t).cpu()
+    assert got.shape == (B, 3, 32, 32) and bool(torch.isfinite(got).all())
+    scale = float(pair.abs().max())
+    assert float((got - pair[torch.arange(B) % 2]).abs().max()) < 2e-2 * scale

@@ -2,12 +2,16 @@
 """Headline benchmark: DDPM denoising steps/s on the default CIFAR10 UNet (BASELINE.json configs[1]).
 
 A "step" is one pass of the hot path over one batch: eps = UNet(x_t, t) at batch 128 per GPU in
-bf16 followed by the DDPM reverse update (Philox noise included), t running down from T = 1000.
-Inputs and weights are resident in HBM before the timed region.  With --gpus N every rank runs its
-own independent batch-128 chain (sampling shards with no data-path collective: weak scaling).
+bf16 followed by the DDPM reverse update (Philox noise included), t running down from T = 1000 -
+the same replayable step `DDPM.generate` runs (one captured hipGraph: time MLP + UNet + noise +
+update + t -> t-1, all loop state resident on the device).  Inputs and weights are resident in HBM
+before the timed region.  With --gpus N every rank runs its own independent batch-128 chain
+(sampling shards with no data-path collective: weak scaling).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode sample|ddim] [--precision bf16|fp32]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode sample|ddim|train|cpu-plumbing] [--precision bf16|bf16x3|fp32]
 
+`python bench.py --gpus N` with N > 1 and no torch.distributed environment starts its N ranks itself
+(`python -m torch.distributed.run`, before this process touches the GPU) and relays rank 0's line.
 Prints ONE JSON line (rank 0) carrying `roofline` (dominant kernel, measured live with HIP events
 on the launch stream) and `cpu_baseline` (the CPU oracle timed on this host's cores, rank 0, N=1).
 """
@@ -16,6 +20,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,9 +31,11 @@ os.environ.setdefault("TQDM_DISABLE", "1")
 
 import torch  # noqa: E402
 
-PEAK = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA TFLOP/s (MI355X_MICROARCH.md, chip-level parameters)
+# dense MFMA TFLOP/s (MI355X_MICROARCH.md, chip-level parameters); bf16x3 runs three bf16 matrix products per algorithmic one
+PEAK = {"bf16": 2500.0, "bf16x3": 2500.0 / 3.0, "fp32": 157.3}
 HBM_PEAK_GBS = 8000.0
 METRIC = "denoising steps/sec + training images/sec, DDPM UNet CIFAR10 32×32 @1/2/4/8 GPU"
+FWD_GFLOP_PER_IMAGE = {"ddpm": 9.809, "iddpm64": 37.50}  # conv + linear + QK^T + AV, 2 x MAC; training = 3x
 
 
 def parse():
@@ -37,17 +45,48 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--precision", default="bf16")
-    ap.add_argument("--mode", default="sample", choices=["sample", "ddim", "train"])
+    ap.add_argument("--mode", default="sample", choices=["sample", "ddim", "train", "cpu-plumbing"])
     ap.add_argument("--model", default="ddpm", choices=["ddpm", "iddpm64"],
                     help="ddpm: BASELINE configs[1]/[2] (default UNet, 32x32); iddpm64: configs[3] (IDDPM ImageNet-64 UNet, attention at "
                          "16x16/8x8, cosine schedule, T=4000; use --batch 32 for the 256-over-8-GPUs shard)")
-    ap.add_argument("--train-steps", type=int, default=8, help="training steps timed for train_images_per_s (0: skip)")
-    ap.add_argument("--graph", action="store_true", help="replay the UNet forward from a hipGraph (small-batch sampling)")
+    ap.add_argument("--train-steps", type=int, default=30, help="training steps timed for train_images_per_s (0: skip)")
+    ap.add_argument("--no-graph", action="store_true", help="issue the step's launches eagerly instead of replaying the captured hipGraph")
+    ap.add_argument("--graph", action="store_true", help=argparse.SUPPRESS)  # accepted for older command lines: the graph is the default now
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-accurate-leg", action="store_true", help="skip the short bf16x3 (accurate mode) throughput leg")
+    ap.add_argument("--config", default=None, help="cpu-plumbing: the LightningCLI YAML to drive (default configs/ddpm/cifar10.yaml)")
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------- launcher (python bench.py --gpus N)
+def spawn_ranks(n: int) -> int:
+    """Start the N ranks as children under torch.distributed.run BEFORE this process has touched the GPU, relay their output,
+    and fail when any rank fails or rank 0's JSON line is missing.  (Never re-exec a process that initialised the GPU.)"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL peer access)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for out in proc.stdout:
+        if out.startswith('{"metric"'):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc != 0:
+        sys.stderr.write(f"bench.py: the {n}-rank run exited with status {rc}\n")
+        return rc
+    return 0 if line is not None else 4
+
+
+# ---------------------------------------------------------------------------------------------- per-kernel roofline
 def roofline_leg(model, x, t_dev, precision):
     """Per-op HIP-event timing of the same forward (dmme_unet_forward_profiled), grouped by kernel
     symbol; the dominant kernel's algorithmic FLOPs / its summed launch time is `achieved`."""
@@ -65,7 +104,7 @@ def roofline_leg(model, x, t_dev, precision):
         flops.append(f.value)
         nbytes.append(b.value)
     packed = model._packed_for(plan)
-    y = torch.empty_like(x)
+    y = torch.empty((x.shape[0], model.out_channels, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
     ms = (C.c_float * n)()
     acc = [0.0] * n
     reps = 5
@@ -93,39 +132,53 @@ def roofline_leg(model, x, t_dev, precision):
             "algo_gbs": round(g["bytes"] / (g["ms"] * 1e-3) / 1e9, 1) if g["ms"] > 0 else 0.0,
         })
     name, g = order[0]
-    traffic = None
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure is the committed
+    # rocprofv3 pass of this very configuration (tools/prof.sh -> profiles/traffic_latest.json), labelled as such, else null
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath) and x.shape[0] == 128 and x.shape[-1] == 32 and precision == "bf16":  # the PMC passes (tools/prof.sh) run this configuration only
+    if os.path.exists(tpath) and x.shape[0] == 128 and x.shape[-1] == 32 and precision == "bf16":
         try:
-            traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
+            rec = json.load(open(tpath))
+            traffic = rec.get(name, {}).get("hbm_bytes_per_launch")
+            if traffic is not None:
+                traffic_source = "file: profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload on a builder box, not this run)"
         except Exception:  # noqa: BLE001
             traffic = None
+    peak = PEAK.get(precision, 2500.0)
     if g["flops"] > 0:
         ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK.get(precision, 2500.0), "unit": "TFLOP/s",
-                "frac": round(ach / PEAK.get(precision, 2500.0), 4)}
+        roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4)}
     else:
         ach = g["bytes"] / (g["ms"] * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
-    roof.update({"traffic": traffic, "launches_per_step": g["count"], "avg_launch_us": round(1e3 * g["ms"] / g["count"], 2),
+    roof.update({"traffic": traffic, "traffic_source": traffic_source, "launches_per_step": g["count"], "avg_launch_us": round(1e3 * g["ms"] / g["count"], 2),
                  "algo_flops_per_launch": g["flops"] / g["count"], "algo_bytes_per_launch": g["bytes"] / g["count"],
                  "algo_gbs": round(g["bytes"] / (g["ms"] * 1e-3) / 1e9, 1), "step_gpu_ms_sum": round(total_ms, 3), "top_kernels": table})
     return roof
 
 
-def cpu_baseline_leg(batch_ref):
-    """The CPU oracle (oracle/, parity-pinned against the reference) timed on this host: a bounded
-    sample of the same workload (same UNet, same update, fp32), scaled to batch-`batch_ref` steps."""
+# ---------------------------------------------------------------------------------------------- CPU baseline (the oracle)
+def _cpu_threads():
+    """threads for the CPU legs: the GPU box shows every host core but grants a 16-core share per GPU - more threads only thrash"""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return min(16, avail), avail
+
+
+def cpu_baseline_leg(batch):
+    """The CPU oracle (oracle/, parity-pinned against the reference) timed on this host at the benchmark's own batch size:
+    same UNet, same DDPM update, fp32; one warm-up step, then steps for about 20 s (at least 3)."""
     from oracle import diffusion as D
     from oracle import synth
     from oracle import unet as O
 
-    # the GPU box exposes every host core but grants a 16-core share per GPU: more threads only thrash
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    threads, avail = _cpu_threads()
+    torch.set_num_threads(threads)
     cfg = O.UNetConfig()
     sd = O.make_state_dict(cfg, 1337)
-    Bc = 8
-    x = synth.normal(1, (Bc, 3, 32, 32))
+    x = synth.normal(1, (batch, 3, 32, 32))
     beta = D.linear_beta(1000)
     alpha, abar = D.alpha_tables(beta)
     z = synth.normal(2, x.shape)
@@ -139,15 +192,77 @@ def cpu_baseline_leg(batch_ref):
                 t0 = time.perf_counter()  # first step is the warm-up
                 continue
             done += 1
-            if time.perf_counter() - t0 > 12.0:
+            if done >= 3 and time.perf_counter() - t0 > 20.0:
                 break
     dt = time.perf_counter() - t0
-    img_steps = done * Bc / dt
-    return {"value": round(img_steps / batch_ref, 4), "unit": f"denoising steps/s at batch {batch_ref} (scaled from the sample)",
-            "image_steps_per_s": round(img_steps, 2), "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{done} DDPM steps of batch {Bc}, fp32, oracle UNet + update, {dt:.1f} s"}
+    return {"value": round(done / dt, 4), "unit": f"denoising steps/s at batch {batch}", "image_steps_per_s": round(done * batch / dt, 2),
+            "cores": threads, "host_cpus_visible": avail, "os_cpu_count": os.cpu_count(), "kind": "port",
+            "sample": f"{done} DDPM steps of batch {batch} (the benchmark's own batch, not scaled) after 1 warm-up, fp32, oracle UNet + update, "
+                      f"{dt:.1f} s, torch intra-op threads = {threads} (the per-GPU core share of the box)"}
 
 
+def cpu_plumbing(args):
+    """BASELINE configs[0]: `configs/ddpm/cifar10.yaml` driving the CPU reference path at batch 1, T = 1000 - ten sampling
+    steps and two training steps, no GPU.  The YAML goes through the product's own parser / constructors (host code); the math
+    runs in the CPU oracle (this leg is the `cpu_baseline` side of the bench: the product path itself has no CPU fallback)."""
+    from dmme_amd import trainer
+    from oracle import diffusion as D
+    from oracle import synth
+    from oracle import unet as O
+
+    threads, avail = _cpu_threads()
+    torch.set_num_threads(threads)
+    path = args.config or os.path.join(ROOT, "configs", "ddpm", "cifar10.yaml")
+    conf = trainer.parse_config(path)
+    torch.manual_seed(1337)
+    module = trainer.build_module(conf)  # CPU-resident parameters (torch default init), never moved to a GPU here
+    proc = module.diffusion_model
+    unet = proc.model
+    c = unet._cfg
+    cfg = O.UNetConfig(c.in_channels, c.pos_dim, c.emb_dim, c.num_groups, float(c.dropout), tuple(c.channels_per_depth[: c.num_depths]), c.num_blocks,
+                       tuple(c.attention_depths[: c.num_attention_depths]))
+    sd = {k: v.detach().clone() for k, v in unet.state_dict().items()}
+    T = proc.timesteps
+    beta = D.linear_beta(T)
+    alpha, abar = D.alpha_tables(beta)
+    x = synth.normal(1, (1, 3, 32, 32))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for k in range(10):
+            t = T - k
+            x = D.ddpm_step(x, t, O.unet_forward(sd, cfg, x, torch.tensor([t])), synth.normal(10 + k, x.shape), beta, alpha, abar)
+    dt_sample = time.perf_counter() - t0
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if k != "condition.0.embeddings"}
+    sdp = dict(sd)
+    sdp.update(params)
+    opt = torch.optim.Adam(list(params.values()), lr=module.lr)
+    losses = []
+    t0 = time.perf_counter()
+    for k in range(2):
+        x0 = synth.uniform(20 + k, (1, 3, 32, 32))
+        tt = synth.randint(30 + k, 1, T, 1)
+        masks = O.make_drop_masks(cfg, 1, 40 + k) if cfg.dropout > 0 else None
+        loss = D.training_loss(lambda xx, t_: O.unet_forward(sdp, cfg, xx, t_, drop_masks=masks), x0, tt, synth.normal(50 + k, x0.shape), abar)
+        opt.zero_grad()
+        loss.backward()
+        if conf["gradient_clip_val"]:
+            torch.nn.utils.clip_grad_norm_(list(params.values()), conf["gradient_clip_val"])
+        opt.step()
+        losses.append(float(loss.detach()))
+    dt_train = time.perf_counter() - t0
+    ok = bool(torch.isfinite(x).all()) and all(v == v for v in losses)
+    print(json.dumps({
+        "metric": METRIC, "value": round(10 / dt_sample, 3), "unit": "denoising steps/s at batch 1 on the CPU reference path (oracle)", "n_gpus": 0,
+        "steps": 10, "warmup": 0, "ms_per_step": round(1e3 * dt_sample / 10, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[0]: {os.path.relpath(path, ROOT) if path.startswith(ROOT) else path} -> {type(module).__name__} / "
+                               f"UNet {sum(v.numel() for v in sd.values())} values, T={T}, batch 1, CPU oracle: 10 sampling steps + 2 training steps"},
+        "train_ms_per_step": round(1e3 * dt_train / 2, 1), "train_losses": [round(v, 5) for v in losses], "finite": ok, "cores": threads,
+        "host_cpus_visible": avail}), flush=True)
+    return 0 if ok else 5
+
+
+# ---------------------------------------------------------------------------------------------- workloads
 def workload(dmme_amd, name, precision):
     """(UNet, image side, T, process class, Lit class, label) of a --model choice"""
     if name == "iddpm64":
@@ -158,11 +273,29 @@ def workload(dmme_amd, name, precision):
     return dmme_amd.UNet(precision=precision), 32, 1000, dmme_amd.DDPM, dmme_amd.LitDDPM, "default UNet (32,416,643 params, random init)"
 
 
-def train_leg(dmme_amd, dev, B, precision, steps, warmup, dist, model_name="ddpm"):
-    """training images/s: q_sample -> UNet fwd (train mode, Dropout2d on) -> MSE -> HIP backward -> (RCCL mean
-    all-reduce of the flat gradient) -> fused clip(1.0)+Adam+EMA -> warm-up LR step; per-GPU batch B."""
+def _fence(dist):
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def _max_over_ranks(dt, dist, dev):
+    if dist is None:
+        return dt
+    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
+
+
+def train_leg(dmme_amd, dev, B, precision, steps, warmup, dist, model_name="ddpm", reduce=True, seed=1337):
+    """training images/s: q_sample -> UNet fwd (train mode, Dropout2d on) -> loss -> HIP backward -> (RCCL mean all-reduce of
+    the flat gradient, first bucket overlapped with the rest of backward) -> fused clip(1.0)+Adam+EMA -> warm-up LR step.
+    Identical initial weights on every rank (same seed), per-rank noise / timesteps / masks afterwards."""
+    from dmme_amd import distributed as DD
     from dmme_amd.train_loop import synthetic_batch, train_step
 
+    rank = dist.get_rank() if dist is not None else 0
+    torch.manual_seed(seed)
     net, side, T, _, lit_cls, _ = workload(dmme_amd, model_name, precision)
     lit = lit_cls(model=net, timesteps=T).to(dev)
     lit.train()
@@ -170,40 +303,80 @@ def train_leg(dmme_amd, dev, B, precision, steps, warmup, dist, model_name="ddpm
     opt, sched = opts[0], scheds[0]["scheduler"]
     for g in opt.param_groups:
         g["max_grad_norm"] = 1.0
+    torch.manual_seed(DD.rank_seed(seed, rank))
     x0 = synthetic_batch(B, dev, (3, side, side))
-
-    def fence():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     loss = None
     for _ in range(warmup):
-        loss = train_step(lit, opt, sched, x0)
-    fence()
+        loss = train_step(lit, opt, sched, x0, reduce=reduce)
+    _fence(dist)
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss = train_step(lit, opt, sched, x0)
-    fence()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        loss = train_step(lit, opt, sched, x0, reduce=reduce)
+    _fence(dist)
+    dt = _max_over_ranks(time.perf_counter() - t0, dist, dev)
     assert torch.isfinite(loss).all(), "non-finite training loss"
-    return dt, float(loss.detach())
+    numel = net.flat_parameters().numel()
+    del lit, opt, sched, net
+    torch.cuda.empty_cache()
+    return dt, float(loss.detach()), numel
+
+
+def allreduce_alone_ms(dist, dev, numel, reps=10):
+    """the step's one collective by itself: mean all-reduce of a flat fp32 gradient buffer, sliced as the training step slices it"""
+    from dmme_amd import distributed as DD
+
+    buf = torch.zeros(numel, dtype=torch.float32, device=dev)
+    for _ in range(2):
+        DD.allreduce_mean_flat(buf)
+    _fence(dist)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        DD.allreduce_mean_flat(buf)
+    _fence(dist)
+    return 1e3 * _max_over_ranks(time.perf_counter() - t0, dist, dev) / reps
+
+
+def chain_leg(proc, runner, n_steps, warmup, steps, dist, dev):
+    """W untimed + K timed replays of the denoising step, loop index wrapping to the top of the chain when it runs out"""
+    from dmme_amd.common.noise import philox_reserve
+
+    left = 0
+
+    def one():
+        nonlocal left
+        if left == 0:
+            seed, off = philox_reserve(dev, runner.x.numel() * n_steps)
+            runner.set(n_steps, seed, off)
+            left = n_steps
+        runner.step()
+        left -= 1
+
+    with torch.no_grad():
+        for _ in range(warmup):
+            one()
+        _fence(dist)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        _fence(dist)
+    return _max_over_ranks(time.perf_counter() - t0, dist, dev)
 
 
 def main():
     args = parse()
+    if args.mode == "cpu-plumbing":
+        return cpu_plumbing(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    ranks_seen = 1
+    if world > 1:
         import torch.distributed as dist
 
         if world != args.gpus:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or plain `python bench.py --gpus N`)")
         # rehearsal on a box with fewer GPUs than ranks: DMME_DIST_BACKEND=gloo lets the ranks share devices (RCCL refuses that)
         backend = os.environ.get("DMME_DIST_BACKEND", "nccl")
         local = local % max(1, torch.cuda.device_count())
@@ -212,83 +385,61 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+        ones = torch.ones(1, device=torch.device("cuda", local))
+        dist.all_reduce(ones)  # the first collective: how many ranks the backend really connected
+        ranks_seen = int(round(float(ones.item())))
+        assert ranks_seen == dist.get_world_size() == world, f"backend connected {ranks_seen} ranks, expected {world}"
     else:
         dist = None
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local)
 
     import dmme_amd
+    from dmme_amd import distributed as DD
 
-    torch.manual_seed(1337 + rank)
     B = args.batch
-    model, side, T, proc_cls, _, label = workload(dmme_amd, args.model, args.precision)
+    gflop = FWD_GFLOP_PER_IMAGE[args.model]
+    peak = PEAK.get(args.precision, 2500.0)
     if args.mode == "train":
-        del model
-        dt, loss = train_leg(dmme_amd, dev, B, args.precision, args.steps, args.warmup, dist, args.model)
+        dt, loss, _ = train_leg(dmme_amd, dev, B, args.precision, args.steps, args.warmup, dist, args.model)
         if rank == 0:
+            tf = world * args.steps * B * 3 * gflop / dt / 1e3
             print(json.dumps({
                 "metric": METRIC, "value": round(world * args.steps * B / dt, 2),
                 "unit": "training images/s (q_sample + UNet fwd/bwd + grad all-reduce + clip + Adam + EMA), summed over GPUs",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
                 "config": {"workload": (f"DDPM CIFAR10 32x32 training step, default UNet, batch {B} per GPU, dropout 0.1" if args.model == "ddpm" else
-                                        f"{label}: hybrid-loss training step at 64x64, batch {B} per GPU"), "global_batch": B * world,
-                           "parallelism": f"dp{world} (RCCL mean all-reduce of the flat fp32 gradient)"}, "final_loss": round(loss, 5)}), flush=True)
+                                        f"IDDPM ImageNet-64 hybrid-loss training step at 64x64, batch {B} per GPU"), "global_batch": B * world,
+                           "parallelism": f"dp{world} (RCCL mean all-reduce of the flat fp32 gradient)"}, "final_loss": round(loss, 5),
+                "ranks_seen": ranks_seen, "step_tflops": round(tf, 1), "step_frac_of_peak": round(tf / (world * peak), 4)}), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
-        return
+        return 0
+
+    torch.manual_seed(1337)  # same weights on every rank ...
+    model, side, T, proc_cls, _, label = workload(dmme_amd, args.model, args.precision)
     model = model.to(dev).eval()
+    torch.manual_seed(DD.rank_seed(1337, rank))  # ... each rank's own chains
     if args.mode == "ddim":
         proc = dmme_amd.DDIM(model, T, 50).to(dev)
+        n_steps = 50
     else:
         proc = proc_cls(model, T).to(dev)
+        n_steps = T
     x = dmme_amd.gaussian((B, 3, side, side), device=dev)
-    all_t = torch.arange(0, T + 1, device=dev).unsqueeze(1)
-    tau = proc._tau_host if args.mode == "ddim" else None
-
-    t_buf = all_t[T].clone()
-
-    def fwd(tt):
-        if args.graph:
-            t_buf.copy_(tt)
-            return model.graphed_forward(x, t_buf)
-        return model(x, tt)
-
-    def one_step(k):
-        with torch.no_grad():
-            if args.mode == "ddim":
-                i = 50 - (k % 50)
-                eps = fwd(all_t[tau[i]])
-                proc._ddim_update(x, eps, i)
-            else:
-                t = T - (k % T)
-                eps = fwd(all_t[t])
-                proc._reverse_update(x, eps, t, None)
-
-    def fence():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for k in range(args.warmup):
-        one_step(k)
-    fence()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        one_step(args.warmup + k)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    runner = proc.chain_runner(x, use_graph=not args.no_graph)
+    assert runner is not None, "the replayable denoising step does not apply to this configuration"
+    elapsed = chain_leg(proc, runner, n_steps, args.warmup, args.steps, dist, dev)
     assert torch.isfinite(x).all(), "non-finite samples"
 
+    step_tf = world * args.steps * B * gflop / elapsed / 1e3
+    update = "DDIM" if args.mode == "ddim" else "IDDPM learned-variance" if args.model == "iddpm64" else "DDPM"
     out = {
         "metric": METRIC,
         "value": round(world * args.steps / elapsed, 3),
-        "unit": f"denoising steps/s (one step = UNet forward + {'DDIM' if args.mode == 'ddim' else 'IDDPM learned-variance' if args.model == 'iddpm64' else 'DDPM'} update on a batch of {B}), summed over GPUs",
+        "unit": f"denoising steps/s (one step = UNet forward + {update} update on a batch of {B}), summed over GPUs",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
@@ -305,42 +456,94 @@ def main():
             "parallelism": f"dp{world} (independent chains per GPU, no data-path collective)",
         },
         "image_steps_per_s": round(world * args.steps * B / elapsed, 1),
+        # whole-step arithmetic rate: B x algorithmic forward FLOPs per step over the measured step time - the
+        # figure the dominant kernel's roofline fraction must not be mistaken for
+        "step_tflops": round(step_tf, 1),
+        "step_frac_of_peak": round(step_tf / (world * peak), 4),
+        "ranks_seen": ranks_seen,
         "train_images_per_s": None,
-        "launches_per_step": int(model._last_plan.lib.dmme_unet_plan_num_launches(model._last_plan.h)) + 2,
-        "hip_graph": bool(args.graph and not getattr(model, "_graph_disabled", False)),
+        "launches_per_step": int(runner.plan.lib.dmme_unet_plan_num_launches(runner.plan.h)) + 1,
+        "hip_graph": bool(runner.graph is not None),
     }
+
     def rank0_legs():  # the per-kernel roofline of the measured forward and the CPU baseline
         if rank == 0:
             if not args.no_roofline:
                 xin = dmme_amd.gaussian((B, 3, side, side), device=dev)
-                out["roofline"] = roofline_leg(model, xin, all_t[500], args.precision)
+                model._last_plan = runner.plan
+                out["roofline"] = roofline_leg(model, xin, proc.timestep_tensor(min(500, T), dev), args.precision)
                 del xin
             if world == 1 and not args.no_cpu_baseline and args.model == "ddpm":
                 out["cpu_baseline"] = cpu_baseline_leg(B)
+
+    def accurate_leg():
+        """the same sampling step in the accurate mode (precision="bf16x3": fp32 activations, every matrix product as three bf16
+        MFMA passes on hi/lo splits - within north_star's 1e-3 of the reference), reported next to the fast mode"""
+        if args.no_accurate_leg or args.precision != "bf16" or args.model != "ddpm" or args.mode != "sample" or "bf16x3" not in dmme_amd._lib.DTYPES:
+            return
+        try:
+            torch.manual_seed(1337)
+            m3 = dmme_amd.UNet(precision="bf16x3").to(dev).eval()
+            p3 = dmme_amd.DDPM(m3, T).to(dev)
+            x3 = dmme_amd.gaussian((B, 3, side, side), device=dev)
+            r3 = p3.chain_runner(x3, use_graph=not args.no_graph)
+            k = max(5, min(20, args.steps))
+            dt3 = chain_leg(p3, r3, T, 3, k, dist, dev)
+            out["accurate_mode"] = {"precision": "bf16x3", "steps_per_s": round(world * k / dt3, 3), "ms_per_step": round(1e3 * dt3 / k, 3),
+                                    "steps": k, "step_tflops_algorithmic": round(world * k * B * gflop / dt3 / 1e3, 1)}
+            del m3, p3, x3, r3
+            torch.cuda.empty_cache()
+        except Exception as exc:  # noqa: BLE001 - a secondary figure must not cost the headline line
+            out["accurate_mode"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
 
     # several ranks: rank 0's legs first, so that a stuck collective in the training leg cannot cost them; one rank: after it (no
     # collective to get stuck in, and the event-bracketed kernel times sit closer to rocprofv3's with the device in its training-leg state)
     if world > 1 or args.train_steps <= 0:
         rank0_legs()
+    accurate_leg()
+    rc = 0
     if args.train_steps > 0:
-        del x
-        # Secondary figure.  Neither an exception nor a stuck collective in it may cost the headline line: past the deadline every
-        # rank leaves through the watchdog, rank 0 printing the line it already has.
+        del x, runner
+        proc._runner = None
+        # Secondary figures.  Neither an exception nor a stuck collective in them may cost the headline line: past the deadline
+        # every rank leaves through the watchdog - rank 0 printing the line it already has - with a NON-zero status, so the launcher
+        # and CI see the hang.
         import threading
 
         def bail():
             if rank == 0:
-                out["train_error"] = "training leg exceeded its deadline"
+                out["train_error"] = "training leg exceeded its deadline (stuck collective?)"
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(3)
 
-        watchdog = threading.Timer(240.0, bail)
+        watchdog = threading.Timer(300.0, bail)
         watchdog.daemon = True
         watchdog.start()
         try:
-            dt_tr, _ = train_leg(dmme_amd, dev, B, args.precision, args.train_steps, 2, dist, args.model)
-            out["train_images_per_s"] = round(world * args.train_steps * B / dt_tr, 1)
-            out["train_ms_per_step"] = round(1e3 * dt_tr / args.train_steps, 2)
+            k = args.train_steps
+            dt_tr, _, numel = train_leg(dmme_amd, dev, B, args.precision, k, 3, dist, args.model)
+            out["train_images_per_s"] = round(world * k * B / dt_tr, 1)
+            out["train_ms_per_step"] = round(1e3 * dt_tr / k, 2)
+            out["train_steps"] = k
+            ttf = world * k * B * 3 * gflop / dt_tr / 1e3
+            out["train_step_tflops"] = round(ttf, 1)
+            out["train_step_frac_of_peak"] = round(ttf / (world * peak), 4)
+            if world > 1:
+                # the same step without its collective, and the collective alone: what the overlap hides
+                dt_nc, _, _ = train_leg(dmme_amd, dev, B, args.precision, k, 3, dist, args.model, reduce=False)
+                ar_ms = allreduce_alone_ms(dist, dev, numel)
+                step_ms, nocomm_ms = 1e3 * dt_tr / k, 1e3 * dt_nc / k
+                exposed = max(0.0, step_ms - nocomm_ms)
+                out["train_dp"] = {
+                    "semantics": f"per-rank batch {B} (the reference under Lightning DDP: YAML batch_size is per rank), global batch {B * world}",
+                    "ms_per_step": round(step_ms, 3), "ms_per_step_without_allreduce": round(nocomm_ms, 3),
+                    "allreduce_alone_ms": round(ar_ms, 3), "allreduce_exposed_ms": round(exposed, 3),
+                    "allreduce_hidden_ms": round(max(0.0, ar_ms - exposed), 3), "gradient_bytes": numel * 4}
+                if B % world == 0 and B // world >= 1:
+                    bs = B // world  # north_star wording: the batch of 128 sharded over the ranks
+                    dt_g, _, _ = train_leg(dmme_amd, dev, bs, args.precision, k, 3, dist, args.model)
+                    out["train_global_batch"] = {"semantics": f"global batch {B} sharded: {bs} per rank (strong scaling of one batch-{B} step)",
+                                                 "images_per_s": round(k * B / dt_g, 1), "ms_per_step": round(1e3 * dt_g / k, 3)}
         except Exception as exc:  # noqa: BLE001
             out["train_error"] = f"{type(exc).__name__}: {exc}"[:300]
         watchdog.cancel()
@@ -351,7 +554,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libdmme_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 F32, BF16 = 0, 1
+CHAIN_DDPM, CHAIN_DDIM, CHAIN_IDDPM = 0, 1, 2
 DTYPES = {"fp32": F32, "float32": F32, "32": F32, "bf16": BF16, "bfloat16": BF16, "16": BF16, "bf16-mixed": BF16, "16-mixed": BF16}
 
 _lock = threading.Lock()
@@ -87,8 +88,8 @@ PROTOTYPES = {
     "dmme_unet_plan_packed_bwd_bytes": (_i64, [_vp]),
     "dmme_unet_plan_bwd_workspace_bytes": (_i64, [_vp]),
     "dmme_unet_pack_params_bwd": (_i, [_vp, _vp, _vp, _vp]),
-    "dmme_unet_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "dmme_unet_backward_buckets": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, BUCKET_FN, _vp]),
+    "dmme_unet_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dmme_unet_backward_buckets": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, BUCKET_FN, _vp]),
     "dmme_unet_plan_grad_buckets": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "dmme_grad_norm": (_i, [_vp, _i64, _vp, _vp, _vp]),
     "dmme_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _vp, _f, _f, _vp]),
@@ -98,6 +99,9 @@ PROTOTYPES = {
     "dmme_q_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp]),
     "dmme_ddpm_step": (_i, [_vp, _vp, _vp, _f, _f, _f, _i, _i64, _vp]),
     "dmme_ddim_step": (_i, [_vp, _vp, _f, _f, _i64, _vp]),
+    "dmme_chain_set": (_i, [_vp, _i64, _vp, _u64, _u64, _vp]),
+    "dmme_chain_update": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp]),
+    "dmme_chain_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "dmme_mse_loss": (_i, [_vp, _vp, _i64, _vp, _vp, _f, _vp, _vp]),
     "dmme_image_batch": (_i, [_vp, _i64, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "dmme_iddpm_step": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _i, _i, _i64, _vp]),

@@ -17,13 +17,17 @@ class _UNetFunction(torch.autograd.Function):
         y, saved = model._forward_impl(x, c, want_ctx=True)
         ctx.model = model
         ctx.saved = saved
+        ctx.want_dx = bool(x.requires_grad)
+        ctx.x_dtype = x.dtype
         return y
 
     @staticmethod
     def backward(ctx, dy: Tensor):
-        ctx.model._backward_impl(ctx.saved, dy)
+        # parameter gradients: accumulated by the library into model.flat_grad() (param.grad views); the gradient with respect
+        # to the input image (guidance, sensitivity tests) is returned to autograd when x required it
+        dx = ctx.model._backward_impl(ctx.saved, dy, want_dx=ctx.want_dx)
         ctx.saved = None
-        return None, None, None, None
+        return (dx.to(ctx.x_dtype) if dx is not None else None), None, None, None
 
 
 def unet_apply(model, x: Tensor, c: Tensor) -> Tensor:

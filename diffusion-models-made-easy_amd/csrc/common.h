@@ -214,6 +214,9 @@ int launch_q_sample(const float* x0, const float* z, const float* sqrt_abar, con
 int launch_ddpm_step(float* x, const float* eps, const float* z, float c1, float c2, float sigma, int add_noise,
                      int64_t numel, hipStream_t s);
 int launch_ddim_step(float* x, const float* eps, float s1, float s2, int64_t numel, hipStream_t s);
+int launch_chain_set(void* state, int64_t i, const int64_t* t_table, uint64_t seed, uint64_t offset, hipStream_t s);
+int launch_chain_update(int kind, float* x, const float* out, const float* coef, const int64_t* t_table, void* state, int B, int64_t chw,
+                        hipStream_t s);
 int launch_image_batch(const uint8_t* data, const int64_t* idx, const uint8_t* flip, int B, int C, int H, int W, float* out, hipStream_t s);
 int launch_iddpm_step(float* x, const float* out, const float* z, float c1, float c2, float log_beta, float log_beta_tilde, int add_noise,
                       int B, int64_t chw, hipStream_t s);

@@ -321,6 +321,111 @@ int launch_iddpm_loss(const float* out, const float* x_t, const float* x_0, cons
     return DMME_OK;
 }
 
+// ------------------------------------------------------------------ replayable chain step (hipGraph-friendly sampling loops)
+// Everything that changes from one denoising step to the next lives in DEVICE memory, so the launch sequence of a step is the
+// same every time and can be replayed from one captured graph: the loop state {i, t = t_table[i], Philox offset and seed, ticket}, the
+// per-index scalars of the update (`coef[i][0..3]`) and the noise itself (drawn here from the same Philox stream / offsets
+// dmme_randn would use: the chain is bit-identical to the eager loop under the same seed).  The block that takes the last
+// ticket has, by construction, run after every block read the state, and advances it: i -= 1, t = t_table[i], offset += quads.
+struct ChainState {
+    long long i;
+    long long t;
+    unsigned long long offset;
+    unsigned long long seed;
+    unsigned int ticket, pad;
+    unsigned long long reserved[3];
+};
+static_assert(sizeof(ChainState) == 64, "ChainState is eight 64-bit words (dmme_hip.h: dmme_chain_*)");
+
+__global__ void chain_set_kernel(ChainState* st, long long i, const long long* __restrict__ t_table, unsigned long long seed, unsigned long long offset) {
+    st->i = i;
+    st->t = t_table[i];
+    st->offset = offset;
+    st->seed = seed;
+    st->ticket = 0u;
+    st->pad = 0u;
+}
+
+// KIND 0: DDPM (coef = 1/sqrt(alpha), beta/sqrt(1-abar), sqrt(beta)), 1: DDIM (sqrt(1-abar_tau_i), sqrt(abar_tau_{i-1})),
+//      2: IDDPM (1/sqrt(alpha), beta/sqrt(1-abar), log beta, log max(beta~, 1e-12)); `out` has 2*chw values per image then
+template <int KIND>
+__global__ void __launch_bounds__(256) chain_update_kernel(float* __restrict__ x, const float* __restrict__ out, const float* __restrict__ coef,
+                                                           const long long* __restrict__ t_table, ChainState* st, int64_t chw, int64_t n4) {
+    const long long i = st->i, t = st->t;
+    const unsigned long long off = st->offset, seed = st->seed;
+    const float c0 = coef[4 * i], c1 = coef[4 * i + 1], c2 = coef[4 * i + 2], c3 = coef[4 * i + 3];
+    const int add_noise = t != 1;
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = q * 4;
+        float4 xv = *reinterpret_cast<const float4*>(x + b);
+        float* xs = reinterpret_cast<float*>(&xv);
+        if (KIND == 1) {
+            const float4 ev = *reinterpret_cast<const float4*>(out + b);
+            const float* es = reinterpret_cast<const float*>(&ev);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xs[j] = __fmul_rn(c1, __fdiv_rn(__fsub_rn(xs[j], __fmul_rn(c0, es[j])), c1));
+        } else {
+            float z[4] = {0.f, 0.f, 0.f, 0.f};
+            if (add_noise) normal4(seed, off + (uint64_t)q, z);  // the reference draws and discards at t == 1: the offset still advances
+            if (KIND == 0) {
+                const float4 ev = *reinterpret_cast<const float4*>(out + b);
+                const float* es = reinterpret_cast<const float*>(&ev);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xs[j] = ddpm_update(xs[j], es[j], z[j], c0, c1, c2, add_noise);
+            } else {
+                const int64_t img = b / chw, r = b - img * chw;  // chw % 4 == 0: a quad never straddles two images
+                const float4 ev = *reinterpret_cast<const float4*>(out + img * 2 * chw + r);
+                const float4 vv = *reinterpret_cast<const float4*>(out + img * 2 * chw + chw + r);
+                const float* es = reinterpret_cast<const float*>(&ev);
+                const float* vs = reinterpret_cast<const float*>(&vv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float m = __fmul_rn(c0, __fsub_rn(xs[j], __fmul_rn(c1, es[j])));
+                    xs[j] = add_noise ? __fadd_rn(m, __fmul_rn(iddpm_std(vs[j], c2, c3), z[j])) : m;
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(x + b) = xv;
+    }
+    __syncthreads();  // every thread of this block has read the state (and is past its loads of it)
+    if (threadIdx.x == 0) {
+        const unsigned tk = atomicAdd(&st->ticket, 1u);
+        if (tk == gridDim.x - 1) {  // last block: all others took their ticket after reading the state
+            const long long ni = i > 0 ? i - 1 : 0;
+            st->i = ni;
+            st->t = t_table[ni];
+            st->offset = off + (unsigned long long)n4;
+            atomicExch(&st->ticket, 0u);
+        }
+    }
+}
+
+int launch_chain_set(void* state, int64_t i, const int64_t* t_table, uint64_t seed, uint64_t offset, hipStream_t s) {
+    hipLaunchKernelGGL(chain_set_kernel, dim3(1), dim3(1), 0, s, (ChainState*)state, (long long)i, (const long long*)t_table, (unsigned long long)seed,
+                       (unsigned long long)offset);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+int launch_chain_update(int kind, float* x, const float* out, const float* coef, const int64_t* t_table, void* state, int B, int64_t chw,
+                        hipStream_t s) {
+    DMME_REQUIRE(kind >= 0 && kind <= 2, DMME_ERR_INVALID, "chain_update: unknown sampler kind %d", kind);
+    DMME_REQUIRE(chw % 4 == 0, DMME_ERR_UNSUPPORTED, "chain_update: image size %lld is not a multiple of 4", (long long)chw);
+    const int64_t n4 = (int64_t)B * chw / 4;
+    if (n4 <= 0) return DMME_OK;
+    const dim3 g(grid_for(n4)), b(256);
+    ChainState* st = (ChainState*)state;
+    const long long* tt = (const long long*)t_table;
+    if (kind == 0)
+        hipLaunchKernelGGL(chain_update_kernel<0>, g, b, 0, s, x, out, coef, tt, st, chw, n4);
+    else if (kind == 1)
+        hipLaunchKernelGGL(chain_update_kernel<1>, g, b, 0, s, x, out, coef, tt, st, chw, n4);
+    else
+        hipLaunchKernelGGL(chain_update_kernel<2>, g, b, 0, s, x, out, coef, tt, st, chw, n4);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
 // ------------------------------------------------------------------ input pipeline: HBM-resident uint8 dataset -> training batch
 // out[b][c][y][x] = norm(ToTensor(flip_b(data[idx[b]])))[c][y][x]: torchvision's ToTensor (uint8 -> float / 255) followed by the
 // reference's norm, (x - 0.5) * 2 (src/dmme/common/norm.py:4-6), and RandomHorizontalFlip as a per-image bit

@@ -1000,7 +1000,7 @@ void op_account(const dmme_plan* P, const Op& o, char* label, int cap, double* f
 extern "C" {
 
 DMME_API const char* dmme_last_error(void) { return g_err; }
-DMME_API int dmme_version(void) { return 100; }
+DMME_API int dmme_version(void) { return 101; }
 DMME_API int dmme_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1275,8 +1275,8 @@ DMME_API int dmme_unet_pack_params_bwd(const dmme_plan* plan, const float* ref_f
 }
 
 static int backward_impl(const dmme_plan* plan, const void* packed, const void* packed_bwd, const float* x, const int64_t* t, int t_len,
-                         const float* d_y, void* workspace, void* bwd_workspace, const float* drop_masks, float* grad_flat, void* stream,
-                         dmme_bucket_fn ready, void* user) {
+                         const float* d_y, void* workspace, void* bwd_workspace, const float* drop_masks, float* grad_flat, float* d_x,
+                         void* stream, dmme_bucket_fn ready, void* user) {
     DMME_REQUIRE(plan && packed && packed_bwd && x && t && d_y && workspace && bwd_workspace && grad_flat, DMME_ERR_INVALID,
                  "unet_backward: null argument");
     DMME_REQUIRE(t_len == 1 || t_len == plan->B, DMME_ERR_INVALID, "unet_backward: bad t_len %d", t_len);
@@ -1455,6 +1455,22 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
             }
             if (rc != DMME_OK) break;
         }
+        if (o.src1 == -2 && d_x) {  // gradient with respect to the network input (NCHW fp32), only on request
+            ConvArgs d{};
+            d.src1 = dy;
+            d.C1 = a.Cout;
+            d.N = B;
+            d.Hin = d.Hout = a.Hout;
+            d.Win = d.Wout = a.Wout;
+            d.stride = 1;
+            d.taps = o.taps;
+            d.Cout = Cin;
+            d.w = pkb + P->params[o.w].packed_bwd_off;
+            d.dst = d_x;
+            d.out_nchw = 1;
+            rc = conv_mfma_supported(dt, d) ? launch_conv_mfma(dt, d, s) : launch_conv_generic(dt, d, s);
+            if (rc != DMME_OK) break;
+        }
         // 4. residual branch: d(res) += dY
         if (o.res1 >= 0) {
             const int R1 = P->tensors[o.res1].C;
@@ -1492,15 +1508,15 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
 
 DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const void* packed_bwd, const float* x,
                                 const int64_t* t, int t_len, const float* d_y, void* workspace, void* bwd_workspace,
-                                const float* drop_masks, float* grad_flat, void* stream) {
-    return backward_impl(plan, packed, packed_bwd, x, t, t_len, d_y, workspace, bwd_workspace, drop_masks, grad_flat, stream, nullptr, nullptr);
+                                const float* drop_masks, float* grad_flat, float* d_x, void* stream) {
+    return backward_impl(plan, packed, packed_bwd, x, t, t_len, d_y, workspace, bwd_workspace, drop_masks, grad_flat, d_x, stream, nullptr, nullptr);
 }
 
 DMME_API int dmme_unet_backward_buckets(const dmme_plan* plan, const void* packed, const void* packed_bwd, const float* x,
                                         const int64_t* t, int t_len, const float* d_y, void* workspace, void* bwd_workspace,
-                                        const float* drop_masks, float* grad_flat, void* stream, dmme_bucket_fn ready, void* user) {
+                                        const float* drop_masks, float* grad_flat, float* d_x, void* stream, dmme_bucket_fn ready, void* user) {
     DMME_REQUIRE(ready, DMME_ERR_INVALID, "unet_backward_buckets: null callback");
-    return backward_impl(plan, packed, packed_bwd, x, t, t_len, d_y, workspace, bwd_workspace, drop_masks, grad_flat, stream, ready, user);
+    return backward_impl(plan, packed, packed_bwd, x, t, t_len, d_y, workspace, bwd_workspace, drop_masks, grad_flat, d_x, stream, ready, user);
 }
 
 DMME_API int dmme_unet_plan_grad_buckets(const dmme_plan* plan, int64_t offsets[2], int64_t numels[2]) {
@@ -1574,6 +1590,30 @@ DMME_API int dmme_ddim_step(float* x, const float* eps, float sqrt_one_minus_aba
                    void* stream) {
     DMME_REQUIRE(x && eps, DMME_ERR_INVALID, "ddim_step: null argument");
     return launch_ddim_step(x, eps, sqrt_one_minus_abar, sqrt_abar_prev, numel, (hipStream_t)stream);
+}
+
+DMME_API int dmme_chain_set(void* state, int64_t i, const int64_t* t_table, uint64_t philox_seed, uint64_t philox_offset, void* stream) {
+    DMME_REQUIRE(state && t_table && i >= 0, DMME_ERR_INVALID, "chain_set: bad argument");
+    return launch_chain_set(state, i, t_table, philox_seed, philox_offset, (hipStream_t)stream);
+}
+
+DMME_API int dmme_chain_update(int kind, float* x, const float* model_out, const float* step_coef, const int64_t* t_table, void* state,
+                               int B, int64_t chw, void* stream) {
+    DMME_REQUIRE(x && model_out && step_coef && t_table && state && B > 0 && chw > 0, DMME_ERR_INVALID, "chain_update: bad argument");
+    return launch_chain_update(kind, x, model_out, step_coef, t_table, state, B, chw, (hipStream_t)stream);
+}
+
+DMME_API int dmme_chain_step(const dmme_plan* plan, const void* packed, float* x, float* model_out, void* workspace, int kind,
+                             const float* step_coef, const int64_t* t_table, void* state, void* stream) {
+    DMME_REQUIRE(plan && packed && x && model_out && workspace && step_coef && t_table && state, DMME_ERR_INVALID, "chain_step: null argument");
+    DMME_REQUIRE((kind == DMME_CHAIN_IDDPM) == (plan->out_channels == 2 * plan->cfg.in_channels), DMME_ERR_INVALID,
+                 "chain_step: sampler kind %d does not fit a network with %d output channels", kind, plan->out_channels);
+    // the timestep the network is evaluated at is the second word of the device-resident loop state
+    const int64_t* t_dev = (const int64_t*)state + 1;
+    int rc = dmme_unet_forward(plan, packed, x, t_dev, 1, model_out, workspace, nullptr, stream);
+    if (rc != DMME_OK) return rc;
+    return launch_chain_update(kind, x, model_out, step_coef, t_table, state, plan->B, (int64_t)plan->cfg.in_channels * plan->H * plan->W,
+                               (hipStream_t)stream);
 }
 
 DMME_API int dmme_image_batch(const uint8_t* data, int64_t n_images, const int64_t* idx, const uint8_t* flip, int B, int C, int H, int W,

@@ -52,21 +52,36 @@ class DDIM(DDPM):
         x = x_tau_i.detach().to(torch.float32).clone()
         return self._ddim_update(x, eps, idx)
 
+    _chain_kind = _lib.CHAIN_DDIM
+
+    def _chain_tables(self):
+        S, tau = self.sub_timesteps, self._tau_host
+        rows = [(0.0, 1.0, 0.0, 0.0)] + [(self._s1[tau[i]], self._s2[tau[i - 1]], 0.0, 0.0) for i in range(1, S + 1)]
+        return S, rows, list(tau)
+
+    def denoise_once(self, x: Tensor, i: int) -> Tensor:
+        i = int(i)
+        done = self._once_via_runner(x, i)
+        if done is not None:
+            return done
+        eps = self.model(x, self.tau_tensor(i, x.device))
+        out = x.detach().to(torch.float32).clone()
+        return self._ddim_update(out, eps, i)
+
+    def tau_tensor(self, i: int, device) -> Tensor:
+        if self._tau_dev is None or self._tau_dev.device != torch.device(device):
+            self._tau_dev = self.tau.to(device).unsqueeze(1)
+        return self._tau_dev[i]
+
     @torch.no_grad()
     def generate(self, img_size: Tuple[int, int, int, int]) -> Tensor:
         """S-step strided chain (reference: diffusion_models/ddim.py:79-99)"""
         dev = self.beta.device
         x = gaussian(img_size, device=dev)
-        if self._tau_dev is None or self._tau_dev.device != dev:
-            self._tau_dev = self.tau.to(dev).unsqueeze(1)
-        # small batches are launch/latency bound: replay the forward from a hipGraph (no gain at B >= 128)
-        graphed = hasattr(self.model, "graphed_forward") and not self.model.training and int(img_size[0]) <= 64
-        t_buf = self._tau_dev[self.sub_timesteps].clone() if graphed else None
+        runner = self.chain_runner(x)
+        if runner is not None:
+            return runner.run(self.sub_timesteps, self.sub_timesteps)
         for i in range(self.sub_timesteps, 0, -1):
-            if graphed:
-                t_buf.copy_(self._tau_dev[i])
-                eps = self.model.graphed_forward(x, t_buf)
-            else:
-                eps = self.model(x, self._tau_dev[i])
+            eps = self.model(x, self.tau_tensor(i, dev))
             self._ddim_update(x, eps, i)
         return x

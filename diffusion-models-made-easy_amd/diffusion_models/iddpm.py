@@ -82,6 +82,14 @@ class IDDPM(DDPM):
         return None
 
     # ------------------------------------------------------------------ sampling
+    _chain_kind = _lib.CHAIN_IDDPM
+
+    def _chain_tables(self):
+        T = self.timesteps
+        finite = lambda v: v if v == v and abs(v) != float("inf") else 0.0  # row 0 is never stepped from
+        rows = [tuple(finite(v) for v in self._coef_host[t][:4]) for t in range(T + 1)]
+        return T, rows, list(range(T + 1))
+
     def _reverse_update(self, x_t: Tensor, model_output: Tensor, t: int, noise: Optional[Tensor]) -> Tensor:
         if noise is None:
             noise = gaussian_like(x_t)  # drawn even when t == 1, then unused (reference :144-149)

@@ -31,6 +31,40 @@ def rank_seed(seed: int, rank: int) -> int:
     return (seed * 1000003 + 7919 * rank) & 0x7FFFFFFFFFFFFFFF
 
 
+def init_from_env(device_index: Optional[int] = None) -> Tuple[int, int, int]:
+    """Join the process group `python -m torch.distributed.run` describes in the environment (no-op for a single process or when
+    already initialised).  Backend "nccl" (= RCCL over xGMI) unless DMME_DIST_BACKEND says otherwise (gloo: CPU tests and
+    several ranks rehearsed on one GPU).  Returns (rank, local_rank, world)."""
+    rank, local, world = env_rank_world()
+    if world > 1 and dist.is_available() and not dist.is_initialized():
+        backend = os.environ.get("DMME_DIST_BACKEND", "nccl")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            idx = local if device_index is None else device_index
+            torch.cuda.set_device(idx)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", idx))
+        else:
+            dist.init_process_group(backend)
+    return rank, local, world
+
+
+def sync_parameters(model, optimizer=None, src: int = 0) -> bool:
+    """Data-parallel start: every rank takes rank `src`'s parameters (and EMA copy), as DistributedDataParallel does when it
+    wraps a module - averaged gradients only mean something for identical replicas.  One broadcast of the flat fp32 buffer."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return False
+    flat = model.flat_parameters()
+    with torch.no_grad():
+        dist.broadcast(flat, src=src)
+    if hasattr(model, "mark_params_updated"):
+        model.mark_params_updated()
+    ema = optimizer.ema_parameters(model) if optimizer is not None and hasattr(optimizer, "ema_parameters") else None
+    if ema is not None:
+        with torch.no_grad():
+            dist.broadcast(ema, src=src)
+    return True
+
+
 def max_over_ranks(value: float, device: Optional[torch.device] = None) -> float:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return value

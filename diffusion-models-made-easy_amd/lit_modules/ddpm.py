@@ -47,7 +47,9 @@ class LitDDPM(_Base):
 
     def forward(self, x_t: Tensor, t: int):
         r"""denoise once: x_t -> x_{t-1} (reference: lit_modules/ddpm.py:65-79)"""
-        timestep = torch.tensor([t], device=x_t.device)
+        if hasattr(self.diffusion_model, "denoise_once") and not isinstance(t, torch.Tensor):
+            return self.diffusion_model.denoise_once(x_t, t)  # resident timestep table: no host-to-device copy per step
+        timestep = torch.as_tensor(t, device=x_t.device).reshape(1)
         return self.diffusion_model.sampling_step(x_t, timestep)
 
     def training_step(self, batch, batch_idx):

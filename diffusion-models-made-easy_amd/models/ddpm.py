@@ -104,6 +104,7 @@ class UNet(nn.Module):
         self._injected_masks: Optional[Tensor] = None
         self._mask_calls = 0
         self._param_epoch = 0  # bumped by optimisers that update the flat buffer through raw pointers
+        self._views_version = 0
         self._flat_grad: Optional[Tensor] = None
         self._bucket_hook = None  # callable(offset, numel): set by distributed.OverlappedGradReducer
 
@@ -181,12 +182,18 @@ class UNet(nn.Module):
         flat = self._flat
         ok = flat.device == first.device and flat.dtype == torch.float32
         if ok:
+            # A Parameter rebound with `p.data = view` (what .cuda() / .to() leave behind, below) keeps its OWN version counter:
+            # in-place writes through it (load_state_dict, torch.optim steps, p.copy_) do not move flat._version.  The sum of
+            # the per-tensor counters is part of every repack / graph key (`_weights_key`).
             base = flat.data_ptr()
+            ver = 0
             for mod, leaf, off, n, shape, is_buf in self._views:
                 t = self._current(mod, leaf, is_buf)
                 if t.data_ptr() != base + 4 * off or t.dtype != torch.float32:
                     ok = False
                     break
+                ver += t._version
+            self._views_version = ver
         if ok:
             return flat
         new = torch.empty(self._ref_numel, dtype=torch.float32, device=first.device)
@@ -200,14 +207,48 @@ class UNet(nn.Module):
                 else:
                     t.data = v
         self._flat = new
+        self._views_version = sum(self._current(mod, leaf, is_buf)._version for mod, leaf, _, _, _, is_buf in self._views)
         for p in self._plans.values():
             p.packed_version = None
         return new
 
+    def _weights_key(self, flat: Tensor):
+        """identifies the parameter VALUES the packed kernel-layout copies / captured graphs were made from: buffer address,
+        its version, the versions of every named tensor viewing it, and the epoch raw-pointer optimisers bump"""
+        return (flat.data_ptr(), flat._version, self._views_version, self._param_epoch)
+
     def _apply(self, fn, *a, **kw):
-        out = super()._apply(fn, *a, **kw)
-        self._ensure_flat()
-        return out
+        """.cuda() / .to(device): ONE copy of the flat buffer and a rebind of the 305 named views, instead of nn.Module's
+        tensor-by-tensor transfer followed by a re-flatten (2 x 305 small copies: the `copyBuffer` dispatches of the round-1
+        profiles).  Conversions that change the dtype take the generic route and are re-flattened to fp32 afterwards."""
+        flat = self._ensure_flat()
+        with torch.no_grad():
+            new = fn(flat)
+        if not (isinstance(new, Tensor) and new.dtype == torch.float32 and new.numel() == flat.numel()):
+            out = super()._apply(fn, *a, **kw)
+            self._ensure_flat()
+            return out
+        if new is not flat and new.data_ptr() != flat.data_ptr():
+            new = new.detach().contiguous()
+            grad = self._flat_grad
+            with torch.no_grad():
+                new_grad = fn(grad).detach().contiguous() if grad is not None else None
+            for mod, leaf, off, n, shape, is_buf in self._views:
+                v = new[off : off + n].view(shape)
+                if is_buf:
+                    mod._buffers[leaf] = v
+                else:
+                    p = mod._parameters[leaf]
+                    had_grad = p.grad is not None
+                    p.data = v
+                    if had_grad:
+                        p.grad = new_grad[off : off + n].view(shape) if new_grad is not None else None
+            self._flat = new
+            self._flat_grad = new_grad
+            for pl in self._plans.values():
+                pl.packed_version = None
+            self._ensure_flat()
+        return self
 
     def flat_parameters(self) -> Tensor:
         """The contiguous fp32 master buffer (reference state_dict order and layouts)."""
@@ -234,7 +275,7 @@ class UNet(nn.Module):
 
     def _packed_for(self, plan: _Plan) -> Tensor:
         flat = self._ensure_flat()
-        ver = (flat.data_ptr(), flat._version, self._param_epoch)
+        ver = self._weights_key(flat)
         if plan.packed_version != ver:
             _lib.check(plan.lib.dmme_unet_pack_params(plan.h, _lib.ptr(flat), _lib.ptr(plan.packed), _lib.stream_ptr()), "dmme_unet_pack_params")
             plan.packed_version = ver
@@ -292,17 +333,23 @@ class UNet(nn.Module):
                     mod._parameters[leaf].grad = g[off : off + n].view(shape)
         return g
 
-    def _backward_impl(self, saved, dy: Tensor):
-        plan, xin, t, masks = saved
+    def _backward_impl(self, saved, dy: Tensor, want_dx: bool = False):
+        plan, xin, t, masks, gen = saved
+        if gen != plan.fwd_gen:
+            raise RuntimeError(
+                "UNet backward: another forward of the same shape ran after the forward this graph belongs to and overwrote its "
+                "saved activations (one workspace per (B, H, W, dtype) plan). Call backward() before the next forward, or "
+                "run the extra forward under a different batch size.")
         lib = plan.lib
         dev = xin.device
+        dx = torch.empty_like(xin) if want_dx else None
         if getattr(plan, "bws", None) is None:
             plan.bws = torch.empty(int(lib.dmme_unet_plan_bwd_workspace_bytes(plan.h)), dtype=torch.uint8, device=dev)
             plan.packed_bwd = torch.empty(int(lib.dmme_unet_plan_packed_bwd_bytes(plan.h)), dtype=torch.uint8, device=dev)
             plan.packed_bwd_version = None
         flat = self._ensure_flat()
         packed = self._packed_for(plan)
-        ver = (flat.data_ptr(), flat._version, self._param_epoch)
+        ver = self._weights_key(flat)
         if plan.packed_bwd_version != ver:
             _lib.check(lib.dmme_unet_pack_params_bwd(plan.h, _lib.ptr(flat), _lib.ptr(plan.packed_bwd), _lib.stream_ptr()), "dmme_unet_pack_params_bwd")
             plan.packed_bwd_version = ver
@@ -321,17 +368,18 @@ class UNet(nn.Module):
             cb = _lib.BUCKET_FN(ready)
             _lib.check(
                 lib.dmme_unet_backward_buckets(plan.h, _lib.ptr(packed), _lib.ptr(plan.packed_bwd), _lib.ptr(xin), _lib.ptr(t), int(t.numel()), _lib.ptr(d),
-                                               _lib.ptr(plan.workspace), _lib.ptr(plan.bws), _lib.ptr(masks), _lib.ptr(g), _lib.stream_ptr(), cb, None),
+                                               _lib.ptr(plan.workspace), _lib.ptr(plan.bws), _lib.ptr(masks), _lib.ptr(g), _lib.ptr(dx), _lib.stream_ptr(), cb, None),
                 "dmme_unet_backward_buckets",
             )
             if errors:
                 raise errors[0]
-            return
+            return dx
         _lib.check(
             lib.dmme_unet_backward(plan.h, _lib.ptr(packed), _lib.ptr(plan.packed_bwd), _lib.ptr(xin), _lib.ptr(t), int(t.numel()), _lib.ptr(d),
-                                   _lib.ptr(plan.workspace), _lib.ptr(plan.bws), _lib.ptr(masks), _lib.ptr(g), _lib.stream_ptr()),
+                                   _lib.ptr(plan.workspace), _lib.ptr(plan.bws), _lib.ptr(masks), _lib.ptr(g), _lib.ptr(dx), _lib.stream_ptr()),
             "dmme_unet_backward",
         )
+        return dx
 
     def _forward_impl(self, x: Tensor, c: Tensor, want_ctx: bool = False):
         B, _, H, W = x.shape
@@ -364,8 +412,11 @@ class UNet(nn.Module):
             "dmme_unet_forward",
         )
         self._last_plan = plan
+        # every forward of this (B, H, W, dtype) overwrites the activations (plan.workspace) and the drawn masks a pending
+        # backward would read: the generation stamp lets that backward refuse instead of producing wrong gradients
+        plan.fwd_gen = getattr(plan, "fwd_gen", 0) + 1
         if want_ctx:
-            return y, (plan, xin, t, masks)
+            return y, (plan, xin, t, masks, plan.fwd_gen)
         return y
 
     # ------------------------------------------------------------------ hipGraph replay (sampling loops)
@@ -380,7 +431,7 @@ class UNet(nn.Module):
         if self.training or getattr(self, "_graph_disabled", False):
             return self._forward_impl(x_static, t_static)
         flat = self._ensure_flat()
-        key = (x_static.data_ptr(), t_static.data_ptr(), tuple(x_static.shape), self._dtype, flat.data_ptr(), flat._version, self._param_epoch)
+        key = (x_static.data_ptr(), t_static.data_ptr(), tuple(x_static.shape), self._dtype) + self._weights_key(flat)
         g = getattr(self, "_graph", None)
         if g is None or g[0] != key:
             try:

@@ -18,16 +18,25 @@ def synthetic_batch(batch_size: int, device, shape=(3, 32, 32)):
     return torch.rand((batch_size, *shape), device=device) * 2 - 1
 
 
-def train_step(module, optimizer, scheduler, x0, clip=None):
+def train_step(module, optimizer, scheduler, x0, clip=None, reduce=True):
     """one optimisation step: loss -> HIP backward (data parallel: the gradient all-reduce of the first bucket runs on a side
-    stream under the rest of backward) -> clip+Adam(+EMA) -> LR step"""
+    stream under the rest of backward) -> clip+Adam(+EMA) -> LR step.  `reduce=False` leaves the gradient exchange out
+    (bench.py times the step without its collective to tell exposed from hidden all-reduce time)."""
     model = module.diffusion_model.model
     reducer = getattr(model, "_grad_reducer", None)
-    if reducer is None and not os.environ.get("DMME_NO_OVERLAP") and D.dist.is_available() and D.dist.is_initialized() and D.dist.get_world_size() > 1:
+    multi = reduce and D.dist.is_available() and D.dist.is_initialized() and D.dist.get_world_size() > 1
+    if multi and not getattr(model, "_dp_synced", False):  # first data-parallel step: identical replicas (rank 0's weights)
+        D.sync_parameters(model, optimizer)
+        model._dp_synced = True
+    if reducer is None and not os.environ.get("DMME_NO_OVERLAP") and multi:
         reducer = model._grad_reducer = D.OverlappedGradReducer(model)
     loss = module.training_step((x0,), 0)
     loss.backward()
-    if reducer is None or not reducer.finish():
+    if not multi:
+        if reducer is not None:  # a reducer left by earlier exchanged steps: discard what this backward reported to it
+            reducer.reported.clear()
+            model._bucket_hook = None
+    elif reducer is None or not reducer.finish():
         D.allreduce_mean_flat(model.flat_grad())
     optimizer.step()
     if scheduler is not None:
@@ -50,6 +59,9 @@ def fit(module, batch_size=128, max_steps=100, clip=None, log_every=50, loader=N
         from .checkpoint import load_checkpoint
 
         first = int(load_checkpoint(ckpt_path, module, opt, sched).get("global_step", 0))
+    model = module.diffusion_model.model
+    if D.sync_parameters(model, opt):  # several ranks: start from rank 0's weights (after a resume too)
+        model._dp_synced = True
     t0 = time.perf_counter()
     batches = None
     for step in range(first, max_steps):

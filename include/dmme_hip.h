@@ -137,13 +137,15 @@ DMME_API int dmme_unet_forward_profiled(const dmme_plan* plan, const void* packe
  * dmme_unet_forward call (same x, t, drop_masks), ACCUMULATES dL/d(parameters) into grad_flat
  * (fp32, reference state_dict order and layouts, like the flat parameter buffer).
  * packed_bwd holds transposed, tap-flipped conv weights (dmme_unet_pack_params_bwd) for the
- * data-gradient convolutions. Replaces torch autograd of models/ddpm.py:281-316. */
+ * data-gradient convolutions. Replaces torch autograd of models/ddpm.py:281-316.
+ * d_x (nullable): when given, receives dL/dx (NCHW fp32, shape of x) - the gradient autograd hands back for an input that
+ * requires grad (guidance-style callers); NULL skips that convolution. */
 DMME_API int64_t dmme_unet_plan_packed_bwd_bytes(const dmme_plan* plan);
 DMME_API int64_t dmme_unet_plan_bwd_workspace_bytes(const dmme_plan* plan);
 DMME_API int dmme_unet_pack_params_bwd(const dmme_plan* plan, const float* ref_flat, void* packed_bwd, void* stream);
 DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const void* packed_bwd, const float* x,
                        const int64_t* t, int t_len, const float* d_y, void* workspace, void* bwd_workspace,
-                       const float* drop_masks, float* grad_flat, void* stream);
+                       const float* drop_masks, float* grad_flat, float* d_x, void* stream);
 /* Same backward in two gradient buckets, so a data-parallel caller can all-reduce the first while the second is still being
  * computed (north star: "RCCL all-reduce of UNet grads over xGMI overlapped with backward"; the reference gets this from
  * Lightning's DDP wrapper around `loss.backward()`).  Bucket 0 = the parameters backward finishes first (up_layers,
@@ -155,7 +157,7 @@ DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const
 typedef void (*dmme_bucket_fn)(void* user, int bucket, int64_t offset, int64_t numel);
 DMME_API int dmme_unet_backward_buckets(const dmme_plan* plan, const void* packed, const void* packed_bwd, const float* x,
                                const int64_t* t, int t_len, const float* d_y, void* workspace, void* bwd_workspace,
-                               const float* drop_masks, float* grad_flat, void* stream, dmme_bucket_fn ready, void* user);
+                               const float* drop_masks, float* grad_flat, float* d_x, void* stream, dmme_bucket_fn ready, void* user);
 DMME_API int dmme_unet_plan_grad_buckets(const dmme_plan* plan, int64_t offsets[2], int64_t numels[2]);
 /* global L2 norm of a flat fp32 gradient buffer (clip_grad_norm_; scratch: 1024 floats) */
 DMME_API int dmme_grad_norm(const float* grad, int64_t numel, float* norm_out, float* scratch, void* stream);
@@ -218,6 +220,33 @@ DMME_API int dmme_mse_loss(const float* eps, const float* target, int64_t numel,
  * flip: uint8[B] or NULL (no augmentation, the reference's test set); W must be a multiple of 4. */
 DMME_API int dmme_image_batch(const uint8_t* data, int64_t n_images, const int64_t* idx, const uint8_t* flip, int B, int C, int H, int W,
                      float* out, void* stream);
+
+/* ---- one replayable denoising step ---------------------------------------------------------------------
+ * The reference's sampling loops run on the host: `for t in range(T, 0, -1)` around `sampling_step`
+ * (diffusion_models/ddpm.py:130, ddim.py:96, iddpm.py), `LitDDPM.forward` builds `torch.tensor([t])` - a host-to-device copy -
+ * every step (lit_modules/ddpm.py:77; called per step by callbacks/generate.py:82).  Here everything that varies from step to
+ * step is device-resident, so ONE launch sequence (time MLP + UNet + noise draw + update + loop-state advance) serves every
+ * step and can be captured in a hipGraph and replayed:
+ *   state     64 bytes of device memory (eight 64-bit words): int64 i (loop index), int64 t (= t_table[i], what the network is
+ *             evaluated at), uint64 Philox offset in quads, uint64 Philox seed, uint32 ticket + pad, three reserved words.
+ *             dmme_chain_set initialises it (a one-thread kernel: the values travel as kernel arguments, no host buffer to
+ *             keep alive, and a graph captured once serves any later seed).
+ *   t_table   int64[n+1]: DDPM / IDDPM: t_table[i] = i; DDIM: the tau table (diffusion_models/ddim.py:41-53)
+ *   step_coef float[n+1][4], per loop index:
+ *             DMME_CHAIN_DDPM  {1/sqrt(alpha_t), beta_t/sqrt(1-abar_t), sqrt(beta_t), -}     (equations/ddpm/ddpm.py:65-71)
+ *             DMME_CHAIN_DDIM  {sqrt(1-abar_tau_i), sqrt(abar_tau_{i-1}), -, -}              (equations/ddim/ddim.py:52-57)
+ *             DMME_CHAIN_IDDPM {1/sqrt(alpha_t), beta_t/sqrt(1-abar_t), log beta_t, log max(beta~_t, 1e-12)}
+ * dmme_chain_update = the sampler update alone (noise drawn in the kernel from Philox(state.seed, state.offset + quad index): the values
+ * dmme_randn would produce at the same offset, so a chain equals the eager loop bit for bit); no noise is added at t == 1 but
+ * the offset advances all the same (the reference draws and discards, diffusion_models/ddpm.py:107-110).  After the update the
+ * state moves on: i -= 1, t = t_table[i], offset += B*chw/4.  dmme_chain_step = dmme_unet_forward at t = state.t followed by
+ * dmme_chain_update; x is updated in place, model_out receives the network output.  chw must be a multiple of 4. */
+enum { DMME_CHAIN_DDPM = 0, DMME_CHAIN_DDIM = 1, DMME_CHAIN_IDDPM = 2 };
+DMME_API int dmme_chain_set(void* state, int64_t i, const int64_t* t_table, uint64_t philox_seed, uint64_t philox_offset, void* stream);
+DMME_API int dmme_chain_update(int kind, float* x, const float* model_out, const float* step_coef, const int64_t* t_table, void* state,
+                      int B, int64_t chw, void* stream);
+DMME_API int dmme_chain_step(const dmme_plan* plan, const void* packed, float* x, float* model_out, void* workspace, int kind,
+                    const float* step_coef, const int64_t* t_table, void* state, void* stream);
 
 /* ---- Improved DDPM (learned variance): model_out is (B, 2C, H, W), channels [0, C) = eps, [C, 2C) = v
  * (IDDPM.forward_model, diffusion_models/iddpm.py:152-164); chw = C*H*W of ONE image of x. */

@@ -203,3 +203,125 @@ def test_trainer_maps_the_yaml_data_section():
     spec = {"class_path": "dmme.CIFAR10", "init_args": {"data_dir": ".", "batch_size": 128, "augs": [{"class_path": "torchvision.transforms.RandomHorizontalFlip"}]}}
     dm = trainer._instantiate(spec)
     assert isinstance(dm, CIFAR10) and dm.batch_size == 128 and isinstance(dm.augs[0], RandomHorizontalFlip)
+
+
+# ------------------------------------------------------------------------------------------ the reference's YAML forms (jsonargparse typing)
+
+_REFERENCE_FORM_YAML = """
+seed_everything: true
+trainer:
+  callbacks:
+    - class_path: pytorch_lightning.callbacks.ModelCheckpoint
+      init_args:
+        every_n_train_steps: 100_000
+  gradient_clip_val: 1.0
+  devices: 1
+  max_steps: 800_000
+  log_every_n_steps: 50
+  precision: 16
+  strategy: null
+ckpt_path: null
+model:
+  class_path: dmme.LitDDPM
+  init_args:
+    lr: 2e-5
+    warmup: 5000
+    decay: 0.9999
+    model:
+      class_path: dmme.models.ddpm.UNet
+      init_args:
+        dropout: 0.0
+        channels_per_depth:
+          - 32
+          - 64
+        attention_depths:
+          - 2
+data:
+  class_path: dmme.CIFAR10
+  init_args:
+    data_dir: "."
+    batch_size: 128
+    augs:
+      - class_path: torchvision.transforms.RandomHorizontalFlip
+"""
+
+
+def test_yaml_in_the_reference_literal_forms_drives_module_and_optimizer(tmp_path):
+    """`lr: 2e-5` is a str and `800_000` an int to YAML 1.1; jsonargparse converts by the constructor's annotations
+    (reference configs/ddpm/cifar10.yaml:41,72-77, lsun_church.yaml:75-90) and so must the bundled runner."""
+    from dmme_amd import trainer
+
+    import yaml
+
+    assert isinstance(yaml.safe_load("lr: 2e-4")["lr"], str)  # the trap itself
+    path = tmp_path / "ref_form.yaml"
+    path.write_text(_REFERENCE_FORM_YAML)
+    conf = trainer.parse_config(str(path))
+    assert conf["max_steps"] == 800000 and conf["gradient_clip_val"] == 1.0 and conf["precision"] == "bf16" and conf["ckpt_path"] is None
+    module = trainer.build_module(conf)
+    assert isinstance(module.lr, float) and module.lr == 2e-5 and isinstance(module.warmup, int)
+    unet = module.diffusion_model.model
+    assert type(unet) is dmme_amd.UNet and unet.dropout == 0.0 and tuple(unet._cfg.channels_per_depth[:2]) == (32, 64)
+    assert any(k.endswith("conv2.2.weight") for k in module.state_dict())  # dropout 0: conv index 2 (models/ddpm.py:25-35)
+    opts, scheds = module.configure_optimizers()
+    assert opts[0].param_groups[0]["lr"] == pytest.approx(2e-5 / 5000)  # WarmupLR already applied its first factor
+    # scalar rules
+    assert trainer._coerce("1e-4", float) == 1e-4 and trainer._coerce("800_000", int) == 800000 and trainer._coerce(3, float) == 3.0
+    assert trainer._coerce(None, typing_optional_float()) is None and trainer._coerce("2.5e-5", typing_optional_float()) == 2.5e-5
+    with pytest.raises((TypeError, ValueError)):
+        trainer._coerce("fast", float)
+    with pytest.raises(TypeError):
+        trainer._instantiate({"class_path": "dmme.LitDDPM", "init_args": {"lr": "quick"}})
+
+
+def typing_optional_float():
+    import typing
+
+    return typing.Optional[float]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/configs"), reason="reference checkout absent (GPU box)")
+@pytest.mark.parametrize("rel,cls,numel", [("ddpm/cifar10", "LitDDPM", 32416643), ("ddim/cifar10", "LitDDIM", 32416643),
+                                           ("iddpm/cifar10", "LitIDDPM", 36168070), ("ddpm/lsun_church", "LitDDPM", 97689219)])
+def test_reference_yaml_files_parse_and_build_unchanged(rel, cls, numel):
+    """build container only: the reference's own files, read in place, build module + optimizer + scheduler"""
+    from dmme_amd import trainer
+
+    conf = trainer.parse_config(f"/root/reference/configs/{rel}.yaml")
+    module = trainer.build_module(conf)
+    assert type(module).__name__ == cls and isinstance(module.lr, float)
+    assert sum(p.numel() for p in module.parameters()) == numel
+    opts, scheds = module.configure_optimizers()
+    assert isinstance(opts[0].param_groups[0]["lr"], float) and scheds[0]["interval"] == "step"
+    assert conf["precision"] == "bf16" and conf["gradient_clip_val"] == 1.0
+
+
+# ------------------------------------------------------------------------------------------ stale packed weights (ADVICE r1, high)
+
+
+def test_weights_key_follows_writes_through_rebound_parameters():
+    """.cuda()/.to() rebind every Parameter with `p.data = view`; such a Parameter keeps its own version counter, so
+    flat._version alone misses load_state_dict / torch.optim / p.copy_ writes.  Reproduced on CPU by a device-less _apply."""
+    net = dmme_amd.UNet(pos_dim=4, emb_dim=8, num_groups=2, channels_per_depth=(4, 8), num_blocks=1)
+    net._apply(lambda t: t.clone())  # what .cuda() does: new tensors, then _ensure_flat re-flattens and rebinds .data
+    flat = net.flat_parameters()
+    p = net.input_conv.weight
+    off = (p.data_ptr() - flat.data_ptr()) // 4
+    assert 0 < off < flat.numel()  # the Parameter is a view of the flat buffer again
+    k0 = net._weights_key(net._ensure_flat())
+    assert net._weights_key(net._ensure_flat()) == k0  # stable without writes
+    with torch.no_grad():
+        p.add_(1.0)
+    k1 = net._weights_key(net._ensure_flat())
+    assert k1 != k0 and float(flat[off]) == float(p.detach().reshape(-1)[0])  # the write landed in the flat buffer and moved the key
+    sd = {k: v.clone() + 0.5 for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    k2 = net._weights_key(net._ensure_flat())
+    assert k2 != k1
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    for q in net.parameters():
+        q.grad = torch.ones_like(q)
+    opt.step()
+    assert net._weights_key(net._ensure_flat()) != k2
+    net.mark_params_updated()
+    assert net._weights_key(net._ensure_flat())[-1] == 1

@@ -466,11 +466,13 @@ def main():
         "hip_graph": bool(runner.graph is not None),
     }
 
+    plan = runner.plan
+
     def rank0_legs():  # the per-kernel roofline of the measured forward and the CPU baseline
         if rank == 0:
             if not args.no_roofline:
                 xin = dmme_amd.gaussian((B, 3, side, side), device=dev)
-                model._last_plan = runner.plan
+                model._last_plan = plan
                 out["roofline"] = roofline_leg(model, xin, proc.timestep_tensor(min(500, T), dev), args.precision)
                 del xin
             if world == 1 and not args.no_cpu_baseline and args.model == "ddpm":

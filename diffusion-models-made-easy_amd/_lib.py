@@ -14,9 +14,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdmme_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-F32, BF16 = 0, 1
+F32, BF16, BF16X3 = 0, 1, 2  # BF16X3: fp32 buffers, three-pass bf16 MFMA convolutions (the accurate mode)
 CHAIN_DDPM, CHAIN_DDIM, CHAIN_IDDPM = 0, 1, 2
-DTYPES = {"fp32": F32, "float32": F32, "32": F32, "bf16": BF16, "bfloat16": BF16, "16": BF16, "bf16-mixed": BF16, "16-mixed": BF16}
+DTYPES = {"fp32": F32, "float32": F32, "32": F32, "bf16": BF16, "bfloat16": BF16, "16": BF16, "bf16-mixed": BF16, "16-mixed": BF16,
+          "bf16x3": BF16X3}
 
 _lock = threading.Lock()
 _lib = None

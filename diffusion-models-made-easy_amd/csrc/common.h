@@ -128,6 +128,8 @@ struct ConvArgs {
     // which also applies bias / time row / residual.  splitk_cap: capacity in floats.
     float* splitk;
     int64_t splitk_cap;
+    // accurate mode (fp32 tensors only): every product as three bf16 MFMA passes on hi/lo splits instead of the fp32 MFMA
+    int x3;
 };
 
 // ---- kernel launchers (defined in the .hip files) ------------------------------------

@@ -15,7 +15,7 @@ namespace dmme {
 
 __device__ __forceinline__ int swz1(int row, int chunk) { return row * ROW_DATA + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, bool ACC3 = false>
 __global__ void __launch_bounds__(256, 2) conv1x1_pipe_kernel(ConvArgs a, int HW, int tiles_n, int xcd_order) {
     constexpr int KC = Frag<T>::KC, EPV = Frag<T>::EPV;
     constexpr int MI = BM / 64, NI = BN / 64;
@@ -138,10 +138,7 @@ __global__ void __launch_bounds__(256, 2) conv1x1_pipe_kernel(ConvArgs a, int HW
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
                     bfr[ni] = *reinterpret_cast<const uint4*>(ldsB + c * BN * ROW_DATA + b_base[ni] + ((cidx ^ b_swz[ni]) << 4));
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) mma_group(af[mi], bfr[ni], acc[mi][ni], (T*)nullptr);
+                mma_tile<typename MmaTag<T, ACC3>::type, MI, NI>(af, bfr, acc);
             }
         }
         __syncthreads();
@@ -188,7 +185,7 @@ bool conv1x1_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* 
     return true;
 }
 
-template <typename T>
+template <typename T, bool ACC3 = false>
 static int launch1_t(const ConvArgs& a, hipStream_t s) {
     const int pick = pick1(a);
     DMME_REQUIRE(pick >= 0, DMME_ERR_UNSUPPORTED, "conv1x1_pipe: no tile");
@@ -206,12 +203,12 @@ static int launch1_t(const ConvArgs& a, hipStream_t s) {
 #define DMME_C1_CASE(IDX, BM_, BN_)                                                                                                   \
     case IDX:                                                                                                                         \
         if (!attr_done[IDX]) {                                                                                                        \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_pipe_kernel<T, BM_, BN_>),                       \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_pipe_kernel<T, BM_, BN_, ACC3>),                 \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                                \
             if (e != hipSuccess) rc = DMME_ERR_HIP;                                                                                   \
             attr_done[IDX] = rc == DMME_OK;                                                                                           \
         }                                                                                                                             \
-        if (rc == DMME_OK) hipLaunchKernelGGL((conv1x1_pipe_kernel<T, BM_, BN_>), grid, dim3(256), lds, s, a, HW, tiles_n, xcd_order); \
+        if (rc == DMME_OK) hipLaunchKernelGGL((conv1x1_pipe_kernel<T, BM_, BN_, ACC3>), grid, dim3(256), lds, s, a, HW, tiles_n, xcd_order); \
         break;
     switch (pick) {
         DMME_C1_CASE(0, 128, 128)
@@ -226,12 +223,13 @@ static int launch1_t(const ConvArgs& a, hipStream_t s) {
 
 int launch_conv1x1_pipe(int dtype, const ConvArgs& a, hipStream_t s) {
     DMME_REQUIRE(conv1x1_pipe_supported(dtype, a), DMME_ERR_UNSUPPORTED, "conv1x1_pipe: unsupported shape");
-    return dtype == DMME_BF16 ? launch1_t<bf16>(a, s) : launch1_t<float>(a, s);
+    if (dtype == DMME_BF16) return launch1_t<bf16>(a, s);
+    return a.x3 ? launch1_t<float, true>(a, s) : launch1_t<float>(a, s);
 }
 
 void conv1x1_pipe_label(int dtype, const ConvArgs& a, char* buf, int cap) {
     const int pick = pick1(a);
-    snprintf(buf, (size_t)cap, "conv1x1_pipe_kernel<%s,%d,%d>", dtype == DMME_BF16 ? "bf16" : "float", pick >= 0 ? k1Cand[pick][0] : 0,
+    snprintf(buf, (size_t)cap, "conv1x1_pipe_kernel<%s,%d,%d>", dtype == DMME_BF16 ? "bf16" : a.x3 ? "float:bf16x3" : "float", pick >= 0 ? k1Cand[pick][0] : 0,
              pick >= 0 ? k1Cand[pick][1] : 0);
 }
 

@@ -57,6 +57,68 @@ __device__ __forceinline__ void mma_group(const uint4& a, const uint4& b, f32x16
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
 }
 
+// ---- accurate mode ("bf16x3"): fp32 tensors, every product as three bf16 MFMA passes ------------------------------------------
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, accumulated in fp32 by the matrix
+// cores.  What is dropped (a_lo*b_lo and the rounding of lo) is ~2^-16 of a product, against 2^-9 for single-pass bf16, so a
+// 44-convolution network stays within north_star's 1e-3 of the fp32 reference - at three bf16 MFMAs (32x32x8: 3 x 32 cycles per
+// 8 channels) instead of four fp32 ones (32x32x2: 4 x 64 cycles).  The operands stay fp32 in HBM and LDS; the split happens
+// on the fragment registers (10 VALU operations per 4 values: cvt_pk, shift / mask, packed subtract, cvt_pk).
+struct X3 {};
+template <typename T, bool ACC3>
+struct MmaTag {
+    typedef T type;
+};
+template <>
+struct MmaTag<float, true> {
+    typedef X3 type;
+};
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+struct Split4 {
+    uint2 hi, lo;
+};
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ Split4 split4(const uint4& v) {
+    const f32x4 x = __builtin_bit_cast(f32x4, v);
+    Split4 s;
+    const unsigned h01 = pack_bf16(x[0], x[1]), h23 = pack_bf16(x[2], x[3]);
+    s.hi = make_uint2(h01, h23);
+    s.lo = make_uint2(pack_bf16(x[0] - __uint_as_float(h01 << 16), x[1] - __uint_as_float(h01 & 0xffff0000u)),
+                      pack_bf16(x[2] - __uint_as_float(h23 << 16), x[3] - __uint_as_float(h23 & 0xffff0000u)));
+    return s;
+}
+__device__ __forceinline__ void mma_x3(const Split4& a, const Split4& b, f32x16& acc) {
+    const s16x4 ah = __builtin_bit_cast(s16x4, a.hi), al = __builtin_bit_cast(s16x4, a.lo);
+    const s16x4 bh = __builtin_bit_cast(s16x4, b.hi), bl = __builtin_bit_cast(s16x4, b.lo);
+    acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(al, bh, acc, 0, 0, 0);  // the small terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ah, bh, acc, 0, 0, 0);
+}
+// all MI x NI products of one fragment group (16 bytes per lane of each operand row tile)
+template <typename TAG, int MI, int NI>
+__device__ __forceinline__ void mma_tile(const uint4 (&af)[MI], const uint4 (&bfr)[NI], f32x16 (&acc)[MI][NI]) {
+    if constexpr (__is_same(TAG, X3)) {
+        Split4 as[MI], bs[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) as[mi] = split4(af[mi]);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bs[ni] = split4(bfr[ni]);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) mma_x3(as[mi], bs[ni], acc[mi][ni]);
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) mma_group(af[mi], bfr[ni], acc[mi][ni], (TAG*)nullptr);
+    }
+}
+
 // apply the fused prologue to one 16-byte vector of activations
 template <typename T>
 __device__ __forceinline__ uint4 prologue_vec(uint4 raw, const float* sc, const float* sh, const float* dm, int pro_silu);

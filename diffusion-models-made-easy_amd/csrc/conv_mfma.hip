@@ -23,7 +23,7 @@
 
 namespace dmme {
 
-template <typename T, int TAPS, int BM, int BN>
+template <typename T, int TAPS, int BM, int BN, bool ACC3 = false>
 __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a, ConvTile g) {
     constexpr int KC = Frag<T>::KC, EPV = Frag<T>::EPV;
     constexpr int MI = BM / 64, NI = BN / 64;  // 32x32 tiles per wave (2x2 waves)
@@ -115,10 +115,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a, ConvTile g) 
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
                     bfr[ni] = *reinterpret_cast<const uint4*>(ldsB + (wn0 + ni * 32 + r) * ROW_PITCH + kg * 32 + h * 16);
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) mma_group(af[mi], bfr[ni], acc[mi][ni], (T*)nullptr);
+                mma_tile<typename MmaTag<T, ACC3>::type, MI, NI>(af, bfr, acc);
             }
         }
     }
@@ -167,7 +164,7 @@ static int pick_tile(const ConvArgs& a, ConvTile& g) {
     return pick;
 }
 
-template <typename T, int TAPS>
+template <typename T, int TAPS, bool ACC3 = false>
 static int launch_sized(const ConvArgs& a, hipStream_t s) {
     ConvTile g{};
     const int pick = pick_tile(a, g);
@@ -177,9 +174,9 @@ static int launch_sized(const ConvArgs& a, hipStream_t s) {
     const size_t stage = (size_t)kCand[pick][0] * kCand[pick][1] * sizeof(float);  // epilogue staging image
     if (lds < stage) lds = stage;
     switch (pick) {
-        case 0: hipLaunchKernelGGL((conv_mfma_kernel<T, TAPS, 128, 128>), grid, dim3(256), lds, s, a, g); break;
-        case 1: hipLaunchKernelGGL((conv_mfma_kernel<T, TAPS, 128, 64>), grid, dim3(256), lds, s, a, g); break;
-        default: hipLaunchKernelGGL((conv_mfma_kernel<T, TAPS, 64, 64>), grid, dim3(256), lds, s, a, g); break;
+        case 0: hipLaunchKernelGGL((conv_mfma_kernel<T, TAPS, 128, 128, ACC3>), grid, dim3(256), lds, s, a, g); break;
+        case 1: hipLaunchKernelGGL((conv_mfma_kernel<T, TAPS, 128, 64, ACC3>), grid, dim3(256), lds, s, a, g); break;
+        default: hipLaunchKernelGGL((conv_mfma_kernel<T, TAPS, 64, 64, ACC3>), grid, dim3(256), lds, s, a, g); break;
     }
     DMME_CHECK_LAUNCH();
     return DMME_OK;
@@ -203,13 +200,14 @@ bool conv_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px)
 void conv_mfma_label(int dtype, const ConvArgs& a, char* buf, int cap) {
     ConvTile g{};
     const int pick = pick_tile(a, g);
-    snprintf(buf, (size_t)cap, "conv_mfma_kernel<%s,%d,%d,%d>", dtype == DMME_BF16 ? "bf16" : "float", a.taps,
+    snprintf(buf, (size_t)cap, "conv_mfma_kernel<%s,%d,%d,%d>", dtype == DMME_BF16 ? "bf16" : a.x3 ? "float:bf16x3" : "float", a.taps,
              pick >= 0 ? kCand[pick][0] : 0, pick >= 0 ? kCand[pick][1] : 0);
 }
 
 int launch_conv_mfma(int dtype, const ConvArgs& a, hipStream_t s) {
     DMME_REQUIRE(conv_mfma_supported(dtype, a), DMME_ERR_UNSUPPORTED, "conv_mfma: unsupported shape");
     if (dtype == DMME_BF16) return a.taps == 9 ? launch_sized<bf16, 9>(a, s) : launch_sized<bf16, 1>(a, s);
+    if (a.x3) return a.taps == 9 ? launch_sized<float, 9, true>(a, s) : launch_sized<float, 1, true>(a, s);
     return a.taps == 9 ? launch_sized<float, 9>(a, s) : launch_sized<float, 1>(a, s);
 }
 

@@ -24,7 +24,7 @@ namespace dmme {
 // GT: taps staged per barrier interval (3 = one kernel row, 9 = the whole 3x3 filter: fewer, longer intervals for
 //     layers whose per-interval matrix work is too short to hide a global-load round trip);
 // UA: halo 16-byte units a thread may own (a_rows * 8 <= 256 * UA).
-template <typename T, int BM, int BN, int GT, int PIPE_UA>
+template <typename T, int BM, int BN, int GT, int PIPE_UA, bool ACC3 = false>
 __global__ void __launch_bounds__(256, GT == 9 ? 1 : 2) conv3x3_pipe_kernel(ConvArgs a, ConvTile g, int shTW, int shTH, int ksplit) {
     constexpr int KC = Frag<T>::KC, EPV = Frag<T>::EPV;
     constexpr int MI = BM / 64, NI = BN / 64;
@@ -199,10 +199,7 @@ __global__ void __launch_bounds__(256, GT == 9 ? 1 : 2) conv3x3_pipe_kernel(Conv
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
                         bfr[ni] = *reinterpret_cast<const uint4*>(ldsB + j * BN * ROW_DATA + b_base[ni] + ((cidx ^ b_swz[ni]) << 4));
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) mma_group(af[mi], bfr[ni], acc[mi][ni], (T*)nullptr);
+                    mma_tile<typename MmaTag<T, ACC3>::type, MI, NI>(af, bfr, acc);
                 }
             }
             __syncthreads();  // every wave is done reading this group's tiles
@@ -735,7 +732,7 @@ static int set_lds_limit(K kernel, size_t bytes) {
     return DMME_OK;
 }
 
-template <typename T>
+template <typename T, bool ACC3 = false>
 static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
     ConvTile g{};
     const int pick = pipe_pick(a, g);
@@ -767,10 +764,10 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
 #define DMME_PIPE_CASE(IDX, BM_, BN_, GT_, UA_, LIM)                                                                          \
     case IDX:                                                                                                                 \
         if (!attr_done[IDX]) {                                                                                                \
-            rc = set_lds_limit(conv3x3_pipe_kernel<T, BM_, BN_, GT_, UA_>, (LIM) * 1024);                                     \
+            rc = set_lds_limit(conv3x3_pipe_kernel<T, BM_, BN_, GT_, UA_, ACC3>, (LIM) * 1024);                               \
             attr_done[IDX] = rc == DMME_OK;                                                                                   \
         }                                                                                                                     \
-        if (rc == DMME_OK) hipLaunchKernelGGL((conv3x3_pipe_kernel<T, BM_, BN_, GT_, UA_>), grid, dim3(256), lds, s, a, g, shTW, shTH, ksplit); \
+        if (rc == DMME_OK) hipLaunchKernelGGL((conv3x3_pipe_kernel<T, BM_, BN_, GT_, UA_, ACC3>), grid, dim3(256), lds, s, a, g, shTW, shTH, ksplit); \
         break;
     switch (pick) {
         DMME_PIPE_CASE(0, 128, 128, 3, 8, 80)
@@ -791,7 +788,8 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
 
 int launch_conv_pipe(int dtype, const ConvArgs& a, hipStream_t s) {
     DMME_REQUIRE(conv_pipe_supported(dtype, a), DMME_ERR_UNSUPPORTED, "conv_pipe: unsupported shape");
-    return dtype == DMME_BF16 ? launch_pipe_t<bf16>(a, s) : launch_pipe_t<float>(a, s);
+    if (dtype == DMME_BF16) return launch_pipe_t<bf16>(a, s);
+    return a.x3 ? launch_pipe_t<float, true>(a, s) : launch_pipe_t<float>(a, s);
 }
 
 bool conv_pipe_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px) {
@@ -825,7 +823,7 @@ void conv_pipe_label(int dtype, const ConvArgs& a, char* buf, int cap) {
     }
     ConvTile g{};
     const int pick = pipe_pick(a, g);
-    snprintf(buf, (size_t)cap, "conv3x3_pipe_kernel<%s,%d,%d,%d,%d>", dtype == DMME_BF16 ? "bf16" : "float",
+    snprintf(buf, (size_t)cap, "conv3x3_pipe_kernel<%s,%d,%d,%d,%d>", dtype == DMME_BF16 ? "bf16" : a.x3 ? "float:bf16x3" : "float",
              pick >= 0 ? kPipeCand[pick][0] : 0, pick >= 0 ? kPipeCand[pick][1] : 0, pick >= 0 ? kPipeCand[pick][2] : 0,
              pick >= 0 ? kPipeUA[pick] : 0);
 }

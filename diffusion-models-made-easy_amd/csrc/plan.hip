@@ -84,6 +84,7 @@ using namespace dmme;
 struct dmme_plan {
     dmme_unet_cfg cfg;
     int B, H, W, dtype, device;
+    int x3 = 0;            // DMME_BF16X3: dtype is DMME_F32 (storage), the convolutions take the three-pass bf16 MFMA path
     int out_channels = 0;  // in_channels (DDPM) or 2 * in_channels (IDDPM: eps, v)
     std::vector<Param> params;
     std::vector<Tensor> tensors;
@@ -690,6 +691,7 @@ void fill_conv(const dmme_plan* P, const Op& o, const char* packed, const float*
                const float* drop_masks, int nt, ConvArgs& a) {
     const int64_t es = (int64_t)dtype_size(P->dtype);
     (void)es;
+    a.x3 = P->x3;
     a.N = P->B;
     if (o.src1 == -2) {
         a.src1 = x;
@@ -937,7 +939,7 @@ int run_op(const dmme_plan* P, const Op& o, const char* pk, const float* x, cons
 // kernel label + algorithmic flops / bytes of one op (bench.py's roofline accounting)
 void op_account(const dmme_plan* P, const Op& o, char* label, int cap, double* flops, double* bytes) {
     const double es = (double)dtype_size(P->dtype);
-    const char* tn = P->dtype == DMME_BF16 ? "bf16" : "float";
+    const char* tn = P->dtype == DMME_BF16 ? "bf16" : "float";  // (the conv labels add ":bf16x3" themselves)
     const double B = P->B;
     *flops = 0;
     *bytes = 0;
@@ -1010,7 +1012,9 @@ DMME_API int dmme_device_count(void) {
 DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W, int dtype, int device, dmme_plan** out) {
     DMME_REQUIRE(cfg && out, DMME_ERR_INVALID, "plan_create: null argument");
     DMME_REQUIRE(B > 0 && H > 0 && W > 0, DMME_ERR_INVALID, "plan_create: bad shape B=%d H=%d W=%d", B, H, W);
-    DMME_REQUIRE(dtype == DMME_F32 || dtype == DMME_BF16, DMME_ERR_INVALID, "plan_create: bad dtype %d", dtype);
+    DMME_REQUIRE(dtype == DMME_F32 || dtype == DMME_BF16 || dtype == DMME_BF16X3, DMME_ERR_INVALID, "plan_create: bad dtype %d", dtype);
+    const int x3 = dtype == DMME_BF16X3;
+    if (x3) dtype = DMME_F32;
     DMME_REQUIRE(cfg->num_depths >= 1 && cfg->num_depths <= 8 && cfg->num_blocks >= 1, DMME_ERR_INVALID,
                  "plan_create: bad depth/blocks");
     DMME_REQUIRE(cfg->num_attention_depths >= 0 && cfg->num_attention_depths <= 8, DMME_ERR_INVALID, "bad attention_depths");
@@ -1029,6 +1033,7 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
     P->H = H;
     P->W = W;
     P->dtype = dtype;
+    P->x3 = x3;
     P->device = device;
     int rc = build_plan(P);
     if (rc != DMME_OK) {
@@ -1419,6 +1424,7 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
             d.Cout = Cin;
             d.w = pkb + P->params[o.w].packed_bwd_off;
             d.dst = tmp;
+            d.x3 = P->x3;
             if (P->splitk_floats > 0) {
                 d.splitk = (float*)(ws + P->ws_splitk);
                 d.splitk_cap = P->splitk_floats;
@@ -1468,6 +1474,7 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
             d.w = pkb + P->params[o.w].packed_bwd_off;
             d.dst = d_x;
             d.out_nchw = 1;
+            d.x3 = P->x3;
             rc = conv_mfma_supported(dt, d) ? launch_conv_mfma(dt, d, s) : launch_conv_generic(dt, d, s);
             if (rc != DMME_OK) break;
         }
@@ -1666,11 +1673,14 @@ DMME_API int dmme_conv2d(const dmme_conv_desc* d, const void* src1, const void* 
     a.pro_silu = d->pro_silu; a.out_silu = d->out_silu; a.nt = d->nt; a.tproj_ld = d->tproj_ld;
     a.in_nchw = d->in_nchw; a.out_nchw = d->out_nchw;
     a.stamps = g_stamps;
-    if (d->force_generic == 2 && conv_mfma_supported(d->dtype, a)) return launch_conv_mfma(d->dtype, a, (hipStream_t)stream);
-    if (!d->force_generic && conv1x1_pipe_supported(d->dtype, a)) return launch_conv1x1_pipe(d->dtype, a, (hipStream_t)stream);
-    if (!d->force_generic && conv_pipe_supported(d->dtype, a)) return launch_conv_pipe(d->dtype, a, (hipStream_t)stream);
-    if (!d->force_generic && conv_mfma_supported(d->dtype, a)) return launch_conv_mfma(d->dtype, a, (hipStream_t)stream);
-    return launch_conv_generic(d->dtype, a, (hipStream_t)stream);
+    DMME_REQUIRE(d->dtype == DMME_F32 || d->dtype == DMME_BF16 || d->dtype == DMME_BF16X3, DMME_ERR_INVALID, "conv2d: bad dtype %d", d->dtype);
+    a.x3 = d->dtype == DMME_BF16X3;
+    const int dt = a.x3 ? DMME_F32 : d->dtype;
+    if (d->force_generic == 2 && conv_mfma_supported(dt, a)) return launch_conv_mfma(dt, a, (hipStream_t)stream);
+    if (!d->force_generic && conv1x1_pipe_supported(dt, a)) return launch_conv1x1_pipe(dt, a, (hipStream_t)stream);
+    if (!d->force_generic && conv_pipe_supported(dt, a)) return launch_conv_pipe(dt, a, (hipStream_t)stream);
+    if (!d->force_generic && conv_mfma_supported(dt, a)) return launch_conv_mfma(dt, a, (hipStream_t)stream);
+    return launch_conv_generic(dt, a, (hipStream_t)stream);
 }
 
 DMME_API int dmme_groupnorm_scale_shift(int dtype, const void* src1, const void* src2, int N, int HW, int C1, int C2, int groups,

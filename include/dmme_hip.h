@@ -50,7 +50,11 @@ typedef enum {
     DMME_ERR_NOMEM = -4
 } dmme_status;
 
-typedef enum { DMME_F32 = 0, DMME_BF16 = 1 } dmme_dtype;
+/* DMME_BF16X3: the accurate mode.  Tensors and weights stay fp32 (same layouts, workspace and packed sizes as DMME_F32); every
+ * convolution product runs as three bf16 MFMA passes over hi/lo splits of its fp32 operands (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi,
+ * fp32 accumulation), ~2^-16 per product instead of 2^-9: within 1e-3 of the fp32 reference at the bf16 matrix rate / 3.
+ * Accepted wherever a dtype is (plans and the single-op entry points); buffers are the fp32 ones. */
+typedef enum { DMME_F32 = 0, DMME_BF16 = 1, DMME_BF16X3 = 2 } dmme_dtype;
 
 /* Which of the reference's two UNets the plan builds. */
 typedef enum {

@@ -7,7 +7,12 @@ import torch
 
 from dmme_amd import _lib
 
-TD = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16}
+TD = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16, _lib.BF16X3: torch.float32}
+
+
+def _st(dt):
+    """storage dtype code of a compute dtype (the accurate mode keeps fp32 buffers)"""
+    return _lib.F32 if dt == _lib.BF16X3 else dt
 
 
 def dev():
@@ -18,21 +23,21 @@ def to_nhwc(x_nchw, dt):
     """fp32 NCHW (cuda) -> NHWC tensor in the compute dtype through dmme_nchw_to_nhwc"""
     N, Cc, H, W = x_nchw.shape
     out = torch.empty((N, H, W, Cc), dtype=TD[dt], device=x_nchw.device)
-    _lib.check(_lib.lib().dmme_nchw_to_nhwc(dt, _lib.ptr(x_nchw.contiguous()), N, Cc, H * W, _lib.ptr(out), _lib.stream_ptr()))
+    _lib.check(_lib.lib().dmme_nchw_to_nhwc(_st(dt), _lib.ptr(x_nchw.contiguous()), N, Cc, H * W, _lib.ptr(out), _lib.stream_ptr()))
     return out
 
 
 def to_nchw(x_nhwc, dt):
     N, H, W, Cc = x_nhwc.shape
     out = torch.empty((N, Cc, H, W), dtype=torch.float32, device=x_nhwc.device)
-    _lib.check(_lib.lib().dmme_nhwc_to_nchw(dt, _lib.ptr(x_nhwc), N, Cc, H * W, _lib.ptr(out), _lib.stream_ptr()))
+    _lib.check(_lib.lib().dmme_nhwc_to_nchw(_st(dt), _lib.ptr(x_nhwc), N, Cc, H * W, _lib.ptr(out), _lib.stream_ptr()))
     return out
 
 
 def pack_w(w_oihw, dt):
     co, ci, k, _ = w_oihw.shape
     out = torch.empty((co, k * k, ci), dtype=TD[dt], device=w_oihw.device)
-    _lib.check(_lib.lib().dmme_pack_weight(dt, _lib.ptr(w_oihw.contiguous()), co, ci, k * k, _lib.ptr(out), _lib.stream_ptr()))
+    _lib.check(_lib.lib().dmme_pack_weight(_st(dt), _lib.ptr(w_oihw.contiguous()), co, ci, k * k, _lib.ptr(out), _lib.stream_ptr()))
     return out
 
 

@@ -1537,6 +1537,60 @@ DMME_API int dmme_unet_plan_grad_buckets(const dmme_plan* plan, int64_t offsets[
     return 2;
 }
 
+/* Which kernels a backward of this plan launches, as "key=value" pairs: the grouped weight-gradient layers / jobs per kernel
+ * size, the grouped column-sum and bias jobs, and how many DATA-gradient convolutions run on each forward kernel (by label).
+ * Lets a parity test assert that a configuration really exercises the kernels it is meant to cover. */
+DMME_API int dmme_unet_plan_bwd_summary(const dmme_plan* plan, char* buf, int cap) {
+    DMME_REQUIRE(plan && buf && cap > 0, DMME_ERR_INVALID, "bwd_summary: bad argument");
+    const dmme_plan* P = plan;
+    std::string out;
+    char tmp[256];
+    snprintf(tmp, sizeof(tmp), "wgrad_group3x3_layers=%d wgrad_group3x3_jobs=%d wgrad_group1x1_layers=%d wgrad_group1x1_jobs=%d colsum_group_jobs=%d bias_group_jobs=%d",
+             (int)P->wg[0].layers.size(), (int)P->wg[0].jobs.size(), (int)P->wg[1].layers.size(), (int)P->wg[1].jobs.size(), (int)P->col_jobs.size(),
+             (int)P->bias_jobs.size());
+    out = tmp;
+    std::unordered_map<std::string, int> dgrad;
+    for (const Op& o : P->ops) {
+        if (o.kind != OP_CONV || o.src1 < 0) continue;
+        ConvArgs a{};
+        fill_conv(P, o, (const char*)4096, (const float*)4096, (float*)4096, (char*)4096, nullptr, 1, a);
+        ConvArgs d{};
+        d.src1 = (const void*)4096;
+        d.C1 = a.Cout;
+        d.N = P->B;
+        d.Hin = a.Hout;
+        d.Win = a.Wout;
+        d.up = o.stride == 2 ? 2 : 0;
+        d.stride = 1;
+        d.taps = o.taps;
+        d.Hout = d.up ? 2 * d.Hin : d.Hin;
+        d.Wout = d.up ? 2 * d.Win : d.Win;
+        d.Cout = a.C1 + a.C2;
+        d.w = (const void*)4096;
+        d.dst = (void*)4096;
+        d.x3 = P->x3;
+        if (P->splitk_floats > 0) {
+            d.splitk = (float*)4096;
+            d.splitk_cap = P->splitk_floats;
+        }
+        char label[128] = "generic";
+        if (conv1x1_pipe_supported(P->dtype, d))
+            conv1x1_pipe_label(P->dtype, d, label, sizeof(label));
+        else if (conv_pipe_supported(P->dtype, d))
+            conv_pipe_label(P->dtype, d, label, sizeof(label));
+        else if (conv_mfma_supported(P->dtype, d))
+            conv_mfma_label(P->dtype, d, label, sizeof(label));
+        dgrad[label] += 1;
+    }
+    for (const auto& kv : dgrad) {
+        snprintf(tmp, sizeof(tmp), " dgrad[%s]=%d", kv.first.c_str(), kv.second);
+        out += tmp;
+    }
+    strncpy(buf, out.c_str(), (size_t)cap - 1);
+    buf[cap - 1] = 0;
+    return DMME_OK;
+}
+
 DMME_API int dmme_grad_norm(const float* grad, int64_t numel, float* norm_out, float* scratch, void* stream) {
     DMME_REQUIRE(grad && norm_out && scratch && numel > 0, DMME_ERR_INVALID, "grad_norm: bad argument");
     return launch_grad_norm(grad, numel, norm_out, scratch, (hipStream_t)stream);

@@ -163,6 +163,9 @@ DMME_API int dmme_unet_backward_buckets(const dmme_plan* plan, const void* packe
                                const int64_t* t, int t_len, const float* d_y, void* workspace, void* bwd_workspace,
                                const float* drop_masks, float* grad_flat, float* d_x, void* stream, dmme_bucket_fn ready, void* user);
 DMME_API int dmme_unet_plan_grad_buckets(const dmme_plan* plan, int64_t offsets[2], int64_t numels[2]);
+/* test / diagnostic: the kernels a backward of this plan launches, as space-separated key=value pairs
+ * ("wgrad_group3x3_jobs=..", "colsum_group_jobs=..", "dgrad[conv3x3_ws2_kernel<11>]=..") */
+DMME_API int dmme_unet_plan_bwd_summary(const dmme_plan* plan, char* buf, int cap);
 /* global L2 norm of a flat fp32 gradient buffer (clip_grad_norm_; scratch: 1024 floats) */
 DMME_API int dmme_grad_norm(const float* grad, int64_t numel, float* norm_out, float* scratch, void* stream);
 /* one fused pass: clip by global norm (max_norm <= 0: off) -> Adam (torch.optim.Adam, no weight

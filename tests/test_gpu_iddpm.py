@@ -306,7 +306,7 @@ def test_attention_heads_kernels(S, C, heads, N):
 
     qkv = synth.normal(S + C + heads, (N, S, 3 * C)) * 1.5
     want = _mha_core_reference(qkv.to(torch.bfloat16).to(torch.float32), heads)
-    for dt, tdt, tol in ((_lib.F32, torch.float32, 2e-5), (_lib.BF16, torch.bfloat16, 1e-2 * max(1.0, float(want.abs().max())))):  # bf16: ~2 output ulps
+    for dt, tdt, tol in ((_lib.F32, torch.float32, 2e-5), (_lib.BF16, torch.bfloat16, 5e-3 * max(1.0, float(want.abs().max())))):  # bf16: K scale, probability and output roundings (test_gpu_ops.BF16_ATTN_RTOL)
         ref = _mha_core_reference(qkv, heads) if dt == _lib.F32 else want
         for force_generic in (1, 0):
             q = qkv.to(tdt).cuda().contiguous()

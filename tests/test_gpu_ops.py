@@ -11,7 +11,13 @@ from oracle import synth
 pytestmark = pytest.mark.gpu
 
 FP32_ATOL = 1e-5  # north_star tolerance for fp32
-BF16_RTOL = 1e-2  # one bf16 output rounding (2^-9) + accumulation-order noise, vs a reference fed the same bf16 operands
+# bf16 kernels against a reference fed the SAME bf16 operands (inputs, weights, the GN/SiLU output re-rounded like the kernel's LDS
+# tile): what is left is the rounding of the stored output - half an ulp, <= 2^-9 of the value - plus fp32 accumulation-order
+# noise and the rare element whose prologue lands on the other side of a rounding boundary.  Bound: 2^-8 of the output's max.
+BF16_RTOL = 2.0**-8
+# attention adds the bf16 rounding of K * C^-0.5 (the reference scales K before the product, models/ddpm.py:58), of the
+# probabilities fed to the second matrix product and of the output: three independent 2^-9 terms on O(1) values
+BF16_ATTN_RTOL = 5e-3
 
 
 def _bf(x):
@@ -144,5 +150,5 @@ def test_attention(case, dtname):
     for force_generic in (True, False):
         got = G.attention(dt, qkv.cuda(), force_generic).cpu()
         err = (got - want).abs().max().item()
-        tol = 1e-5 if dtname == "fp32" else 2e-2 * want.abs().max().item()
+        tol = 1e-5 if dtname == "fp32" else BF16_ATTN_RTOL * want.abs().max().item()
         assert err <= tol, f"attention {case} {dtname} generic={force_generic}: {err:.3e} > {tol:.3e}"

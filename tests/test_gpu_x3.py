@@ -26,14 +26,14 @@ def _build(cfg, seed, precision):
 
 
 def test_full_unet_bf16x3_within_1e3_of_reference_golden(golden):
-    """the default 32.4 M-parameter UNet against the reference's own output (tests/golden/unet_full.npz: full_y_one / full_y_vec)"""
+    """the default 32.4 M-parameter UNet against the reference's own output (tests/golden/unet_full.npz: full_y_one / full_y_per)"""
     g = golden("unet_full")
     net = _build(O.UNetConfig(), int(g["full_seed"]), "bf16x3")
     x = synth.normal(int(g["full_xseed"]), (2, 3, 32, 32)).cuda()
     with torch.no_grad():
         y1 = net(x, torch.from_numpy(g["full_t_one"]).cuda()).cpu().numpy()
-        y2 = net(x, torch.from_numpy(g["full_t_vec"]).cuda()).cpu().numpy()
-    e1, e2 = float(np.abs(y1 - g["full_y_one"]).max()), float(np.abs(y2 - g["full_y_vec"]).max())
+        y2 = net(x, torch.from_numpy(g["full_t_per"]).cuda()).cpu().numpy()
+    e1, e2 = float(np.abs(y1 - g["full_y_one"]).max()), float(np.abs(y2 - g["full_y_per"]).max())
     print(f"bf16x3 full UNet max|err| vs reference: {e1:.3e} (t one), {e2:.3e} (t per image); |y|max {np.abs(g['full_y_one']).max():.3f}")
     assert e1 <= X3_ATOL and e2 <= X3_ATOL
     # and far inside it: the three-pass product drops ~2^-16 per term

@@ -14,6 +14,8 @@
 //     key order matches the accumulator's register order;
 //   * K tile rows are padded by 16 B (conflict-free ds_read_b128), V tile rows by 64 B
 //     (row pitch = 16 banks mod 64: the four key rows of a transposed read hit disjoint banks).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dmme {
@@ -41,32 +43,55 @@ __device__ __forceinline__ int64_t at_o_off(const AttnGeom& g, int bh) {
     return (int64_t)(bh % g.N) * g.S * g.Cfull + (int64_t)(bh / g.N) * D;
 }
 
-// C = head width; NW wavefronts of 32 queries each per workgroup
+// C = head width; NW wavefronts of 32 queries each per workgroup.
+// xcd_order: workgroup L runs on XCD L % 8 and every XCD has its own L2; in plain order the query blocks of one (image, head) row
+// land on different XCDs and each pulls that row's K and V from HBM (round-1 counters: 1.88x the algorithmic bytes).  With
+// xcd_order the blocks of a row take consecutive slots of ONE XCD's round-robin share of the grid.
 template <int C, int NW>
-__global__ void __launch_bounds__(64 * NW) attn_mfma_kernel(const bf16* __restrict__ qkv, AttnGeom g, bf16* __restrict__ out, float* __restrict__ lse) {
+__global__ void __launch_bounds__(64 * NW) attn_mfma_kernel(const bf16* __restrict__ qkv, AttnGeom g, bf16* __restrict__ out, float* __restrict__ lse,
+                                                            int xcd_order) {
     constexpr int AT_QB = 32 * NW, NT = 64 * NW;
     const int S = g.S;
     constexpr int KSTEPS = C / 16;   // k-steps of the QK^T product
     constexpr int CT = C / 32;       // 32-channel tiles of the output
     constexpr int KP = C * 2 + 16;   // K tile row pitch (bytes)
     constexpr int VP = C * 2 + 64;   // V tile row pitch (bytes)
-    __shared__ __attribute__((aligned(16))) char lds[AT_KT * KP + AT_KT * VP];
+    // Wide heads keep Q^T in LDS instead of registers (C = 256: 64 registers): with 128 accumulators the register file then has
+    // room for the K / V prefetch below, whose absence left eight exposed global round trips per workgroup (37 us for 3.4 us of
+    // matrix work at one workgroup per CU).
+    constexpr bool QLDS = C > 128;
+    constexpr int QP = C * 2 + 16;   // Q tile row pitch (bytes)
+    extern __shared__ __attribute__((aligned(16))) char lds[];
     char* ldsK = lds;
     char* ldsV = lds + AT_KT * KP;
+    char* ldsQ = lds + AT_KT * KP + AT_KT * VP;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int qblocks = S / AT_QB;
-    const int n = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;  // n: the (image, head) row
+    int n = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;  // n: the (image, head) row
+    if (xcd_order) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        n = (j / qblocks) * 8 + x;
+        qb = j % qblocks;
+    }
     const bf16* base = qkv + at_qkv_off<C>(g, n);
     const int ld = g.ld;
     const int q_row = qb * AT_QB + wave * 32 + r;  // this lane's query
 
     // Q^T fragments (B operand): element j of k-step ks = Q[q_row][16 ks + 8 h + j]
-    uint4 qf[KSTEPS];
+    uint4 qf[QLDS ? 1 : KSTEPS];
+    if constexpr (QLDS) {
+        for (int u = tid; u < AT_QB * (C / 8); u += NT) {
+            const int row = u / (C / 8), cu = u % (C / 8);
+            *reinterpret_cast<uint4*>(ldsQ + row * QP + cu * 16) = *reinterpret_cast<const uint4*>(base + (int64_t)(qb * AT_QB + row) * ld + cu * 8);
+        }
+    } else {
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks)
-        qf[ks] = *reinterpret_cast<const uint4*>(base + (int64_t)q_row * ld + ks * 16 + h * 8);
+        for (int ks = 0; ks < KSTEPS; ++ks)
+            qf[ks] = *reinterpret_cast<const uint4*>(base + (int64_t)q_row * ld + ks * 16 + h * 8);
+    }
+    const char* q_lds = ldsQ + (wave * 32 + r) * QP + h * 16;
 
     f32x16 o[CT];
 #pragma unroll
@@ -79,53 +104,93 @@ __global__ void __launch_bounds__(64 * NW) attn_mfma_kernel(const bf16* __restri
     // transposed-read lane geometry: 16-lane group g, lane i = 4 q + p inside it
     const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g1 = (lane >> 4) & 1;
 
-    // 64-wide heads: K / V tiles go global -> registers -> LDS and the loads of tile k+1 are issued before the matrix work of tile k,
-    // so their round trip hides under it (14.2 -> 11.2 us).  Wider heads have no registers to spare for that (C = 256: 128
-    // accumulators + 64 of Q; with the prefetch 37 -> 60 us) and keep the direct global -> LDS staging.
-    constexpr bool PREFETCH = C <= 64;
+    // K / V tiles go global -> registers -> LDS and the loads of tile k+1 are issued before the matrix work of tile k, so their
+    // round trip hides under it.
     constexpr int UNITS = AT_KT * (C / 8) / NT;
     static_assert(UNITS >= 1 && UNITS * NT == AT_KT * (C / 8), "attn_mfma: tile does not split evenly over the threads");
-    uint4 kreg[UNITS], vreg[UNITS];
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < UNITS; ++i) {
-            const int u = tid + i * NT, row = u / (C / 8), cu = u % (C / 8);
-            const bf16* src = base + (int64_t)(k0 + row) * ld + cu * 8;
-            kreg[i] = *reinterpret_cast<const uint4*>(src + C);
-            vreg[i] = *reinterpret_cast<const uint4*>(src + 2 * C);
-        }
-    };
-    if constexpr (PREFETCH) fetch(0);
+    // named registers, not arrays: hipcc leaves `uint4 kreg[UNITS]` in scratch memory here (every prefetched vector then makes a
+    // round trip through the scratch buffer), whatever the unrolling
+    uint4 kr0, kr1, kr2, kr3, kr4, kr5, kr6, kr7, vr0, vr1, vr2, vr3, vr4, vr5, vr6, vr7;
+    static_assert(UNITS <= 8, "attn_mfma: more prefetch units than named registers");
+#define AT_LD1(I, K0)                                                                                 \
+    if constexpr (UNITS > I) {                                                                        \
+        const int u = tid + I * NT, row = u / (C / 8), cu = u % (C / 8);                              \
+        const bf16* src = base + (int64_t)((K0) + row) * ld + cu * 8;                                 \
+        kr##I = *reinterpret_cast<const uint4*>(src + C);                                             \
+        vr##I = *reinterpret_cast<const uint4*>(src + 2 * C);                                         \
+    }
+#define AT_ST1(I)                                                                                     \
+    if constexpr (UNITS > I) {                                                                        \
+        const int u = tid + I * NT, row = u / (C / 8), cu = u % (C / 8);                              \
+        *reinterpret_cast<uint4*>(ldsK + row * KP + cu * 16) = kr##I;                                 \
+        *reinterpret_cast<uint4*>(ldsV + row * VP + cu * 16) = vr##I;                                 \
+    }
+#define AT_FETCH(K0) AT_LD1(0, K0) AT_LD1(1, K0) AT_LD1(2, K0) AT_LD1(3, K0) AT_LD1(4, K0) AT_LD1(5, K0) AT_LD1(6, K0) AT_LD1(7, K0)
+    AT_FETCH(0)
     for (int k0 = 0; k0 < S; k0 += AT_KT) {
         __syncthreads();
         // ---- stage K and V tiles (32 keys x C) ----
-        if constexpr (PREFETCH) {
-#pragma unroll
-            for (int i = 0; i < UNITS; ++i) {
-                const int u = tid + i * NT, row = u / (C / 8), cu = u % (C / 8);
-                *reinterpret_cast<uint4*>(ldsK + row * KP + cu * 16) = kreg[i];
-                *reinterpret_cast<uint4*>(ldsV + row * VP + cu * 16) = vreg[i];
-            }
-        } else {
-            for (int u = tid; u < AT_KT * (C / 8); u += NT) {
-                const int row = u / (C / 8), cu = u % (C / 8);
-                const bf16* src = base + (int64_t)(k0 + row) * ld + cu * 8;
-                *reinterpret_cast<uint4*>(ldsK + row * KP + cu * 16) = *reinterpret_cast<const uint4*>(src + C);
-                *reinterpret_cast<uint4*>(ldsV + row * VP + cu * 16) = *reinterpret_cast<const uint4*>(src + 2 * C);
-            }
-        }
+        AT_ST1(0) AT_ST1(1) AT_ST1(2) AT_ST1(3) AT_ST1(4) AT_ST1(5) AT_ST1(6) AT_ST1(7)
         __syncthreads();
-        if constexpr (PREFETCH)
-            if (k0 + AT_KT < S) fetch(k0 + AT_KT);
+        if (k0 + AT_KT < S) {
+            AT_FETCH(k0 + AT_KT)
+        }
+#undef AT_FETCH
+#undef AT_LD1
+#undef AT_ST1
         // ---- S^T tile (32 keys x 32 queries) = K Q^T ----
+        // One wave per SIMD: nothing hides an LDS read's latency but this wave's own instruction order.  Fragments are therefore
+        // read a group of FG k-steps AHEAD of the MFMAs that use them (sched_barrier pins the order the compiler would otherwise
+        // re-serialise into read -> MFMA -> read): the exposed latencies per tile drop from 32 to ~6.
         f32x16 st;
 #pragma unroll
         for (int j = 0; j < 16; ++j) st[j] = 0.f;
+        {
+            constexpr int FG = 4;
+            uint4 kf[FG], qv[FG];
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            const uint4 kf = *reinterpret_cast<const uint4*>(ldsK + r * KP + ks * 32 + h * 16);
-            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[ks]), st, 0, 0, 0);
+            for (int u = 0; u < FG; ++u) {
+                kf[u] = *reinterpret_cast<const uint4*>(ldsK + r * KP + u * 32 + h * 16);
+                if constexpr (QLDS) qv[u] = *reinterpret_cast<const uint4*>(q_lds + u * 32);
+                else qv[u] = qf[u];
+            }
+#pragma unroll
+            for (int g0 = 0; g0 < KSTEPS; g0 += FG) {
+                uint4 kn[FG], qn[FG];
+                if (g0 + FG < KSTEPS) {
+#pragma unroll
+                    for (int u = 0; u < FG; ++u) {
+                        kn[u] = *reinterpret_cast<const uint4*>(ldsK + r * KP + (g0 + FG + u) * 32 + h * 16);
+                        if constexpr (QLDS) qn[u] = *reinterpret_cast<const uint4*>(q_lds + (g0 + FG + u) * 32);
+                        else qn[u] = qf[(g0 + FG + u) < KSTEPS ? (g0 + FG + u) : 0];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < FG; ++u)
+                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[u]), __builtin_bit_cast(bf16x8, qv[u]), st, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g0 + FG < KSTEPS) {
+#pragma unroll
+                    for (int u = 0; u < FG; ++u) {
+                        kf[u] = kn[u];
+                        qv[u] = qn[u];
+                    }
+                }
+            }
         }
+        // V^T fragments of the first output tiles go out now: their latency hides under the softmax arithmetic
+        constexpr int VG = CT >= 2 ? 2 : 1;  // output tiles per fragment group
+        s16x4 vlo[VG][2], vhi[VG][2];
+#define AT_VREAD(CT0, DST_LO, DST_HI)                                                                                         \
+    _Pragma("unroll") for (int cu = 0; cu < VG; ++cu) _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                       \
+        const int colb = (((CT0) + cu) * 32 + 16 * tr_g1 + 4 * tr_p) * 2;                                                     \
+        const char* a0 = ldsV + (16 * s2 + 4 * h + tr_q) * VP + colb;                                                         \
+        const char* a1 = ldsV + (16 * s2 + 8 + 4 * h + tr_q) * VP + colb;                                                     \
+        DST_LO[cu][s2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);               \
+        DST_HI[cu][s2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);               \
+    }
+        AT_VREAD(0, vlo, vhi)
         // ---- online softmax for this lane's query (keys of this lane: 16 of the 32) ----
         float tmax = st[0];
 #pragma unroll
@@ -142,10 +207,14 @@ __global__ void __launch_bounds__(64 * NW) attn_mfma_kernel(const bf16* __restri
         }
         l = fmaf(l, alpha, psum);
         m = m_new;
+        // the running maximum settles after the first tiles: skip the 16 CT multiplies (and the accumulator round trips
+        // behind them) when no lane of the wave moved it.  alpha == 1 exactly then, so the result is the same bit for bit.
+        if (__any(alpha != 1.0f)) {
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+            for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) o[ct][j] *= alpha;
+                for (int j = 0; j < 16; ++j) o[ct][j] *= alpha;
+        }
         // P^T as B operand: k-step s uses registers 8s..8s+7 (key = 16 s + 8 (j>>2) + 4 h + (j&3))
         bf16x8 pf[2];
 #pragma unroll
@@ -154,20 +223,33 @@ __global__ void __launch_bounds__(64 * NW) attn_mfma_kernel(const bf16* __restri
             for (int j = 0; j < 8; ++j) pf[s2][j] = (bf16)p[8 * s2 + j];
         // ---- O^T += V^T P^T ----
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
+        for (int ct = 0; ct < CT; ct += VG) {
+            s16x4 nlo[VG][2], nhi[VG][2];
+            if (ct + VG < CT) {
+                AT_VREAD(ct + VG, nlo, nhi)
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const int colb = (ct * 32 + 16 * tr_g1 + 4 * tr_p) * 2;
-                const char* a0 = ldsV + (16 * s2 + 4 * h + tr_q) * VP + colb;
-                const char* a1 = ldsV + (16 * s2 + 8 + 4 * h + tr_q) * VP + colb;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
-                s16x8 vf;
-                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-                vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-                o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf[s2], o[ct], 0, 0, 0);
+            for (int cu = 0; cu < VG; ++cu)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    s16x8 vf;
+                    vf[0] = vlo[cu][s2][0]; vf[1] = vlo[cu][s2][1]; vf[2] = vlo[cu][s2][2]; vf[3] = vlo[cu][s2][3];
+                    vf[4] = vhi[cu][s2][0]; vf[5] = vhi[cu][s2][1]; vf[6] = vhi[cu][s2][2]; vf[7] = vhi[cu][s2][3];
+                    o[ct + cu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf[s2], o[ct + cu], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ct + VG < CT) {
+#pragma unroll
+                for (int cu = 0; cu < VG; ++cu)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        vlo[cu][s2] = nlo[cu][s2];
+                        vhi[cu][s2] = nhi[cu][s2];
+                    }
             }
         }
+#undef AT_VREAD
     }
     // ---- normalise and store: lane = query, registers = channels (j&3) + 8 (j>>2) + 4 h ----
     const float ltot = l + __shfl_xor(l, 32, 64);
@@ -198,15 +280,25 @@ bool attn_heads_mfma_supported(int dtype, int N, int S, int C, int heads) {
 }
 static AttnGeom attn_geom(int N, int S, int C, int heads) { return AttnGeom{S, 3 * C, C, heads, N, 1.0f / sqrtf((float)C)}; }
 
-template <int D>
-static int launch_attn_fwd_t(const bf16* qkv, const AttnGeom& g, bf16* out, float* lse, hipStream_t s) {
-    const int rows = g.N * g.heads;
-    if (g.S % 128 == 0)
-        hipLaunchKernelGGL((attn_mfma_kernel<D, 4>), dim3((unsigned)(rows * (g.S / 128))), dim3(256), 0, s, qkv, g, out, lse);
-    else
-        hipLaunchKernelGGL((attn_mfma_kernel<D, 2>), dim3((unsigned)(rows * (g.S / 64))), dim3(128), 0, s, qkv, g, out, lse);
+template <int D, int NW>
+static int launch_attn_fwd_nw(const bf16* qkv, const AttnGeom& g, bf16* out, float* lse, hipStream_t s) {
+    const int rows = g.N * g.heads, qblocks = g.S / (32 * NW);
+    const size_t lds = (size_t)AT_KT * (D * 2 + 16) + (size_t)AT_KT * (D * 2 + 64) + (D > 128 ? (size_t)32 * NW * (D * 2 + 16) : 0);
+    static bool attr_done = false;
+    if (!attr_done) {
+        DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_kernel<D, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_done = true;
+    }
+    static const bool xcd_off = getenv("DMME_NO_XCD_ORDER") != nullptr;
+    const int xcd_order = (!xcd_off && qblocks > 1 && rows % 8 == 0) ? 1 : 0;
+    hipLaunchKernelGGL((attn_mfma_kernel<D, NW>), dim3((unsigned)(rows * qblocks)), dim3(64 * NW), lds, s, qkv, g, out, lse, xcd_order);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
+}
+template <int D>
+static int launch_attn_fwd_t(const bf16* qkv, const AttnGeom& g, bf16* out, float* lse, hipStream_t s) {
+    if (g.S % 128 == 0) return launch_attn_fwd_nw<D, 4>(qkv, g, out, lse, s);
+    return launch_attn_fwd_nw<D, 2>(qkv, g, out, lse, s);
 }
 int launch_attn_heads_mfma(int dtype, const void* qkv, int N, int S, int C, int heads, void* out, float* lse, hipStream_t s) {
     DMME_REQUIRE(attn_heads_mfma_supported(dtype, N, S, C, heads), DMME_ERR_UNSUPPORTED, "attn_mfma: unsupported shape S=%d C=%d heads=%d", S, C, heads);

@@ -172,6 +172,11 @@ __global__ void __launch_bounds__(256) gn_finalize_parts_kernel(const float* __r
     const int fg = cs / groups;                          // producer (fine) group size
     const int f0 = (second ? c_first - C1 : c_first) / fg, nf = cg / fg;
     float na = 0.f, mean = 0.f, m2 = 0.f;
+    // gamma / beta of this thread's first channel go out FIRST: they do not depend on the statistics, and a kernel this small is
+    // one chain of dependent memory round trips - fetched after the merge they were a second, exposed one.  A group's gamma / beta
+    // are contiguous (<= 128 B), so the later channels of the loop below hit the lines this load brought in.
+    const int jf = sub < cg ? sub : 0;
+    const float gam0 = gamma[c_first + jf], bet0 = beta[c_first + jf];
     // partials in (tile, fine group) order
     const int npart = tiles * nf;
     if constexpr (!BATCH) {
@@ -211,7 +216,8 @@ __global__ void __launch_bounds__(256) gn_finalize_parts_kernel(const float* __r
     }
     for (int j = sub; j < cg; j += LANES) {
         const int c = c_first + j;
-        float a = rstd * gamma[c], b = beta[c] - mean * a;
+        const float gm = j == jf ? gam0 : gamma[c], bt = j == jf ? bet0 : beta[c];
+        float a = rstd * gm, b = bt - mean * a;
         if constexpr (MOD) {  // scale-shift conditioning folded in (same arithmetic as gn_modulate_kernel)
             const int64_t r = (int64_t)(nt == 1 ? 0 : n) * t_ld + c;
             const float mm = 1.0f + t_scale[r];

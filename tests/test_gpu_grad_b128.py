@@ -20,9 +20,15 @@ pytestmark = pytest.mark.gpu
 # fewer than 1024 values are pooled by class).  Every product dY * act(x) carries two bf16 roundings (u = 2^-9 each, independent),
 # and a gradient entry is a sum of N*H*W such products with heavy cancellation, so its relative error is u * sqrt(2) times the
 # cancellation ratio ||terms||_2 / |sum| - a few per cent for the deep 3x3 filters, less for the sums that cancel less.
-# Bounds = 1.25 x measured (printed by the test).
-CLASS_BOUNDS = {"conv3x3": 0.08, "conv1x1": 0.08, "linear": 0.08, "bias": 0.08, "gn_gamma": 0.08, "gn_beta": 0.08}
-SAME_PRECISION_BOUND = 0.02  # bf16 B = 128 against bf16 B = 2 of the same library: same roundings, other kernels / summation orders
+# The worst tensors are the ones fed by the 4x4 maps (middle_layers.0: 16 pixels per image, so few terms to average over): measured
+# conv3x3 4.3e-2, linear 4.1e-2, conv1x1 3.8e-2, conv / linear biases 5.6e-3, GroupNorm gamma 7.4e-3 / beta 6.1e-3 (the 1-D tensors
+# sum over every pixel of a channel and cancel far less); the whole flat gradient is off by 7.9e-3.  IDDPM-64 at batch 32 measures
+# the same (4.3e-2 / 4.1e-2 / 3.8e-2 / 3.3e-3 / 3.5e-3 / 3.7e-3).  Bounds = 1.25 x measured.
+CLASS_BOUNDS = {"conv3x3": 5.4e-2, "conv1x1": 4.8e-2, "linear": 5.1e-2, "bias": 7.0e-3, "gn_gamma": 9.3e-3, "gn_beta": 7.7e-3}
+FLAT_BOUND = 1.0e-2  # whole flat gradient, measured 7.9e-3
+# The batch-128 run against the batch-2 run of the same library (other kernels: persistent vs 4-wave tiles, other summation orders,
+# hence other roundings): two estimates with the SAME error statistics - measured B = 2 vs oracle 4.6e-2 / B = 128 vs oracle
+# 4.3e-2 / B = 128 vs B = 2 3.8e-2 - so the batch-128 kernels are as accurate as the small-batch ones, bounded by the same table.
 
 
 def _classes(net):
@@ -110,7 +116,7 @@ def test_ddpm_batch128_bf16_train_gradients_vs_fp32_oracle():
         loss = ddpm.training_step(x0.repeat(r, 1, 1, 1).cuda(), t=t.repeat(r).cuda(), noise=z.repeat(r, 1, 1, 1).cuda())
         loss.backward()
         torch.cuda.synchronize()
-        return net, float(loss), {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()}
+        return net, float(loss.detach()), {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()}
 
     net2, loss2, g2 = run(2)
     net, loss128, g128 = run(2 * reps)
@@ -135,8 +141,11 @@ def test_ddpm_batch128_bf16_train_gradients_vs_fp32_oracle():
     print(f"whole flat gradient: relative error {total:.3e}")
     for c, (rel, name) in vs_ref.items():
         assert rel <= CLASS_BOUNDS[c], f"{c}: {rel:.3e} > {CLASS_BOUNDS[c]} at {name}"
+    assert total <= FLAT_BOUND, total
     for c, (rel, name) in vs_b2.items():
-        assert rel <= SAME_PRECISION_BOUND, f"{c}: B=128 vs B=2 {rel:.3e} at {name}"
+        assert rel <= CLASS_BOUNDS[c], f"{c}: B=128 vs B=2 {rel:.3e} at {name}"
+    for c, (rel, name) in b2_vs_ref.items():  # and the large batch is no worse than the small one by more than the table's margin
+        assert vs_ref[c][0] <= 1.25 * max(rel, 1e-3), (c, vs_ref[c], rel)
 
 
 def test_iddpm64_batch32_bf16_train_gradients_vs_fp32_path():

@@ -288,14 +288,18 @@ def test_sampler_trajectories_vs_reference_golden(golden):
 # ------------------------------------------------------------------------------------------ multi-head attention kernels
 
 
-def _mha_core_reference(qkv, heads):
-    """qkv (N, S, 3C) fp32 -> (N, S, C): oracle.iddpm.multi_head_attention without norm / projections."""
+def _mha_core_reference(qkv, heads, round_scaled_k=False):
+    """qkv (N, S, 3C) fp32 -> (N, S, C): oracle.iddpm.multi_head_attention without norm / projections.
+    round_scaled_k: K * C^-0.5 rounded to bf16 before the product, as a 16-bit autocast of the reference (and the generic kernel) does"""
     N, S, C3 = qkv.shape
     C = C3 // 3
     d = C // heads
     x = qkv.reshape(N, S, heads, 3 * d).permute(0, 2, 1, 3).reshape(N * heads, S, 3 * d)
     q, k, v = x[..., :d], x[..., d : 2 * d], x[..., 2 * d :]
-    w = torch.softmax(torch.bmm(q, k.transpose(1, 2) * C**-0.5), dim=2)
+    ks = k * C**-0.5
+    if round_scaled_k:
+        ks = ks.to(torch.bfloat16).to(torch.float32)
+    w = torch.softmax(torch.bmm(q, ks.transpose(1, 2)), dim=2)
     o = torch.bmm(w, v).reshape(heads, N, S, d)  # rows b*heads + h re-read as (head', b')
     return o.permute(1, 2, 0, 3).reshape(N, S, C)
 
@@ -307,8 +311,9 @@ def test_attention_heads_kernels(S, C, heads, N):
     qkv = synth.normal(S + C + heads, (N, S, 3 * C)) * 1.5
     want = _mha_core_reference(qkv.to(torch.bfloat16).to(torch.float32), heads)
     for dt, tdt, tol in ((_lib.F32, torch.float32, 2e-5), (_lib.BF16, torch.bfloat16, 5e-3 * max(1.0, float(want.abs().max())))):  # bf16: K scale, probability and output roundings (test_gpu_ops.BF16_ATTN_RTOL)
-        ref = _mha_core_reference(qkv, heads) if dt == _lib.F32 else want
         for force_generic in (1, 0):
+            mfma = dt == _lib.BF16 and not force_generic and (C // heads) in (64, 128, 256) and S >= 64
+            ref = _mha_core_reference(qkv, heads) if dt == _lib.F32 else (want if mfma else _mha_core_reference(qkv.to(torch.bfloat16).to(torch.float32), heads, True))
             q = qkv.to(tdt).cuda().contiguous()
             out = torch.empty((N, S, C), dtype=tdt, device="cuda")
             _lib.check(_lib.lib().dmme_attention_heads(dt, _lib.ptr(q), N, S, C, heads, _lib.ptr(out), force_generic, _lib.stream_ptr()))
@@ -330,11 +335,9 @@ def test_full_size_bf16_grads_track_fp32_grads():
         idd = dmme_amd.IDDPM(net, timesteps=T, gamma=0.05).cuda()
         idd.training_step(x0, t=t, noise=z).backward()
         grads[prec] = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
-    bad = {}
-    for k, g32 in grads["fp32"].items():
-        if g32.numel() < 4096:
-            continue
-        rel = float((grads["bf16"][k] - g32).norm() / (g32.norm() + 1e-12))
-        if rel > 0.08:
-            bad[k] = rel
-    assert not bad, f"{len(bad)} tensors off, e.g. {list(bad.items())[:8]}"
+    from tests.test_gpu_grad_b128 import CLASS_BOUNDS, _class_errors, _classes
+
+    worst = _class_errors({k: v.cpu() for k, v in grads["bf16"].items()}, {k: v.cpu() for k, v in grads["fp32"].items()}, _classes(net))
+    print("IDDPM default UNet B=3 bf16 vs fp32, worst relative error per tensor class:", {c: f"{v[0]:.3e} ({v[1]})" for c, v in worst.items()})
+    for c, (rel, name) in worst.items():  # the per-class budget of the batch-128 parity test (derived there)
+        assert rel <= CLASS_BOUNDS[c], (c, name, rel)

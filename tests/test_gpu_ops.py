@@ -147,8 +147,15 @@ def test_attention(case, dtname):
     src = _bf(qkv) if dtname == "bf16" else qkv
     q, k, v = src[:, :, :Cc].double(), src[:, :, Cc : 2 * Cc].double(), src[:, :, 2 * Cc :].double()
     want = (torch.softmax(q @ (k.transpose(1, 2) * Cc**-0.5), dim=2) @ v).float()
+    # The reference multiplies K by C^-0.5 BEFORE the product (models/ddpm.py:58): under a 16-bit autocast that product is rounded
+    # to 16 bits.  The generic kernel reproduces that rounding, the MFMA kernel scales the fp32 scores instead (closer to the fp32
+    # reference); each is held against the reference fed its own operands.
+    k_rounded = _bf(src[:, :, Cc : 2 * Cc] * Cc**-0.5).double()
+    want_rk = (torch.softmax(q @ k_rounded.transpose(1, 2), dim=2) @ v).float()
     for force_generic in (True, False):
         got = G.attention(dt, qkv.cuda(), force_generic).cpu()
-        err = (got - want).abs().max().item()
+        ref = want_rk if (dtname == "bf16" and (force_generic or S < 64 or Cc % 64)) else want
+        err = (got - ref).abs().max().item()
         tol = 1e-5 if dtname == "fp32" else BF16_ATTN_RTOL * want.abs().max().item()
+        print(f"attention {case} {dtname} generic={force_generic}: err {err:.3e} (tol {tol:.3e})")
         assert err <= tol, f"attention {case} {dtname} generic={force_generic}: {err:.3e} > {tol:.3e}"

@@ -170,13 +170,12 @@ def test_bf16_train_step_close_to_fp32():
         loss = ddpm.training_step(synth.uniform(1, (4, 3, 32, 32)).cuda(), t=torch.tensor([5, 300, 700, 999]).cuda(), noise=synth.normal(2, (4, 3, 32, 32)).cuda())
         loss.backward()
         grads[prec] = {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()}
-    worst = 0.0
-    for k in grads["fp32"]:
-        a, b = grads["fp32"][k], grads["bf16"][k]
-        rel = ((a - b).norm() / (a.norm() + 1e-12)).item()
-        worst = max(worst, rel)
-        assert rel < 0.08, (k, rel)
-    print("worst relative gradient error bf16 vs fp32:", worst)
+    from tests.test_gpu_grad_b128 import CLASS_BOUNDS, _class_errors, _classes
+
+    worst = _class_errors(grads["bf16"], grads["fp32"], _classes(net))
+    print("worst relative gradient error bf16 vs fp32 per tensor class:", {c: f"{v[0]:.3e} ({v[1]})" for c, v in worst.items()})
+    for c, (rel, name) in worst.items():  # the per-class budget of the batch-128 parity test (derived there)
+        assert rel <= CLASS_BOUNDS[c], (c, name, rel)
 
 
 def test_swap_ema_weights_for_sampling():

@@ -15,14 +15,16 @@ FP32_ATOL = 1e-5  # north_star: 1e-5 fp32
 # north_star asks 1e-3 for the reduced-precision path: that is met by precision="bf16x3" (tests/test_gpu_x3.py).  The fast
 # single-pass bf16 mode rounds every stored tensor and matrix operand to 8 significant bits (u = 2^-9): its error is budgeted
 #  and asserted at 1.25 x what is measured on the default UNet - rel-RMS 8.0e-3, max-abs 1.15e-2 on |y| <= 1.34.
-BF16_REL_RMS = 1.0e-2
-BF16_MAX_ABS = 1.45e-2
-BF16_WALK_A = 2.5  # e_k <= A u sqrt(n_k) along the network (provisional until measured; see the growth test)
+BF16_REL_RMS = 1.0e-2   # measured 7.81e-3
+BF16_MAX_ABS = 1.36e-2  # measured 1.084e-2
+# e_k <= A u sqrt(n_k) along the network: measured A = 0.67 .. 0.93 down the encoder and through the middle (a clean random walk),
+# falling to 0.29 at the last decoder block as the skip connections bring in tensors with fewer roundings behind them
+BF16_WALK_A = 1.2
 # other geometries in bf16, each at 1.25 x its own measured (rel-RMS, max-abs / |want|max); filled from the printed values
 BF16_BOUNDS = {
     "default": (BF16_REL_RMS, BF16_MAX_ABS),
-    "lsun_church_256": (1.5e-2, 6e-2),
-    "uneven_splitk_192": (1.5e-2, 6e-2),
+    "lsun_church_256": (1.08e-2, 1.14e-2),    # measured 8.63e-3, 9.06e-3
+    "uneven_splitk_192": (1.14e-2, 1.35e-2),  # measured 9.08e-3, 1.07e-2
 }
 
 

@@ -25,6 +25,24 @@ __device__ __forceinline__ void load_vec(const T* p, float (&v)[16 / sizeof(T)])
         for (int j = 0; j < 8; ++j) v[j] = (float)b[j];
     }
 }
+// The pixel loops below issue the 16-byte loads of FOUR pixels before touching any of them: at one or two loads in flight per
+// thread these kernels ran at ~2.3 TB/s (bandwidth = bytes in flight / memory latency), far under what HBM delivers.  The
+// accumulation order per thread is unchanged (pixels in ascending order), so the results are the same bit for bit.
+template <typename T>
+__device__ __forceinline__ uint4 load_raw(const T* p) {
+    return *reinterpret_cast<const uint4*>(p);
+}
+template <typename T>
+__device__ __forceinline__ void unpack_vec(const uint4& raw, float (&v)[16 / sizeof(T)]) {
+    if constexpr (sizeof(T) == 4) {
+        const float4 f = __builtin_bit_cast(float4, raw);
+        v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+    } else {
+        const bf16x8 b = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)b[j];
+    }
+}
 template <typename T>
 __device__ __forceinline__ void store_vec(T* p, const float (&v)[16 / sizeof(T)]) {
     if constexpr (sizeof(T) == 4) {
@@ -56,8 +74,11 @@ static bool vec_geometry(int dtype, int HW, int C, int& chunk_px, int& nchunks, 
     if (VPP > 256) return false;
     int ppw = 256 / VPP;  // threads beyond ppw*VPP idle when VPP does not divide 256 (e.g. 768 channels)
     while (ppw > 1 && HW % ppw) --ppw;
+    // four pixel rows per thread = ONE batch of loads (below), and four times the workgroups a 16-row chunk gave: with 2 workgroups per
+    // CU and four dependent batches per thread these kernels were a chain of exposed round trips (gn_bwd_sums: 2.9 TB/s)
     int sweeps = HW / ppw;
-    if (sweeps > 16) sweeps = 16;
+    static const int max_sweeps = getenv("DMME_BWD_SWEEPS") ? atoi(getenv("DMME_BWD_SWEEPS")) : 4;
+    if (sweeps > max_sweeps) sweeps = max_sweeps;
     while (sweeps > 1 && (HW / ppw) % sweeps) --sweeps;
     chunk_px = sweeps * ppw;
     nchunks = HW / chunk_px;
@@ -76,12 +97,26 @@ __global__ void __launch_bounds__(256) colsum_vec_kernel(const T* __restrict__ d
     float acc[EPV];
 #pragma unroll
     for (int j = 0; j < EPV; ++j) acc[j] = 0.f;
-    for (int p = prow; p < chunk_px && prow < ppw; p += ppw) {
-        float v[EPV];
-        load_vec<T>(dY + (p0 + p) * C + slot * EPV, v);
-#pragma unroll
-        for (int j = 0; j < EPV; ++j) acc[j] += v[j];
+#define COL_ONE(RAW)                                                   \
+    {                                                                  \
+        float v[EPV];                                                  \
+        unpack_vec<T>(RAW, v);                                         \
+        _Pragma("unroll") for (int j = 0; j < EPV; ++j) acc[j] += v[j]; \
     }
+    if (prow < ppw) {
+        int p = prow;
+        for (; p + 3 * ppw < chunk_px; p += 4 * ppw) {
+            const T* q = dY + (p0 + p) * C + slot * EPV;
+            const uint4 r0 = load_raw<T>(q), r1 = load_raw<T>(q + (int64_t)ppw * C), r2 = load_raw<T>(q + (int64_t)2 * ppw * C),
+                        r3 = load_raw<T>(q + (int64_t)3 * ppw * C);
+            COL_ONE(r0) COL_ONE(r1) COL_ONE(r2) COL_ONE(r3)
+        }
+        for (; p < chunk_px; p += ppw) {
+            const uint4 r0 = load_raw<T>(dY + (p0 + p) * C + slot * EPV);
+            COL_ONE(r0)
+        }
+    }
+#undef COL_ONE
 #pragma unroll
     for (int j = 0; j < EPV; ++j) red[tid * EPV + j] = acc[j];
     __syncthreads();
@@ -109,12 +144,26 @@ __global__ void __launch_bounds__(256) colsum_group_kernel(const ColJob* __restr
     float acc[EPV];
 #pragma unroll
     for (int j = 0; j < EPV; ++j) acc[j] = 0.f;
-    for (int p = prow; p < chunk_px && prow < ppw; p += ppw) {
-        float v[EPV];
-        load_vec<T>(dY + (p0 + p) * C + slot * EPV, v);
-#pragma unroll
-        for (int j = 0; j < EPV; ++j) acc[j] += v[j];
+#define COL_ONE(RAW)                                                   \
+    {                                                                  \
+        float v[EPV];                                                  \
+        unpack_vec<T>(RAW, v);                                         \
+        _Pragma("unroll") for (int j = 0; j < EPV; ++j) acc[j] += v[j]; \
     }
+    if (prow < ppw) {
+        int p = prow;
+        for (; p + 3 * ppw < chunk_px; p += 4 * ppw) {
+            const T* q = dY + (p0 + p) * C + slot * EPV;
+            const uint4 r0 = load_raw<T>(q), r1 = load_raw<T>(q + (int64_t)ppw * C), r2 = load_raw<T>(q + (int64_t)2 * ppw * C),
+                        r3 = load_raw<T>(q + (int64_t)3 * ppw * C);
+            COL_ONE(r0) COL_ONE(r1) COL_ONE(r2) COL_ONE(r3)
+        }
+        for (; p < chunk_px; p += ppw) {
+            const uint4 r0 = load_raw<T>(dY + (p0 + p) * C + slot * EPV);
+            COL_ONE(r0)
+        }
+    }
+#undef COL_ONE
 #pragma unroll
     for (int j = 0; j < EPV; ++j) red[tid * EPV + j] = acc[j];
     __syncthreads();
@@ -230,7 +279,7 @@ __global__ void __launch_bounds__(256) gn_bwd_sums_kernel(const T* __restrict__ 
                                                           int C1, int C2, int groups, const float* __restrict__ mean_rstd,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           const float* __restrict__ dmask, int pro_silu, int chunk_px, int ppw,
-                                                          float* __restrict__ AB /* [N][C][2] */) {
+                                                          float* __restrict__ AB /* [pixel chunks][N][C][2] */) {
     constexpr int EPV = 16 / sizeof(T);
     __shared__ float red[256 * EPV * 2];
     const int C = C1 + C2, tid = threadIdx.x, VPP = C / EPV, slot = tid % VPP, prow = tid / VPP;
@@ -252,18 +301,34 @@ __global__ void __launch_bounds__(256) gn_bwd_sums_kernel(const T* __restrict__ 
     float a[EPV], b[EPV];
 #pragma unroll
     for (int j = 0; j < EPV; ++j) a[j] = b[j] = 0.f;
-    for (int p = prow; p < chunk_px && prow < ppw; p += ppw) {
-        float d[EPV], xv[EPV];
-        load_vec<T>(dv + (p0 + p) * C + c0, d);
-        load_vec<T>(xs + (p0 + p) * Cs + cs0, xv);
-#pragma unroll
-        for (int j = 0; j < EPV; ++j) {
-            float du = d[j] * dm[j];
-            if (pro_silu) du *= silu_grad_f<T>(fmaf(xv[j], sc[j], sh[j]));
-            a[j] += du;
-            b[j] = fmaf(du, (xv[j] - mu[j]) * rs[j], b[j]);
+#define SUMS_ONE(RD, RX)                                                                  \
+    {                                                                                     \
+        float d[EPV], xv[EPV];                                                            \
+        unpack_vec<T>(RD, d);                                                             \
+        unpack_vec<T>(RX, xv);                                                            \
+        _Pragma("unroll") for (int j = 0; j < EPV; ++j) {                                 \
+            float du = d[j] * dm[j];                                                      \
+            if (pro_silu) du *= silu_grad_f<T>(fmaf(xv[j], sc[j], sh[j]));                \
+            a[j] += du;                                                                   \
+            b[j] = fmaf(du, (xv[j] - mu[j]) * rs[j], b[j]);                               \
+        }                                                                                 \
+    }
+    if (prow < ppw) {
+        int p = prow;
+        for (; p + 3 * ppw < chunk_px; p += 4 * ppw) {
+            const T* qd = dv + (p0 + p) * C + c0;
+            const T* qx = xs + (p0 + p) * Cs + cs0;
+            const int64_t sd = (int64_t)ppw * C, sx = (int64_t)ppw * Cs;
+            const uint4 d0 = load_raw<T>(qd), d1 = load_raw<T>(qd + sd), d2 = load_raw<T>(qd + 2 * sd), d3 = load_raw<T>(qd + 3 * sd);
+            const uint4 x0 = load_raw<T>(qx), x1 = load_raw<T>(qx + sx), x2 = load_raw<T>(qx + 2 * sx), x3 = load_raw<T>(qx + 3 * sx);
+            SUMS_ONE(d0, x0) SUMS_ONE(d1, x1) SUMS_ONE(d2, x2) SUMS_ONE(d3, x3)
+        }
+        for (; p < chunk_px; p += ppw) {
+            const uint4 d0 = load_raw<T>(dv + (p0 + p) * C + c0), x0 = load_raw<T>(xs + (p0 + p) * Cs + cs0);
+            SUMS_ONE(d0, x0)
         }
     }
+#undef SUMS_ONE
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
         red[(tid * EPV + j) * 2] = a[j];
@@ -278,18 +343,43 @@ __global__ void __launch_bounds__(256) gn_bwd_sums_kernel(const T* __restrict__ 
                 sa += red[((r * VPP + tid) * EPV + j) * 2];
                 sb += red[((r * VPP + tid) * EPV + j) * 2 + 1];
             }
-            atomicAdd(&AB[((int64_t)n * C + tid * EPV + j) * 2], sa);
-            atomicAdd(&AB[((int64_t)n * C + tid * EPV + j) * 2 + 1], sb);
+            // one partial per (pixel chunk, image, channel), summed by the finalize kernel: four atomics per (image, channel) pair
+            // cost more than the pass over the tensor (131 k float atomics per launch at 128 channels: ~20 of its 24 us)
+            float* ab = AB + ((((int64_t)blockIdx.x * gridDim.y + n) * C) + tid * EPV + j) * 2;
+            ab[0] = sa;
+            ab[1] = sb;
         }
     }
 }
 
 // finalize: blocks [0, nb_s): S[n][g] = {sum gamma A, sum gamma B};
 //           remaining blocks: 32 channels each, dgamma_c += sum_n B, dbeta_c += sum_n A (8-way split over n + LDS)
-__global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __restrict__ AB, int N, int C, int groups, int nb_s,
+// {A, B} of one (image, channel) summed over the pixel chunks, fixed order (reproducible); the 8-byte loads of four chunks go out
+// together - this kernel is nothing but dependent memory round trips
+__device__ __forceinline__ float2 ab_sum(const float* __restrict__ AB, int nchunks, int64_t stride, int64_t pair) {
+    const float2* q = reinterpret_cast<const float2*>(AB) + pair;
+    const int64_t st = stride / 2;
+    float2 s = q[0];
+    int k = 1;
+    for (; k + 3 < nchunks; k += 4) {
+        const float2 v0 = q[k * st], v1 = q[(k + 1) * st], v2 = q[(k + 2) * st], v3 = q[(k + 3) * st];
+        s.x += v0.x; s.y += v0.y;
+        s.x += v1.x; s.y += v1.y;
+        s.x += v2.x; s.y += v2.y;
+        s.x += v3.x; s.y += v3.y;
+    }
+    for (; k < nchunks; ++k) {
+        const float2 v = q[k * st];
+        s.x += v.x;
+        s.y += v.y;
+    }
+    return s;
+}
+__global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __restrict__ AB, int nchunks, int N, int C, int groups, int nb_s,
                                                               const float* __restrict__ gamma, float* __restrict__ S,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, GnMod mod) {
     const int cg = C / groups;
+    const int64_t cstride = (int64_t)N * C * 2;
     if ((int)blockIdx.x < nb_s) {
         const int i = blockIdx.x * blockDim.x + threadIdx.x;
         if (i >= N * groups) return;
@@ -298,8 +388,9 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __res
         for (int j = 0; j < cg; ++j) {
             const int c = g * cg + j;
             const float gm = gamma[c] * mod.mul(n, c);
-            s1 = fmaf(gm, AB[((int64_t)n * C + c) * 2], s1);
-            s2 = fmaf(gm, AB[((int64_t)n * C + c) * 2 + 1], s2);
+            const float2 ab = ab_sum(AB, nchunks, cstride, (int64_t)n * C + c);
+            s1 = fmaf(gm, ab.x, s1);
+            s2 = fmaf(gm, ab.y, s2);
         }
         S[(int64_t)i * 2] = s1;
         S[(int64_t)i * 2 + 1] = s2;
@@ -311,7 +402,8 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __res
     float a = 0.f, b = 0.f;
     if (c < C)
         for (int n = seg; n < N; n += 8) {
-            const float an = AB[((int64_t)n * C + c) * 2], bn = AB[((int64_t)n * C + c) * 2 + 1], m = mod.mul(n, c);
+            const float2 ab = ab_sum(AB, nchunks, cstride, (int64_t)n * C + c);
+            const float an = ab.x, bn = ab.y, m = mod.mul(n, c);
             a = fmaf(an, m, a);
             b = fmaf(bn, m, b);
             mod.emit(n, c, an, bn, gamma[c]);
@@ -363,21 +455,45 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
         k1[j] = S[((int64_t)n * groups + g) * 2] * inv;
         k2[j] = S[((int64_t)n * groups + g) * 2 + 1] * inv;
     }
-    for (int p = prow; p < chunk_px; p += ppw) {
-        float d[EPV], xv[EPV], o[EPV];
-        load_vec<T>(dv + (p0 + p) * C + c0, d);
-        load_vec<T>(xs + (p0 + p) * Cs + cs0, xv);
-        if (acc) load_vec<T>(dst + (p0 + p) * Cs + cs0, o);
-#pragma unroll
-        for (int j = 0; j < EPV; ++j) {
-            float du = d[j] * dm[j];
-            if (pro_silu) du *= silu_grad_f<T>(fmaf(xv[j], sc[j], sh[j]));
-            const float xhat = (xv[j] - mu[j]) * rs[j];
-            const float dx = rs[j] * (du * gm[j] - (k1[j] + xhat * k2[j]));
-            o[j] = acc ? o[j] + dx : dx;
-        }
-        store_vec<T>(dst + (p0 + p) * Cs + cs0, o);
+#define APPLY_ONE(RD, RX, RO, PP)                                                         \
+    {                                                                                     \
+        float d[EPV], xv[EPV], o[EPV];                                                    \
+        unpack_vec<T>(RD, d);                                                             \
+        unpack_vec<T>(RX, xv);                                                            \
+        unpack_vec<T>(RO, o);                                                             \
+        _Pragma("unroll") for (int j = 0; j < EPV; ++j) {                                 \
+            float du = d[j] * dm[j];                                                      \
+            if (pro_silu) du *= silu_grad_f<T>(fmaf(xv[j], sc[j], sh[j]));                \
+            const float xhat = (xv[j] - mu[j]) * rs[j];                                   \
+            const float dx = rs[j] * (du * gm[j] - (k1[j] + xhat * k2[j]));               \
+            o[j] = acc ? o[j] + dx : dx;                                                  \
+        }                                                                                 \
+        store_vec<T>(dst + (p0 + (PP)) * Cs + cs0, o);                                    \
     }
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    int p = prow;
+    for (; p + 3 * ppw < chunk_px; p += 4 * ppw) {
+        const T* qd = dv + (p0 + p) * C + c0;
+        const T* qx = xs + (p0 + p) * Cs + cs0;
+        const T* qo = dst + (p0 + p) * Cs + cs0;
+        const int64_t sd = (int64_t)ppw * C, sx = (int64_t)ppw * Cs;
+        const uint4 d0 = load_raw<T>(qd), d1 = load_raw<T>(qd + sd), d2 = load_raw<T>(qd + 2 * sd), d3 = load_raw<T>(qd + 3 * sd);
+        const uint4 x0 = load_raw<T>(qx), x1 = load_raw<T>(qx + sx), x2 = load_raw<T>(qx + 2 * sx), x3 = load_raw<T>(qx + 3 * sx);
+        uint4 o0 = zero4, o1 = zero4, o2 = zero4, o3 = zero4;
+        if (acc) {
+            o0 = load_raw<T>(qo);
+            o1 = load_raw<T>(qo + sx);
+            o2 = load_raw<T>(qo + 2 * sx);
+            o3 = load_raw<T>(qo + 3 * sx);
+        }
+        APPLY_ONE(d0, x0, o0, p) APPLY_ONE(d1, x1, o1, p + ppw) APPLY_ONE(d2, x2, o2, p + 2 * ppw) APPLY_ONE(d3, x3, o3, p + 3 * ppw)
+    }
+    for (; p < chunk_px; p += ppw) {
+        const uint4 d0 = load_raw<T>(dv + (p0 + p) * C + c0), x0 = load_raw<T>(xs + (p0 + p) * Cs + cs0);
+        const uint4 o0 = acc ? load_raw<T>(dst + (p0 + p) * Cs + cs0) : zero4;
+        APPLY_ONE(d0, x0, o0, p)
+    }
+#undef APPLY_ONE
 }
 
 // dst1[.., :C1] (+)= src[.., :C1], dst2[.., :C2] (+)= src[.., C1:]  with 16-byte accesses
@@ -454,19 +570,34 @@ __global__ void __launch_bounds__(256) gn_bwd_small_kernel(const T* __restrict__
     float a[EPV], bq[EPV];
 #pragma unroll
     for (int j = 0; j < EPV; ++j) a[j] = bq[j] = 0.f;
-    if (active)
-        for (int p = prow; p < HW; p += ppw) {
-            float d[EPV], xv[EPV];
-            load_vec<T>(dv + (p0 + p) * C + c0, d);
-            load_vec<T>(xs + (p0 + p) * Cs + cs0, xv);
-#pragma unroll
-            for (int j = 0; j < EPV; ++j) {
-                float du = d[j] * dm[j];
-                if (pro_silu) du *= silu_grad_f<T>(fmaf(xv[j], sc[j], sh[j]));
-                a[j] += du;
-                bq[j] = fmaf(du, (xv[j] - mu[j]) * rs[j], bq[j]);
-            }
+#define SMALL_SUMS_ONE(RD, RX)                                                            \
+    {                                                                                     \
+        float d[EPV], xv[EPV];                                                            \
+        unpack_vec<T>(RD, d);                                                             \
+        unpack_vec<T>(RX, xv);                                                            \
+        _Pragma("unroll") for (int j = 0; j < EPV; ++j) {                                 \
+            float du = d[j] * dm[j];                                                      \
+            if (pro_silu) du *= silu_grad_f<T>(fmaf(xv[j], sc[j], sh[j]));                \
+            a[j] += du;                                                                   \
+            bq[j] = fmaf(du, (xv[j] - mu[j]) * rs[j], bq[j]);                             \
+        }                                                                                 \
+    }
+    if (active) {
+        int p = prow;
+        for (; p + 3 * ppw < HW; p += 4 * ppw) {
+            const T* qd = dv + (p0 + p) * C + c0;
+            const T* qx = xs + (p0 + p) * Cs + cs0;
+            const int64_t sd = (int64_t)ppw * C, sx = (int64_t)ppw * Cs;
+            const uint4 d0 = load_raw<T>(qd), d1 = load_raw<T>(qd + sd), d2 = load_raw<T>(qd + 2 * sd), d3 = load_raw<T>(qd + 3 * sd);
+            const uint4 x0 = load_raw<T>(qx), x1 = load_raw<T>(qx + sx), x2 = load_raw<T>(qx + 2 * sx), x3 = load_raw<T>(qx + 3 * sx);
+            SMALL_SUMS_ONE(d0, x0) SMALL_SUMS_ONE(d1, x1) SMALL_SUMS_ONE(d2, x2) SMALL_SUMS_ONE(d3, x3)
         }
+        for (; p < HW; p += ppw) {
+            const uint4 d0 = load_raw<T>(dv + (p0 + p) * C + c0), x0 = load_raw<T>(xs + (p0 + p) * Cs + cs0);
+            SMALL_SUMS_ONE(d0, x0)
+        }
+    }
+#undef SMALL_SUMS_ONE
     if (active)
 #pragma unroll
         for (int j = 0; j < EPV; ++j) {
@@ -507,26 +638,59 @@ __global__ void __launch_bounds__(256) gn_bwd_small_kernel(const T* __restrict__
         k1[j] = gS1[g] * inv;
         k2[j] = gS2[g] * inv;
     }
-    for (int p = prow; p < HW; p += ppw) {
-        float d[EPV], xv[EPV], o[EPV];
-        load_vec<T>(dv + (p0 + p) * C + c0, d);
-        load_vec<T>(xs + (p0 + p) * Cs + cs0, xv);
-        if (acc) load_vec<T>(dst + (p0 + p) * Cs + cs0, o);
-#pragma unroll
-        for (int j = 0; j < EPV; ++j) {
-            float du = d[j] * dm[j];
-            if (pro_silu) du *= silu_grad_f<T>(fmaf(xv[j], sc[j], sh[j]));
-            const float xhat = (xv[j] - mu[j]) * rs[j];
-            const float dx = rs[j] * (du * gm[j] - (k1[j] + xhat * k2[j]));
-            o[j] = acc ? o[j] + dx : dx;
-        }
-        store_vec<T>(dst + (p0 + p) * Cs + cs0, o);
+#define SMALL_APPLY_ONE(RD, RX, RO, PP)                                                   \
+    {                                                                                     \
+        float d[EPV], xv[EPV], o[EPV];                                                    \
+        unpack_vec<T>(RD, d);                                                             \
+        unpack_vec<T>(RX, xv);                                                            \
+        unpack_vec<T>(RO, o);                                                             \
+        _Pragma("unroll") for (int j = 0; j < EPV; ++j) {                                 \
+            float du = d[j] * dm[j];                                                      \
+            if (pro_silu) du *= silu_grad_f<T>(fmaf(xv[j], sc[j], sh[j]));                \
+            const float xhat = (xv[j] - mu[j]) * rs[j];                                   \
+            const float dx = rs[j] * (du * gm[j] - (k1[j] + xhat * k2[j]));               \
+            o[j] = acc ? o[j] + dx : dx;                                                  \
+        }                                                                                 \
+        store_vec<T>(dst + (p0 + (PP)) * Cs + cs0, o);                                    \
     }
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    int p = prow;
+    for (; p + 3 * ppw < HW; p += 4 * ppw) {
+        const T* qd = dv + (p0 + p) * C + c0;
+        const T* qx = xs + (p0 + p) * Cs + cs0;
+        const T* qo = dst + (p0 + p) * Cs + cs0;
+        const int64_t sd = (int64_t)ppw * C, sx = (int64_t)ppw * Cs;
+        const uint4 d0 = load_raw<T>(qd), d1 = load_raw<T>(qd + sd), d2 = load_raw<T>(qd + 2 * sd), d3 = load_raw<T>(qd + 3 * sd);
+        const uint4 x0 = load_raw<T>(qx), x1 = load_raw<T>(qx + sx), x2 = load_raw<T>(qx + 2 * sx), x3 = load_raw<T>(qx + 3 * sx);
+        uint4 o0 = zero4, o1 = zero4, o2 = zero4, o3 = zero4;
+        if (acc) {
+            o0 = load_raw<T>(qo);
+            o1 = load_raw<T>(qo + sx);
+            o2 = load_raw<T>(qo + 2 * sx);
+            o3 = load_raw<T>(qo + 3 * sx);
+        }
+        SMALL_APPLY_ONE(d0, x0, o0, p) SMALL_APPLY_ONE(d1, x1, o1, p + ppw) SMALL_APPLY_ONE(d2, x2, o2, p + 2 * ppw)
+        SMALL_APPLY_ONE(d3, x3, o3, p + 3 * ppw)
+    }
+    for (; p < HW; p += ppw) {
+        const uint4 d0 = load_raw<T>(dv + (p0 + p) * C + c0), x0 = load_raw<T>(xs + (p0 + p) * Cs + cs0);
+        const uint4 o0 = acc ? load_raw<T>(dst + (p0 + p) * Cs + cs0) : zero4;
+        SMALL_APPLY_ONE(d0, x0, o0, p)
+    }
+#undef SMALL_APPLY_ONE
 }
 
 static bool gn_bwd_small_supported(int dtype, int HW, int C1, int C2, int groups) {
     const int EPV = dtype == DMME_BF16 ? 8 : 4, C = C1 + C2;
     return HW <= 64 && C <= 512 && groups <= 64 && C % groups == 0 && C1 % EPV == 0 && C2 % EPV == 0 && C / EPV <= 256 && !getenv("DMME_NO_GN_SMALL");
+}
+
+// pixel chunks of the two-pass GroupNorm backward = partial rows of its channel-sum scratch ([chunks][N][C][2] floats); 1 when the
+// one-workgroup-per-image kernel or the generic path serves the shape
+int gn_bwd_fast_chunks(int dtype, int HW, int C) {
+    int cp, nc, pw;
+    if (!vec_geometry(dtype, HW, C, cp, nc, pw)) return 1;
+    return nc;
 }
 
 bool gn_bwd_fast_supported(int dtype, int HW, int C1, int C2) {
@@ -535,7 +699,7 @@ bool gn_bwd_fast_supported(int dtype, int HW, int C1, int C2) {
     return (C1 % EPV) == 0 && vec_geometry(dtype, HW, C1 + C2, a, b, c);
 }
 
-// AB: N*C*2 floats, zero on entry;  S: N*groups*2 floats of scratch
+// AB: gn_bwd_fast_chunks * N*C*2 floats (every entry is written: no zeroing needed);  S: N*groups*2 floats of scratch
 int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2, int N, int HW, int C1, int C2, int groups,
                        const float* gamma, const float* mean_rstd, const float* scale, const float* shift, const float* dmask,
                        int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, float* AB, float* S, GnMod mod,
@@ -562,7 +726,7 @@ int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2
                            groups, mean_rstd, scale, shift, dmask, pro_silu, chunk_px, ppw, AB);
     DMME_CHECK_LAUNCH();
     const int nb_s = (N * groups + 255) / 256;
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(nb_s + (C + 31) / 32), dim3(256), 0, s, AB, N, C, groups, nb_s, gamma, S, dgamma, dbeta, mod);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(nb_s + (C + 31) / 32), dim3(256), 0, s, AB, nchunks, N, C, groups, nb_s, gamma, S, dgamma, dbeta, mod);
     DMME_CHECK_LAUNCH();
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dv, (const bf16*)x1, (const bf16*)x2, HW, C1, C2, groups,

@@ -320,6 +320,7 @@ int launch_colsum_group(int dtype, const ColJob* jobs_dev, int njobs, void* bws,
 int launch_colsum_fast(int dtype, const void* dY, int N, int HW, int C, float* rowsum, float* dbias, float* dtproj, int ld, int nt,
                        hipStream_t s);
 bool gn_bwd_fast_supported(int dtype, int HW, int C1, int C2);
+int gn_bwd_fast_chunks(int dtype, int HW, int C);
 int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2, int N, int HW, int C1, int C2, int groups,
                        const float* gamma, const float* mean_rstd, const float* scale, const float* shift, const float* dmask,
                        int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, float* AB_zeroed,

@@ -582,13 +582,15 @@ int build_plan(dmme_plan* P) {
             for (Op& o : P->ops) {
                 if (o.kind != OP_CONV) continue;
                 o.b_rowsum = balloc((int64_t)B * P->params[o.w].cout * 4);
-                if (o.gn >= 0) {
-                    const Op& gop = P->ops[o.gn];
-                    const int C = P->tensors[gop.gn_src1].C + (gop.gn_src2 >= 0 ? P->tensors[gop.gn_src2].C : 0);
-                    o.b_ab = balloc((int64_t)B * C * 2 * 4);
-                }
             }
             P->bws_zero_bytes = bw - P->bws_zero;
+            for (Op& o : P->ops) {  // GroupNorm channel sums, one partial row per pixel chunk (written whole: outside the cleared region)
+                if (o.kind != OP_CONV || o.gn < 0) continue;
+                const Op& gop = P->ops[o.gn];
+                const Tensor& t1 = P->tensors[gop.gn_src1];
+                const int C = t1.C + (gop.gn_src2 >= 0 ? P->tensors[gop.gn_src2].C : 0);
+                o.b_ab = balloc((int64_t)gn_bwd_fast_chunks(P->dtype, t1.H * t1.W, C) * B * C * 2 * 4);
+            }
             P->bws_gnS = balloc((int64_t)B * c.num_groups * 2 * 4);
         }
         P->bws_tmp = balloc(tmp_max);

@@ -177,6 +177,9 @@ int launch_attn_heads(int dtype, const void* qkv, int N, int S, int C, int heads
 int launch_attn_heads_bwd(int dtype, const void* qkv, const void* dO, int N, int S, int C, int heads, float* P, float* dS, void* dqkv, hipStream_t s);
 // scale-shift conditioning folded into a GroupNorm's per-(n, c) scale / shift: sc *= 1 + t_scale, sh = sh * (1 + t_scale) + t_shift
 int launch_gn_modulate(float* scale, float* shift, const float* t_shift, const float* t_scale, int ld, int nt, int N, int C, hipStream_t s);
+// accurate mode (fp32 tensors, three-pass bf16 MFMA products): fused attention, head widths 64 / 128 / 256
+bool attn_x3_supported(int N, int S, int C, int heads);
+int launch_attn_x3(const void* qkv, int N, int S, int C, int heads, void* out, hipStream_t s);
 bool attn_mfma_supported(int dtype, int N, int S, int C);
 // lse (nullable): [N][S] log2-domain log-sum-exp of the scaled scores, kept for the backward pass
 int launch_attn_mfma(int dtype, const void* qkv, int N, int S, int C, void* out, float* lse, hipStream_t s);

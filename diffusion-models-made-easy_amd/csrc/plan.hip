@@ -926,6 +926,8 @@ int run_op(const dmme_plan* P, const Op& o, const char* pk, const float* x, cons
         case OP_ATTN: {
             const Tensor& q = P->tensors[o.at_qkv];
             const int S = q.H * q.W, C = q.C / 3;
+            if (P->x3 && attn_x3_supported(P->B, S, C, o.at_heads))  // (no log-sum-exp kept: the fp32 backward recomputes the scores)
+                return launch_attn_x3(ws + q.off, P->B, S, C, o.at_heads, ws + P->tensors[o.at_out].off, s);
             if (o.at_heads > 1) {
                 if (attn_heads_mfma_supported(P->dtype, P->B, S, C, o.at_heads))
                     return launch_attn_heads_mfma(P->dtype, ws + q.off, P->B, S, C, o.at_heads, ws + P->tensors[o.at_out].off, (float*)(ws + o.at_lse), s);
@@ -987,7 +989,9 @@ void op_account(const dmme_plan* P, const Op& o, char* label, int cap, double* f
         case OP_ATTN: {
             const Tensor& q = P->tensors[o.at_qkv];
             const double S = q.H * q.W, C = q.C / 3;
-            if (o.at_heads > 1)
+            if (P->x3 && attn_x3_supported(P->B, (int)S, (int)C, o.at_heads))
+                snprintf(label, cap, "attn_x3_kernel");
+            else if (o.at_heads > 1)
                 snprintf(label, cap, attn_heads_mfma_supported(P->dtype, P->B, (int)S, (int)C, o.at_heads) ? "attn_mfma_kernel<%s,heads>" : "attn_generic_kernel<%s,heads>", tn);
             else
                 snprintf(label, cap, attn_mfma_supported(P->dtype, P->B, (int)S, (int)C) ? "attn_mfma_kernel<%s>" : "attn_generic_kernel<%s>", tn);
@@ -1755,12 +1759,20 @@ DMME_API int dmme_groupnorm_scale_shift(int dtype, const void* src1, const void*
 
 DMME_API int dmme_attention(int dtype, const void* qkv, int N, int S, int C, void* out, int force_generic, void* stream) {
     DMME_REQUIRE(qkv && out && N > 0 && S > 0 && C > 0, DMME_ERR_INVALID, "attention: bad argument");
+    if (dtype == DMME_BF16X3) {  // fp32 buffers; the three-pass MFMA kernel where it applies
+        if (!force_generic && attn_x3_supported(N, S, C, 1)) return launch_attn_x3(qkv, N, S, C, 1, out, (hipStream_t)stream);
+        dtype = DMME_F32;
+    }
     if (!force_generic && attn_mfma_supported(dtype, N, S, C)) return launch_attn_mfma(dtype, qkv, N, S, C, out, nullptr, (hipStream_t)stream);
     return launch_attn_generic(dtype, qkv, N, S, C, out, (hipStream_t)stream);
 }
 
 DMME_API int dmme_attention_heads(int dtype, const void* qkv, int N, int S, int C, int heads, void* out, int force_generic, void* stream) {
     DMME_REQUIRE(qkv && out && N > 0 && S > 0 && C > 0 && heads > 0 && C % heads == 0, DMME_ERR_INVALID, "attention_heads: bad argument");
+    if (dtype == DMME_BF16X3) {
+        if (!force_generic && attn_x3_supported(N, S, C, heads)) return launch_attn_x3(qkv, N, S, C, heads, out, (hipStream_t)stream);
+        dtype = DMME_F32;
+    }
     if (!force_generic && attn_heads_mfma_supported(dtype, N, S, C, heads))
         return launch_attn_heads_mfma(dtype, qkv, N, S, C, heads, out, nullptr, (hipStream_t)stream);
     return launch_attn_heads(dtype, qkv, N, S, C, heads, out, (hipStream_t)stream);

@@ -12,8 +12,19 @@ from oracle import synth
 pytestmark = pytest.mark.gpu
 
 FP32_ATOL = 1e-5
-BF16_REL_RMS = 1.5e-2  # same bounds as the DDPM network (tests/test_gpu_unet.py)
-BF16_MAX_ABS = 6e-2
+# single-pass bf16 against the fp32 oracle: (rel-RMS, max-abs / |want|max) per geometry at 1.25 x the measured values (the error
+# budget is the DDPM network's, tests/test_gpu_unet.py / DESIGN.md section 2; the accurate mode is precision="bf16x3")
+BF16_BOUNDS = {"iddpm_default_32": (9.7e-3, 1.08e-2),  # measured 7.72e-3, 8.64e-3
+               "iddpm_imagenet64": (8.4e-3, 8.9e-3)}   # measured 6.65e-3, 7.06e-3
+
+
+def _assert_bf16_close(got, want, tag):
+    err = (got - want).abs()
+    rel_rms = float(err.pow(2).mean().sqrt() / want.pow(2).mean().sqrt())
+    max_rel = float(err.max() / want.abs().max())
+    print(f"bf16 [{tag}]: rel-RMS {rel_rms:.3e}, max-abs / |want|max {max_rel:.3e} (|want|max {float(want.abs().max()):.3f})")
+    lim = BF16_BOUNDS[tag]
+    assert rel_rms <= lim[0] and max_rel <= lim[1], (tag, rel_rms, max_rel, lim)
 
 
 def _build(cfg, seed, precision, train=False):
@@ -95,9 +106,7 @@ def test_unet_full_bf16_vs_oracle():
     want = OI.unet_forward(sd, cfg, x, t)
     with torch.no_grad():
         got = net(x.cuda(), t.cuda()).cpu()
-    err = (got - want).abs()
-    rel_rms = float(err.pow(2).mean().sqrt() / want.pow(2).mean().sqrt())
-    assert rel_rms < BF16_REL_RMS and float(err.max()) < BF16_MAX_ABS * max(1.0, float(want.abs().max())), (rel_rms, float(err.max()))
+    _assert_bf16_close(got, want, "iddpm_default_32")
 
 
 def test_unet_64x64_config4_bf16_vs_oracle():
@@ -110,9 +119,7 @@ def test_unet_64x64_config4_bf16_vs_oracle():
     want = OI.unet_forward(sd, cfg, x, t)
     with torch.no_grad():
         got = net(x.cuda(), t.cuda()).cpu()
-    err = (got - want).abs()
-    rel_rms = float(err.pow(2).mean().sqrt() / want.pow(2).mean().sqrt())
-    assert rel_rms < BF16_REL_RMS and float(err.max()) < BF16_MAX_ABS * max(1.0, float(want.abs().max())), (rel_rms, float(err.max()))
+    _assert_bf16_close(got, want, "iddpm_imagenet64")
 
 
 def test_unet_64x64_config4_fp32_vs_oracle():

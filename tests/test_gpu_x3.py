@@ -107,3 +107,23 @@ def test_bf16x3_training_step_gradients_vs_fp32():
     assert abs(outs["fp32"][0] - outs["bf16x3"][0]) <= 1e-4 * abs(outs["fp32"][0])
     g32, g3 = outs["fp32"][1], outs["bf16x3"][1]
     assert float((g32 - g3).norm() / g32.norm()) <= 1e-3
+
+
+@pytest.mark.parametrize("N,S,C,heads", [(3, 256, 256, 1), (2, 256, 128, 1), (3, 256, 256, 4), (5, 64, 256, 4), (2, 128, 64, 1)])
+def test_attention_bf16x3_vs_fp64(N, S, C, heads):
+    """the three-pass MFMA attention kernel (fp32 in / out) against an fp64 softmax(q k^T C^-0.5) v of the same fp32 operands, single- and
+    multi-head (the IDDPM head view with the reference's batch-mixing merge): within 2e-5 of the output's max"""
+    from dmme_amd import _lib
+
+    qkv = synth.normal(S + C + heads, (N, S, 3 * C)) * 1.5
+    d = C // heads
+    x = qkv.double().reshape(N, S, heads, 3 * d).permute(0, 2, 1, 3).reshape(N * heads, S, 3 * d)
+    q, k, v = x[..., :d], x[..., d : 2 * d], x[..., 2 * d :]
+    w = torch.softmax(torch.bmm(q, k.transpose(1, 2) * C**-0.5), dim=2)
+    want = torch.bmm(w, v).reshape(heads, N, S, d).permute(1, 2, 0, 3).reshape(N, S, C)  # rows b*heads + h re-read as (head', b')
+    qd = qkv.cuda().contiguous()
+    out = torch.empty((N, S, C), dtype=torch.float32, device="cuda")
+    _lib.check(_lib.lib().dmme_attention_heads(_lib.BF16X3, _lib.ptr(qd), N, S, C, heads, _lib.ptr(out), 0, _lib.stream_ptr()))
+    err = float((out.double().cpu() - want).abs().max() / want.abs().max())
+    print(f"attention bf16x3 N={N} S={S} C={C} heads={heads}: rel err {err:.2e}")
+    assert err <= 2e-5

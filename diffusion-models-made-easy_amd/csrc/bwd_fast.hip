@@ -74,10 +74,10 @@ static bool vec_geometry(int dtype, int HW, int C, int& chunk_px, int& nchunks, 
     if (VPP > 256) return false;
     int ppw = 256 / VPP;  // threads beyond ppw*VPP idle when VPP does not divide 256 (e.g. 768 channels)
     while (ppw > 1 && HW % ppw) --ppw;
-    // four pixel rows per thread = ONE batch of loads (below), and four times the workgroups a 16-row chunk gave: with 2 workgroups per
-    // CU and four dependent batches per thread these kernels were a chain of exposed round trips (gn_bwd_sums: 2.9 TB/s)
+    // 16 pixel rows per thread (four batches of four loads in flight).  Measured (training step, batch 128): 16 rows 11.96 ms, 8 rows
+    // 12.27, 4 rows 13.3 (4x the workgroups, but 4x the per-chunk partial rows for the finalize kernels to sum), 32 rows 11.99, 64 rows 12.22
     int sweeps = HW / ppw;
-    static const int max_sweeps = getenv("DMME_BWD_SWEEPS") ? atoi(getenv("DMME_BWD_SWEEPS")) : 4;
+    static const int max_sweeps = getenv("DMME_BWD_SWEEPS") ? atoi(getenv("DMME_BWD_SWEEPS")) : 16;
     if (sweeps > max_sweeps) sweeps = max_sweeps;
     while (sweeps > 1 && (HW / ppw) % sweeps) --sweeps;
     chunk_px = sweeps * ppw;

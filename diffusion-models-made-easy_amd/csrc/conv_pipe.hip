@@ -282,19 +282,10 @@ static int pipe_ksplit(const ConvArgs& a, const ConvTile& g, int pick, int KC) {
     return ks < 1 ? 1 : ks;
 }
 
-// Experiment kept compiled out (build with -DWS_ASM_LOADS=1 -DWS_DMA_AHEAD2=1): the filter DMA issued TWO stages ahead.  It needs the halo
-// loads as inline asm, because hipcc waits vmcnt(0) at the first use of an ordinary load's result while an LDS-DMA is pending, which
-// would put the wait for the look-ahead DMA at the start of every stage.  Measured (tools/stamp_ws.py): the consumer's wait on a plain
-// layer drops from ~450 to ~150 cycles per stage (stage 1.8 k -> 1.6 k); with the GroupNorm/SiLU prologue the producers' own stage work
-// is the limit and nothing changes; over the network's 18 forward launches 65.4 -> 64.1 us (-2 %), step time within noise.  All GPU tests
-// pass bit-exactly with it, but asm loads bypass the compiler's hazard tracking (a register copy ahead of the counted wait would read a
-// stale value), so it is not the default for a 2 % gain on one kernel.
-#ifndef WS_ASM_LOADS
-#define WS_ASM_LOADS 0
-#endif
-#ifndef WS_DMA_AHEAD2
-#define WS_DMA_AHEAD2 0
-#endif
+// (Measured and removed: the filter DMA issued TWO stages ahead, which needs the halo loads as inline asm because hipcc waits
+// vmcnt(0) at the first use of an ordinary load's result while an LDS-DMA is pending.  Consumer wait on a plain layer 450 -> 150
+// cycles per stage, nothing with the GroupNorm/SiLU prologue, 65.4 -> 64.1 us over the network's launches: asm loads bypass the
+// compiler's hazard tracking - too sharp a tool for 2 % of one kernel.  DESIGN.md section 4 keeps the numbers.)
 struct WsTile { int n0, oy0, ox0, co0, ts; };
 __device__ __forceinline__ WsTile ws_tile_of(const ConvTile& g, int shTW, int shTH, int kt, int bn) {
     const int t = (int)blockIdx.x + kt * (int)gridDim.x;
@@ -438,13 +429,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             const int Cs = second ? a.C2 : a.C1;
             const int px = a_pix[i] < 0 ? 0 : a_pix[i];
             const char* gp = sbase + (size_t)((unsigned)(px * Cs + cu * EPV) * 2u);
-#if WS_ASM_LOADS && defined(__HIP_DEVICE_COMPILE__)
-            // issued behind the compiler's back: it never inserts a wait for these registers.  Every end-of-stage counted wait retires
-            // all but the youngest operations, and a unit is consumed nine stages after it was loaded, so it has always landed.
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(areg[i]) : "v"(gp) : "memory");
-#else
             areg[i] = *reinterpret_cast<const u32x4*>(gp);
-#endif
         };
         auto store_A = [&](int i, char* dstA) __attribute__((always_inline)) {
             u32x4 val = areg[i];
@@ -485,13 +470,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
                 load_A(i, 0);
             }
             dma_tap(WS_RING(0), tcur.co0, 0, 0);
-#if WS_DMA_AHEAD2
-            dma_tap(WS_RING(1), tcur.co0, 0, 1);
-#endif
             load_par(WS_PAR(0), 0);
-#if WS_ASM_LOADS && defined(__HIP_DEVICE_COMPILE__)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
 #pragma unroll
             for (int i = 0; i < PIPE_UA; ++i) store_A(i, WS_BUFA(0));
 #pragma unroll
@@ -505,11 +484,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         if (new_tile) set_pix((i), tnn);      \
         load_A((i), lc * KC);                 \
     }
-#if WS_ASM_LOADS
-#define WS_A_ARRIVED(i) {}
-#else
 #define WS_A_ARRIVED(i) { asm volatile("" : "+v"(areg[i][0]), "+v"(areg[i][1]), "+v"(areg[i][2]), "+v"(areg[i][3])); }
-#endif
         // stage TP = tap TP of chunk (kt, cc): DMA of the next stage's tap, 1-2 halo units of the next chunk, barrier
 #define WS_PSTAGE(TP)                                                                                                   \
     {                                                                                                                   \
@@ -526,16 +501,8 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         else if ((TP) == 8) { WS_A_ARRIVED(9) WS_A_ARRIVED(10) }                                                        \
         else { WS_A_ARRIVED((TP) + 1) }                                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
-        bool dma_issued = true;                                                                                         \
-        if (WS_DMA_AHEAD2) { /* the tap TWO stages on: its slot (TP + 2) % 3 was last read in stage TP - 1 */              \
-            if ((TP) < 7) dma_tap(WS_RING(((TP) + 2) % 3), tcur.co0, cc, (TP) + 2);                                     \
-            else if ((TP) == 7) dma_tap(WS_RING(0), nk == kt ? tcur.co0 : tnext.co0, nc, 0);                            \
-            else if (!last_c) dma_tap(WS_RING(1), tcur.co0, nc, 1);                                                     \
-            else dma_issued = false; /* tile ends: R1 is about to stage the epilogue; tap 1 of the next tile goes out after it */ \
-        } else {                                                                                                        \
-            if ((TP) < 8) dma_tap(WS_RING(((TP) + 1) % 3), tcur.co0, cc, (TP) + 1);                                     \
-            else dma_tap(WS_RING(0), nk == kt ? tcur.co0 : tnext.co0, nc, 0);                                           \
-        }                                                                                                               \
+        if ((TP) < 8) dma_tap(WS_RING(((TP) + 1) % 3), tcur.co0, cc, (TP) + 1);                                         \
+        else dma_tap(WS_RING(0), nk == kt ? tcur.co0 : tnext.co0, nc, 0);                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
         {                                                                                                               \
             const bool do_store = have_n;                                                                               \
@@ -547,10 +514,6 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             else { WS_A_UNIT((TP) + 1) }                                                                                \
         }                                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
-        if (WS_DMA_AHEAD2) { /* retire the DMA issued a stage ago; this stage's DMA (4) and halo loads stay in flight */   \
-            if (dma_issued) wait_vm_keep<(((TP) == 0 || (TP) == 8) ? 2 : 1) + UB>();                                    \
-            else wait_vm_keep<2>();                                                                                     \
-        } else                                                                                                          \
         wait_vm_keep<((TP) == 0 || (TP) == 8) ? 2 : 1>(); /* retire the DMA, leave this stage's halo loads in flight */ \
         __builtin_amdgcn_s_barrier();                                                                                   \
         if ((TP) == 8) {                                                                                                \
@@ -561,7 +524,6 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
                 ++kt;                                                                                                   \
                 tcur = tnext;                                                                                           \
                 tnext = WS_TILE(kt + 1 < K ? kt + 1 : kt);                                                              \
-                if (WS_DMA_AHEAD2 && kt < K) dma_tap(WS_RING(1), tcur.co0, 0, 1);                                       \
             }                                                                                                           \
         }                                                                                                               \
     }

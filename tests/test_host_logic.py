@@ -325,3 +325,66 @@ def test_weights_key_follows_writes_through_rebound_parameters():
     assert net._weights_key(net._ensure_flat()) != k2
     net.mark_params_updated()
     assert net._weights_key(net._ensure_flat())[-1] == 1
+
+
+# ------------------------------------------------------------------------------------------ device-resident loop tables (dmme_chain_*)
+
+
+def test_chain_tables_hold_the_reference_update_scalars(golden):
+    """the per-index scalars a replayed step reads from device memory are the ones the eager loop passes as kernel arguments:
+    DDPM 1/sqrt(alpha_t), beta_t/sqrt(1-abar_t), sqrt(beta_t) (equations/ddpm/ddpm.py:65-71); DDIM sqrt(1-abar_tau_i),
+    sqrt(abar_tau_{i-1}) with t_table = tau (equations/ddim/ddim.py:52-57); IDDPM the log-variance pair (equations/iddpm/losses.py:34-37)"""
+    from oracle import diffusion as OD
+
+    T = 1000
+    d = dmme_amd.DDPM(torch.nn.Identity(), T)
+    n, rows, ttab = d._chain_tables()
+    beta = OD.linear_beta(T)
+    alpha, abar = OD.alpha_tables(beta)
+    assert n == T and ttab == list(range(T + 1)) and len(rows) == T + 1
+    for t in (1, 2, 500, 1000):
+        want = (float(1 / torch.sqrt(alpha[t])), float(beta[t] / torch.sqrt(1 - abar[t])), float(torch.sqrt(beta[t])))
+        assert rows[t][:3] == want, (t, rows[t], want)
+    assert all(v == v for r in rows for v in r)  # row 0 (never stepped from) holds no NaN either
+    dd = dmme_amd.DDIM(torch.nn.Identity(), T, 50)
+    n, rows, ttab = dd._chain_tables()
+    tau = OD.tau_table(T, 50)
+    assert n == 50 and ttab == [int(v) for v in tau]
+    for i in (1, 2, 25, 50):
+        want = (float(torch.sqrt(1 - abar[int(tau[i])])), float(torch.sqrt(abar[int(tau[i - 1])])))
+        assert rows[i][:2] == want, (i, rows[i], want)
+    idd = dmme_amd.IDDPM(torch.nn.Identity(), 100)
+    n, rows, ttab = idd._chain_tables()
+    assert n == 100 and ttab == list(range(101))
+    for t in (1, 50, 100):
+        assert list(rows[t]) == list(idd._coef_host[t][:4])
+
+
+def test_bench_defaults_and_rank_launcher_command(monkeypatch):
+    """`python bench.py` defaults finish within minutes; `--gpus N` without a torch.distributed environment builds the
+    torch.distributed.run command line the contract names (127.0.0.1, one rank per GPU) instead of exiting"""
+    import importlib
+    import sys as _sys
+
+    monkeypatch.setattr(_sys, "argv", ["bench.py"])
+    bench = importlib.import_module("bench")
+    a = bench.parse()
+    assert a.gpus == 1 and a.steps <= 100 and a.warmup <= 20 and a.batch == 128 and a.precision == "bf16" and a.mode == "sample"
+    seen = {}
+
+    class _P:
+        stdout = iter(['{"metric": "m", "value": 1}\n', "noise\n"])
+
+        def wait(self):
+            return 0
+
+    def fake_popen(cmd, **kw):
+        seen["cmd"] = cmd
+        return _P()
+
+    monkeypatch.setattr(bench.subprocess, "Popen", fake_popen)
+    monkeypatch.setattr(_sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7"])
+    assert bench.spawn_ranks(4) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "7"]

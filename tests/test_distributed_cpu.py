@@ -63,6 +63,73 @@ def _worker(rank, world, path):
             raise AssertionError("expected RuntimeError")
         except RuntimeError:
             red.handles.clear(); red.reported.clear()
+        # data-parallel start: every rank takes rank 0's parameters and EMA copy (DDP's broadcast at wrap time); replicas that began
+        # from different random weights end up identical, and the module is told its buffer changed under it
+        class FakeUNet:
+            def __init__(self, w):
+                self.w, self.epoch = w, 0
+
+            def flat_parameters(self):
+                return self.w
+
+            def mark_params_updated(self):
+                self.epoch += 1
+
+        class FakeOpt:
+            def __init__(self, e):
+                self.e = e
+
+            def ema_parameters(self, model):
+                return self.e
+
+        torch.manual_seed(100 + rank)
+        net, opt = FakeUNet(torch.randn(500)), FakeOpt(torch.randn(500))
+        assert D.sync_parameters(net, opt) is True and net.epoch == 1
+        gathered = [torch.empty(500) for _ in range(world)]
+        dist.all_gather(gathered, net.w)
+        assert all(torch.equal(g, gathered[0]) for g in gathered)
+        torch.manual_seed(100)
+        assert torch.equal(net.w, torch.randn(500)) and torch.equal(opt.e, torch.randn(500))  # rank 0's draws, in its order
+        # one train_step over the process group with the real loop (a stand-in module: no GPU here): gradients averaged, step taken
+        from dmme_amd.train_loop import train_step
+
+        class Lit:
+            class _DM:
+                pass
+
+            def __init__(self, model):
+                self.diffusion_model = Lit._DM()
+                self.diffusion_model.model = model
+
+            def training_step(self, batch, idx):
+                m = self.diffusion_model.model
+                loss = ((m.p * batch[0]).sum()) ** 2
+                return loss
+
+        class TinyModel(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.p = torch.nn.Parameter(torch.ones(4) * (1 + rank))  # differs per rank until synchronised
+                self._g = torch.zeros(4)
+
+            def flat_parameters(self):
+                return self.p.data
+
+            def flat_grad(self):
+                if self.p.grad is None:
+                    self.p.grad = self._g
+                return self.p.grad
+
+            def mark_params_updated(self):
+                pass
+
+        tm = TinyModel()
+        sgd = torch.optim.SGD(tm.parameters(), lr=0.1)
+        x0 = torch.arange(4.0) + rank
+        train_step(Lit(tm), sgd, None, x0)
+        ref = torch.ones(4, requires_grad=True)  # what a single process computes on the mean of the two per-rank losses
+        (sum(((ref * (torch.arange(4.0) + r)).sum()) ** 2 for r in range(world)) / world).backward()
+        assert torch.allclose(tm.p.data, torch.ones(4) - 0.1 * ref.grad, atol=1e-6), (tm.p.data, ref.grad)
     finally:
         dist.destroy_process_group()
 

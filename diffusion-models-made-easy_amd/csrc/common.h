@@ -134,6 +134,7 @@ struct ConvArgs {
 
 // ---- kernel launchers (defined in the .hip files) ------------------------------------
 int launch_conv_generic(int dtype, const ConvArgs& a, hipStream_t s);
+int launch_l2_stream(const void* buf, int64_t bytes, int iters, int mode, int depth, int blocks, unsigned* sink, hipStream_t s);
 const char* conv_generic_kernel_name(const ConvArgs& a);
 bool conv_in_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px);
 // returns DMME_ERR_UNSUPPORTED (without setting the error) when the shape is outside
@@ -168,7 +169,9 @@ bool gn_fast_supported(int dtype, int N, int HW, int C1, int C2, int groups);
 size_t gn_fast_scratch_floats(int N, int HW, int C, int groups);
 int launch_gn_fast(int dtype, const void* src1, const void* src2, int N, int HW, int C1, int C2, int groups,
                    const float* gamma, const float* beta, float eps, float* scale, float* shift, float* mean_rstd,
-                   float* partial, hipStream_t s);
+                   float* partial, hipStream_t s, void* act = nullptr, int act_silu = 0, const float* dmask = nullptr);
+// the one-workgroup-per-image GroupNorm (maps of at most 64 pixels) can also write the consumer's pre-activated input
+bool gn_small_act_supported(int dtype, int HW, int C1, int C2, int groups);
 
 int launch_attn_generic(int dtype, const void* qkv, int N, int S, int C, void* out, hipStream_t s);
 // multi-head attention as the reference ships it (models/iddpm.py:35-47): head h owns qkv channels [h*3d, (h+1)*3d) split

@@ -572,4 +572,62 @@ int launch_pack_table(int dtype, const PackItem* items_dev, int n_items, const f
     return DMME_OK;
 }
 
+// ------------------------------------------------------------------ diagnostic: what one CU can pull from L2
+// Every workgroup (one per CU) streams the same `bytes` of an L2-resident buffer `iters` times, DEPTH 16-byte loads in flight per
+// thread (mode 0: into registers; mode 1: global -> LDS DMA, no registers).  tools/l2_stream.py turns the elapsed time into bytes
+// per clock per CU - the number every tile-size decision in DESIGN.md section 4 leans on.
+template <int DEPTH>
+__global__ void __launch_bounds__(256) l2_stream_kernel(const uint4* __restrict__ buf, int nvec, int iters, unsigned* __restrict__ sink) {
+    unsigned acc = 0;
+    const int tid = threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+        for (int base = 0; base + DEPTH * 256 <= nvec; base += DEPTH * 256) {
+            uint4 v[DEPTH];
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) v[d] = buf[base + d * 256 + tid];
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) acc ^= v[d].x ^ v[d].y ^ v[d].z ^ v[d].w;
+        }
+    }
+    if (acc == 0x12345u) sink[blockIdx.x] = acc;  // keeps the loads alive
+}
+typedef __attribute__((address_space(3))) char l2s_lds_c;
+template <int DEPTH>
+__global__ void __launch_bounds__(256) l2_stream_dma_kernel(const uint4* __restrict__ buf, int nvec, int iters, unsigned* __restrict__ sink) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    (void)wave;
+    unsigned acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        for (int base = 0; base + DEPTH * 256 <= nvec; base += DEPTH * 256) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(size_t)(l2s_lds_c*)lds + (unsigned)((d * 4 + wave) * 1024)));
+                __builtin_amdgcn_global_load_lds(buf + base + d * 256 + tid, (l2s_lds_c*)(size_t)l, 16, 0, 0);
+#endif
+            }
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        }
+        acc ^= reinterpret_cast<unsigned*>(lds)[tid];
+    }
+    if (acc == 0x12345u) sink[blockIdx.x] = acc;
+}
+int launch_l2_stream(const void* buf, int64_t bytes, int iters, int mode, int depth, int blocks, unsigned* sink, hipStream_t s) {
+    const int nvec = (int)(bytes / 16);
+    DMME_REQUIRE(buf && sink && nvec >= 16 * 256 && iters > 0 && blocks > 0, DMME_ERR_INVALID, "l2_stream: bad argument");
+    const dim3 g((unsigned)blocks), b(256);
+#define L2S_CASE(D)                                                                                                             \
+    if (depth == D) {                                                                                                           \
+        if (mode == 0) hipLaunchKernelGGL(l2_stream_kernel<D>, g, b, 0, s, (const uint4*)buf, nvec, iters, sink);               \
+        else hipLaunchKernelGGL(l2_stream_dma_kernel<D>, g, b, D * 4096, s, (const uint4*)buf, nvec, iters, sink);              \
+    }
+    L2S_CASE(1) L2S_CASE(2) L2S_CASE(4) L2S_CASE(8) L2S_CASE(16)
+#undef L2S_CASE
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
 }  // namespace dmme

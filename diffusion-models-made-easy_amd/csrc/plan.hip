@@ -60,6 +60,10 @@ struct Op {
     // scale-shift conditioning (iddpm.ResBlock, models/iddpm.py:117-118): columns of tproj holding (shift | scale), -1: none.
     // The GroupNorm output becomes GN(h) * (scale + 1) + shift, folded into the per-(n, c) scale / shift the consumer applies.
     int gn_mod_col = -1, gn_mod_C = 0;
+    // small maps: this GroupNorm also writes its consumer's pre-activated input (gn_small_kernel); -1: the conv applies the affine itself
+    int64_t gn_act = -1;   // workspace offset of act [N][HW][C] in the compute dtype
+    int gn_force_small = 0;  // statistics from the one-workgroup-per-image kernel even where the producers left partials (it writes act)
+    int gn_consumer = -1;  // the conv op that reads it (its pro_silu / Dropout2d mask define the activation)
     // OP_CONV
     int src1 = -1, src2 = -1;  // tensor ids; -2: network input (NCHW fp32)
     int w = -1, b = -1;
@@ -70,6 +74,7 @@ struct Op {
     int res1 = -1, res2 = -1;
     int dst = -1;              // tensor id; -2: network output (NCHW fp32)
     int up = 0, stride = 1, taps = 9;
+    int use_act = 0;           // FORWARD reads the pre-activated tensor of its GroupNorm (backward still works from src1 / src2 + scale / shift)
     int wg_layer = -1;         // index into the grouped weight-gradient table of its kernel size (-1: per-layer kernels)
     int bias_deferred = 0;     // its bias / time-projection reduction runs in the grouped launch
     // OP_ATTN
@@ -689,8 +694,10 @@ int run_any_conv(int dtype, const ConvArgs& a, hipStream_t s) {
 }
 
 // fill the device-side descriptor of a conv op
+// fwd: the forward launch (a conv whose GroupNorm pre-activated its input reads that tensor and applies nothing); the backward
+// passes false and sees the raw sources with their scale / shift / mask, which is what it differentiates through
 void fill_conv(const dmme_plan* P, const Op& o, const char* packed, const float* x, float* y, char* ws,
-               const float* drop_masks, int nt, ConvArgs& a) {
+               const float* drop_masks, int nt, ConvArgs& a, bool fwd = false) {
     const int64_t es = (int64_t)dtype_size(P->dtype);
     (void)es;
     a.x3 = P->x3;
@@ -729,6 +736,14 @@ void fill_conv(const dmme_plan* P, const Op& o, const char* packed, const float*
     a.pro_silu = o.pro_silu;
     a.out_silu = o.out_silu;
     if (o.dmask_off >= 0 && drop_masks) a.dmask = drop_masks + o.dmask_off;
+    if (fwd && o.use_act) {
+        a.src1 = ws + P->ops[o.gn].gn_act;
+        a.C1 = a.C1 + a.C2;
+        a.src2 = nullptr;
+        a.C2 = 0;
+        a.scale = a.shift = a.dmask = nullptr;
+        a.pro_silu = 0;
+    }
     if (o.tproj_col >= 0) {
         a.tproj = (const float*)(ws + P->ws_tproj) + o.tproj_col;
         a.tproj_ld = P->tproj_cols;
@@ -829,6 +844,7 @@ void build_wgrad_group(dmme_plan* P, dmme_plan::WgGroup& G, int taps, int op_lo 
 
 // can this GroupNorm be finalised from the partials its producers emitted?
 bool gn_from_parts(const dmme_plan* P, const Op& o) {
+    if (o.gn_force_small) return false;
     const Tensor& t1 = P->tensors[o.gn_src1];
     if (t1.stats_off < 0) return false;
     const int G = P->cfg.num_groups;
@@ -870,8 +886,39 @@ void assign_stats(dmme_plan* P) {
     P->ws_bytes = ws;
 }
 
+// Small maps: the GroupNorms that run as one workgroup per image (maps of at most 64 pixels: their producers tile several images
+// together and cannot fuse the statistics) also write the consumer conv's pre-activated input, once per element.  Not for the
+// scale-shift blocks of the IDDPM UNet (their per-(n, c) affine is modulated after the norm kernel).
+void assign_preact(dmme_plan* P) {
+    int64_t ws = P->ws_bytes;
+    const int64_t es = (int64_t)dtype_size(P->dtype);
+    for (int ci = 0; ci < (int)P->ops.size(); ++ci) {
+        Op& cv = P->ops[ci];
+        if (cv.kind != OP_CONV || cv.gn < 0 || cv.src1 < 0 || cv.up || cv.stride != 1) continue;
+        Op& g = P->ops[cv.gn];
+        static const bool over_parts = getenv("DMME_PREACT_PARTS") && atoi(getenv("DMME_PREACT_PARTS")) != 0;
+        if (g.gn_mod_col >= 0 || g.gn_act >= 0) continue;
+        const Tensor& t1 = P->tensors[g.gn_src1];
+        const int C2 = g.gn_src2 >= 0 ? P->tensors[g.gn_src2].C : 0;
+        if (g.gn_src1 != cv.src1 || g.gn_src2 != cv.src2) continue;
+        if (!gn_small_act_supported(P->dtype, t1.H * t1.W, t1.C, C2, P->cfg.num_groups)) continue;
+        // 8x8 maps: one image per 64-pixel tile, so the producers did leave partials and the norm is a 5 us finalize launch.  Taking
+        // the whole-image kernel there instead (DMME_PREACT_PARTS=1) was measured neutral: the consumers drop 34.9 -> 29.1 us, the
+        // three-pass norm kernel costs 12 us instead of 5.5 (step 2.999 vs 3.016 ms) - off by default
+        if (gn_from_parts(P, g)) {
+            if (!over_parts) continue;
+            g.gn_force_small = 1;
+        }
+        g.gn_act = ws;
+        g.gn_consumer = ci;
+        cv.use_act = 1;
+        ws = align_up(ws + (int64_t)P->B * t1.H * t1.W * (t1.C + C2) * es, 256);
+    }
+    P->ws_bytes = ws;
+}
+
 // GroupNorm statistics folded with the affine into per-(n, c) scale / shift for the consuming conv's prologue
-int run_gn(const dmme_plan* P, const Op& o, const char* pk, char* ws, int nt, hipStream_t s) {
+int run_gn(const dmme_plan* P, const Op& o, const char* pk, char* ws, int nt, const float* drop_masks, hipStream_t s) {
     // scale-shift conditioning (iddpm.ResBlock): (shift | scale) columns of the batched time projection
     const float* tsh = o.gn_mod_col >= 0 ? (const float*)(ws + P->ws_tproj) + o.gn_mod_col : nullptr;
     const float* tsc = tsh ? tsh + o.gn_mod_C : nullptr;
@@ -891,9 +938,19 @@ int run_gn(const dmme_plan* P, const Op& o, const char* pk, char* ws, int nt, hi
                                         t2 ? t2->stats_cnt : 0, C2, P->B, P->cfg.num_groups, gam, bet, 1e-5f, sc, sh,
                                         (float*)(ws + o.gn_mr), tsh, tsc, P->tproj_cols, nt, s);
     }
-    if (gn_fast_supported(P->dtype, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups))
+    if (gn_fast_supported(P->dtype, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups)) {
+        void* act = nullptr;
+        int act_silu = 0;
+        const float* dm = nullptr;
+        if (o.gn_act >= 0) {
+            const Op& cv = P->ops[o.gn_consumer];
+            act = ws + o.gn_act;
+            act_silu = cv.pro_silu;
+            if (cv.dmask_off >= 0 && drop_masks) dm = drop_masks + cv.dmask_off;
+        }
         rc = launch_gn_fast(P->dtype, s1, s2, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups, gam, bet, 1e-5f, sc, sh,
-                            (float*)(ws + o.gn_mr), (float*)(ws + P->ws_gnpart), s);
+                            (float*)(ws + o.gn_mr), (float*)(ws + P->ws_gnpart), s, act, act_silu, dm);
+    }
     else
         rc = launch_gn_generic(P->dtype, s1, s2, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups, gam, bet, 1e-5f, sc, sh,
                                (float*)(ws + o.gn_mr), s);
@@ -917,10 +974,10 @@ int run_op(const dmme_plan* P, const Op& o, const char* pk, const float* x, cons
                                       (float*)(ws + o.lin_out), s);
         }
         case OP_GN:
-            return run_gn(P, o, pk, ws, nt, s);
+            return run_gn(P, o, pk, ws, nt, drop_masks, s);
         case OP_CONV: {
             ConvArgs a{};
-            fill_conv(P, o, pk, x, y, ws, drop_masks, nt, a);
+            fill_conv(P, o, pk, x, y, ws, drop_masks, nt, a, true);
             return run_any_conv(P->dtype, a, s);
         }
         case OP_ATTN: {
@@ -971,7 +1028,7 @@ void op_account(const dmme_plan* P, const Op& o, char* label, int cap, double* f
         }
         case OP_CONV: {
             ConvArgs a{};
-            fill_conv(P, o, (const char*)4096, (const float*)4096, (float*)4096, (char*)4096, nullptr, 1, a);
+            fill_conv(P, o, (const char*)4096, (const float*)4096, (float*)4096, (char*)4096, nullptr, 1, a, true);
             if (conv1x1_pipe_supported(P->dtype, a))
                 conv1x1_pipe_label(P->dtype, a, label, cap);
             else if (conv_pipe_supported(P->dtype, a))
@@ -1047,6 +1104,7 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
         return rc;
     }
     if (!getenv("DMME_NO_FUSED_GN")) assign_stats(P);
+    if (!getenv("DMME_NO_PREACT")) assign_preact(P);
     if (device >= 0) {
         // bucket boundary: parameters from the first up_layers entry on are finished first by backward
         P->op_split = (int)P->ops.size();
@@ -1708,6 +1766,10 @@ DMME_API int dmme_mse_loss(const float* eps, const float* target, int64_t numel,
                   float* scratch, void* stream) {
     DMME_REQUIRE(eps && target && loss && scratch, DMME_ERR_INVALID, "mse_loss: null argument");
     return launch_mse(eps, target, numel, loss, d_eps, grad_scale, scratch, (hipStream_t)stream);
+}
+
+DMME_API int dmme_debug_l2_stream(const void* buf, int64_t bytes, int iters, int mode, int depth, int blocks, void* sink, void* stream) {
+    return launch_l2_stream(buf, bytes, iters, mode, depth, blocks, (unsigned*)sink, (hipStream_t)stream);
 }
 
 static long long* g_stamps = nullptr;

@@ -130,6 +130,8 @@ struct ConvArgs {
     int64_t splitk_cap;
     // accurate mode (fp32 tensors only): every product as three bf16 MFMA passes on hi/lo splits instead of the fp32 MFMA
     int x3;
+    // pipelined 3x3 kernel, 64-cout bf16 tiles: filter tiles by LDS-DMA into a second buffer instead of through registers
+    int dma_b;
 };
 
 // ---- kernel launchers (defined in the .hip files) ------------------------------------

@@ -27,6 +27,24 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_byte_addr)
     (void)lds_byte_addr;
 #endif
 }
+// The same DMA issued behind the compiler's back, for a wave that READS LDS itself while its DMA into another buffer is in flight: hipcc
+// cannot tell the buffers apart and puts `s_waitcnt vmcnt(0)` in front of the first LDS read after a builtin DMA (the whole round trip
+// lands before the matrix work instead of under it).  The asm form has no memory clobber; the caller must (i) keep every ordinary access
+// to the destination buffer behind a workgroup barrier and (ii) retire the DMA itself with wait_vm_all() before that barrier - the
+// compiler's own counted waits do not know these operations and can only over-wait (they retire in order).
+__device__ __forceinline__ void glds16_hidden(const void* gsrc, unsigned lds_byte_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_byte_addr) : "m0");
+#else
+    (void)gsrc;
+    (void)lds_byte_addr;
+#endif
+}
+__device__ __forceinline__ void wait_vm_all() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
 template <int N>
 __device__ __forceinline__ void wait_vm_keep() {  // retire all but the N youngest vector-memory operations; all LDS operations
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -35,6 +35,14 @@ __global__ void __launch_bounds__(256, GT == 9 ? 1 : 2) conv3x3_pipe_kernel(Conv
     PIPE_STAMP(0);
     char* ldsA = lds;
     char* ldsB = lds + (size_t)g.a_rows * ROW_DATA;
+    // Filter tiles by LDS-DMA (bf16, one kernel row per interval, 64-cout tiles: two filter buffers fit beside the halo): the next
+    // interval's taps go global -> LDS into the OTHER buffer with no register or ds_write in between.  Interval stamps of the
+    // register path: 1.6 k of a chunk's 11.6 k cycles were VGPR-sourced LDS stores of filter tiles, and one of its two barriers per
+    // interval only protected the single buffer.
+    constexpr bool DMAB_OK = sizeof(T) == 2 && GT == 3 && BN == 64;
+    constexpr int B_BYTES = GT * BN * ROW_DATA;
+    const bool dmab = DMAB_OK && a.dma_b;
+    int cur = 0;  // filter buffer the matrix work reads (DMA path)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
@@ -74,7 +82,29 @@ __global__ void __launch_bounds__(256, GT == 9 ? 1 : 2) conv3x3_pipe_kernel(Conv
                 if (b_off[k] >= 0) breg[j][k] = *reinterpret_cast<const uint4*>(wbase + b_off[k] + (grp * GT + j) * Cin + c0);
             }
     };
-    load_B(ch_begin * KC, 0);
+    // DMA form: a wave instruction fills 8 consecutive 128-byte rows lane-linearly, so the XOR swizzle goes on the SOURCE chunk; rows
+    // past Cout re-read the last filter row (their output columns are never stored)
+    int bd_off[UB];
+#pragma unroll
+    for (int k = 0; k < UB; ++k) {
+        const int row = urow + 32 * k;
+        const int co = co0 + row < a.Cout ? co0 + row : a.Cout - 1;
+        bd_off[k] = co * 9 * Cin + (cu ^ ((row >> 1) & 7)) * EPV;
+    }
+    auto dma_B = [&](int c0, int grp, int buf) __attribute__((always_inline)) {
+        const unsigned lbase = (unsigned)(size_t)(lds_c*)(ldsB + buf * B_BYTES) + (unsigned)(wave * 8 * ROW_DATA);
+#pragma unroll
+        for (int j = 0; j < GT; ++j)
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)(lbase + (unsigned)((j * BN + 32 * k) * ROW_DATA)));
+                glds16_hidden(wbase + bd_off[k] + (grp * GT + j) * Cin + c0, l);
+            }
+    };
+    if (dmab)
+        dma_B(ch_begin * KC, 0, 0);
+    else
+        load_B(ch_begin * KC, 0);
 
     // ---- chunk-invariant staging descriptors ----
     int a_pix[PIPE_UA];  // source pixel index, -1: zero (padding / past the batch), -2: no such unit
@@ -160,7 +190,8 @@ __global__ void __launch_bounds__(256, GT == 9 ? 1 : 2) conv3x3_pipe_kernel(Conv
     load_A(ch_begin * KC);
     PIPE_STAMP(1);
     store_A(ch_begin * KC);
-    store_B();
+    if (!dmab) store_B();
+    if (dmab) wait_vm_all();
     __syncthreads();
     PIPE_STAMP(2);
 
@@ -174,9 +205,13 @@ __global__ void __launch_bounds__(256, GT == 9 ? 1 : 2) conv3x3_pipe_kernel(Conv
             const bool more = !(last_grp && ch == nchunks - 1);
             const int nc0 = (last_grp ? ch + 1 : ch) * KC;
             if (more) {
-                load_B(nc0, last_grp ? 0 : grp + 1);
-                if (last_grp) load_A(nc0);
+                if (last_grp) load_A(nc0);  // ahead of the DMA: hipcc guards the prefetch registers with a vmcnt(0) the DMA must not sit behind
+                if (dmab)
+                    dma_B(nc0, last_grp ? 0 : grp + 1, cur ^ 1);
+                else
+                    load_B(nc0, last_grp ? 0 : grp + 1);
             }
+            const char* ldsBc = ldsB + cur * B_BYTES;
             // ---- GT taps x KC of matrix work out of LDS ----
 #pragma unroll
             for (int j = 0; j < GT; ++j) {
@@ -198,16 +233,26 @@ __global__ void __launch_bounds__(256, GT == 9 ? 1 : 2) conv3x3_pipe_kernel(Conv
                         af[mi] = *reinterpret_cast<const uint4*>(ldsA + abase[mi] + ((cidx ^ aswz[mi]) << 4));
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
-                        bfr[ni] = *reinterpret_cast<const uint4*>(ldsB + j * BN * ROW_DATA + b_base[ni] + ((cidx ^ b_swz[ni]) << 4));
+                        bfr[ni] = *reinterpret_cast<const uint4*>(ldsBc + j * BN * ROW_DATA + b_base[ni] + ((cidx ^ b_swz[ni]) << 4));
                     mma_tile<typename MmaTag<T, ACC3>::type, MI, NI>(af, bfr, acc);
                 }
             }
-            __syncthreads();  // every wave is done reading this group's tiles
-            if (more) {
-                store_B();
-                if (last_grp) store_A(nc0);
+            if (dmab) {
+                if (more && last_grp) {
+                    __syncthreads();  // every wave is done reading this chunk's halo
+                    store_A(nc0);
+                }
+                wait_vm_all();    // this wave's share of the next taps has landed ...
+                __syncthreads();  // ... so has everyone's; and every wave is done with this interval's buffer
+                cur ^= 1;
+            } else {
+                __syncthreads();  // every wave is done reading this group's tiles
+                if (more) {
+                    store_B();
+                    if (last_grp) store_A(nc0);
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
     }
 
@@ -641,6 +686,11 @@ static int ws_pick(const ConvArgs& a, ConvTile& g) {
 static const int kPipeCand[4][3] = {{128, 128, 3}, {128, 64, 3}, {64, 64, 3}, {64, 64, 9}};
 static const int kPipeUA[4] = {8, 8, 8, 11};
 static size_t pipe_lds(const ConvTile& g, int BN, int GT) { return (size_t)g.a_rows * ROW_DATA + (size_t)GT * BN * ROW_DATA; }  // >= BM*BN*4 always
+// the DMA filter path (bf16, GT = 3, 64-cout tiles) needs a second filter buffer inside the 2-workgroups-per-CU budget
+static bool pipe_dma_ok(int dtype, const ConvTile& g, int BN, int GT) {
+    static const bool off = getenv("DMME_NO_PIPE_DMA") != nullptr;
+    return !off && dtype == DMME_BF16 && GT == 3 && BN == 64 && pipe_lds(g, BN, GT) + (size_t)GT * BN * ROW_DATA <= 80 * 1024;
+}
 
 static int ilog2(int v) {
     int s = 0;
@@ -719,7 +769,10 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
             return DMME_OK;
         }
     }
-    const size_t lds = pipe_lds(g, kPipeCand[pick][1], kPipeCand[pick][2]);
+    size_t lds = pipe_lds(g, kPipeCand[pick][1], kPipeCand[pick][2]);
+    ConvArgs ad = a;
+    ad.dma_b = (sizeof(T) == 2 && !ACC3 && pipe_dma_ok(DMME_BF16, g, kPipeCand[pick][1], kPipeCand[pick][2])) ? 1 : 0;
+    if (ad.dma_b) lds += (size_t)kPipeCand[pick][2] * kPipeCand[pick][1] * ROW_DATA;
     const int shTW = ilog2(g.TW), shTH = ilog2(g.TH);
     static bool attr_done[4] = {false, false, false, false};
     int rc = DMME_OK;
@@ -729,7 +782,7 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
             rc = set_lds_limit(conv3x3_pipe_kernel<T, BM_, BN_, GT_, UA_, ACC3>, (LIM) * 1024);                               \
             attr_done[IDX] = rc == DMME_OK;                                                                                   \
         }                                                                                                                     \
-        if (rc == DMME_OK) hipLaunchKernelGGL((conv3x3_pipe_kernel<T, BM_, BN_, GT_, UA_, ACC3>), grid, dim3(256), lds, s, a, g, shTW, shTH, ksplit); \
+        if (rc == DMME_OK) hipLaunchKernelGGL((conv3x3_pipe_kernel<T, BM_, BN_, GT_, UA_, ACC3>), grid, dim3(256), lds, s, ad, g, shTW, shTH, ksplit); \
         break;
     switch (pick) {
         DMME_PIPE_CASE(0, 128, 128, 3, 8, 80)

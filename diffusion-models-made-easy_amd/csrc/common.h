@@ -149,6 +149,10 @@ void conv_mfma_label(int dtype, const ConvArgs& a, char* buf, int cap);
 bool conv_pipe_supported(int dtype, const ConvArgs& a);
 int launch_conv_pipe(int dtype, const ConvArgs& a, hipStream_t s);
 void conv_pipe_label(int dtype, const ConvArgs& a, char* buf, int cap);
+// K-split-over-waves 3x3 kernel for layers with few output pixels (conv_kw.hip); launch_conv_pipe dispatches to it
+struct ConvTile;
+bool conv_kw_pick(int dtype, const ConvArgs& a, ConvTile& g, int* ni, int* ring);
+int launch_conv_kw(const ConvArgs& a, const ConvTile& g, int NI, int ring, int ksplit, hipStream_t s);
 // software-pipelined 1x1 variant (conv1x1_pipe.hip); preferred for taps == 1
 bool conv1x1_pipe_supported(int dtype, const ConvArgs& a);
 int launch_conv1x1_pipe(int dtype, const ConvArgs& a, hipStream_t s);

@@ -40,9 +40,24 @@ __device__ __forceinline__ void glds16_hidden(const void* gsrc, unsigned lds_byt
     (void)lds_byte_addr;
 #endif
 }
+// the same with a wave-uniform base pointer and a per-lane byte offset (no 64-bit vector add per instruction); M0 written by the add
+__device__ __forceinline__ void glds16_hidden_s(const void* sbase, unsigned lane_off, unsigned lds_byte_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(sbase), "s"(lds_byte_addr) : "m0");
+#else
+    (void)sbase;
+    (void)lane_off;
+    (void)lds_byte_addr;
+#endif
+}
 __device__ __forceinline__ void wait_vm_all() {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+__device__ __forceinline__ void wait_lgkm_all() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
 }
 template <int N>

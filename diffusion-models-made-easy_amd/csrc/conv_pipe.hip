@@ -683,8 +683,8 @@ static int ws_pick(const ConvArgs& a, ConvTile& g) {
 
 // candidate kernels: {BM, BN, GT}; the 9-tap variant serves layers with too little work per interval
 // (few workgroups or stride 2) and owns a larger LDS footprint
-static const int kPipeCand[4][3] = {{128, 128, 3}, {128, 64, 3}, {64, 64, 3}, {64, 64, 9}};
-static const int kPipeUA[4] = {8, 8, 8, 11};
+static const int kPipeCand[5][3] = {{128, 128, 3}, {128, 64, 3}, {64, 64, 3}, {64, 64, 9}, {64, 64, 3}};
+static const int kPipeUA[5] = {8, 8, 8, 11, 10};  // [4]: stride 2 (a 64-pixel tile's halo is 17 x 17 rows), two workgroups per CU
 static size_t pipe_lds(const ConvTile& g, int BN, int GT) { return (size_t)g.a_rows * ROW_DATA + (size_t)GT * BN * ROW_DATA; }  // >= BM*BN*4 always
 // the DMA filter path (bf16, GT = 3, 64-cout tiles) needs a second filter buffer inside the 2-workgroups-per-CU budget
 static bool pipe_dma_ok(int dtype, const ConvTile& g, int BN, int GT) {
@@ -726,6 +726,16 @@ static int pipe_pick(const ConvArgs& a, ConvTile& g) {
             g = t;
         }
     }
+    // stride 2: a 64-pixel tile's 17 x 17 halo and a whole 3x3 filter leave one workgroup per CU (110 KB); with 3-tap intervals two fit
+    // (DownSample 32 -> 16 at B = 128: 65.8 -> 43.6 us, 16 -> 8: 59.8 -> 38.5 us)
+    static const bool s2_gt9 = getenv("DMME_S2_GT9") != nullptr;
+    if (!s2_gt9 && a.stride == 2) {
+        ConvTile t;
+        if (pipe_fits(a, 4, t) && (int64_t)t.tiles_m * t.tiles_n >= 2 * 256) {
+            pick = 4;
+            g = t;
+        }
+    }
     return pick;
 }
 
@@ -741,6 +751,38 @@ bool conv_pipe_supported(int dtype, const ConvArgs& a) {
 template <typename K>
 static int set_lds_limit(K kernel, size_t bytes) {
     DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return DMME_OK;
+}
+
+// the 64 x 64 four-wave instances (8x8 / 4x4 maps, small batches) give way to the K-split-over-waves kernel (conv_kw.hip)
+// (pick 3 = layers with fewer than 512 workgroups; the 512-workgroup 8x8 layers stay on the two-per-CU four-wave kernel: 20.8 vs 28.8 us)
+static bool kw_replaces(int pick) {
+    static const int all = getenv("DMME_KW_ALL") != nullptr;
+    return pick == 3 || (all && pick == 2);
+}
+static int kw_ksplit(const ConvArgs& a, const ConvTile& g) {
+    static const bool off = getenv("DMME_NO_SPLITK") != nullptr;
+    if (off || !a.splitk || a.gn_part || a.out_silu || a.out_nchw || a.res2 || a.Cout % 4) return 1;
+    const int64_t wgs = (int64_t)g.tiles_m * g.tiles_n;
+    if (wgs > 64) return 1;
+    int ks = (a.C1 + a.C2) / 64;
+    const int room = (int)(256 / wgs);
+    if (ks > room) ks = room;
+    if (ks > 4) ks = 4;
+    const int64_t out = (int64_t)a.N * a.Hout * a.Wout * a.Cout;
+    while (ks > 1 && ks * out > a.splitk_cap) --ks;
+    return ks < 1 ? 1 : ks;
+}
+template <typename T>
+static int launch_kw_t(const ConvArgs& a, const ConvTile& gk, int ni, int ring, hipStream_t s) {
+    const int ksplit = kw_ksplit(a, gk);
+    const int rc = launch_conv_kw(a, gk, ni, ring, ksplit, s);
+    if (rc != DMME_OK) return rc;
+    if (ksplit > 1) {
+        const int64_t total4 = (int64_t)a.N * a.Hout * a.Wout * (a.Cout / 4);
+        hipLaunchKernelGGL(conv_splitk_finish_kernel<T>, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, a, ksplit, total4);
+        DMME_CHECK_LAUNCH();
+    }
     return DMME_OK;
 }
 
@@ -769,12 +811,19 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
             return DMME_OK;
         }
     }
+    if constexpr (sizeof(T) == 2) {
+        if (kw_replaces(pick)) {
+            ConvTile gk{};
+            int kni = 0, kring = 0;
+            if (conv_kw_pick(DMME_BF16, a, gk, &kni, &kring)) return launch_kw_t<T>(a, gk, kni, kring, s);
+        }
+    }
     size_t lds = pipe_lds(g, kPipeCand[pick][1], kPipeCand[pick][2]);
     ConvArgs ad = a;
     ad.dma_b = (sizeof(T) == 2 && !ACC3 && pipe_dma_ok(DMME_BF16, g, kPipeCand[pick][1], kPipeCand[pick][2])) ? 1 : 0;
     if (ad.dma_b) lds += (size_t)kPipeCand[pick][2] * kPipeCand[pick][1] * ROW_DATA;
     const int shTW = ilog2(g.TW), shTH = ilog2(g.TH);
-    static bool attr_done[4] = {false, false, false, false};
+    static bool attr_done[5] = {false, false, false, false, false};
     int rc = DMME_OK;
 #define DMME_PIPE_CASE(IDX, BM_, BN_, GT_, UA_, LIM)                                                                          \
     case IDX:                                                                                                                 \
@@ -789,6 +838,7 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
         DMME_PIPE_CASE(1, 128, 64, 3, 8, 80)
         DMME_PIPE_CASE(2, 64, 64, 3, 8, 80)
         DMME_PIPE_CASE(3, 64, 64, 9, 11, 128)
+        DMME_PIPE_CASE(4, 64, 64, 3, 10, 80)
     }
 #undef DMME_PIPE_CASE
     if (rc != DMME_OK) return rc;
@@ -821,6 +871,16 @@ bool conv_pipe_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int
     ConvTile g{};
     const int pick = pipe_pick(a, g);
     if (pick < 0) return false;
+    if (kw_replaces(pick)) {
+        ConvTile gk{};
+        int kni = 0, kring = 0;
+        if (conv_kw_pick(dtype, a, gk, &kni, &kring)) {
+            if (!stats_tile_ok(a, gk, 32 * kni, cg, 8)) return false;
+            *tiles = gk.tiles_x * gk.tiles_y;
+            *px = 64;
+            return true;
+        }
+    }
     if (!stats_tile_ok(a, g, kPipeCand[pick][1], cg, dtype == DMME_BF16 ? 8 : 4)) return false;
     *tiles = g.tiles_x * g.tiles_y;
     *px = kPipeCand[pick][0];
@@ -838,6 +898,14 @@ void conv_pipe_label(int dtype, const ConvArgs& a, char* buf, int cap) {
     }
     ConvTile g{};
     const int pick = pipe_pick(a, g);
+    if (kw_replaces(pick)) {
+        ConvTile gk{};
+        int kni = 0, kring = 0;
+        if (conv_kw_pick(dtype, a, gk, &kni, &kring)) {
+            snprintf(buf, (size_t)cap, "conv3x3_kw_kernel<%d,%d>", kni, kring);
+            return;
+        }
+    }
     snprintf(buf, (size_t)cap, "conv3x3_pipe_kernel<%s,%d,%d,%d,%d>", dtype == DMME_BF16 ? "bf16" : a.x3 ? "float:bf16x3" : "float",
              pick >= 0 ? kPipeCand[pick][0] : 0, pick >= 0 ? kPipeCand[pick][1] : 0, pick >= 0 ? kPipeCand[pick][2] : 0,
              pick >= 0 ? kPipeUA[pick] : 0);

@@ -574,7 +574,7 @@ int launch_pack_table(int dtype, const PackItem* items_dev, int n_items, const f
 
 // ------------------------------------------------------------------ diagnostic: what one CU can pull from L2
 // Every workgroup (one per CU) streams the same `bytes` of an L2-resident buffer `iters` times, DEPTH 16-byte loads in flight per
-// thread (mode 0: into registers; mode 1: global -> LDS DMA, no registers).  tools/l2_stream.py turns the elapsed time into bytes
+// thread (mode 0: into registers; mode 1: global -> LDS DMA, no registers; mode m >= 2: DMA gathering eight 128-byte rows per wave instruction, m 16-byte vectors apart).  tools/l2_stream.py turns the elapsed time into bytes
 // per clock per CU - the number every tile-size decision in DESIGN.md section 4 leans on.
 template <int DEPTH>
 __global__ void __launch_bounds__(256) l2_stream_kernel(const uint4* __restrict__ buf, int nvec, int iters, unsigned* __restrict__ sink) {
@@ -593,7 +593,7 @@ __global__ void __launch_bounds__(256) l2_stream_kernel(const uint4* __restrict_
 }
 typedef __attribute__((address_space(3))) char l2s_lds_c;
 template <int DEPTH>
-__global__ void __launch_bounds__(256) l2_stream_dma_kernel(const uint4* __restrict__ buf, int nvec, int iters, unsigned* __restrict__ sink) {
+__global__ void __launch_bounds__(256) l2_stream_dma_kernel(const uint4* __restrict__ buf, int nvec, int iters, unsigned* __restrict__ sink, int row_stride) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, wave = tid >> 6;
     (void)wave;
@@ -604,7 +604,10 @@ __global__ void __launch_bounds__(256) l2_stream_dma_kernel(const uint4* __restr
             for (int d = 0; d < DEPTH; ++d) {
 #if defined(__HIP_DEVICE_COMPILE__)
                 const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(size_t)(l2s_lds_c*)lds + (unsigned)((d * 4 + wave) * 1024)));
-                __builtin_amdgcn_global_load_lds(buf + base + d * 256 + tid, (l2s_lds_c*)(size_t)l, 16, 0, 0);
+                // row_stride > 0: the convolutions' access shape - a wave instruction gathers eight 128-byte rows `row_stride` vectors apart
+                const int idx = row_stride ? (int)(((unsigned)(base / 8 + d * 32 + (tid >> 3)) * (unsigned)row_stride + (unsigned)(tid & 7)) % (unsigned)nvec)
+                                           : base + d * 256 + tid;
+                __builtin_amdgcn_global_load_lds(buf + idx, (l2s_lds_c*)(size_t)l, 16, 0, 0);
 #endif
             }
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -622,7 +625,7 @@ int launch_l2_stream(const void* buf, int64_t bytes, int iters, int mode, int de
 #define L2S_CASE(D)                                                                                                             \
     if (depth == D) {                                                                                                           \
         if (mode == 0) hipLaunchKernelGGL(l2_stream_kernel<D>, g, b, 0, s, (const uint4*)buf, nvec, iters, sink);               \
-        else hipLaunchKernelGGL(l2_stream_dma_kernel<D>, g, b, D * 4096, s, (const uint4*)buf, nvec, iters, sink);              \
+        else hipLaunchKernelGGL(l2_stream_dma_kernel<D>, g, b, D * 4096, s, (const uint4*)buf, nvec, iters, sink, mode >= 2 ? mode : 0); \
     }
     L2S_CASE(1) L2S_CASE(2) L2S_CASE(4) L2S_CASE(8) L2S_CASE(16)
 #undef L2S_CASE

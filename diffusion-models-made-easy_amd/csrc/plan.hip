@@ -793,6 +793,7 @@ void build_wgrad_group(dmme_plan* P, dmme_plan::WgGroup& G, int taps, int op_lo 
         L.scale_off = o.gn >= 0 ? P->ops[o.gn].gn_scale : -1;
         L.shift_off = o.gn >= 0 ? P->ops[o.gn].gn_shift : -1;
         L.dmask_off = o.dmask_off;
+        if (getenv("DMME_WG_NOPRO")) { L.scale_off = L.shift_off = -1; L.dmask_off = -1; L.pro_silu = 0; }  // EXPERIMENT timing only
         L.dy_off = P->gt_off[o.dst];
         L.dw_off = P->params[o.w].wp_off;
         o.wg_layer = (int)G.layers.size();

@@ -5,6 +5,7 @@ import torch, dmme_amd
 from dmme_amd import _lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+thr = float(sys.argv[3]) if len(sys.argv) > 3 else 0.02  # ms
 m = dmme_amd.UNet(precision=prec).cuda().eval()
 x = dmme_amd.gaussian((B, 3, 32, 32), device="cuda"); t = torch.tensor([500], device="cuda")
 with torch.no_grad(): m(x, t)
@@ -19,5 +20,5 @@ for r in range(6):
     if r:
         for i in range(n): acc[i] += ms[i] / 5
 for i, (lab, fl, by) in enumerate(info):
-    if acc[i] > 0.02: print(f"{i:3d} {lab:38s} {acc[i]*1e3:8.1f} us  {fl/1e9:7.2f} GFLOP {fl/acc[i]/1e9 if acc[i] else 0:8.1f} TF  {by/1e6:7.1f} MB {by/acc[i]/1e6:8.1f} GB/s")
+    if acc[i] >= thr: print(f"{i:3d} {lab:38s} {acc[i]*1e3:8.1f} us  {fl/1e9:7.2f} GFLOP {fl/acc[i]/1e9 if acc[i] else 0:8.1f} TF  {by/1e6:7.1f} MB {by/acc[i]/1e6:8.1f} GB/s")
 print("total ms", sum(acc))

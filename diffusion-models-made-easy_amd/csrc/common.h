@@ -99,6 +99,17 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 }
 
 // Device-side description of one convolution launch (generic and MFMA kernels share it).
+// A GroupNorm whose statistics the PRODUCING conv completes in its own epilogue (tiles of whole images: 8x8, 4x4 maps): the conv
+// writes the norm's per-(n, c) scale / shift rows and {mean, rstd} itself - no finalize launch, no separate norm kernel.
+struct GnOut {
+    const float* gamma;  // [C] of the consuming norm
+    const float* beta;
+    float* scale;        // [N][C]
+    float* shift;
+    float* mean_rstd;    // [N][groups][2]
+    int C, cg, c_off;    // the norm's width and group size; channel c of this conv's output is channel c_off + c of the norm
+};
+
 struct ConvArgs {
     const void* src1;
     const void* src2;
@@ -132,6 +143,14 @@ struct ConvArgs {
     int x3;
     // pipelined 3x3 kernel, 64-cout bf16 tiles: filter tiles by LDS-DMA into a second buffer instead of through registers
     int dma_b;
+    // norms finished by this conv's epilogue (n_gno = 0: none) and, for norm gno[act_k], the consumer's pre-activated input
+    // act[n][p][act_C] = T(silu?(y * scale + shift) * mask) (null: not written)
+    GnOut gno[2];
+    int n_gno;
+    float gn_eps;
+    void* act;
+    int act_k, act_silu;
+    const float* act_dmask;  // [N][gno[act_k].C] or null
 };
 
 // ---- kernel launchers (defined in the .hip files) ------------------------------------
@@ -153,6 +172,8 @@ void conv_pipe_label(int dtype, const ConvArgs& a, char* buf, int cap);
 struct ConvTile;
 bool conv_kw_pick(int dtype, const ConvArgs& a, ConvTile& g, int* ni, int* ring);
 int launch_conv_kw(const ConvArgs& a, const ConvTile& g, int NI, int ring, int ksplit, hipStream_t s);
+// will the kernel that runs this conv finish the norms consuming its output (ConvArgs::n_gno set; cg[k]: their group sizes)?
+bool conv_gn_direct_query(int dtype, const ConvArgs& a, const int* cg, int n);
 // software-pipelined 1x1 variant (conv1x1_pipe.hip); preferred for taps == 1
 bool conv1x1_pipe_supported(int dtype, const ConvArgs& a);
 int launch_conv1x1_pipe(int dtype, const ConvArgs& a, hipStream_t s);

@@ -231,14 +231,14 @@ __device__ __forceinline__ bool conv_epilogue_is_staged(const ConvArgs& a, int T
 // MSTRIDE: staged rows between a wave's consecutive 32-row accumulator tiles (32: contiguous rows)
 template <typename T, int BN, int MI, int NI, int MSTRIDE = 32>
 __device__ __forceinline__ void conv_epilogue_stage(const ConvArgs& a, f32x16 (&acc)[MI][NI], int co0, int wn0, int r, int h, int wm0, int n0,
-                                                    float* stage) {
+                                                    float* stage, bool with_trow = true) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int c = wn0 + ni * 32 + r, co = co0 + c;
         float fold = 0.f;
         if (co < a.Cout) {
             fold = a.bias ? a.bias[co] : 0.f;
-            if (a.tproj) fold += a.tproj[(a.nt == 1 ? 0 : n0) * a.tproj_ld + co];
+            if (a.tproj && with_trow) fold += a.tproj[(a.nt == 1 ? 0 : n0) * a.tproj_ld + co];
         }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -389,6 +389,184 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, int co0, 
             o[0] = mean;
             o[1] = M2;
         }
+    }
+}
+
+// The store loop for 64-pixel tiles of WHOLE images (TN = 64 / HW images of HW = 2^k pixels; 256 threads), finishing the GroupNorms
+// that consume this conv's output (ConvArgs::gno): complete per-(image, group) statistics -> scale / shift / {mean, rstd} rows, and the
+// consumer's pre-activated input.  Statistics of the stored (rounded) values, merged with Chan's formula in a fixed order:
+//   thread: one 16-byte vector per item (VEC values) -> wave: lanes VPR apart hold the same channel vector of consecutive pixels
+//   (PB = 64 / VPR pixels, never straddling an image: HW >= PB) -> LDS -> one thread per (image, vector) over the image's blocks ->
+//   one thread per (image, group) over the group's vectors.
+// add_trow: the time-embedding row differs per image inside the tile (training: nt = N) and was left out of the staged image.
+// `stage`: the fp32 [64][BN] image, followed by 16 KB of scratch this function uses (kDirectLds bytes in all).
+constexpr int kDirectLds = 64 * 64 * 4 + 16 * 1024;
+template <typename T, int BN, typename PixFn>
+__device__ __forceinline__ void conv_epilogue_store_direct(const ConvArgs& a, int co0, int n0, int HW, PixFn pix_of, float* stage, bool add_trow) {
+    constexpr int BM = 64, NT = 256, VEC = 16 / sizeof(T), VPR = BN / VEC, ITEMS = BM * VPR / NT, PB = 64 / VPR, NPB = BM / PB;
+    static_assert(ITEMS >= 1 && NPB == 4 * ITEMS, "conv_epilogue_store_direct: tile shape");
+    const int tid = threadIdx.x, wave = tid >> 6, vec = tid % VPR;
+    const int TN = BM / HW, sh_hw = 31 - __builtin_clz(HW);
+    float* blk = stage + BM * BN;          // [NPB][VPR][2]
+    float* img = blk + NPB * VPR * 2;      // [TN][VPR][2]   (TN * VPR <= 256)
+    float* mr = img + 512;                 // [2][TN * VPR][2] {mean, rstd} per (image, vector), per norm
+    float* ssc = mr + 1024;                // [TN * BN] scale, then [TN * BN] shift of norm act_k
+    float* ssh = ssc + 1024;
+    T* __restrict__ dst = (T*)a.dst;
+    const T* __restrict__ res = (const T*)a.res1;
+    uint4 kept[ITEMS];  // the stored vectors (for act)
+#pragma unroll
+    for (int q = 0; q < ITEMS; ++q) {
+        const int it = tid + q * NT, m = it / VPR;
+        const int co = co0 + vec * VEC;
+        const int opix = pix_of(m);  // -1: image past the batch (its statistics are computed and never written)
+        const int off = (opix < 0 ? 0 : opix) * a.Cout + co;
+        const float* sp = stage + m * BN + vec * VEC;
+        float v[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(sp + e);
+            v[e] = t[0]; v[e + 1] = t[1]; v[e + 2] = t[2]; v[e + 3] = t[3];
+        }
+        if (add_trow) {
+            const float* tr = a.tproj + (int64_t)(n0 + (m >> sh_hw) < a.N ? n0 + (m >> sh_hw) : 0) * a.tproj_ld + co;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] += tr[e];
+        }
+        float x[VEC];
+        if constexpr (sizeof(T) == 4) {
+            if (res) {
+                const f32x4 rv = *reinterpret_cast<const f32x4*>(res + off);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += rv[e];
+            }
+            const f32x4 o = {v[0], v[1], v[2], v[3]};
+            if (opix >= 0) *reinterpret_cast<f32x4*>(dst + off) = o;
+            kept[q] = __builtin_bit_cast(uint4, o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = v[e];
+        } else {
+            if (res) {
+                const bf16x8 rv = *reinterpret_cast<const bf16x8*>(res + off);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+            if (opix >= 0) *reinterpret_cast<bf16x8*>(dst + off) = o;
+            kept[q] = __builtin_bit_cast(uint4, o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = (float)o[e];
+        }
+        // this vector: mean, M2 of VEC values; then the PB pixels of this wave with the same channel vector (equal counts)
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s += x[e];
+        float mean = s * (1.f / VEC), m2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float d = x[e] - mean;
+            m2 = fmaf(d, d, m2);
+        }
+        float cnt = (float)VEC;
+#pragma unroll
+        for (int o = VPR; o < 64; o <<= 1) {
+            const float om = __shfl_xor(mean, o, 64), o2 = __shfl_xor(m2, o, 64);
+            const float d = om - mean;
+            m2 += o2 + d * d * (0.5f * cnt);
+            mean = 0.5f * (mean + om);
+            cnt *= 2.f;
+        }
+        if ((tid & 63) < VPR) {
+            float* b = blk + ((4 * q + wave) * VPR + vec) * 2;
+            b[0] = mean;
+            b[1] = m2;
+        }
+    }
+    __syncthreads();
+    // (image, vector): the image's HW / PB blocks, in pixel order
+    if (tid < TN * VPR) {
+        const int tn = tid / VPR, v = tid % VPR, nb = HW / PB;
+        const float cb = (float)(PB * VEC);
+        float na = 0.f, mean = 0.f, m2 = 0.f;
+        for (int b = 0; b < nb; ++b) {
+            const float* q = blk + ((tn * nb + b) * VPR + v) * 2;
+            const float delta = q[0] - mean, tot = na + cb;
+            const float rt = __builtin_amdgcn_rcpf(tot);
+            mean += delta * (cb * rt);
+            m2 += q[1] + delta * delta * (na * cb * rt);
+            na = tot;
+        }
+        img[tid * 2] = mean;
+        img[tid * 2 + 1] = m2;
+    }
+    __syncthreads();
+    // (image, group) of each norm: the group's cg / VEC vectors, in channel order
+    const float cv = (float)(HW * VEC);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (k >= a.n_gno) break;
+        const GnOut& G = a.gno[k];
+        const int f = G.cg / VEC, gpt = VPR / f;  // vectors per group, groups per image in this tile
+        if (tid < TN * gpt) {
+            const int tn = tid / gpt, gi = tid % gpt;
+            float na = 0.f, mean = 0.f, m2 = 0.f;
+            for (int j = 0; j < f; ++j) {
+                const float* q = img + (tn * VPR + gi * f + j) * 2;
+                const float delta = q[0] - mean, tot = na + cv;
+                const float rt = __builtin_amdgcn_rcpf(tot);
+                mean += delta * (cv * rt);
+                m2 += q[1] + delta * delta * (na * cv * rt);
+                na = tot;
+            }
+            const float rstd = 1.0f / sqrtf(m2 / na + a.gn_eps);
+            for (int j = 0; j < f; ++j) {
+                float* o = mr + (k * 256 + tn * VPR + gi * f + j) * 2;
+                o[0] = mean;
+                o[1] = rstd;
+            }
+            if (n0 + tn < a.N && G.mean_rstd) {
+                float* o = G.mean_rstd + ((int64_t)(n0 + tn) * (G.C / G.cg) + (G.c_off + co0) / G.cg + gi) * 2;
+                o[0] = mean;
+                o[1] = rstd;
+            }
+        }
+    }
+    __syncthreads();
+    // scale / shift rows: one (image, channel) per thread and pass
+    for (int idx = tid; idx < TN * BN; idx += NT) {
+        const int tn = idx / BN, c = idx % BN;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (k >= a.n_gno) break;
+            const GnOut& G = a.gno[k];
+            const float* q = mr + (k * 256 + tn * VPR + c / VEC) * 2;
+            const int cc = G.c_off + co0 + c;
+            const float sc = q[1] * G.gamma[cc], sh = G.beta[cc] - q[0] * sc;
+            if (n0 + tn < a.N) {
+                G.scale[(int64_t)(n0 + tn) * G.C + cc] = sc;
+                G.shift[(int64_t)(n0 + tn) * G.C + cc] = sh;
+            }
+            if (a.act && k == a.act_k) {
+                ssc[idx] = sc;
+                ssh[idx] = sh;
+            }
+        }
+    }
+    if (!a.act) return;
+    __syncthreads();
+    const GnOut& GA = a.gno[a.act_k];
+    T* __restrict__ act = (T*)a.act;
+#pragma unroll
+    for (int q = 0; q < ITEMS; ++q) {
+        const int it = tid + q * NT, m = it / VPR;
+        const int opix = pix_of(m);
+        if (opix < 0) continue;
+        const int tn = m >> sh_hw;
+        const float* dm = a.act_dmask ? a.act_dmask + (int64_t)(n0 + tn) * GA.C + GA.c_off + co0 + vec * VEC : nullptr;
+        const uint4 o = prologue_vec<T>(kept[q], ssc + tn * BN + vec * VEC, ssh + tn * BN + vec * VEC, dm, a.act_silu);
+        *reinterpret_cast<uint4*>(act + (int64_t)opix * GA.C + GA.c_off + co0 + vec * VEC) = o;
     }
 }
 

@@ -360,7 +360,13 @@ __global__ void __launch_bounds__(256, 1) conv3x3_kw_kernel(ConvArgs a, ConvTile
         return;
     }
     const int tile_s = ty_blk * g.tiles_x + tx_blk;
-    if (conv_epilogue_is_staged<T>(a, g.TN)) {
+    if (a.n_gno > 0) {  // whole-image tile (host-checked): finish the consuming GroupNorms here
+        const bool add_trow = a.tproj && a.nt != 1 && g.TN > 1;
+        __syncthreads();
+        if (wave < NQ) conv_epilogue_stage<T, BN, 1, 1>(a, tot, co0, wn0, r, h, wm0, n0, reinterpret_cast<float*>(lds), !add_trow);
+        __syncthreads();
+        conv_epilogue_store_direct<T, BN>(a, co0, n0, a.Hout * a.Wout, pix_of, reinterpret_cast<float*>(lds), add_trow);
+    } else if (conv_epilogue_is_staged<T>(a, g.TN)) {
         __syncthreads();  // the partial sums have been read: the staging image may overwrite them
         if (wave < NQ) conv_epilogue_stage<T, BN, 1, 1>(a, tot, co0, wn0, r, h, wm0, n0, reinterpret_cast<float*>(lds));
         __syncthreads();

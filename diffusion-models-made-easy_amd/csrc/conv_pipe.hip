@@ -280,6 +280,16 @@ __global__ void __launch_bounds__(256, GT == 9 ? 1 : 2) conv3x3_pipe_kernel(Conv
         PIPE_STAMP(4);
         return;
     }
+    if constexpr (BM == 64) {
+        if (a.n_gno > 0) {  // whole-image tile (host-checked): finish the consuming GroupNorms here
+            const bool add_trow = a.tproj && a.nt != 1 && g.TN > 1;
+            conv_epilogue_stage<T, BN, MI, NI>(a, acc, co0, wn0, r, h, wm0, n0, reinterpret_cast<float*>(lds), !add_trow);
+            __syncthreads();
+            conv_epilogue_store_direct<T, BN>(a, co0, n0, a.Hout * a.Wout, pix_of, reinterpret_cast<float*>(lds), add_trow);
+            PIPE_STAMP(4);
+            return;
+        }
+    }
     conv_epilogue<T, BM, BN, MI, NI>(a, acc, co0, wn0, r, h, wm0, n0, g.TN, pix_of, reinterpret_cast<float*>(lds), ty_blk * g.tiles_x + tx_blk);
     PIPE_STAMP(4);
 #undef PIPE_STAMP
@@ -312,7 +322,7 @@ __global__ void __launch_bounds__(256) conv_splitk_finish_kernel(ConvArgs a, int
 }
 static int pipe_ksplit(const ConvArgs& a, const ConvTile& g, int pick, int KC) {
     static const bool off = getenv("DMME_NO_SPLITK") != nullptr;
-    if (off || !a.splitk || pick != 3 || a.stride != 1 || a.gn_part || a.out_silu || a.out_nchw || a.res2 || a.Cout % 4) return 1;
+    if (off || !a.splitk || pick != 3 || a.stride != 1 || a.gn_part || a.n_gno || a.out_silu || a.out_nchw || a.res2 || a.Cout % 4) return 1;
     const int64_t wgs = (int64_t)g.tiles_m * g.tiles_n;
     if (wgs > 128) return 1;  // a full wave of workgroups already
     // stamps (tools/stamp_pipe.py): these layers stream 92 KB per 64-channel chunk per workgroup through ONE CU's L2 port
@@ -762,7 +772,7 @@ static bool kw_replaces(int pick) {
 }
 static int kw_ksplit(const ConvArgs& a, const ConvTile& g) {
     static const bool off = getenv("DMME_NO_SPLITK") != nullptr;
-    if (off || !a.splitk || a.gn_part || a.out_silu || a.out_nchw || a.res2 || a.Cout % 4) return 1;
+    if (off || !a.splitk || a.gn_part || a.n_gno || a.out_silu || a.out_nchw || a.res2 || a.Cout % 4) return 1;
     const int64_t wgs = (int64_t)g.tiles_m * g.tiles_n;
     if (wgs > 64) return 1;
     int ks = (a.C1 + a.C2) / 64;
@@ -822,6 +832,7 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
     ConvArgs ad = a;
     ad.dma_b = (sizeof(T) == 2 && !ACC3 && pipe_dma_ok(DMME_BF16, g, kPipeCand[pick][1], kPipeCand[pick][2])) ? 1 : 0;
     if (ad.dma_b) lds += (size_t)kPipeCand[pick][2] * kPipeCand[pick][1] * ROW_DATA;
+    if (a.n_gno && lds < (size_t)kDirectLds) lds = kDirectLds;
     const int shTW = ilog2(g.TW), shTH = ilog2(g.TH);
     static bool attr_done[5] = {false, false, false, false, false};
     int rc = DMME_OK;
@@ -855,6 +866,42 @@ int launch_conv_pipe(int dtype, const ConvArgs& a, hipStream_t s) {
     DMME_REQUIRE(conv_pipe_supported(dtype, a), DMME_ERR_UNSUPPORTED, "conv_pipe: unsupported shape");
     if (dtype == DMME_BF16) return launch_pipe_t<bf16>(a, s);
     return a.x3 ? launch_pipe_t<float, true>(a, s) : launch_pipe_t<float>(a, s);
+}
+
+bool conv_gn_direct_query(int dtype, const ConvArgs& a, const int* cg, int n) {
+    static const bool off = getenv("DMME_NO_GN_DIRECT") != nullptr;
+    if (off || n < 1 || n > 2 || a.taps != 9 || !conv_pipe_supported(dtype, a)) return false;
+    const int VEC = dtype == DMME_BF16 ? 8 : 4;
+    const int HW = a.Hout * a.Wout;
+    if (a.out_silu || a.out_nchw || a.res2 || a.Cout % VEC || HW > 64 || (HW & (HW - 1))) return false;
+    if (dtype == DMME_BF16 && !getenv("DMME_NO_WS")) {
+        ConvTile gw{};
+        if (ws_pick(a, gw)) return false;
+    }
+    ConvArgs b = a;  // would the split-K heuristic (few workgroups) take this conv?  then it keeps that path
+    b.n_gno = 0;
+    b.gn_part = nullptr;
+    b.splitk = (float*)4096;
+    b.splitk_cap = (int64_t)1 << 40;
+    ConvTile g{};
+    const int pick = pipe_pick(a, g);
+    if (pick < 0) return false;
+    int BN = 0;
+    ConvTile gk{};
+    int kni = 0, kring = 0;
+    if (kw_replaces(pick) && conv_kw_pick(dtype, a, gk, &kni, &kring)) {
+        if (a.up || kw_ksplit(b, gk) != 1) return false;
+        g = gk;
+        BN = 32 * kni;
+    } else {
+        if (kPipeCand[pick][0] != 64 || pipe_ksplit(b, g, pick, dtype == DMME_BF16 ? 64 : 32) != 1) return false;
+        BN = kPipeCand[pick][1];
+    }
+    if (g.TH != a.Hout || g.TW != a.Wout || g.TN * g.TH * g.TW != 64 || a.Cout % BN) return false;  // whole images, whole cout tiles
+    if (HW < 64 / (BN / VEC)) return false;  // a wave's pixels per channel vector must not straddle images
+    for (int k = 0; k < n; ++k)
+        if (cg[k] % VEC || BN % cg[k]) return false;
+    return true;
 }
 
 bool conv_pipe_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px) {

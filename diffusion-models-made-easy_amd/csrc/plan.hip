@@ -64,6 +64,7 @@ struct Op {
     int64_t gn_act = -1;   // workspace offset of act [N][HW][C] in the compute dtype
     int gn_force_small = 0;  // statistics from the one-workgroup-per-image kernel even where the producers left partials (it writes act)
     int gn_consumer = -1;  // the conv op that reads it (its pro_silu / Dropout2d mask define the activation)
+    int gn_direct = 0;     // every source's producing conv finishes this norm in its epilogue (ConvArgs::gno): no launch here
     // OP_CONV
     int src1 = -1, src2 = -1;  // tensor ids; -2: network input (NCHW fp32)
     int w = -1, b = -1;
@@ -75,6 +76,8 @@ struct Op {
     int dst = -1;              // tensor id; -2: network output (NCHW fp32)
     int up = 0, stride = 1, taps = 9;
     int use_act = 0;           // FORWARD reads the pre-activated tensor of its GroupNorm (backward still works from src1 / src2 + scale / shift)
+    int gd_n = 0, gd_gn[2] = {-1, -1}, gd_coff[2] = {0, 0};  // norms this conv's forward epilogue finishes (op index, channel offset in the norm)
+    int gd_act = -1;           // which of them also gets the consumer's pre-activated input written (-1: none)
     int wg_layer = -1;         // index into the grouped weight-gradient table of its kernel size (-1: per-layer kernels)
     int bias_deferred = 0;     // its bias / time-projection reduction runs in the grouped launch
     // OP_ATTN
@@ -758,6 +761,29 @@ void fill_conv(const dmme_plan* P, const Op& o, const char* packed, const float*
         a.splitk = (float*)(ws + P->ws_splitk);
         a.splitk_cap = P->splitk_floats;
     }
+    if (fwd && o.gd_n > 0) {
+        a.n_gno = o.gd_n;
+        a.gn_eps = 1e-5f;
+        for (int k = 0; k < o.gd_n; ++k) {
+            const Op& g = P->ops[o.gd_gn[k]];
+            GnOut& G = a.gno[k];
+            G.gamma = (const float*)(packed + P->params[g.gn_gamma].packed_off);
+            G.beta = (const float*)(packed + P->params[g.gn_beta].packed_off);
+            G.scale = (float*)(ws + g.gn_scale);
+            G.shift = (float*)(ws + g.gn_shift);
+            G.mean_rstd = (float*)(ws + g.gn_mr);
+            G.C = P->tensors[g.gn_src1].C + (g.gn_src2 >= 0 ? P->tensors[g.gn_src2].C : 0);
+            G.cg = G.C / P->cfg.num_groups;
+            G.c_off = o.gd_coff[k];
+            if (k == o.gd_act) {
+                const Op& cv = P->ops[g.gn_consumer];
+                a.act = ws + g.gn_act;
+                a.act_k = k;
+                a.act_silu = cv.pro_silu;
+                a.act_dmask = (cv.dmask_off >= 0 && drop_masks) ? drop_masks + cv.dmask_off : nullptr;
+            }
+        }
+    }
     if (o.dst == -2) {
         a.dst = y;
         a.out_nchw = 1;
@@ -793,7 +819,6 @@ void build_wgrad_group(dmme_plan* P, dmme_plan::WgGroup& G, int taps, int op_lo 
         L.scale_off = o.gn >= 0 ? P->ops[o.gn].gn_scale : -1;
         L.shift_off = o.gn >= 0 ? P->ops[o.gn].gn_shift : -1;
         L.dmask_off = o.dmask_off;
-        if (getenv("DMME_WG_NOPRO")) { L.scale_off = L.shift_off = -1; L.dmask_off = -1; L.pro_silu = 0; }  // EXPERIMENT timing only
         L.dy_off = P->gt_off[o.dst];
         L.dw_off = P->params[o.w].wp_off;
         o.wg_layer = (int)G.layers.size();
@@ -887,6 +912,94 @@ void assign_stats(dmme_plan* P) {
     P->ws_bytes = ws;
 }
 
+// Small maps again, from the producer's side: a conv whose tile is 64 pixels of WHOLE images (8x8, 4x4 maps) sees every value of an
+// (image, group) in one workgroup, so its epilogue can finish the norms that consume its output - scale / shift / {mean, rstd} rows
+// and, for a single-source norm, the consumer's pre-activated input - and the norm itself is no launch at all
+// (conv_epilogue_store_direct).  A tensor goes this way only if ALL the norms reading it do (else it would need partials as well),
+// and a norm only if all its sources do.
+void assign_direct(dmme_plan* P) {
+    const int nT = (int)P->tensors.size(), nO = (int)P->ops.size();
+    const int G = P->cfg.num_groups;
+    std::vector<int> producer(nT, -1);
+    for (int oi = 0; oi < nO; ++oi)
+        if (P->ops[oi].kind == OP_CONV && P->ops[oi].dst >= 0) producer[P->ops[oi].dst] = oi;
+    struct Use { int gn, coff; };
+    std::vector<std::vector<Use>> uses(nT);
+    for (int oi = 0; oi < nO; ++oi) {
+        const Op& g = P->ops[oi];
+        if (g.kind != OP_GN) continue;
+        uses[g.gn_src1].push_back({oi, 0});
+        if (g.gn_src2 >= 0) uses[g.gn_src2].push_back({oi, P->tensors[g.gn_src1].C});
+    }
+    std::vector<char> elig(nT, 0);
+    for (int t = 0; t < nT; ++t) {
+        if (producer[t] < 0 || uses[t].empty() || uses[t].size() > 2) continue;
+        const Op& o = P->ops[producer[t]];
+        ConvArgs a{};
+        fill_conv(P, o, (const char*)4096, (const float*)4096, (float*)4096, (char*)4096, nullptr, 1, a);
+        a.nt = o.tproj_col >= 0 ? P->B : 0;
+        a.gn_part = nullptr;
+        a.n_gno = (int)uses[t].size();
+        bool ok = true;
+        int cgs[2] = {0, 0};
+        for (size_t k = 0; k < uses[t].size(); ++k) {
+            const Op& g = P->ops[uses[t][k].gn];
+            const int C = P->tensors[g.gn_src1].C + (g.gn_src2 >= 0 ? P->tensors[g.gn_src2].C : 0);
+            if (g.gn_mod_col >= 0 || C % G || uses[t][k].coff % (C / G)) ok = false;
+            cgs[k] = C / G;
+        }
+        if (ok && conv_gn_direct_query(P->dtype, a, cgs, (int)uses[t].size())) elig[t] = 1;
+    }
+    for (bool changed = true; changed;) {  // a norm needs all its sources, a tensor all its norms
+        changed = false;
+        for (int t = 0; t < nT; ++t) {
+            if (!elig[t]) continue;
+            for (const Use& u : uses[t]) {
+                const Op& g = P->ops[u.gn];
+                if (!elig[g.gn_src1] || (g.gn_src2 >= 0 && !elig[g.gn_src2])) {
+                    elig[t] = 0;
+                    changed = true;
+                    break;
+                }
+            }
+        }
+    }
+    int64_t ws = P->ws_bytes;
+    const int64_t es = (int64_t)dtype_size(P->dtype);
+    for (int t = 0; t < nT; ++t) {
+        if (!elig[t]) continue;
+        Op& o = P->ops[producer[t]];
+        P->tensors[t].stats_off = -1;  // no partials: nothing merges them
+        o.gd_n = (int)uses[t].size();
+        for (int k = 0; k < o.gd_n; ++k) {
+            o.gd_gn[k] = uses[t][k].gn;
+            o.gd_coff[k] = uses[t][k].coff;
+            P->ops[uses[t][k].gn].gn_direct = 1;
+        }
+    }
+    for (const Op& o : P->ops)
+        if (o.kind == OP_GN && o.gn_direct) --P->n_launches;
+    if (getenv("DMME_NO_PREACT")) return;
+    // single-source direct norms: the producer also writes the consumer's pre-activated input
+    for (int ci = 0; ci < nO; ++ci) {
+        Op& cv = P->ops[ci];
+        if (cv.kind != OP_CONV || cv.gn < 0 || cv.src1 < 0 || cv.up || cv.stride != 1) continue;
+        Op& g = P->ops[cv.gn];
+        if (!g.gn_direct || g.gn_src2 >= 0 || g.gn_act >= 0 || g.gn_src1 != cv.src1 || cv.src2 >= 0) continue;
+        Op& pr = P->ops[producer[g.gn_src1]];
+        if (pr.gd_act >= 0) continue;  // one pre-activated output per producer
+        for (int k = 0; k < pr.gd_n; ++k)
+            if (pr.gd_gn[k] == cv.gn) pr.gd_act = k;
+        if (pr.gd_act < 0) continue;
+        const Tensor& t1 = P->tensors[g.gn_src1];
+        g.gn_act = ws;
+        g.gn_consumer = ci;
+        cv.use_act = 1;
+        ws = align_up(ws + (int64_t)P->B * t1.H * t1.W * t1.C * es, 256);
+    }
+    P->ws_bytes = ws;
+}
+
 // Small maps: the GroupNorms that run as one workgroup per image (maps of at most 64 pixels: their producers tile several images
 // together and cannot fuse the statistics) also write the consumer conv's pre-activated input, once per element.  Not for the
 // scale-shift blocks of the IDDPM UNet (their per-(n, c) affine is modulated after the norm kernel).
@@ -898,7 +1011,7 @@ void assign_preact(dmme_plan* P) {
         if (cv.kind != OP_CONV || cv.gn < 0 || cv.src1 < 0 || cv.up || cv.stride != 1) continue;
         Op& g = P->ops[cv.gn];
         static const bool over_parts = getenv("DMME_PREACT_PARTS") && atoi(getenv("DMME_PREACT_PARTS")) != 0;
-        if (g.gn_mod_col >= 0 || g.gn_act >= 0) continue;
+        if (g.gn_mod_col >= 0 || g.gn_act >= 0 || g.gn_direct) continue;
         const Tensor& t1 = P->tensors[g.gn_src1];
         const int C2 = g.gn_src2 >= 0 ? P->tensors[g.gn_src2].C : 0;
         if (g.gn_src1 != cv.src1 || g.gn_src2 != cv.src2) continue;
@@ -920,6 +1033,7 @@ void assign_preact(dmme_plan* P) {
 
 // GroupNorm statistics folded with the affine into per-(n, c) scale / shift for the consuming conv's prologue
 int run_gn(const dmme_plan* P, const Op& o, const char* pk, char* ws, int nt, const float* drop_masks, hipStream_t s) {
+    if (o.gn_direct) return DMME_OK;  // its producers wrote scale / shift / {mean, rstd} (and act)
     // scale-shift conditioning (iddpm.ResBlock): (shift | scale) columns of the batched time projection
     const float* tsh = o.gn_mod_col >= 0 ? (const float*)(ws + P->ws_tproj) + o.gn_mod_col : nullptr;
     const float* tsc = tsh ? tsh + o.gn_mod_C : nullptr;
@@ -1105,6 +1219,7 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
         return rc;
     }
     if (!getenv("DMME_NO_FUSED_GN")) assign_stats(P);
+    if (!getenv("DMME_NO_FUSED_GN") && !getenv("DMME_NO_GN_DIRECT")) assign_direct(P);
     if (!getenv("DMME_NO_PREACT")) assign_preact(P);
     if (device >= 0) {
         // bucket boundary: parameters from the first up_layers entry on are finished first by backward

@@ -174,6 +174,7 @@ bool conv_kw_pick(int dtype, const ConvArgs& a, ConvTile& g, int* ni, int* ring)
 int launch_conv_kw(const ConvArgs& a, const ConvTile& g, int NI, int ring, int ksplit, hipStream_t s);
 // will the kernel that runs this conv finish the norms consuming its output (ConvArgs::n_gno set; cg[k]: their group sizes)?
 bool conv_gn_direct_query(int dtype, const ConvArgs& a, const int* cg, int n);
+bool conv_gn_direct_ws_query(int dtype, const ConvArgs& a, const int* cg, int n);  // a.gn_cg: the output tensor's own group size
 // software-pipelined 1x1 variant (conv1x1_pipe.hip); preferred for taps == 1
 bool conv1x1_pipe_supported(int dtype, const ConvArgs& a);
 int launch_conv1x1_pipe(int dtype, const ConvArgs& a, hipStream_t s);

@@ -261,9 +261,12 @@ __device__ __forceinline__ void conv_epilogue_res_prefetch(const ConvArgs& a, in
         if (res) pre[q] = *reinterpret_cast<const uint4*>(res + pix_of(m) * a.Cout + co0 + cg * VEC);
     }
 }
+// direct_pass (wave-specialised kernel, whole-image tiles stored in two passes): -1 - statistics leave as partials; 0 - first pass, the
+// group threads keep their (mean, M2) in `carry`; 1 - second pass: merged with the carry, and the consuming norms (ConvArgs::gno) get
+// their scale / shift / {mean, rstd} rows from here - no finalize launch.
 template <typename T, int BM, int BN, int NT, typename PixFn>
 __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, int co0, int n0, PixFn pix_of, float* stage, int tile_s,
-                                                    const uint4* pre = nullptr) {
+                                                    const uint4* pre = nullptr, int direct_pass = -1, float* carry = nullptr) {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int VPR = BN / VEC;  // vectors per pixel row of the tile
     T* __restrict__ dst = (T*)a.dst;
@@ -321,7 +324,7 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, int co0, 
     } else {
         for (int it = threadIdx.x; it < BM * VPR; it += NT) item(it, nullptr);
     }
-    if (a.gn_part) {
+    if (a.gn_part || direct_pass >= 0) {
         // per-thread (mean, M2) from <= 64 values (negligible cancellation), exchanged through LDS and merged
         // with Chan's formula by one thread per group.  TN == 1: the tile is one image.
         const int cgs = a.gn_cg;
@@ -384,10 +387,46 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, int co0, 
                     M2 += q[1] + delta * delta * (na * cnt * rt);
                     na = tot;
                 }
-            const int G = a.Cout / cgs;
-            float* o = a.gn_part + (((int64_t)n0 * a.gn_tiles + tile_s) * G + (co0 / cgs + g)) * 2;
-            o[0] = mean;
-            o[1] = M2;
+            if (direct_pass < 0) {
+                const int G = a.Cout / cgs;
+                float* o = a.gn_part + (((int64_t)n0 * a.gn_tiles + tile_s) * G + (co0 / cgs + g)) * 2;
+                o[0] = mean;
+                o[1] = M2;
+            } else if (direct_pass == 0) {
+                carry[0] = mean;
+                carry[1] = M2;
+            } else {
+                // the image's two halves (equal counts), then for each consuming norm its group = f adjacent groups of this tensor
+                // (neighbouring threads of wave 0: equal counts again)
+                const float d0 = carry[0] - mean;
+                float m2f = M2 + carry[1] + d0 * d0 * (0.5f * na), meanf = 0.5f * (mean + carry[0]), nf = 2.f * na;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    if (k >= a.n_gno) break;
+                    const GnOut& Gk = a.gno[k];
+                    const int f = Gk.cg / cgs;
+                    float mk = meanf, m2k = m2f, nk = nf;
+                    for (int o = 1; o < f; o <<= 1) {
+                        const float om = __shfl_xor(mk, o, 64), o2 = __shfl_xor(m2k, o, 64);
+                        const float d = om - mk;
+                        m2k += o2 + d * d * (0.5f * nk);
+                        mk = 0.5f * (mk + om);
+                        nk *= 2.f;
+                    }
+                    const float rstd = 1.0f / sqrtf(m2k / nk + a.gn_eps);
+                    const int c_first = Gk.c_off + co0 + g * cgs;
+                    if (g % f == 0) {
+                        float* o = Gk.mean_rstd + ((int64_t)n0 * (Gk.C / Gk.cg) + c_first / Gk.cg) * 2;
+                        o[0] = mk;
+                        o[1] = rstd;
+                    }
+                    for (int j = 0; j < cgs; ++j) {
+                        const float sc = rstd * Gk.gamma[c_first + j];
+                        Gk.scale[(int64_t)n0 * Gk.C + c_first + j] = sc;
+                        Gk.shift[(int64_t)n0 * Gk.C + c_first + j] = Gk.beta[c_first + j] - mk * sc;
+                    }
+                }
+            }
         }
     }
 }
@@ -414,6 +453,16 @@ __device__ __forceinline__ void conv_epilogue_store_direct(const ConvArgs& a, in
     float* ssh = ssc + 1024;
     T* __restrict__ dst = (T*)a.dst;
     const T* __restrict__ res = (const T*)a.res1;
+    // gamma / beta of this thread's first (image, channel) go out now: they do not depend on the statistics, and fetched after them
+    // they were an exposed round trip at the end of every tile
+    float gm0[2] = {0.f, 0.f}, bt0[2] = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (k < a.n_gno) {
+            const int cc = a.gno[k].c_off + co0 + tid % BN;
+            gm0[k] = a.gno[k].gamma[cc];
+            bt0[k] = a.gno[k].beta[cc];
+        }
     uint4 kept[ITEMS];  // the stored vectors (for act)
 #pragma unroll
     for (int q = 0; q < ITEMS; ++q) {
@@ -543,7 +592,8 @@ __device__ __forceinline__ void conv_epilogue_store_direct(const ConvArgs& a, in
             const GnOut& G = a.gno[k];
             const float* q = mr + (k * 256 + tn * VPR + c / VEC) * 2;
             const int cc = G.c_off + co0 + c;
-            const float sc = q[1] * G.gamma[cc], sh = G.beta[cc] - q[0] * sc;
+            const float gm = idx == tid ? gm0[k] : G.gamma[cc], bt = idx == tid ? bt0[k] : G.beta[cc];
+            const float sc = q[1] * gm, sh = bt - q[0] * sc;
             if (n0 + tn < a.N) {
                 G.scale[(int64_t)(n0 + tn) * G.C + cc] = sc;
                 G.shift[(int64_t)(n0 + tn) * G.C + cc] = sh;

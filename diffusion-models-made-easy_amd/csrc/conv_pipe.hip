@@ -419,6 +419,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
     if (K > 1) WS_FILL_PAR(1)
     __syncthreads();
     const int mTW = (1 << shTW) - 1, mTH = (1 << shTH) - 1;
+    float gn_carry[2] = {0.f, 0.f};  // whole-image tiles finishing their norms: the group threads' first-pass (mean, M2)
     const bool estamp = tid == 0 && blockIdx.x == 0;  // diagnostic stamps of the epilogue passes (consumer wave 0, workgroup 0)
     int e_i = 0;
     // tile epilogue, 128 pixels per pass through R1|R2|A1: the consumer waves owning the pass's rows stage their
@@ -439,7 +440,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         WS_ESTAMP()                                                                                                                \
         __syncthreads();                                                                                                           \
         WS_ESTAMP()                                                                                                                \
-        conv_epilogue_store<T, 128, BN, 512>(a, (TT).co0, (TT).n0, pix_of, stage, 2 * (TT).ts + p, rpre);                          \
+        conv_epilogue_store<T, 128, BN, 512>(a, (TT).co0, (TT).n0, pix_of, stage, 2 * (TT).ts + p, rpre, a.n_gno ? p : -1, gn_carry); \
         WS_ESTAMP()                                                                                                                \
         __syncthreads(); /* everyone is done with the staging area */                                                              \
     }
@@ -876,7 +877,7 @@ bool conv_gn_direct_query(int dtype, const ConvArgs& a, const int* cg, int n) {
     if (a.out_silu || a.out_nchw || a.res2 || a.Cout % VEC || HW > 64 || (HW & (HW - 1))) return false;
     if (dtype == DMME_BF16 && !getenv("DMME_NO_WS")) {
         ConvTile gw{};
-        if (ws_pick(a, gw)) return false;
+        if (ws_pick(a, gw)) return false;  // (conv_gn_direct_ws_query answers for that kernel)
     }
     ConvArgs b = a;  // would the split-K heuristic (few workgroups) take this conv?  then it keeps that path
     b.n_gno = 0;
@@ -901,6 +902,22 @@ bool conv_gn_direct_query(int dtype, const ConvArgs& a, const int* cg, int n) {
     if (HW < 64 / (BN / VEC)) return false;  // a wave's pixels per channel vector must not straddle images
     for (int k = 0; k < n; ++k)
         if (cg[k] % VEC || BN % cg[k]) return false;
+    return true;
+}
+
+// the wave-specialised kernel: its 256-pixel tile is a whole 16x16 image, stored in two passes whose statistics it merges itself
+// (scale / shift / {mean, rstd} only - the first pass is in memory before the statistics exist, so no pre-activated output)
+bool conv_gn_direct_ws_query(int dtype, const ConvArgs& a, const int* cg, int n) {
+    static const bool off = getenv("DMME_NO_GN_DIRECT") != nullptr || getenv("DMME_NO_GN_DIRECT_WS") != nullptr;
+    if (off || dtype != DMME_BF16 || getenv("DMME_NO_WS") || n < 1 || n > 2 || !conv_pipe_supported(dtype, a)) return false;
+    ConvTile gw{};
+    if (!ws_pick(a, gw) || gw.TH != a.Hout || gw.TW != a.Wout || gw.TH * gw.TW != 256) return false;
+    const int cgs = a.gn_cg;  // this tensor's own group size
+    if (cgs < 8 || cgs % 8 || 128 % cgs || !stats_tile_ok(a, gw, 128, cgs, 8)) return false;
+    for (int k = 0; k < n; ++k) {
+        const int f = cg[k] / cgs;
+        if (cg[k] % cgs || (f != 1 && f != 2 && f != 4) || 128 % cg[k]) return false;
+    }
     return true;
 }
 

@@ -764,6 +764,7 @@ void fill_conv(const dmme_plan* P, const Op& o, const char* packed, const float*
     if (fwd && o.gd_n > 0) {
         a.n_gno = o.gd_n;
         a.gn_eps = 1e-5f;
+        a.gn_cg = P->tensors[o.dst].C / P->cfg.num_groups;
         for (int k = 0; k < o.gd_n; ++k) {
             const Op& g = P->ops[o.gd_gn[k]];
             GnOut& G = a.gno[k];
@@ -948,7 +949,9 @@ void assign_direct(dmme_plan* P) {
             if (g.gn_mod_col >= 0 || C % G || uses[t][k].coff % (C / G)) ok = false;
             cgs[k] = C / G;
         }
+        a.gn_cg = P->tensors[t].C / G;
         if (ok && conv_gn_direct_query(P->dtype, a, cgs, (int)uses[t].size())) elig[t] = 1;
+        else if (ok && P->tensors[t].C % G == 0 && conv_gn_direct_ws_query(P->dtype, a, cgs, (int)uses[t].size())) elig[t] = 2;  // no act output
     }
     for (bool changed = true; changed;) {  // a norm needs all its sources, a tensor all its norms
         changed = false;
@@ -987,7 +990,7 @@ void assign_direct(dmme_plan* P) {
         Op& g = P->ops[cv.gn];
         if (!g.gn_direct || g.gn_src2 >= 0 || g.gn_act >= 0 || g.gn_src1 != cv.src1 || cv.src2 >= 0) continue;
         Op& pr = P->ops[producer[g.gn_src1]];
-        if (pr.gd_act >= 0) continue;  // one pre-activated output per producer
+        if (pr.gd_act >= 0 || elig[g.gn_src1] != 1) continue;  // one pre-activated output per producer; not from the two-pass kernel
         for (int k = 0; k < pr.gd_n; ++k)
             if (pr.gd_gn[k] == cv.gn) pr.gd_act = k;
         if (pr.gd_act < 0) continue;

@@ -40,7 +40,7 @@ def _run(net, x, t, direct):
     return y, n
 
 
-@pytest.mark.parametrize("precision,atol_ref,rel_ab,fewer", [("fp32", 1e-5, 2e-6, 8), ("bf16", 1.36e-2, 6e-3, 20)])
+@pytest.mark.parametrize("precision,atol_ref,rel_ab,fewer", [("fp32", 1e-5, 2e-6, 8), ("bf16", 1.36e-2, 1.0e-2, 20)])
 def test_batch128_direct_groupnorm_vs_reference_and_vs_launched_norms(golden, precision, atol_ref, rel_ab, fewer):
     g = golden("unet_full")
     seed = int(g["full_seed"])

@@ -599,14 +599,19 @@ __global__ void __launch_bounds__(256) l2_stream_dma_kernel(const uint4* __restr
     (void)wave;
     unsigned acc = 0;
     for (int it = 0; it < iters; ++it) {
+        int gbase = 0;  // gather mode: first row of this batch, in vectors
         for (int base = 0; base + DEPTH * 256 <= nvec; base += DEPTH * 256) {
+            if (row_stride) {
+                gbase += DEPTH * 32 * row_stride;
+                if (gbase + (DEPTH * 32 + 32) * row_stride >= nvec) gbase = 0;
+            }
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
 #if defined(__HIP_DEVICE_COMPILE__)
                 const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(size_t)(l2s_lds_c*)lds + (unsigned)((d * 4 + wave) * 1024)));
                 // row_stride > 0: the convolutions' access shape - a wave instruction gathers eight 128-byte rows `row_stride` vectors apart
-                const int idx = row_stride ? (int)(((unsigned)(base / 8 + d * 32 + (tid >> 3)) * (unsigned)row_stride + (unsigned)(tid & 7)) % (unsigned)nvec)
-                                           : base + d * 256 + tid;
+                // (cheap addressing: a per-lane offset plus a uniform base that wraps by compare - no division in the loop)
+                const int idx = row_stride ? gbase + (d * 32 + (tid >> 3)) * row_stride + (tid & 7) : base + d * 256 + tid;
                 __builtin_amdgcn_global_load_lds(buf + idx, (l2s_lds_c*)(size_t)l, 16, 0, 0);
 #endif
             }

@@ -7,7 +7,7 @@
 // The group sums follow from the channel sums, so no per-group reduction over pixels is needed.
 #include <stdlib.h>
 
-#include "common.h"
+#include "conv_common.h"
 
 namespace dmme {
 
@@ -430,7 +430,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ mean_rstd, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ dmask, int pro_silu,
                                                            const float* __restrict__ S, int chunk_px, int ppw, T* __restrict__ dx1, T* __restrict__ dx2,
-                                                           int acc1, int acc2, GnMod mod) {
+                                                           int acc1, int acc2, GnMod mod, T* __restrict__ act) {
     constexpr int EPV = 16 / sizeof(T);
     const int C = C1 + C2, tid = threadIdx.x, VPP = C / EPV, slot = tid % VPP, prow = tid / VPP;
     if (prow >= ppw) return;
@@ -469,6 +469,8 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
             o[j] = acc ? o[j] + dx : dx;                                                  \
         }                                                                                 \
         store_vec<T>(dst + (p0 + (PP)) * Cs + cs0, o);                                    \
+        if (act) /* the conv's pre-activated input, for the deferred weight gradient: the forward's own prologue on the same bits */ \
+            *reinterpret_cast<uint4*>(act + (p0 + (PP)) * C + c0) = prologue_vec<T>(RX, sc, sh, dmask ? dm : nullptr, pro_silu); \
     }
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
     int p = prow;
@@ -543,7 +545,7 @@ __global__ void __launch_bounds__(256) gn_bwd_small_kernel(const T* __restrict__
                                                            int C2, int groups, const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ dmask, int pro_silu, T* __restrict__ dx1, T* __restrict__ dx2,
-                                                           int acc1, int acc2, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                           int acc1, int acc2, float* __restrict__ dgamma, float* __restrict__ dbeta, T* __restrict__ act) {
     constexpr int EPV = 16 / sizeof(T);
     __shared__ float red[256 * EPV * 2];
     __shared__ float chA[512], chB[512], gS1[64], gS2[64];
@@ -652,6 +654,7 @@ __global__ void __launch_bounds__(256) gn_bwd_small_kernel(const T* __restrict__
             o[j] = acc ? o[j] + dx : dx;                                                  \
         }                                                                                 \
         store_vec<T>(dst + (p0 + (PP)) * Cs + cs0, o);                                    \
+        if (act) *reinterpret_cast<uint4*>(act + (p0 + (PP)) * C + c0) = prologue_vec<T>(RX, sc, sh, dmask ? dm : nullptr, pro_silu); \
     }
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
     int p = prow;
@@ -703,14 +706,14 @@ bool gn_bwd_fast_supported(int dtype, int HW, int C1, int C2) {
 int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2, int N, int HW, int C1, int C2, int groups,
                        const float* gamma, const float* mean_rstd, const float* scale, const float* shift, const float* dmask,
                        int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, float* AB, float* S, GnMod mod,
-                       hipStream_t s) {
+                       hipStream_t s, void* act) {
     if (!mod.t_scale && gn_bwd_small_supported(dtype, HW, C1, C2, groups)) {
         if (dtype == DMME_BF16)
             hipLaunchKernelGGL(gn_bwd_small_kernel<bf16>, dim3(N), dim3(256), 0, s, (const bf16*)dv, (const bf16*)x1, (const bf16*)x2, HW, C1, C2, groups,
-                               gamma, mean_rstd, scale, shift, dmask, pro_silu, (bf16*)dx1, (bf16*)dx2, acc1, acc2, dgamma, dbeta);
+                               gamma, mean_rstd, scale, shift, dmask, pro_silu, (bf16*)dx1, (bf16*)dx2, acc1, acc2, dgamma, dbeta, (bf16*)act);
         else
             hipLaunchKernelGGL(gn_bwd_small_kernel<float>, dim3(N), dim3(256), 0, s, (const float*)dv, (const float*)x1, (const float*)x2, HW, C1, C2,
-                               groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, (float*)dx1, (float*)dx2, acc1, acc2, dgamma, dbeta);
+                               groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, (float*)dx1, (float*)dx2, acc1, acc2, dgamma, dbeta, (float*)act);
         DMME_CHECK_LAUNCH();
         return DMME_OK;
     }
@@ -730,10 +733,10 @@ int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2
     DMME_CHECK_LAUNCH();
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dv, (const bf16*)x1, (const bf16*)x2, HW, C1, C2, groups,
-                           gamma, mean_rstd, scale, shift, dmask, pro_silu, S, chunk_px, ppw, (bf16*)dx1, (bf16*)dx2, acc1, acc2, mod);
+                           gamma, mean_rstd, scale, shift, dmask, pro_silu, S, chunk_px, ppw, (bf16*)dx1, (bf16*)dx2, acc1, acc2, mod, (bf16*)act);
     else
         hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)dv, (const float*)x1, (const float*)x2, HW, C1, C2,
-                           groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, S, chunk_px, ppw, (float*)dx1, (float*)dx2, acc1, acc2, mod);
+                           groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, S, chunk_px, ppw, (float*)dx1, (float*)dx2, acc1, acc2, mod, (float*)act);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }

@@ -286,6 +286,8 @@ struct WgLayer {
     int64_t dmask_off;             // floats into the drop-mask buffer (-1: none)
     int64_t dy_off;                // bytes into the backward workspace: gradient of the conv output
     int64_t dw_off;                // floats into the packed weight-gradient image
+    int64_t act_off;               // the conv's pre-activated input [N][Hin][Win][C1 + C2] (-1: none - src1 / src2 + prologue), bytes into
+    int act_bws;                   //   the backward workspace (written by the GroupNorm backward) or the forward one (written by the forward)
     int N, Hin, Win, C1, C2, up, Hout, Wout, Cout, pro_silu;
     int shTW, shTH;
     int ks_off[4], half_off;       // LDS byte offsets of tile pixels 16*ks and 4 relative to pixel 0 (input tile rows)
@@ -358,7 +360,7 @@ int gn_bwd_fast_chunks(int dtype, int HW, int C);
 int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2, int N, int HW, int C1, int C2, int groups,
                        const float* gamma, const float* mean_rstd, const float* scale, const float* shift, const float* dmask,
                        int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, float* AB_zeroed,
-                       float* S_scratch, GnMod mod, hipStream_t s);
+                       float* S_scratch, GnMod mod, hipStream_t s, void* act = nullptr);
 bool grad_acc_fast_supported(int dtype, int C1, int C2, int pool);
 int launch_grad_acc_fast(int dtype, const void* src, void* d1, void* d2, int C1, int C2, int acc1, int acc2, int64_t npix, hipStream_t s);
 int launch_grad_acc(int dtype, const void* src, void* d1, void* d2, int C1, int C2, int acc1, int acc2, int pool, int N, int H, int W,

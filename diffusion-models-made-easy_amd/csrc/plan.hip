@@ -79,6 +79,8 @@ struct Op {
     int gd_n = 0, gd_gn[2] = {-1, -1}, gd_coff[2] = {0, 0};  // norms this conv's forward epilogue finishes (op index, channel offset in the norm)
     int gd_act = -1;           // which of them also gets the consumer's pre-activated input written (-1: none)
     int wg_layer = -1;         // index into the grouped weight-gradient table of its kernel size (-1: per-layer kernels)
+    int64_t wg_act = -1;       // backward workspace offset of its pre-activated input, written by its GroupNorm's backward for the
+                               // deferred weight gradient (-1: none)
     int bias_deferred = 0;     // its bias / time-projection reduction runs in the grouped launch
     // OP_ATTN
     int at_qkv = -1, at_out = -1, at_heads = 1;
@@ -820,6 +822,24 @@ void build_wgrad_group(dmme_plan* P, dmme_plan::WgGroup& G, int taps, int op_lo 
         L.scale_off = o.gn >= 0 ? P->ops[o.gn].gn_scale : -1;
         L.shift_off = o.gn >= 0 ? P->ops[o.gn].gn_shift : -1;
         L.dmask_off = o.dmask_off;
+        // The weight gradient's second operand is the conv's ACTIVATED input.  Recomputing GroupNorm + SiLU + dropout per MFMA operand
+        // made the grouped kernel VALU-issue bound; instead it reads the activated tensor: the forward's own (small maps, use_act), or
+        // one the GroupNorm backward of this conv writes on its way (it holds x, scale, shift and the mask anyway: one more store).
+        L.act_off = -1;
+        L.act_bws = 0;
+        if (taps == 9 && o.gn >= 0 && !getenv("DMME_NO_WG_ACT")) {
+            const Op& gop = P->ops[o.gn];
+            if (o.use_act && gop.gn_act >= 0) {
+                L.act_off = gop.gn_act;
+            } else if (gop.gn_src1 == o.src1 && gop.gn_src2 == o.src2 && gn_bwd_fast_supported(P->dtype, a.Hin * a.Win, a.C1, a.C2)) {
+                if (o.wg_act < 0) {
+                    o.wg_act = align_up(P->bws_bytes, 256);
+                    P->bws_bytes = o.wg_act + (int64_t)P->B * a.Hin * a.Win * (a.C1 + a.C2) * (int64_t)dtype_size(P->dtype);
+                }
+                L.act_off = o.wg_act;
+                L.act_bws = 1;
+            }
+        }
         L.dy_off = P->gt_off[o.dst];
         L.dw_off = P->params[o.w].wp_off;
         o.wg_layer = (int)G.layers.size();
@@ -1633,7 +1653,8 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
                     rc = launch_gn_bwd_fast(dt, tmp, a.src1, a.src2, B, t1.H * t1.W, a.C1, a.C2, G,
                                             (const float*)(pk + P->params[gop.gn_gamma].packed_off), (const float*)(ws + gop.gn_mr), a.scale,
                                             a.shift, a.dmask, a.pro_silu, g1, g2, acc1, acc2, grad_flat + P->params[gop.gn_gamma].ref_off,
-                                            grad_flat + P->params[gop.gn_beta].ref_off, (float*)(bws + o.b_ab), (float*)(bws + P->bws_gnS), mod, s);
+                                            grad_flat + P->params[gop.gn_beta].ref_off, (float*)(bws + o.b_ab), (float*)(bws + P->bws_gnS), mod, s,
+                                            o.wg_act >= 0 ? bws + o.wg_act : nullptr);
                 else
                 rc = launch_gn_bwd_generic(dt, tmp, a.src1, a.src2, B, t1.H * t1.W, a.C1, a.C2, G,
                                            (const float*)(pk + P->params[gop.gn_gamma].packed_off), (const float*)(ws + gop.gn_mr),

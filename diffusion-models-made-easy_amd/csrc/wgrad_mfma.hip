@@ -218,12 +218,12 @@ __global__ void __launch_bounds__(256, 2) wgrad_group_kernel(const WgLayer* __re
     const ConvTile g = L.g;
     const int shTW = L.shTW, shTH = L.shTH;
     const int N = L.N, Hin = L.Hin, Win = L.Win, C1 = L.C1, C2 = L.C2, up = L.up, Hout = L.Hout, Wout = L.Wout, Cout = L.Cout;
-    const int pro_silu = L.pro_silu;
+    const int pro_silu = L.act_off >= 0 ? 0 : L.pro_silu;
     const T* dY = (const T*)(bws + L.dy_off);
     float* dWp = wimage + L.dw_off;
-    const float* scale = L.scale_off >= 0 ? (const float*)(ws + L.scale_off) : nullptr;
-    const float* shift = L.scale_off >= 0 ? (const float*)(ws + L.shift_off) : nullptr;
-    const float* dmask = (drop_masks && L.dmask_off >= 0) ? drop_masks + L.dmask_off : nullptr;
+    const float* scale = L.scale_off >= 0 && L.act_off < 0 ? (const float*)(ws + L.scale_off) : nullptr;
+    const float* shift = scale ? (const float*)(ws + L.shift_off) : nullptr;
+    const float* dmask = (drop_masks && L.dmask_off >= 0 && L.act_off < 0) ? drop_masks + L.dmask_off : nullptr;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wco = (wave >> 1) * 32 * WM, wci = (wave & 1) * 32 * WN;
@@ -233,9 +233,10 @@ __global__ void __launch_bounds__(256, 2) wgrad_group_kernel(const WgLayer* __re
     const int Hv = up ? 2 * Hin : Hin, Wv = up ? 2 * Win : Win;
     const int mTW = (1 << shTW) - 1, mTH = (1 << shTH) - 1;
     const int halo_px = g.HH * g.HWd;
-    const bool second = ci0 >= C1;
-    const T* sbase = (const T*)(ws + (second ? L.src2_off : L.src1_off));
-    const int Cs = second ? C2 : C1, cs0 = second ? ci0 - C1 : ci0;
+    const bool has_act = L.act_off >= 0;  // pre-activated input: one tensor over all C1 + C2 channels, nothing to apply
+    const bool second = !has_act && ci0 >= C1;
+    const T* sbase = has_act ? (const T*)((L.act_bws ? bws : ws) + L.act_off) : (const T*)(ws + (second ? L.src2_off : L.src1_off));
+    const int Cs = has_act ? C1 + C2 : second ? C2 : C1, cs0 = second ? ci0 - C1 : ci0;
     f32x16 acc[TAPS][WM][WN];
 #pragma unroll
     for (int k = 0; k < TAPS; ++k)

@@ -291,6 +291,7 @@ struct WgLayer {
     int N, Hin, Win, C1, C2, up, Hout, Wout, Cout, pro_silu;
     int shTW, shTH;
     int ks_off[4], half_off;       // LDS byte offsets of tile pixels 16*ks and 4 relative to pixel 0 (input tile rows)
+    int ks_row[4], half_row;       // the same in halo rows (the DMA-fed kernel's 128-byte swizzled rows)
     ConvTile g;
 };
 struct WgJob {
@@ -299,8 +300,10 @@ struct WgJob {
 // fills the geometry fields of L when the conv qualifies (offsets are the caller's)
 // co_tile / ci_tile: the job tile of the kernel that will run it (64x64 for 3x3, 128x128 for 1x1)
 bool wgrad_group_layer(int dtype, const ConvArgs& a, WgLayer& L, int* co_tile, int* ci_tile);
+// dma: every layer of the table has a single prologue-free operand tensor (WgLayer::act_off, or one source and no norm): both tiles
+// arrive by LDS-DMA; zero_page: >= 16 zero bytes in device memory (the source of padding rows)
 int launch_wgrad_group(int dtype, int taps, const WgLayer* layers_dev, const WgJob* jobs_dev, int njobs, const void* ws, const void* bws,
-                       const float* drop_masks, float* wimage, hipStream_t s);
+                       const float* drop_masks, float* wimage, hipStream_t s, int dma = 0, const void* zero_page = nullptr);
 int launch_wgrad_unpack(const PackItem* items_dev, int n_items, const float* image, float* grad_flat, hipStream_t s);
 int launch_colsum(int dtype, const void* dY, int N, int HW, int C, float* rowsum, float* dbias, float* dtproj, int ld, int nt,
                   hipStream_t s);

@@ -115,7 +115,7 @@ struct dmme_plan {
     int p_l1w = -1, p_l1b = -1, p_l2w = -1, p_l2b = -1;
     int64_t packed_bwd_bytes = 0, bws_bytes = 0;
     std::vector<int64_t> gt_off;           // gradient buffer of every forward tensor
-    int64_t bws_zero = 0, bws_zero_bytes = 0, bws_wimage = 0, bws_gnS = 0;  // region cleared once per backward
+    int64_t bws_zero = 0, bws_zero_bytes = 0, bws_wimage = 0, bws_gnS = 0, bws_zpage = 0;  // region cleared once per backward
     PackItem* items_unpack_dev = nullptr;
     int n_items_unpack = 0;
     int64_t bws_tmp = 0, bws_dy = 0, bws_rowsum = 0, bws_dtproj = 0, bws_dtemb = 0, bws_dh1 = 0, bws_z = 0, bws_attP = 0,
@@ -129,6 +129,7 @@ struct dmme_plan {
         std::vector<WgJob> jobs;
         WgLayer* layers_dev = nullptr;
         WgJob* jobs_dev = nullptr;
+        int dma = 0;  // every layer's second operand is one prologue-free tensor: the LDS-DMA kernel runs the table
     } wg[2];  // 3x3, 1x1
     // Two-bucket backward (gradient all-reduce overlapped with backward): bucket 0 = the parameters backward finishes first
     // (up_layers, middle_layers, output_conv: the contiguous tail of the flat buffer), bucket 1 = the rest.  Plan-time split of
@@ -593,6 +594,7 @@ int build_plan(dmme_plan* P) {
                 if (o.kind != OP_CONV) continue;
                 o.b_rowsum = balloc((int64_t)B * P->params[o.w].cout * 4);
             }
+            P->bws_zpage = balloc(256);  // a page of zeros: the padding rows of the DMA-fed weight gradient
             P->bws_zero_bytes = bw - P->bws_zero;
             for (Op& o : P->ops) {  // GroupNorm channel sums, one partial row per pixel chunk (written whole: outside the cleared region)
                 if (o.kind != OP_CONV || o.gn < 0) continue;
@@ -856,6 +858,9 @@ void build_wgrad_group(dmme_plan* P, dmme_plan::WgGroup& G, int taps, int op_lo 
             if (gr.ntiles > 0) groups.push_back(gr);
         }
     }
+    G.dma = taps == 9 && !G.layers.empty() && !getenv("DMME_NO_WG_DMA");
+    for (const WgLayer& L : G.layers)
+        if (!(L.act_off >= 0 || (L.C2 == 0 && L.scale_off < 0 && L.dmask_off < 0 && !L.pro_silu)) || L.Cout % 64) G.dma = 0;
     // All (cout tile, cin tile) jobs of one pixel range read the same dY and activation tiles: they go to ONE XCD
     // (consecutive positions of its round-robin slice of the grid, blockIdx % 8), so the re-reads hit that XCD's L2
     // instead of HBM.  Groups are placed longest first on the least-loaded XCD; short slices are padded with empty jobs.
@@ -1528,7 +1533,7 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
         for (int k = 0; k < 2; ++k) {
             const dmme_plan::WgGroup& G = b < 0 ? P->wg[k] : P->wgb[b][k];
             if (!G.jobs_dev) continue;
-            r = launch_wgrad_group(dt, G.taps, G.layers_dev, G.jobs_dev, (int)G.jobs.size(), ws, bws, drop_masks, wimage, s);
+            r = launch_wgrad_group(dt, G.taps, G.layers_dev, G.jobs_dev, (int)G.jobs.size(), ws, bws, drop_masks, wimage, s, G.dma, bws + P->bws_zpage);
             if (r != DMME_OK) return r;
         }
         {

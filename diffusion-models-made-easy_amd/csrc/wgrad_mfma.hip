@@ -360,6 +360,154 @@ __global__ void __launch_bounds__(256, 2) wgrad_group_kernel(const WgLayer* __re
             }
 }
 
+// ---- the same 3x3 job with BOTH operand tiles by LDS-DMA -------------------------------------------------------------------------
+// Once the activated input exists as a tensor (WgLayer::act_off), neither operand needs a register: the dY tile (64 pixels x 64 couts)
+// and the input halo tile (<= 160 rows x 64 cins) of tile t + 1 go global -> LDS into the other half of a double buffer while the MFMAs
+// of tile t run; padding rows read a page of zeros.  One workgroup barrier per tile, no VGPR staging, no ds_write, no prologue.
+// LDS layout [channel half][row][64 B]: a wave only ever reads the 32 channels of its own quadrant, and a transposed read touches 4
+// consecutive rows x 32 B - at a 64-byte pitch those cover disjoint banks with no padding or swizzle, and every fragment address of a
+// tile is (per-lane base) + (wave-uniform offset) + (immediate): under one VALU instruction per MFMA (the register-staged kernel spent
+// eight, which made it VALU-issue bound: 4 cycles each against the MFMA's 32).
+template <typename T>
+__global__ void __launch_bounds__(256, 2) wgrad_dma_kernel(const WgLayer* __restrict__ layers, const WgJob* __restrict__ jobs,
+                                                          const char* __restrict__ ws, const char* __restrict__ bws,
+                                                          const char* __restrict__ zero_page, float* __restrict__ wimage) {
+    static_assert(sizeof(T) == 2, "bf16 only");
+    constexpr int TAPS = 9, HB = 64;                       // bytes of one row of one channel half
+    constexpr int Y_HALF = WG_PX * HB, Y_BYTES = 2 * Y_HALF;  // 8 KB
+    constexpr int V_ROWS = 160, V_HALF = V_ROWS * HB, BUF = Y_BYTES + 2 * V_HALF, VU = 5;  // 28 KB per buffer; <= 20 halo DMA instructions
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const WgJob job = jobs[blockIdx.x];
+    if (job.ntiles <= 0) return;  // padding of a short XCD slice
+    const WgLayer& L = layers[job.layer];
+    const ConvTile g = L.g;
+    const int shTW = L.shTW, shTH = L.shTH;
+    const int Hin = L.Hin, Win = L.Win, up = L.up, Hout = L.Hout, Wout = L.Wout, Cout = L.Cout;
+    const int Cin = L.C1 + L.C2;
+    const char* dY = bws + L.dy_off;
+    const char* vbase = L.act_off >= 0 ? (L.act_bws ? bws : ws) + L.act_off : ws + L.src1_off;
+    float* dWp = wimage + L.dw_off;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;
+    const int r = lane & 31, h = lane >> 5;
+    const int co0 = job.cot * 64, ci0 = job.cit * 64;
+    const int Hv = up ? 2 * Hin : Hin, Wv = up ? 2 * Win : Win;
+    const int mTW = (1 << shTW) - 1, mTH = (1 << shTH) - 1;
+    const int halo_px = g.HH * g.HWd, HWo = Hout * Wout;
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[k][j] = 0.f;
+
+    // ---- DMA descriptors (tile-invariant).  Instruction j = wave + 4 k of a tile fills 16 rows of channel half (j & 1):
+    // lane -> row 16 (j >> 1) + (lane >> 2), 16-byte piece (lane & 3) of the half
+    const int prow = lane >> 2, piece = lane & 3;
+    unsigned y_off[2];  // byte offset of this lane's dY vector relative to the tile's first pixel
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int j = wave + 4 * k, m = 16 * (j >> 1) + prow;
+        const int tx = m & mTW, ty = (m >> shTW) & mTH, tn = m >> (shTW + shTH);
+        y_off[k] = (unsigned)(((tn * HWo + ty * Wout + tx) * Cout + co0 + (j & 1) * 32 + piece * 8) * 2);
+    }
+    int v_hy[VU], v_hx[VU], v_tn[VU];
+#pragma unroll
+    for (int k = 0; k < VU; ++k) {
+        const int j = wave + 4 * k, row = 16 * (j >> 1) + prow;
+        const int tn = (int)__umulhi((unsigned)row, g.magic_px), rem = row - tn * halo_px;
+        const int hy = (int)__umulhi((unsigned)rem, g.magic_w);
+        v_tn[k] = row < g.a_rows ? tn : -1;
+        v_hy[k] = hy;
+        v_hx[k] = rem - hy * g.HWd;
+    }
+    const int v_cb = (ci0 + (wave & 1) * 32 + piece * 8) * 2;  // (j & 1) == (wave & 1) for every k
+    const int n_vj = 2 * ((g.a_rows + 15) >> 4);              // halo DMA instructions of a tile
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lds_c*)lds);
+    auto issue_tile = [&](int tile, int buf) __attribute__((always_inline)) {
+        const int tx_blk = tile % g.tiles_x, ty_blk = (tile / g.tiles_x) % g.tiles_y;
+        const int n0 = (tile / (g.tiles_x * g.tiles_y)) * g.TN;
+        const int oy0 = ty_blk << shTH, ox0 = tx_blk << shTW;
+        const char* ybase = dY + (int64_t)((n0 * Hout + oy0) * Wout + ox0) * Cout * 2;  // wave-uniform
+        const unsigned lb = lds0 + (unsigned)(buf * BUF);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int j = wave + 4 * k;
+            glds16_hidden_s(ybase, y_off[k], lb + (unsigned)((j & 1) * Y_HALF + (j >> 1) * 1024));
+        }
+#pragma unroll
+        for (int k = 0; k < VU; ++k) {
+            const int j = wave + 4 * k;
+            if (j >= n_vj) break;  // wave-uniform
+            const int iy = oy0 - 1 + v_hy[k], ix = ox0 - 1 + v_hx[k];
+            const bool ok = v_tn[k] >= 0 && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+            const int sy = up ? (iy >> 1) : iy, sx = up ? (ix >> 1) : ix;
+            const int64_t off = (int64_t)(((n0 + v_tn[k]) * Hin + sy) * Win + sx) * Cin * 2 + v_cb;
+            const char* src = ok ? vbase + off : zero_page;
+            glds16_hidden(src, lb + (unsigned)(Y_BYTES + (j & 1) * V_HALF + (j >> 1) * 1024));
+        }
+    };
+
+    // ---- fragment addresses: lane (tr_q, tr_p, tr_g1) of a transposed read takes 8 bytes of row 8 h + tr_q (+ 4 for the second read) ----
+    const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g1 = (lane >> 4) & 1;
+    const unsigned colb = (unsigned)((16 * tr_g1 + 4 * tr_p) * 2);
+    const unsigned a_lane = (unsigned)((wco >> 5) * Y_HALF + (8 * h + tr_q) * HB) + colb;
+    unsigned b_lane;
+    {
+        const int m = 8 * h + tr_q;
+        const int tx = m & mTW, ty = (m >> shTW) & mTH, tn = m >> (shTW + shTH);
+        b_lane = (unsigned)(Y_BYTES + (wci >> 5) * V_HALF + ((tn * g.HH + ty) * g.HWd + tx) * HB) + colb;
+    }
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4_d;
+#define WGD_TR(ADDR, IMM) __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_d*)(size_t)((ADDR) + (IMM)))
+    const int row_b = g.HWd * HB, half_b = L.half_row * HB;
+    int ks_b[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ks_b[ks] = L.ks_row[ks] * HB;
+
+    const int tile_end = job.tile0 + job.ntiles;
+    issue_tile(job.tile0, 0);
+    int buf = 0;
+#pragma unroll 1
+    for (int tile = job.tile0; tile < tile_end; ++tile) {
+        wait_vm_all();     // this wave's share of tile `tile` has landed (nothing younger is in flight)
+        __syncthreads();   // everyone's has - and everyone is done reading the other buffer
+        if (tile + 1 < tile_end) issue_tile(tile + 1, buf ^ 1);
+        const unsigned base = lds0 + (unsigned)(buf * BUF);
+        const unsigned ya = base + a_lane, va = base + b_lane;
+#pragma unroll
+        for (int ks = 0; ks < WG_PX / 16; ++ks) {
+            const s16x4 alo = WGD_TR(ya, ks * 16 * HB), ahi = WGD_TR(ya, ks * 16 * HB + 4 * HB);
+            s16x8 af;
+            af[0] = alo[0]; af[1] = alo[1]; af[2] = alo[2]; af[3] = alo[3];
+            af[4] = ahi[0]; af[5] = ahi[1]; af[6] = ahi[2]; af[7] = ahi[3];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const unsigned vlo = va + (unsigned)(ks_b[ks] + dy * row_b), vhi = vlo + (unsigned)half_b;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const s16x4 lo = WGD_TR(vlo, dx * HB), hi = WGD_TR(vhi, dx * HB);
+                    s16x8 bfr;
+                    bfr[0] = lo[0]; bfr[1] = lo[1]; bfr[2] = lo[2]; bfr[3] = lo[3];
+                    bfr[4] = hi[0]; bfr[5] = hi[1]; bfr[6] = hi[2]; bfr[7] = hi[3];
+                    acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bfr),
+                                                                              acc[dy * 3 + dx], 0, 0, 0);
+                }
+            }
+        }
+        buf ^= 1;
+    }
+#undef WGD_TR
+    const int ci = ci0 + wci + r;
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int co = co0 + wco + (j & 3) + 8 * (j >> 2) + 4 * h;
+            if (co < Cout) atomicAdd(dWp + ((int64_t)co * TAPS + tap) * Cin + ci, acc[tap][j]);
+        }
+}
+
 static bool wg_tile(const ConvArgs& a, ConvTile& g) {
     if (!make_tile(a, WG_PX, 64, g)) return false;
     if (g.TW < 4) return false;  // 4-pixel transposed-read blocks must stay inside one tile row
@@ -453,8 +601,12 @@ bool wgrad_group_layer(int dtype, const ConvArgs& a, WgLayer& L, int* co_tile, i
         const int tx = m & (g.TW - 1), ty = (m >> L.shTW) & (g.TH - 1), tn = m >> (L.shTW + L.shTH);
         return (tn * g.HH + ty) * g.HWd + tx;
     };
-    for (int ks = 0; ks < 4; ++ks) L.ks_off[ks] = row_of(16 * ks) * VP;
+    for (int ks = 0; ks < 4; ++ks) {
+        L.ks_off[ks] = row_of(16 * ks) * VP;
+        L.ks_row[ks] = row_of(16 * ks);
+    }
     L.half_off = row_of(4) * VP;
+    L.half_row = row_of(4);
     L.N = a.N; L.Hin = a.Hin; L.Win = a.Win; L.C1 = a.C1; L.C2 = a.C2; L.up = a.up;
     L.Hout = a.Hout; L.Wout = a.Wout; L.Cout = a.Cout; L.pro_silu = a.pro_silu;
     *co_tile = CO;
@@ -463,9 +615,17 @@ bool wgrad_group_layer(int dtype, const ConvArgs& a, WgLayer& L, int* co_tile, i
 }
 
 int launch_wgrad_group(int dtype, int taps, const WgLayer* layers_dev, const WgJob* jobs_dev, int njobs, const void* ws, const void* bws,
-                       const float* drop_masks, float* wimage, hipStream_t s) {
+                       const float* drop_masks, float* wimage, hipStream_t s, int dma, const void* zero_page) {
     DMME_REQUIRE(dtype == DMME_BF16 && (taps == 9 || taps == 1), DMME_ERR_UNSUPPORTED, "grouped weight gradient: bf16, 3x3 or 1x1 only");
     if (njobs <= 0) return DMME_OK;
+    if (taps == 9 && dma && zero_page) {
+        constexpr size_t lds = 2 * (WG_PX * 128 + 160 * 128);
+        static_assert(lds <= 64 * 1024, "two workgroups per CU");
+        hipLaunchKernelGGL((wgrad_dma_kernel<bf16>), dim3((unsigned)njobs), dim3(256), lds, s, layers_dev, jobs_dev, (const char*)ws, (const char*)bws,
+                           (const char*)zero_page, wimage);
+        DMME_CHECK_LAUNCH();
+        return DMME_OK;
+    }
     if (taps == 9) {
         constexpr size_t lds = WgGroupGeom<9, 1, 1>::LDS;
         static_assert(lds <= 64 * 1024, "LDS tile");

@@ -829,7 +829,7 @@ void build_wgrad_group(dmme_plan* P, dmme_plan::WgGroup& G, int taps, int op_lo 
         // one the GroupNorm backward of this conv writes on its way (it holds x, scale, shift and the mask anyway: one more store).
         L.act_off = -1;
         L.act_bws = 0;
-        if (taps == 9 && o.gn >= 0 && !getenv("DMME_NO_WG_ACT")) {
+        if (o.gn >= 0 && !getenv("DMME_NO_WG_ACT")) {
             const Op& gop = P->ops[o.gn];
             if (o.use_act && gop.gn_act >= 0) {
                 L.act_off = gop.gn_act;
@@ -858,9 +858,11 @@ void build_wgrad_group(dmme_plan* P, dmme_plan::WgGroup& G, int taps, int op_lo 
             if (gr.ntiles > 0) groups.push_back(gr);
         }
     }
-    G.dma = taps == 9 && !G.layers.empty() && !getenv("DMME_NO_WG_DMA");
+    G.dma = !G.layers.empty() && !getenv("DMME_NO_WG_DMA");
     for (const WgLayer& L : G.layers)
-        if (!(L.act_off >= 0 || (L.C2 == 0 && L.scale_off < 0 && L.dmask_off < 0 && !L.pro_silu)) || L.Cout % 64) G.dma = 0;
+        if (!(L.act_off >= 0 || ((L.C2 == 0 || taps == 1) && L.scale_off < 0 && L.dmask_off < 0 && !L.pro_silu)) || L.Cout % (taps == 9 ? 64 : 128) ||
+            (taps == 1 && (L.C1 + L.C2) % 128))
+            G.dma = 0;
     // All (cout tile, cin tile) jobs of one pixel range read the same dY and activation tiles: they go to ONE XCD
     // (consecutive positions of its round-robin slice of the grid, blockIdx % 8), so the re-reads hit that XCD's L2
     // instead of HBM.  Groups are placed longest first on the least-loaded XCD; short slices are padded with empty jobs.

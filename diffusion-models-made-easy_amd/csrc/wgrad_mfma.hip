@@ -508,6 +508,113 @@ __global__ void __launch_bounds__(256, 2) wgrad_dma_kernel(const WgLayer* __rest
         }
 }
 
+// ---- 1x1 jobs (128 couts x 128 cins) the same way: no halo, both tiles are 64 pixels x 128 channels in [channel quarter][pixel][64 B] ----
+template <typename T>
+__global__ void __launch_bounds__(256, 2) wgrad_dma1_kernel(const WgLayer* __restrict__ layers, const WgJob* __restrict__ jobs,
+                                                           const char* __restrict__ ws, const char* __restrict__ bws, float* __restrict__ wimage) {
+    static_assert(sizeof(T) == 2, "bf16 only");
+    constexpr int HB = 64, QB = WG_PX * HB, TILE = 4 * QB, BUF = 2 * TILE;  // 4 KB per quarter, 16 KB per operand tile, 32 KB per buffer
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const WgJob job = jobs[blockIdx.x];
+    if (job.ntiles <= 0) return;
+    const WgLayer& L = layers[job.layer];
+    const ConvTile g = L.g;
+    const int shTW = L.shTW, shTH = L.shTH;
+    const int Hout = L.Hout, Wout = L.Wout, Cout = L.Cout, Cin = L.C1 + L.C2;
+    const char* dY = bws + L.dy_off;
+    const int co0 = job.cot * 128, ci0 = job.cit * 128;
+    // the job's 128 input channels: the activated tensor, or (no norm in front of the conv) one of the two concatenated sources
+    const bool has_act = L.act_off >= 0, second = !has_act && ci0 >= L.C1;
+    const char* vbase = has_act ? (L.act_bws ? bws : ws) + L.act_off : ws + (second ? L.src2_off : L.src1_off);
+    const int Cs = has_act ? Cin : second ? L.C2 : L.C1, cs0 = second ? ci0 - L.C1 : ci0;
+    float* dWp = wimage + L.dw_off;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int mTW = (1 << shTW) - 1, mTH = (1 << shTH) - 1;
+    const int HWo = Hout * Wout;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
+    // DMA: instruction j = wave + 4 k (k < 4) of an operand tile fills 16 pixels of channel quarter (j & 3) = wave: rows 16 k + (lane >> 2)
+    const int prow = lane >> 2, piece = lane & 3;
+    unsigned y_off[4], v_off[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int m = 16 * k + prow;
+        const int tx = m & mTW, ty = (m >> shTW) & mTH, tn = m >> (shTW + shTH);
+        const int pix = tn * HWo + ty * Wout + tx;
+        y_off[k] = (unsigned)((pix * Cout + co0 + wave * 32 + piece * 8) * 2);
+        v_off[k] = (unsigned)((pix * Cs + cs0 + wave * 32 + piece * 8) * 2);
+    }
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lds_c*)lds);
+    auto issue_tile = [&](int tile, int buf) __attribute__((always_inline)) {
+        const int tx_blk = tile % g.tiles_x, ty_blk = (tile / g.tiles_x) % g.tiles_y;
+        const int n0 = (tile / (g.tiles_x * g.tiles_y)) * g.TN;
+        const int64_t p0 = (int64_t)((n0 * Hout + (ty_blk << shTH)) * Wout + (tx_blk << shTW));
+        const char* ybase = dY + p0 * Cout * 2;
+        const char* xbase = vbase + p0 * Cs * 2;
+        const unsigned lb = lds0 + (unsigned)(buf * BUF + wave * QB);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) glds16_hidden_s(ybase, y_off[k], lb + (unsigned)(k * 1024));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) glds16_hidden_s(xbase, v_off[k], lb + (unsigned)(TILE + k * 1024));
+    };
+    const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g1 = (lane >> 4) & 1;
+    const unsigned lane_b = (unsigned)((8 * h + tr_q) * HB + (16 * tr_g1 + 4 * tr_p) * 2);
+    const unsigned a_lane = (unsigned)((wave >> 1) * 2 * QB) + lane_b, b_lane = (unsigned)(TILE + (wave & 1) * 2 * QB) + lane_b;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4_d;
+#define WGD_TR(ADDR, IMM) __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_d*)(size_t)((ADDR) + (IMM)))
+    const int tile_end = job.tile0 + job.ntiles;
+    issue_tile(job.tile0, 0);
+    int buf = 0;
+#pragma unroll 1
+    for (int tile = job.tile0; tile < tile_end; ++tile) {
+        wait_vm_all();
+        __syncthreads();
+        if (tile + 1 < tile_end) issue_tile(tile + 1, buf ^ 1);
+        const unsigned base = lds0 + (unsigned)(buf * BUF);
+        const unsigned ya = base + a_lane, va = base + b_lane;
+#pragma unroll
+        for (int ks = 0; ks < WG_PX / 16; ++ks) {
+            s16x8 af[2], bfr[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const s16x4 lo = WGD_TR(ya, a * QB + ks * 16 * HB), hi = WGD_TR(ya, a * QB + ks * 16 * HB + 4 * HB);
+                af[a][0] = lo[0]; af[a][1] = lo[1]; af[a][2] = lo[2]; af[a][3] = lo[3];
+                af[a][4] = hi[0]; af[a][5] = hi[1]; af[a][6] = hi[2]; af[a][7] = hi[3];
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const s16x4 lo = WGD_TR(va, b * QB + ks * 16 * HB), hi = WGD_TR(va, b * QB + ks * 16 * HB + 4 * HB);
+                bfr[b][0] = lo[0]; bfr[b][1] = lo[1]; bfr[b][2] = lo[2]; bfr[b][3] = lo[3];
+                bfr[b][4] = hi[0]; bfr[b][5] = hi[1]; bfr[b][6] = hi[2]; bfr[b][7] = hi[3];
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[a]), __builtin_bit_cast(bf16x8, bfr[b]), acc[a][b], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+#undef WGD_TR
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int ci = ci0 + (wave & 1) * 64 + 32 * b + r;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int co = co0 + (wave >> 1) * 64 + 32 * a + (j & 3) + 8 * (j >> 2) + 4 * h;
+                if (co < Cout) atomicAdd(dWp + (int64_t)co * Cin + ci, acc[a][b][j]);
+            }
+        }
+}
+
 static bool wg_tile(const ConvArgs& a, ConvTile& g) {
     if (!make_tile(a, WG_PX, 64, g)) return false;
     if (g.TW < 4) return false;  // 4-pixel transposed-read blocks must stay inside one tile row
@@ -623,6 +730,13 @@ int launch_wgrad_group(int dtype, int taps, const WgLayer* layers_dev, const WgJ
         static_assert(lds <= 64 * 1024, "two workgroups per CU");
         hipLaunchKernelGGL((wgrad_dma_kernel<bf16>), dim3((unsigned)njobs), dim3(256), lds, s, layers_dev, jobs_dev, (const char*)ws, (const char*)bws,
                            (const char*)zero_page, wimage);
+        DMME_CHECK_LAUNCH();
+        return DMME_OK;
+    }
+    if (taps == 1 && dma) {
+        constexpr size_t lds = 2 * 2 * 4 * WG_PX * 64;
+        static_assert(lds <= 64 * 1024, "two workgroups per CU");
+        hipLaunchKernelGGL((wgrad_dma1_kernel<bf16>), dim3((unsigned)njobs), dim3(256), lds, s, layers_dev, jobs_dev, (const char*)ws, (const char*)bws, wimage);
         DMME_CHECK_LAUNCH();
         return DMME_OK;
     }

@@ -772,6 +772,11 @@ static bool kw_replaces(int pick) {
     return pick == 3 || (all && pick == 2);
 }
 static int kw_ksplit(const ConvArgs& a, const ConvTile& g) {
+    // Measured with this kernel: a split over workgroups no longer pays at any batch (B = 1: 775 -> 846 steps/s without it, B = 8:
+    // 728 -> 792, B = 32: 586 -> 611) - a workgroup's fixed cost is ~5 us whatever its share of K, the finish kernel is one more dependent
+    // launch, and an unsplit conv finishes its norms itself.  Kept behind DMME_KW_SPLITK for experiments.
+    static const bool on = getenv("DMME_KW_SPLITK") != nullptr;
+    if (!on) return 1;
     static const bool off = getenv("DMME_NO_SPLITK") != nullptr;
     if (off || !a.splitk || a.gn_part || a.n_gno || a.out_silu || a.out_nchw || a.res2 || a.Cout % 4) return 1;
     const int64_t wgs = (int64_t)g.tiles_m * g.tiles_n;

@@ -50,7 +50,9 @@ def test_plan_is_host_only_and_reports_errors():
     assert lib.dmme_unet_plan_workspace_bytes(h) > 0 and lib.dmme_unet_plan_packed_bytes(h) > 2 * 32_416_643
     assert lib.dmme_unet_plan_dropmask_numel(h) == 128 * 4736
     n_ops = lib.dmme_unet_plan_num_ops(h)
-    assert n_ops == lib.dmme_unet_plan_num_launches(h) > 100
+    # launches = ops minus the GroupNorms their producing convs finish in the epilogue (8x8 / 4x4 / 16x16 whole-image tiles)
+    n_launch = lib.dmme_unet_plan_num_launches(h)
+    assert n_ops >= n_launch > 100 and n_ops - n_launch <= 40
     label = C.create_string_buffer(128)
     fl, by = C.c_double(), C.c_double()
     total = 0.0

@@ -14,7 +14,7 @@ dev = torch.device("cuda:0")
 sink = torch.zeros(4096, dtype=torch.int32, device=dev)
 for kib in (256, 1024, 16384):
     buf = torch.randint(0, 2**31 - 1, (kib * 256,), dtype=torch.int32, device=dev)
-    for mode in (0, 1):
+    for mode in (0, 1, 288):  # registers, LDS-DMA contiguous, LDS-DMA gathering 128-byte rows 4608 bytes apart (a 3x3 filter row stride)
         for depth in (1, 4, 16):
             for blocks in (256, 512, 1024):
                 iters = max(1, (64 << 20) // (kib << 10))
@@ -33,5 +33,5 @@ for kib in (256, 1024, 16384):
                 per_wg = iters * (kib << 10)
                 total = per_wg * blocks
                 wg_per_cu = max(1, blocks // 256)
-                print(f"buffer {kib:6d} KiB  mode {'dma' if mode else 'reg'}  depth {depth:2d}  workgroups {blocks:5d}: {total / sec / 1e12:6.2f} TB/s aggregate, "
+                print(f"buffer {kib:6d} KiB  mode {'reg' if mode == 0 else 'dma' if mode == 1 else 'dma-gather'}  depth {depth:2d}  workgroups {blocks:5d}: {total / sec / 1e12:6.2f} TB/s aggregate, "
                       f"{total / 256 / sec / 2.4e9:6.1f} B/clk per CU ({wg_per_cu} workgroups per CU)", flush=True)

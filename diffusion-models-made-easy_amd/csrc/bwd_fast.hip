@@ -598,8 +598,11 @@ __global__ void __launch_bounds__(256) gn_bwd_small_kernel(const T* __restrict__
     constexpr int EPV = 16 / sizeof(T);
     __shared__ float red[256 * EPV * 2];
     __shared__ float chA[512], chB[512], gS1[64], gS2[64];
-    const int C = C1 + C2, tid = threadIdx.x, VPP = C / EPV, ppw = 256 / VPP, slot = tid % VPP, prow = tid / VPP;
-    const int n = blockIdx.x, c0 = slot * EPV, cg = C / groups;
+    // gridDim.y channel slices of whole groups per image (groups are independent): a quarter of the serial work per workgroup, four
+    // times the workgroups - the kernel is three dependent phases over an image that already sits in L2
+    const int C = C1 + C2, Cw = C / (int)gridDim.y, cb = (int)blockIdx.y * Cw;
+    const int tid = threadIdx.x, VPP = Cw / EPV, ppw = 256 / VPP, slot = tid % VPP, prow = tid / VPP;
+    const int n = blockIdx.x, c0 = cb + slot * EPV, cg = C / groups;
     const bool active = prow < ppw;
     const bool second = c0 >= C1;
     const T* xs = second ? x2 : x1;
@@ -656,25 +659,25 @@ __global__ void __launch_bounds__(256) gn_bwd_small_kernel(const T* __restrict__
             red[(tid * EPV + j) * 2 + 1] = bq[j];
         }
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
-        const int v = c / EPV, j = c % EPV;
+    for (int lc = tid; lc < Cw; lc += 256) {  // lc: channel within this slice
+        const int v = lc / EPV, j = lc % EPV;
         float sa = 0.f, sb = 0.f;
         for (int r = 0; r < ppw; ++r) {
             sa += red[((r * VPP + v) * EPV + j) * 2];
             sb += red[((r * VPP + v) * EPV + j) * 2 + 1];
         }
-        chA[c] = sa;
-        chB[c] = sb;
-        atomicAdd(&dbeta[c], sa);
-        atomicAdd(&dgamma[c], sb);
+        chA[lc] = sa;
+        chB[lc] = sb;
+        atomicAdd(&dbeta[cb + lc], sa);
+        atomicAdd(&dgamma[cb + lc], sb);
     }
     __syncthreads();
-    if (tid < groups) {
+    if (tid < Cw / cg) {  // the slice's groups
         float s1 = 0.f, s2 = 0.f;
         for (int j = 0; j < cg; ++j) {
-            const int c = tid * cg + j;
-            s1 = fmaf(gamma[c], chA[c], s1);
-            s2 = fmaf(gamma[c], chB[c], s2);
+            const int lc = tid * cg + j;
+            s1 = fmaf(gamma[cb + lc], chA[lc], s1);
+            s2 = fmaf(gamma[cb + lc], chB[lc], s2);
         }
         gS1[tid] = s1;
         gS2[tid] = s2;
@@ -685,7 +688,7 @@ __global__ void __launch_bounds__(256) gn_bwd_small_kernel(const T* __restrict__
     float k1[EPV], k2[EPV];
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
-        const int g = (c0 + j) / cg;
+        const int g = (c0 - cb + j) / cg;
         k1[j] = gS1[g] * inv;
         k2[j] = gS2[g] * inv;
     }
@@ -757,11 +760,22 @@ int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2
                        int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, float* AB, float* S, GnMod mod,
                        hipStream_t s, void* act) {
     if (!mod.t_scale && gn_bwd_small_supported(dtype, HW, C1, C2, groups)) {
+        // channel slices: whole groups, whole 16-byte vectors, not straddling the two concatenated sources, <= 256 threads per pixel row
+        const int Call = C1 + C2, cgs = Call / groups, epv = dtype == DMME_BF16 ? 8 : 4;
+        int slices = 1;
+        static const bool slice_off = getenv("DMME_NO_GN_BWD_SLICES") != nullptr;
+        for (int cand = 4; cand >= 2 && !slice_off; cand >>= 1) {
+            const int w = Call / cand;
+            if (Call % cand == 0 && w % cgs == 0 && w % epv == 0 && C1 % w == 0 && (int64_t)N * cand <= 1024) {
+                slices = cand;
+                break;
+            }
+        }
         if (dtype == DMME_BF16)
-            hipLaunchKernelGGL(gn_bwd_small_kernel<bf16>, dim3(N), dim3(256), 0, s, (const bf16*)dv, (const bf16*)x1, (const bf16*)x2, HW, C1, C2, groups,
+            hipLaunchKernelGGL(gn_bwd_small_kernel<bf16>, dim3(N, slices), dim3(256), 0, s, (const bf16*)dv, (const bf16*)x1, (const bf16*)x2, HW, C1, C2, groups,
                                gamma, mean_rstd, scale, shift, dmask, pro_silu, (bf16*)dx1, (bf16*)dx2, acc1, acc2, dgamma, dbeta, (bf16*)act);
         else
-            hipLaunchKernelGGL(gn_bwd_small_kernel<float>, dim3(N), dim3(256), 0, s, (const float*)dv, (const float*)x1, (const float*)x2, HW, C1, C2,
+            hipLaunchKernelGGL(gn_bwd_small_kernel<float>, dim3(N, slices), dim3(256), 0, s, (const float*)dv, (const float*)x1, (const float*)x2, HW, C1, C2,
                                groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, (float*)dx1, (float*)dx2, acc1, acc2, dgamma, dbeta, (float*)act);
         DMME_CHECK_LAUNCH();
         return DMME_OK;

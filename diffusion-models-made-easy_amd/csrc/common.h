@@ -168,6 +168,9 @@ void conv_mfma_label(int dtype, const ConvArgs& a, char* buf, int cap);
 bool conv_pipe_supported(int dtype, const ConvArgs& a);
 int launch_conv_pipe(int dtype, const ConvArgs& a, hipStream_t s);
 void conv_pipe_label(int dtype, const ConvArgs& a, char* buf, int cap);
+// the 3- / 6-channel output conv as one 27- / 54-column GEMM + a 9-term gather (conv_thin.hip)
+bool conv_out_thin_supported(int dtype, const ConvArgs& a);
+int launch_conv_out_thin(const ConvArgs& a, hipStream_t s);
 // K-split-over-waves 3x3 kernel for layers with few output pixels (conv_kw.hip); launch_conv_pipe dispatches to it
 struct ConvTile;
 bool conv_kw_pick(int dtype, const ConvArgs& a, ConvTile& g, int* ni, int* ring);

@@ -694,6 +694,7 @@ int build_unpack_items(dmme_plan* P, std::vector<PackItem>& items) {
 }
 
 int run_any_conv(int dtype, const ConvArgs& a, hipStream_t s) {
+    if (conv_out_thin_supported(dtype, a)) return launch_conv_out_thin(a, s);
     if (conv1x1_pipe_supported(dtype, a)) return launch_conv1x1_pipe(dtype, a, s);
     if (conv_pipe_supported(dtype, a)) return launch_conv_pipe(dtype, a, s);
     if (conv_mfma_supported(dtype, a)) return launch_conv_mfma(dtype, a, s);
@@ -1174,7 +1175,9 @@ void op_account(const dmme_plan* P, const Op& o, char* label, int cap, double* f
         case OP_CONV: {
             ConvArgs a{};
             fill_conv(P, o, (const char*)4096, (const float*)4096, (float*)4096, (char*)4096, nullptr, 1, a, true);
-            if (conv1x1_pipe_supported(P->dtype, a))
+            if (conv_out_thin_supported(P->dtype, a))
+                snprintf(label, cap, "conv_out_thin_kernel<%d>", a.Cout * 9 <= 32 ? 1 : 2);
+            else if (conv1x1_pipe_supported(P->dtype, a))
                 conv1x1_pipe_label(P->dtype, a, label, cap);
             else if (conv_pipe_supported(P->dtype, a))
                 conv_pipe_label(P->dtype, a, label, cap);

@@ -623,6 +623,71 @@ __global__ void __launch_bounds__(256) l2_stream_dma_kernel(const uint4* __restr
     }
     if (acc == 0x12345u) sink[blockIdx.x] = acc;
 }
+// ------------------------------------------------------------------ diagnostic: do VALU work and MFMAs of two waves on one SIMD overlap?
+// 512 threads per workgroup, one workgroup per CU: waves 0-3 issue `iters` rounds of eight independent 32x32x16 bf16 MFMAs (the
+// wave-specialised conv kernel's consumer), waves 4-7 `iters` rounds of the GroupNorm/SiLU prologue arithmetic on eight values (its
+// producer).  mode bit 0: run the MFMA waves, bit 1: run the VALU waves, bit 2: accumulators in AccVGPRs (inline asm) instead of
+// wherever the compiler puts them (arch VGPRs at this occupancy).
+typedef float f32x16_d __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_d __attribute__((ext_vector_type(8)));
+__global__ void __launch_bounds__(512, 1) mfma_valu_kernel(int mode, int iters, float* __restrict__ sink) {
+    const int wave = threadIdx.x >> 6;
+    float out = 0.f;
+    if (wave < 4) {
+        if (!(mode & 1)) return;
+        bf16x8_d a, b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            a[e] = (__bf16)(float)(threadIdx.x + e);
+            b[e] = (__bf16)(float)(threadIdx.x ^ e);
+        }
+        f32x16_d acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[k][j] = 0.f;
+        if (mode & 4) {
+            for (int it = 0; it < iters; ++it) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[k]) : "v"(a), "v"(b));
+#endif
+            }
+        } else {
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[k], 0, 0, 0);
+                asm volatile("" ::: "memory");
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out += acc[k][0] + acc[k][15];
+    } else {
+        if (!(mode & 2)) return;
+        float v[8], sc = 1.0001f + threadIdx.x * 1e-6f, sh = 0.01f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.1f * e + threadIdx.x * 1e-3f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int rep = 0; rep < 4; ++rep)  // ~ the prologue of four 16-byte halo units per MFMA round
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float u = fmaf(v[e], sc, sh);
+                    v[e] = u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * u)) * 0.999f;
+                }
+            asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out += v[e];
+    }
+    if (out == 12345.678f) sink[blockIdx.x] = out;
+}
+int launch_mfma_valu(int mode, int iters, int blocks, float* sink, hipStream_t s) {
+    hipLaunchKernelGGL(mfma_valu_kernel, dim3((unsigned)blocks), dim3(512), 0, s, mode, iters, sink);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
 int launch_l2_stream(const void* buf, int64_t bytes, int iters, int mode, int depth, int blocks, unsigned* sink, hipStream_t s) {
     const int nvec = (int)(bytes / 16);
     DMME_REQUIRE(buf && sink && nvec >= 16 * 256 && iters > 0 && blocks > 0, DMME_ERR_INVALID, "l2_stream: bad argument");

@@ -170,6 +170,9 @@ DMME_API int dmme_unet_plan_bwd_summary(const dmme_plan* plan, char* buf, int ca
  * times with `depth` (1, 2, 4, 8, 16) 16-byte loads in flight per thread; mode 0 loads into registers, mode 1 uses the global -> LDS DMA,
  * mode m >= 2 the DMA in the convolutions' access shape (a wave instruction gathers eight 128-byte rows m 16-byte vectors apart, e.g.
  * 288 = a 3x3 filter row of 256 input channels).  sink: `blocks` uint32 of scratch.  Measures what a CU can draw from L2. */
+/* diagnostic (tools/mfma_valu.py): do the MFMAs of one wave and the VALU work of another wave on the same SIMD overlap?  `blocks`
+ * workgroups of 512 threads; mode bit 0: MFMA waves run, bit 1: VALU waves run, bit 2: MFMA accumulators in AccVGPRs.  sink: `blocks` floats. */
+DMME_API int dmme_debug_mfma_valu(int mode, int iters, int blocks, void* sink, void* stream);
 DMME_API int dmme_debug_l2_stream(const void* buf, int64_t bytes, int iters, int mode, int depth, int blocks, void* sink, void* stream);
 /* global L2 norm of a flat fp32 gradient buffer (clip_grad_norm_; scratch: 1024 floats) */
 DMME_API int dmme_grad_norm(const float* grad, int64_t numel, float* norm_out, float* scratch, void* stream);

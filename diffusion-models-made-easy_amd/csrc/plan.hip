@@ -1953,6 +1953,7 @@ DMME_API int dmme_conv2d(const dmme_conv_desc* d, const void* src1, const void* 
     a.x3 = d->dtype == DMME_BF16X3;
     const int dt = a.x3 ? DMME_F32 : d->dtype;
     if (d->force_generic == 2 && conv_mfma_supported(dt, a)) return launch_conv_mfma(dt, a, (hipStream_t)stream);
+    if (!d->force_generic && conv_out_thin_supported(dt, a)) return launch_conv_out_thin(a, (hipStream_t)stream);
     if (!d->force_generic && conv1x1_pipe_supported(dt, a)) return launch_conv1x1_pipe(dt, a, (hipStream_t)stream);
     if (!d->force_generic && conv_pipe_supported(dt, a)) return launch_conv_pipe(dt, a, (hipStream_t)stream);
     if (!d->force_generic && conv_mfma_supported(dt, a)) return launch_conv_mfma(dt, a, (hipStream_t)stream);

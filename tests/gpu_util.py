@@ -42,8 +42,9 @@ def pack_w(w_oihw, dt):
 
 
 def conv2d(dt, x1, w, b, x2=None, scale=None, shift=None, dmask=None, tproj=None, res=None, stride=1, upsample=False,
-           pro_silu=False, out_silu=False, force_generic=False):
-    """x1/x2/res: fp32 NCHW cuda tensors; w: (Cout, Cin, k, k); returns fp32 NCHW."""
+           pro_silu=False, out_silu=False, force_generic=False, out_nchw=False):
+    """x1/x2/res: fp32 NCHW cuda tensors; w: (Cout, Cin, k, k); returns fp32 NCHW (out_nchw: written that way by the kernel itself,
+    like the network's output conv)."""
     N, C1, H, W = x1.shape
     k = w.shape[-1]
     d = _lib.ConvDesc()
@@ -53,7 +54,7 @@ def conv2d(dt, x1, w, b, x2=None, scale=None, shift=None, dmask=None, tproj=None
     d.pro_silu, d.out_silu = int(pro_silu), int(out_silu)
     d.nt = 0 if tproj is None else tproj.shape[0]
     d.tproj_ld = 0 if tproj is None else tproj.shape[1]
-    d.in_nchw = d.out_nchw = 0
+    d.in_nchw, d.out_nchw = 0, int(out_nchw)
     d.force_generic = int(force_generic)
     Hv, Wv = (2 * H, 2 * W) if upsample else (H, W)
     Ho, Wo = Hv // stride, Wv // stride
@@ -61,7 +62,8 @@ def conv2d(dt, x1, w, b, x2=None, scale=None, shift=None, dmask=None, tproj=None
     a2 = None if x2 is None else to_nhwc(x2, dt)
     r1 = None if res is None else to_nhwc(res, dt)
     wp = pack_w(w, dt)
-    out = torch.empty((N, Ho, Wo, w.shape[0]), dtype=TD[dt], device=x1.device)
+    out = (torch.empty((N, w.shape[0], Ho, Wo), dtype=torch.float32, device=x1.device) if out_nchw
+           else torch.empty((N, Ho, Wo, w.shape[0]), dtype=TD[dt], device=x1.device))
     f = lambda t: None if t is None else t.to(torch.float32).contiguous()
     sc, sh, dm, tp, bb = f(scale), f(shift), f(dmask), f(tproj), f(b)
     _lib.check(
@@ -69,7 +71,7 @@ def conv2d(dt, x1, w, b, x2=None, scale=None, shift=None, dmask=None, tproj=None
                                _lib.ptr(tp), _lib.ptr(r1), _lib.ptr(None), w.shape[0], _lib.ptr(out), _lib.stream_ptr()),
         "dmme_conv2d",
     )
-    return to_nchw(out, dt)
+    return out if out_nchw else to_nchw(out, dt)
 
 
 def gn_scale_shift(dt, x1, gamma, beta, groups, x2=None, force_generic=False, eps=1e-5):

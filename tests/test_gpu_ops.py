@@ -105,6 +105,31 @@ def test_conv(case, dtname):
         assert err <= tol, f"{name} {dtname} generic={force_generic}: max err {err:.3e} > {tol:.3e}"
 
 
+@pytest.mark.parametrize("shape", [(3, 128, 32, 3), (2, 64, 64, 6), (5, 256, 32, 3), (130, 128, 32, 3)], ids=["ddpm_out", "iddpm_out_6ch", "c256", "b130"])
+def test_output_conv_thin_kernel(shape):
+    """the network's last conv (GroupNorm + SiLU in front, 3 / 6 couts, NCHW fp32 out) through conv_out_thin_kernel - taps as GEMM
+    columns + a 9-term gather - against the fp64 convolution of the same bf16 operands"""
+    from dmme_amd import _lib
+    from tests import gpu_util as G
+
+    N, C, H, Cout = shape
+    seed = 4242 + C + Cout
+    x = synth.normal(seed, (N, C, H, H))
+    w = synth.uniform(seed + 2, (Cout, C, 3, 3)) / np.sqrt(C * 9)
+    b = synth.uniform(seed + 3, (Cout,)) * 0.1
+    scale = 1 + 0.3 * synth.normal(seed + 4, (N, C))
+    shift = 0.2 * synth.normal(seed + 5, (N, C))
+    ref = _ref_conv(x, w, b, None, scale, shift, None, None, None, 1, False, True, False, True)
+    cu = lambda t: t.cuda()
+    y = G.conv2d(_lib.dtype_code("bf16"), cu(x), cu(w), cu(b), None, cu(scale), cu(shift), None, None, None, 1, False, True, False, 0, out_nchw=True)
+    y_gen = G.conv2d(_lib.dtype_code("bf16"), cu(x), cu(w), cu(b), None, cu(scale), cu(shift), None, None, None, 1, False, True, False, 1, out_nchw=True)
+    torch.cuda.synchronize()
+    # fp32 output of bf16 operands: only accumulation order (and the rare prologue rounding flip) separates it from the reference
+    tol = 2.0**-9 * ref.abs().max().item()
+    err, err_gen = (y.cpu() - ref).abs().max().item(), (y_gen.cpu() - ref).abs().max().item()
+    assert err <= tol and err_gen <= tol, (err, err_gen, tol)
+
+
 GN_CASES = [(3, 128, 0, 32, 32), (2, 256, 256, 8, 32), (2, 128, 128, 16, 32), (5, 256, 0, 4, 32), (2, 8, 4, 16, 2), (3, 16, 0, 8, 2), (2, 256, 0, 16, 32)]
 
 

@@ -118,7 +118,7 @@ struct dmme_plan {
     int64_t bws_zero = 0, bws_zero_bytes = 0, bws_wimage = 0, bws_gnS = 0, bws_zpage = 0;  // region cleared once per backward
     PackItem* items_unpack_dev = nullptr;
     int n_items_unpack = 0;
-    int64_t bws_tmp = 0, bws_dy = 0, bws_rowsum = 0, bws_dtproj = 0, bws_dtemb = 0, bws_dh1 = 0, bws_z = 0, bws_attP = 0,
+    int64_t bws_tmp = 0, bws_dy = 0, bws_rowsum = 0, bws_dtproj = 0, bws_dtemb = 0, bws_dh1 = 0, bws_z = 0, bws_wT = 0, bws_attP = 0,
             bws_attdS = 0;
     PackItem* items_bwd_dev = nullptr;
     int n_items_bwd = 0;
@@ -612,6 +612,7 @@ int build_plan(dmme_plan* P) {
         P->bws_dtemb = balloc((int64_t)B * c.emb_dim * 4);
         P->bws_dh1 = balloc((int64_t)B * c.emb_dim * 4);
         P->bws_z = balloc((int64_t)B * c.emb_dim * 4);
+        P->bws_wT = balloc((int64_t)(tcols > c.emb_dim ? tcols : c.emb_dim) * c.emb_dim * es);
         P->bws_attP = balloc(att_max);
         P->bws_attdS = balloc(att_max);
         P->bws_bytes = bw;
@@ -1710,14 +1711,18 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
     float* dtemb = (float*)(bws + P->bws_dtemb);
     float* dh1 = (float*)(bws + P->bws_dh1);
     float* z = (float*)(bws + P->bws_z);
-    rc = launch_small_gemm(dt, 1, dtproj, tc, pk + P->tproj_w_off, emb, nt, emb, tc, nullptr, 0, dtemb, emb, s);
+    // input gradients of the Linears as NT GEMMs against a transposed copy of the weights (K contiguous in both operands)
+    char* wT = bws + P->bws_wT;
+    rc = launch_transpose(dt, pk + P->tproj_w_off, tc, emb, wT, s);
+    if (rc == DMME_OK) rc = launch_small_gemm(dt, 0, dtproj, tc, wT, tc, nt, emb, tc, nullptr, 0, dtemb, emb, s);
     if (rc != DMME_OK) return rc;
     // temb = silu(z2), z2 = h1 W2^T + b2
     rc = launch_small_gemm(dt, 0, h1, emb, pk + P->params[P->p_l2w].packed_off, emb, nt, emb, emb, (const float*)(pk + P->params[P->p_l2b].packed_off), 0, z, emb, s);
     if (rc == DMME_OK) rc = launch_silu_bwd(dtemb, z, nt * emb, s);
     if (rc == DMME_OK) rc = launch_small_gemm(dt, 2, dtemb, emb, h1, emb, emb, emb, nt, nullptr, 0, grad_flat + P->params[P->p_l2w].ref_off, emb, s);
     if (rc == DMME_OK) rc = launch_nsum(dtemb, nt, emb, emb, 1, grad_flat + P->params[P->p_l2b].ref_off, s);
-    if (rc == DMME_OK) rc = launch_small_gemm(dt, 1, dtemb, emb, pk + P->params[P->p_l2w].packed_off, emb, nt, emb, emb, nullptr, 0, dh1, emb, s);
+    if (rc == DMME_OK) rc = launch_transpose(dt, pk + P->params[P->p_l2w].packed_off, emb, emb, wT, s);
+    if (rc == DMME_OK) rc = launch_small_gemm(dt, 0, dtemb, emb, wT, emb, nt, emb, emb, nullptr, 0, dh1, emb, s);
     // h1 = silu(z1), z1 = e W1^T + b1
     if (rc == DMME_OK) rc = launch_small_gemm(dt, 0, esin, pos, pk + P->params[P->p_l1w].packed_off, pos, nt, emb, pos, (const float*)(pk + P->params[P->p_l1b].packed_off), 0, z, emb, s);
     if (rc == DMME_OK) rc = launch_silu_bwd(dh1, z, nt * emb, s);

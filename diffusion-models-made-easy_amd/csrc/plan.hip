@@ -130,11 +130,12 @@ struct dmme_plan {
         WgLayer* layers_dev = nullptr;
         WgJob* jobs_dev = nullptr;
         int dma = 0;  // every layer's second operand is one prologue-free tensor: the LDS-DMA kernel runs the table
-    } wg[2];  // 3x3, 1x1
+        int stride = 1;
+    } wg[3];  // 3x3, 1x1, 3x3 stride 2 (LDS-DMA kernel only)
     // Two-bucket backward (gradient all-reduce overlapped with backward): bucket 0 = the parameters backward finishes first
     // (up_layers, middle_layers, output_conv: the contiguous tail of the flat buffer), bucket 1 = the rest.  Plan-time split of
     // every deferred table at that boundary: [0] = bucket 0, [1] = bucket 1.
-    WgGroup wgb[2][2];
+    WgGroup wgb[2][3];
     int op_split = 0;                 // first op (forward order) of bucket 0
     int64_t bucket_off = 0;           // flat offset where bucket 0 starts
     int bias_split = 0;               // bias_jobs[bias_split:] belong to bucket 0
@@ -807,15 +808,20 @@ void fill_conv(const dmme_plan* P, const Op& o, const char* packed, const float*
 
 // Grouped weight gradients: every 3x3 stride-1 conv the all-taps MFMA kernel supports is taken out of the per-layer
 // sequence; its (cout tile, cin tile) pairs are cut into jobs of at most `q` consecutive 64-pixel tiles, longest first.
-void build_wgrad_group(dmme_plan* P, dmme_plan::WgGroup& G, int taps, int op_lo = 0, int op_hi = 1 << 30) {
+static int wg_index(const Op& o) { return o.taps == 1 ? 1 : o.stride == 2 ? 2 : 0; }
+void build_wgrad_group(dmme_plan* P, dmme_plan::WgGroup& G, int gi, int op_lo = 0, int op_hi = 1 << 30) {
+    const int taps = gi == 1 ? 1 : 9, stride = gi == 2 ? 2 : 1;
     G.taps = taps;
+    G.stride = stride;
+    if (stride == 2 && getenv("DMME_NO_WG_S2")) return;
     if (P->dtype != DMME_BF16 || getenv("DMME_NO_WGRAD_GROUP")) return;
-    const int q = taps == 9 ? (getenv("DMME_WG_Q") ? atoi(getenv("DMME_WG_Q")) : 64) : (getenv("DMME_WG_Q1") ? atoi(getenv("DMME_WG_Q1")) : 64);
+    // (the stride-2 table is three small layers: shorter jobs, or 80 workgroups would carry it)
+    const int q = stride == 2 ? 16 : taps == 9 ? (getenv("DMME_WG_Q") ? atoi(getenv("DMME_WG_Q")) : 64) : (getenv("DMME_WG_Q1") ? atoi(getenv("DMME_WG_Q1")) : 64);
     struct Grp { int layer, n_co, n_ci, tile0, ntiles; };
     std::vector<Grp> groups;
     for (int oi = (int)P->ops.size() - 1; oi >= 0; --oi) {
         Op& o = P->ops[oi];
-        if (o.kind != OP_CONV || o.src1 < 0 || o.dst < 0 || o.taps != taps || oi < op_lo || oi >= op_hi) continue;
+        if (o.kind != OP_CONV || o.src1 < 0 || o.dst < 0 || o.taps != taps || o.stride != stride || oi < op_lo || oi >= op_hi) continue;
         ConvArgs a{};
         fill_conv(P, o, nullptr, nullptr, nullptr, nullptr, nullptr, 1, a);
         WgLayer L{};
@@ -865,6 +871,15 @@ void build_wgrad_group(dmme_plan* P, dmme_plan::WgGroup& G, int taps, int op_lo 
         if (!(L.act_off >= 0 || ((L.C2 == 0 || taps == 1) && L.scale_off < 0 && L.dmask_off < 0 && !L.pro_silu)) || L.Cout % (taps == 9 ? 64 : 128) ||
             (taps == 1 && (L.C1 + L.C2) % 128))
             G.dma = 0;
+    if (stride == 2) {
+        if (!G.dma) {  // no register-staged fallback for stride 2: those layers stay on the per-layer kernel
+            for (Op& o : P->ops)
+                if (o.kind == OP_CONV && o.taps == 9 && o.stride == 2) o.wg_layer = -1;
+            G.layers.clear();
+            return;
+        }
+        G.dma = 2;
+    }
     // All (cout tile, cin tile) jobs of one pixel range read the same dY and activation tiles: they go to ONE XCD
     // (consecutive positions of its round-robin slice of the grid, blockIdx % 8), so the re-reads hit that XCD's L2
     // instead of HBM.  Groups are placed longest first on the least-loaded XCD; short slices are padded with empty jobs.
@@ -1283,10 +1298,9 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
         for (const auto& tb : P->tblocks)
             if ((P->params[tb.tw].ref_off >= P->bucket_off) != (tb.col >= P->tcol_split)) P->op_split = -1;
         for (int b = 0; b < 2 && P->op_split > 0; ++b)  // before the "all" build: that one leaves the final Op::wg_layer values
-            for (int k = 0; k < 2; ++k)
-                build_wgrad_group(P, P->wgb[b][k], k == 0 ? 9 : 1, b == 0 ? P->op_split : 0, b == 0 ? 1 << 30 : P->op_split);
-        build_wgrad_group(P, P->wg[0], 9);
-        build_wgrad_group(P, P->wg[1], 1);
+            for (int k = 0; k < 3; ++k)
+                build_wgrad_group(P, P->wgb[b][k], k, b == 0 ? P->op_split : 0, b == 0 ? 1 << 30 : P->op_split);
+        for (int k = 0; k < 3; ++k) build_wgrad_group(P, P->wg[k], k);
         if (!getenv("DMME_NO_BIAS_GROUP"))
             for (Op& o : P->ops) {
                 if (o.kind != OP_CONV) continue;
@@ -1362,7 +1376,7 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
             if (e == hipSuccess) e = hipMalloc((void**)&P->bias_jobs_dev, P->bias_jobs.size() * sizeof(BiasJob));
             if (e == hipSuccess) e = hipMemcpy(P->bias_jobs_dev, P->bias_jobs.data(), P->bias_jobs.size() * sizeof(BiasJob), hipMemcpyHostToDevice);
         }
-        for (dmme_plan::WgGroup* G : {&P->wg[0], &P->wg[1], &P->wgb[0][0], &P->wgb[0][1], &P->wgb[1][0], &P->wgb[1][1]}) {
+        for (dmme_plan::WgGroup* G : {&P->wg[0], &P->wg[1], &P->wg[2], &P->wgb[0][0], &P->wgb[0][1], &P->wgb[0][2], &P->wgb[1][0], &P->wgb[1][1], &P->wgb[1][2]}) {
             if (G->jobs.empty()) continue;
             if (e == hipSuccess) e = hipMalloc((void**)&G->layers_dev, G->layers.size() * sizeof(WgLayer));
             if (e == hipSuccess) e = hipMemcpy(G->layers_dev, G->layers.data(), G->layers.size() * sizeof(WgLayer), hipMemcpyHostToDevice);
@@ -1392,7 +1406,7 @@ DMME_API void dmme_unet_plan_destroy(dmme_plan* plan) {
     if (plan->items_dev) (void)hipFree(plan->items_dev);
     if (plan->items_bwd_dev) (void)hipFree(plan->items_bwd_dev);
     if (plan->items_unpack_dev) (void)hipFree(plan->items_unpack_dev);
-    for (dmme_plan::WgGroup* G : {&plan->wg[0], &plan->wg[1], &plan->wgb[0][0], &plan->wgb[0][1], &plan->wgb[1][0], &plan->wgb[1][1]}) {
+    for (dmme_plan::WgGroup* G : {&plan->wg[0], &plan->wg[1], &plan->wg[2], &plan->wgb[0][0], &plan->wgb[0][1], &plan->wgb[0][2], &plan->wgb[1][0], &plan->wgb[1][1], &plan->wgb[1][2]}) {
         if (G->layers_dev) (void)hipFree(G->layers_dev);
         if (G->jobs_dev) (void)hipFree(G->jobs_dev);
     }
@@ -1536,7 +1550,7 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
             if (j1 > j0) r = launch_bias_tproj_group(P->bias_jobs_dev + j0, j1 - j0, bws, grad_flat, dtproj, B, tc, nt, s);
             if (r != DMME_OK) return r;
         }
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < 3; ++k) {
             const dmme_plan::WgGroup& G = b < 0 ? P->wg[k] : P->wgb[b][k];
             if (!G.jobs_dev) continue;
             r = launch_wgrad_group(dt, G.taps, G.layers_dev, G.jobs_dev, (int)G.jobs.size(), ws, bws, drop_masks, wimage, s, G.dma, bws + P->bws_zpage);
@@ -1613,7 +1627,7 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
                                o.tproj_col >= 0 ? dtproj + o.tproj_col : nullptr, P->tproj_cols, nt, s);
         if (rc != DMME_OK) break;
         // 2. weight gradient: deferred to the grouped launch below, or per layer (packed image / reference layout)
-        if (o.wg_layer >= 0 && (buckets ? P->wgb[oi >= P->op_split ? 0 : 1][o.taps == 9 ? 0 : 1].jobs_dev : P->wg[o.taps == 9 ? 0 : 1].jobs_dev))
+        if (o.wg_layer >= 0 && (buckets ? P->wgb[oi >= P->op_split ? 0 : 1][wg_index(o)].jobs_dev : P->wg[wg_index(o)].jobs_dev))
             rc = DMME_OK;
         else if (wgrad_mfma_supported(dt, a))
             rc = launch_wgrad_mfma(dt, a, dy, wimage + P->params[o.w].wp_off, s);

@@ -368,14 +368,16 @@ __global__ void __launch_bounds__(256, 2) wgrad_group_kernel(const WgLayer* __re
 // consecutive rows x 32 B - at a 64-byte pitch those cover disjoint banks with no padding or swizzle, and every fragment address of a
 // tile is (per-lane base) + (wave-uniform offset) + (immediate): under one VALU instruction per MFMA (the register-staged kernel spent
 // eight, which made it VALU-issue bound: 4 cycles each against the MFMA's 32).
-template <typename T>
-__global__ void __launch_bounds__(256, 2) wgrad_dma_kernel(const WgLayer* __restrict__ layers, const WgJob* __restrict__ jobs,
-                                                          const char* __restrict__ ws, const char* __restrict__ bws,
-                                                          const char* __restrict__ zero_page, float* __restrict__ wimage) {
+// STRIDE 2 (the three DownSample convs; no upsampling there): the 64-pixel tile's halo is 17 x 17 / 9 x 33 rows (four 4x4 images: 4 x 9 x 9) - V_ROWS 336, one
+// workgroup per CU - instead of the per-layer kernel's ~65 us of atomics per layer.
+template <typename T, int STRIDE, int V_ROWS>
+__global__ void __launch_bounds__(256, STRIDE == 1 ? 2 : 1) wgrad_dma_kernel(const WgLayer* __restrict__ layers, const WgJob* __restrict__ jobs,
+                                                                            const char* __restrict__ ws, const char* __restrict__ bws,
+                                                                            const char* __restrict__ zero_page, float* __restrict__ wimage) {
     static_assert(sizeof(T) == 2, "bf16 only");
     constexpr int TAPS = 9, HB = 64;                       // bytes of one row of one channel half
     constexpr int Y_HALF = WG_PX * HB, Y_BYTES = 2 * Y_HALF;  // 8 KB
-    constexpr int V_ROWS = 160, V_HALF = V_ROWS * HB, BUF = Y_BYTES + 2 * V_HALF, VU = 5;  // 28 KB per buffer; <= 20 halo DMA instructions
+    constexpr int V_HALF = V_ROWS * HB, BUF = Y_BYTES + 2 * V_HALF, VU = (V_ROWS / 16 * 2 + 3) / 4;  // halo DMA instructions per wave
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const WgJob job = jobs[blockIdx.x];
     if (job.ntiles <= 0) return;  // padding of a short XCD slice
@@ -439,7 +441,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_dma_kernel(const WgLayer* __rest
         for (int k = 0; k < VU; ++k) {
             const int j = wave + 4 * k;
             if (j >= n_vj) break;  // wave-uniform
-            const int iy = oy0 - 1 + v_hy[k], ix = ox0 - 1 + v_hx[k];
+            const int iy = oy0 * STRIDE - 1 + v_hy[k], ix = ox0 * STRIDE - 1 + v_hx[k];
             const bool ok = v_tn[k] >= 0 && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
             const int sy = up ? (iy >> 1) : iy, sx = up ? (ix >> 1) : ix;
             const int64_t off = (int64_t)(((n0 + v_tn[k]) * Hin + sy) * Win + sx) * Cin * 2 + v_cb;
@@ -456,7 +458,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_dma_kernel(const WgLayer* __rest
     {
         const int m = 8 * h + tr_q;
         const int tx = m & mTW, ty = (m >> shTW) & mTH, tn = m >> (shTW + shTH);
-        b_lane = (unsigned)(Y_BYTES + (wci >> 5) * V_HALF + ((tn * g.HH + ty) * g.HWd + tx) * HB) + colb;
+        b_lane = (unsigned)(Y_BYTES + (wci >> 5) * V_HALF + ((tn * g.HH + ty * STRIDE) * g.HWd + tx * STRIDE) * HB) + colb;
     }
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4_d;
 #define WGD_TR(ADDR, IMM) __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_d*)(size_t)((ADDR) + (IMM)))
@@ -691,13 +693,13 @@ int launch_wgrad_unpack(const PackItem* items_dev, int n_items, const float* ima
 }
 
 bool wgrad_group_layer(int dtype, const ConvArgs& a, WgLayer& L, int* co_tile, int* ci_tile) {
-    if (dtype != DMME_BF16 || (a.taps != 9 && a.taps != 1) || a.stride != 1 || a.in_nchw || a.up == 2) return false;
+    if (dtype != DMME_BF16 || (a.taps != 9 && a.taps != 1) || (a.stride != 1 && !(a.stride == 2 && a.taps == 9 && !a.up)) || a.in_nchw || a.up == 2) return false;
     if (a.taps == 1 && a.up) return false;
     const int CO = a.taps == 9 ? 64 : 128, CI = a.taps == 9 ? 64 : 128;
     const int Cin = a.C1 + a.C2;
     if (Cin % CI || a.C1 % CI || a.Cout % 8) return false;
     ConvTile g{};
-    if (!make_tile(a, WG_PX, 64, g) || g.TW < 4 || g.a_rows > (a.taps == 9 ? 160 : 64) || a.N % g.TN) return false;
+    if (!make_tile(a, WG_PX, 64, g) || g.TW < 4 || g.a_rows > (a.taps == 1 ? 64 : a.stride == 2 ? 336 : 160) || a.N % g.TN) return false;
     L.g = g;
     L.shTW = L.shTH = 0;
     while ((1 << L.shTW) < g.TW) ++L.shTW;
@@ -706,7 +708,7 @@ bool wgrad_group_layer(int dtype, const ConvArgs& a, WgLayer& L, int* co_tile, i
     const int VP = CI * 2 + 64;
     auto row_of = [&](int m) {  // halo row of tile pixel m (tap 0)
         const int tx = m & (g.TW - 1), ty = (m >> L.shTW) & (g.TH - 1), tn = m >> (L.shTW + L.shTH);
-        return (tn * g.HH + ty) * g.HWd + tx;
+        return (tn * g.HH + ty * a.stride) * g.HWd + tx * a.stride;
     };
     for (int ks = 0; ks < 4; ++ks) {
         L.ks_off[ks] = row_of(16 * ks) * VP;
@@ -725,10 +727,22 @@ int launch_wgrad_group(int dtype, int taps, const WgLayer* layers_dev, const WgJ
                        const float* drop_masks, float* wimage, hipStream_t s, int dma, const void* zero_page) {
     DMME_REQUIRE(dtype == DMME_BF16 && (taps == 9 || taps == 1), DMME_ERR_UNSUPPORTED, "grouped weight gradient: bf16, 3x3 or 1x1 only");
     if (njobs <= 0) return DMME_OK;
+    if (taps == 9 && dma == 2 && zero_page) {  // the stride-2 table
+        constexpr size_t lds = 2 * (WG_PX * 128 + 336 * 128);
+        static bool attr = false;
+        if (!attr) {
+            DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<bf16, 2, 336>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr = true;
+        }
+        hipLaunchKernelGGL((wgrad_dma_kernel<bf16, 2, 336>), dim3((unsigned)njobs), dim3(256), lds, s, layers_dev, jobs_dev, (const char*)ws, (const char*)bws,
+                           (const char*)zero_page, wimage);
+        DMME_CHECK_LAUNCH();
+        return DMME_OK;
+    }
     if (taps == 9 && dma && zero_page) {
         constexpr size_t lds = 2 * (WG_PX * 128 + 160 * 128);
         static_assert(lds <= 64 * 1024, "two workgroups per CU");
-        hipLaunchKernelGGL((wgrad_dma_kernel<bf16>), dim3((unsigned)njobs), dim3(256), lds, s, layers_dev, jobs_dev, (const char*)ws, (const char*)bws,
+        hipLaunchKernelGGL((wgrad_dma_kernel<bf16, 1, 160>), dim3((unsigned)njobs), dim3(256), lds, s, layers_dev, jobs_dev, (const char*)ws, (const char*)bws,
                            (const char*)zero_page, wimage);
         DMME_CHECK_LAUNCH();
         return DMME_OK;

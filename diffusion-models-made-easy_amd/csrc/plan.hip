@@ -1657,12 +1657,25 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
                 d.splitk = (float*)(ws + P->ws_splitk);
                 d.splitk_cap = P->splitk_floats;
             }
-            rc = run_any_conv(dt, d, s);
-            if (rc != DMME_OK) break;
             const Tensor& t1 = P->tensors[o.src1];
             char* g1 = gptr(o.src1);
             char* g2 = o.src2 >= 0 ? gptr(o.src2) : nullptr;
             const int acc1 = claim(o.src1), acc2 = o.src2 >= 0 ? claim(o.src2) : 0;
+            // a conv with no norm in front of it, one source and no fused upsample: its data gradient IS the source's gradient -
+            // written (or, through the epilogue's residual input, accumulated in place: each vector is read and written by one thread)
+            // straight into that buffer instead of a scratch tensor plus an accumulation launch
+            static const bool direct_off = getenv("DMME_NO_DGRAD_DIRECT") != nullptr;
+            const bool dgrad_direct = !direct_off && o.gn < 0 && o.src2 < 0 && o.up != 1;
+            if (dgrad_direct) {
+                d.dst = g1;
+                if (acc1) {
+                    d.res1 = g1;
+                    d.R1 = Cin;
+                }
+            }
+            rc = run_any_conv(dt, d, s);
+            if (rc != DMME_OK) break;
+
             if (o.gn >= 0) {
                 const Op& gop = P->ops[o.gn];
                 GnMod mod{};
@@ -1685,7 +1698,7 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
                                            (const float*)(pk + P->params[gop.gn_gamma].packed_off), (const float*)(ws + gop.gn_mr),
                                            a.scale, a.shift, a.dmask, a.pro_silu, g1, g2, acc1, acc2,
                                            grad_flat + P->params[gop.gn_gamma].ref_off, grad_flat + P->params[gop.gn_beta].ref_off, mod, s);
-            } else {
+            } else if (!dgrad_direct) {
                 rc = launch_grad_acc(dt, tmp, g1, g2, a.C1, a.C2, acc1, acc2, o.up == 1 ? 1 : 0, B, t1.H, t1.W, s);
             }
             if (rc != DMME_OK) break;

@@ -78,6 +78,7 @@ struct Op {
     int use_act = 0;           // FORWARD reads the pre-activated tensor of its GroupNorm (backward still works from src1 / src2 + scale / shift)
     int gd_n = 0, gd_gn[2] = {-1, -1}, gd_coff[2] = {0, 0};  // norms this conv's forward epilogue finishes (op index, channel offset in the norm)
     int gd_act = -1;           // which of them also gets the consumer's pre-activated input written (-1: none)
+    int res_alias = 0;         // backward: the residual input's gradient buffer is this conv's output gradient buffer (no copy)
     int wg_layer = -1;         // index into the grouped weight-gradient table of its kernel size (-1: per-layer kernels)
     int64_t wg_act = -1;       // backward workspace offset of its pre-activated input, written by its GroupNorm's backward for the
                                // deferred weight gradient (-1: none)
@@ -566,6 +567,24 @@ int build_plan(dmme_plan* P) {
         for (const Tensor& t : P->tensors) {
             P->gt_off.push_back(balloc((int64_t)B * t.H * t.W * t.C * es));
             if (t.C > cmax) cmax = t.C;
+        }
+        // A ResBlock's 1x1 residual conv feeds nothing but the residual input of conv2: the gradient of its output IS the gradient of
+        // the block's output - the two tensors share one gradient buffer instead of a copy launch per block
+        if (!getenv("DMME_NO_RES_ALIAS")) {
+            std::vector<int> uses(P->tensors.size(), 0), producer(P->tensors.size(), -1);
+            for (int oi = 0; oi < (int)ops.size(); ++oi) {
+                const Op& o = ops[oi];
+                for (int id : {o.src1, o.src2, o.res1, o.res2, o.gn_src1, o.gn_src2, o.at_qkv})
+                    if (id >= 0) ++uses[id];
+                if (o.kind == OP_CONV && o.dst >= 0) producer[o.dst] = oi;
+            }
+            for (Op& o : ops) {
+                if (o.kind != OP_CONV || o.res1 < 0 || o.res2 >= 0 || o.dst < 0) continue;
+                const int r = o.res1;
+                if (uses[r] != 1 || producer[r] < 0 || ops[producer[r]].kind != OP_CONV || P->tensors[r].C != P->tensors[o.dst].C) continue;
+                P->gt_off[r] = P->gt_off[o.dst];
+                o.res_alias = 1;
+            }
         }
         for (const Op& o : ops) {
             if (o.kind == OP_CONV && o.src1 >= 0) {
@@ -1721,7 +1740,9 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
             if (rc != DMME_OK) break;
         }
         // 4. residual branch: d(res) += dY
-        if (o.res1 >= 0) {
+        if (o.res1 >= 0 && o.res_alias) {
+            written[o.res1] = 1;  // (its gradient buffer is dY itself)
+        } else if (o.res1 >= 0) {
             const int R1 = P->tensors[o.res1].C;
             const int acc1 = claim(o.res1), acc2 = o.res2 >= 0 ? claim(o.res2) : 0;
             rc = launch_grad_acc(dt, dy, gptr(o.res1), o.res2 >= 0 ? gptr(o.res2) : nullptr, R1, a.Cout - R1, acc1, acc2, 0, B,

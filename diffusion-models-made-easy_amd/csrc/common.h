@@ -174,8 +174,8 @@ bool conv_out_thin_supported(int dtype, const ConvArgs& a);
 int launch_conv_out_thin(const ConvArgs& a, hipStream_t s);
 // K-split-over-waves 3x3 kernel for layers with few output pixels (conv_kw.hip); launch_conv_pipe dispatches to it
 struct ConvTile;
-bool conv_kw_pick(int dtype, const ConvArgs& a, ConvTile& g, int* ni, int* ring);
-int launch_conv_kw(const ConvArgs& a, const ConvTile& g, int NI, int ring, int ksplit, hipStream_t s);
+bool conv_kw_pick(int dtype, const ConvArgs& a, ConvTile& g, int* ni, int* ring, int* bm);
+int launch_conv_kw(const ConvArgs& a, const ConvTile& g, int NI, int ring, int BM, int ksplit, hipStream_t s);
 // will the kernel that runs this conv finish the norms consuming its output (ConvArgs::n_gno set; cg[k]: their group sizes)?
 bool conv_gn_direct_query(int dtype, const ConvArgs& a, const int* cg, int n);
 bool conv_gn_direct_ws_query(int dtype, const ConvArgs& a, const int* cg, int n);  // a.gn_cg: the output tensor's own group size

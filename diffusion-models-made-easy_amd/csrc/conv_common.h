@@ -431,7 +431,7 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, int co0, 
     }
 }
 
-// The store loop for 64-pixel tiles of WHOLE images (TN = 64 / HW images of HW = 2^k pixels; 256 threads), finishing the GroupNorms
+// The store loop for 64- / 128-pixel tiles of WHOLE images (TN = BM / HW images of HW = 2^k pixels; 256 threads), finishing the GroupNorms
 // that consume this conv's output (ConvArgs::gno): complete per-(image, group) statistics -> scale / shift / {mean, rstd} rows, and the
 // consumer's pre-activated input.  Statistics of the stored (rounded) values, merged with Chan's formula in a fixed order:
 //   thread: one 16-byte vector per item (VEC values) -> wave: lanes VPR apart hold the same channel vector of consecutive pixels
@@ -439,10 +439,10 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, int co0, 
 //   one thread per (image, group) over the group's vectors.
 // add_trow: the time-embedding row differs per image inside the tile (training: nt = N) and was left out of the staged image.
 // `stage`: the fp32 [64][BN] image, followed by 16 KB of scratch this function uses (kDirectLds bytes in all).
-constexpr int kDirectLds = 64 * 64 * 4 + 16 * 1024;
-template <typename T, int BN, typename PixFn>
+constexpr int kDirectLds = 64 * 64 * 4 + 16 * 1024;  // (BM = 64; the 128-pixel kw tiles own 130 KB anyway)
+template <typename T, int BN, int BM = 64, typename PixFn>
 __device__ __forceinline__ void conv_epilogue_store_direct(const ConvArgs& a, int co0, int n0, int HW, PixFn pix_of, float* stage, bool add_trow) {
-    constexpr int BM = 64, NT = 256, VEC = 16 / sizeof(T), VPR = BN / VEC, ITEMS = BM * VPR / NT, PB = 64 / VPR, NPB = BM / PB;
+    constexpr int NT = 256, VEC = 16 / sizeof(T), VPR = BN / VEC, ITEMS = BM * VPR / NT, PB = 64 / VPR, NPB = BM / PB;
     static_assert(ITEMS >= 1 && NPB == 4 * ITEMS, "conv_epilogue_store_direct: tile shape");
     const int tid = threadIdx.x, wave = tid >> 6, vec = tid % VPR;
     const int TN = BM / HW, sh_hw = 31 - __builtin_clz(HW);

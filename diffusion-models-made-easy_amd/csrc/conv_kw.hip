@@ -23,15 +23,19 @@ namespace dmme {
 // DENSE: the tile is TN WHOLE images (8x8, 4x4, 2x2 maps): the halo tile is just the tile's 64 pixels (one contiguous run of the NHWC
 // tensor) plus one row of zeros, and a fragment row whose tap falls outside its image reads that row - 8 KB of halo per wave instead of
 // up to 18 (4x4 maps: 144 halo rows for 64 pixels), which is what makes room for a ring deep enough to cover the L2 round trip.
-template <int NI, int RING, bool DENSE>
+// BM: 64 pixels, or 128 where that still gives every CU a workgroup (8x8 maps at the benchmark batch: two images per tile) - per
+// workgroup the fixed ~5 us (arguments, first round trip, cross-wave sum, epilogue) is then paid for twice the matrix work.
+template <int NI, int RING, bool DENSE, int BM>
 __global__ void __launch_bounds__(256, 1) conv3x3_kw_kernel(ConvArgs a, ConvTile g, int shTW, int shTH, int ksplit_dbg) {
     using T = bf16;
     const int ksplit = ksplit_dbg;
-    constexpr int KC = 64, EPV = 8, BM = 64, MI = 2, BN = 32 * NI;
+    constexpr int KC = 64, EPV = 8, MI = BM / 32, BN = 32 * NI;
     constexpr int U_BYTES = BN * ROW_DATA;  // one unit of filters: BN cout rows of one tap of one 64-channel chunk
     constexpr int NPI = BN / 8;             // DMA wave-instructions per unit (8 rows of 128 B each)
     constexpr int D = RING - 1;             // units in flight ahead of the one being consumed
-    constexpr int NQ = MI * NI;             // 32 x 32 sub-tiles of the output tile; wave q finishes sub-tile q
+    constexpr int NQ = MI * NI;             // 32 x 32 sub-tiles of the output tile
+    constexpr int OWN = NQ > 4 ? NQ / 4 : 1;  // sub-tiles a wave finishes: q = OWN * wave .. (consecutive couts of one 32-pixel row block)
+    static_assert(OWN <= NI && NI % OWN == 0, "a wave's sub-tiles share their pixel rows");
     static_assert(D >= 1 && D * NPI < 64, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) char lds[];
 #define KW_STAMP(K) do { if (a.stamps && blockIdx.x < 2 && blockIdx.y == 0 && threadIdx.x == 0) a.stamps[blockIdx.x * 8 + (K)] = (long long)wall_clock64(); } while (0)
@@ -298,7 +302,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_kw_kernel(ConvArgs a, ConvTile
 #undef KW_READ_FRAGS
     KW_STAMP(3);
 
-    // ---- sum the four partial tiles: wave q ends up with sub-tile q (mi = q / NI, ni = q % NI), added in wave order ----
+    // ---- sum the four partial tiles: wave w ends up with sub-tiles OWN w .. OWN w + OWN - 1 (q = mi * NI + ni), added in wave order ----
     float* red = reinterpret_cast<float*>(lds);  // [wave][q][j][lane]
     __syncthreads();                              // every wave is done with its halo / ring (all DMA retired by its last wait)
 #pragma unroll
@@ -306,38 +310,42 @@ __global__ void __launch_bounds__(256, 1) conv3x3_kw_kernel(ConvArgs a, ConvTile
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int q = mi * NI + ni;
-            if (q != wave) {
+            if (q / OWN != wave) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) red[((wave * NQ + q) * 16 + j) * 64 + lane] = acc[mi][ni][j];
             }
         }
     __syncthreads();
-    f32x16 tot[1][1];
-    if (wave < NQ) {
-        f32x16 own;
+    f32x16 tot[1][OWN];
+    const bool owner = wave * OWN < NQ;
+    if (owner) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) own[j] = 0.f;
+        for (int o = 0; o < OWN; ++o) {
+            f32x16 own;
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+            for (int j = 0; j < 16; ++j) own[j] = 0.f;
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                if (mi * NI + ni == wave) own = acc[mi][ni];
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            f32x16 p;
-            if (w == wave) {
-                p = own;
-            } else {
+                for (int ni = 0; ni < NI; ++ni)
+                    if (mi * NI + ni == wave * OWN + o) own = acc[mi][ni];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) p[j] = red[((w * NQ + wave) * 16 + j) * 64 + lane];
+            for (int w = 0; w < 4; ++w) {
+                f32x16 p;
+                if (w == wave) {
+                    p = own;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) p[j] = red[((w * NQ + wave * OWN + o) * 16 + j) * 64 + lane];
+                }
+                if (w == 0)
+                    tot[0][o] = p;
+                else
+                    tot[0][o] += p;
             }
-            if (w == 0)
-                tot[0][0] = p;
-            else
-                tot[0][0] += p;
         }
     }
-    const int wm0 = (wave / NI) * 32, wn0 = (wave % NI) * 32;  // of the owner waves
+    const int wm0 = ((wave * OWN) / NI) * 32, wn0 = ((wave * OWN) % NI) * 32;  // of the owner waves
 
     auto pix_of = [&](int m) -> int {
         const int tx = m & mTW, ty = (m >> shTW) & mTH, tn = m >> (shTW + shTH);
@@ -345,14 +353,17 @@ __global__ void __launch_bounds__(256, 1) conv3x3_kw_kernel(ConvArgs a, ConvTile
         return n < a.N ? (n * a.Hout + oy0 + ty) * a.Wout + ox0 + tx : -1;
     };
     if (ksplit > 1) {  // raw partial sums: lane = cout (coalesced 128-byte rows), register = pixel
-        if (wave < NQ) {
+        if (owner) {
             float* part = a.splitk + (int64_t)blockIdx.y * a.N * a.Hout * a.Wout * a.Cout;
-            const int co = co0 + wn0 + r;
-            if (co < a.Cout) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int opix = pix_of(wm0 + (j & 3) + 8 * (j >> 2) + 4 * h);
-                    if (opix >= 0) part[(int64_t)opix * a.Cout + co] = tot[0][0][j];
+            for (int o = 0; o < OWN; ++o) {
+                const int co = co0 + wn0 + 32 * o + r;
+                if (co < a.Cout) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int opix = pix_of(wm0 + (j & 3) + 8 * (j >> 2) + 4 * h);
+                        if (opix >= 0) part[(int64_t)opix * a.Cout + co] = tot[0][o][j];
+                    }
                 }
             }
         }
@@ -363,57 +374,66 @@ __global__ void __launch_bounds__(256, 1) conv3x3_kw_kernel(ConvArgs a, ConvTile
     if (a.n_gno > 0) {  // whole-image tile (host-checked): finish the consuming GroupNorms here
         const bool add_trow = a.tproj && a.nt != 1 && g.TN > 1;
         __syncthreads();
-        if (wave < NQ) conv_epilogue_stage<T, BN, 1, 1>(a, tot, co0, wn0, r, h, wm0, n0, reinterpret_cast<float*>(lds), !add_trow);
+        if (owner) conv_epilogue_stage<T, BN, 1, OWN>(a, tot, co0, wn0, r, h, wm0, n0, reinterpret_cast<float*>(lds), !add_trow);
         __syncthreads();
-        conv_epilogue_store_direct<T, BN>(a, co0, n0, a.Hout * a.Wout, pix_of, reinterpret_cast<float*>(lds), add_trow);
+        conv_epilogue_store_direct<T, BN, BM>(a, co0, n0, a.Hout * a.Wout, pix_of, reinterpret_cast<float*>(lds), add_trow);
     } else if (conv_epilogue_is_staged<T>(a, g.TN)) {
         __syncthreads();  // the partial sums have been read: the staging image may overwrite them
-        if (wave < NQ) conv_epilogue_stage<T, BN, 1, 1>(a, tot, co0, wn0, r, h, wm0, n0, reinterpret_cast<float*>(lds));
+        if (owner) conv_epilogue_stage<T, BN, 1, OWN>(a, tot, co0, wn0, r, h, wm0, n0, reinterpret_cast<float*>(lds));
         __syncthreads();
         conv_epilogue_store<T, BM, BN, 256>(a, co0, n0, pix_of, reinterpret_cast<float*>(lds), tile_s);
-    } else if (wave < NQ) {
-        conv_epilogue<T, BM, BN, 1, 1>(a, tot, co0, wn0, r, h, wm0, n0, g.TN, pix_of, reinterpret_cast<float*>(lds), tile_s);  // general path: no barrier
+    } else if (owner) {
+        conv_epilogue<T, BM, BN, 1, OWN>(a, tot, co0, wn0, r, h, wm0, n0, g.TN, pix_of, reinterpret_cast<float*>(lds), tile_s);  // general path: no barrier
     }
     KW_STAMP(4);
 #undef KW_STAMP
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
-static bool kw_dense(const ConvArgs& a, const ConvTile& g) { return !a.up && g.TH == a.Hout && g.TW == a.Wout && g.TN * g.TH * g.TW == 64; }
-static size_t kw_lds(const ConvArgs& a, const ConvTile& g, int NI, int ring) {
-    const size_t halo = kw_dense(a, g) ? (size_t)(64 + 8) * ROW_DATA : (size_t)((g.a_rows + 7) & ~7) * ROW_DATA;
+static bool kw_dense(const ConvArgs& a, const ConvTile& g, int BM) { return !a.up && g.TH == a.Hout && g.TW == a.Wout && g.TN * g.TH * g.TW == BM; }
+static size_t kw_lds(const ConvArgs& a, const ConvTile& g, int BM, int NI, int ring) {
+    const size_t halo = kw_dense(a, g, BM) ? (size_t)(BM + 8) * ROW_DATA : (size_t)((g.a_rows + 7) & ~7) * ROW_DATA;
     const size_t per_wave = halo + (size_t)ring * 32 * NI * ROW_DATA;
-    const size_t red = (size_t)4 * 64 * 32 * NI * 4;
+    const size_t red = (size_t)4 * BM * 32 * NI * 4;
     return 4 * per_wave > red ? 4 * per_wave : red;
 }
 
-// which instance (NI, RING) runs this conv; false: not this kernel's shape
-bool conv_kw_pick(int dtype, const ConvArgs& a, ConvTile& g, int* ni_out, int* ring_out) {
+// which instance (BM, NI, RING) runs this conv; false: not this kernel's shape
+bool conv_kw_pick(int dtype, const ConvArgs& a, ConvTile& g, int* ni_out, int* ring_out, int* bm_out) {
     static const bool off = getenv("DMME_NO_KW") != nullptr;
     static const int force_ni = getenv("DMME_KW_NI") ? atoi(getenv("DMME_KW_NI")) : 0;
+    static const int force_bm = getenv("DMME_KW_BM") ? atoi(getenv("DMME_KW_BM")) : 0;
     static const int max_ring = getenv("DMME_KW_RING") ? atoi(getenv("DMME_KW_RING")) : 6;
     if (off || dtype != DMME_BF16 || a.x3) return false;
     const int Cin = a.C1 + a.C2;
     if (a.taps != 9 || a.stride != 1 || a.up == 2 || a.in_nchw || Cin % 64 || a.C1 % 64 || a.Cout < 32) return false;
     if ((int64_t)a.Cout * 9 * Cin >= (1ll << 31) || (int64_t)a.N * a.Hin * a.Win * (a.C1 > a.C2 ? a.C1 : a.C2) >= (1ll << 31)) return false;
-    // 32-cout tiles when 64-cout tiles leave CUs idle: twice the workgroups, half the filter stream per wave
-    ConvTile t{};
-    if (!make_tile(a, 64, 64, t) || t.a_rows > 256) return false;  // okmask: <= 32 halo vectors per lane
-    int NI = (int64_t)t.tiles_m * ((a.Cout + 63) / 64) < 256 ? 1 : 2;
-    if (force_ni) NI = force_ni;
-    if (!make_tile(a, 64, 32 * NI, t)) return false;
+    // the largest tile that still gives every CU a workgroup (the filter stream per MFMA halves with BM, the fixed cost per workgroup
+    // is paid for more work); below that, 64 x 32: the most workgroups
+    static const int kCand[4][2] = {{128, 2}, {128, 1}, {64, 2}, {64, 1}};
     static const int kRings[4] = {6, 4, 3, 2};
-    int ring = 0;
-    for (int cand : kRings)
-        if (cand <= max_ring && kw_lds(a, t, NI, cand) <= 160 * 1024) {
-            ring = cand;
-            break;
-        }
-    if (!ring) return false;
-    g = t;
-    *ni_out = NI;
-    *ring_out = ring;
-    return true;
+    for (int c = 0; c < 4; ++c) {
+        const int BM = kCand[c][0], NI = kCand[c][1];
+        if ((force_ni && NI != force_ni) || (force_bm && BM != force_bm)) continue;
+        if (a.Cout % (32 * NI) && c < 3) continue;  // (partial cout tiles only on the smallest tile)
+        ConvTile t{};
+        if (!make_tile(a, BM, 32 * NI, t) || t.a_rows > 256) continue;  // okmask: <= 32 halo vectors per lane
+        if (BM == 128 && !kw_dense(a, t, BM)) continue;                  // the 128-pixel form is for whole-image tiles
+        if (c < 3 && !force_ni && !force_bm && (int64_t)t.tiles_m * t.tiles_n < 256) continue;
+        int ring = 0;
+        for (int cand : kRings)
+            if (cand <= max_ring && kw_lds(a, t, BM, NI, cand) <= 160 * 1024) {
+                ring = cand;
+                break;
+            }
+        if (!ring) continue;
+        g = t;
+        *ni_out = NI;
+        *ring_out = ring;
+        *bm_out = BM;
+        return true;
+    }
+    return false;
 }
 
 static int ilog2_kw(int v) {
@@ -422,26 +442,26 @@ static int ilog2_kw(int v) {
     return s;
 }
 
-template <int NI, int RING, bool DENSE>
+template <int NI, int RING, bool DENSE, int BM>
 static int launch_kw_inst(const ConvArgs& a, const ConvTile& g, int ksplit, size_t lds, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_kw_kernel<NI, RING, DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_kw_kernel<NI, RING, DENSE, BM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024));
         attr_done = true;
     }
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)ksplit);
-    hipLaunchKernelGGL((conv3x3_kw_kernel<NI, RING, DENSE>), grid, dim3(256), lds, s, a, g, ilog2_kw(g.TW), ilog2_kw(g.TH), ksplit);
+    hipLaunchKernelGGL((conv3x3_kw_kernel<NI, RING, DENSE, BM>), grid, dim3(256), lds, s, a, g, ilog2_kw(g.TW), ilog2_kw(g.TH), ksplit);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }
 
-int launch_conv_kw(const ConvArgs& a, const ConvTile& g, int NI, int ring, int ksplit, hipStream_t s) {
-    const size_t lds = kw_lds(a, g, NI, ring);
-    const bool dense = kw_dense(a, g);
+int launch_conv_kw(const ConvArgs& a, const ConvTile& g, int NI, int ring, int BM, int ksplit, hipStream_t s) {
+    const size_t lds = kw_lds(a, g, BM, NI, ring);
+    const bool dense = kw_dense(a, g, BM);
 #define DMME_KW_CASE(NI_, RING_)                                                                                       \
-    if (NI == NI_ && ring == RING_)                                                                                    \
-        return dense ? launch_kw_inst<NI_, RING_, true>(a, g, ksplit, lds, s) : launch_kw_inst<NI_, RING_, false>(a, g, ksplit, lds, s);
+    if (BM == 64 && NI == NI_ && ring == RING_)                                                                        \
+        return dense ? launch_kw_inst<NI_, RING_, true, 64>(a, g, ksplit, lds, s) : launch_kw_inst<NI_, RING_, false, 64>(a, g, ksplit, lds, s);
     DMME_KW_CASE(1, 2)
     DMME_KW_CASE(1, 3)
     DMME_KW_CASE(1, 4)
@@ -451,6 +471,15 @@ int launch_conv_kw(const ConvArgs& a, const ConvTile& g, int NI, int ring, int k
     DMME_KW_CASE(2, 4)
     DMME_KW_CASE(2, 6)
 #undef DMME_KW_CASE
+#define DMME_KW_CASE128(NI_, RING_) \
+    if (BM == 128 && dense && NI == NI_ && ring == RING_) return launch_kw_inst<NI_, RING_, true, 128>(a, g, ksplit, lds, s);
+    DMME_KW_CASE128(1, 2)
+    DMME_KW_CASE128(1, 3)
+    DMME_KW_CASE128(1, 4)
+    DMME_KW_CASE128(1, 6)
+    DMME_KW_CASE128(2, 2)
+    DMME_KW_CASE128(2, 3)
+#undef DMME_KW_CASE128
     DMME_REQUIRE(false, DMME_ERR_UNSUPPORTED, "conv_kw: no such instance");
     return DMME_OK;
 }

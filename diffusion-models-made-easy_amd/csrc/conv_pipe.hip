@@ -765,11 +765,14 @@ static int set_lds_limit(K kernel, size_t bytes) {
     return DMME_OK;
 }
 
-// the 64 x 64 four-wave instances (8x8 / 4x4 maps, small batches) give way to the K-split-over-waves kernel (conv_kw.hip)
-// (pick 3 = layers with fewer than 512 workgroups; the 512-workgroup 8x8 layers stay on the two-per-CU four-wave kernel: 20.8 vs 28.8 us)
-static bool kw_replaces(int pick) {
+// the 64 x 64 four-wave instances (8x8 / 4x4 maps, small batches) give way to the K-split-over-waves kernel (conv_kw.hip): pick 3
+// (layers with fewer than 512 workgroups) always; the 512-workgroup 8x8 layers only where its 128-pixel tile applies (with 64-pixel
+// tiles the two-per-CU four-wave kernel is as fast: 20.8 vs 21.4 us)
+static bool kw_takes(int dtype, const ConvArgs& a, int pick, ConvTile& gk, int* ni, int* ring, int* bm) {
     static const int all = getenv("DMME_KW_ALL") != nullptr;
-    return pick == 3 || (all && pick == 2);
+    if (pick != 3 && pick != 2) return false;
+    if (!conv_kw_pick(dtype, a, gk, ni, ring, bm)) return false;
+    return pick == 3 || all || *bm == 128;
 }
 static int kw_ksplit(const ConvArgs& a, const ConvTile& g) {
     // Measured with this kernel: a split over workgroups no longer pays at any batch (B = 1: 775 -> 846 steps/s without it, B = 8:
@@ -790,9 +793,9 @@ static int kw_ksplit(const ConvArgs& a, const ConvTile& g) {
     return ks < 1 ? 1 : ks;
 }
 template <typename T>
-static int launch_kw_t(const ConvArgs& a, const ConvTile& gk, int ni, int ring, hipStream_t s) {
+static int launch_kw_t(const ConvArgs& a, const ConvTile& gk, int ni, int ring, int bm, hipStream_t s) {
     const int ksplit = kw_ksplit(a, gk);
-    const int rc = launch_conv_kw(a, gk, ni, ring, ksplit, s);
+    const int rc = launch_conv_kw(a, gk, ni, ring, bm, ksplit, s);
     if (rc != DMME_OK) return rc;
     if (ksplit > 1) {
         const int64_t total4 = (int64_t)a.N * a.Hout * a.Wout * (a.Cout / 4);
@@ -828,11 +831,9 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
         }
     }
     if constexpr (sizeof(T) == 2) {
-        if (kw_replaces(pick)) {
-            ConvTile gk{};
-            int kni = 0, kring = 0;
-            if (conv_kw_pick(DMME_BF16, a, gk, &kni, &kring)) return launch_kw_t<T>(a, gk, kni, kring, s);
-        }
+        ConvTile gk{};
+        int kni = 0, kring = 0, kbm = 0;
+        if (kw_takes(DMME_BF16, a, pick, gk, &kni, &kring, &kbm)) return launch_kw_t<T>(a, gk, kni, kring, kbm, s);
     }
     size_t lds = pipe_lds(g, kPipeCand[pick][1], kPipeCand[pick][2]);
     ConvArgs ad = a;
@@ -892,18 +893,19 @@ bool conv_gn_direct_query(int dtype, const ConvArgs& a, const int* cg, int n) {
     ConvTile g{};
     const int pick = pipe_pick(a, g);
     if (pick < 0) return false;
-    int BN = 0;
+    int BN = 0, BM = 64;
     ConvTile gk{};
-    int kni = 0, kring = 0;
-    if (kw_replaces(pick) && conv_kw_pick(dtype, a, gk, &kni, &kring)) {
+    int kni = 0, kring = 0, kbm = 0;
+    if (kw_takes(dtype, a, pick, gk, &kni, &kring, &kbm)) {
         if (a.up || kw_ksplit(b, gk) != 1) return false;
         g = gk;
         BN = 32 * kni;
+        BM = kbm;
     } else {
         if (kPipeCand[pick][0] != 64 || pipe_ksplit(b, g, pick, dtype == DMME_BF16 ? 64 : 32) != 1) return false;
         BN = kPipeCand[pick][1];
     }
-    if (g.TH != a.Hout || g.TW != a.Wout || g.TN * g.TH * g.TW != 64 || a.Cout % BN) return false;  // whole images, whole cout tiles
+    if (g.TH != a.Hout || g.TW != a.Wout || g.TN * g.TH * g.TW != BM || a.Cout % BN) return false;  // whole images, whole cout tiles
     if (HW < 64 / (BN / VEC)) return false;  // a wave's pixels per channel vector must not straddle images
     for (int k = 0; k < n; ++k)
         if (cg[k] % VEC || BN % cg[k]) return false;
@@ -940,13 +942,13 @@ bool conv_pipe_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int
     ConvTile g{};
     const int pick = pipe_pick(a, g);
     if (pick < 0) return false;
-    if (kw_replaces(pick)) {
+    {
         ConvTile gk{};
-        int kni = 0, kring = 0;
-        if (conv_kw_pick(dtype, a, gk, &kni, &kring)) {
+        int kni = 0, kring = 0, kbm = 0;
+        if (kw_takes(dtype, a, pick, gk, &kni, &kring, &kbm)) {
             if (!stats_tile_ok(a, gk, 32 * kni, cg, 8)) return false;
             *tiles = gk.tiles_x * gk.tiles_y;
-            *px = 64;
+            *px = kbm;
             return true;
         }
     }
@@ -967,11 +969,11 @@ void conv_pipe_label(int dtype, const ConvArgs& a, char* buf, int cap) {
     }
     ConvTile g{};
     const int pick = pipe_pick(a, g);
-    if (kw_replaces(pick)) {
+    {
         ConvTile gk{};
-        int kni = 0, kring = 0;
-        if (conv_kw_pick(dtype, a, gk, &kni, &kring)) {
-            snprintf(buf, (size_t)cap, "conv3x3_kw_kernel<%d,%d>", kni, kring);
+        int kni = 0, kring = 0, kbm = 0;
+        if (kw_takes(dtype, a, pick, gk, &kni, &kring, &kbm)) {
+            snprintf(buf, (size_t)cap, "conv3x3_kw_kernel<%d,%d,%d>", kni, kring, kbm);
             return;
         }
     }

@@ -184,6 +184,10 @@ bool conv1x1_pipe_supported(int dtype, const ConvArgs& a);
 int launch_conv1x1_pipe(int dtype, const ConvArgs& a, hipStream_t s);
 void conv1x1_pipe_label(int dtype, const ConvArgs& a, char* buf, int cap);
 bool conv1x1_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px);
+// activation-stationary 1x1 variant for K <= 256 (conv1x1_as.hip); launch_conv1x1_pipe dispatches to it
+bool conv1x1_as_supported(int dtype, const ConvArgs& a);
+bool conv1x1_as_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px);
+int launch_conv1x1_as(const ConvArgs& a, hipStream_t s);
 // can the kernel that would run this conv also emit GroupNorm partials of its output (group size cg)?
 // on success: tiles = spatial tiles per image, px = pixels per tile (the partial's element count is px*cg)
 bool conv_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px);

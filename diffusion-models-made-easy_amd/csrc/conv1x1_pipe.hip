@@ -175,6 +175,11 @@ bool conv1x1_pipe_supported(int dtype, const ConvArgs& a) {
 }
 
 bool conv1x1_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px) {
+    {
+        ConvArgs b = a;  // the activation-stationary kernel takes this conv (with or without statistics): its tiles
+        b.gn_part = nullptr;
+        if (conv1x1_as_supported(dtype, b)) return conv1x1_as_stats_query(dtype, a, cg, tiles, px);
+    }
     const int pick = pick1(a);
     if (pick < 0) return false;
     const int BM = k1Cand[pick][0], BN = k1Cand[pick][1], HW = a.Hout * a.Wout, vec = dtype == DMME_BF16 ? 8 : 4;
@@ -223,11 +228,16 @@ static int launch1_t(const ConvArgs& a, hipStream_t s) {
 
 int launch_conv1x1_pipe(int dtype, const ConvArgs& a, hipStream_t s) {
     DMME_REQUIRE(conv1x1_pipe_supported(dtype, a), DMME_ERR_UNSUPPORTED, "conv1x1_pipe: unsupported shape");
+    if (conv1x1_as_supported(dtype, a)) return launch_conv1x1_as(a, s);
     if (dtype == DMME_BF16) return launch1_t<bf16>(a, s);
     return a.x3 ? launch1_t<float, true>(a, s) : launch1_t<float>(a, s);
 }
 
 void conv1x1_pipe_label(int dtype, const ConvArgs& a, char* buf, int cap) {
+    if (conv1x1_as_supported(dtype, a)) {
+        snprintf(buf, (size_t)cap, "conv1x1_as_kernel<%d>", (a.C1 + a.C2) / 64);
+        return;
+    }
     const int pick = pick1(a);
     snprintf(buf, (size_t)cap, "conv1x1_pipe_kernel<%s,%d,%d>", dtype == DMME_BF16 ? "bf16" : a.x3 ? "float:bf16x3" : "float", pick >= 0 ? k1Cand[pick][0] : 0,
              pick >= 0 ? k1Cand[pick][1] : 0);

@@ -70,6 +70,11 @@ CASES = [
     ("ws_cat256_32", 64, 128, 128, 32, 128, 3, 1, False, True, 1, False),
     ("ws_up256_16", 32, 256, 0, 16, 256, 3, 1, True, False, 0, False),
     ("ws_plain256_16", 128, 256, 0, 16, 256, 3, 1, False, False, 0, False),
+    # K <= 256, >= 4 units of 64 couts, whole 128-pixel tiles: the activation-stationary 1x1 kernel (bf16)
+    ("as_proj256_res", 3, 256, 0, 16, 256, 1, 1, False, False, 1, True),
+    ("as_cat128_128_to256", 2, 128, 128, 16, 256, 1, 1, False, True, 0, False),
+    ("as_k128_to384", 1, 128, 0, 32, 384, 1, 1, False, True, 0, True),
+    ("as_8x8_two_images_per_tile", 6, 256, 0, 8, 512, 1, 1, False, False, 1, True),
 ]
 
 

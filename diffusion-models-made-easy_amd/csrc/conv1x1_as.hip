@@ -1,19 +1,22 @@
 // 1x1 convolution with the ACTIVATIONS STATIONARY IN REGISTERS: nn.Conv2d(kernel_size=1) of Attention.qkv_proj / proj and
-// ResBlock.residual (models/ddpm.py:51-52,109) at K = Cin <= 256, the GroupNorm apply in front of qkv_proj included.
+// ResBlock.residual (models/ddpm.py:51-52,109) at K = Cin = 128 / 256, the GroupNorm apply in front of qkv_proj included.
 //
 // These GEMMs have a SHORT K: a 128 x 128 output tile is 64 MFMAs per wave behind 128 KB of operands, so a tiled kernel that loads,
 // stages and synchronises per tile (conv1x1_pipe.hip: 1536 workgroups for qkv, each re-reading and re-normalising its activation
-// tile for one of six cout tiles) spends its life in exposed round trips: 46 us for 12.9 GFLOP / 67 MB.  Here a workgroup owns 128
-// pixels for ALL couts:
-//   * its activation tile (128 px x K) comes in once by LDS-DMA, is read into MFMA A-fragments (64 px x K per wave: 16 x 2 x 4
-//     registers at K = 256), normalised there, and never touched again;
-//   * the weights stream through a 3-slot LDS ring in units of 64 couts x K (32 KB at K = 256) by LDS-DMA, two units in flight;
-//     waves (pm, cn) = (pixel half, cout half of the unit) compute 64 px x 32 couts per unit: one B fragment read per two MFMAs;
-//   * each wave finishes its own 64 x 32 piece from its registers (the MFMAs run transposed and a half-wave swap gives every lane 8
-//     consecutive couts of one pixel; bias is the accumulators' initial value, the residual arrives by LDS-DMA into a private
-//     double buffer): 16-byte stores, GroupNorm partials of 64-pixel tiles.
-// One workgroup barrier per unit.  The waves' vector-memory queue holds filter DMA, residual DMA and output stores in a fixed
-// order, so every wait is a counted `s_waitcnt vmcnt(N)` (they retire in order); nothing in the loop is a compiler-visible load.
+// tile for one of six cout tiles) spends its life in exposed round trips: 46 us for 12.9 GFLOP / 67 MB.  Here a workgroup of eight
+// waves owns 128 pixels for ALL couts:
+//   * its activation tile (128 px x K) comes in once by LDS-DMA, is normalised in place by all 512 threads (rolled loop), is read into
+//     MFMA fragments (64 px x K per MFMA wave: 16 x 2 x 4 registers at K = 256) and never touched again;
+//   * the weights stream through an LDS ring in units of 64 couts x K (32 KB at K = 256) by LDS-DMA, up to two units in flight; the four
+//     MFMA waves (pixel half, cout half of the unit) compute 64 px x 32 couts per unit with one weight fragment read per two MFMAs.
+//     The MFMAs run transposed (weights as the A operand), so a half-wave register swap (v_permlane32_swap) leaves every lane with 8
+//     consecutive couts of one pixel: the unit goes to an LDS stage as 16-byte vectors, bias being the accumulators' initial value;
+//   * the other four waves are the STORE TEAM: they take each staged unit to memory in whole 128-byte rows, add the residual and keep
+//     the GroupNorm partials (32-pixel tiles, mean then M2 by two wave reductions).  Measured on the first version (one team doing
+//     both): with every CU storing at the same moment the stores are accepted at the chip's HBM write rate and a wave that issues them
+//     stalls for the whole drain (0.9 us per unit, MFMAs idle); a second wave per SIMD takes that stall instead.
+// One workgroup barrier per unit.  The MFMA waves' vector-memory queue holds only their weight DMA, so every wait is a counted
+// `s_waitcnt vmcnt(N)` (retired in order); the store team uses ordinary loads / stores.  qkv (B = 128): 46 -> 27 us, proj 20.6 -> 17.
 #include <stdio.h>
 
 #include "conv_common.h"
@@ -292,9 +295,15 @@ __global__ void __launch_bounds__(512) conv1x1_as_kernel(ConvArgs a, int HW, int
             bfr[SET][kk] = __builtin_bit_cast(uint4, *reinterpret_cast<const lds_u32x4_as*>(rb_ + (tB ^ (kk << 5))));               \
     } while (0)
     const lds_c* F3 = (const lds_c*)foldL;
-    f32x4 fold[4];  // bias of the lane's 16 cout rows: 4 h + 8 g + (0..3)
+    f32x16 fold;  // bias of the lane's 16 cout rows 4 h + 8 g + (0..3), register order: the first MFMA's C operand (no copies)
 #define AS_FOLD(U)                                                                                                                 \
-    _Pragma("unroll") for (int g = 0; g < 4; ++g) fold[g] = *reinterpret_cast<const lds_f32x4_as*>(F3 + ((U) * 64 + cn * 32 + 8 * g + 4 * h) * 4)
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                                \
+        const f32x4 t_ = *reinterpret_cast<const lds_f32x4_as*>(F3 + ((U) * 64 + cn * 32 + 8 * g + 4 * h) * 4);                    \
+        fold[4 * g] = t_[0];                                                                                                       \
+        fold[4 * g + 1] = t_[1];                                                                                                   \
+        fold[4 * g + 2] = t_[2];                                                                                                   \
+        fold[4 * g + 3] = t_[3];                                                                                                   \
+    }
     AS_READ(0, 0, 0);
     AS_FOLD(0);
     int slot = 0;
@@ -308,8 +317,6 @@ __global__ void __launch_bounds__(512) conv1x1_as_kernel(ConvArgs a, int HW, int
         const int nslot = slot == RING - 1 ? 0 : slot + 1;
         f32x16 acc[2];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[0][j] = acc[1][j] = fold[j >> 2][j & 3];
-#pragma unroll
         for (int kg = 0; kg < KCH; ++kg) {  // 4 k-steps per group, the next group's fragments read under this group's MFMAs
             if (kg + 1 < KCH) {
                 if (kg & 1)
@@ -322,7 +329,8 @@ __global__ void __launch_bounds__(512) conv1x1_as_kernel(ConvArgs a, int HW, int
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
                     acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bfr[kg & 1][kk]),
-                                                                      __builtin_bit_cast(bf16x8, af[mi][4 * kg + kk]), acc[mi], 0, 0, 0);
+                                                                      __builtin_bit_cast(bf16x8, af[mi][4 * kg + kk]),
+                                                                      kg == 0 && kk == 0 ? fold : acc[mi], 0, 0, 0);
         }
         if (u < 3) AS_STAMP(4 + 3 * u);
         // ---- this wave's 64 px x 32 couts of unit u -> bf16, staged for the store team ----
@@ -374,7 +382,7 @@ static bool as_stats_cg_ok(int cg) { return cg == 8 || cg == 16 || cg == 32; }
 // shape rules (statistics aside)
 static bool as_shape_ok(int dtype, const ConvArgs& a) {
     static const bool off = getenv("DMME_NO_CONV1X1_AS") != nullptr;
-    static const int min_units = getenv("DMME_AS_MIN_UNITS") ? atoi(getenv("DMME_AS_MIN_UNITS")) : 4;
+    static const int min_units = getenv("DMME_AS_MIN_UNITS") ? atoi(getenv("DMME_AS_MIN_UNITS")) : 2;
     if (off || dtype != DMME_BF16 || a.x3) return false;
     if (a.taps != 1 || a.stride != 1 || a.up || a.in_nchw || a.out_nchw || a.out_silu || a.res2 || a.n_gno) return false;
     if (a.tproj && a.nt != 1) return false;

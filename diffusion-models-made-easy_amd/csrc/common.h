@@ -65,6 +65,38 @@ __device__ __forceinline__ float silu_fast(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 
+// Wave-wide reductions without LDS traffic.  `__shfl_xor` is a ds_bpermute (an LDS-pipe round trip per step: six dependent ones per
+// reduction, ~100 cycles each); here the four steps inside a 16-lane row are DPP operands of the add itself (quad_perm swaps, then
+// the mirrors: the lanes they pair already hold identical partial results, so they act as lane ^ 4 / lane ^ 8), and the two steps
+// across rows are the gfx950 row / half-wave register swaps.  Every lane ends up with the same bits.
+// (The swaps are inline asm: this hipcc folds several calls of __builtin_amdgcn_permlane32_swap with different operands into one;
+// `s_nop 1`: a VALU result needs two wait states before a swap reads it, and the hazard recogniser does not see inside asm.)
+__device__ __forceinline__ void permlane16_swap(float& x, float& y) {  // odd 16-lane rows of x <-> even rows of y
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+#endif
+}
+__device__ __forceinline__ void permlane32_swap(float& x, float& y) {  // lanes 32-63 of x <-> lanes 0-31 of y
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+#endif
+}
+#define DMME_DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
+__device__ __forceinline__ float row16_sum(float v) {  // over the lane's 16-lane row
+    v += DMME_DPP_F(v, 0xB1);   // quad_perm [1,0,3,2]
+    v += DMME_DPP_F(v, 0x4E);   // quad_perm [2,3,0,1]
+    v += DMME_DPP_F(v, 0x141);  // row_half_mirror
+    v += DMME_DPP_F(v, 0x140);  // row_mirror
+    return v;
+}
+__device__ __forceinline__ float half_sum(float v) {  // over the lane's 32-lane half wave
+    v = row16_sum(v);
+    float a = v, b = v;
+    permlane16_swap(a, b);  // a: the even row's value in both rows of a pair, b: the odd row's
+    return a + b;
+}
+// (the general-purpose reductions keep the xor butterfly of ds_bpermute steps: their callers are HBM-bound kernels, and the bf16
+// network's max-error statistics are calibrated on this summation order)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

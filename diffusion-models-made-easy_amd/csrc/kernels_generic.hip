@@ -182,11 +182,8 @@ __global__ void __launch_bounds__(256) conv_in_mfma_kernel(ConvArgs a, int nbloc
                             s += x;
                             ss = fmaf(x, x, ss);
                         }
-#pragma unroll
-                        for (int o = 1; o < 32; o <<= 1) {
-                            s += __shfl_xor(s, o, 64);
-                            ss += __shfl_xor(ss, o, 64);
-                        }
+                        s = half_sum(s);  // over this half-wave's 32 pixels
+                        ss = half_sum(ss);
                         if (r == 0) {
                             const float mean = s * (1.f / 128.f);
                             float* po = a.gn_part + (((int64_t)n * a.gn_tiles + (rem >> 5)) * (a.Cout / 4) + ct * 8 + 2 * gq + h) * 2;

@@ -142,6 +142,19 @@ struct GnOut {
     int C, cg, c_off;    // the norm's width and group size; channel c of this conv's output is channel c_off + c of the norm
 };
 
+// A GroupNorm whose statistics arrive as the producers' per-tile partials and are merged by the CONSUMING conv itself (its parameter
+// fill; wave-specialised 3x3 kernel) instead of by a finalize launch.  Same layout as launch_gn_finalize_parts' arguments: source i has
+// t_i partials per image of cnt_i elements each, [N][t_i][groups][2] {mean, M2}; a consumer group is nf whole producer groups of one source.
+struct GnIn {
+    const float* p1;
+    const float* p2;
+    int t1, cnt1, C1, t2, cnt2, C2, groups;
+    const float* gamma;
+    const float* beta;
+    float eps;
+    float* mean_rstd;  // [N][groups][2], written (with scale / shift) by the workgroup holding the image's first tile
+};
+
 struct ConvArgs {
     const void* src1;
     const void* src2;
@@ -183,6 +196,8 @@ struct ConvArgs {
     void* act;
     int act_k, act_silu;
     const float* act_dmask;  // [N][gno[act_k].C] or null
+    GnIn gni;                 // has_gni: scale / shift come from gni's partials (the arrays are outputs of this conv, not inputs)
+    int has_gni;
 };
 
 // ---- kernel launchers (defined in the .hip files) ------------------------------------
@@ -199,6 +214,8 @@ int launch_conv_mfma(int dtype, const ConvArgs& a, hipStream_t s);
 void conv_mfma_label(int dtype, const ConvArgs& a, char* buf, int cap);
 // software-pipelined 3x3 stride-1 variant (conv_pipe.hip); preferred when it applies
 bool conv_pipe_supported(int dtype, const ConvArgs& a);
+// would this conv run on the wave-specialised kernel, and can that kernel merge its norm's partials itself (ConvArgs::gni)?
+bool conv_gn_in_query(int dtype, const ConvArgs& a);
 int launch_conv_pipe(int dtype, const ConvArgs& a, hipStream_t s);
 void conv_pipe_label(int dtype, const ConvArgs& a, char* buf, int cap);
 // the 3- / 6-channel output conv as one 27- / 54-column GEMM + a 9-term gather (conv_thin.hip)

@@ -378,6 +378,61 @@ __device__ __forceinline__ WsTile ws_tile_of(const ConvTile& g, int shTW, int sh
 //   filter taps (128 couts x 64 channels = 16 KB, filled by LDS-DMA one stage ahead; slot = stage % 3).
 // A tile ends on slot R2 and buffer A1 (9 stages per chunk, even chunk count) while the next tile's first tap / chunk
 // are already in R0 / A0, so R1|R2|A1 (>= 64 KB) stages the epilogue: two passes of 128 pixels.
+// Parameter rows of image n for the wave-specialised kernel when the norm in front of it is finished HERE (ConvArgs::gni): thread c
+// merges the partials of its channel's group - all of one source, equal counts, so the mean is the average of the means and
+// M2 = sum M2_i + cnt * sum (mean_i - mean)^2 (two passes over <= 64 L2-resident float2, no divisions in the loop) - and derives its
+// own scale / shift; `writer` (the workgroup with the image's first tile) also leaves scale / shift / {mean, rstd} in memory for
+// whoever reads them later (the backward pass).  One launch less per norm: a finalize kernel this small costs its dispatch, its
+// cold instruction fetch and two dependent round trips, ~6 us between two convolutions.
+__device__ __forceinline__ void ws_fill_par_gni(const ConvArgs& a, int n, bool writer, float* par, int Cin, int tid, int nthr) {
+    const GnIn& G = a.gni;
+    const int cg = Cin / G.groups;
+    for (int c = tid; c < Cin; c += nthr) {
+        const int g = c / cg, c_first = g * cg;
+        const bool second = c_first >= G.C1;
+        const float* p = second ? G.p2 : G.p1;
+        const int tiles = second ? G.t2 : G.t1, cs = second ? G.C2 : G.C1, cnt = second ? G.cnt2 : G.cnt1;
+        const int fg = cs / G.groups, f0 = (second ? c_first - G.C1 : c_first) / fg, nf = cg / fg;  // nf = 1, 2, 4
+        const int lnf = nf == 1 ? 0 : nf == 2 ? 1 : 2, npart = tiles << lnf;                        // <= 32 (host-checked)
+        const float* q0 = p + ((int64_t)n * tiles * G.groups + f0) * 2;  // partial (t, f) at q0 + (t * groups + f) * 2
+        const float gam = G.gamma[c], bet = G.beta[c], dmk = a.dmask ? a.dmask[n * Cin + c] : 1.f;
+        // every partial requested before the first is used: ONE round trip (a loop of load-then-add is npart dependent ones)
+        float2 v[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            v[k] = make_float2(0.f, 0.f);
+            if (k < npart) v[k] = *reinterpret_cast<const float2*>(q0 + ((k >> lnf) * G.groups + (k & (nf - 1))) * 2);
+        }
+        float sm = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            sm += v[k].x;
+            s2 += v[k].y;
+        }
+        const float inv = 1.f / (float)npart, mean = sm * inv;
+        float dd = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const float d = k < npart ? v[k].x - mean : 0.f;
+            dd = fmaf(d, d, dd);
+        }
+        const float var = (s2 + (float)cnt * dd) * inv / (float)cnt;
+        const float rstd = 1.0f / sqrtf(var + G.eps);
+        const float sc = rstd * gam, sh = bet - mean * sc;
+        par[c] = sc;
+        par[Cin + c] = sh;
+        par[2 * Cin + c] = dmk;
+        if (writer) {
+            const_cast<float*>(a.scale)[(int64_t)n * Cin + c] = sc;
+            const_cast<float*>(a.shift)[(int64_t)n * Cin + c] = sh;
+            if (G.mean_rstd && c == c_first) {
+                G.mean_rstd[((int64_t)n * G.groups + g) * 2] = mean;
+                G.mean_rstd[((int64_t)n * G.groups + g) * 2 + 1] = rstd;
+            }
+        }
+    }
+}
+
 template <int PIPE_UA>
 __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTile g, int shTW, int shTH, int ntiles) {
     using T = bf16;
@@ -404,19 +459,26 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
     // scale / shift / mask of tile kt's image -> parameter buffer kt & 1 (all 512 threads).  Tiles 0 and 1 here; tile kt + 2
     // at the end of tile kt's epilogue (the producers' last use of that buffer - tile kt's last chunk - is behind them,
     // their first use for tile kt + 2 is nine stages before tile kt + 1 ends)
-#define WS_FILL_PAR(KT)                                                   \
+#define WS_FILL_PAR_N(KT, NTHR)                                           \
     {                                                                     \
         float* par = WS_PAR(KT);                                          \
-        const int pn0 = WS_TILE(KT).n0;                                   \
-        for (int c = tid; c < Cin; c += 512) {                            \
-            const int so = pn0 * Cin + c;                                 \
-            par[c] = a.scale ? a.scale[so] : 1.f;                         \
-            par[Cin + c] = a.scale ? a.shift[so] : 0.f;                   \
-            par[2 * Cin + c] = a.dmask ? a.dmask[so] : 1.f;               \
+        const TileXY ft_ = WS_TILE(KT);                                   \
+        if (a.has_gni) {                                                  \
+            ws_fill_par_gni(a, ft_.n0, ft_.ts == 0 && ft_.co0 == 0, par, Cin, tid, NTHR); \
+        } else {                                                          \
+            const int pn0 = ft_.n0;                                       \
+            for (int c = tid; c < Cin; c += (NTHR)) {                     \
+                const int so = pn0 * Cin + c;                             \
+                par[c] = a.scale ? a.scale[so] : 1.f;                     \
+                par[Cin + c] = a.scale ? a.shift[so] : 0.f;               \
+                par[2 * Cin + c] = a.dmask ? a.dmask[so] : 1.f;           \
+            }                                                             \
         }                                                                 \
     }
+#define WS_FILL_PAR(KT) WS_FILL_PAR_N(KT, 512)
+    // tile 1's rows: by the consumer waves, below, while the producers bring in the first stage (the producers first read them nine
+    // stages before tile 0 ends, behind dozens of workgroup barriers) - a second round trip off the preamble's critical path
     WS_FILL_PAR(0)
-    if (K > 1) WS_FILL_PAR(1)
     __syncthreads();
     const int mTW = (1 << shTW) - 1, mTH = (1 << shTH) - 1;
     float gn_carry[2] = {0.f, 0.f};  // whole-image tiles finishing their norms: the group threads' first-pass (mean, M2)
@@ -594,6 +656,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
     }
 
     // ---- consumers: wave tile 128 pixels x 64 couts ----
+    if (K > 1) WS_FILL_PAR_N(1, 256)
     __builtin_amdgcn_s_setprio(3);  // the MFMA stream wins issue arbitration against the producer wave of its SIMD (~1 %; giving the
                                     // priority to the producers instead changes nothing: their GN-mode stage is not an issue-slot problem)
     const int wrow = wave >> 1, wn0 = (wave & 1) * 64;
@@ -668,6 +731,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
 #undef WS2_EPILOGUE
 #undef WS2_PASS
 #undef WS_FILL_PAR
+#undef WS_FILL_PAR_N
 #undef WS_ESTAMP
 #undef WS_BUFA
 #undef WS_RING
@@ -873,6 +937,13 @@ int launch_conv_pipe(int dtype, const ConvArgs& a, hipStream_t s) {
     DMME_REQUIRE(conv_pipe_supported(dtype, a), DMME_ERR_UNSUPPORTED, "conv_pipe: unsupported shape");
     if (dtype == DMME_BF16) return launch_pipe_t<bf16>(a, s);
     return a.x3 ? launch_pipe_t<float, true>(a, s) : launch_pipe_t<float>(a, s);
+}
+
+bool conv_gn_in_query(int dtype, const ConvArgs& a) {
+    static const bool off = getenv("DMME_NO_GN_IN") != nullptr;
+    if (off || dtype != DMME_BF16 || getenv("DMME_NO_WS") || !conv_pipe_supported(dtype, a)) return false;
+    ConvTile gw{};
+    return ws_pick(a, gw) != 0;
 }
 
 bool conv_gn_direct_query(int dtype, const ConvArgs& a, const int* cg, int n) {

@@ -65,6 +65,7 @@ struct Op {
     int gn_force_small = 0;  // statistics from the one-workgroup-per-image kernel even where the producers left partials (it writes act)
     int gn_consumer = -1;  // the conv op that reads it (its pro_silu / Dropout2d mask define the activation)
     int gn_direct = 0;     // every source's producing conv finishes this norm in its epilogue (ConvArgs::gno): no launch here
+    int gn_in_consumer = 0;  // the consuming conv merges the producers' partials itself (ConvArgs::gni): no launch here
     // OP_CONV
     int src1 = -1, src2 = -1;  // tensor ids; -2: network input (NCHW fp32)
     int w = -1, b = -1;
@@ -761,6 +762,25 @@ void fill_conv(const dmme_plan* P, const Op& o, const char* packed, const float*
     if (o.gn >= 0) {
         a.scale = (const float*)(ws + P->ops[o.gn].gn_scale);
         a.shift = (const float*)(ws + P->ops[o.gn].gn_shift);
+        const Op& g = P->ops[o.gn];
+        if (fwd && g.gn_in_consumer) {
+            const Tensor& t1 = P->tensors[g.gn_src1];
+            const Tensor* t2 = g.gn_src2 >= 0 ? &P->tensors[g.gn_src2] : nullptr;
+            a.has_gni = 1;
+            a.gni.p1 = (const float*)(ws + t1.stats_off);
+            a.gni.t1 = t1.stats_tiles;
+            a.gni.cnt1 = t1.stats_cnt;
+            a.gni.C1 = t1.C;
+            a.gni.p2 = t2 ? (const float*)(ws + t2->stats_off) : nullptr;
+            a.gni.t2 = t2 ? t2->stats_tiles : 0;
+            a.gni.cnt2 = t2 ? t2->stats_cnt : 0;
+            a.gni.C2 = t2 ? t2->C : 0;
+            a.gni.groups = P->cfg.num_groups;
+            a.gni.gamma = (const float*)(packed + P->params[g.gn_gamma].packed_off);
+            a.gni.beta = (const float*)(packed + P->params[g.gn_beta].packed_off);
+            a.gni.eps = 1e-5f;
+            a.gni.mean_rstd = (float*)(ws + g.gn_mr);
+        }
     }
     a.pro_silu = o.pro_silu;
     a.out_silu = o.out_silu;
@@ -1098,8 +1118,35 @@ void assign_preact(dmme_plan* P) {
 }
 
 // GroupNorm statistics folded with the affine into per-(n, c) scale / shift for the consuming conv's prologue
+// Norms finished by their CONSUMER: a conv on the wave-specialised kernel whose norm's statistics are the producers' partials merges
+// them in its parameter fill (ws_fill_par_gni) - no finalize launch between the two convolutions.
+void assign_gn_in(dmme_plan* P) {
+    for (Op& cv : P->ops) {
+        if (cv.kind != OP_CONV || cv.gn < 0 || cv.use_act) continue;
+        Op& g = P->ops[cv.gn];
+        if (g.gn_direct || g.gn_in_consumer || g.gn_mod_col >= 0 || g.gn_act >= 0 || !gn_from_parts(P, g)) continue;
+        if (g.gn_src1 != cv.src1 || g.gn_src2 != cv.src2) continue;
+        const Tensor& t1 = P->tensors[g.gn_src1];
+        // partials per consumer group: tiles x (producer groups per consumer group), at most 32 (one batch of loads in the fill);
+        // 64x64 maps have hundreds - the batched finalize kernel's job
+        const int G = P->cfg.num_groups, Cn = t1.C + (g.gn_src2 >= 0 ? P->tensors[g.gn_src2].C : 0);
+        bool fits = t1.stats_tiles * ((Cn / G) / (t1.C / G)) <= 32;
+        if (g.gn_src2 >= 0) {
+            const Tensor& t2 = P->tensors[g.gn_src2];
+            fits = fits && t2.stats_tiles * ((Cn / G) / (t2.C / G)) <= 32;
+        }
+        if (!fits) continue;
+        ConvArgs a{};
+        fill_conv(P, cv, (const char*)4096, (const float*)4096, (float*)4096, (char*)4096, nullptr, 1, a);
+        a.nt = cv.tproj_col >= 0 ? P->B : 0;
+        if (!conv_gn_in_query(P->dtype, a)) continue;
+        g.gn_in_consumer = 1;
+        --P->n_launches;
+    }
+}
+
 int run_gn(const dmme_plan* P, const Op& o, const char* pk, char* ws, int nt, const float* drop_masks, hipStream_t s) {
-    if (o.gn_direct) return DMME_OK;  // its producers wrote scale / shift / {mean, rstd} (and act)
+    if (o.gn_direct || o.gn_in_consumer) return DMME_OK;  // its producers (its consumer) wrote scale / shift / {mean, rstd} (and act)
     // scale-shift conditioning (iddpm.ResBlock): (shift | scale) columns of the batched time projection
     const float* tsh = o.gn_mod_col >= 0 ? (const float*)(ws + P->ws_tproj) + o.gn_mod_col : nullptr;
     const float* tsc = tsh ? tsh + o.gn_mod_C : nullptr;
@@ -1289,6 +1336,7 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
     if (!getenv("DMME_NO_FUSED_GN")) assign_stats(P);
     if (!getenv("DMME_NO_FUSED_GN") && !getenv("DMME_NO_GN_DIRECT")) assign_direct(P);
     if (!getenv("DMME_NO_PREACT")) assign_preact(P);
+    if (!getenv("DMME_NO_FUSED_GN")) assign_gn_in(P);
     if (device >= 0) {
         // bucket boundary: parameters from the first up_layers entry on are finished first by backward
         P->op_split = (int)P->ops.size();

@@ -136,9 +136,16 @@ __global__ void __launch_bounds__(512) conv1x1_as_kernel(ConvArgs a, int HW, int
         // bias (+ the uniform time row) and the prologue rows of the tile's image (host-checked: one image per tile) into LDS
         for (int c = t; c < a.Cout; c += 256) foldL[c] = (a.bias ? a.bias[c] : 0.f) + (a.tproj ? a.tproj[c] : 0.f);
         if (has_pro && t < K) {
-            const int so = (p0 / HW) * K + t;
-            parL[t] = a.scale ? a.scale[so] : 1.f;
-            parL[K + t] = a.scale ? a.shift[so] : 0.f;
+            const int n = p0 / HW, so = n * K + t;
+            float sc = 1.f, sh = 0.f;
+            if (a.has_gni) {  // the norm in front of this conv is finished here, from its producers' partials
+                gn_in_scale_shift(a, n, t, K, p0 == n * HW, sc, sh);
+            } else if (a.scale) {
+                sc = a.scale[so];
+                sh = a.shift[so];
+            }
+            parL[t] = sc;
+            parL[K + t] = sh;
             parL[2 * K + t] = a.dmask ? a.dmask[so] : 1.f;
         }
         wait_lgkm_all();

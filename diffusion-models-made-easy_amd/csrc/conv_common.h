@@ -210,6 +210,55 @@ __device__ __forceinline__ uint4 prologue_vec<bf16>(uint4 raw, const float* sc, 
 
 
 
+// A GroupNorm finished by its CONSUMER (ConvArgs::gni): channel c's scale / shift of image n from the producers' per-tile partials.
+// All partials of a consumer group come from one source with equal counts, so the mean is the average of the means and
+// M2 = sum M2_i + cnt * sum (mean_i - mean)^2.  Every partial is requested before the first is used - ONE round trip (a
+// load-then-add loop is npart dependent ones: that version made the consumer slower than the launch it saved).  `writer` (one
+// workgroup per image) also leaves scale / shift / {mean, rstd} in memory for later readers (the backward pass).  A finalize kernel
+// this small costs its dispatch, a cold instruction fetch and two dependent round trips: ~6 us between two convolutions.
+__device__ __forceinline__ void gn_in_scale_shift(const ConvArgs& a, int n, int c, int C, bool writer, float& sc, float& sh) {
+    const GnIn& G = a.gni;
+    const int cg = C / G.groups, g = c / cg, c_first = g * cg;
+    const bool second = c_first >= G.C1;
+    const float* p = second ? G.p2 : G.p1;
+    const int tiles = second ? G.t2 : G.t1, cs = second ? G.C2 : G.C1, cnt = second ? G.cnt2 : G.cnt1;
+    const int fg = cs / G.groups, f0 = (second ? c_first - G.C1 : c_first) / fg, nf = cg / fg;  // nf = 1, 2, 4
+    const int lnf = nf == 1 ? 0 : nf == 2 ? 1 : 2, npart = tiles << lnf;                        // <= 32 (host-checked)
+    const float* q0 = p + ((int64_t)n * tiles * G.groups + f0) * 2;  // partial (t, f) at q0 + (t * groups + f) * 2
+    const float gam = G.gamma[c], bet = G.beta[c];
+    float2 v[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        v[k] = make_float2(0.f, 0.f);
+        if (k < npart) v[k] = *reinterpret_cast<const float2*>(q0 + ((k >> lnf) * G.groups + (k & (nf - 1))) * 2);
+    }
+    float sm = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        sm += v[k].x;
+        s2 += v[k].y;
+    }
+    const float inv = 1.f / (float)npart, mean = sm * inv;
+    float dd = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const float d = k < npart ? v[k].x - mean : 0.f;
+        dd = fmaf(d, d, dd);
+    }
+    const float var = (s2 + (float)cnt * dd) * inv / (float)cnt;
+    const float rstd = 1.0f / sqrtf(var + G.eps);
+    sc = rstd * gam;
+    sh = bet - mean * sc;
+    if (writer) {
+        const_cast<float*>(a.scale)[(int64_t)n * C + c] = sc;
+        const_cast<float*>(a.shift)[(int64_t)n * C + c] = sh;
+        if (G.mean_rstd && c == c_first) {
+            G.mean_rstd[((int64_t)n * G.groups + g) * 2] = mean;
+            G.mean_rstd[((int64_t)n * G.groups + g) * 2 + 1] = rstd;
+        }
+    }
+}
+
 // Shared epilogue of the implicit-GEMM kernels.  acc layout (32x32 MFMA tile): lane = cout
 // column r, registers j = pixel rows (j&3) + 8*(j>>2) + 4*h -- a lane's values are 2 bytes wide
 // and 2*Cout bytes apart in the NHWC output, so storing them directly costs 64 narrow store

@@ -378,58 +378,16 @@ __device__ __forceinline__ WsTile ws_tile_of(const ConvTile& g, int shTW, int sh
 //   filter taps (128 couts x 64 channels = 16 KB, filled by LDS-DMA one stage ahead; slot = stage % 3).
 // A tile ends on slot R2 and buffer A1 (9 stages per chunk, even chunk count) while the next tile's first tap / chunk
 // are already in R0 / A0, so R1|R2|A1 (>= 64 KB) stages the epilogue: two passes of 128 pixels.
-// Parameter rows of image n for the wave-specialised kernel when the norm in front of it is finished HERE (ConvArgs::gni): thread c
-// merges the partials of its channel's group - all of one source, equal counts, so the mean is the average of the means and
-// M2 = sum M2_i + cnt * sum (mean_i - mean)^2 (two passes over <= 64 L2-resident float2, no divisions in the loop) - and derives its
-// own scale / shift; `writer` (the workgroup with the image's first tile) also leaves scale / shift / {mean, rstd} in memory for
-// whoever reads them later (the backward pass).  One launch less per norm: a finalize kernel this small costs its dispatch, its
-// cold instruction fetch and two dependent round trips, ~6 us between two convolutions.
+// Parameter rows of image n for the wave-specialised kernel when the norm in front of it is finished HERE (ConvArgs::gni,
+// gn_in_scale_shift in conv_common.h): one thread per channel.
 __device__ __forceinline__ void ws_fill_par_gni(const ConvArgs& a, int n, bool writer, float* par, int Cin, int tid, int nthr) {
-    const GnIn& G = a.gni;
-    const int cg = Cin / G.groups;
     for (int c = tid; c < Cin; c += nthr) {
-        const int g = c / cg, c_first = g * cg;
-        const bool second = c_first >= G.C1;
-        const float* p = second ? G.p2 : G.p1;
-        const int tiles = second ? G.t2 : G.t1, cs = second ? G.C2 : G.C1, cnt = second ? G.cnt2 : G.cnt1;
-        const int fg = cs / G.groups, f0 = (second ? c_first - G.C1 : c_first) / fg, nf = cg / fg;  // nf = 1, 2, 4
-        const int lnf = nf == 1 ? 0 : nf == 2 ? 1 : 2, npart = tiles << lnf;                        // <= 32 (host-checked)
-        const float* q0 = p + ((int64_t)n * tiles * G.groups + f0) * 2;  // partial (t, f) at q0 + (t * groups + f) * 2
-        const float gam = G.gamma[c], bet = G.beta[c], dmk = a.dmask ? a.dmask[n * Cin + c] : 1.f;
-        // every partial requested before the first is used: ONE round trip (a loop of load-then-add is npart dependent ones)
-        float2 v[32];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            v[k] = make_float2(0.f, 0.f);
-            if (k < npart) v[k] = *reinterpret_cast<const float2*>(q0 + ((k >> lnf) * G.groups + (k & (nf - 1))) * 2);
-        }
-        float sm = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            sm += v[k].x;
-            s2 += v[k].y;
-        }
-        const float inv = 1.f / (float)npart, mean = sm * inv;
-        float dd = 0.f;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            const float d = k < npart ? v[k].x - mean : 0.f;
-            dd = fmaf(d, d, dd);
-        }
-        const float var = (s2 + (float)cnt * dd) * inv / (float)cnt;
-        const float rstd = 1.0f / sqrtf(var + G.eps);
-        const float sc = rstd * gam, sh = bet - mean * sc;
+        float sc, sh;
+        const float dmk = a.dmask ? a.dmask[n * Cin + c] : 1.f;
+        gn_in_scale_shift(a, n, c, Cin, writer, sc, sh);
         par[c] = sc;
         par[Cin + c] = sh;
         par[2 * Cin + c] = dmk;
-        if (writer) {
-            const_cast<float*>(a.scale)[(int64_t)n * Cin + c] = sc;
-            const_cast<float*>(a.shift)[(int64_t)n * Cin + c] = sh;
-            if (G.mean_rstd && c == c_first) {
-                G.mean_rstd[((int64_t)n * G.groups + g) * 2] = mean;
-                G.mean_rstd[((int64_t)n * G.groups + g) * 2 + 1] = rstd;
-            }
-        }
     }
 }
 
@@ -941,7 +899,9 @@ int launch_conv_pipe(int dtype, const ConvArgs& a, hipStream_t s) {
 
 bool conv_gn_in_query(int dtype, const ConvArgs& a) {
     static const bool off = getenv("DMME_NO_GN_IN") != nullptr;
-    if (off || dtype != DMME_BF16 || getenv("DMME_NO_WS") || !conv_pipe_supported(dtype, a)) return false;
+    if (off || dtype != DMME_BF16) return false;
+    if (a.taps == 1) return conv1x1_as_supported(dtype, a);  // its store team fills the rows while the tile comes in
+    if (getenv("DMME_NO_WS") || !conv_pipe_supported(dtype, a)) return false;
     ConvTile gw{};
     return ws_pick(a, gw) != 0;
 }

@@ -528,7 +528,7 @@ int launch_pack_weight(int dtype, const float* src, int Cout, int Cin, int taps,
 // packed order ([cout][tap][cin], or [cin][taps-1-tap][cout] for the data-gradient copy) with contiguous runs too.
 template <typename T>
 __global__ void __launch_bounds__(256) pack_table_kernel(const PackItem* items, const float* ref, char* packed) {
-    __shared__ float tile[8192 + 256];
+    __shared__ __attribute__((aligned(16))) float tile[8192 + 256];
     const PackItem it = items[blockIdx.x];
     const float* src = ref + it.src_off;
     if (it.as_f32 == 1) {
@@ -540,21 +540,90 @@ __global__ void __launch_bounds__(256) pack_table_kernel(const PackItem* items, 
     const int taps = it.taps, nci = it.nci, seg = nci * taps;  // contiguous source run per cout
     const int pitch = seg | 1;                                  // odd pitch: conflict-free column reads
     const int total = it.rows * seg;
-    for (int e = threadIdx.x; e < total; e += blockDim.x) {
-        const int co = e / seg, rem = e - co * seg;
-        tile[co * pitch + rem] = src[((int64_t)(it.row0 + co) * it.cin + it.ci0) * taps + rem];
+    // source runs as 16-byte loads where the geometry allows (every run starts on a 16-byte boundary and is whole vectors long):
+    // a quarter of the load instructions and of the index arithmetic of the scalar loop
+    const float* run0 = src + ((int64_t)it.row0 * it.cin + it.ci0) * taps;
+    const bool vec_in = (seg & 3) == 0 && ((it.cin * taps) & 3) == 0 && (((size_t)run0) & 15) == 0;
+    // all of a thread's loads are requested before the first is stored (a load-then-store loop is one HBM round trip per iteration:
+    // 8-32 dependent ones per workgroup, which is what this kernel's 125 us were)
+    if (vec_in) {
+        const int seg4 = seg >> 2, total4 = it.rows * seg4;  // <= 2048: at most 8 vectors per thread
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = threadIdx.x + 256 * k;
+            if (e < total4) {
+                const int co = e / seg4, q = e - co * seg4;
+                v[k] = *reinterpret_cast<const float4*>(run0 + (int64_t)co * it.cin * taps + 4 * q);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = threadIdx.x + 256 * k;
+            if (e < total4) {
+                const int co = e / seg4, q = e - co * seg4;
+                float* t = tile + co * pitch + 4 * q;
+                t[0] = v[k].x;
+                t[1] = v[k].y;
+                t[2] = v[k].z;
+                t[3] = v[k].w;
+            }
+        }
+    } else {
+        for (int base = 0; base < total; base += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = base + threadIdx.x + 256 * k;
+                if (e < total) {
+                    const int co = e / seg, rem = e - co * seg;
+                    v[k] = run0[(int64_t)co * it.cin * taps + rem];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = base + threadIdx.x + 256 * k;
+                if (e < total) {
+                    const int co = e / seg, rem = e - co * seg;
+                    tile[co * pitch + rem] = v[k];
+                }
+            }
+        }
     }
     __syncthreads();
     T* dst = (T*)(packed + it.dst_off);
+    constexpr int V = 16 / (int)sizeof(T);  // elements per 16-byte store
     if (it.as_f32 == 2) {  // dst[ci][taps-1-tap][co]: runs of `rows` couts
-        for (int e = threadIdx.x; e < total; e += blockDim.x) {
-            const int co = e % it.rows, q = e / it.rows, tap = q % taps, cil = q / taps;
-            dst[((int64_t)(it.ci0 + cil) * taps + (taps - 1 - tap)) * it.cout + it.row0 + co] = from_f<T>(tile[co * pitch + cil * taps + tap]);
+        if (it.rows % V == 0 && it.cout % V == 0 && it.row0 % V == 0) {
+            const int rv = it.rows / V, totalv = rv * seg;
+            for (int e = threadIdx.x; e < totalv; e += blockDim.x) {
+                const int cv = e % rv, q = e / rv, tap = q % taps, cil = q / taps;
+                T o[V];
+#pragma unroll
+                for (int j = 0; j < V; ++j) o[j] = from_f<T>(tile[(cv * V + j) * pitch + cil * taps + tap]);
+                *reinterpret_cast<uint4*>(dst + ((int64_t)(it.ci0 + cil) * taps + (taps - 1 - tap)) * it.cout + it.row0 + cv * V) = *reinterpret_cast<const uint4*>(o);
+            }
+        } else {
+            for (int e = threadIdx.x; e < total; e += blockDim.x) {
+                const int co = e % it.rows, q = e / it.rows, tap = q % taps, cil = q / taps;
+                dst[((int64_t)(it.ci0 + cil) * taps + (taps - 1 - tap)) * it.cout + it.row0 + co] = from_f<T>(tile[co * pitch + cil * taps + tap]);
+            }
         }
     } else {               // dst[co][tap][ci]: runs of nci cins
-        for (int e = threadIdx.x; e < total; e += blockDim.x) {
-            const int cil = e % nci, q = e / nci, tap = q % taps, co = q / taps;
-            dst[((int64_t)(it.row0 + co) * taps + tap) * it.cin + it.ci0 + cil] = from_f<T>(tile[co * pitch + cil * taps + tap]);
+        if (nci % V == 0 && it.cin % V == 0 && it.ci0 % V == 0) {
+            const int nv = nci / V, totalv = it.rows * taps * nv;
+            for (int e = threadIdx.x; e < totalv; e += blockDim.x) {
+                const int cv = e % nv, q = e / nv, tap = q % taps, co = q / taps;
+                T o[V];
+#pragma unroll
+                for (int j = 0; j < V; ++j) o[j] = from_f<T>(tile[co * pitch + (cv * V + j) * taps + tap]);
+                *reinterpret_cast<uint4*>(dst + ((int64_t)(it.row0 + co) * taps + tap) * it.cin + it.ci0 + cv * V) = *reinterpret_cast<const uint4*>(o);
+            }
+        } else {
+            for (int e = threadIdx.x; e < total; e += blockDim.x) {
+                const int cil = e % nci, q = e / nci, tap = q % taps, co = q / taps;
+                dst[((int64_t)(it.row0 + co) * taps + tap) * it.cin + it.ci0 + cil] = from_f<T>(tile[co * pitch + cil * taps + tap]);
+            }
         }
     }
 }

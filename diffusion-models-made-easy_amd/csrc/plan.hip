@@ -654,6 +654,7 @@ static void push_pack_items(const Param& p, int64_t dst_off, int as_f32, bool wi
         nco = p.cout < 64 ? p.cout : 64;
         nci = LIMIT / (nco * p.taps);
         if (nci > p.cin) nci = p.cin;
+        if (nci >= 4) nci &= ~3;  // whole 16-byte vectors per source run (pack_table_kernel's vector loads)
         if (nci < 1) nci = 1;
     } else {
         nci = p.cin;

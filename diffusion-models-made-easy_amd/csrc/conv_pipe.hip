@@ -898,8 +898,8 @@ int launch_conv_pipe(int dtype, const ConvArgs& a, hipStream_t s) {
 }
 
 bool conv_gn_in_query(int dtype, const ConvArgs& a) {
-    static const bool off = getenv("DMME_NO_GN_IN") != nullptr;
-    if (off || dtype != DMME_BF16) return false;
+    if (getenv("DMME_NO_GN_IN") || dtype != DMME_BF16) return false;  // (read per plan build, like DMME_NO_GN_DIRECT: the tests toggle it)
+    if (conv_out_thin_supported(dtype, a)) return true;       // the thin output conv keeps its image's rows in LDS anyway
     if (a.taps == 1) return conv1x1_as_supported(dtype, a);  // its store team fills the rows while the tile comes in
     if (getenv("DMME_NO_WS") || !conv_pipe_supported(dtype, a)) return false;
     ConvTile gw{};

@@ -51,8 +51,15 @@ __global__ void __launch_bounds__(256) conv_out_thin_kernel(ConvArgs a, int R) {
     const bool w_once = ksteps <= 8;
     if (w_once) load_w(0);
     for (int c = tid; c < C; c += 256) {
-        par[c] = a.scale ? a.scale[(int64_t)n * C + c] : 1.f;
-        par[C + c] = a.scale ? a.shift[(int64_t)n * C + c] : 0.f;
+        float sc = 1.f, sh = 0.f;
+        if (a.has_gni) {  // the norm in front of this conv is finished here, from its producers' partials (gn_in_scale_shift)
+            gn_in_scale_shift(a, n, c, C, y0 == 0, sc, sh);
+        } else if (a.scale) {
+            sc = a.scale[(int64_t)n * C + c];
+            sh = a.shift[(int64_t)n * C + c];
+        }
+        par[c] = sc;
+        par[C + c] = sh;
     }
     __syncthreads();
 

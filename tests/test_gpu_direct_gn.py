@@ -26,17 +26,17 @@ def _build(seed, precision, direct):
     return net
 
 
-def _run(net, x, t, direct):
+def _run(net, x, t, direct, switch="DMME_NO_GN_DIRECT"):
     if direct:
-        os.environ.pop("DMME_NO_GN_DIRECT", None)
+        os.environ.pop(switch, None)
     else:
-        os.environ["DMME_NO_GN_DIRECT"] = "1"
+        os.environ[switch] = "1"
     try:
         with torch.no_grad():
             y = net(x, t).float().cpu()
         n = net._last_plan.lib.dmme_unet_plan_num_launches(net._last_plan.h)
     finally:
-        os.environ.pop("DMME_NO_GN_DIRECT", None)
+        os.environ.pop(switch, None)
     return y, n
 
 
@@ -60,6 +60,28 @@ def test_batch128_direct_groupnorm_vs_reference_and_vs_launched_norms(golden, pr
     print(f"{precision}: launches {nb} -> {na}; max|err| vs reference {e_ref:.3e}; relative rms between the two paths {e_ab:.3e}")
     assert e_ref <= atol_ref
     assert e_ab <= rel_ab
+
+
+def test_batch128_groupnorm_finished_by_consumer_vs_reference_and_vs_finalize_launches(golden):
+    """norms whose statistics are the producers' partials, merged by the CONSUMING conv's parameter fill (gn_in_scale_shift: the
+    wave-specialised 3x3 kernel, the activation-stationary 1x1 kernel) instead of a finalize launch: B = 128 against the reference's
+    golden rows and against the same network with the launches (DMME_NO_GN_IN, read when a plan is built)"""
+    g = golden("unet_full")
+    seed = int(g["full_seed"])
+    base = synth.normal(int(g["full_xseed"]), (2, 3, 32, 32))
+    x = base.repeat(64, 1, 1, 1).cuda()
+    t = torch.from_numpy(g["full_t_one"]).cuda()
+    ya, na = _run(_build(seed, "bf16", True), x, t, True, "DMME_NO_GN_IN")
+    yb, nb = _run(_build(seed, "bf16", False), x, t, False, "DMME_NO_GN_IN")
+    assert nb - na >= 10, (na, nb)  # 14 on the default UNet: every norm in front of those two kernels at the 32x32 / 16x16 levels
+    rows = ya.reshape(64, 2, 3, 32, 32)
+    assert torch.equal(rows, rows[:1].expand_as(rows))  # every image pair took the same arithmetic
+    ref = torch.from_numpy(g["full_y_one"])
+    e_ref = float((rows[0] - ref).abs().max())
+    e_ab = float((ya - yb).pow(2).mean().sqrt() / yb.pow(2).mean().sqrt())
+    print(f"launches {nb} -> {na}; max|err| vs reference {e_ref:.3e}; relative rms between the two paths {e_ab:.3e}")
+    assert e_ref <= 1.36e-2  # the bf16 network's bound (tests/test_gpu_unet.py)
+    assert e_ab <= 1.0e-2    # (the two merges differ in rounding only: equal-count batch form vs sequential Chan updates)
 
 
 def test_batch128_training_forward_direct_groupnorm_saves_mean_rstd():

@@ -180,14 +180,40 @@ __global__ void __launch_bounds__(256) gn_finalize_parts_kernel(const float* __r
     // partials in (tile, fine group) order
     const int npart = tiles * nf;
     if constexpr (!BATCH) {
-        for (int t = 0; t < tiles; ++t)
-            for (int f = 0; f < nf; ++f) {
-                const float* q = p + (((int64_t)n * tiles + t) * groups + f0 + f) * 2;
-                const float delta = q[0] - mean, tot = na + m;
-                mean += delta * (m / tot);
-                m2 += q[1] + delta * delta * (na * m / tot);
-                na = tot;
+        if (npart <= 16) {
+            // every partial requested before the first is merged: one round trip (the loop below is npart dependent ones - most of
+            // this kernel's 6 us); merged in the same order, so the same bits
+            float2 v[16];
+            int t = 0, f = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                v[k] = make_float2(0.f, 0.f);
+                if (k < npart) {
+                    v[k] = *reinterpret_cast<const float2*>(p + (((int64_t)n * tiles + t) * groups + f0 + f) * 2);
+                    if (++f == nf) {
+                        f = 0;
+                        ++t;
+                    }
+                }
             }
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k < npart) {
+                    const float delta = v[k].x - mean, tot = na + m;
+                    mean += delta * (m / tot);
+                    m2 += v[k].y + delta * delta * (na * m / tot);
+                    na = tot;
+                }
+        } else {
+            for (int t = 0; t < tiles; ++t)
+                for (int f = 0; f < nf; ++f) {
+                    const float* q = p + (((int64_t)n * tiles + t) * groups + f0 + f) * 2;
+                    const float delta = q[0] - mean, tot = na + m;
+                    mean += delta * (m / tot);
+                    m2 += q[1] + delta * delta * (na * m / tot);
+                    na = tot;
+                }
+        }
     } else {
         for (int k = sub; k < npart; k += LANES) {
             const int t = nf == 1 ? k : k / nf, f = nf == 1 ? 0 : k - t * nf;

@@ -50,9 +50,10 @@ def test_plan_is_host_only_and_reports_errors():
     assert lib.dmme_unet_plan_workspace_bytes(h) > 0 and lib.dmme_unet_plan_packed_bytes(h) > 2 * 32_416_643
     assert lib.dmme_unet_plan_dropmask_numel(h) == 128 * 4736
     n_ops = lib.dmme_unet_plan_num_ops(h)
-    # launches = ops minus the GroupNorms their producing convs finish in the epilogue (8x8 / 4x4 / 16x16 whole-image tiles)
+    # launches = ops minus the GroupNorms finished by their producing convs' epilogues (8x8 / 4x4 / 16x16 whole-image tiles) or by
+    # their consuming conv's parameter fill (the norms in front of the persistent 3x3 / the activation-stationary 1x1 kernel)
     n_launch = lib.dmme_unet_plan_num_launches(h)
-    assert n_ops >= n_launch > 100 and n_ops - n_launch <= 40
+    assert n_ops >= n_launch > 80 and n_ops - n_launch <= 51  # (the default UNet has 51 norms)
     label = C.create_string_buffer(128)
     fl, by = C.c_double(), C.c_double()
     total = 0.0

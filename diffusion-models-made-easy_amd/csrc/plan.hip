@@ -1246,7 +1246,9 @@ void op_account(const dmme_plan* P, const Op& o, char* label, int cap, double* f
             const Tensor& t1 = P->tensors[o.gn_src1];
             const int C = t1.C + (o.gn_src2 >= 0 ? P->tensors[o.gn_src2].C : 0);
             const bool fast = gn_fast_supported(P->dtype, P->B, t1.H * t1.W, t1.C, C - t1.C, P->cfg.num_groups);
-            if (gn_from_parts(P, o)) {
+            if (o.gn_direct || o.gn_in_consumer) {  // no launch: "(...)" labels are skipped by the per-kernel tables
+                snprintf(label, cap, o.gn_direct ? "(norm finished by its producers' epilogues)" : "(norm finished by its consumer's parameter fill)");
+            } else if (gn_from_parts(P, o)) {
                 snprintf(label, cap, "gn_finalize_parts_kernel");
                 *bytes = 2.0 * B * C * 4;
             } else {

@@ -20,5 +20,5 @@ for r in range(6):
     if r:
         for i in range(n): acc[i] += ms[i] / 5
 for i, (lab, fl, by) in enumerate(info):
-    if acc[i] >= thr: print(f"{i:3d} {lab:38s} {acc[i]*1e3:8.1f} us  {fl/1e9:7.2f} GFLOP {fl/acc[i]/1e9 if acc[i] else 0:8.1f} TF  {by/1e6:7.1f} MB {by/acc[i]/1e6:8.1f} GB/s")
-print("total ms", sum(acc))
+    if acc[i] >= thr and not lab.startswith("("): print(f"{i:3d} {lab:38s} {acc[i]*1e3:8.1f} us  {fl/1e9:7.2f} GFLOP {fl/acc[i]/1e9 if acc[i] else 0:8.1f} TF  {by/1e6:7.1f} MB {by/acc[i]/1e6:8.1f} GB/s")
+print("total ms", sum(a for a, (lab, _, _) in zip(acc, info) if not lab.startswith("(")))

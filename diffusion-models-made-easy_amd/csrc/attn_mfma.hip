@@ -147,41 +147,36 @@ __global__ void __launch_bounds__(64 * NW) attn_mfma_kernel(const bf16* __restri
         for (int j = 0; j < 16; ++j) st[j] = 0.f;
         {
             constexpr int FG = 4;
-            uint4 kf[FG], qv[FG];
+            uint4 kf[2][FG], qv[2][FG];  // two fragment sets, indexed by the (compile-time) group parity: no register copies
 #pragma unroll
             for (int u = 0; u < FG; ++u) {
-                kf[u] = *reinterpret_cast<const uint4*>(ldsK + r * KP + u * 32 + h * 16);
-                if constexpr (QLDS) qv[u] = *reinterpret_cast<const uint4*>(q_lds + u * 32);
-                else qv[u] = qf[u];
+                kf[0][u] = *reinterpret_cast<const uint4*>(ldsK + r * KP + u * 32 + h * 16);
+                if constexpr (QLDS) qv[0][u] = *reinterpret_cast<const uint4*>(q_lds + u * 32);
+                else qv[0][u] = qf[u];
             }
 #pragma unroll
             for (int g0 = 0; g0 < KSTEPS; g0 += FG) {
-                uint4 kn[FG], qn[FG];
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int cur = (g0 / FG) & 1, nxt = cur ^ 1;
                 if (g0 + FG < KSTEPS) {
 #pragma unroll
                     for (int u = 0; u < FG; ++u) {
-                        kn[u] = *reinterpret_cast<const uint4*>(ldsK + r * KP + (g0 + FG + u) * 32 + h * 16);
-                        if constexpr (QLDS) qn[u] = *reinterpret_cast<const uint4*>(q_lds + (g0 + FG + u) * 32);
-                        else qn[u] = qf[(g0 + FG + u) < KSTEPS ? (g0 + FG + u) : 0];
+                        kf[nxt][u] = *reinterpret_cast<const uint4*>(ldsK + r * KP + (g0 + FG + u) * 32 + h * 16);
+                        if constexpr (QLDS) qv[nxt][u] = *reinterpret_cast<const uint4*>(q_lds + (g0 + FG + u) * 32);
+                        else qv[nxt][u] = qf[(g0 + FG + u) < KSTEPS ? (g0 + FG + u) : 0];
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < FG; ++u)
-                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[u]), __builtin_bit_cast(bf16x8, qv[u]), st, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[cur][u]), __builtin_bit_cast(bf16x8, qv[cur][u]), st, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (g0 + FG < KSTEPS) {
-#pragma unroll
-                    for (int u = 0; u < FG; ++u) {
-                        kf[u] = kn[u];
-                        qv[u] = qn[u];
-                    }
-                }
             }
         }
         // V^T fragments of the first output tiles go out now: their latency hides under the softmax arithmetic
         constexpr int VG = CT >= 2 ? 2 : 1;  // output tiles per fragment group
-        s16x4 vlo[VG][2], vhi[VG][2];
+        s16x4 vlo[2][VG][2], vhi[2][VG][2];  // two sets by group parity, as above
 #define AT_VREAD(CT0, DST_LO, DST_HI)                                                                                         \
     _Pragma("unroll") for (int cu = 0; cu < VG; ++cu) _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                       \
         const int colb = (((CT0) + cu) * 32 + 16 * tr_g1 + 4 * tr_p) * 2;                                                     \
@@ -190,19 +185,19 @@ __global__ void __launch_bounds__(64 * NW) attn_mfma_kernel(const bf16* __restri
         DST_LO[cu][s2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);               \
         DST_HI[cu][s2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);               \
     }
-        AT_VREAD(0, vlo, vhi)
+        AT_VREAD(0, vlo[0], vhi[0])
         // ---- online softmax for this lane's query (keys of this lane: 16 of the 32) ----
         float tmax = st[0];
 #pragma unroll
         for (int j = 1; j < 16; ++j) tmax = fmaxf(tmax, st[j]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m, tmax * c1);
-        const float alpha = exp2f(m - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);  // (v_exp_f32: arguments <= 0, a flushed denormal is a zero weight)
         float psum = 0.f;
         float p[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            p[j] = exp2f(fmaf(st[j], c1, -m_new));
+            p[j] = __builtin_amdgcn_exp2f(fmaf(st[j], c1, -m_new));
             psum += p[j];
         }
         l = fmaf(l, alpha, psum);
@@ -224,9 +219,9 @@ __global__ void __launch_bounds__(64 * NW) attn_mfma_kernel(const bf16* __restri
         // ---- O^T += V^T P^T ----
 #pragma unroll
         for (int ct = 0; ct < CT; ct += VG) {
-            s16x4 nlo[VG][2], nhi[VG][2];
+            const int cur = (ct / VG) & 1, nxt = cur ^ 1;
             if (ct + VG < CT) {
-                AT_VREAD(ct + VG, nlo, nhi)
+                AT_VREAD(ct + VG, vlo[nxt], vhi[nxt])
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -234,20 +229,11 @@ __global__ void __launch_bounds__(64 * NW) attn_mfma_kernel(const bf16* __restri
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     s16x8 vf;
-                    vf[0] = vlo[cu][s2][0]; vf[1] = vlo[cu][s2][1]; vf[2] = vlo[cu][s2][2]; vf[3] = vlo[cu][s2][3];
-                    vf[4] = vhi[cu][s2][0]; vf[5] = vhi[cu][s2][1]; vf[6] = vhi[cu][s2][2]; vf[7] = vhi[cu][s2][3];
+                    vf[0] = vlo[cur][cu][s2][0]; vf[1] = vlo[cur][cu][s2][1]; vf[2] = vlo[cur][cu][s2][2]; vf[3] = vlo[cur][cu][s2][3];
+                    vf[4] = vhi[cur][cu][s2][0]; vf[5] = vhi[cur][cu][s2][1]; vf[6] = vhi[cur][cu][s2][2]; vf[7] = vhi[cur][cu][s2][3];
                     o[ct + cu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf[s2], o[ct + cu], 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
-            if (ct + VG < CT) {
-#pragma unroll
-                for (int cu = 0; cu < VG; ++cu)
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        vlo[cu][s2] = nlo[cu][s2];
-                        vhi[cu][s2] = nhi[cu][s2];
-                    }
-            }
         }
 #undef AT_VREAD
     }

@@ -130,6 +130,7 @@ __global__ void __launch_bounds__(256) conv_in_kernel(ConvArgs a, int px_per_blo
 // weights are the row operand (held in registers for the wave's lifetime), 32 consecutive pixels the columns, so a
 // lane ends up with 4 consecutive couts of ITS pixel per register group: 8-byte (bf16) NHWC stores.
 typedef float f32x16_g __attribute__((ext_vector_type(16)));
+typedef float f32x4_g __attribute__((ext_vector_type(4)));
 template <typename T, int CT>  // CT: 32-cout tiles per wave (Cout = 32 * CT)
 __global__ void __launch_bounds__(256) conv_in_mfma_kernel(ConvArgs a, int nblocks) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
@@ -373,8 +374,70 @@ __global__ void __launch_bounds__(256) attn_generic_kernel(const T* __restrict__
     }
 }
 
+// S = 16 (the 4x4 maps): ONE workgroup per (image, head) instead of one per query - q, k, v of the row block (16 x d each) in LDS as
+// fp32, thread (i, j) computes score (i, j), the 16 lanes of a row reduce max / sum with DPP row operations, thread (i, c-block) the
+// output.  Same roundings as attn_generic_kernel (k * C^-0.5 and the normalised probabilities rounded to T), which ran 16 active
+// threads per workgroup through 256-long dependent dot products: 20 us for 0.03 GFLOP at B = 128.
+template <typename T>
+__global__ void __launch_bounds__(256) attn_s16_kernel(const T* __restrict__ qkv, int C, int heads, int N, T* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int S = 16;
+    const int d = C / heads, dp = d + 4;  // (+4 floats: rows of one quantity on different banks)
+    float* qs = sm;                        // [16][dp]
+    float* ks = qs + S * dp;
+    float* vs = ks + S * dp;
+    float* ps = vs + S * dp;               // [16][17]
+    const int bh = blockIdx.x, n = bh / heads, hd = bh % heads, tid = threadIdx.x;
+    const T* base = qkv + (int64_t)n * S * 3 * C + (int64_t)hd * 3 * d;
+    const float kscale = powf((float)C, -0.5f);
+    for (int e = tid; e < S * d; e += 256) {
+        const int row = e / d, c = e - row * d;
+        const T* p = base + (int64_t)row * 3 * C + c;
+        qs[row * dp + c] = to_f(p[0]);
+        ks[row * dp + c] = to_f(from_f<T>(to_f(p[d]) * kscale));
+        vs[row * dp + c] = to_f(p[2 * d]);
+    }
+    __syncthreads();
+    const int i = tid >> 4, j = tid & 15;
+    float acc = 0.f;
+    for (int c = 0; c < d; c += 4) {
+        const f32x4_g a = *reinterpret_cast<const f32x4_g*>(qs + i * dp + c), b = *reinterpret_cast<const f32x4_g*>(ks + j * dp + c);
+        acc = fmaf(a[0], b[0], acc);
+        acc = fmaf(a[1], b[1], acc);
+        acc = fmaf(a[2], b[2], acc);
+        acc = fmaf(a[3], b[3], acc);
+    }
+    float m = acc;  // the 16 lanes of a DPP row are this query's 16 keys
+    m = fmaxf(m, DMME_DPP_F(m, 0xB1));
+    m = fmaxf(m, DMME_DPP_F(m, 0x4E));
+    m = fmaxf(m, DMME_DPP_F(m, 0x141));
+    m = fmaxf(m, DMME_DPP_F(m, 0x140));
+    const float e = expf(acc - m);
+    const float tot = row16_sum(e);
+    ps[i * 17 + j] = to_f(from_f<T>(e * (1.0f / tot)));
+    __syncthreads();
+    const int on = bh % N, oh = bh / N;
+    for (int c = j; c < d; c += 16) {  // lanes of a row: consecutive channels
+        float o = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < S; ++jj) o = fmaf(ps[i * 17 + jj], vs[jj * dp + c], o);
+        out[((int64_t)on * S + i) * C + oh * d + c] = from_f<T>(o);
+    }
+}
+
 int launch_attn_heads(int dtype, const void* qkv, int N, int S, int C, int heads, void* out, hipStream_t s) {
     DMME_REQUIRE(heads >= 1 && C % heads == 0, DMME_ERR_INVALID, "attention: width %d not divisible by %d heads", C, heads);
+    if (S == 16 && (C / heads) % 4 == 0 && C / heads <= 1024 && !getenv("DMME_NO_ATTN_S16")) {
+        const size_t lds16 = (size_t)(3 * 16 * (C / heads + 4) + 16 * 17) * sizeof(float);
+        if (lds16 <= 64 * 1024) {
+            if (dtype == DMME_BF16)
+                hipLaunchKernelGGL(attn_s16_kernel<bf16>, dim3((unsigned)(N * heads)), dim3(256), lds16, s, (const bf16*)qkv, C, heads, N, (bf16*)out);
+            else
+                hipLaunchKernelGGL(attn_s16_kernel<float>, dim3((unsigned)(N * heads)), dim3(256), lds16, s, (const float*)qkv, C, heads, N, (float*)out);
+            DMME_CHECK_LAUNCH();
+            return DMME_OK;
+        }
+    }
     const size_t lds = (size_t)(C / heads + S + 16) * sizeof(float);
     DMME_REQUIRE(lds <= 64 * 1024, DMME_ERR_UNSUPPORTED, "attention generic: d+S too large (%d+%d)", C / heads, S);
     dim3 grid(S, N * heads);

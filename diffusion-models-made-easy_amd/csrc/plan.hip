@@ -1282,9 +1282,9 @@ void op_account(const dmme_plan* P, const Op& o, char* label, int cap, double* f
             if (P->x3 && attn_x3_supported(P->B, (int)S, (int)C, o.at_heads))
                 snprintf(label, cap, "attn_x3_kernel");
             else if (o.at_heads > 1)
-                snprintf(label, cap, attn_heads_mfma_supported(P->dtype, P->B, (int)S, (int)C, o.at_heads) ? "attn_mfma_kernel<%s,heads>" : "attn_generic_kernel<%s,heads>", tn);
+                snprintf(label, cap, attn_heads_mfma_supported(P->dtype, P->B, (int)S, (int)C, o.at_heads) ? "attn_mfma_kernel<%s,heads>" : S == 16 ? "attn_s16_kernel<%s,heads>" : "attn_generic_kernel<%s,heads>", tn);
             else
-                snprintf(label, cap, attn_mfma_supported(P->dtype, P->B, (int)S, (int)C) ? "attn_mfma_kernel<%s>" : "attn_generic_kernel<%s>", tn);
+                snprintf(label, cap, attn_mfma_supported(P->dtype, P->B, (int)S, (int)C) ? "attn_mfma_kernel<%s>" : S == 16 ? "attn_s16_kernel<%s>" : "attn_generic_kernel<%s>", tn);
             *flops = 4.0 * B * S * S * C;
             *bytes = B * S * 4.0 * C * es;
             break;

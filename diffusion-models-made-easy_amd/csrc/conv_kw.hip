@@ -25,6 +25,8 @@ namespace dmme {
 // up to 18 (4x4 maps: 144 halo rows for 64 pixels), which is what makes room for a ring deep enough to cover the L2 round trip.
 // BM: 64 pixels, or 128 where that still gives every CU a workgroup (8x8 maps at the benchmark batch: two images per tile) - per
 // workgroup the fixed ~5 us (arguments, first round trip, cross-wave sum, epilogue) is then paid for twice the matrix work.
+constexpr int KW_PAR_BYTES = 512;
+
 template <int NI, int RING, bool DENSE, int BM>
 __global__ void __launch_bounds__(256, 1) conv3x3_kw_kernel(ConvArgs a, ConvTile g, int shTW, int shTH, int ksplit_dbg) {
     using T = bf16;
@@ -43,9 +45,10 @@ __global__ void __launch_bounds__(256, 1) conv3x3_kw_kernel(ConvArgs a, ConvTile
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int a_bytes = DENSE ? (BM + 8) * ROW_DATA : ((g.a_rows + 7) & ~7) * ROW_DATA;  // whole 1 KB DMA blocks; DENSE: row 64 = zeros
-    const int wave_bytes = a_bytes + RING * U_BYTES;
+    const int wave_bytes = a_bytes + RING * U_BYTES + KW_PAR_BYTES;
     char* ldsA = lds + wave * wave_bytes;
     char* ldsR = ldsA + a_bytes;
+    float* parW = reinterpret_cast<float*>(ldsR + RING * U_BYTES);  // [2][64]: scale / shift of the wave's current chunk (ConvArgs::gni only)
 
     const int tile_n = blockIdx.x % g.tiles_n, tile_m = blockIdx.x / g.tiles_n;
     const int tx_blk = tile_m % g.tiles_x, ty_blk = (tile_m / g.tiles_x) % g.tiles_y;
@@ -107,6 +110,41 @@ __global__ void __launch_bounds__(256, 1) conv3x3_kw_kernel(ConvArgs a, ConvTile
     const unsigned a_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lds_c*)ldsA);
     unsigned okmask = 0;  // bit i: this lane's vector of iteration i is inside an image of the batch
     const int HWo = a.Hout * a.Wout;
+    // The norm in front of this conv finished HERE (ConvArgs::gni; one image per tile, host-checked): lane l derives scale / shift of
+    // channel c0 + l of the wave's chunk from the producers' partials (gn_in_scale_shift: one batch of loads, in flight together with
+    // the chunk's halo DMA) and leaves them in the wave's own LDS rows for the in-place transform.  At small batches every norm of the
+    // 32x32 / 16x16 levels was a finalize launch between two latency-bound convs.
+    const bool gni_writer = tile_n == 0 && tx_blk == 0 && ty_blk == 0;
+    auto gni_rows = [&](int c0) __attribute__((always_inline)) {
+        if (!a.has_gni) return;
+        float sc, sh;
+        gn_in_scale_shift(a, n0, c0 + lane, Cin, gni_writer, sc, sh);
+        parW[lane] = sc;
+        parW[64 + lane] = sh;
+    };
+    auto gni_vec = [&](uint4 raw, int piece_src, const float* dm) __attribute__((always_inline)) -> uint4 {
+        typedef __attribute__((address_space(3))) f32x4 lf4;
+        const lds_c* P3 = (const lds_c*)parW;
+        bf16x8 x = __builtin_bit_cast(bf16x8, raw);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e += 4) {
+            const f32x4 s4 = *(const lf4*)(P3 + (piece_src * 8 + e) * 4), h4 = *(const lf4*)(P3 + (64 + piece_src * 8 + e) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[e + j] = fmaf((float)x[e + j], s4[j], h4[j]);
+        }
+        if (a.pro_silu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = silu_fast(v[e]);
+        }
+        if (dm) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= dm[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = (bf16)v[e];
+        return __builtin_bit_cast(uint4, x);
+    };
     auto halo_issue = [&](int c0) __attribute__((always_inline)) {
         const bool second = c0 >= a.C1;
         const T* sbase = second ? (const T*)a.src2 : (const T*)a.src1;
@@ -122,6 +160,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_kw_kernel(ConvArgs a, ConvTile
                 okmask |= ok ? 1u << i : 0u;
                 glds16_hidden(sbase + (int64_t)(ok ? gp : 0) * Cs + cb + ((lane & 7) ^ ((row >> 1) & 7)) * EPV, a_base + (unsigned)(i * 8 * ROW_DATA));
             }
+            gni_rows(c0);
             return;
         }
 #pragma unroll 1
@@ -136,6 +175,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_kw_kernel(ConvArgs a, ConvTile
             okmask |= ok ? 1u << i : 0u;
             glds16_hidden(sbase + (int64_t)pix * Cs + cb + ((lane & 7) ^ ((row >> 1) & 7)) * EPV, a_base + (unsigned)(i * 8 * ROW_DATA));
         }
+        gni_rows(c0);
     };
     const bool has_pro = a.scale || a.dmask || a.pro_silu;
     auto halo_finish = [&](int c0) __attribute__((always_inline)) {
@@ -149,8 +189,11 @@ __global__ void __launch_bounds__(256, 1) conv3x3_kw_kernel(ConvArgs a, ConvTile
                 if ((okmask >> i) & 1u) {
                     const int n = n0 + ((row >> shTW) >> shTH);
                     const int so = n * Cin + c0 + ((lane & 7) ^ ((row >> 1) & 7)) * EPV;
-                    *p = prologue_vec<T>(*p, a.scale ? a.scale + so : nullptr, a.scale ? a.shift + so : nullptr, a.dmask ? a.dmask + so : nullptr,
-                                         a.pro_silu);
+                    if (a.has_gni)
+                        *p = gni_vec(*p, (lane & 7) ^ ((row >> 1) & 7), a.dmask ? a.dmask + so : nullptr);
+                    else
+                        *p = prologue_vec<T>(*p, a.scale ? a.scale + so : nullptr, a.scale ? a.shift + so : nullptr, a.dmask ? a.dmask + so : nullptr,
+                                             a.pro_silu);
                 }
             }
             return;
@@ -164,8 +207,11 @@ __global__ void __launch_bounds__(256, 1) conv3x3_kw_kernel(ConvArgs a, ConvTile
             } else if (has_pro) {
                 const int n = n0 + (int)__umulhi((unsigned)row, g.magic_px);
                 const int so = n * Cin + c0 + ((lane & 7) ^ ((row >> 1) & 7)) * EPV;  // the source piece this LDS piece holds
-                *p = prologue_vec<T>(*p, a.scale ? a.scale + so : nullptr, a.scale ? a.shift + so : nullptr, a.dmask ? a.dmask + so : nullptr,
-                                     a.pro_silu);
+                if (a.has_gni)
+                    *p = gni_vec(*p, (lane & 7) ^ ((row >> 1) & 7), a.dmask ? a.dmask + so : nullptr);
+                else
+                    *p = prologue_vec<T>(*p, a.scale ? a.scale + so : nullptr, a.scale ? a.shift + so : nullptr, a.dmask ? a.dmask + so : nullptr,
+                                         a.pro_silu);
             }
         }
     };
@@ -393,7 +439,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_kw_kernel(ConvArgs a, ConvTile
 static bool kw_dense(const ConvArgs& a, const ConvTile& g, int BM) { return !a.up && g.TH == a.Hout && g.TW == a.Wout && g.TN * g.TH * g.TW == BM; }
 static size_t kw_lds(const ConvArgs& a, const ConvTile& g, int BM, int NI, int ring) {
     const size_t halo = kw_dense(a, g, BM) ? (size_t)(BM + 8) * ROW_DATA : (size_t)((g.a_rows + 7) & ~7) * ROW_DATA;
-    const size_t per_wave = halo + (size_t)ring * 32 * NI * ROW_DATA;
+    const size_t per_wave = halo + (size_t)ring * 32 * NI * ROW_DATA + KW_PAR_BYTES;
     const size_t red = (size_t)4 * BM * 32 * NI * 4;
     return 4 * per_wave > red ? 4 * per_wave : red;
 }

@@ -901,9 +901,15 @@ bool conv_gn_in_query(int dtype, const ConvArgs& a) {
     if (getenv("DMME_NO_GN_IN") || dtype != DMME_BF16) return false;  // (read per plan build, like DMME_NO_GN_DIRECT: the tests toggle it)
     if (conv_out_thin_supported(dtype, a)) return true;       // the thin output conv keeps its image's rows in LDS anyway
     if (a.taps == 1) return conv1x1_as_supported(dtype, a);  // its store team fills the rows while the tile comes in
-    if (getenv("DMME_NO_WS") || !conv_pipe_supported(dtype, a)) return false;
+    if (!conv_pipe_supported(dtype, a)) return false;
     ConvTile gw{};
-    return ws_pick(a, gw) != 0;
+    if (!getenv("DMME_NO_WS") && ws_pick(a, gw)) return true;
+    // the K-split kernel (small batches): one image per tile, the wave's own chunk rows in its LDS
+    ConvTile g{}, gk{};
+    const int pick = pipe_pick(a, g);
+    int kni = 0, kring = 0, kbm = 0;
+    if (getenv("DMME_NO_GN_IN_KW") || pick < 0 || !kw_takes(dtype, a, pick, gk, &kni, &kring, &kbm)) return false;
+    return gk.TN == 1 && kw_ksplit(a, gk) == 1;
 }
 
 bool conv_gn_direct_query(int dtype, const ConvArgs& a, const int* cg, int n) {

@@ -153,6 +153,11 @@ struct GnIn {
     const float* beta;
     float eps;
     float* mean_rstd;  // [N][groups][2], written (with scale / shift) by the workgroup holding the image's first tile
+    // scale-shift conditioning folded in (iddpm.ResBlock; null: none): scale' = scale (1 + t_scale), shift' = shift (1 + t_scale) + t_shift,
+    // rows [nt][t_ld] of the batched time projection (nt == 1: one row for the batch)
+    const float* t_shift;
+    const float* t_scale;
+    int t_ld, nt;
 };
 
 struct ConvArgs {

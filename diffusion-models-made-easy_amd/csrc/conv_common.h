@@ -249,6 +249,12 @@ __device__ __forceinline__ void gn_in_scale_shift(const ConvArgs& a, int n, int 
     const float rstd = 1.0f / sqrtf(var + G.eps);
     sc = rstd * gam;
     sh = bet - mean * sc;
+    if (G.t_scale) {  // same arithmetic as gn_finalize_parts_kernel<.., MOD>
+        const int64_t r = (int64_t)(G.nt == 1 ? 0 : n) * G.t_ld + c;
+        const float mm = 1.0f + G.t_scale[r];
+        sc = sc * mm;
+        sh = fmaf(sh, mm, G.t_shift[r]);
+    }
     if (writer) {
         const_cast<float*>(a.scale)[(int64_t)n * C + c] = sc;
         const_cast<float*>(a.shift)[(int64_t)n * C + c] = sh;

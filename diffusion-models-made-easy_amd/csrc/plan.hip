@@ -781,6 +781,12 @@ void fill_conv(const dmme_plan* P, const Op& o, const char* packed, const float*
             a.gni.beta = (const float*)(packed + P->params[g.gn_beta].packed_off);
             a.gni.eps = 1e-5f;
             a.gni.mean_rstd = (float*)(ws + g.gn_mr);
+            if (g.gn_mod_col >= 0) {  // scale-shift conditioning: (shift | scale) columns of the batched time projection
+                a.gni.t_shift = (const float*)(ws + P->ws_tproj) + g.gn_mod_col;
+                a.gni.t_scale = a.gni.t_shift + g.gn_mod_C;
+                a.gni.t_ld = P->tproj_cols;
+                a.gni.nt = nt;
+            }
         }
     }
     a.pro_silu = o.pro_silu;
@@ -1125,7 +1131,7 @@ void assign_gn_in(dmme_plan* P) {
     for (Op& cv : P->ops) {
         if (cv.kind != OP_CONV || cv.gn < 0 || cv.use_act) continue;
         Op& g = P->ops[cv.gn];
-        if (g.gn_direct || g.gn_in_consumer || g.gn_mod_col >= 0 || g.gn_act >= 0 || !gn_from_parts(P, g)) continue;
+        if (g.gn_direct || g.gn_in_consumer || g.gn_act >= 0 || !gn_from_parts(P, g)) continue;
         if (g.gn_src1 != cv.src1 || g.gn_src2 != cv.src2) continue;
         const Tensor& t1 = P->tensors[g.gn_src1];
         // partials per consumer group: tiles x (producer groups per consumer group), at most 32 (one batch of loads in the fill);

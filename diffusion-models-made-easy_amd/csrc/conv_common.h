@@ -265,6 +265,38 @@ __device__ __forceinline__ void gn_in_scale_shift(const ConvArgs& a, int n, int 
     }
 }
 
+// prologue_vec<bf16> with the scale / shift rows in LDS (a norm finished by this conv: ConvArgs::gni): typed LDS reads - through
+// generic pointers they would be flat loads, which count on vmcnt and would drain the kernels' LDS-DMA queues
+__device__ __forceinline__ uint4 prologue_vec_ldsrows(uint4 raw, const float* sc_lds, const float* sh_lds, const float* dm, int pro_silu) {
+    typedef __attribute__((address_space(3))) f32x4 lf4;
+    typedef __attribute__((address_space(3))) char lc;
+    const lc* s3 = (const lc*)sc_lds;
+    const lc* h3 = (const lc*)sh_lds;
+    bf16x8 x = __builtin_bit_cast(bf16x8, raw);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e += 4) {
+        const f32x4 s4 = *(const lf4*)(s3 + e * 4), h4 = *(const lf4*)(h3 + e * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[e + j] = fmaf((float)x[e + j], s4[j], h4[j]);
+    }
+    if (pro_silu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = silu_fast(v[e]);
+    }
+    if (dm) {
+        const f32x4 m0 = *reinterpret_cast<const f32x4*>(dm), m1 = *reinterpret_cast<const f32x4*>(dm + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] *= m0[j];
+            v[4 + j] *= m1[j];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (bf16)v[e];
+    return __builtin_bit_cast(uint4, x);
+}
+
 // Shared epilogue of the implicit-GEMM kernels.  acc layout (32x32 MFMA tile): lane = cout
 // column r, registers j = pixel rows (j&3) + 8*(j>>2) + 4*h -- a lane's values are 2 bytes wide
 // and 2*Cout bytes apart in the NHWC output, so storing them directly costs 64 narrow store

@@ -43,6 +43,7 @@ __global__ void __launch_bounds__(256, GT == 9 ? 1 : 2) conv3x3_pipe_kernel(Conv
     constexpr int B_BYTES = GT * BN * ROW_DATA;
     const bool dmab = DMAB_OK && a.dma_b;
     int cur = 0;  // filter buffer the matrix work reads (DMA path)
+    float* gni_par = reinterpret_cast<float*>(ldsB + (size_t)B_BYTES * (dmab ? 2 : 1));  // [2][Cin] scale / shift rows (ConvArgs::gni only)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
@@ -172,8 +173,16 @@ __global__ void __launch_bounds__(256, GT == 9 ? 1 : 2) conv3x3_pipe_kernel(Conv
             uint4 val = make_uint4(0u, 0u, 0u, 0u);
             if (a_pix[i] >= 0) {
                 const int so = a_ss[i] + cc;
-                val = prologue_vec<T>(areg[i], a.scale ? a.scale + so : nullptr, a.scale ? a.shift + so : nullptr,
-                                      a.dmask ? a.dmask + so : nullptr, a.pro_silu);
+                if constexpr (sizeof(T) == 2) {
+                    if (a.has_gni)
+                        val = prologue_vec_ldsrows(areg[i], gni_par + cc, gni_par + Cin + cc, a.dmask ? a.dmask + so : nullptr, a.pro_silu);
+                    else
+                        val = prologue_vec<T>(areg[i], a.scale ? a.scale + so : nullptr, a.scale ? a.shift + so : nullptr,
+                                              a.dmask ? a.dmask + so : nullptr, a.pro_silu);
+                } else {
+                    val = prologue_vec<T>(areg[i], a.scale ? a.scale + so : nullptr, a.scale ? a.shift + so : nullptr,
+                                          a.dmask ? a.dmask + so : nullptr, a.pro_silu);
+                }
             }
             *reinterpret_cast<uint4*>(ldsA + swz_off(urow + 32 * i, cu)) = val;
         }
@@ -188,6 +197,17 @@ __global__ void __launch_bounds__(256, GT == 9 ? 1 : 2) conv3x3_pipe_kernel(Conv
 
     // ---- prologue: first halo chunk (the first filter group is already in flight) ----
     load_A(ch_begin * KC);
+    // the norm in front of this conv finished HERE (ConvArgs::gni; host-checked: one image per tile, no split-K): every thread derives
+    // the scale / shift of a channel of the tile's image from the producers' partials into LDS rows behind the operand buffers
+    if (a.has_gni) {
+        for (int c = tid; c < Cin; c += 256) {
+            float sc, sh;
+            gn_in_scale_shift(a, n0, c, Cin, tile_n == 0 && tx_blk == 0 && ty_blk == 0, sc, sh);
+            gni_par[c] = sc;
+            gni_par[Cin + c] = sh;
+        }
+        __syncthreads();
+    }
     PIPE_STAMP(1);
     store_A(ch_begin * KC);
     if (!dmab) store_B();
@@ -321,6 +341,7 @@ __global__ void __launch_bounds__(256) conv_splitk_finish_kernel(ConvArgs a, int
     }
 }
 static int pipe_ksplit(const ConvArgs& a, const ConvTile& g, int pick, int KC) {
+    if (a.has_gni) return 1;  // (the rows are per workgroup: every K slice would derive them again)
     static const bool off = getenv("DMME_NO_SPLITK") != nullptr;
     if (off || !a.splitk || pick != 3 || a.stride != 1 || a.gn_part || a.n_gno || a.out_silu || a.out_nchw || a.res2 || a.Cout % 4) return 1;
     const int64_t wgs = (int64_t)g.tiles_m * g.tiles_n;
@@ -861,6 +882,7 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
     ConvArgs ad = a;
     ad.dma_b = (sizeof(T) == 2 && !ACC3 && pipe_dma_ok(DMME_BF16, g, kPipeCand[pick][1], kPipeCand[pick][2])) ? 1 : 0;
     if (ad.dma_b) lds += (size_t)kPipeCand[pick][2] * kPipeCand[pick][1] * ROW_DATA;
+    if (a.has_gni) lds += (size_t)2 * (a.C1 + a.C2) * 4;  // scale / shift rows behind the operand buffers
     if (a.n_gno && lds < (size_t)kDirectLds) lds = kDirectLds;
     const int shTW = ilog2(g.TW), shTH = ilog2(g.TH);
     static bool attr_done[5] = {false, false, false, false, false};
@@ -908,8 +930,18 @@ bool conv_gn_in_query(int dtype, const ConvArgs& a) {
     ConvTile g{}, gk{};
     const int pick = pipe_pick(a, g);
     int kni = 0, kring = 0, kbm = 0;
-    if (getenv("DMME_NO_GN_IN_KW") || pick < 0 || !kw_takes(dtype, a, pick, gk, &kni, &kring, &kbm)) return false;
-    return gk.TN == 1 && kw_ksplit(a, gk) == 1;
+    if (pick < 0) return false;
+    if (!getenv("DMME_NO_GN_IN_KW") && kw_takes(dtype, a, pick, gk, &kni, &kring, &kbm)) return gk.TN == 1 && kw_ksplit(a, gk) == 1;
+    if (kw_takes(dtype, a, pick, gk, &kni, &kring, &kbm)) return false;
+    // the four-wave kernel: rows in LDS behind its operand buffers (two workgroups per CU: the 80 KB budget must still hold)
+    if (getenv("DMME_NO_GN_IN_PIPE") || g.TN != 1) return false;
+    ConvArgs b = a;
+    b.has_gni = 1;
+    b.splitk = nullptr;
+    size_t lds = pipe_lds(g, kPipeCand[pick][1], kPipeCand[pick][2]);
+    if (pipe_dma_ok(dtype, g, kPipeCand[pick][1], kPipeCand[pick][2])) lds += (size_t)kPipeCand[pick][2] * kPipeCand[pick][1] * ROW_DATA;
+    lds += (size_t)2 * (a.C1 + a.C2) * 4;
+    return lds <= (size_t)(kPipeCand[pick][2] == 9 ? 128 : 80) * 1024;
 }
 
 bool conv_gn_direct_query(int dtype, const ConvArgs& a, const int* cg, int n) {

@@ -238,6 +238,7 @@ bool conv1x1_pipe_supported(int dtype, const ConvArgs& a);
 int launch_conv1x1_pipe(int dtype, const ConvArgs& a, hipStream_t s);
 void conv1x1_pipe_label(int dtype, const ConvArgs& a, char* buf, int cap);
 bool conv1x1_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px);
+bool conv1x1_pipe_gn_in_ok(int dtype, const ConvArgs& a);
 // activation-stationary 1x1 variant for K <= 256 (conv1x1_as.hip); launch_conv1x1_pipe dispatches to it
 bool conv1x1_as_supported(int dtype, const ConvArgs& a);
 bool conv1x1_as_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px);

@@ -23,6 +23,8 @@ __global__ void __launch_bounds__(256, 2) conv1x1_pipe_kernel(ConvArgs a, int HW
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* ldsA = lds;                          // [2 chunks][BM rows][128 B]
     char* ldsB = lds + 2 * BM * ROW_DATA;      // [2 chunks][BN rows][128 B]
+    // [2][Cin] scale / shift rows (ConvArgs::gni only), behind whichever is larger: the operand buffers or the epilogue's staging image
+    float* gni_par = reinterpret_cast<float*>(lds + (2 * (BM + BN) * ROW_DATA > BM * BN * 4 ? 2 * (BM + BN) * ROW_DATA : BM * BN * 4));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
@@ -108,8 +110,16 @@ __global__ void __launch_bounds__(256, 2) conv1x1_pipe_kernel(ConvArgs a, int HW
                 uint4 val = make_uint4(0u, 0u, 0u, 0u);
                 if (a_n[i] >= 0) {
                     const int so = a_n[i] * Cin + cc;
-                    val = prologue_vec<T>(areg[c][i], a.scale ? a.scale + so : nullptr, a.scale ? a.shift + so : nullptr,
-                                          a.dmask ? a.dmask + so : nullptr, a.pro_silu);
+                    if constexpr (sizeof(T) == 2) {
+                        if (a.has_gni)
+                            val = prologue_vec_ldsrows(areg[c][i], gni_par + cc, gni_par + Cin + cc, a.dmask ? a.dmask + so : nullptr, a.pro_silu);
+                        else
+                            val = prologue_vec<T>(areg[c][i], a.scale ? a.scale + so : nullptr, a.scale ? a.shift + so : nullptr,
+                                                  a.dmask ? a.dmask + so : nullptr, a.pro_silu);
+                    } else {
+                        val = prologue_vec<T>(areg[c][i], a.scale ? a.scale + so : nullptr, a.scale ? a.shift + so : nullptr,
+                                              a.dmask ? a.dmask + so : nullptr, a.pro_silu);
+                    }
                 }
                 *reinterpret_cast<uint4*>(ldsA + c * BM * ROW_DATA + swz1(urow + 32 * i, cu)) = val;
             }
@@ -119,6 +129,18 @@ __global__ void __launch_bounds__(256, 2) conv1x1_pipe_kernel(ConvArgs a, int HW
     };
 
     load_step(0);
+    // the norm in front of this conv finished HERE (ConvArgs::gni; host-checked: the tile lies inside one image): scale / shift rows of
+    // that image into LDS behind the operand buffers, from the producers' partials
+    if (a.has_gni) {
+        const int n = p0 / HW;
+        for (int c = tid; c < Cin; c += 256) {
+            float sc, sh;
+            gn_in_scale_shift(a, n, c, Cin, tile_n == 0 && p0 == n * HW, sc, sh);
+            gni_par[c] = sc;
+            gni_par[Cin + c] = sh;
+        }
+        __syncthreads();
+    }
     store_step(0);
     __syncthreads();
 #pragma unroll 1
@@ -174,6 +196,17 @@ bool conv1x1_pipe_supported(int dtype, const ConvArgs& a) {
     return pick1(a) >= 0;
 }
 
+// can the tiled kernel finish the norm in front of this conv itself (its tile inside one image, LDS budget)?
+bool conv1x1_pipe_gn_in_ok(int dtype, const ConvArgs& a) {
+    if (dtype != DMME_BF16 || getenv("DMME_NO_GN_IN_PIPE") || getenv("DMME_NO_GN_IN_PIPE1") || !conv1x1_pipe_supported(dtype, a)) return false;
+    const int pick = pick1(a);
+    if (pick < 0) return false;
+    const int BM = k1Cand[pick][0], BN = k1Cand[pick][1], HW = a.Hout * a.Wout;
+    size_t lds = (size_t)2 * (BM + BN) * ROW_DATA;
+    if (lds < (size_t)BM * BN * 4) lds = (size_t)BM * BN * 4;
+    return HW % BM == 0 && lds + (size_t)2 * (a.C1 + a.C2) * 4 <= 80 * 1024;
+}
+
 bool conv1x1_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px) {
     {
         ConvArgs b = a;  // the activation-stationary kernel takes this conv (with or without statistics): its tiles
@@ -203,6 +236,7 @@ static int launch1_t(const ConvArgs& a, hipStream_t s) {
     const int xcd_order = (!xcd_off && tiles_n > 1 && tiles_m % 8 == 0) ? 1 : 0;
     size_t lds = (size_t)2 * (BM + BN) * ROW_DATA;
     if (lds < (size_t)BM * BN * 4) lds = (size_t)BM * BN * 4;
+    if (a.has_gni) lds += (size_t)2 * (a.C1 + a.C2) * 4;
     static bool attr_done[3] = {false, false, false};
     int rc = DMME_OK;
 #define DMME_C1_CASE(IDX, BM_, BN_)                                                                                                   \

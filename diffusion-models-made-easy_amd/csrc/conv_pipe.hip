@@ -922,7 +922,7 @@ int launch_conv_pipe(int dtype, const ConvArgs& a, hipStream_t s) {
 bool conv_gn_in_query(int dtype, const ConvArgs& a) {
     if (getenv("DMME_NO_GN_IN") || dtype != DMME_BF16) return false;  // (read per plan build, like DMME_NO_GN_DIRECT: the tests toggle it)
     if (conv_out_thin_supported(dtype, a)) return true;       // the thin output conv keeps its image's rows in LDS anyway
-    if (a.taps == 1) return conv1x1_as_supported(dtype, a);  // its store team fills the rows while the tile comes in
+    if (a.taps == 1) return conv1x1_as_supported(dtype, a) || conv1x1_pipe_gn_in_ok(dtype, a);  // the store team / the tiled kernel's preamble
     if (!conv_pipe_supported(dtype, a)) return false;
     ConvTile gw{};
     if (!getenv("DMME_NO_WS") && ws_pick(a, gw)) return true;

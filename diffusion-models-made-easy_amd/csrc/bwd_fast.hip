@@ -479,11 +479,61 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ mean_rstd, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ dmask, int pro_silu,
                                                            const float* __restrict__ S, int chunk_px, int ppw, T* __restrict__ dx1, T* __restrict__ dx2,
-                                                           int acc1, int acc2, GnMod mod, T* __restrict__ act) {
+                                                           int acc1, int acc2, GnMod mod, T* __restrict__ act, const float* __restrict__ AB,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
     constexpr int EPV = 16 / sizeof(T);
     const int C = C1 + C2, tid = threadIdx.x, VPP = C / EPV, slot = tid % VPP, prow = tid / VPP;
-    if (prow >= ppw) return;
     const int n = blockIdx.y, c0 = slot * EPV, cg = C / groups;
+    // AB != null: the group sums come from the per-chunk channel sums HERE instead of from a finalize launch between the two passes
+    // (gn_bwd_finalize_image_kernel's arithmetic, same order: same bits).  Every workgroup of an image repeats the merge - the partial
+    // rows of one norm are a few MB, L2-resident, and the reads hide behind the other workgroups' streaming; the workgroup of the
+    // image's first chunk also adds the batch sums (dgamma, dbeta, the IDDPM conditioning rows).  26 launches fewer per training step.
+    __shared__ float ga[1024], gb[1024], gS1[256], gS2[256];
+    if (AB) {
+        const int nchunks = (int)gridDim.x, N = (int)gridDim.y;
+        const int64_t cstride = (int64_t)N * C;  // pairs per chunk row
+        const float2* q0 = reinterpret_cast<const float2*>(AB) + (int64_t)n * C;
+        for (int c = tid; c < C; c += 256) {
+            const float2* q = q0 + c;
+            float sa = 0.f, sb = 0.f;
+            int k = 0;
+            for (; k + 7 < nchunks; k += 8) {
+                float2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = q[(int64_t)(k + u) * cstride];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    sa += v[u].x;
+                    sb += v[u].y;
+                }
+            }
+            for (; k < nchunks; ++k) {
+                const float2 v = q[(int64_t)k * cstride];
+                sa += v.x;
+                sb += v.y;
+            }
+            const float gmm = gamma[c], m = mod.mul(n, c);
+            ga[c] = gmm * m * sa;
+            gb[c] = gmm * m * sb;
+            if (blockIdx.x == 0) {
+                atomicAdd(&dbeta[c], sa * m);
+                atomicAdd(&dgamma[c], sb * m);
+                mod.emit(n, c, sa, sb, gmm);
+            }
+        }
+        __syncthreads();
+        if (tid < groups) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int j = 0; j < cg; ++j) {
+                s1 += ga[tid * cg + j];
+                s2 += gb[tid * cg + j];
+            }
+            gS1[tid] = s1;
+            gS2[tid] = s2;
+        }
+        __syncthreads();
+    }
+    if (prow >= ppw) return;
     const bool second = c0 >= C1;
     const T* xs = second ? x2 : x1;
     T* dst = second ? dx2 : dx1;
@@ -501,8 +551,8 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
         mu[j] = mean_rstd[((int64_t)n * groups + g) * 2];
         rs[j] = mean_rstd[((int64_t)n * groups + g) * 2 + 1];
         gm[j] = gamma[c] * mod.mul(n, c);
-        k1[j] = S[((int64_t)n * groups + g) * 2] * inv;
-        k2[j] = S[((int64_t)n * groups + g) * 2 + 1] * inv;
+        k1[j] = (AB ? gS1[g] : S[((int64_t)n * groups + g) * 2]) * inv;
+        k2[j] = (AB ? gS2[g] : S[((int64_t)n * groups + g) * 2 + 1]) * inv;
     }
 #define APPLY_ONE(RD, RX, RO, PP)                                                         \
     {                                                                                     \
@@ -792,7 +842,10 @@ int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2
                            groups, mean_rstd, scale, shift, dmask, pro_silu, chunk_px, ppw, AB);
     DMME_CHECK_LAUNCH();
     static const bool per_image_off = getenv("DMME_NO_GN_BWD_IMAGE") != nullptr;
-    if (!per_image_off && C <= 1024 && groups <= 256) {
+    static const bool fused_off = getenv("DMME_NO_GN_BWD_FUSED_FIN") != nullptr;
+    const bool fused_fin = !per_image_off && !fused_off && C <= 1024 && groups <= 256;  // the apply kernel merges the chunk sums itself
+    if (fused_fin) {
+    } else if (!per_image_off && C <= 1024 && groups <= 256) {
         hipLaunchKernelGGL(gn_bwd_finalize_image_kernel, dim3(N), dim3(256), 0, s, AB, nchunks, N, C, groups, gamma, S, dgamma, dbeta, mod);
     } else {
         const int nb_s = (N * groups + 255) / 256;
@@ -801,10 +854,12 @@ int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2
     DMME_CHECK_LAUNCH();
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dv, (const bf16*)x1, (const bf16*)x2, HW, C1, C2, groups,
-                           gamma, mean_rstd, scale, shift, dmask, pro_silu, S, chunk_px, ppw, (bf16*)dx1, (bf16*)dx2, acc1, acc2, mod, (bf16*)act);
+                           gamma, mean_rstd, scale, shift, dmask, pro_silu, S, chunk_px, ppw, (bf16*)dx1, (bf16*)dx2, acc1, acc2, mod, (bf16*)act,
+                           fused_fin ? AB : nullptr, dgamma, dbeta);
     else
         hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)dv, (const float*)x1, (const float*)x2, HW, C1, C2,
-                           groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, S, chunk_px, ppw, (float*)dx1, (float*)dx2, acc1, acc2, mod, (float*)act);
+                           groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, S, chunk_px, ppw, (float*)dx1, (float*)dx2, acc1, acc2, mod, (float*)act,
+                           fused_fin ? AB : nullptr, dgamma, dbeta);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }

@@ -438,7 +438,7 @@ int launch_silu_bwd(float* dy, const float* z, int n, hipStream_t s);
 // small fp32 GEMMs (small_gemm.hip): mode 0 NT (forward linear), 1 NN (input gradient), 2 TN (weight gradient, accumulating)
 int launch_transpose(int dtype, const void* src, int R, int C, void* dst, hipStream_t s);  // dst[c][r] = src[r][c], elements of the compute dtype
 int launch_small_gemm(int dtype, int mode, const float* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias, int out_silu,
-                      float* C, int ldc, hipStream_t s);
+                      float* C, int ldc, hipStream_t s, float* Cpre = nullptr);
 int launch_nsum(const float* Mx, int N, int C, int64_t stride, int estride, float* out, hipStream_t s);
 // one launch for a set of Linear layers: per-64-row-tile (gemm) / per-32-column (sum) output bases, in floats
 int launch_small_gemm_tn_tiled(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc,

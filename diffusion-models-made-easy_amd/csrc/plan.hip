@@ -53,6 +53,7 @@ struct Op {
     // OP_LINEAR: in (fp32 ws offset) -> out (fp32 ws offset)
     int64_t lin_in = 0, lin_out = 0;
     int lin_K = 0, lin_N = 0, lin_w = -1, lin_b = -1, lin_silu = 0;
+    int64_t lin_pre = -1;  // workspace offset of the layer's pre-activation copy (time MLP, training batch), -1: none
     // OP_GN
     int gn_src1 = -1, gn_src2 = -1, gn_gamma = -1, gn_beta = -1;
     int64_t b_rowsum = 0, b_ab = 0;  // backward scratch (bytes in the zeroed region): column sums of dY, GroupNorm channel sums
@@ -104,6 +105,7 @@ struct dmme_plan {
     std::unordered_map<std::string, int> named;  // module name -> tensor id
     int64_t ref_numel = 0, packed_bytes = 0, ws_bytes = 0, dropmask_numel = 0;
     int64_t ws_tsin = 0, ws_th1 = 0, ws_temb = 0, ws_tproj = 0, ws_gnpart = 0;
+    int64_t ws_tz1 = -1, ws_tz2 = -1;  // pre-activations of the two time-MLP layers (written at training batch; the backward's SiLU')
     int64_t ws_splitk = 0, splitk_floats = 0;  // split-K partial sums of the small-map convolutions (forward and data gradient)
     int tproj_cols = 0;
     int64_t tproj_w_off = 0, tproj_b_off = 0;  // packed byte offsets of the concatenated projection
@@ -381,6 +383,8 @@ int build_plan(dmme_plan* P) {
     P->ws_tsin = ws_alloc((int64_t)B * c.pos_dim * 4);
     P->ws_th1 = ws_alloc((int64_t)B * c.emb_dim * 4);
     P->ws_temb = ws_alloc((int64_t)B * c.emb_dim * 4);
+    P->ws_tz1 = ws_alloc((int64_t)B * c.emb_dim * 4);
+    P->ws_tz2 = ws_alloc((int64_t)B * c.emb_dim * 4);
     P->ws_tproj = ws_alloc((int64_t)B * tcols * 4);
 
     std::vector<Op>& ops = P->ops;
@@ -391,11 +395,13 @@ int build_plan(dmme_plan* P) {
         Op a{};
         a.kind = OP_LINEAR;
         a.lin_in = P->ws_tsin; a.lin_out = P->ws_th1; a.lin_K = c.pos_dim; a.lin_N = c.emb_dim;
+        a.lin_pre = P->ws_tz1;
         a.lin_w = l1w; a.lin_b = l1b; a.lin_silu = 1;
         ops.push_back(a);
         Op b{};
         b.kind = OP_LINEAR;
         b.lin_in = P->ws_th1; b.lin_out = P->ws_temb; b.lin_K = c.emb_dim; b.lin_N = c.emb_dim;
+        b.lin_pre = P->ws_tz2;
         b.lin_w = l2w; b.lin_b = l2b; b.lin_silu = 1;
         ops.push_back(b);
         Op d{};
@@ -1204,7 +1210,7 @@ int run_op(const dmme_plan* P, const Op& o, const char* pk, const float* x, cons
             const float* b = (const float*)(o.lin_b >= 0 ? pk + P->params[o.lin_b].packed_off : pk + P->tproj_b_off);
             if (nt > 4)
                 return launch_small_gemm(P->dtype, 0, (const float*)(ws + o.lin_in), o.lin_K, w, o.lin_K, nt, o.lin_N, o.lin_K, b, o.lin_silu,
-                                         (float*)(ws + o.lin_out), o.lin_N, s);
+                                         (float*)(ws + o.lin_out), o.lin_N, s, o.lin_pre >= 0 ? (float*)(ws + o.lin_pre) : nullptr);
             return launch_linear_wave(P->dtype, (const float*)(ws + o.lin_in), nt, o.lin_K, w, b, o.lin_N, o.lin_silu,
                                       (float*)(ws + o.lin_out), s);
         }
@@ -1822,14 +1828,22 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
     if (rc == DMME_OK) rc = launch_small_gemm(dt, 0, dtproj, tc, wT, tc, nt, emb, tc, nullptr, 0, dtemb, emb, s);
     if (rc != DMME_OK) return rc;
     // temb = silu(z2), z2 = h1 W2^T + b2
-    rc = launch_small_gemm(dt, 0, h1, emb, pk + P->params[P->p_l2w].packed_off, emb, nt, emb, emb, (const float*)(pk + P->params[P->p_l2b].packed_off), 0, z, emb, s);
+    // (the forward kept both pre-activations when it ran at a training batch: no recompute GEMMs here)
+    const bool saved_pre = nt > 4 && P->ws_tz1 >= 0 && P->ws_tz2 >= 0 && !getenv("DMME_NO_TIME_PRE");
+    if (saved_pre)
+        z = (float*)(ws + P->ws_tz2);
+    else
+        rc = launch_small_gemm(dt, 0, h1, emb, pk + P->params[P->p_l2w].packed_off, emb, nt, emb, emb, (const float*)(pk + P->params[P->p_l2b].packed_off), 0, z, emb, s);
     if (rc == DMME_OK) rc = launch_silu_bwd(dtemb, z, nt * emb, s);
     if (rc == DMME_OK) rc = launch_small_gemm(dt, 2, dtemb, emb, h1, emb, emb, emb, nt, nullptr, 0, grad_flat + P->params[P->p_l2w].ref_off, emb, s);
     if (rc == DMME_OK) rc = launch_nsum(dtemb, nt, emb, emb, 1, grad_flat + P->params[P->p_l2b].ref_off, s);
     if (rc == DMME_OK) rc = launch_transpose(dt, pk + P->params[P->p_l2w].packed_off, emb, emb, wT, s);
     if (rc == DMME_OK) rc = launch_small_gemm(dt, 0, dtemb, emb, wT, emb, nt, emb, emb, nullptr, 0, dh1, emb, s);
     // h1 = silu(z1), z1 = e W1^T + b1
-    if (rc == DMME_OK) rc = launch_small_gemm(dt, 0, esin, pos, pk + P->params[P->p_l1w].packed_off, pos, nt, emb, pos, (const float*)(pk + P->params[P->p_l1b].packed_off), 0, z, emb, s);
+    if (saved_pre)
+        z = (float*)(ws + P->ws_tz1);
+    else if (rc == DMME_OK)
+        rc = launch_small_gemm(dt, 0, esin, pos, pk + P->params[P->p_l1w].packed_off, pos, nt, emb, pos, (const float*)(pk + P->params[P->p_l1b].packed_off), 0, z, emb, s);
     if (rc == DMME_OK) rc = launch_silu_bwd(dh1, z, nt * emb, s);
     if (rc == DMME_OK) rc = launch_small_gemm(dt, 2, dh1, emb, esin, pos, emb, pos, nt, nullptr, 0, grad_flat + P->params[P->p_l1w].ref_off, pos, s);
     if (rc == DMME_OK) rc = launch_nsum(dh1, nt, emb, emb, 1, grad_flat + P->params[P->p_l1b].ref_off, s);

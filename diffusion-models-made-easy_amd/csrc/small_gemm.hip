@@ -16,7 +16,7 @@ enum { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256) small_gemm_kernel(const float* __restrict__ A, int lda, const void* __restrict__ Bv, int ldb, int M, int N,
                                                          int K, const float* __restrict__ bias, int out_silu, float* __restrict__ Cm, int ldc, int ksplit,
-                                                         const int64_t* __restrict__ mtile_off) {
+                                                         const int64_t* __restrict__ mtile_off, float* __restrict__ Cpre) {
     constexpr int KS = 32, UP = KS * 64 / 256;  // elements of each operand tile per thread and stage
     __shared__ float As[2][KS][64 + 4];
     __shared__ float Bs[2][KS][64 + 4];
@@ -109,6 +109,7 @@ __global__ void __launch_bounds__(256) small_gemm_kernel(const float* __restrict
                 atomicAdd(&Cm[(int64_t)m * ldc + n], v);
             } else {
                 if (bias) v += bias[n];
+                if (Cpre) Cpre[(int64_t)m * ldc + n] = v;  // the pre-activation, kept for the backward pass (training)
                 if (out_silu) v = silu_f(v);
                 Cm[(int64_t)m * ldc + n] = v;
             }
@@ -126,7 +127,7 @@ typedef float f32x16_sg __attribute__((ext_vector_type(16)));
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256) small_gemm_mfma_kernel(const float* __restrict__ A, int lda, const void* __restrict__ Bv, int ldb, int M, int N,
                                                               int K, const float* __restrict__ bias, int out_silu, float* __restrict__ Cm, int ldc,
-                                                              int ksplit, const int64_t* __restrict__ mtile_off) {
+                                                              int ksplit, const int64_t* __restrict__ mtile_off, float* __restrict__ Cpre) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     const int n0 = (blockIdx.x * 4 + wave) * 32, m0 = blockIdx.y * 32;
     if (n0 >= N) return;
@@ -220,6 +221,7 @@ __global__ void __launch_bounds__(256) small_gemm_mfma_kernel(const float* __res
             atomicAdd(&Cm[(int64_t)mm * ldc + n], v);
         } else {
             if (bias) v += bias[n];
+            if (Cpre) Cpre[(int64_t)mm * ldc + n] = v;
             if (out_silu) v = silu_f(v);
             Cm[(int64_t)mm * ldc + n] = v;
         }
@@ -232,7 +234,7 @@ static bool sg_mfma() {
 }
 
 int launch_small_gemm(int dtype, int mode, const float* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias, int out_silu,
-                      float* C, int ldc, hipStream_t s) {
+                      float* C, int ldc, hipStream_t s, float* Cpre) {
     if (sg_mfma()) {
         // few waves and a long K with a linear epilogue: split the reduction (atomics into a zeroed C)
         int ksplit = 1;
@@ -246,7 +248,7 @@ int launch_small_gemm(int dtype, int mode, const float* A, int lda, const void* 
         }
         if (ksplit > 1) DMME_CHECK_HIP(hipMemsetAsync(C, 0, (size_t)M * ldc * sizeof(float), s));
         dim3 grid((N + 127) / 128, (M + 31) / 32, ksplit);
-#define DMME_SGM(TT, MM) hipLaunchKernelGGL((small_gemm_mfma_kernel<TT, MM>), grid, dim3(256), 0, s, A, lda, B, ldb, M, N, K, bias, out_silu, C, ldc, ksplit, (const int64_t*)nullptr)
+#define DMME_SGM(TT, MM) hipLaunchKernelGGL((small_gemm_mfma_kernel<TT, MM>), grid, dim3(256), 0, s, A, lda, B, ldb, M, N, K, bias, out_silu, C, ldc, ksplit, (const int64_t*)nullptr, Cpre)
         if (mode == GEMM_TN) {
             DMME_SGM(float, GEMM_TN);
         } else if (dtype == DMME_BF16) {
@@ -267,7 +269,7 @@ int launch_small_gemm(int dtype, int mode, const float* A, int lda, const void* 
     }
     if (ksplit > 1) DMME_CHECK_HIP(hipMemsetAsync(C, 0, (size_t)M * ldc * sizeof(float), s));
     dim3 grid((N + 63) / 64, (M + 63) / 64, ksplit);
-#define DMME_SG(TT, MM) hipLaunchKernelGGL((small_gemm_kernel<TT, MM>), grid, dim3(256), 0, s, A, lda, B, ldb, M, N, K, bias, out_silu, C, ldc, ksplit, (const int64_t*)nullptr)
+#define DMME_SG(TT, MM) hipLaunchKernelGGL((small_gemm_kernel<TT, MM>), grid, dim3(256), 0, s, A, lda, B, ldb, M, N, K, bias, out_silu, C, ldc, ksplit, (const int64_t*)nullptr, Cpre)
     if (mode == GEMM_TN) {
         DMME_SG(float, GEMM_TN);
     } else if (dtype == DMME_BF16) {
@@ -310,13 +312,13 @@ int launch_small_gemm_tn_tiled(const float* A, int lda, const float* B, int ldb,
     if (sg_mfma()) {
         dim3 gridm((N + 127) / 128, (M + 31) / 32, 1);
         hipLaunchKernelGGL((small_gemm_mfma_kernel<float, GEMM_TN>), gridm, dim3(256), 0, s, A, lda, (const void*)B, ldb, M, N, K, (const float*)nullptr, 0, C,
-                           ldc, 1, mtile_off);
+                           ldc, 1, mtile_off, (float*)nullptr);
         DMME_CHECK_LAUNCH();
         return DMME_OK;
     }
     dim3 grid((N + 63) / 64, (M + 63) / 64, 1);
     hipLaunchKernelGGL((small_gemm_kernel<float, GEMM_TN>), grid, dim3(256), 0, s, A, lda, (const void*)B, ldb, M, N, K, (const float*)nullptr, 0, C, ldc,
-                       1, mtile_off);
+                       1, mtile_off, (float*)nullptr);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }

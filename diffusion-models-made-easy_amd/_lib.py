@@ -11,7 +11,7 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdmme_hip.so")
+LIB_PATH = os.environ.get("DMME_LIB_PATH") or os.path.join(_HERE, "libdmme_hip.so")  # (override: A/B runs of two builds on one box)
 CSRC = os.path.join(_HERE, "csrc")
 
 F32, BF16, BF16X3 = 0, 1, 2  # BF16X3: fp32 buffers, three-pass bf16 MFMA convolutions (the accurate mode)

@@ -131,15 +131,17 @@ __global__ void __launch_bounds__(256, 2) conv1x1_pipe_kernel(ConvArgs a, int HW
     load_step(0);
     // the norm in front of this conv finished HERE (ConvArgs::gni; host-checked: the tile lies inside one image): scale / shift rows of
     // that image into LDS behind the operand buffers, from the producers' partials
-    if (a.has_gni) {
-        const int n = p0 / HW;
-        for (int c = tid; c < Cin; c += 256) {
-            float sc, sh;
-            gn_in_scale_shift(a, n, c, Cin, tile_n == 0 && p0 == n * HW, sc, sh);
-            gni_par[c] = sc;
-            gni_par[Cin + c] = sh;
+    if constexpr (sizeof(T) == 2) {
+        if (a.has_gni) {
+            const int n = p0 / HW;
+            for (int c = tid; c < Cin; c += 256) {
+                float sc, sh;
+                gn_in_scale_shift<8>(a, n, c, Cin, tile_n == 0 && p0 == n * HW, sc, sh);
+                gni_par[c] = sc;
+                gni_par[Cin + c] = sh;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     store_step(0);
     __syncthreads();

@@ -216,8 +216,11 @@ __device__ __forceinline__ uint4 prologue_vec<bf16>(uint4 raw, const float* sc, 
 // load-then-add loop is npart dependent ones: that version made the consumer slower than the launch it saved).  `writer` (one
 // workgroup per image) also leaves scale / shift / {mean, rstd} in memory for later readers (the backward pass).  A finalize kernel
 // this small costs its dispatch, a cold instruction fetch and two dependent round trips: ~6 us between two convolutions.
-__device__ __forceinline__ void gn_in_scale_shift(const ConvArgs& a, int n, int c, int C, bool writer, float& sc, float& sh) {
-    const GnIn& G = a.gni;
+// NB: partials requested per batch.  32 = all at once (one round trip; 64 registers of the preamble - fine where the kernel's own peak
+// is higher anyway); 8 = a rolled loop of batches, twice (sums, then the centred squares out of L1 / L2): the four-wave kernels, whose
+// main-loop register allocation the 32-wide form inflated (SGPR spills 28 -> 93 in the 128 x 64 instance).
+template <int NB = 32>
+__device__ __forceinline__ void gn_in_scale_shift_g(const GnIn& G, float* scale_w, float* shift_w, int n, int c, int C, bool writer, float& sc, float& sh) {
     const int cg = C / G.groups, g = c / cg, c_first = g * cg;
     const bool second = c_first >= G.C1;
     const float* p = second ? G.p2 : G.p1;
@@ -226,24 +229,58 @@ __device__ __forceinline__ void gn_in_scale_shift(const ConvArgs& a, int n, int 
     const int lnf = nf == 1 ? 0 : nf == 2 ? 1 : 2, npart = tiles << lnf;                        // <= 32 (host-checked)
     const float* q0 = p + ((int64_t)n * tiles * G.groups + f0) * 2;  // partial (t, f) at q0 + (t * groups + f) * 2
     const float gam = G.gamma[c], bet = G.beta[c];
-    float2 v[32];
+    float sm = 0.f, s2 = 0.f, dd = 0.f, mean = 0.f;
+    const float inv = 1.f / (float)npart;
+    if constexpr (NB >= 32) {
+        float2 v[32];
 #pragma unroll
-    for (int k = 0; k < 32; ++k) {
-        v[k] = make_float2(0.f, 0.f);
-        if (k < npart) v[k] = *reinterpret_cast<const float2*>(q0 + ((k >> lnf) * G.groups + (k & (nf - 1))) * 2);
-    }
-    float sm = 0.f, s2 = 0.f;
+        for (int k = 0; k < 32; ++k) {
+            v[k] = make_float2(0.f, 0.f);
+            if (k < npart) v[k] = *reinterpret_cast<const float2*>(q0 + ((k >> lnf) * G.groups + (k & (nf - 1))) * 2);
+        }
 #pragma unroll
-    for (int k = 0; k < 32; ++k) {
-        sm += v[k].x;
-        s2 += v[k].y;
-    }
-    const float inv = 1.f / (float)npart, mean = sm * inv;
-    float dd = 0.f;
+        for (int k = 0; k < 32; ++k) {
+            sm += v[k].x;
+            s2 += v[k].y;
+        }
+        mean = sm * inv;
 #pragma unroll
-    for (int k = 0; k < 32; ++k) {
-        const float d = k < npart ? v[k].x - mean : 0.f;
-        dd = fmaf(d, d, dd);
+        for (int k = 0; k < 32; ++k) {
+            const float d = k < npart ? v[k].x - mean : 0.f;
+            dd = fmaf(d, d, dd);
+        }
+    } else {
+#pragma unroll 1
+        for (int base = 0; base < npart; base += NB) {
+            float2 v[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int kk = base + k;
+                v[k] = make_float2(0.f, 0.f);
+                if (kk < npart) v[k] = *reinterpret_cast<const float2*>(q0 + ((kk >> lnf) * G.groups + (kk & (nf - 1))) * 2);
+            }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                sm += v[k].x;
+                s2 += v[k].y;
+            }
+        }
+        mean = sm * inv;
+#pragma unroll 1
+        for (int base = 0; base < npart; base += NB) {
+            float v[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int kk = base + k;
+                v[k] = mean;
+                if (kk < npart) v[k] = q0[((kk >> lnf) * G.groups + (kk & (nf - 1))) * 2];
+            }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const float d = v[k] - mean;
+                dd = fmaf(d, d, dd);
+            }
+        }
     }
     const float var = (s2 + (float)cnt * dd) * inv / (float)cnt;
     const float rstd = 1.0f / sqrtf(var + G.eps);
@@ -256,13 +293,18 @@ __device__ __forceinline__ void gn_in_scale_shift(const ConvArgs& a, int n, int 
         sh = fmaf(sh, mm, G.t_shift[r]);
     }
     if (writer) {
-        const_cast<float*>(a.scale)[(int64_t)n * C + c] = sc;
-        const_cast<float*>(a.shift)[(int64_t)n * C + c] = sh;
+        scale_w[(int64_t)n * C + c] = sc;
+        shift_w[(int64_t)n * C + c] = sh;
         if (G.mean_rstd && c == c_first) {
             G.mean_rstd[((int64_t)n * G.groups + g) * 2] = mean;
             G.mean_rstd[((int64_t)n * G.groups + g) * 2 + 1] = rstd;
         }
     }
+}
+
+template <int NB = 32>
+__device__ __forceinline__ void gn_in_scale_shift(const ConvArgs& a, int n, int c, int C, bool writer, float& sc, float& sh) {
+    gn_in_scale_shift_g<NB>(a.gni, const_cast<float*>(a.scale), const_cast<float*>(a.shift), n, c, C, writer, sc, sh);
 }
 
 // prologue_vec<bf16> with the scale / shift rows in LDS (a norm finished by this conv: ConvArgs::gni): typed LDS reads - through

@@ -199,14 +199,16 @@ __global__ void __launch_bounds__(256, GT == 9 ? 1 : 2) conv3x3_pipe_kernel(Conv
     load_A(ch_begin * KC);
     // the norm in front of this conv finished HERE (ConvArgs::gni; host-checked: one image per tile, no split-K): every thread derives
     // the scale / shift of a channel of the tile's image from the producers' partials into LDS rows behind the operand buffers
-    if (a.has_gni) {
-        for (int c = tid; c < Cin; c += 256) {
-            float sc, sh;
-            gn_in_scale_shift(a, n0, c, Cin, tile_n == 0 && tx_blk == 0 && ty_blk == 0, sc, sh);
-            gni_par[c] = sc;
-            gni_par[Cin + c] = sh;
+    if constexpr (sizeof(T) == 2) {
+        if (a.has_gni) {
+            for (int c = tid; c < Cin; c += 256) {
+                float sc, sh;
+                gn_in_scale_shift<8>(a, n0, c, Cin, tile_n == 0 && tx_blk == 0 && ty_blk == 0, sc, sh);
+                gni_par[c] = sc;
+                gni_par[Cin + c] = sh;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     PIPE_STAMP(1);
     store_A(ch_begin * KC);

@@ -144,15 +144,28 @@ __global__ void __launch_bounds__(256) conv_in_mfma_kernel(ConvArgs a, int nbloc
             wreg[ct][j] = k < K ? to_f(((const T*)a.w)[(int64_t)(ct * 32 + r) * K + k]) : 0.f;
         }
     const int HW = a.Hout * a.Wout;
+    // per-lane tap table, once per wave: k-step j of this lane is input element (ci, dy, dx) - the divisions by the run-time Cin and
+    // the bias loads used to be redone for every 32-pixel block (~1500 non-MFMA instructions per block, most of them this arithmetic)
+    int t_off[14], t_dy[14], t_dx[14];
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+        const int k = 2 * j + h, tap = k / Cin, ci = k - tap * Cin;
+        t_dy[j] = k < K ? tap / 3 - 1 : 1 << 20;  // (past K: never inside the image)
+        t_dx[j] = tap % 3 - 1;
+        t_off[j] = (ci * a.Hin + (tap / 3 - 1)) * a.Win + tap % 3 - 1;
+    }
+    __shared__ __attribute__((aligned(16))) float biasL[128];
+    if (threadIdx.x < 32 * CT) biasL[threadIdx.x] = a.bias ? a.bias[threadIdx.x] : 0.f;
+    __syncthreads();
     for (int blk = blockIdx.x * 4 + (threadIdx.x >> 6); blk < nblocks; blk += gridDim.x * 4) {
         const int p = blk * 32 + r;  // this lane's pixel (column); N*H*W is a multiple of 32
         const int n = p / HW, rem = p - n * HW, oy = rem / a.Wout, ox = rem - oy * a.Wout;
+        const float* xb = (const float*)a.src1 + ((int64_t)n * Cin * a.Hin + oy) * a.Win + ox;
         float xv[14];
 #pragma unroll
         for (int j = 0; j < 14; ++j) {
-            const int k = 2 * j + h, tap = k / Cin, ci = k - tap * Cin;
-            const int iy = oy - 1 + tap / 3, ix = ox - 1 + tap % 3;
-            xv[j] = (k < K && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) ? ((const float*)a.src1)[(((int64_t)n * Cin + ci) * a.Hin + iy) * a.Win + ix] : 0.f;
+            const bool in = (unsigned)(oy + t_dy[j]) < (unsigned)a.Hin && (unsigned)(ox + t_dx[j]) < (unsigned)a.Win;
+            xv[j] = in ? xb[t_off[j]] : 0.f;
         }
         constexpr int PITCH = CT * 32 + 4;  // bf16 elements per staged pixel row (+8 bytes: rows on different banks)
         __shared__ __attribute__((aligned(16))) unsigned short stage_in[4][32 * PITCH];
@@ -161,7 +174,13 @@ __global__ void __launch_bounds__(256) conv_in_mfma_kernel(ConvArgs a, int nbloc
         for (int ct = 0; ct < CT; ++ct) {
             f32x16_g acc;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc[j] = a.bias ? a.bias[ct * 32 + (j & 3) + 8 * (j >> 2) + 4 * h] : 0.f;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4_g b4 = *reinterpret_cast<const f32x4_g*>(biasL + ct * 32 + 8 * g4 + 4 * h);
+                acc[4 * g4] = b4[0];
+                acc[4 * g4 + 1] = b4[1];
+                acc[4 * g4 + 2] = b4[2];
+                acc[4 * g4 + 3] = b4[3];
+            }
 #pragma unroll
             for (int j = 0; j < 14; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[ct][j], xv[j], acc, 0, 0, 0);
             if constexpr (sizeof(T) == 2) {

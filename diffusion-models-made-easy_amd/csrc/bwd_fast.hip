@@ -480,7 +480,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ shift, const float* __restrict__ dmask, int pro_silu,
                                                            const float* __restrict__ S, int chunk_px, int ppw, T* __restrict__ dx1, T* __restrict__ dx2,
                                                            int acc1, int acc2, GnMod mod, T* __restrict__ act, const float* __restrict__ AB,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ rows) {
     constexpr int EPV = 16 / sizeof(T);
     const int C = C1 + C2, tid = threadIdx.x, VPP = C / EPV, slot = tid % VPP, prow = tid / VPP;
     const int n = blockIdx.y, c0 = slot * EPV, cg = C / groups;
@@ -516,8 +516,13 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
             ga[c] = gmm * m * sa;
             gb[c] = gmm * m * sb;
             if (blockIdx.x == 0) {
-                atomicAdd(&dbeta[c], sa * m);
-                atomicAdd(&dgamma[c], sb * m);
+                if (rows) {  // (see gn_bwd_small_kernel)
+                    rows[(int64_t)n * C + c] = sa * m;
+                    rows[((int64_t)N + n) * C + c] = sb * m;
+                } else {
+                    atomicAdd(&dbeta[c], sa * m);
+                    atomicAdd(&dgamma[c], sb * m);
+                }
                 mod.emit(n, c, sa, sb, gmm);
             }
         }
@@ -644,7 +649,8 @@ __global__ void __launch_bounds__(256) gn_bwd_small_kernel(const T* __restrict__
                                                            int C2, int groups, const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ dmask, int pro_silu, T* __restrict__ dx1, T* __restrict__ dx2,
-                                                           int acc1, int acc2, float* __restrict__ dgamma, float* __restrict__ dbeta, T* __restrict__ act) {
+                                                           int acc1, int acc2, float* __restrict__ dgamma, float* __restrict__ dbeta, T* __restrict__ act,
+                                                           float* __restrict__ rows) {
     constexpr int EPV = 16 / sizeof(T);
     __shared__ float red[256 * EPV * 2];
     __shared__ float chA[512], chB[512], gS1[64], gS2[64];
@@ -718,8 +724,13 @@ __global__ void __launch_bounds__(256) gn_bwd_small_kernel(const T* __restrict__
         }
         chA[lc] = sa;
         chB[lc] = sb;
-        atomicAdd(&dbeta[cb + lc], sa);
-        atomicAdd(&dgamma[cb + lc], sb);
+        if (rows) {  // per-image rows [2][N][C], summed over the batch by the grouped bias reduction at the end of backward: 128 images
+            rows[(int64_t)n * C + cb + lc] = sa;                              // adding into the same C addresses were 128-way atomics
+            rows[((int64_t)gridDim.x + n) * C + cb + lc] = sb;               // (2.6 us of this kernel's 15)
+        } else {
+            atomicAdd(&dbeta[cb + lc], sa);
+            atomicAdd(&dgamma[cb + lc], sb);
+        }
     }
     __syncthreads();
     if (tid < Cw / cg) {  // the slice's groups
@@ -804,11 +815,20 @@ bool gn_bwd_fast_supported(int dtype, int HW, int C1, int C2) {
     return (C1 % EPV) == 0 && vec_geometry(dtype, HW, C1 + C2, a, b, c);
 }
 
+// will launch_gn_bwd_fast leave the batch sums of dgamma / dbeta as per-image rows (instead of same-address atomics)?  Mirrors its dispatch.
+bool gn_bwd_rows_supported(int dtype, int HW, int C1, int C2, int groups, bool has_mod) {
+    if (getenv("DMME_NO_GN_BWD_ROWS")) return false;
+    if (!has_mod && gn_bwd_small_supported(dtype, HW, C1, C2, groups)) return true;
+    const int C = C1 + C2;
+    return !getenv("DMME_NO_GN_BWD_IMAGE") && !getenv("DMME_NO_GN_BWD_FUSED_FIN") && C <= 1024 && groups <= 256;
+}
+
 // AB: gn_bwd_fast_chunks * N*C*2 floats (every entry is written: no zeroing needed);  S: N*groups*2 floats of scratch
 int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2, int N, int HW, int C1, int C2, int groups,
                        const float* gamma, const float* mean_rstd, const float* scale, const float* shift, const float* dmask,
                        int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, float* AB, float* S, GnMod mod,
-                       hipStream_t s, void* act) {
+                       hipStream_t s, void* act, float* rows) {
+    if (rows && !gn_bwd_rows_supported(dtype, HW, C1, C2, groups, mod.t_scale != nullptr)) rows = nullptr;  // (the plan asked the same question)
     if (!mod.t_scale && gn_bwd_small_supported(dtype, HW, C1, C2, groups)) {
         // channel slices: whole groups, whole 16-byte vectors, not straddling the two concatenated sources, <= 256 threads per pixel row
         const int Call = C1 + C2, cgs = Call / groups, epv = dtype == DMME_BF16 ? 8 : 4;
@@ -823,10 +843,10 @@ int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2
         }
         if (dtype == DMME_BF16)
             hipLaunchKernelGGL(gn_bwd_small_kernel<bf16>, dim3(N, slices), dim3(256), 0, s, (const bf16*)dv, (const bf16*)x1, (const bf16*)x2, HW, C1, C2, groups,
-                               gamma, mean_rstd, scale, shift, dmask, pro_silu, (bf16*)dx1, (bf16*)dx2, acc1, acc2, dgamma, dbeta, (bf16*)act);
+                               gamma, mean_rstd, scale, shift, dmask, pro_silu, (bf16*)dx1, (bf16*)dx2, acc1, acc2, dgamma, dbeta, (bf16*)act, rows);
         else
             hipLaunchKernelGGL(gn_bwd_small_kernel<float>, dim3(N, slices), dim3(256), 0, s, (const float*)dv, (const float*)x1, (const float*)x2, HW, C1, C2,
-                               groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, (float*)dx1, (float*)dx2, acc1, acc2, dgamma, dbeta, (float*)act);
+                               groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, (float*)dx1, (float*)dx2, acc1, acc2, dgamma, dbeta, (float*)act, rows);
         DMME_CHECK_LAUNCH();
         return DMME_OK;
     }
@@ -855,11 +875,11 @@ int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dv, (const bf16*)x1, (const bf16*)x2, HW, C1, C2, groups,
                            gamma, mean_rstd, scale, shift, dmask, pro_silu, S, chunk_px, ppw, (bf16*)dx1, (bf16*)dx2, acc1, acc2, mod, (bf16*)act,
-                           fused_fin ? AB : nullptr, dgamma, dbeta);
+                           fused_fin ? AB : nullptr, dgamma, dbeta, fused_fin ? rows : nullptr);
     else
         hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)dv, (const float*)x1, (const float*)x2, HW, C1, C2,
                            groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, S, chunk_px, ppw, (float*)dx1, (float*)dx2, acc1, acc2, mod, (float*)act,
-                           fused_fin ? AB : nullptr, dgamma, dbeta);
+                           fused_fin ? AB : nullptr, dgamma, dbeta, fused_fin ? rows : nullptr);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }

@@ -57,6 +57,8 @@ struct Op {
     // OP_GN
     int gn_src1 = -1, gn_src2 = -1, gn_gamma = -1, gn_beta = -1;
     int64_t b_rowsum = 0, b_ab = 0;  // backward scratch (bytes in the zeroed region): column sums of dY, GroupNorm channel sums
+    int64_t b_gnrows = -1;           // [2][N][C] per-image sums for dbeta / dgamma of this conv's GroupNorm (written whole)
+    int gn_rows_deferred = 0;        // ... reduced over the batch by the grouped bias launch instead of same-address atomics
     int64_t gn_scale = 0, gn_shift = 0, gn_mr = 0;  // workspace offsets: scale/shift [N][C], {mean, rstd} [N][G][2]
     // scale-shift conditioning (iddpm.ResBlock, models/iddpm.py:117-118): columns of tproj holding (shift | scale), -1: none.
     // The GroupNorm output becomes GN(h) * (scale + 1) + shift, folded into the per-(n, c) scale / shift the consumer applies.
@@ -629,6 +631,7 @@ int build_plan(dmme_plan* P) {
                 const Tensor& t1 = P->tensors[gop.gn_src1];
                 const int C = t1.C + (gop.gn_src2 >= 0 ? P->tensors[gop.gn_src2].C : 0);
                 o.b_ab = balloc((int64_t)gn_bwd_fast_chunks(P->dtype, t1.H * t1.W, C) * B * C * 2 * 4);
+                o.b_gnrows = balloc((int64_t)2 * B * C * 4);
             }
             P->bws_gnS = balloc((int64_t)B * c.num_groups * 2 * 4);
         }
@@ -1388,6 +1391,28 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
                 if (o.kind != OP_CONV) continue;
                 ConvArgs a{};
                 fill_conv(P, o, nullptr, nullptr, nullptr, nullptr, nullptr, 1, a);
+                if (o.gn >= 0 && o.b_gnrows >= 0) {
+                    // the norm in front of this conv: its backward leaves per-image dbeta / dgamma rows, summed over the batch by the same
+                    // grouped launch as the biases.  Bucket (gradient exchange overlap): by the NORM's op index, its jobs first.
+                    const Op& gop = P->ops[o.gn];
+                    const Tensor& t1 = P->tensors[gop.gn_src1];
+                    const int C1 = t1.C, C2 = gop.gn_src2 >= 0 ? P->tensors[gop.gn_src2].C : 0, C = C1 + C2;
+                    if (gn_bwd_fast_supported(P->dtype, t1.H * t1.W, C1, C2) &&
+                        gn_bwd_rows_supported(P->dtype, t1.H * t1.W, C1, C2, P->cfg.num_groups, gop.gn_mod_col >= 0)) {
+                        o.gn_rows_deferred = 1;
+                        for (int which = 0; which < 2; ++which)
+                            for (int cb = 0; cb < (C + 31) / 32; ++cb) {
+                                BiasJob j{};
+                                j.rowsum_off = o.b_gnrows + (int64_t)which * P->B * C * 4;
+                                j.dbias_off = P->params[which == 0 ? gop.gn_beta : gop.gn_gamma].ref_off;
+                                j.C = C;
+                                j.cblock = cb;
+                                j.tcol = -1;
+                                P->bias_jobs.push_back(j);
+                            }
+                        if (o.gn < P->op_split) P->bias_split = (int)P->bias_jobs.size();
+                    }
+                }
                 if (!colsum_fast_supported(P->dtype, a.Hout * a.Wout, a.Cout)) continue;
                 o.bias_deferred = 1;
                 if ((int)(&o - P->ops.data()) < P->op_split) P->bias_split = (int)P->bias_jobs.size() + (a.Cout + 31) / 32;
@@ -1774,7 +1799,8 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
                                             (const float*)(pk + P->params[gop.gn_gamma].packed_off), (const float*)(ws + gop.gn_mr), a.scale,
                                             a.shift, a.dmask, a.pro_silu, g1, g2, acc1, acc2, grad_flat + P->params[gop.gn_gamma].ref_off,
                                             grad_flat + P->params[gop.gn_beta].ref_off, (float*)(bws + o.b_ab), (float*)(bws + P->bws_gnS), mod, s,
-                                            o.wg_act >= 0 ? bws + o.wg_act : nullptr);
+                                            o.wg_act >= 0 ? bws + o.wg_act : nullptr,
+                                            o.gn_rows_deferred && P->bias_jobs_dev ? (float*)(bws + o.b_gnrows) : nullptr);
                 else
                 rc = launch_gn_bwd_generic(dt, tmp, a.src1, a.src2, B, t1.H * t1.W, a.C1, a.C2, G,
                                            (const float*)(pk + P->params[gop.gn_gamma].packed_off), (const float*)(ws + gop.gn_mr),

@@ -480,7 +480,8 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ shift, const float* __restrict__ dmask, int pro_silu,
                                                            const float* __restrict__ S, int chunk_px, int ppw, T* __restrict__ dx1, T* __restrict__ dx2,
                                                            int acc1, int acc2, GnMod mod, T* __restrict__ act, const float* __restrict__ AB,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ rows) {
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ rows,
+                                                           const T* __restrict__ extra) {
     constexpr int EPV = 16 / sizeof(T);
     const int C = C1 + C2, tid = threadIdx.x, VPP = C / EPV, slot = tid % VPP, prow = tid / VPP;
     const int n = blockIdx.y, c0 = slot * EPV, cg = C / groups;
@@ -559,17 +560,20 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
         k1[j] = (AB ? gS1[g] : S[((int64_t)n * groups + g) * 2]) * inv;
         k2[j] = (AB ? gS2[g] : S[((int64_t)n * groups + g) * 2 + 1]) * inv;
     }
+    // `extra` (single-source norms): one more addend of the source's gradient - the identity-residual branch of the block (d x += d out),
+    // which used to be its own read-modify-write launch over the same tensor (27 per training step)
 #define APPLY_ONE(RD, RX, RO, PP)                                                         \
     {                                                                                     \
-        float d[EPV], xv[EPV], o[EPV];                                                    \
+        float d[EPV], xv[EPV], o[EPV], ev[EPV];                                           \
         unpack_vec<T>(RD, d);                                                             \
         unpack_vec<T>(RX, xv);                                                            \
         unpack_vec<T>(RO, o);                                                             \
+        unpack_vec<T>(extra ? load_raw<T>(extra + (p0 + (PP)) * Cs + cs0) : zero4, ev);   \
         _Pragma("unroll") for (int j = 0; j < EPV; ++j) {                                 \
             float du = d[j] * dm[j];                                                      \
             if (pro_silu) du *= silu_grad_f<T>(fmaf(xv[j], sc[j], sh[j]));                \
             const float xhat = (xv[j] - mu[j]) * rs[j];                                   \
-            const float dx = rs[j] * (du * gm[j] - (k1[j] + xhat * k2[j]));               \
+            const float dx = rs[j] * (du * gm[j] - (k1[j] + xhat * k2[j])) + ev[j];       \
             o[j] = acc ? o[j] + dx : dx;                                                  \
         }                                                                                 \
         store_vec<T>(dst + (p0 + (PP)) * Cs + cs0, o);                                    \
@@ -650,7 +654,7 @@ __global__ void __launch_bounds__(256) gn_bwd_small_kernel(const T* __restrict__
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ dmask, int pro_silu, T* __restrict__ dx1, T* __restrict__ dx2,
                                                            int acc1, int acc2, float* __restrict__ dgamma, float* __restrict__ dbeta, T* __restrict__ act,
-                                                           float* __restrict__ rows) {
+                                                           float* __restrict__ rows, const T* __restrict__ extra) {
     constexpr int EPV = 16 / sizeof(T);
     __shared__ float red[256 * EPV * 2];
     __shared__ float chA[512], chB[512], gS1[64], gS2[64];
@@ -755,15 +759,16 @@ __global__ void __launch_bounds__(256) gn_bwd_small_kernel(const T* __restrict__
     }
 #define SMALL_APPLY_ONE(RD, RX, RO, PP)                                                   \
     {                                                                                     \
-        float d[EPV], xv[EPV], o[EPV];                                                    \
+        float d[EPV], xv[EPV], o[EPV], ev[EPV];                                           \
         unpack_vec<T>(RD, d);                                                             \
         unpack_vec<T>(RX, xv);                                                            \
         unpack_vec<T>(RO, o);                                                             \
+        unpack_vec<T>(extra ? load_raw<T>(extra + (p0 + (PP)) * Cs + cs0) : zero4, ev);   \
         _Pragma("unroll") for (int j = 0; j < EPV; ++j) {                                 \
             float du = d[j] * dm[j];                                                      \
             if (pro_silu) du *= silu_grad_f<T>(fmaf(xv[j], sc[j], sh[j]));                \
             const float xhat = (xv[j] - mu[j]) * rs[j];                                   \
-            const float dx = rs[j] * (du * gm[j] - (k1[j] + xhat * k2[j]));               \
+            const float dx = rs[j] * (du * gm[j] - (k1[j] + xhat * k2[j])) + ev[j];       \
             o[j] = acc ? o[j] + dx : dx;                                                  \
         }                                                                                 \
         store_vec<T>(dst + (p0 + (PP)) * Cs + cs0, o);                                    \
@@ -827,7 +832,7 @@ bool gn_bwd_rows_supported(int dtype, int HW, int C1, int C2, int groups, bool h
 int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2, int N, int HW, int C1, int C2, int groups,
                        const float* gamma, const float* mean_rstd, const float* scale, const float* shift, const float* dmask,
                        int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, float* AB, float* S, GnMod mod,
-                       hipStream_t s, void* act, float* rows) {
+                       hipStream_t s, void* act, float* rows, const void* extra) {
     if (rows && !gn_bwd_rows_supported(dtype, HW, C1, C2, groups, mod.t_scale != nullptr)) rows = nullptr;  // (the plan asked the same question)
     if (!mod.t_scale && gn_bwd_small_supported(dtype, HW, C1, C2, groups)) {
         // channel slices: whole groups, whole 16-byte vectors, not straddling the two concatenated sources, <= 256 threads per pixel row
@@ -843,10 +848,10 @@ int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2
         }
         if (dtype == DMME_BF16)
             hipLaunchKernelGGL(gn_bwd_small_kernel<bf16>, dim3(N, slices), dim3(256), 0, s, (const bf16*)dv, (const bf16*)x1, (const bf16*)x2, HW, C1, C2, groups,
-                               gamma, mean_rstd, scale, shift, dmask, pro_silu, (bf16*)dx1, (bf16*)dx2, acc1, acc2, dgamma, dbeta, (bf16*)act, rows);
+                               gamma, mean_rstd, scale, shift, dmask, pro_silu, (bf16*)dx1, (bf16*)dx2, acc1, acc2, dgamma, dbeta, (bf16*)act, rows, (const bf16*)extra);
         else
             hipLaunchKernelGGL(gn_bwd_small_kernel<float>, dim3(N, slices), dim3(256), 0, s, (const float*)dv, (const float*)x1, (const float*)x2, HW, C1, C2,
-                               groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, (float*)dx1, (float*)dx2, acc1, acc2, dgamma, dbeta, (float*)act, rows);
+                               groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, (float*)dx1, (float*)dx2, acc1, acc2, dgamma, dbeta, (float*)act, rows, (const float*)extra);
         DMME_CHECK_LAUNCH();
         return DMME_OK;
     }
@@ -875,11 +880,11 @@ int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dv, (const bf16*)x1, (const bf16*)x2, HW, C1, C2, groups,
                            gamma, mean_rstd, scale, shift, dmask, pro_silu, S, chunk_px, ppw, (bf16*)dx1, (bf16*)dx2, acc1, acc2, mod, (bf16*)act,
-                           fused_fin ? AB : nullptr, dgamma, dbeta, fused_fin ? rows : nullptr);
+                           fused_fin ? AB : nullptr, dgamma, dbeta, fused_fin ? rows : nullptr, (const bf16*)extra);
     else
         hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)dv, (const float*)x1, (const float*)x2, HW, C1, C2,
                            groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, S, chunk_px, ppw, (float*)dx1, (float*)dx2, acc1, acc2, mod, (float*)act,
-                           fused_fin ? AB : nullptr, dgamma, dbeta, fused_fin ? rows : nullptr);
+                           fused_fin ? AB : nullptr, dgamma, dbeta, fused_fin ? rows : nullptr, (const float*)extra);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }

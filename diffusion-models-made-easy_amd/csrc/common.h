@@ -426,7 +426,7 @@ int gn_bwd_fast_chunks(int dtype, int HW, int C);
 int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2, int N, int HW, int C1, int C2, int groups,
                        const float* gamma, const float* mean_rstd, const float* scale, const float* shift, const float* dmask,
                        int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, float* AB_zeroed,
-                       float* S_scratch, GnMod mod, hipStream_t s, void* act = nullptr, float* rows = nullptr);
+                       float* S_scratch, GnMod mod, hipStream_t s, void* act = nullptr, float* rows = nullptr, const void* extra = nullptr);
 bool gn_bwd_rows_supported(int dtype, int HW, int C1, int C2, int groups, bool has_mod);
 bool grad_acc_fast_supported(int dtype, int C1, int C2, int pool);
 int launch_grad_acc_fast(int dtype, const void* src, void* d1, void* d2, int C1, int C2, int acc1, int acc2, int64_t npix, hipStream_t s);

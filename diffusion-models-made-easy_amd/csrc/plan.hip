@@ -1634,6 +1634,20 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
         written[id] = 1;
         return acc;
     };
+    // identity-residual branches (d x += d out of a ResBlock / attention block) are not launched on their own: the pointer waits here
+    // until the GroupNorm backward that writes x's gradient anyway (norm1 / the attention norm of the same block) takes it as one more
+    // addend; anything else that needs x's gradient first gets it through flush_pending
+    static const bool res_extra_off = getenv("DMME_NO_RES_EXTRA") != nullptr;
+    std::vector<const char*> pending(P->tensors.size(), nullptr);
+    auto flush_pending = [&](int id) -> int {
+        if (id < 0 || !pending[id]) return DMME_OK;
+        const Tensor& t = P->tensors[id];
+        const char* src = pending[id];
+        pending[id] = nullptr;
+        const int acc = claim(id);
+        return launch_grad_acc(dt, src, gptr(id), nullptr, t.C, 0, acc, 0, 0, B, t.H, t.W, s);
+    };
+
     DMME_CHECK_HIP(hipMemsetAsync(bws + P->bws_zero, 0, (size_t)P->bws_zero_bytes, s));
     float* wimage = (float*)(bws + P->bws_wimage);
     float* dtproj = (float*)(bws + P->bws_dtproj);
@@ -1696,6 +1710,8 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
         }
         const Op& o = P->ops[oi];
         if (o.kind == OP_ATTN) {
+            rc = flush_pending(o.at_out);
+            if (rc != DMME_OK) break;
             const Tensor& q = P->tensors[o.at_qkv];
             const int S = q.H * q.W, C = q.C / 3;
             DMME_REQUIRE(written[o.at_out], DMME_ERR_INVALID, "backward: attention output has no gradient");
@@ -1717,6 +1733,10 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
         if (o.kind != OP_CONV) continue;
         ConvArgs a{};
         fill_conv(P, o, pk, x, nullptr, ws, drop_masks, nt, a);
+        if (o.dst >= 0) {
+            rc = flush_pending(o.dst);
+            if (rc != DMME_OK) break;
+        }
         const char* dy = o.dst == -2 ? bws + P->bws_dy : gptr(o.dst);
         if (o.dst != -2) DMME_REQUIRE(written[o.dst], DMME_ERR_INVALID, "backward: tensor %d has no gradient", o.dst);
         const int Cin = a.C1 + a.C2;
@@ -1767,6 +1787,20 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
             const Tensor& t1 = P->tensors[o.src1];
             char* g1 = gptr(o.src1);
             char* g2 = o.src2 >= 0 ? gptr(o.src2) : nullptr;
+            const char* extra = nullptr;  // a waiting residual branch of the source: taken along by the GroupNorm backward below
+            if (pending[o.src1]) {
+                if (o.gn >= 0 && o.src2 < 0 && gn_bwd_fast_supported(dt, t1.H * t1.W, a.C1, a.C2)) {
+                    extra = pending[o.src1];
+                    pending[o.src1] = nullptr;
+                } else {
+                    rc = flush_pending(o.src1);
+                    if (rc != DMME_OK) break;
+                }
+            }
+            if (o.src2 >= 0) {
+                rc = flush_pending(o.src2);
+                if (rc != DMME_OK) break;
+            }
             const int acc1 = claim(o.src1), acc2 = o.src2 >= 0 ? claim(o.src2) : 0;
             // a conv with no norm in front of it, one source and no fused upsample: its data gradient IS the source's gradient -
             // written (or, through the epilogue's residual input, accumulated in place: each vector is read and written by one thread)
@@ -1800,7 +1834,7 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
                                             a.shift, a.dmask, a.pro_silu, g1, g2, acc1, acc2, grad_flat + P->params[gop.gn_gamma].ref_off,
                                             grad_flat + P->params[gop.gn_beta].ref_off, (float*)(bws + o.b_ab), (float*)(bws + P->bws_gnS), mod, s,
                                             o.wg_act >= 0 ? bws + o.wg_act : nullptr,
-                                            o.gn_rows_deferred && P->bias_jobs_dev ? (float*)(bws + o.b_gnrows) : nullptr);
+                                            o.gn_rows_deferred && P->bias_jobs_dev ? (float*)(bws + o.b_gnrows) : nullptr, extra);
                 else
                 rc = launch_gn_bwd_generic(dt, tmp, a.src1, a.src2, B, t1.H * t1.W, a.C1, a.C2, G,
                                            (const float*)(pk + P->params[gop.gn_gamma].packed_off), (const float*)(ws + gop.gn_mr),
@@ -1833,11 +1867,17 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
             written[o.res1] = 1;  // (its gradient buffer is dY itself)
         } else if (o.res1 >= 0) {
             const int R1 = P->tensors[o.res1].C;
-            const int acc1 = claim(o.res1), acc2 = o.res2 >= 0 ? claim(o.res2) : 0;
-            rc = launch_grad_acc(dt, dy, gptr(o.res1), o.res2 >= 0 ? gptr(o.res2) : nullptr, R1, a.Cout - R1, acc1, acc2, 0, B,
-                                 a.Hout, a.Wout, s);
+            if (!res_extra_off && o.res2 < 0 && R1 == a.Cout && o.dst >= 0) {
+                rc = flush_pending(o.res1);  // (one waiting branch per tensor)
+                pending[o.res1] = dy;
+            } else {
+                const int acc1 = claim(o.res1), acc2 = o.res2 >= 0 ? claim(o.res2) : 0;
+                rc = launch_grad_acc(dt, dy, gptr(o.res1), o.res2 >= 0 ? gptr(o.res2) : nullptr, R1, a.Cout - R1, acc1, acc2, 0, B,
+                                     a.Hout, a.Wout, s);
+            }
         }
     }
+    for (int id = 0; id < (int)pending.size() && rc == DMME_OK; ++id) rc = flush_pending(id);
     if (rc != DMME_OK) return rc;
     rc = flush(buckets ? 1 : -1);
     if (rc != DMME_OK) return rc;

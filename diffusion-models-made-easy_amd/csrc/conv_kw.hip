@@ -115,10 +115,18 @@ __global__ void __launch_bounds__(256, 1) conv3x3_kw_kernel(ConvArgs a, ConvTile
     // the chunk's halo DMA) and leaves them in the wave's own LDS rows for the in-place transform.  At small batches every norm of the
     // 32x32 / 16x16 levels was a finalize launch between two latency-bound convs.
     const bool gni_writer = tile_n == 0 && tx_blk == 0 && ty_blk == 0;
+    // (tiles of one image keep the chunk's rows in LDS in any case: read per vector from global memory inside the rolled transform loop
+    // they were a dependent round trip per iteration - 4.8 us of a 15.6 us batch-1 launch)
+    const bool rows_in_lds = a.has_gni || (a.scale && g.TN == 1);
     auto gni_rows = [&](int c0) __attribute__((always_inline)) {
-        if (!a.has_gni) return;
+        if (!rows_in_lds) return;
         float sc, sh;
-        gn_in_scale_shift(a, n0, c0 + lane, Cin, gni_writer, sc, sh);
+        if (a.has_gni) {
+            gn_in_scale_shift(a, n0, c0 + lane, Cin, gni_writer, sc, sh);
+        } else {
+            sc = a.scale[n0 * Cin + c0 + lane];
+            sh = a.shift[n0 * Cin + c0 + lane];
+        }
         parW[lane] = sc;
         parW[64 + lane] = sh;
     };
@@ -189,7 +197,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_kw_kernel(ConvArgs a, ConvTile
                 if ((okmask >> i) & 1u) {
                     const int n = n0 + ((row >> shTW) >> shTH);
                     const int so = n * Cin + c0 + ((lane & 7) ^ ((row >> 1) & 7)) * EPV;
-                    if (a.has_gni)
+                    if (rows_in_lds)
                         *p = gni_vec(*p, (lane & 7) ^ ((row >> 1) & 7), a.dmask ? a.dmask + so : nullptr);
                     else
                         *p = prologue_vec<T>(*p, a.scale ? a.scale + so : nullptr, a.scale ? a.shift + so : nullptr, a.dmask ? a.dmask + so : nullptr,
@@ -207,7 +215,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_kw_kernel(ConvArgs a, ConvTile
             } else if (has_pro) {
                 const int n = n0 + (int)__umulhi((unsigned)row, g.magic_px);
                 const int so = n * Cin + c0 + ((lane & 7) ^ ((row >> 1) & 7)) * EPV;  // the source piece this LDS piece holds
-                if (a.has_gni)
+                if (rows_in_lds)
                     *p = gni_vec(*p, (lane & 7) ^ ((row >> 1) & 7), a.dmask ? a.dmask + so : nullptr);
                 else
                     *p = prologue_vec<T>(*p, a.scale ? a.scale + so : nullptr, a.scale ? a.shift + so : nullptr, a.dmask ? a.dmask + so : nullptr,

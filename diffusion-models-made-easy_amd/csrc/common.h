@@ -31,6 +31,7 @@ void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 #define DMME_CHECK_LAUNCH() DMME_CHECK_HIP(hipGetLastError())
 
 typedef __bf16 bf16;
+typedef _Float16 f16;  // IEEE half: the reference's own AMP dtype (configs/ddpm/cifar10.yaml:53 `precision: 16`), 8x finer than bf16
 
 template <typename T>
 struct dtype_of;
@@ -42,11 +43,16 @@ template <>
 struct dtype_of<bf16> {
     static constexpr int value = DMME_BF16;
 };
+template <>
+struct dtype_of<f16> {
+    static constexpr int value = DMME_F16;
+};
 
-__host__ __device__ inline size_t dtype_size(int dt) { return dt == DMME_BF16 ? 2 : 4; }
+__host__ __device__ inline size_t dtype_size(int dt) { return dt == DMME_BF16 || dt == DMME_F16 ? 2 : 4; }
 
 __device__ __forceinline__ float to_f(float v) { return v; }
 __device__ __forceinline__ float to_f(bf16 v) { return (float)v; }
+__device__ __forceinline__ float to_f(f16 v) { return (float)v; }
 template <typename T>
 __device__ __forceinline__ T from_f(float v);
 template <>
@@ -56,6 +62,10 @@ __device__ __forceinline__ float from_f<float>(float v) {
 template <>
 __device__ __forceinline__ bf16 from_f<bf16>(float v) {
     return (bf16)v;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserving
+}
+template <>
+__device__ __forceinline__ f16 from_f<f16>(float v) {
+    return (f16)v;  // v_cvt_f16_f32: round-to-nearest-even
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }

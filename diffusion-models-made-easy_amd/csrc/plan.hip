@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "common.h"
+#include "lvl.h"
 
 namespace dmme {
 
@@ -90,6 +91,18 @@ struct Op {
     // OP_ATTN
     int at_qkv = -1, at_out = -1, at_heads = 1;
     int64_t at_lse = 0;  // workspace offset of the forward's log-sum-exp [N][S]
+    // level engine (lvl_engine.hip): index of the run that executes this op (-1: its own launch); the run's first op launches it
+    int lvl = -1, lvl_first = 0;
+};
+
+// one persistent launch for a stretch of the op list on a 4x4 / 8x8 map (lvl.h)
+struct LvlRun {
+    int op_first = 0, op_last = 0;  // plan ops [op_first, op_last]
+    int sh = 0, NG = 0, NGS = 0;
+    std::vector<LvlOp> ops;
+    LvlOp* ops_dev = nullptr;
+    unsigned* sync_dev = nullptr;   // [16] control words (epoch, done, error), then the flag rows [n_ops * 2][NG][LVL_NS]
+    double flops = 0, bytes = 0;
 };
 
 }  // namespace dmme
@@ -157,6 +170,7 @@ struct dmme_plan {
     std::vector<ColJob> col_jobs;     // column sums of dY of every bias-deferred conv: one grouped launch per flush
     ColJob* col_jobs_dev = nullptr;
     int col_split = 0;                // col_jobs[col_split:] belong to bucket 0
+    std::vector<LvlRun> lvl_runs;     // level-engine launches (small maps)
 };
 
 namespace {
@@ -968,6 +982,259 @@ void build_wgrad_group(dmme_plan* P, dmme_plan::WgGroup& G, int gi, int op_lo = 
         }
 }
 
+// ---- level engine: which stretches of the op list become ONE persistent launch (lvl.h, lvl_engine.hip) ---------------------------
+// A stretch qualifies when every op in it lives on one 4x4 / 8x8 map and has the shape the engine is built for: DDPM ResBlocks whose
+// convs have 256 couts (8 slices of 32), inputs of whole 64-channel chunks, norms with group sizes 8 / 16 / 32, single-head attention on
+// 4x4 maps.  Anything else (other widths, the IDDPM blocks, fp32) keeps its per-op launches.
+static int op_level(const dmme_plan* P, const Op& o) {  // the map width all tensors of the op share (4 / 8), 0: not a level op
+    auto hw = [&](int id, int& H, int& W) {
+        if (id < 0) return true;
+        const Tensor& t = P->tensors[id];
+        if (H == 0) {
+            H = t.H;
+            W = t.W;
+            return true;
+        }
+        return t.H == H && t.W == W;
+    };
+    int H = 0, W = 0;
+    bool ok = true;
+    if (o.kind == OP_CONV) {
+        if (o.src1 < 0 || o.dst < 0 || o.stride != 1 || o.up || (o.taps != 1 && o.taps != 9)) return 0;
+        for (int id : {o.src1, o.src2, o.dst, o.res1, o.res2}) ok = ok && hw(id, H, W);
+    } else if (o.kind == OP_GN) {
+        ok = hw(o.gn_src1, H, W) && hw(o.gn_src2, H, W);
+    } else if (o.kind == OP_ATTN) {
+        ok = hw(o.at_qkv, H, W) && hw(o.at_out, H, W);
+    } else {
+        return 0;
+    }
+    if (!ok || H != W || (H != 4 && H != 8)) return 0;
+    return H;
+}
+
+static bool build_lvl_run(dmme_plan* P, int i0, int i1, int lvl_w, int64_t& ws, LvlRun& R, std::vector<std::pair<int, int64_t>>& gn_acts) {
+    const int B = P->B, G = P->cfg.num_groups, HW = lvl_w * lvl_w;
+    const int64_t es = (int64_t)dtype_size(P->dtype);
+    std::vector<LvlOp> pre, body;           // LVL_NORM ops of tensors written before the launch; the ops proper
+    std::unordered_map<int, int> prod;      // tensor id -> index into `body` of the op that produces it in this run
+    std::unordered_map<int, int> pre_of;    // tensor id -> index into `pre`
+    // flag rows are (final op index) * 2 + which; body indices are shifted by pre.size() at the end: encode body rows as 1000000 + ...
+    auto row_of = [&](int tensor) -> int {
+        auto it = prod.find(tensor);
+        if (it != prod.end()) return 1000000 + it->second * 2;
+        auto jt = pre_of.find(tensor);
+        if (jt != pre_of.end()) return jt->second * 2;  // the LVL_NORM op that pre-activates it (its act is what the consumer reads)
+        return -1;
+    };
+    auto blank = [&]() {
+        LvlOp o{};
+        o.kind = LVL_CONV;
+        o.taps = 1;
+        o.wait0 = o.wait1 = -1;
+        o.a1_off = o.a2_off = o.dst_off = o.res_off = o.sc_off = -1;
+        o.tproj_col = -1;
+        o.keep = -1;
+        o.signal = 1;
+        for (auto& n : o.norm) n.act_off = n.dmask_off = -1;
+        return o;
+    };
+    for (int oi = i0; oi < i1; ++oi) {
+        const Op& o = P->ops[oi];
+        if (o.kind == OP_GN) {
+            if (o.gn_mod_col >= 0) return false;
+            const Tensor& t1 = P->tensors[o.gn_src1];
+            const int C2 = o.gn_src2 >= 0 ? P->tensors[o.gn_src2].C : 0, Cn = t1.C + C2;
+            if (Cn % G) return false;
+            const int cg = Cn / G;
+            if (cg % 8 || 32 % cg || t1.C != 256 || (C2 != 0 && C2 != 256)) return false;
+            int consumer = -1;  // the conv this norm feeds (exactly one: conv1 / conv2 / qkv_proj)
+            for (int ci = oi + 1; ci < i1; ++ci)
+                if (P->ops[ci].kind == OP_CONV && P->ops[ci].gn == oi) {
+                    if (consumer >= 0) return false;
+                    consumer = ci;
+                }
+            if (consumer < 0) return false;
+            const Op& cv = P->ops[consumer];
+            if (cv.src1 != o.gn_src1 || cv.src2 != o.gn_src2) return false;
+            const int64_t act = ws;
+            ws = align_up(ws + (int64_t)B * HW * Cn * es, 256);
+            gn_acts.push_back({oi, act});
+            int coff = 0;
+            for (int src : {o.gn_src1, o.gn_src2}) {
+                if (src < 0) continue;
+                LvlNorm n{};
+                n.gamma_off = P->params[o.gn_gamma].packed_off;
+                n.beta_off = P->params[o.gn_beta].packed_off;
+                n.scale_off = o.gn_scale;
+                n.shift_off = o.gn_shift;
+                n.mr_off = o.gn_mr;
+                n.act_off = act;
+                n.dmask_off = cv.dmask_off;
+                n.Cn = Cn;
+                n.cg = cg;
+                n.c_off = coff;
+                n.act_silu = cv.pro_silu;
+                LvlOp* host = nullptr;
+                auto it = prod.find(src);
+                if (it != prod.end()) {
+                    host = &body[it->second];
+                } else {
+                    auto jt = pre_of.find(src);
+                    if (jt == pre_of.end()) {
+                        LvlOp q = blank();
+                        q.kind = LVL_NORM;
+                        q.dst_off = P->tensors[src].off;
+                        q.dst_C = P->tensors[src].C;
+                        q.dst_c0 = 0;
+                        pre_of[src] = (int)pre.size();
+                        pre.push_back(q);
+                        jt = pre_of.find(src);
+                    }
+                    host = &pre[jt->second];
+                }
+                if (host->n_norm >= 2) return false;
+                // a 768-wide qkv tensor never feeds a norm; every other engine tensor is 256 wide: one LvlOp per tensor
+                host->norm[host->n_norm++] = n;
+                coff += P->tensors[src].C;
+            }
+            continue;
+        }
+        if (o.kind == OP_ATTN) {
+            const Tensor& q = P->tensors[o.at_qkv];
+            if (o.at_heads != 1 || HW != 16 || q.C != 768 || body.size() < 3 || body[body.size() - 1].keep != 2) return false;
+            LvlOp a = blank();
+            a.kind = LVL_ATTN;
+            a.dst_off = P->tensors[o.at_out].off;
+            a.dst_C = P->tensors[o.at_out].C;
+            a.dst_c0 = 0;
+            a.kscale = 1.0f / sqrtf((float)(q.C / 3));
+            a.sc_off = ws;
+            ws = align_up(ws + (int64_t)R.NG * LVL_NS * 1024 * 4, 256);
+            prod[o.at_out] = (int)body.size();
+            body.push_back(a);
+            R.flops += 4.0 * B * HW * HW * (q.C / 3);
+            continue;
+        }
+        // OP_CONV
+        const Param& w = P->params[o.w];
+        const Tensor& t1 = P->tensors[o.src1];
+        const int C1 = t1.C, C2 = o.src2 >= 0 ? P->tensors[o.src2].C : 0, Cin = C1 + C2;
+        const bool is_qkv = w.cout == 768 && oi + 1 < i1 && P->ops[oi + 1].kind == OP_ATTN && P->ops[oi + 1].at_qkv == o.dst;
+        if ((w.cout != 256 && !is_qkv) || Cin % 64 || C1 % 64 || o.out_silu || o.res2 >= 0) return false;
+        if (o.gn < 0 && (o.pro_silu || o.dmask_off >= 0)) return false;
+        {   // every wave's quarter of the (chunk, tap) units must touch at most two 64-channel chunks (its A region)
+            const int U = (Cin / 64) * o.taps;
+            for (int wv = 0; wv < 4; ++wv) {
+                const int u0 = U * wv / 4, nu = U * (wv + 1) / 4 - u0;
+                if (nu < 1 || (u0 + nu - 1) / o.taps - u0 / o.taps > 1) return false;
+            }
+        }
+        LvlOp c = blank();
+        c.taps = o.taps;
+        if (o.gn >= 0) {  // the pre-activated input its norm's producers wrote
+            int64_t act = -1;
+            for (auto& ga : gn_acts)
+                if (ga.first == o.gn) act = ga.second;
+            if (act < 0) return false;
+            c.a1_off = act;
+            c.C1 = Cin;
+            c.C2 = 0;
+        } else {
+            c.a1_off = t1.off;
+            c.C1 = C1;
+            c.a2_off = o.src2 >= 0 ? P->tensors[o.src2].off : -1;
+            c.C2 = C2;
+        }
+        c.wait0 = row_of(o.src1);
+        c.wait1 = o.src2 >= 0 ? row_of(o.src2) : -1;
+        if (o.gn >= 0 && ((c.wait0 < 0) || (o.src2 >= 0 && c.wait1 < 0))) return false;  // (an act tensor always has a producer in the run)
+        c.w_off = w.packed_off;
+        c.b_off = P->params[o.b].packed_off;
+        c.dst_off = P->tensors[o.dst].off;
+        c.dst_C = P->tensors[o.dst].C;
+        c.tproj_col = o.tproj_col;
+        if (o.res1 >= 0) {
+            if (P->tensors[o.res1].C != 256) return false;
+            c.res_off = P->tensors[o.res1].off;
+            c.res_C = 256;
+            c.res_c0 = 0;
+        }
+        R.flops += 2.0 * B * HW * (double)w.cout * Cin * o.taps;
+        R.bytes += (double)w.cout * Cin * o.taps * es + (double)B * HW * (Cin + w.cout) * es;
+        if (is_qkv) {
+            for (int j = 0; j < 3; ++j) {
+                LvlOp q = c;
+                q.w_row0 = 256 * j;
+                q.dst_c0 = 256 * j;
+                q.keep = j;
+                q.reuse_a = j > 0;
+                if (j > 0) q.wait0 = q.wait1 = -1;
+                body.push_back(q);
+            }
+            prod[o.dst] = (int)body.size() - 1;
+        } else {
+            prod[o.dst] = (int)body.size();
+            body.push_back(c);
+        }
+    }
+    const int shift = (int)pre.size();
+    R.ops = pre;
+    for (LvlOp c : body) {
+        for (int* wr : {&c.wait0, &c.wait1})
+            if (*wr >= 1000000) *wr = (*wr - 1000000) + shift * 2;
+        R.ops.push_back(c);
+    }
+    return !body.empty();
+}
+
+void assign_levels(dmme_plan* P) {
+    if (getenv("DMME_NO_LVL") || P->cfg.arch != DMME_ARCH_DDPM || P->x3 || (P->dtype != DMME_BF16 && P->dtype != DMME_F16)) return;
+    const int mask = getenv("DMME_LVL_MASK") ? atoi(getenv("DMME_LVL_MASK")) : 12;  // bit 2: 4x4 maps, bit 3: 8x8 maps
+    const int nO = (int)P->ops.size();
+    int i = 0;
+    while (i < nO) {
+        const int L = op_level(P, P->ops[i]);
+        if (!L) {
+            ++i;
+            continue;
+        }
+        int j = i;
+        while (j < nO && op_level(P, P->ops[j]) == L) ++j;
+        if (mask & L) {
+            LvlRun R;
+            R.op_first = i;
+            R.op_last = j - 1;
+            R.sh = L == 4 ? 2 : 3;
+            R.NG = (P->B * L * L + LVL_BM - 1) / LVL_BM;
+            R.NGS = R.NG < LVL_MAX_WG / LVL_NS ? R.NG : LVL_MAX_WG / LVL_NS;
+            int64_t ws = P->ws_bytes;
+            std::vector<std::pair<int, int64_t>> gn_acts;
+            if (build_lvl_run(P, i, j, L, ws, R, gn_acts)) {
+                P->ws_bytes = ws;
+                const int ri = (int)P->lvl_runs.size();
+                for (int oi = i; oi < j; ++oi) {
+                    Op& o = P->ops[oi];
+                    o.lvl = ri;
+                    o.lvl_first = oi == i;
+                    if (o.kind == OP_GN) o.gn_direct = 1;  // (no launch of its own; its rows and act come from the engine)
+                }
+                for (auto& ga : gn_acts) {
+                    Op& g = P->ops[ga.first];
+                    g.gn_act = ga.second;
+                    for (int ci = ga.first + 1; ci < j; ++ci)
+                        if (P->ops[ci].kind == OP_CONV && P->ops[ci].gn == ga.first) {
+                            g.gn_consumer = ci;
+                            P->ops[ci].use_act = 1;
+                        }
+                }
+                P->lvl_runs.push_back(R);
+            }
+        }
+        i = j;
+    }
+}
+
 // can this GroupNorm be finalised from the partials its producers emitted?
 bool gn_from_parts(const dmme_plan* P, const Op& o) {
     if (o.gn_force_small) return false;
@@ -989,14 +1256,14 @@ bool gn_from_parts(const dmme_plan* P, const Op& o) {
 void assign_stats(dmme_plan* P) {
     std::vector<char> wanted(P->tensors.size(), 0);
     for (const Op& o : P->ops)
-        if (o.kind == OP_GN) {
+        if (o.kind == OP_GN && o.lvl < 0) {  // (norms inside a level run are finished by the engine)
             wanted[o.gn_src1] = 1;
             if (o.gn_src2 >= 0) wanted[o.gn_src2] = 1;
         }
     const int G = P->cfg.num_groups;
     int64_t ws = P->ws_bytes;
     for (const Op& o : P->ops) {
-        if (o.kind != OP_CONV || o.dst < 0 || !wanted[o.dst]) continue;
+        if (o.kind != OP_CONV || o.dst < 0 || !wanted[o.dst] || o.lvl >= 0) continue;
         Tensor& td = P->tensors[o.dst];
         if (td.C % G) continue;
         ConvArgs a{};
@@ -1022,12 +1289,12 @@ void assign_direct(dmme_plan* P) {
     const int G = P->cfg.num_groups;
     std::vector<int> producer(nT, -1);
     for (int oi = 0; oi < nO; ++oi)
-        if (P->ops[oi].kind == OP_CONV && P->ops[oi].dst >= 0) producer[P->ops[oi].dst] = oi;
+        if (P->ops[oi].kind == OP_CONV && P->ops[oi].dst >= 0 && P->ops[oi].lvl < 0) producer[P->ops[oi].dst] = oi;
     struct Use { int gn, coff; };
     std::vector<std::vector<Use>> uses(nT);
     for (int oi = 0; oi < nO; ++oi) {
         const Op& g = P->ops[oi];
-        if (g.kind != OP_GN) continue;
+        if (g.kind != OP_GN || g.lvl >= 0) continue;
         uses[g.gn_src1].push_back({oi, 0});
         if (g.gn_src2 >= 0) uses[g.gn_src2].push_back({oi, P->tensors[g.gn_src1].C});
     }
@@ -1079,13 +1346,11 @@ void assign_direct(dmme_plan* P) {
             P->ops[uses[t][k].gn].gn_direct = 1;
         }
     }
-    for (const Op& o : P->ops)
-        if (o.kind == OP_GN && o.gn_direct) --P->n_launches;
     if (getenv("DMME_NO_PREACT")) return;
     // single-source direct norms: the producer also writes the consumer's pre-activated input
     for (int ci = 0; ci < nO; ++ci) {
         Op& cv = P->ops[ci];
-        if (cv.kind != OP_CONV || cv.gn < 0 || cv.src1 < 0 || cv.up || cv.stride != 1) continue;
+        if (cv.kind != OP_CONV || cv.gn < 0 || cv.src1 < 0 || cv.up || cv.stride != 1 || cv.lvl >= 0) continue;
         Op& g = P->ops[cv.gn];
         if (!g.gn_direct || g.gn_src2 >= 0 || g.gn_act >= 0 || g.gn_src1 != cv.src1 || cv.src2 >= 0) continue;
         Op& pr = P->ops[producer[g.gn_src1]];
@@ -1110,7 +1375,7 @@ void assign_preact(dmme_plan* P) {
     const int64_t es = (int64_t)dtype_size(P->dtype);
     for (int ci = 0; ci < (int)P->ops.size(); ++ci) {
         Op& cv = P->ops[ci];
-        if (cv.kind != OP_CONV || cv.gn < 0 || cv.src1 < 0 || cv.up || cv.stride != 1) continue;
+        if (cv.kind != OP_CONV || cv.gn < 0 || cv.src1 < 0 || cv.up || cv.stride != 1 || cv.lvl >= 0) continue;
         Op& g = P->ops[cv.gn];
         static const bool over_parts = getenv("DMME_PREACT_PARTS") && atoi(getenv("DMME_PREACT_PARTS")) != 0;
         if (g.gn_mod_col >= 0 || g.gn_act >= 0 || g.gn_direct) continue;
@@ -1138,7 +1403,7 @@ void assign_preact(dmme_plan* P) {
 // them in its parameter fill (ws_fill_par_gni) - no finalize launch between the two convolutions.
 void assign_gn_in(dmme_plan* P) {
     for (Op& cv : P->ops) {
-        if (cv.kind != OP_CONV || cv.gn < 0 || cv.use_act) continue;
+        if (cv.kind != OP_CONV || cv.gn < 0 || cv.use_act || cv.lvl >= 0) continue;
         Op& g = P->ops[cv.gn];
         if (g.gn_direct || g.gn_in_consumer || g.gn_act >= 0 || !gn_from_parts(P, g)) continue;
         if (g.gn_src1 != cv.src1 || g.gn_src2 != cv.src2) continue;
@@ -1157,7 +1422,6 @@ void assign_gn_in(dmme_plan* P) {
         a.nt = cv.tproj_col >= 0 ? P->B : 0;
         if (!conv_gn_in_query(P->dtype, a)) continue;
         g.gn_in_consumer = 1;
-        --P->n_launches;
     }
 }
 
@@ -1202,8 +1466,29 @@ int run_gn(const dmme_plan* P, const Op& o, const char* pk, char* ws, int nt, co
     return launch_gn_modulate(sc, sh, tsh, tsc, P->tproj_cols, nt, P->B, o.gn_mod_C, s);
 }
 
+int run_level(const dmme_plan* P, const LvlRun& R, const char* pk, char* ws, int nt, const float* drop_masks, hipStream_t s) {
+    DMME_REQUIRE(R.ops_dev && R.sync_dev, DMME_ERR_INVALID, "level engine: the plan was created without a device");
+    LvlArgs a{};
+    a.ops = R.ops_dev;
+    a.n_ops = (int)R.ops.size();
+    a.ws = ws;
+    a.packed = pk;
+    a.drop_masks = drop_masks;
+    a.tproj = (const float*)(ws + P->ws_tproj);
+    a.tproj_ld = P->tproj_cols;
+    a.nt = nt;
+    a.N = P->B;
+    a.sh = R.sh;
+    a.NG = R.NG;
+    a.NGS = R.NGS;
+    a.ctl = R.sync_dev;
+    a.flags = R.sync_dev + 16;
+    return launch_lvl_engine(P->dtype, a, s);
+}
+
 int run_op(const dmme_plan* P, const Op& o, const char* pk, const float* x, const int64_t* t, int nt, float* y,
            char* ws, const float* drop_masks, hipStream_t s) {
+    if (o.lvl >= 0) return o.lvl_first ? run_level(P, P->lvl_runs[o.lvl], pk, ws, nt, drop_masks, s) : DMME_OK;
     switch (o.kind) {
         case OP_SINUS:
             return launch_time_sinusoid(t, nt, (const float*)(pk + P->params[P->freqs_param].packed_off),
@@ -1248,6 +1533,17 @@ void op_account(const dmme_plan* P, const Op& o, char* label, int cap, double* f
     const double B = P->B;
     *flops = 0;
     *bytes = 0;
+    if (o.lvl >= 0) {  // one launch for the whole run: accounted on its first op
+        const LvlRun& R = P->lvl_runs[o.lvl];
+        if (o.lvl_first) {
+            snprintf(label, cap, "lvl_engine_kernel<%dx%d>", 1 << R.sh, 1 << R.sh);
+            *flops = R.flops;
+            *bytes = R.bytes;
+        } else {
+            snprintf(label, cap, "(level engine)");
+        }
+        return;
+    }
     switch (o.kind) {
         case OP_SINUS:
             snprintf(label, cap, "time_sinusoid_kernel");
@@ -1351,10 +1647,20 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
         delete P;
         return rc;
     }
+    assign_levels(P);
     if (!getenv("DMME_NO_FUSED_GN")) assign_stats(P);
     if (!getenv("DMME_NO_FUSED_GN") && !getenv("DMME_NO_GN_DIRECT")) assign_direct(P);
     if (!getenv("DMME_NO_PREACT")) assign_preact(P);
     if (!getenv("DMME_NO_FUSED_GN")) assign_gn_in(P);
+    P->n_launches = 0;
+    for (const Op& o : P->ops) {
+        if (o.lvl >= 0)
+            P->n_launches += o.lvl_first;
+        else if (o.kind == OP_GN)
+            P->n_launches += !(o.gn_direct || o.gn_in_consumer);
+        else
+            ++P->n_launches;
+    }
     if (device >= 0) {
         // bucket boundary: parameters from the first up_layers entry on are finished first by backward
         P->op_split = (int)P->ops.size();
@@ -1490,6 +1796,13 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
             if (e == hipSuccess) e = hipMalloc((void**)&G->jobs_dev, G->jobs.size() * sizeof(WgJob));
             if (e == hipSuccess) e = hipMemcpy(G->jobs_dev, G->jobs.data(), G->jobs.size() * sizeof(WgJob), hipMemcpyHostToDevice);
         }
+        for (LvlRun& R : P->lvl_runs) {
+            const size_t words = 16 + R.ops.size() * 2 * (size_t)R.NG * LVL_NS;
+            if (e == hipSuccess) e = hipMalloc((void**)&R.ops_dev, R.ops.size() * sizeof(LvlOp));
+            if (e == hipSuccess) e = hipMemcpy(R.ops_dev, R.ops.data(), R.ops.size() * sizeof(LvlOp), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMalloc((void**)&R.sync_dev, words * 4);
+            if (e == hipSuccess) e = hipMemset(R.sync_dev, 0, words * 4);
+        }
         P->unpack_split = (int)uitems.size();
         for (int i = 0; i < (int)uitems.size(); ++i)
             if (uitems[i].src_off >= P->bucket_off) {
@@ -1520,6 +1833,10 @@ DMME_API void dmme_unet_plan_destroy(dmme_plan* plan) {
     if (plan->tp_tiles_dev) (void)hipFree(plan->tp_tiles_dev);
     if (plan->bias_jobs_dev) (void)hipFree(plan->bias_jobs_dev);
     if (plan->col_jobs_dev) (void)hipFree(plan->col_jobs_dev);
+    for (LvlRun& R : plan->lvl_runs) {
+        if (R.ops_dev) (void)hipFree(R.ops_dev);
+        if (R.sync_dev) (void)hipFree(R.sync_dev);
+    }
     delete plan;
 }
 
@@ -1572,6 +1889,24 @@ DMME_API int dmme_unet_forward(const dmme_plan* plan, const void* packed, const 
 }
 
 DMME_API int dmme_unet_plan_num_ops(const dmme_plan* plan) { return plan ? (int)plan->ops.size() : 0; }
+
+DMME_API int dmme_unet_plan_level_info(const dmme_plan* plan, char* buf, int cap) {
+    DMME_REQUIRE(plan && buf && cap > 0, DMME_ERR_INVALID, "level_info: bad argument");
+    std::string out;
+    char tmp[192];
+    snprintf(tmp, sizeof(tmp), "runs=%d", (int)plan->lvl_runs.size());
+    out = tmp;
+    for (const LvlRun& R : plan->lvl_runs) {
+        unsigned ctl[3] = {0, 0, 0};
+        if (R.sync_dev) DMME_CHECK_HIP(hipMemcpy(ctl, R.sync_dev, sizeof(ctl), hipMemcpyDeviceToHost));  // (synchronises with the device)
+        snprintf(tmp, sizeof(tmp), " [map=%dx%d plan_ops=%d-%d engine_ops=%d groups=%d resident=%d workgroups=%d epoch=%u err=%u]", 1 << R.sh, 1 << R.sh,
+                 R.op_first, R.op_last, (int)R.ops.size(), R.NG, R.NGS, R.NGS * LVL_NS, ctl[0], ctl[2]);
+        out += tmp;
+    }
+    strncpy(buf, out.c_str(), (size_t)cap - 1);
+    buf[cap - 1] = 0;
+    return DMME_OK;
+}
 
 DMME_API int dmme_unet_plan_op_info(const dmme_plan* plan, int index, char* label, int label_cap, double* flops,
                                     double* bytes) {

@@ -54,7 +54,7 @@ typedef enum {
  * convolution product runs as three bf16 MFMA passes over hi/lo splits of its fp32 operands (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi,
  * fp32 accumulation), ~2^-16 per product instead of 2^-9: within 1e-3 of the fp32 reference at the bf16 matrix rate / 3.
  * Accepted wherever a dtype is (plans and the single-op entry points); buffers are the fp32 ones. */
-typedef enum { DMME_F32 = 0, DMME_BF16 = 1, DMME_BF16X3 = 2 } dmme_dtype;
+typedef enum { DMME_F32 = 0, DMME_BF16 = 1, DMME_BF16X3 = 2, DMME_F16 = 3 } dmme_dtype;
 
 /* Which of the reference's two UNets the plan builds. */
 typedef enum {
@@ -130,6 +130,11 @@ DMME_API int dmme_unet_forward(const dmme_plan* plan, const void* packed, const 
  * forward_profiled: same launches as dmme_unet_forward, but each op is bracketed by HIP
  * events on `stream`; synchronises, then writes one elapsed time per op (ms). */
 DMME_API int dmme_unet_plan_num_ops(const dmme_plan* plan);
+/* Level-engine launches of this plan (csrc/lvl_engine.hip: one persistent launch per stretch of layers on a 4x4 / 8x8 map, replacing
+ * the per-layer launches of ResBlock / Attention there, models/ddpm.py:118-133, 38-75) as text: "runs=N [map=4x4 plan_ops=a-b
+ * engine_ops=.. groups=.. resident=.. workgroups=.. epoch=.. err=..] ...".  err != 0: a bounded in-kernel wait timed out (results of
+ * that launch are invalid).  Synchronises with the device (reads the control words). */
+DMME_API int dmme_unet_plan_level_info(const dmme_plan* plan, char* buf, int cap);
 DMME_API int dmme_unet_plan_op_info(const dmme_plan* plan, int index, char* label, int label_cap, double* flops,
                            double* bytes);
 DMME_API int dmme_unet_forward_profiled(const dmme_plan* plan, const void* packed, const float* x, const int64_t* t,

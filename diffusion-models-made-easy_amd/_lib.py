@@ -95,7 +95,10 @@ PROTOTYPES = {
     "dmme_unet_plan_grad_buckets": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "dmme_unet_plan_bwd_summary": (_i, [_vp, C.c_char_p, _i]),
     "dmme_grad_norm": (_i, [_vp, _i64, _vp, _vp, _vp]),
-    "dmme_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _vp, _f, _f, _vp]),
+    "dmme_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _vp, _f, _f, _f, _vp]),
+    "dmme_grad_pack_bf16": (_i, [_vp, _i64, _vp, _i64, _vp]),
+    "dmme_shard_reduce_bf16": (_i, [_vp, _i, _i64, _f, _vp, _vp]),
+    "dmme_grad_unpack_bf16": (_i, [_vp, _i64, _vp, _vp]),
     "dmme_unet_debug_read": (_i, [_vp, _vp, C.c_char_p, _vp, _i64, C.POINTER(_i64), _vp]),
     "dmme_dropout_masks": (_i, [_vp, _u64, _u64, _vp, _vp]),
     "dmme_randn": (_i, [_vp, _i64, _u64, _u64, _vp]),

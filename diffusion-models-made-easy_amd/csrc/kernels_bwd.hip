@@ -743,18 +743,19 @@ int launch_grad_norm(const float* g, int64_t n, float* norm_out, float* scratch,
 }
 
 // clip-by-global-norm + Adam (+ EMA) over flat fp32 buffers, one pass:
-//   g *= min(1, max_norm / (norm + 1e-6))                       (torch.nn.utils.clip_grad_norm_)
+//   g *= grad_scale (1 / world when the exchange left SUMS in the buffer: the mean's divide rides on this pass)
+//   g *= min(1, max_norm / (norm + 1e-6))                       (torch.nn.utils.clip_grad_norm_; norm = grad_scale * ||buffer||)
 //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2
 //   p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)                 (torch.optim.Adam, no weight decay)
 //   ema = d ema + (1-d) p                                        (callbacks/ema.py:169-176)
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, float* __restrict__ ema, int64_t n, float lr, float b1, float b2,
                                                    float eps, float bc1, float bc2_sqrt, const float* __restrict__ norm, float max_norm,
-                                                   float ema_decay) {
-    float clip = 1.0f;
+                                                   float ema_decay, float grad_scale) {
+    float clip = grad_scale;
     if (norm && max_norm > 0.f) {
-        const float c = max_norm / (norm[0] + 1e-6f);
-        clip = c < 1.0f ? c : 1.0f;
+        const float c = max_norm / (norm[0] * grad_scale + 1e-6f);
+        clip = c < 1.0f ? c * grad_scale : grad_scale;
     }
     const float step = lr / bc1;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -769,11 +770,48 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
     }
 }
 int launch_adam(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr, float b1, float b2, float eps, int step,
-                const float* norm, float max_norm, float ema_decay, hipStream_t s) {
+                const float* norm, float max_norm, float ema_decay, float grad_scale, hipStream_t s) {
     const float bc1 = 1.0f - powf(b1, (float)step), bc2s = sqrtf(1.0f - powf(b2, (float)step));
     int64_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, ema, n, lr, b1, b2, eps, bc1, bc2s, norm, max_norm, ema_decay);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, ema, n, lr, b1, b2, eps, bc1, bc2s, norm, max_norm, ema_decay, grad_scale);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+// ---- gradient exchange with bf16 on the wire and fp32 accumulation (distributed.Bf16ShardExchange) ----
+// pack: fp32 gradient slice -> bf16 send buffer (round-to-nearest-even), zero padded to a multiple of the world size
+__global__ void __launch_bounds__(256) grad_pack_bf16_kernel(const float* __restrict__ g, int64_t n, bf16* __restrict__ dst, int64_t n_pad) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (bf16)(i < n ? g[i] : 0.f);
+}
+// reduce: this rank's shard as received from every rank, [world][per] bf16 -> scale * sum in fp32 (fixed order: rank 0 first), rounded once
+__global__ void __launch_bounds__(256) shard_reduce_bf16_kernel(const bf16* __restrict__ recv, int world, int64_t per, float scale, bf16* __restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x) {
+        float acc = 0.f;
+        for (int j = 0; j < world; ++j) acc += (float)recv[(int64_t)j * per + i];
+        out[i] = (bf16)(acc * scale);
+    }
+}
+// unpack: gathered bf16 means -> the fp32 gradient slice every rank's optimiser reads (identical bits on every rank)
+__global__ void __launch_bounds__(256) grad_unpack_bf16_kernel(const bf16* __restrict__ src, int64_t n, float* __restrict__ g) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) g[i] = (float)src[i];
+}
+static unsigned exch_blocks(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (unsigned)(b > 4096 ? 4096 : b < 1 ? 1 : b);
+}
+int launch_grad_pack_bf16(const float* g, int64_t n, void* dst, int64_t n_pad, hipStream_t s) {
+    hipLaunchKernelGGL(grad_pack_bf16_kernel, dim3(exch_blocks(n_pad)), dim3(256), 0, s, g, n, (bf16*)dst, n_pad);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+int launch_shard_reduce_bf16(const void* recv, int world, int64_t per, float scale, void* out, hipStream_t s) {
+    hipLaunchKernelGGL(shard_reduce_bf16_kernel, dim3(exch_blocks(per)), dim3(256), 0, s, (const bf16*)recv, world, per, scale, (bf16*)out);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+int launch_grad_unpack_bf16(const void* src, int64_t n, float* g, hipStream_t s) {
+    hipLaunchKernelGGL(grad_unpack_bf16_kernel, dim3(exch_blocks(n)), dim3(256), 0, s, (const bf16*)src, n, g);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }

@@ -1609,7 +1609,7 @@ void op_account(const dmme_plan* P, const Op& o, char* label, int cap, double* f
 extern "C" {
 
 DMME_API const char* dmme_last_error(void) { return g_err; }
-DMME_API int dmme_version(void) { return 102; }
+DMME_API int dmme_version(void) { return 103; }
 DMME_API int dmme_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -2337,10 +2337,23 @@ DMME_API int dmme_grad_norm(const float* grad, int64_t numel, float* norm_out, f
 
 DMME_API int dmme_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema, int64_t numel, float lr,
                             float beta1, float beta2, float eps, int step, const float* grad_norm, float max_norm, float ema_decay,
-                            void* stream) {
-    DMME_REQUIRE(param && grad && exp_avg && exp_avg_sq && numel > 0 && step >= 1, DMME_ERR_INVALID, "adam_step: bad argument");
-    return launch_adam(param, grad, exp_avg, exp_avg_sq, ema, numel, lr, beta1, beta2, eps, step, grad_norm, max_norm, ema_decay,
+                            float grad_scale, void* stream) {
+    DMME_REQUIRE(param && grad && exp_avg && exp_avg_sq && numel > 0 && step >= 1 && grad_scale > 0.f, DMME_ERR_INVALID, "adam_step: bad argument");
+    return launch_adam(param, grad, exp_avg, exp_avg_sq, ema, numel, lr, beta1, beta2, eps, step, grad_norm, max_norm, ema_decay, grad_scale,
                        (hipStream_t)stream);
+}
+
+DMME_API int dmme_grad_pack_bf16(const float* grad, int64_t numel, void* dst_bf16, int64_t numel_padded, void* stream) {
+    DMME_REQUIRE(grad && dst_bf16 && numel > 0 && numel_padded >= numel, DMME_ERR_INVALID, "grad_pack_bf16: bad argument");
+    return launch_grad_pack_bf16(grad, numel, dst_bf16, numel_padded, (hipStream_t)stream);
+}
+DMME_API int dmme_shard_reduce_bf16(const void* recv_bf16, int world, int64_t per_rank, float scale, void* out_bf16, void* stream) {
+    DMME_REQUIRE(recv_bf16 && out_bf16 && world >= 1 && per_rank > 0, DMME_ERR_INVALID, "shard_reduce_bf16: bad argument");
+    return launch_shard_reduce_bf16(recv_bf16, world, per_rank, scale, out_bf16, (hipStream_t)stream);
+}
+DMME_API int dmme_grad_unpack_bf16(const void* src_bf16, int64_t numel, float* grad, void* stream) {
+    DMME_REQUIRE(src_bf16 && grad && numel > 0, DMME_ERR_INVALID, "grad_unpack_bf16: bad argument");
+    return launch_grad_unpack_bf16(src_bf16, numel, grad, (hipStream_t)stream);
 }
 
 DMME_API int dmme_unet_debug_read(const dmme_plan* plan, const void* workspace, const char* name, float* dst,

@@ -3,8 +3,13 @@
 Sampling shards the batch across ranks with NO data-path collective (chains are
 independent): each rank derives its own Philox stream from (seed, rank) and
 only timing / optional result gathering touch the process group.  Training adds exactly
-one exchange per step: the mean all-reduce of the flat UNet gradient buffer, issued in
-reverse-layer-order buckets so it can overlap the rest of backward."""
+one exchange per step: the mean of the flat UNet gradient buffer over the ranks, issued in
+reverse-layer-order buckets so it can overlap the rest of backward.  Two wire formats
+(`exchange=`): "fp32-allreduce" (RCCL ring all-reduce of the fp32 buffer, the divide by the
+world size folded into the fused clip + Adam pass) and "bf16-rs-ag" (Bf16ShardExchange: bf16 on
+the wire, every rank's shard sent directly to its owner over all xGMI links at once, fp32
+accumulation at the owner, all-gather of the rounded means: SURVEY 8e's design for the
+16-images-per-GPU reading of north_star)."""
 
 from __future__ import annotations
 
@@ -85,16 +90,19 @@ def bucket_slices(numel: int, bucket_elems: int) -> List[Tuple[int, int]]:
     return out
 
 
-def allreduce_mean_flat(flat_grad: torch.Tensor, bucket_elems: int = 8 << 20, async_op: bool = False):
-    """Mean all-reduce of a flat gradient buffer in reverse-order buckets.  With async_op the
-    work handles are returned so the caller can overlap them with remaining backward work."""
+def allreduce_mean_flat(flat_grad: torch.Tensor, bucket_elems: int = 8 << 20, async_op: bool = False, mean: bool = True):
+    """All-reduce of a flat gradient buffer in reverse-order buckets.  With async_op the work handles are
+    returned so the caller can overlap them with remaining backward work.  mean=False leaves the rank SUMS in the
+    buffer: the caller folds 1 / world into the optimiser's fused pass (FusedAdam.grad_scale) instead of sweeping
+    the buffer once more here."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return []
     world = dist.get_world_size()
     handles = []
     for b, e in bucket_slices(flat_grad.numel(), bucket_elems):
         view = flat_grad[b:e]
-        view.div_(world)
+        if mean:
+            view.div_(world)
         h = dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=async_op)
         if async_op:
             handles.append(h)
@@ -111,13 +119,32 @@ class OverlappedGradReducer:
     the compute stream wait for the side stream before the optimiser reads the gradients.  On CPU tensors (gloo tests) there are no
     streams: the collectives run asynchronously and `finish()` waits on their handles."""
 
-    def __init__(self, model, bucket_elems: int = 8 << 20):
+    exchange = "fp32-allreduce"
+
+    def __init__(self, model, bucket_elems: int = 8 << 20, fold_mean: bool = True):
         self.model = model
         self.bucket_elems = bucket_elems
+        self.fold_mean = fold_mean  # leave rank SUMS in the buffer; `grad_scale()` (1 / world) goes into the fused clip + Adam pass
         self.handles = []
         self.reported = []
         self._stream = None
-        model._bucket_hook = self.bucket_ready  # picked up by UNet._backward_impl
+        self.attach()
+
+    def attach(self):
+        """backward reports its gradient buckets to this reducer (UNet._backward_impl picks the hook up)"""
+        self.model._bucket_hook = self.bucket_ready
+
+    def detach(self):
+        """a step WITHOUT gradient exchange on a model that has a reducer: nothing may be issued from inside its backward"""
+        self.model._bucket_hook = None
+        for h in self.handles:
+            h.wait()
+        self.handles.clear()
+        self.reported.clear()
+
+    def grad_scale(self) -> float:
+        """what the optimiser must multiply the exchanged buffer by to obtain the mean gradient"""
+        return 1.0 / dist.get_world_size() if (self.fold_mean and self.active()) else 1.0
 
     def active(self) -> bool:
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
@@ -141,7 +168,8 @@ class OverlappedGradReducer:
             self._reduce(view, world)
 
     def _reduce(self, view: torch.Tensor, world: int):
-        view.div_(world)
+        if not self.fold_mean:
+            view.div_(world)
         for b, e in bucket_slices(view.numel(), self.bucket_elems):
             self.handles.append(dist.all_reduce(view[b:e], op=dist.ReduceOp.SUM, async_op=True))
 
@@ -164,3 +192,77 @@ class OverlappedGradReducer:
         self.handles.clear()
         self.reported.clear()
         return True
+
+
+class Bf16ShardExchange(OverlappedGradReducer):
+    """Gradient mean with bf16 on the wire and fp32 accumulation: reduce-scatter + all-gather in their DIRECT form.
+
+    xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce of M bytes moves 2 (w-1)/w M per GPU over ONE outgoing link
+    (fp32: 227 MB -> ~1.5 ms), while sending shard j straight to rank j uses all links at once: 2 x M/w per peer (bf16: 2 x 8.1 MB ->
+    ~0.11 ms at world 8).  Per sub-bucket (slices of `bucket_elems`, the tail of the flat buffer first, at least four per
+    step so the exchange pipelines under the rest of backward):
+      pack      fp32 slice -> bf16, padded to world x per            (dmme_grad_pack_bf16)
+      all-to-all   rank r sends its copy of shard j to rank j        (torch.distributed: RCCL all_to_all_single)
+      reduce    owner: sum of the w received copies in fp32, rank order, x 1/w, ONE rounding to bf16   (dmme_shard_reduce_bf16)
+      all-gather   the rounded means                                  (RCCL all_gather_into_tensor)
+      unpack    bf16 -> the fp32 gradient buffer                      (dmme_grad_unpack_bf16)
+    The owner also takes the ROUNDED mean of its own shard, so every rank's buffer holds identical bits and clip + Adam + EMA stay
+    rank-identical with no further communication.  Error: one bf16 rounding per contribution (2^-9 relative each, independent) and one
+    of the mean - against 4-5 % per-tensor gradient error of the bf16 backward itself.  On CPU tensors (gloo
+    tests) the three conversions run as torch ops with the same roundings."""
+
+    exchange = "bf16-rs-ag"
+
+    def __init__(self, model, bucket_elems: int = 4 << 20):
+        super().__init__(model, bucket_elems, fold_mean=False)
+        self._bufs = {}
+
+    def grad_scale(self) -> float:
+        return 1.0  # the owner's reduce already divided
+
+    def _buffers(self, pad: int, per: int, like: torch.Tensor):
+        key = (pad, like.device)
+        b = self._bufs.get(key)
+        if b is None:
+            mk = lambda n: torch.empty(n, dtype=torch.bfloat16, device=like.device)
+            b = self._bufs[key] = (mk(pad), mk(pad), mk(per), mk(pad))
+        return b
+
+    def _reduce(self, view: torch.Tensor, world: int):
+        for b, e in bucket_slices(view.numel(), self.bucket_elems):
+            self._exchange(view[b:e], world)
+
+    def _exchange(self, v: torch.Tensor, world: int):
+        n = v.numel()
+        per = (n + world - 1) // world
+        pad = per * world
+        send, recv, shard, gathered = self._buffers(pad, per, v)
+        if v.is_cuda:
+            from . import _lib
+
+            lib, st = _lib.lib(), _lib.stream_ptr()
+            _lib.check(lib.dmme_grad_pack_bf16(_lib.ptr(v), n, _lib.ptr(send), pad, st), "dmme_grad_pack_bf16")
+            dist.all_to_all_single(recv, send)
+            _lib.check(lib.dmme_shard_reduce_bf16(_lib.ptr(recv), world, per, 1.0 / world, _lib.ptr(shard), st), "dmme_shard_reduce_bf16")
+            dist.all_gather_into_tensor(gathered, shard)
+            _lib.check(lib.dmme_grad_unpack_bf16(_lib.ptr(gathered), n, _lib.ptr(v), st), "dmme_grad_unpack_bf16")
+        else:  # gloo rehearsal on CPU tensors: the same roundings and summation order with torch ops
+            send.zero_()
+            send[:n].copy_(v)
+            dist.all_to_all_single(recv, send)
+            acc = torch.zeros(per, dtype=torch.float32)
+            for j in range(world):
+                acc += recv[j * per : (j + 1) * per].to(torch.float32)
+            shard.copy_(acc * (1.0 / world))
+            dist.all_gather_into_tensor(gathered, shard)
+            v.copy_(gathered[:n])
+
+
+def make_reducer(model, exchange: Optional[str] = None):
+    """the gradient exchange of a data-parallel run: DMME_EXCHANGE / `exchange` = 'fp32-allreduce' (default) or 'bf16-rs-ag'"""
+    kind = exchange or os.environ.get("DMME_EXCHANGE", "fp32-allreduce")
+    if kind == "bf16-rs-ag":
+        return Bf16ShardExchange(model)
+    if kind != "fp32-allreduce":
+        raise ValueError(f"unknown gradient exchange '{kind}' (fp32-allreduce | bf16-rs-ag)")
+    return OverlappedGradReducer(model)

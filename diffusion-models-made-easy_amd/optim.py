@@ -32,6 +32,9 @@ class FusedAdam(torch.optim.Optimizer):
                     self._owners.append(owner)
         self._flat_state = {}
         self.last_grad_norm = None
+        # multiplies the gradient inside the fused pass: 1 / world when the data-parallel exchange left rank SUMS in the flat buffer
+        # (distributed.py folds the mean's divide into this pass instead of a separate sweep over 130 MB); consumed by ONE step
+        self.grad_scale = 1.0
 
     def zero_grad(self, set_to_none: bool = False):
         for m in self._owners:
@@ -61,10 +64,11 @@ class FusedAdam(torch.optim.Optimizer):
                 self.last_grad_norm = st["norm"]
             _lib.check(
                 lib.dmme_adam_step(_lib.ptr(flat), _lib.ptr(grad), _lib.ptr(st["m"]), _lib.ptr(st["v"]), _lib.ptr(st["ema"]), flat.numel(), lr, b1, b2, eps,
-                                   self._step_count, norm_ptr, max_norm, decay, _lib.stream_ptr()),
+                                   self._step_count, norm_ptr, max_norm, decay, float(self.grad_scale), _lib.stream_ptr()),
                 "dmme_adam_step",
             )
             m.mark_params_updated()
+        self.grad_scale = 1.0
         return loss
 
     def ema_parameters(self, model):

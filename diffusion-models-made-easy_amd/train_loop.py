@@ -18,26 +18,38 @@ def synthetic_batch(batch_size: int, device, shape=(3, 32, 32)):
     return torch.rand((batch_size, *shape), device=device) * 2 - 1
 
 
-def train_step(module, optimizer, scheduler, x0, clip=None, reduce=True):
-    """one optimisation step: loss -> HIP backward (data parallel: the gradient all-reduce of the first bucket runs on a side
+def train_step(module, optimizer, scheduler, x0, clip=None, reduce=True, exchange=None):
+    """one optimisation step: loss -> HIP backward (data parallel: the gradient exchange of the first bucket runs on a side
     stream under the rest of backward) -> clip+Adam(+EMA) -> LR step.  `reduce=False` leaves the gradient exchange out
-    (bench.py times the step without its collective to tell exposed from hidden all-reduce time)."""
+    (bench.py times the step without its collective to tell exposed from hidden exchange time).  `exchange`: wire format of
+    the gradient mean (distributed.make_reducer: "fp32-allreduce" | "bf16-rs-ag"; default DMME_EXCHANGE or fp32)."""
     model = module.diffusion_model.model
     reducer = getattr(model, "_grad_reducer", None)
     multi = reduce and D.dist.is_available() and D.dist.is_initialized() and D.dist.get_world_size() > 1
     if multi and not getattr(model, "_dp_synced", False):  # first data-parallel step: identical replicas (rank 0's weights)
         D.sync_parameters(model, optimizer)
         model._dp_synced = True
-    if reducer is None and not os.environ.get("DMME_NO_OVERLAP") and multi:
-        reducer = model._grad_reducer = D.OverlappedGradReducer(model)
+    if multi and not os.environ.get("DMME_NO_OVERLAP"):
+        if reducer is not None and exchange is not None and reducer.exchange != exchange:
+            reducer.detach()
+            reducer = None
+        if reducer is None:
+            reducer = model._grad_reducer = D.make_reducer(model, exchange)
+        reducer.attach()
+    elif reducer is not None:
+        # no exchange in this step: the hook must be gone BEFORE backward runs, or that backward would issue all-reduces (and divide
+        # the gradients) on the side stream with nobody waiting for them
+        reducer.detach()
     loss = module.training_step((x0,), 0)
     loss.backward()
-    if not multi:
-        if reducer is not None:  # a reducer left by earlier exchanged steps: discard what this backward reported to it
-            reducer.reported.clear()
-            model._bucket_hook = None
-    elif reducer is None or not reducer.finish():
-        D.allreduce_mean_flat(model.flat_grad())
+    if multi:
+        if reducer is not None and getattr(model, "_bucket_hook", None) is not None and reducer.finish():
+            if hasattr(optimizer, "grad_scale"):
+                optimizer.grad_scale = reducer.grad_scale()
+            elif reducer.grad_scale() != 1.0:
+                model.flat_grad().mul_(reducer.grad_scale())
+        else:
+            D.allreduce_mean_flat(model.flat_grad())
     optimizer.step()
     if scheduler is not None:
         scheduler.step()

@@ -183,10 +183,19 @@ DMME_API int dmme_debug_l2_stream(const void* buf, int64_t bytes, int iters, int
 DMME_API int dmme_grad_norm(const float* grad, int64_t numel, float* norm_out, float* scratch, void* stream);
 /* one fused pass: clip by global norm (max_norm <= 0: off) -> Adam (torch.optim.Adam, no weight
  * decay; reference lit_modules/ddpm.py:130) -> optional EMA (reference callbacks/ema.py:169-176;
- * ema may be NULL).  `step` is 1-based; grad_norm is the device scalar of dmme_grad_norm. */
+ * ema may be NULL).  `step` is 1-based; grad_norm is the device scalar of dmme_grad_norm.
+ * grad_scale multiplies the gradient (and its norm) first: 1 / world when the exchange left rank SUMS in the buffer, else 1. */
 DMME_API int dmme_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema, int64_t numel,
-                   float lr, float beta1, float beta2, float eps, int step, const float* grad_norm, float max_norm,
-                   float ema_decay, void* stream);
+                            float lr, float beta1, float beta2, float eps, int step, const float* grad_norm, float max_norm,
+                            float ema_decay, float grad_scale, void* stream);
+/* ---- data-parallel gradient exchange with bf16 on the wire (the reference relies on Lightning DDP for this step:
+ * configs/ddpm/cifar10.yaml:28,51,62 `devices`, `strategy`, `replace_sampler_ddp`; NCCL's fp32 ring all-reduce there).  One bucket =
+ * pack (fp32 -> bf16, zero padded to world * per_rank) -> all-to-all of the per-rank shards (torch.distributed / RCCL) ->
+ * shard_reduce (fp32 accumulation in rank order, x scale = 1 / world, ONE rounding) -> all-gather of the bf16 means -> unpack into
+ * the fp32 gradient buffer: every rank ends with identical bits; each GPU sends and receives 2 x numel / world x 2 bytes per peer. */
+DMME_API int dmme_grad_pack_bf16(const float* grad, int64_t numel, void* dst_bf16, int64_t numel_padded, void* stream);
+DMME_API int dmme_shard_reduce_bf16(const void* recv_bf16, int world, int64_t per_rank, float scale, void* out_bf16, void* stream);
+DMME_API int dmme_grad_unpack_bf16(const void* src_bf16, int64_t numel, float* grad, void* stream);
 
 /* Copy an intermediate activation (the output of module `name`, e.g. "down_layers.3",
  * "input_conv", "condition") out of the workspace as fp32 NCHW for parity tests.

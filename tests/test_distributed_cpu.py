@@ -49,13 +49,37 @@ def _worker(rank, world, path):
 
         m = FakeModel(full[rank].clone())
         red = D.OverlappedGradReducer(m, bucket_elems=256)
-        assert m._bucket_hook == red.bucket_ready
+        assert m._bucket_hook == red.bucket_ready and red.exchange == "fp32-allreduce"
         red.bucket_ready(600, 400)   # what dmme_unet_backward_buckets reports first
         red.bucket_ready(0, 600)
         assert red.finish() is True
-        assert torch.allclose(m.g, full.mean(0), atol=1e-6)
+        # the buffer holds rank SUMS: the mean's divide is folded into the fused clip + Adam pass (FusedAdam.grad_scale)
+        assert red.grad_scale() == 1.0 / world and torch.allclose(m.g * red.grad_scale(), full.mean(0), atol=1e-6)
         m.g.copy_(full[rank])        # a backward that reported nothing is reduced in one piece
-        assert red.finish() is True and torch.allclose(m.g, full.mean(0), atol=1e-6)
+        assert red.finish() is True and torch.allclose(m.g * red.grad_scale(), full.mean(0), atol=1e-6)
+        m.g.copy_(full[rank])        # a step WITHOUT exchange on a model that has a reducer: the hook is gone, nothing is pending
+        red.detach()
+        assert m._bucket_hook is None and not red.handles and not red.reported
+        red.attach()
+        assert m._bucket_hook == red.bucket_ready
+        m2 = FakeModel(full[rank].clone())  # the unfolded form divides before the all-reduce, as round 2 did
+        red2 = D.OverlappedGradReducer(m2, bucket_elems=256, fold_mean=False)
+        red2.bucket_ready(0, 1000)
+        assert red2.finish() is True and red2.grad_scale() == 1.0 and torch.allclose(m2.g, full.mean(0), atol=1e-6)
+        # bf16 on the wire, fp32 accumulation at the shard owner, identical bits on every rank (Bf16ShardExchange)
+        m3 = FakeModel(full[rank].clone())
+        red3 = D.make_reducer(m3, "bf16-rs-ag")
+        red3.bucket_elems = 301      # sub-buckets that do not divide by the world size: padding path; >= 4 exchanges per step
+        assert red3.exchange == "bf16-rs-ag" and len(D.bucket_slices(1000, red3.bucket_elems)) >= 4
+        red3.bucket_ready(600, 400)
+        red3.bucket_ready(0, 600)
+        assert red3.finish() is True and red3.grad_scale() == 1.0
+        want = (full.to(torch.bfloat16).to(torch.float32).sum(0) / world).to(torch.bfloat16).to(torch.float32)
+        assert torch.equal(m3.g, want), float((m3.g - want).abs().max())          # exactly: rounded contributions, fp32 sum, one rounding
+        assert float((m3.g - full.mean(0)).abs().max()) <= 2.0 ** -7 * float(full.abs().max())  # and within bf16 rounding of the fp32 mean
+        allg = [torch.empty(1000) for _ in range(world)]
+        dist.all_gather(allg, m3.g)
+        assert all(torch.equal(a, allg[0]) for a in allg)                      # rank-identical: clip / Adam / EMA need no further exchange
         m.g.copy_(full[rank])
         red.bucket_ready(600, 400)   # a partial report is an error, not a silent half-reduction
         try:
@@ -127,9 +151,22 @@ def _worker(rank, world, path):
         sgd = torch.optim.SGD(tm.parameters(), lr=0.1)
         x0 = torch.arange(4.0) + rank
         train_step(Lit(tm), sgd, None, x0)
-        ref = torch.ones(4, requires_grad=True)  # what a single process computes on the mean of the two per-rank losses
+        ref = torch.ones(4, requires_grad=True)  # what a single process computes on the mean of the per-rank losses
         (sum(((ref * (torch.arange(4.0) + r)).sum()) ** 2 for r in range(world)) / world).backward()
         assert torch.allclose(tm.p.data, torch.ones(4) - 0.1 * ref.grad, atol=1e-6), (tm.p.data, ref.grad)
+        # reduce=False on a model that already has a reducer: its backward must not reach the reducer at all
+        assert tm._grad_reducer is not None and tm._bucket_hook is not None
+        before = tm.p.data.clone()
+        train_step(Lit(tm), sgd, None, x0, reduce=False)
+        assert tm._bucket_hook is None and not tm._grad_reducer.handles and not tm._grad_reducer.reported
+        loc = before.clone().requires_grad_(True)
+        (((loc * x0).sum()) ** 2).backward()
+        assert torch.allclose(tm.p.data, before - 0.1 * loc.grad, atol=1e-5)   # a purely local step
+        # ... and the next exchanged step reinstalls the hook; here with the bf16 wire format
+        tm.p.data.copy_(torch.ones(4))
+        train_step(Lit(tm), sgd, None, x0, exchange="bf16-rs-ag")
+        assert tm._bucket_hook is not None and tm._grad_reducer.exchange == "bf16-rs-ag"
+        assert torch.allclose(tm.p.data, torch.ones(4) - 0.1 * ref.grad, rtol=2.0 ** -7, atol=1e-3), (tm.p.data, ref.grad)
     finally:
         dist.destroy_process_group()
 
@@ -137,3 +174,9 @@ def _worker(rank, world, path):
 def test_two_rank_gloo():
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(2, os.path.join(d, "rdv")), nprocs=2, join=True)
+
+
+def test_four_rank_gloo():
+    """the same exchanges at world size 4 (shard owners 0..3, sub-buckets that do not divide by 4)"""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(4, os.path.join(d, "rdv")), nprocs=4, join=True)

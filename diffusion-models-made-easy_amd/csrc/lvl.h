@@ -34,7 +34,7 @@ struct LvlNorm {
 struct LvlOp {
     int kind;                 // LVL_CONV / LVL_NORM / LVL_ATTN
     int taps;                 // 9 or 1
-    int C1, C2;               // channels of the A operand's sources (C2 = 0: one source); multiples of 64
+    int C1, C2;               // channels of the A operand's sources (C2 = 0: one source); C1 + C2 a multiple of 256, C1 of 64
     int64_t a1_off, a2_off;   // bytes into the workspace: T [N][HW][C1], [N][HW][C2]
     int wait0, wait1;         // flag rows (op indices * 2 + which) that cover the sources; -1: complete before the launch
     int reuse_a;              // the A image of the previous op is this op's too (q / k / v share the normalised input)
@@ -63,9 +63,11 @@ struct LvlArgs {
     const float* tproj;       // [nt][tproj_ld]
     int tproj_ld, nt;
     int N, sh;                // batch; log2 of the map's width (= height): 2 or 3
-    int NG, NGS;              // pixel groups; groups resident at once (grid = NGS * LVL_NS)
+    int NG, NGS, GB;          // pixel groups; groups per op iteration of a workgroup (1 / 2); iterations resident at once (grid = NGS * LVL_NS)
     unsigned* flags;          // [n_ops * 2][NG][LVL_NS]
     unsigned* ctl;            // [0] epoch of the last completed launch, [1] workgroups of this launch that are done, [2] error word
+    long long* stamps;        // diagnostic (null: off): 100 MHz wall-clock stamps of workgroup `stamp_wg`, [op iteration][8] (dmme_debug_set_stamps)
+    int stamp_wg;
 };
 
 int launch_lvl_engine(int dtype, const LvlArgs& a, hipStream_t s);

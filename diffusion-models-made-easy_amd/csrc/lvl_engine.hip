@@ -32,20 +32,20 @@
 
 namespace dmme {
 
-constexpr int LVL_RING = 4;                                            // filter units (32 couts x 128 B = 4 KB) per wave ring
-constexpr int LVL_D = LVL_RING - 1;                                    // units requested ahead of the one being consumed
-constexpr int LVL_NPI = LVL_BN / 8;                                    // DMA wave-instructions per unit
-constexpr int LVL_ZROW = 2 * LVL_BM;                                   // LDS row of zeros (out-of-image taps read it)
-constexpr int LVL_A_BYTES = (2 * LVL_BM + 8) * ROW_DATA;               // two 64-channel chunks of the group's pixels + zeros
+constexpr int LVL_NPI = LVL_BN / 8;                                    // DMA wave-instructions per filter unit (32 couts x 128 B = 4 KB)
 constexpr int LVL_U_BYTES = LVL_BN * ROW_DATA;
-constexpr int LVL_WAVE_BYTES = LVL_A_BYTES + LVL_RING * LVL_U_BYTES;
+// One workgroup handles GB pixel groups per op iteration (GB = 2 when a workgroup owns several groups: the filter stream is then shared
+// by twice the matrix work and every fixed cost of an iteration is paid half as often).  Per wave: the A image - GB groups x ONE
+// 64-channel chunk (the K loop runs in passes of 256 channels, wave w takes chunk 4 p + w of pass p) + 8 rows of zeros - and the
+// filter ring; both variants use the same 33 KB: GB = 1 -> 9 KB + 6 slots, GB = 2 -> 17 KB + 4 slots.
+constexpr int LVL_WAVE_BYTES = (2 * LVL_BM + 8) * ROW_DATA + 4 * LVL_U_BYTES;  // 33792
 constexpr int LVL_KEEP_OFF = 4 * LVL_WAVE_BYTES;                       // q / k / v slices of the attention block: [3][64 px][32 ch] T
 constexpr int LVL_KEEP_BYTES = 3 * LVL_BM * LVL_BN * 2;
-constexpr int LVL_BLK_OFF = LVL_KEEP_OFF + LVL_KEEP_BYTES;             // statistics exchange: [4 pixel blocks][4 vectors][2]
-constexpr int LVL_LDS = LVL_BLK_OFF + 512;
+constexpr int LVL_BLK_OFF = LVL_KEEP_OFF + LVL_KEEP_BYTES;             // statistics exchange: [GB][4 pixel blocks][4 vectors][2]
+constexpr int LVL_LDS = LVL_BLK_OFF + 1024;
 constexpr int LVL_SPIN_LIMIT = 1 << 19;                                // polls before a wait gives up (~a second)
 static_assert(LVL_LDS <= 160 * 1024, "level engine: LDS budget");
-static_assert(LVL_D * LVL_NPI < 64, "vmcnt is a 6-bit counter");
+static_assert((LVL_BM + 8) * ROW_DATA + 6 * LVL_U_BYTES <= LVL_WAVE_BYTES, "level engine: GB = 1 layout");
 
 size_t lvl_engine_lds_bytes() { return LVL_LDS; }
 
@@ -130,25 +130,64 @@ __device__ __forceinline__ void lvl_wait_row(const unsigned* f, unsigned epoch, 
 // (callers put a compiler barrier behind the wait: nothing orders later loads behind a relaxed atomic load for the compiler)
 __device__ __forceinline__ void lvl_compiler_fence() { asm volatile("" ::: "memory"); }
 
-template <typename T>
+// (mean, M2) of equal-count sets merged over the 16 pixels a wave holds of one channel vector (lanes 4 apart): DPP row rotations
+// by 4 and by 8 (each lane meets the lanes that share lane & 3 in its 16-lane row, in disjoint pairs), then the row and half-wave
+// swaps.  Chan's formula for equal counts: mean = (a + b) / 2, M2 = M2a + M2b + (a - b)^2 n / 2.  (ds_bpermute shuffles cost an LDS
+// round trip per step: eight dependent ones per epilogue.)
+__device__ __forceinline__ void lvl_merge_pair(float& mean, float& m2, float om, float o2, float cnt) {
+    const float d = om - mean;
+    m2 += o2 + d * d * (0.5f * cnt);
+    mean = 0.5f * (mean + om);
+}
+__device__ __forceinline__ void lvl_merge16(float& mean, float& m2) {
+    lvl_merge_pair(mean, m2, DMME_DPP_F(mean, 0x124), DMME_DPP_F(m2, 0x124), 8.f);   // row_ror:4
+    lvl_merge_pair(mean, m2, DMME_DPP_F(mean, 0x128), DMME_DPP_F(m2, 0x128), 16.f);  // row_ror:8
+    {
+        float a = mean, b = mean, a2 = m2, b2 = m2;
+        permlane16_swap(a, b);  // a: the even row's value in both rows of a pair, b: the odd row's
+        permlane16_swap(a2, b2);
+        mean = a;
+        m2 = a2;
+        lvl_merge_pair(mean, m2, b, b2, 32.f);
+    }
+    {
+        float a = mean, b = mean, a2 = m2, b2 = m2;
+        permlane32_swap(a, b);  // a: the lower half-wave's value everywhere, b: the upper's
+        permlane32_swap(a2, b2);
+        mean = a;
+        m2 = a2;
+        lvl_merge_pair(mean, m2, b, b2, 64.f);
+    }
+}
+
+template <typename T, int GB>
 __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const LvlOp* __restrict__ ops) {
+    constexpr int RING = GB == 1 ? 6 : 4;          // filter units per wave ring
+    constexpr int D = RING - 1;                    // units requested ahead of the one being consumed
+    constexpr int MI = 2 * GB;                     // 32-pixel row blocks per iteration
+    constexpr int ZROW = GB * LVL_BM;              // LDS row of zeros (out-of-image taps read it)
+    constexpr int A_BYTES = (GB * LVL_BM + 8) * ROW_DATA;
+    static_assert(D * LVL_NPI < 64, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int s = (int)blockIdx.x % LVL_NS, g0 = (int)blockIdx.x / LVL_NS;
+    const int s = (int)blockIdx.x % LVL_NS, b0 = (int)blockIdx.x / LVL_NS;
     char* ldsA = lds + wave * LVL_WAVE_BYTES;
-    char* ldsR = ldsA + LVL_A_BYTES;
+    char* ldsR = ldsA + A_BYTES;
     T* keep = reinterpret_cast<T*>(lds + LVL_KEEP_OFF);
     float* blk = reinterpret_cast<float*>(lds + LVL_BLK_OFF);
     const unsigned epoch = lvl_flag_load(&A.ctl[0]) + 1u;  // (the counter moves only after EVERY workgroup of a launch has finished)
     unsigned* const err = &A.ctl[2];
-
+    {   // the op table is read through the scalar cache, one op at a time: bring its lines into L2 now (a cold miss is ~1 us per op)
+        const int n_lines = (A.n_ops * (int)sizeof(LvlOp) + 63) / 64;
+        if (tid < n_lines) asm volatile("" ::"v"(reinterpret_cast<const volatile int*>(ops)[tid * 16]));
+    }
     const int sh = A.sh, sh2 = 2 * sh, HW = 1 << sh2, mW = (1 << sh) - 1;
     const int npix = A.N * HW;
-    if (lane < 64) *reinterpret_cast<uint4*>(ldsA + LVL_ZROW * ROW_DATA + lane * 16) = make_uint4(0u, 0u, 0u, 0u);  // 8 rows of zeros
+    *reinterpret_cast<uint4*>(ldsA + ZROW * ROW_DATA + lane * 16) = make_uint4(0u, 0u, 0u, 0u);  // 8 rows of zeros
 
-    // ---- per-lane fragment geometry (fixed for the launch): MFMA row r of pixel block mi is pixel mi * 32 + r of the group ----
-    unsigned a_valid[2];  // bit t: tap t of this lane's pixel lies inside its image
+    // ---- per-lane fragment geometry (fixed for the launch): MFMA row r of pixel block mi is pixel mi * 32 + r of the iteration ----
+    unsigned a_valid[2];  // bit t: tap t of this lane's pixel lies inside its image (the same for every group: groups are whole images)
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         const int m = mi * 32 + r, tx = m & mW, ty = (m >> sh) & mW;
@@ -165,7 +204,7 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
     const lds_c* ldsA3 = (const lds_c*)ldsA;
     const unsigned ring_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lds_c*)ldsR);
 
-    // ---- filter stream state of this wave (conv_kw.hip's ring discipline; the stream of an op may start before the op does) ----
+    // ---- filter stream state of this wave (conv_kw.hip's ring discipline; the stream of an op starts before the op does) ----
     unsigned boff[LVL_NPI];
     const char* dptr = nullptr;
     unsigned dslot = ring_base;
@@ -175,17 +214,16 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
 #pragma unroll
         for (int i = 0; i < LVL_NPI; ++i) glds16_hidden_s(dptr, boff[i], dslot + (unsigned)(i * 8 * ROW_DATA));
         dptr += d_cin2;
-        if (++dtap == d_taps) {
+        if (++dtap == d_taps) {  // next pass: the wave's chunk moves on by 4 chunks (256 channels), tap 0
             dtap = 0;
-            dptr += 128 - d_taps * d_cin2;
+            dptr += 512 - d_taps * d_cin2;
         }
-        dslot = dslot + LVL_U_BYTES == ring_base + LVL_RING * LVL_U_BYTES ? ring_base : dslot + LVL_U_BYTES;
+        dslot = dslot + LVL_U_BYTES == ring_base + RING * LVL_U_BYTES ? ring_base : dslot + LVL_U_BYTES;
         --d_left;
     };
-    // start the filter stream of conv op `o`: the first LVL_D units of this wave
+    // start the filter stream of conv op `o`: the first D units of this wave (pass-major, tap-minor; wave w owns chunk 4 p + w)
     auto prime = [&](const LvlOp& o) __attribute__((always_inline)) {
-        const int Cin = o.C1 + o.C2, U = (Cin >> 6) * o.taps;
-        const int u0 = U * wave / 4, nu = U * (wave + 1) / 4 - u0;
+        const int Cin = o.C1 + o.C2;
 #pragma unroll
         for (int i = 0; i < LVL_NPI; ++i) {
             const int row = 8 * i + (lane >> 3);
@@ -193,201 +231,242 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
         }
         d_taps = o.taps;
         d_cin2 = Cin * 2;
-        dtap = u0 % o.taps;
-        dptr = A.packed + o.w_off + ((int64_t)dtap * Cin + (u0 / o.taps) * 64) * 2;
+        dtap = 0;
+        dptr = A.packed + o.w_off + wave * 128;
         dslot = ring_base;
-        d_left = nu;
+        d_left = (Cin >> 8) * o.taps;
 #pragma unroll
-        for (int d = 0; d < LVL_D; ++d)
+        for (int d = 0; d < D; ++d)
             if (d_left > 0) dma_next();
         primed = true;
     };
 
+    int stamp_it = 0;
+#define LV_STAMP(K) do { if (A.stamps && (int)blockIdx.x == A.stamp_wg && tid == 0 && stamp_it < 120) A.stamps[stamp_it * 8 + (K)] = (long long)wall_clock64(); } while (0)
     // ------------------------------------------------------------------------------------------------------------------------
+    const int NB = (A.NG + GB - 1) / GB;  // iterations per op over all workgroups: batches of GB groups
     for (int oi = 0; oi < A.n_ops; ++oi) {
         const LvlOp& op = ops[oi];
-        for (int g = g0; g < A.NG; g += A.NGS) {
-            const int m = tid >> 2, vec = tid & 3;  // this thread's item of the 64 x 32 slice: pixel m, channels vec * 8 ..
-            const int gp = g * LVL_BM + m;          // pixel index in the NHWC tensors
-            const bool okp = gp < npix;
-            const int gpc = okp ? gp : 0;
-            const int n_img = gpc >> sh2;
+        for (int bt = b0; bt < NB; bt += A.NGS) {
+            const int m = tid >> 2, vec = tid & 3;  // this thread's item of each 64 x 32 slice: pixel m, channels vec * 8 ..
             const int co = LVL_BN * s + vec * 8;    // first of the thread's 8 channels among the op's 256
-            uint4 ovec = make_uint4(0u, 0u, 0u, 0u);  // the slice's values as stored (T)
+            int gpv[GB];                            // pixel index in the NHWC tensors per group (-1: past the batch)
+#pragma unroll
+            for (int j = 0; j < GB; ++j) {
+                const int g = bt * GB + j, gp = g * LVL_BM + m;
+                gpv[j] = (g < A.NG && gp < npix) ? gp : -1;
+            }
+            uint4 ovec[GB];  // the slices' values as stored (T)
             bool have_out = false;
+            LV_STAMP(0);
+            // gamma / beta of the norms this op finishes depend on nothing: requested first, used last
+            f32x4 gm[2][2], bt4[2][2];
+            if (op.kind != LVL_ATTN) {
+#pragma unroll
+                for (int kx = 0; kx < 2; ++kx) {
+                    if (kx >= op.n_norm) break;
+                    const LvlNorm& G = op.norm[kx];
+                    const float* gp_ = reinterpret_cast<const float*>(A.packed + G.gamma_off) + G.c_off + co;
+                    const float* bp_ = reinterpret_cast<const float*>(A.packed + G.beta_off) + G.c_off + co;
+                    gm[kx][0] = *reinterpret_cast<const f32x4*>(gp_);
+                    gm[kx][1] = *reinterpret_cast<const f32x4*>(gp_ + 4);
+                    bt4[kx][0] = *reinterpret_cast<const f32x4*>(bp_);
+                    bt4[kx][1] = *reinterpret_cast<const f32x4*>(bp_ + 4);
+                }
+            }
 
             if (op.kind == LVL_CONV) {
-                const int Cin = op.C1 + op.C2, taps = op.taps, U = (Cin >> 6) * taps;
-                const int u0 = U * wave / 4, nu = U * (wave + 1) / 4 - u0;
-                const int c_lo = u0 / taps;
+                const int Cin = op.C1 + op.C2, taps = op.taps, npass = Cin >> 8;
                 if (!primed) prime(op);
-                // ---- A operand: this wave's one or two 64-channel chunks of the group's 64 pixels, gathered after the hand-off ----
-                if (!op.reuse_a) {
-                    if (op.wait0 >= 0) lvl_wait_row(A.flags + ((int64_t)op.wait0 * A.NG + g) * LVL_NS, epoch, lane, err);
-                    if (op.wait1 >= 0) lvl_wait_row(A.flags + ((int64_t)op.wait1 * A.NG + g) * LVL_NS, epoch, lane, err);
-                    lvl_compiler_fence();
-                    const int c_hi = (u0 + nu - 1) / taps;
-                    for (int c = c_lo; c <= c_hi; ++c) {
-                        const bool second = c * 64 >= op.C1;
-                        const int Cs = second ? op.C2 : op.C1, cb = second ? c * 64 - op.C1 : c * 64;
-                        const lvl_rsrc rs = lvl_make_rsrc(A.ws + (second ? op.a2_off : op.a1_off), (unsigned)npix * (unsigned)Cs * 2u);
-                        uint4 v[8];
+                f32x16 acc[MI];
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const int row = 8 * i + (lane >> 3), p = g * LVL_BM + row;
-                            v[i] = lvl_ld(rs, (unsigned)((p < npix ? p : 0) * Cs + cb + ((lane & 7) ^ ((row >> 1) & 7)) * 8) * 2u);
-                        }
-#pragma unroll
-                        for (int i = 0; i < 8; ++i)
-                            *reinterpret_cast<uint4*>(ldsA + ((c - c_lo) * LVL_BM + 8 * i + (lane >> 3)) * ROW_DATA + (lane & 7) * 16) = v[i];
-                    }
-                }
-                // ---- main loop: units u0 .. u0 + nu - 1 of this wave, software-pipelined as in conv_kw.hip ----
-                f32x16 acc[2];
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int j = 0; j < 16; ++j) acc[mi][j] = 0.f;
-                uint4 af[2][4][2], bfr[2][4];
-#define LV_READ_FRAGS(SET, TAP, SLOT_ADDR, AOFF)                                                                                  \
+                uint4 af[2][4][MI], bfr[2][4];
+#define LV_READ_FRAGS(SET, TAP, SLOT_ADDR)                                                                                        \
     do {                                                                                                                           \
         const int t9_ = taps == 9 ? (TAP) : 4;                                                                                     \
         const int ty3_ = t9_ >= 6 ? 2 : t9_ >= 3 ? 1 : 0, tx3_ = t9_ - 3 * ty3_;                                                   \
-        const int tap_off_ = ((ty3_ - 1) << sh) + (tx3_ - 1) + (AOFF);                                                             \
-        int ta_[2];                                                                                                                \
-        _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) {                                                                         \
+        const int tap_off_ = ((ty3_ - 1) << sh) + (tx3_ - 1);                                                                      \
+        int ta_[MI];                                                                                                               \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                                        \
             int row_ = mi * 32 + r + tap_off_;                                                                                     \
-            if (!((a_valid[mi] >> t9_) & 1u)) row_ = LVL_ZROW;                                                                     \
+            if (!((a_valid[mi & 1] >> t9_) & 1u)) row_ = ZROW;                                                                     \
             ta_[mi] = row_ * ROW_DATA + ((h ^ ((row_ >> 1) & 7)) << 4);                                                            \
         }                                                                                                                          \
         const lds_c* rb_ = (const lds_c*)(size_t)(SLOT_ADDR);                                                                      \
         _Pragma("unroll") for (int kg = 0; kg < 4; ++kg) {                                                                         \
-            _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                                       \
+            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                                      \
                 af[SET][kg][mi] = __builtin_bit_cast(uint4, *reinterpret_cast<const lds_u32x4_lv*>(ldsA3 + (ta_[mi] ^ (kg << 5))));    \
             bfr[SET][kg] = __builtin_bit_cast(uint4, *reinterpret_cast<const lds_u32x4_lv*>(rb_ + tb[kg]));                            \
         }                                                                                                                          \
     } while (0)
-#define LV_MMA(CUR, KG)                                  \
-    do {                                                 \
-        mma16<T>(af[CUR][KG][0], bfr[CUR][KG], acc[0]);  \
-        mma16<T>(af[CUR][KG][1], bfr[CUR][KG], acc[1]);  \
+#define LV_MMA(CUR, KG)                                                                            \
+    do {                                                                                           \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) mma16<T>(af[CUR][KG][mi], bfr[CUR][KG], acc[mi]); \
     } while (0)
-                int chunk = c_lo, tap = u0 - c_lo * taps;
-                if (d_left > 0) {
-                    dma_next();
-                    wait_vm_keep<LVL_NPI>();  // unit 0 (and everything older: the gather) has landed; one unit may be in flight
-                } else {
-                    wait_vm_keep<0>();
-                }
-                LV_READ_FRAGS(0, tap, ring_base, 0);
-                unsigned rslot = ring_base + LVL_U_BYTES;
-                int k = 0;
+// one step = the MFMAs of unit k of the pass (fragment set CUR); the request for a later unit goes out under k-group 0, the fragments
+// of unit k + 1 (set NXT) are read under k-groups 1-3
 #define LV_STEP(CUR, NXT)                                                                                                          \
     do {                                                                                                                           \
-        const bool more_ = k + 1 < nu;                                                                                             \
-        int ntap_ = tap + 1, nchunk_ = chunk;                                                                                      \
-        if (ntap_ == taps) {                                                                                                       \
-            ntap_ = 0;                                                                                                             \
-            ++nchunk_;                                                                                                             \
-        }                                                                                                                          \
-        wait_lgkm_all(); /* set CUR is complete - and unit k's slot is free for unit k + RING */                                   \
+        const bool more_ = k + 1 < taps;                                                                                           \
+        wait_lgkm_all(); /* set CUR is complete - and its unit's slot is free for the unit RING further on */                      \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
         LV_MMA(CUR, 0);                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
-        const bool req_ = more_ && d_left > 0;                                                                                     \
+        const bool req_ = d_left > 0;                                                                                              \
         if (req_) dma_next();                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
         LV_MMA(CUR, 1);                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
         if (more_) {                                                                                                               \
             if (req_)                                                                                                              \
-                wait_vm_keep<LVL_D * LVL_NPI>(); /* unit k + 1 has landed; units k + 2 .. k + 1 + D may be in flight */            \
+                wait_vm_keep<D * LVL_NPI>(); /* the next unit has landed; the D units behind it may be in flight */                \
             else                                                                                                                   \
                 wait_vm_keep<0>();                                                                                                 \
-            LV_READ_FRAGS(NXT, ntap_, rslot, (nchunk_ - c_lo) * LVL_BM);                                                           \
+            LV_READ_FRAGS(NXT, k + 1, rslot);                                                                                      \
         }                                                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
         LV_MMA(CUR, 2);                                                                                                            \
         LV_MMA(CUR, 3);                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
-        tap = ntap_;                                                                                                               \
-        chunk = nchunk_;                                                                                                           \
-        rslot = rslot + LVL_U_BYTES == ring_base + LVL_RING * LVL_U_BYTES ? ring_base : rslot + LVL_U_BYTES;                       \
+        rslot = rslot + LVL_U_BYTES == ring_base + RING * LVL_U_BYTES ? ring_base : rslot + LVL_U_BYTES;                           \
         ++k;                                                                                                                       \
     } while (0)
+                unsigned rslot = ring_base;  // LDS address of the slot of the next unit whose fragments will be read
+                for (int p = 0; p < npass; ++p) {
+                    // ---- A operand of this pass: chunk 4 p + wave of the GB groups' 64 pixels each, gathered after the hand-off ----
+                    if (!op.reuse_a) {
+                        if (p == 0) {
+#pragma unroll
+                            for (int j = 0; j < GB; ++j) {
+                                const int g = bt * GB + j;
+                                if (g >= A.NG) break;
+                                if (op.wait0 >= 0) lvl_wait_row(A.flags + ((int64_t)op.wait0 * A.NG + g) * LVL_NS, epoch, lane, err);
+                                if (op.wait1 >= 0) lvl_wait_row(A.flags + ((int64_t)op.wait1 * A.NG + g) * LVL_NS, epoch, lane, err);
+                            }
+                            lvl_compiler_fence();
+                            LV_STAMP(1);
+                        }
+                        const int c = p * 4 + wave;
+                        const bool second = c * 64 >= op.C1;
+                        const int Cs = second ? op.C2 : op.C1, cb = second ? c * 64 - op.C1 : c * 64;
+                        const lvl_rsrc rs = lvl_make_rsrc(A.ws + (second ? op.a2_off : op.a1_off), (unsigned)npix * (unsigned)Cs * 2u);
+                        uint4 v[GB][8];
+#pragma unroll
+                        for (int j = 0; j < GB; ++j)
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const int row = 8 * i + (lane >> 3), px = (bt * GB + j) * LVL_BM + row;
+                                v[j][i] = lvl_ld(rs, (unsigned)((px < npix ? px : 0) * Cs + cb + ((lane & 7) ^ ((row >> 1) & 7)) * 8) * 2u);
+                            }
+#pragma unroll
+                        for (int j = 0; j < GB; ++j)
+#pragma unroll
+                            for (int i = 0; i < 8; ++i)
+                                *reinterpret_cast<uint4*>(ldsA + (j * LVL_BM + 8 * i + (lane >> 3)) * ROW_DATA + (lane & 7) * 16) = v[j][i];
+                    }
+                    if (p == 0 && d_left > 0) {
+                        dma_next();
+                        wait_vm_keep<LVL_NPI>();  // the pass's first unit (and everything older: the gather) has landed
+                    } else {
+                        wait_vm_keep<0>();
+                    }
+                    if (p == 0) LV_STAMP(2);
+                    LV_READ_FRAGS(0, 0, rslot);
+                    rslot = rslot + LVL_U_BYTES == ring_base + RING * LVL_U_BYTES ? ring_base : rslot + LVL_U_BYTES;
+                    int k = 0;
 #pragma unroll 1
-                while (k + 1 < nu) {
-                    LV_STEP(0, 1);
-                    LV_STEP(1, 0);
+                    while (k + 1 < taps) {
+                        LV_STEP(0, 1);
+                        LV_STEP(1, 0);
+                    }
+                    if (k < taps) LV_STEP(0, 1);
                 }
-                if (k < nu) LV_STEP(0, 1);
 #undef LV_STEP
 #undef LV_MMA
 #undef LV_READ_FRAGS
                 primed = false;
-                // ---- partial tile of this wave -> its own ring (every unit has been consumed; the next stream starts after the epilogue;
-                // the A image stays intact for an op that shares it) ----
+                LV_STAMP(3);
+                // ---- partial tiles of this wave -> its own ring (every unit has been consumed; the next stream starts after the
+                // epilogue; the A image stays intact for an op that shares it) ----
                 float* redw = reinterpret_cast<float*>(ldsR);
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int j = 0; j < 16; ++j) redw[(mi * 16 + j) * 64 + lane] = acc[mi][j];
-                // what the item needs besides the sums goes out before the barrier: residual, bias, time row
-                uint4 resv = make_uint4(0u, 0u, 0u, 0u);
-                if (op.res_off >= 0) {
-                    const lvl_rsrc rr = lvl_make_rsrc(A.ws + op.res_off, (unsigned)npix * (unsigned)op.res_C * 2u);
-                    resv = lvl_ld(rr, (unsigned)(gpc * op.res_C + op.res_c0 + co) * 2u);
-                }
+                // what the items need besides the sums goes out before the barrier: residual, bias, time row
+                uint4 resv[GB];
                 const float* bp = reinterpret_cast<const float*>(A.packed + op.b_off) + op.w_row0 + co;
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
-                float fold[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-                if (op.tproj_col >= 0) {
-                    const float* tp = A.tproj + (int64_t)(A.nt == 1 ? 0 : n_img) * A.tproj_ld + op.tproj_col + co;
-                    const f32x4 t0 = *reinterpret_cast<const f32x4*>(tp), t1 = *reinterpret_cast<const f32x4*>(tp + 4);
+                const f32x4 b0v = *reinterpret_cast<const f32x4*>(bp), b1v = *reinterpret_cast<const f32x4*>(bp + 4);
+                float fold[GB][8];
+#pragma unroll
+                for (int j = 0; j < GB; ++j) {
+                    const int gpc = gpv[j] < 0 ? 0 : gpv[j];
+                    resv[j] = make_uint4(0u, 0u, 0u, 0u);
+                    if (op.res_off >= 0) {
+                        const lvl_rsrc rr = lvl_make_rsrc(A.ws + op.res_off, (unsigned)npix * (unsigned)op.res_C * 2u);
+                        resv[j] = lvl_ld(rr, (unsigned)(gpc * op.res_C + op.res_c0 + co) * 2u);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        fold[e] += t0[e];
-                        fold[4 + e] += t1[e];
+                        fold[j][e] = b0v[e];
+                        fold[j][4 + e] = b1v[e];
+                    }
+                    if (op.tproj_col >= 0) {
+                        const float* tp = A.tproj + (int64_t)(A.nt == 1 ? 0 : gpc >> sh2) * A.tproj_ld + op.tproj_col + co;
+                        const f32x4 t0 = *reinterpret_cast<const f32x4*>(tp), t1 = *reinterpret_cast<const f32x4*>(tp + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            fold[j][e] += t0[e];
+                            fold[j][4 + e] += t1[e];
+                        }
                     }
                 }
                 __syncthreads();
                 // acc layout of a 32 x 32 tile: lane = cout column + 32 * (pixel row bit 2), register j = pixel rows (j & 3) + 8 * (j >> 2)
                 const int pr = m & 31, jj = (pr & 3) + 4 * (pr >> 3), hh = (pr >> 2) & 1;
-                float v[8];
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const float* q = reinterpret_cast<const float*>(lds + w * LVL_WAVE_BYTES + LVL_A_BYTES) + ((m >> 5) * 16 + jj) * 64 + hh * 32 + vec * 8;
-                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(q), x1 = *reinterpret_cast<const f32x4*>(q + 4);
+                for (int j = 0; j < GB; ++j) {
+                    float v[8];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = w == 0 ? x0[e] : v[e] + x0[e];
-                        v[4 + e] = w == 0 ? x1[e] : v[4 + e] + x1[e];
+                    for (int w = 0; w < 4; ++w) {
+                        const float* q = reinterpret_cast<const float*>(lds + w * LVL_WAVE_BYTES + A_BYTES) + ((2 * j + (m >> 5)) * 16 + jj) * 64 + hh * 32 + vec * 8;
+                        const f32x4 x0 = *reinterpret_cast<const f32x4*>(q), x1 = *reinterpret_cast<const f32x4*>(q + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = w == 0 ? x0[e] : v[e] + x0[e];
+                            v[4 + e] = w == 0 ? x1[e] : v[4 + e] + x1[e];
+                        }
                     }
-                }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += fold[e];
-                if (op.res_off >= 0) {
-                    float rv[8];
-                    unpack8<T>(resv, rv);
+                    for (int e = 0; e < 8; ++e) v[e] += fold[j][e];
+                    if (op.res_off >= 0) {
+                        float rv[8];
+                        unpack8<T>(resv[j], rv);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += rv[e];
+                        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+                    }
+                    ovec[j] = pack8<T>(v);
+                    if (op.dst_off >= 0 && gpv[j] >= 0) {
+                        const lvl_rsrc rd = lvl_make_rsrc(A.ws + op.dst_off, (unsigned)npix * (unsigned)op.dst_C * 2u);
+                        lvl_st(rd, (unsigned)(gpv[j] * op.dst_C + op.dst_c0 + co) * 2u, ovec[j]);
+                    }
+                    if (GB == 1 && op.keep >= 0) *reinterpret_cast<uint4*>(keep + (op.keep * LVL_BM + m) * LVL_BN + vec * 8) = ovec[j];
                 }
-                ovec = pack8<T>(v);
                 have_out = true;
-                if (op.dst_off >= 0 && okp) {
-                    const lvl_rsrc rd = lvl_make_rsrc(A.ws + op.dst_off, (unsigned)npix * (unsigned)op.dst_C * 2u);
-                    lvl_st(rd, (unsigned)(gp * op.dst_C + op.dst_c0 + co) * 2u, ovec);
-                }
-                if (op.keep >= 0) *reinterpret_cast<uint4*>(keep + (op.keep * LVL_BM + m) * LVL_BN + vec * 8) = ovec;
             } else if (op.kind == LVL_NORM) {
                 // a tensor written before this launch (stride-2 / upsampling conv output): its slice is only normalised here
                 const T* src = reinterpret_cast<const T*>(A.ws + op.dst_off);
-                ovec = *reinterpret_cast<const uint4*>(src + (int64_t)gpc * op.dst_C + op.dst_c0 + co);
+#pragma unroll
+                for (int j = 0; j < GB; ++j) ovec[j] = *reinterpret_cast<const uint4*>(src + (int64_t)(gpv[j] < 0 ? 0 : gpv[j]) * op.dst_C + op.dst_c0 + co);
                 have_out = true;
-            } else {
+            } else if (GB == 1) {
                 // ---- single-head attention over the 16 pixels of each 4x4 image (models/ddpm.py:54-63): this workgroup holds channels
                 // [32 s, 32 s + 32) of q, k, v of its 4 images (keep slots 0 / 1 / 2).  Partial scores over those channels -> exchange ->
                 // full scores, softmax, P (rounded to T as attn_s16_kernel does) x this slice of v.
+                const int g = bt;
                 const int i_img = tid >> 6, qa = (tid >> 2) & 15, bq = tid & 3;
                 float ps[4] = {0.f, 0.f, 0.f, 0.f};
                 {
@@ -432,16 +511,16 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
                     sc4[3] += __uint_as_float(part[w].w);
                 }
                 float mx = fmaxf(fmaxf(sc4[0], sc4[1]), fmaxf(sc4[2], sc4[3]));  // a query's 16 keys: this lane's 4 and its quad's
-                mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+                mx = fmaxf(mx, DMME_DPP_F(mx, 0xB1));  // quad_perm [1,0,3,2]
+                mx = fmaxf(mx, DMME_DPP_F(mx, 0x4E));  // quad_perm [2,3,0,1]
                 float ex[4], tot = 0.f;
 #pragma unroll
                 for (int bb = 0; bb < 4; ++bb) {
                     ex[bb] = expf(sc4[bb] - mx);
                     tot += ex[bb];
                 }
-                tot += __shfl_xor(tot, 1, 64);
-                tot += __shfl_xor(tot, 2, 64);
+                tot += DMME_DPP_F(tot, 0xB1);
+                tot += DMME_DPP_F(tot, 0x4E);
                 const float inv = 1.0f / tot;
                 float* Pm = reinterpret_cast<float*>(lds);  // [4 images][16][16]; the A regions are idle during this op
                 *reinterpret_cast<f32x4*>(Pm + tid * 4) = f32x4{to_f(from_f<T>(ex[0] * inv)), to_f(from_f<T>(ex[1] * inv)), to_f(from_f<T>(ex[2] * inv)),
@@ -461,134 +540,122 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
                         for (int e = 0; e < 8; ++e) ov[e] = fmaf(p4[bb], vv[e], ov[e]);
                     }
                 }
-                if (okp) {
+                if (gpv[0] >= 0) {
                     const lvl_rsrc rd = lvl_make_rsrc(A.ws + op.dst_off, (unsigned)npix * (unsigned)op.dst_C * 2u);
-                    lvl_st(rd, (unsigned)(gp * op.dst_C + op.dst_c0 + co) * 2u, pack8<T>(ov));
+                    lvl_st(rd, (unsigned)(gpv[0] * op.dst_C + op.dst_c0 + co) * 2u, pack8<T>(ov));
                 }
             }
 
-            // ---- the GroupNorms that read this slice: statistics, rows, the consumers' pre-activated inputs ----
+            // ---- the GroupNorms that read these slices: statistics, rows, the consumers' pre-activated inputs ----
             if (have_out && op.n_norm > 0) {
-                float x[8];
-                unpack8<T>(ovec, x);  // statistics of the values the consumers read back (rounded to T)
-                // gamma / beta do not depend on the statistics: requested now
-                f32x4 gm[2][2], bt[2][2];
+                float x[GB][8];
 #pragma unroll
-                for (int kx = 0; kx < 2; ++kx) {
-                    if (kx >= op.n_norm) break;
-                    const LvlNorm& G = op.norm[kx];
-                    const float* gp_ = reinterpret_cast<const float*>(A.packed + G.gamma_off) + G.c_off + co;
-                    const float* bp_ = reinterpret_cast<const float*>(A.packed + G.beta_off) + G.c_off + co;
-                    gm[kx][0] = *reinterpret_cast<const f32x4*>(gp_);
-                    gm[kx][1] = *reinterpret_cast<const f32x4*>(gp_ + 4);
-                    bt[kx][0] = *reinterpret_cast<const f32x4*>(bp_);
-                    bt[kx][1] = *reinterpret_cast<const f32x4*>(bp_ + 4);
-                }
-                float sm = 0.f;
+                for (int j = 0; j < GB; ++j) {
+                    unpack8<T>(ovec[j], x[j]);  // statistics of the values the consumers read back (rounded to T)
+                    float sm = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) sm += x[e];
-                float mean = sm * 0.125f, m2 = 0.f;
+                    for (int e = 0; e < 8; ++e) sm += x[j][e];
+                    float mean = sm * 0.125f, m2 = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float d = x[e] - mean;
-                    m2 = fmaf(d, d, m2);
-                }
-                float cnt = 8.f;
-#pragma unroll
-                for (int o = 4; o < 64; o <<= 1) {  // lanes 4 apart: the same channel vector of the wave's 16 consecutive pixels
-                    const float om = __shfl_xor(mean, o, 64), o2 = __shfl_xor(m2, o, 64);
-                    const float d = om - mean;
-                    m2 += o2 + d * d * (0.5f * cnt);
-                    mean = 0.5f * (mean + om);
-                    cnt *= 2.f;
-                }
-                if (lane < 4) {
-                    blk[(wave * 4 + lane) * 2] = mean;
-                    blk[(wave * 4 + lane) * 2 + 1] = m2;
+                    for (int e = 0; e < 8; ++e) {
+                        const float d = x[j][e] - mean;
+                        m2 = fmaf(d, d, m2);
+                    }
+                    lvl_merge16(mean, m2);  // the wave's 16 consecutive pixels of this channel vector
+                    if (lane < 4) {
+                        blk[((j * 4 + wave) * 4 + lane) * 2] = mean;
+                        blk[((j * 4 + wave) * 4 + lane) * 2 + 1] = m2;
+                    }
                 }
                 __syncthreads();
                 const int nb = HW >> 4, b_first = ((m >> 4) / nb) * nb;  // pixel blocks (16 px) of this thread's image
 #pragma unroll
-                for (int kx = 0; kx < 2; ++kx) {
-                    if (kx >= op.n_norm) break;
-                    const LvlNorm& G = op.norm[kx];
-                    const int f = G.cg >> 3, v_first = (vec / f) * f;  // the group = f adjacent vectors of this slice
-                    float gna = 0.f, gmean = 0.f, gm2 = 0.f;
-                    for (int vv = 0; vv < f; ++vv) {
-                        float na = 0.f, vmean = 0.f, vm2 = 0.f;  // (image, vector): the image's blocks in pixel order
-                        for (int b = 0; b < nb; ++b) {
-                            const float* q = blk + ((b_first + b) * 4 + v_first + vv) * 2;
-                            const float delta = q[0] - vmean, totn = na + 128.f;
+                for (int j = 0; j < GB; ++j) {
+                    const int n_img = (gpv[j] < 0 ? 0 : gpv[j]) >> sh2;
+#pragma unroll
+                    for (int kx = 0; kx < 2; ++kx) {
+                        if (kx >= op.n_norm) break;
+                        const LvlNorm& G = op.norm[kx];
+                        const int f = G.cg >> 3, v_first = (vec / f) * f;  // the group = f adjacent vectors of this slice
+                        float gna = 0.f, gmean = 0.f, gm2 = 0.f;
+                        for (int vv = 0; vv < f; ++vv) {
+                            float na = 0.f, vmean = 0.f, vm2 = 0.f;  // (image, vector): the image's blocks in pixel order
+                            for (int b = 0; b < nb; ++b) {
+                                const float* q = blk + ((j * 4 + b_first + b) * 4 + v_first + vv) * 2;
+                                const float delta = q[0] - vmean, totn = na + 128.f;
+                                const float rt = __builtin_amdgcn_rcpf(totn);
+                                vmean += delta * (128.f * rt);
+                                vm2 += q[1] + delta * delta * (na * 128.f * rt);
+                                na = totn;
+                            }
+                            const float delta = vmean - gmean, totn = gna + na;  // (image, group): the group's vectors in channel order
                             const float rt = __builtin_amdgcn_rcpf(totn);
-                            vmean += delta * (128.f * rt);
-                            vm2 += q[1] + delta * delta * (na * 128.f * rt);
-                            na = totn;
+                            gmean += delta * (na * rt);
+                            gm2 += vm2 + delta * delta * (gna * na * rt);
+                            gna = totn;
                         }
-                        const float delta = vmean - gmean, totn = gna + na;  // (image, group): the group's vectors in channel order
-                        const float rt = __builtin_amdgcn_rcpf(totn);
-                        gmean += delta * (na * rt);
-                        gm2 += vm2 + delta * delta * (gna * na * rt);
-                        gna = totn;
-                    }
-                    const float rstd = 1.0f / sqrtf(gm2 / gna + 1e-5f);
-                    const int cn = G.c_off + co;
-                    float sc[8], shf[8];
+                        const float rstd = __builtin_amdgcn_rsqf(gm2 * __builtin_amdgcn_rcpf(gna) + 1e-5f);
+                        const int cn = G.c_off + co;
+                        float sc[8], shf[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        sc[e] = rstd * gm[kx][e >> 2][e & 3];
-                        shf[e] = bt[kx][e >> 2][e & 3] - gmean * sc[e];
-                    }
-                    if (okp && (m & (HW - 1)) == 0) {  // first pixel of an image: the rows the backward pass reads
-                        float* so = reinterpret_cast<float*>(A.ws + G.scale_off) + (int64_t)n_img * G.Cn + cn;
-                        float* ho = reinterpret_cast<float*>(A.ws + G.shift_off) + (int64_t)n_img * G.Cn + cn;
-                        *reinterpret_cast<f32x4*>(so) = f32x4{sc[0], sc[1], sc[2], sc[3]};
-                        *reinterpret_cast<f32x4*>(so + 4) = f32x4{sc[4], sc[5], sc[6], sc[7]};
-                        *reinterpret_cast<f32x4*>(ho) = f32x4{shf[0], shf[1], shf[2], shf[3]};
-                        *reinterpret_cast<f32x4*>(ho + 4) = f32x4{shf[4], shf[5], shf[6], shf[7]};
-                        if (vec % f == 0) {
-                            float* mo = reinterpret_cast<float*>(A.ws + G.mr_off) + ((int64_t)n_img * (G.Cn / G.cg) + cn / G.cg) * 2;
-                            mo[0] = gmean;
-                            mo[1] = rstd;
+                        for (int e = 0; e < 8; ++e) {
+                            sc[e] = rstd * gm[kx][e >> 2][e & 3];
+                            shf[e] = bt4[kx][e >> 2][e & 3] - gmean * sc[e];
                         }
-                    }
-                    if (G.act_off >= 0 && okp) {
-                        float y[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) y[e] = fmaf(x[e], sc[e], shf[e]);
-                        if (G.act_silu) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) y[e] = silu_fast(y[e]);
-                        }
-                        if (G.dmask_off >= 0 && A.drop_masks) {
-                            const float* dm = A.drop_masks + G.dmask_off + (int64_t)n_img * G.Cn + cn;
-                            const f32x4 d0 = *reinterpret_cast<const f32x4*>(dm), d1 = *reinterpret_cast<const f32x4*>(dm + 4);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                y[e] *= d0[e];
-                                y[4 + e] *= d1[e];
+                        if (gpv[j] >= 0 && (m & (HW - 1)) == 0) {  // first pixel of an image: the rows the backward pass reads
+                            float* so = reinterpret_cast<float*>(A.ws + G.scale_off) + (int64_t)n_img * G.Cn + cn;
+                            float* ho = reinterpret_cast<float*>(A.ws + G.shift_off) + (int64_t)n_img * G.Cn + cn;
+                            *reinterpret_cast<f32x4*>(so) = f32x4{sc[0], sc[1], sc[2], sc[3]};
+                            *reinterpret_cast<f32x4*>(so + 4) = f32x4{sc[4], sc[5], sc[6], sc[7]};
+                            *reinterpret_cast<f32x4*>(ho) = f32x4{shf[0], shf[1], shf[2], shf[3]};
+                            *reinterpret_cast<f32x4*>(ho + 4) = f32x4{shf[4], shf[5], shf[6], shf[7]};
+                            if (vec % f == 0) {
+                                float* mo = reinterpret_cast<float*>(A.ws + G.mr_off) + ((int64_t)n_img * (G.Cn / G.cg) + cn / G.cg) * 2;
+                                mo[0] = gmean;
+                                mo[1] = rstd;
                             }
                         }
-                        const lvl_rsrc ra = lvl_make_rsrc(A.ws + G.act_off, (unsigned)npix * (unsigned)G.Cn * 2u);
-                        lvl_st(ra, (unsigned)(gp * G.Cn + cn) * 2u, pack8<T>(y));
+                        if (G.act_off >= 0 && gpv[j] >= 0) {
+                            float y[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) y[e] = fmaf(x[j][e], sc[e], shf[e]);
+                            if (G.act_silu) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) y[e] = silu_fast(y[e]);
+                            }
+                            if (G.dmask_off >= 0 && A.drop_masks) {
+                                const float* dm = A.drop_masks + G.dmask_off + (int64_t)n_img * G.Cn + cn;
+                                const f32x4 d0 = *reinterpret_cast<const f32x4*>(dm), d1 = *reinterpret_cast<const f32x4*>(dm + 4);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    y[e] *= d0[e];
+                                    y[4 + e] *= d1[e];
+                                }
+                            }
+                            const lvl_rsrc ra = lvl_make_rsrc(A.ws + G.act_off, (unsigned)npix * (unsigned)G.Cn * 2u);
+                            lvl_st(ra, (unsigned)(gpv[j] * G.Cn + cn) * 2u, pack8<T>(y));
+                        }
                     }
                 }
             }
 
-            // ---- publish: every store of every wave acknowledged, then one flag word ----
+            // ---- publish: every store of every wave acknowledged, then one flag word per group ----
+            LV_STAMP(4);
             wait_vm_all();
             __syncthreads();
-            if (op.signal && tid == 0) lvl_flag_store(A.flags + ((int64_t)(oi * 2) * A.NG + g) * LVL_NS + s, epoch);
+            LV_STAMP(5);
+            if (op.signal && tid < GB && bt * GB + tid < A.NG) lvl_flag_store(A.flags + ((int64_t)(oi * 2) * A.NG + bt * GB + tid) * LVL_NS + s, epoch);
             // the filter stream of whatever conv comes next starts now, before the wait for its input
             {
-                int oj = oi, gj = g + A.NGS;
-                if (gj >= A.NG) {
-                    ++oj;
-                    gj = g0;
-                }
+                int oj = oi;
+                if (bt + A.NGS >= NB) ++oj;
                 if (oj < A.n_ops && ops[oj].kind == LVL_CONV) prime(ops[oj]);
             }
+            LV_STAMP(6);
+            ++stamp_it;
         }
     }
+#undef LV_STAMP
     if (tid == 0) {  // the last workgroup to finish closes the epoch
         const unsigned old = __hip_atomic_fetch_add(&A.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old == gridDim.x - 1) {
@@ -598,23 +665,24 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
     }
 }
 
-int launch_lvl_engine(int dtype, const LvlArgs& a, hipStream_t s) {
-    DMME_REQUIRE(dtype == DMME_BF16 || dtype == DMME_F16, DMME_ERR_UNSUPPORTED, "level engine: 16-bit operand types only");
-    DMME_REQUIRE(a.NGS >= 1 && a.NGS * LVL_NS <= LVL_MAX_WG && a.NG >= 1 && (a.sh == 2 || a.sh == 3), DMME_ERR_INVALID, "level engine: bad geometry");
-    static bool attr_done[2] = {false, false};
-    const int ti = dtype == DMME_F16 ? 1 : 0;
-    const void* fn = ti ? reinterpret_cast<const void*>(lvl_engine_kernel<f16>) : reinterpret_cast<const void*>(lvl_engine_kernel<bf16>);
-    if (!attr_done[ti]) {
-        DMME_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done[ti] = true;
+template <typename T, int GB>
+static int launch_lvl_inst(const LvlArgs& a, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lvl_engine_kernel<T, GB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
     }
-    const dim3 grid((unsigned)(a.NGS * LVL_NS));
-    if (ti)
-        hipLaunchKernelGGL(lvl_engine_kernel<f16>, grid, dim3(256), LVL_LDS, s, a, a.ops);
-    else
-        hipLaunchKernelGGL(lvl_engine_kernel<bf16>, grid, dim3(256), LVL_LDS, s, a, a.ops);
+    hipLaunchKernelGGL((lvl_engine_kernel<T, GB>), dim3((unsigned)(a.NGS * LVL_NS)), dim3(256), LVL_LDS, s, a, a.ops);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
+}
+
+int launch_lvl_engine(int dtype, const LvlArgs& a, hipStream_t s) {
+    DMME_REQUIRE(dtype == DMME_BF16 || dtype == DMME_F16, DMME_ERR_UNSUPPORTED, "level engine: 16-bit operand types only");
+    DMME_REQUIRE(a.NGS >= 1 && a.NGS * LVL_NS <= LVL_MAX_WG && a.NG >= 1 && (a.sh == 2 || a.sh == 3) && (a.GB == 1 || a.GB == 2), DMME_ERR_INVALID,
+                 "level engine: bad geometry");
+    if (dtype == DMME_F16) return a.GB == 2 ? launch_lvl_inst<f16, 2>(a, s) : launch_lvl_inst<f16, 1>(a, s);
+    return a.GB == 2 ? launch_lvl_inst<bf16, 2>(a, s) : launch_lvl_inst<bf16, 1>(a, s);
 }
 
 }  // namespace dmme

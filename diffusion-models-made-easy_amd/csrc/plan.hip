@@ -98,8 +98,9 @@ struct Op {
 // one persistent launch for a stretch of the op list on a 4x4 / 8x8 map (lvl.h)
 struct LvlRun {
     int op_first = 0, op_last = 0;  // plan ops [op_first, op_last]
-    int sh = 0, NG = 0, NGS = 0;
+    int sh = 0, NG = 0, NGS = 0, GB = 1;
     std::vector<LvlOp> ops;
+    std::vector<std::pair<int, int>> made;  // (tensor id, index of the op that produces / normalises it): later runs attach norms there
     LvlOp* ops_dev = nullptr;
     unsigned* sync_dev = nullptr;   // [16] control words (epoch, done, error), then the flag rows [n_ops * 2][NG][LVL_NS]
     double flops = 0, bytes = 0;
@@ -1013,12 +1014,19 @@ static int op_level(const dmme_plan* P, const Op& o) {  // the map width all ten
     return H;
 }
 
-static bool build_lvl_run(dmme_plan* P, int i0, int i1, int lvl_w, int64_t& ws, LvlRun& R, std::vector<std::pair<int, int64_t>>& gn_acts) {
+struct LvlXAttach {  // a norm of this run finished by an op of an EARLIER run (the producer of a skip tensor)
+    int run, op;
+    LvlNorm norm;
+};
+static bool build_lvl_run(dmme_plan* P, int i0, int i1, int lvl_w, int64_t& ws, LvlRun& R, std::vector<std::pair<int, int64_t>>& gn_acts,
+                          const std::unordered_map<int, std::pair<int, int>>& made, std::vector<LvlXAttach>& xattach) {
     const int B = P->B, G = P->cfg.num_groups, HW = lvl_w * lvl_w;
     const int64_t es = (int64_t)dtype_size(P->dtype);
     std::vector<LvlOp> pre, body;           // LVL_NORM ops of tensors written before the launch; the ops proper
     std::unordered_map<int, int> prod;      // tensor id -> index into `body` of the op that produces it in this run
     std::unordered_map<int, int> pre_of;    // tensor id -> index into `pre`
+    std::vector<int> xsrc;                  // tensors whose norms an earlier run's op finishes (complete before this launch)
+    auto is_x = [&](int t) { return std::find(xsrc.begin(), xsrc.end(), t) != xsrc.end(); };
     // flag rows are (final op index) * 2 + which; body indices are shifted by pre.size() at the end: encode body rows as 1000000 + ...
     auto row_of = [&](int tensor) -> int {
         auto it = prod.find(tensor);
@@ -1077,8 +1085,18 @@ static bool build_lvl_run(dmme_plan* P, int i0, int i1, int lvl_w, int64_t& ws, 
                 n.act_silu = cv.pro_silu;
                 LvlOp* host = nullptr;
                 auto it = prod.find(src);
+                auto mt = made.find(src);
                 if (it != prod.end()) {
                     host = &body[it->second];
+                } else if (mt != made.end() && pre_of.find(src) == pre_of.end()) {
+                    // produced by the engine in an earlier launch (a skip tensor of the down path): that op gets the norm, if it has room
+                    int used = P->lvl_runs[mt->second.first].ops[mt->second.second].n_norm;
+                    for (const LvlXAttach& xa : xattach) used += xa.run == mt->second.first && xa.op == mt->second.second;
+                    if (used >= 2) return false;
+                    xattach.push_back({mt->second.first, mt->second.second, n});
+                    xsrc.push_back(src);
+                    coff += P->tensors[src].C;
+                    continue;
                 } else {
                     auto jt = pre_of.find(src);
                     if (jt == pre_of.end()) {
@@ -1123,13 +1141,7 @@ static bool build_lvl_run(dmme_plan* P, int i0, int i1, int lvl_w, int64_t& ws, 
         const bool is_qkv = w.cout == 768 && oi + 1 < i1 && P->ops[oi + 1].kind == OP_ATTN && P->ops[oi + 1].at_qkv == o.dst;
         if ((w.cout != 256 && !is_qkv) || Cin % 64 || C1 % 64 || o.out_silu || o.res2 >= 0) return false;
         if (o.gn < 0 && (o.pro_silu || o.dmask_off >= 0)) return false;
-        {   // every wave's quarter of the (chunk, tap) units must touch at most two 64-channel chunks (its A region)
-            const int U = (Cin / 64) * o.taps;
-            for (int wv = 0; wv < 4; ++wv) {
-                const int u0 = U * wv / 4, nu = U * (wv + 1) / 4 - u0;
-                if (nu < 1 || (u0 + nu - 1) / o.taps - u0 / o.taps > 1) return false;
-            }
-        }
+        if (Cin % 256) return false;  // the K loop runs in passes of 256 channels: one 64-channel chunk per wave and pass
         LvlOp c = blank();
         c.taps = o.taps;
         if (o.gn >= 0) {  // the pre-activated input its norm's producers wrote
@@ -1148,7 +1160,7 @@ static bool build_lvl_run(dmme_plan* P, int i0, int i1, int lvl_w, int64_t& ws, 
         }
         c.wait0 = row_of(o.src1);
         c.wait1 = o.src2 >= 0 ? row_of(o.src2) : -1;
-        if (o.gn >= 0 && ((c.wait0 < 0) || (o.src2 >= 0 && c.wait1 < 0))) return false;  // (an act tensor always has a producer in the run)
+        if (o.gn >= 0 && ((c.wait0 < 0 && !is_x(o.src1)) || (o.src2 >= 0 && c.wait1 < 0 && !is_x(o.src2)))) return false;  // (an act tensor has a producer)
         c.w_off = w.packed_off;
         c.b_off = P->params[o.b].packed_off;
         c.dst_off = P->tensors[o.dst].off;
@@ -1185,6 +1197,9 @@ static bool build_lvl_run(dmme_plan* P, int i0, int i1, int lvl_w, int64_t& ws, 
             if (*wr >= 1000000) *wr = (*wr - 1000000) + shift * 2;
         R.ops.push_back(c);
     }
+    R.made.clear();
+    for (auto& kv : pre_of) R.made.push_back({kv.first, kv.second});
+    for (auto& kv : prod) R.made.push_back({kv.first, kv.second + shift});
     return !body.empty();
 }
 
@@ -1192,6 +1207,7 @@ void assign_levels(dmme_plan* P) {
     if (getenv("DMME_NO_LVL") || P->cfg.arch != DMME_ARCH_DDPM || P->x3 || (P->dtype != DMME_BF16 && P->dtype != DMME_F16)) return;
     const int mask = getenv("DMME_LVL_MASK") ? atoi(getenv("DMME_LVL_MASK")) : 12;  // bit 2: 4x4 maps, bit 3: 8x8 maps
     const int nO = (int)P->ops.size();
+    std::unordered_map<int, std::pair<int, int>> made;  // tensor id -> (run, op) of the engine op that holds its slices
     int i = 0;
     while (i < nO) {
         const int L = op_level(P, P->ops[i]);
@@ -1207,11 +1223,24 @@ void assign_levels(dmme_plan* P) {
             R.op_last = j - 1;
             R.sh = L == 4 ? 2 : 3;
             R.NG = (P->B * L * L + LVL_BM - 1) / LVL_BM;
-            R.NGS = R.NG < LVL_MAX_WG / LVL_NS ? R.NG : LVL_MAX_WG / LVL_NS;
             int64_t ws = P->ws_bytes;
             std::vector<std::pair<int, int64_t>> gn_acts;
-            if (build_lvl_run(P, i, j, L, ws, R, gn_acts)) {
+            std::vector<LvlXAttach> xattach;
+            if (build_lvl_run(P, i, j, L, ws, R, gn_acts, getenv("DMME_LVL_NO_XRUN") ? std::unordered_map<int, std::pair<int, int>>() : made, xattach)) {
                 P->ws_bytes = ws;
+                for (const LvlXAttach& xa : xattach) {
+                    LvlOp& host = P->lvl_runs[xa.run].ops[xa.op];
+                    host.norm[host.n_norm++] = xa.norm;
+                }
+                for (auto& mk : R.made) made[mk.first] = {(int)P->lvl_runs.size(), mk.second};
+                // two groups per op iteration where a workgroup owns several (the filter stream is shared by twice the matrix work);
+                // the attention block keeps q / k / v of ONE group in LDS
+                bool has_attn = false;
+                for (const LvlOp& lo : R.ops) has_attn = has_attn || lo.kind == LVL_ATTN;
+                const int slots = LVL_MAX_WG / LVL_NS;
+                R.GB = (R.NG > slots && !has_attn && !getenv("DMME_LVL_GB1")) ? 2 : 1;
+                const int nb = (R.NG + R.GB - 1) / R.GB;
+                R.NGS = nb < slots ? nb : slots;
                 const int ri = (int)P->lvl_runs.size();
                 for (int oi = i; oi < j; ++oi) {
                     Op& o = P->ops[oi];
@@ -1466,6 +1495,10 @@ int run_gn(const dmme_plan* P, const Op& o, const char* pk, char* ws, int nt, co
     return launch_gn_modulate(sc, sh, tsh, tsc, P->tproj_cols, nt, P->B, o.gn_mod_C, s);
 }
 
+// diagnostic: in-kernel stamps of one workgroup of one level run (dmme_debug_level_stamps)
+static long long* g_lvl_stamps = nullptr;
+static int g_lvl_stamp_run = -1, g_lvl_stamp_wg = 0;
+
 int run_level(const dmme_plan* P, const LvlRun& R, const char* pk, char* ws, int nt, const float* drop_masks, hipStream_t s) {
     DMME_REQUIRE(R.ops_dev && R.sync_dev, DMME_ERR_INVALID, "level engine: the plan was created without a device");
     LvlArgs a{};
@@ -1481,8 +1514,13 @@ int run_level(const dmme_plan* P, const LvlRun& R, const char* pk, char* ws, int
     a.sh = R.sh;
     a.NG = R.NG;
     a.NGS = R.NGS;
+    a.GB = R.GB;
     a.ctl = R.sync_dev;
     a.flags = R.sync_dev + 16;
+    if (g_lvl_stamps && g_lvl_stamp_run == (int)(&R - P->lvl_runs.data())) {
+        a.stamps = g_lvl_stamps;
+        a.stamp_wg = g_lvl_stamp_wg;
+    }
     return launch_lvl_engine(P->dtype, a, s);
 }
 
@@ -1899,8 +1937,8 @@ DMME_API int dmme_unet_plan_level_info(const dmme_plan* plan, char* buf, int cap
     for (const LvlRun& R : plan->lvl_runs) {
         unsigned ctl[3] = {0, 0, 0};
         if (R.sync_dev) DMME_CHECK_HIP(hipMemcpy(ctl, R.sync_dev, sizeof(ctl), hipMemcpyDeviceToHost));  // (synchronises with the device)
-        snprintf(tmp, sizeof(tmp), " [map=%dx%d plan_ops=%d-%d engine_ops=%d groups=%d resident=%d workgroups=%d epoch=%u err=%u]", 1 << R.sh, 1 << R.sh,
-                 R.op_first, R.op_last, (int)R.ops.size(), R.NG, R.NGS, R.NGS * LVL_NS, ctl[0], ctl[2]);
+        snprintf(tmp, sizeof(tmp), " [map=%dx%d plan_ops=%d-%d engine_ops=%d groups=%d per_iteration=%d workgroups=%d epoch=%u err=%u]", 1 << R.sh, 1 << R.sh,
+                 R.op_first, R.op_last, (int)R.ops.size(), R.NG, R.GB, R.NGS * LVL_NS, ctl[0], ctl[2]);
         out += tmp;
     }
     strncpy(buf, out.c_str(), (size_t)cap - 1);
@@ -2464,6 +2502,12 @@ DMME_API int dmme_debug_l2_stream(const void* buf, int64_t bytes, int iters, int
     return launch_l2_stream(buf, bytes, iters, mode, depth, blocks, (unsigned*)sink, (hipStream_t)stream);
 }
 
+DMME_API int dmme_debug_level_stamps(void* buf, int run, int workgroup) {
+    g_lvl_stamps = (long long*)buf;
+    g_lvl_stamp_run = run;
+    g_lvl_stamp_wg = workgroup;
+    return DMME_OK;
+}
 static long long* g_stamps = nullptr;
 DMME_API int dmme_debug_set_stamps(void* buf) {
     g_stamps = (long long*)buf;

@@ -132,7 +132,7 @@ DMME_API int dmme_unet_forward(const dmme_plan* plan, const void* packed, const 
 DMME_API int dmme_unet_plan_num_ops(const dmme_plan* plan);
 /* Level-engine launches of this plan (csrc/lvl_engine.hip: one persistent launch per stretch of layers on a 4x4 / 8x8 map, replacing
  * the per-layer launches of ResBlock / Attention there, models/ddpm.py:118-133, 38-75) as text: "runs=N [map=4x4 plan_ops=a-b
- * engine_ops=.. groups=.. resident=.. workgroups=.. epoch=.. err=..] ...".  err != 0: a bounded in-kernel wait timed out (results of
+ * engine_ops=.. groups=.. per_iteration=.. workgroups=.. epoch=.. err=..] ...".  err != 0: a bounded in-kernel wait timed out (results of
  * that launch are invalid).  Synchronises with the device (reads the control words). */
 DMME_API int dmme_unet_plan_level_info(const dmme_plan* plan, char* buf, int cap);
 DMME_API int dmme_unet_plan_op_info(const dmme_plan* plan, int index, char* label, int label_cap, double* flops,
@@ -177,6 +177,10 @@ DMME_API int dmme_unet_plan_bwd_summary(const dmme_plan* plan, char* buf, int ca
  * 288 = a 3x3 filter row of 256 input channels).  sink: `blocks` uint32 of scratch.  Measures what a CU can draw from L2. */
 /* diagnostic (tools/mfma_valu.py): do the MFMAs of one wave and the VALU work of another wave on the same SIMD overlap?  `blocks`
  * workgroups of 512 threads; mode bit 0: MFMA waves run, bit 1: VALU waves run, bit 2: MFMA accumulators in AccVGPRs.  sink: `blocks` floats. */
+/* diagnostic (tools/stamp_lvl.py): workgroup `workgroup` of level run `run` writes 100 MHz wall-clock stamps per op iteration into
+ * buf ([120][8] int64; NULL: off): 0 start, 1 hand-off seen, 2 input gathered + first filter unit landed, 3 main loop done,
+ * 4 epilogue done, 5 stores acknowledged + barrier, 6 flag stored and the next filter stream started. */
+DMME_API int dmme_debug_level_stamps(void* buf, int run, int workgroup);
 DMME_API int dmme_debug_mfma_valu(int mode, int iters, int blocks, void* sink, void* stream);
 DMME_API int dmme_debug_l2_stream(const void* buf, int64_t bytes, int iters, int mode, int depth, int blocks, void* sink, void* stream);
 /* global L2 norm of a flat fp32 gradient buffer (clip_grad_norm_; scratch: 1024 floats) */

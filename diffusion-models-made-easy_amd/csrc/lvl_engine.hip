@@ -178,9 +178,13 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
     float* blk = reinterpret_cast<float*>(lds + LVL_BLK_OFF);
     const unsigned epoch = lvl_flag_load(&A.ctl[0]) + 1u;  // (the counter moves only after EVERY workgroup of a launch has finished)
     unsigned* const err = &A.ctl[2];
-    {   // the op table is read through the scalar cache, one op at a time: bring its lines into L2 now (a cold miss is ~1 us per op)
+    {   // the op table is read through the scalar cache, one op at a time, and every first touch of a line is a round trip to L2 or
+        // beyond on the critical path of its op: touch every line now (independent scalar loads, one latency for all of them)
+        const int* w = reinterpret_cast<const int*>(ops);
         const int n_lines = (A.n_ops * (int)sizeof(LvlOp) + 63) / 64;
-        if (tid < n_lines) asm volatile("" ::"v"(reinterpret_cast<const volatile int*>(ops)[tid * 16]));
+        int sink = 0;
+        for (int i = 0; i < n_lines; ++i) sink += w[i * 16];
+        asm volatile("" ::"s"(sink));
     }
     const int sh = A.sh, sh2 = 2 * sh, HW = 1 << sh2, mW = (1 << sh) - 1;
     const int npix = A.N * HW;
@@ -205,10 +209,19 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
     const unsigned ring_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lds_c*)ldsR);
 
     // ---- filter stream state of this wave (conv_kw.hip's ring discipline; the stream of an op starts before the op does) ----
+    // REGU > 0: the first REGU units of an op bypass the ring - their filter fragments are loaded straight into registers when the stream
+    // starts (row r, the four 16-byte pieces of this lane's half of each k-group), so that a 256-channel 3x3 conv (9 units per wave)
+    // has ALL its units requested before it starts (a unit requested inside the main loop comes back after ~2 us: the weights come
+    // from beyond L2).  Measured and OFF (REGU = 0): the registers are loaded at the end of one loop iteration and read in the next,
+    // hipcc copies loop-carried registers at the back edge and therefore waits for the loads right where they are issued - 2.5 us
+    // per op instead of the 1.5 us the main loop would have saved (B = 1, 4x4 run: 152 -> 198 us).
+    constexpr int REGU = 0;
+    uint4 breg0[4], breg1[4], breg2[4];
     unsigned boff[LVL_NPI];
     const char* dptr = nullptr;
     unsigned dslot = ring_base;
-    int dtap = 0, d_taps = 9, d_cin2 = 0, d_left = 0;  // d_left: units of the current stream not yet requested
+    int dtap = 0, d_taps = 9, d_cin2 = 0, d_left = 0;  // d_left: ring units of the current stream not yet requested
+    int d_req = 0;                                       // ring units requested so far
     bool primed = false;
     auto dma_next = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -220,10 +233,29 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
         }
         dslot = dslot + LVL_U_BYTES == ring_base + RING * LVL_U_BYTES ? ring_base : dslot + LVL_U_BYTES;
         --d_left;
+        ++d_req;
     };
-    // start the filter stream of conv op `o`: the first D units of this wave (pass-major, tap-minor; wave w owns chunk 4 p + w)
+    // start the filter stream of conv op `o` (pass-major, tap-minor; wave w owns chunk 4 p + w): units 0 .. REGU-1 into registers,
+    // the next D units into the ring
     auto prime = [&](const LvlOp& o) __attribute__((always_inline)) {
-        const int Cin = o.C1 + o.C2;
+        const int Cin = o.C1 + o.C2, nu = (Cin >> 8) * o.taps;
+        const char* wbase = A.packed + o.w_off + wave * 128;
+        {
+            const char* rowp = wbase + (int64_t)((o.w_row0 + LVL_BN * s + r) * o.taps * Cin) * 2 + h * 16;
+#pragma unroll
+            for (int u = 0; u < REGU; ++u) {
+                if (u >= nu) break;
+                const int pu = u / o.taps, tu = u - pu * o.taps;
+                const char* q = rowp + pu * 512 + (int64_t)tu * Cin * 2;
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(q + kg * 32);
+                    if (u == 0) breg0[kg] = v;
+                    if (u == 1) breg1[kg] = v;
+                    if (u == 2) breg2[kg] = v;
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < LVL_NPI; ++i) {
             const int row = 8 * i + (lane >> 3);
@@ -231,10 +263,12 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
         }
         d_taps = o.taps;
         d_cin2 = Cin * 2;
-        dtap = 0;
-        dptr = A.packed + o.w_off + wave * 128;
+        const int p0 = REGU / o.taps;  // the first ring unit
+        dtap = REGU - p0 * o.taps;
+        dptr = wbase + p0 * 512 + (int64_t)dtap * Cin * 2;
         dslot = ring_base;
-        d_left = (Cin >> 8) * o.taps;
+        d_left = nu > REGU ? nu - REGU : 0;
+        d_req = 0;
 #pragma unroll
         for (int d = 0; d < D; ++d)
             if (d_left > 0) dma_next();
@@ -278,13 +312,43 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
             if (op.kind == LVL_CONV) {
                 const int Cin = op.C1 + op.C2, taps = op.taps, npass = Cin >> 8;
                 if (!primed) prime(op);
+                // what the items need besides the sums is requested NOW (residual, bias, time row: a round trip of 1-2 us that the main loop hides)
+                uint4 resv[GB];
+                const float* bp = reinterpret_cast<const float*>(A.packed + op.b_off) + op.w_row0 + co;
+                const f32x4 b0v = *reinterpret_cast<const f32x4*>(bp), b1v = *reinterpret_cast<const f32x4*>(bp + 4);
+                float fold[GB][8];
+#pragma unroll
+                for (int j = 0; j < GB; ++j) {
+                    const int gpc = gpv[j] < 0 ? 0 : gpv[j];
+                    resv[j] = make_uint4(0u, 0u, 0u, 0u);
+                    if (op.res_off >= 0) {
+                        const lvl_rsrc rr = lvl_make_rsrc(A.ws + op.res_off, (unsigned)npix * (unsigned)op.res_C * 2u);
+                        resv[j] = lvl_ld(rr, (unsigned)(gpc * op.res_C + op.res_c0 + co) * 2u);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        fold[j][e] = b0v[e];
+                        fold[j][4 + e] = b1v[e];
+                    }
+                    if (op.tproj_col >= 0) {
+                        const float* tp = A.tproj + (int64_t)(A.nt == 1 ? 0 : gpc >> sh2) * A.tproj_ld + op.tproj_col + co;
+                        const f32x4 t0 = *reinterpret_cast<const f32x4*>(tp), t1 = *reinterpret_cast<const f32x4*>(tp + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            fold[j][e] += t0[e];
+                            fold[j][4 + e] += t1[e];
+                        }
+                    }
+                }
                 f32x16 acc[MI];
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int j = 0; j < 16; ++j) acc[mi][j] = 0.f;
                 uint4 af[2][4][MI], bfr[2][4];
-#define LV_READ_FRAGS(SET, TAP, SLOT_ADDR)                                                                                        \
+/* fragments of unit KU (tap TAP of the current pass) into set SET: the input rows from the A image, the filter rows from the       \
+   registers (KU < REGU) or from the ring slot at `rslot`, which then moves on */                                                   \
+#define LV_READ_FRAGS(SET, TAP, KU)                                                                                               \
     do {                                                                                                                           \
         const int t9_ = taps == 9 ? (TAP) : 4;                                                                                     \
         const int ty3_ = t9_ >= 6 ? 2 : t9_ >= 3 ? 1 : 0, tx3_ = t9_ - 3 * ty3_;                                                   \
@@ -295,11 +359,31 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
             if (!((a_valid[mi & 1] >> t9_) & 1u)) row_ = ZROW;                                                                     \
             ta_[mi] = row_ * ROW_DATA + ((h ^ ((row_ >> 1) & 7)) << 4);                                                            \
         }                                                                                                                          \
-        const lds_c* rb_ = (const lds_c*)(size_t)(SLOT_ADDR);                                                                      \
-        _Pragma("unroll") for (int kg = 0; kg < 4; ++kg) {                                                                         \
+        _Pragma("unroll") for (int kg = 0; kg < 4; ++kg)                                                                           \
             _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                                      \
                 af[SET][kg][mi] = __builtin_bit_cast(uint4, *reinterpret_cast<const lds_u32x4_lv*>(ldsA3 + (ta_[mi] ^ (kg << 5))));    \
-            bfr[SET][kg] = __builtin_bit_cast(uint4, *reinterpret_cast<const lds_u32x4_lv*>(rb_ + tb[kg]));                            \
+        if ((KU) >= REGU) {                                                                                                        \
+            const lds_c* rb_ = (const lds_c*)(size_t)rslot;                                                                        \
+            _Pragma("unroll") for (int kg = 0; kg < 4; ++kg)                                                                       \
+                bfr[SET][kg] = __builtin_bit_cast(uint4, *reinterpret_cast<const lds_u32x4_lv*>(rb_ + tb[kg]));                    \
+            rslot = rslot + LVL_U_BYTES == ring_base + RING * LVL_U_BYTES ? ring_base : rslot + LVL_U_BYTES;                       \
+            ++q_read;                                                                                                              \
+        } else if ((KU) == 0) {                                                                                                    \
+            _Pragma("unroll") for (int kg = 0; kg < 4; ++kg) bfr[SET][kg] = breg0[kg];                                             \
+        } else if ((KU) == 1) {                                                                                                    \
+            _Pragma("unroll") for (int kg = 0; kg < 4; ++kg) bfr[SET][kg] = breg1[kg];                                             \
+        } else {                                                                                                                   \
+            _Pragma("unroll") for (int kg = 0; kg < 4; ++kg) bfr[SET][kg] = breg2[kg];                                             \
+        }                                                                                                                          \
+    } while (0)
+/* before the fragments of ring unit q_read are read: it has landed when at most the units requested after it are outstanding */  \
+#define LV_WAIT_UNIT(KU)                                                                                                          \
+    do {                                                                                                                           \
+        if ((KU) >= REGU) {                                                                                                        \
+            if (d_req - (q_read + 1) >= D)                                                                                         \
+                wait_vm_keep<D * LVL_NPI>();                                                                                       \
+            else                                                                                                                   \
+                wait_vm_keep<0>();                                                                                                 \
         }                                                                                                                          \
     } while (0)
 #define LV_MMA(CUR, KG)                                                                            \
@@ -311,30 +395,27 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
 #define LV_STEP(CUR, NXT)                                                                                                          \
     do {                                                                                                                           \
         const bool more_ = k + 1 < taps;                                                                                           \
-        wait_lgkm_all(); /* set CUR is complete - and its unit's slot is free for the unit RING further on */                      \
+        wait_lgkm_all(); /* set CUR is complete - and, if it came from the ring, its slot is free for the unit RING further on */  \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
         LV_MMA(CUR, 0);                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
-        const bool req_ = d_left > 0;                                                                                              \
-        if (req_) dma_next();                                                                                                      \
+        if (ku >= REGU && d_left > 0) dma_next();                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
         LV_MMA(CUR, 1);                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
         if (more_) {                                                                                                               \
-            if (req_)                                                                                                              \
-                wait_vm_keep<D * LVL_NPI>(); /* the next unit has landed; the D units behind it may be in flight */                \
-            else                                                                                                                   \
-                wait_vm_keep<0>();                                                                                                 \
-            LV_READ_FRAGS(NXT, k + 1, rslot);                                                                                      \
+            LV_WAIT_UNIT(ku + 1);                                                                                                  \
+            LV_READ_FRAGS(NXT, k + 1, ku + 1);                                                                                     \
         }                                                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
         LV_MMA(CUR, 2);                                                                                                            \
         LV_MMA(CUR, 3);                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
-        rslot = rslot + LVL_U_BYTES == ring_base + RING * LVL_U_BYTES ? ring_base : rslot + LVL_U_BYTES;                           \
         ++k;                                                                                                                       \
+        ++ku;                                                                                                                      \
     } while (0)
-                unsigned rslot = ring_base;  // LDS address of the slot of the next unit whose fragments will be read
+                unsigned rslot = ring_base;  // LDS address of the slot of the next ring unit whose fragments will be read
+                int q_read = 0, ku = 0;      // ring units read so far; index of the unit being multiplied
                 for (int p = 0; p < npass; ++p) {
                     // ---- A operand of this pass: chunk 4 p + wave of the GB groups' 64 pixels each, gathered after the hand-off ----
                     if (!op.reuse_a) {
@@ -367,15 +448,10 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
                             for (int i = 0; i < 8; ++i)
                                 *reinterpret_cast<uint4*>(ldsA + (j * LVL_BM + 8 * i + (lane >> 3)) * ROW_DATA + (lane & 7) * 16) = v[j][i];
                     }
-                    if (p == 0 && d_left > 0) {
-                        dma_next();
-                        wait_vm_keep<LVL_NPI>();  // the pass's first unit (and everything older: the gather) has landed
-                    } else {
-                        wait_vm_keep<0>();
-                    }
+                    if (p == 0 && d_left > 0) dma_next();  // the ring is full now: RING units requested
+                    LV_WAIT_UNIT(ku);
                     if (p == 0) LV_STAMP(2);
-                    LV_READ_FRAGS(0, 0, rslot);
-                    rslot = rslot + LVL_U_BYTES == ring_base + RING * LVL_U_BYTES ? ring_base : rslot + LVL_U_BYTES;
+                    LV_READ_FRAGS(0, 0, ku);
                     int k = 0;
 #pragma unroll 1
                     while (k + 1 < taps) {
@@ -386,6 +462,7 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
                 }
 #undef LV_STEP
 #undef LV_MMA
+#undef LV_WAIT_UNIT
 #undef LV_READ_FRAGS
                 primed = false;
                 LV_STAMP(3);
@@ -396,34 +473,6 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int j = 0; j < 16; ++j) redw[(mi * 16 + j) * 64 + lane] = acc[mi][j];
-                // what the items need besides the sums goes out before the barrier: residual, bias, time row
-                uint4 resv[GB];
-                const float* bp = reinterpret_cast<const float*>(A.packed + op.b_off) + op.w_row0 + co;
-                const f32x4 b0v = *reinterpret_cast<const f32x4*>(bp), b1v = *reinterpret_cast<const f32x4*>(bp + 4);
-                float fold[GB][8];
-#pragma unroll
-                for (int j = 0; j < GB; ++j) {
-                    const int gpc = gpv[j] < 0 ? 0 : gpv[j];
-                    resv[j] = make_uint4(0u, 0u, 0u, 0u);
-                    if (op.res_off >= 0) {
-                        const lvl_rsrc rr = lvl_make_rsrc(A.ws + op.res_off, (unsigned)npix * (unsigned)op.res_C * 2u);
-                        resv[j] = lvl_ld(rr, (unsigned)(gpc * op.res_C + op.res_c0 + co) * 2u);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        fold[j][e] = b0v[e];
-                        fold[j][4 + e] = b1v[e];
-                    }
-                    if (op.tproj_col >= 0) {
-                        const float* tp = A.tproj + (int64_t)(A.nt == 1 ? 0 : gpc >> sh2) * A.tproj_ld + op.tproj_col + co;
-                        const f32x4 t0 = *reinterpret_cast<const f32x4*>(tp), t1 = *reinterpret_cast<const f32x4*>(tp + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            fold[j][e] += t0[e];
-                            fold[j][4 + e] += t1[e];
-                        }
-                    }
-                }
                 __syncthreads();
                 // acc layout of a 32 x 32 tile: lane = cout column + 32 * (pixel row bit 2), register j = pixel rows (j & 3) + 8 * (j >> 2)
                 const int pr = m & 31, jj = (pr & 3) + 4 * (pr >> 3), hh = (pr >> 2) & 1;

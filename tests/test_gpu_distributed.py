@@ -46,7 +46,16 @@ def _worker(rank, world, path):
             assert len(red.reported) == 2
             assert red.finish() is True
             torch.cuda.synchronize()
+            # the buffer holds the rank SUMS; 1 / world rides on the fused clip + Adam pass (FusedAdam.grad_scale)
+            got = got * red.grad_scale()
+            assert red.grad_scale() == 1.0 / world
             assert torch.allclose(got, want, rtol=1e-5, atol=1e-6 * float(want.abs().max())), float((got - want).abs().max())
+        red.detach()
+        red = D.OverlappedGradReducer(net, bucket_elems=4096, fold_mean=False)  # the unfolded form: divide, then all-reduce
+        got = _local_grads(net, rank)
+        assert red.finish() is True and red.grad_scale() == 1.0
+        torch.cuda.synchronize()
+        assert torch.allclose(got, want, rtol=1e-5, atol=1e-6 * float(want.abs().max())), float((got - want).abs().max())
         # every rank ends with the same bits
         mine = got.clone()
         other = got.clone()
@@ -59,3 +68,59 @@ def _worker(rank, world, path):
 def test_two_ranks_overlapped_gradient_exchange():
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(2, os.path.join(d, "rdv")), nprocs=2, join=True)
+
+
+def test_bf16_exchange_kernels_match_their_torch_restatement():
+    """dmme_grad_pack_bf16 / dmme_shard_reduce_bf16 / dmme_grad_unpack_bf16 (the GPU side of distributed.Bf16ShardExchange) against
+    the torch ops the gloo rehearsal uses on CPU tensors: same roundings, same summation order - bit for bit"""
+    from dmme_amd import _lib
+
+    lib, st = _lib.lib(), _lib.stream_ptr()
+    torch.manual_seed(0)
+    for n, world in ((1000, 2), (4097, 4), (1 << 20, 8)):
+        g = torch.randn(n, device="cuda") * 3
+        per = (n + world - 1) // world
+        pad = per * world
+        send = torch.empty(pad, dtype=torch.bfloat16, device="cuda")
+        _lib.check(lib.dmme_grad_pack_bf16(_lib.ptr(g), n, _lib.ptr(send), pad, st), "pack")
+        want = torch.zeros(pad, dtype=torch.bfloat16, device="cuda")
+        want[:n] = g.to(torch.bfloat16)
+        assert torch.equal(send, want)
+        recv = (torch.randn(world, per, device="cuda") * 3).to(torch.bfloat16)  # what the all-to-all would deliver
+        shard = torch.empty(per, dtype=torch.bfloat16, device="cuda")
+        _lib.check(lib.dmme_shard_reduce_bf16(_lib.ptr(recv), world, per, 1.0 / world, _lib.ptr(shard), st), "reduce")
+        acc = torch.zeros(per, device="cuda")
+        for j in range(world):
+            acc += recv[j].float()
+        assert torch.equal(shard, (acc * (1.0 / world)).to(torch.bfloat16))
+        out = torch.empty(n, device="cuda")
+        _lib.check(lib.dmme_grad_unpack_bf16(_lib.ptr(send), n, _lib.ptr(out), st), "unpack")
+        assert torch.equal(out, send[:n].float())
+
+
+def test_fused_adam_grad_scale_equals_a_prescaled_gradient():
+    """FusedAdam.grad_scale (the 1 / world of a sum-reducing exchange, folded into clip + Adam + EMA): one step on sums with
+    grad_scale = 1/8 equals one step on the mean, clip included"""
+    import dmme_amd
+    from dmme_amd.optim import FusedAdam
+    from oracle import unet as O
+
+    cfg = O.TINY
+    nets, opts = [], []
+    for _ in range(2):
+        torch.manual_seed(4)
+        net = dmme_amd.UNet(cfg.in_channels, cfg.pos_dim, cfg.emb_dim, cfg.num_groups, 0.0, cfg.channels_per_depth, cfg.num_blocks, cfg.attention_depths).cuda()
+        nets.append(net)
+        opts.append(FusedAdam(net.parameters(), lr=1e-3, max_grad_norm=0.5, ema_decay=0.99))
+    torch.manual_seed(9)
+    gsum = torch.randn_like(nets[0].flat_parameters()) * 8
+    nets[0].flat_grad().copy_(gsum)
+    opts[0].grad_scale = 1.0 / 8
+    nets[1].flat_grad().copy_(gsum / 8)
+    for o in opts:
+        o.step()
+    torch.cuda.synchronize()
+    assert opts[0].grad_scale == 1.0  # consumed by the step
+    a, b = nets[0].flat_parameters(), nets[1].flat_parameters()
+    assert float((a - b).abs().max()) <= 1e-7, float((a - b).abs().max())
+    assert abs(float(opts[0].last_grad_norm) / 8 - float(opts[1].last_grad_norm)) <= 1e-4 * float(opts[1].last_grad_norm)

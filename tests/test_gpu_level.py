@@ -1,0 +1,156 @@
+"""-m gpu: the level engine (csrc/lvl_engine.hip) - ONE persistent launch per stretch of layers on the 8x8 / 4x4 maps, replacing the
+per-layer launches of ResBlock / Attention there (reference: models/ddpm.py:118-133, 38-75, 297-313).  Checked against the reference's
+golden output, against the per-op launch path on the same inputs (DMME_NO_LVL, read when a plan is built), per module of the two
+levels, in train mode with Dropout2d masks and per-image timesteps, through its gradients, and for its bounded waits (error word)."""
+
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth
+from oracle import unet as O
+
+pytestmark = pytest.mark.gpu
+
+LEVEL_MODULES = ["down_layers.6", "down_layers.7", "down_layers.9", "down_layers.10", "middle_layers.0", "middle_layers.1", "up_layers.0",
+                 "up_layers.1", "up_layers.2", "up_layers.4", "up_layers.5", "up_layers.6"]
+
+
+def _net(seed, precision, lvl, train=False):
+    import dmme_amd
+
+    cfg = O.UNetConfig()
+    net = dmme_amd.UNet(precision=precision)
+    net.load_state_dict(O.make_state_dict(cfg, seed), strict=True)
+    net = net.cuda()
+    net.train(train)
+    net._lvl = lvl
+    return net
+
+
+class _env:
+    def __init__(self, lvl):
+        self.lvl = lvl
+
+    def __enter__(self):
+        if self.lvl:
+            os.environ.pop("DMME_NO_LVL", None)
+        else:
+            os.environ["DMME_NO_LVL"] = "1"
+
+    def __exit__(self, *a):
+        os.environ.pop("DMME_NO_LVL", None)
+
+
+def _info(net):
+    from dmme_amd import _lib
+
+    buf = C.create_string_buffer(2048)
+    _lib.check(net._last_plan.lib.dmme_unet_plan_level_info(net._last_plan.h, buf, 2048), "level_info")
+    return buf.value.decode()
+
+
+def _forward(net, x, t, acts=False):
+    with _env(net._lvl), torch.no_grad():
+        y = net(x, t).float().cpu()
+        a = {m: net.debug_activation(m).cpu() for m in LEVEL_MODULES} if acts else None
+    return y, a
+
+
+@pytest.mark.parametrize("B", [1, 2, 5, 32, 128])
+def test_level_engine_vs_reference_golden_and_vs_per_op_launches(golden, B):
+    """bf16 default UNet: the reference's golden row (unet_full.npz: output of the imported reference), every module of the 8x8 / 4x4
+    levels against the per-op path.  B = 1, 2, 5: partial pixel groups (a 4x4 group is 4 images); 32: one group per workgroup on both
+    levels; 128: two groups per iteration on the 8x8 levels."""
+    g = golden("unet_full")
+    seed = int(g["full_seed"])
+    base = synth.normal(int(g["full_xseed"]), (2, 3, 32, 32))
+    x = base.repeat((B + 1) // 2, 1, 1, 1)[:B].cuda()
+    t = torch.from_numpy(g["full_t_one"]).cuda()
+    on, off = _net(seed, "bf16", True), _net(seed, "bf16", False)
+    ya, aa = _forward(on, x, t, acts=True)
+    yb, ab = _forward(off, x, t, acts=True)
+    info = _info(on)
+    assert info.startswith("runs=3") and "err=0" in info and "err=1" not in info, info
+    assert _info(off).startswith("runs=0")
+    na, nb = (n._last_plan.lib.dmme_unet_plan_num_launches(n._last_plan.h) for n in (on, off))
+    assert nb - na >= 28, (na, nb)
+    ref = torch.from_numpy(g["full_y_one"])
+    for i in range(B):  # every image of the batch took the arithmetic of its golden row
+        assert float((ya[i] - ref[i % 2]).abs().max()) <= 1.36e-2, i  # the bf16 network's bound (tests/test_gpu_unet.py)
+    if B >= 4:
+        assert torch.equal(ya[2:4], ya[0:2])
+    worst = 0.0
+    for m in LEVEL_MODULES:
+        d = float((aa[m] - ab[m]).pow(2).mean().sqrt() / ab[m].pow(2).mean().sqrt())
+        worst = max(worst, d)
+        assert not torch.isnan(aa[m]).any(), m
+    e_ab = float((ya - yb).pow(2).mean().sqrt() / yb.pow(2).mean().sqrt())
+    print(f"B={B}: launches {nb} -> {na}; output rel-rms between the paths {e_ab:.3e}; worst level module {worst:.3e}; {info}")
+    assert worst <= 8e-3 and e_ab <= 1.0e-2  # two bf16 evaluations of one network: independent roundings, not an error
+
+
+def test_level_engine_replays_and_counts_epochs(golden):
+    """flags carry the launch's epoch (nothing is re-initialised between launches): 40 forwards on one plan, identical bits each time"""
+    g = golden("unet_full")
+    net = _net(int(g["full_seed"]), "bf16", True)
+    x = synth.normal(3, (8, 3, 32, 32)).cuda()
+    t = torch.tensor([77]).cuda()
+    y0, _ = _forward(net, x, t)
+    for _ in range(39):
+        y, _ = _forward(net, x, t)
+        assert torch.equal(y, y0)
+    info = _info(net)
+    assert info.count("epoch=40") == 3 and "err=1" not in info, info
+
+
+def test_level_engine_train_mode_loss_and_gradients_vs_per_op_path():
+    """train mode: Dropout2d masks inside the pre-activated inputs, one time-embedding row per image, and everything the backward pass
+    reads (scale / shift / {mean, rstd} rows, the pre-activated tensors of the weight gradient): one step's loss and flat gradient with
+    and without the engine, same seed"""
+    import dmme_amd
+
+    def step(lvl):
+        with _env(lvl):
+            torch.manual_seed(0)
+            net = dmme_amd.UNet(precision="bf16").cuda().train()
+            x = torch.randn(32, 3, 32, 32, device="cuda", generator=torch.Generator("cuda").manual_seed(3))
+            t = torch.arange(32, device="cuda") * 31 % 1000
+            y = net(x, t)
+            l = (y.float() ** 2).mean()
+            l.backward()
+            return float(l.detach()), net.flat_grad().float().clone(), _info(net)
+
+    la, ga, info = step(True)
+    lb, gb, _ = step(False)
+    rel = float((ga - gb).norm() / gb.norm())
+    print(f"train step: loss {la:.6f} (engine) vs {lb:.6f}; flat gradient relative difference {rel:.3e}; {info}")
+    assert info.startswith("runs=3") and "err=1" not in info
+    assert abs(la - lb) <= 2e-3 * abs(lb)
+    assert rel <= 3e-2  # two bf16 backward passes over differently rounded activations (per-tensor budget: DESIGN.md section 2)
+
+
+def test_level_engine_fp32_and_other_geometries_keep_their_launches():
+    """what the engine does not take stays on the per-op path: fp32 / bf16x3 plans, the tiny test configuration, the IDDPM blocks"""
+    import dmme_amd
+
+    for precision in ("fp32", "bf16x3"):
+        net = dmme_amd.UNet(precision=precision).cuda().eval()
+        with torch.no_grad():
+            net(torch.zeros(2, 3, 32, 32, device="cuda"), torch.tensor([5]).cuda())
+        assert _info(net).startswith("runs=0")
+    cfg = O.TINY
+    net = dmme_amd.UNet(cfg.in_channels, cfg.pos_dim, cfg.emb_dim, cfg.num_groups, cfg.dropout, cfg.channels_per_depth, cfg.num_blocks,
+                        cfg.attention_depths, precision="bf16").cuda().eval()
+    with torch.no_grad():
+        net(torch.zeros(2, 3, 32, 32, device="cuda"), torch.tensor([5]).cuda())
+    assert _info(net).startswith("runs=0")
+    from dmme_amd.models.iddpm import UNet as IUNet
+
+    inet = IUNet(precision="bf16").cuda().eval()
+    with torch.no_grad():
+        inet(torch.zeros(2, 3, 32, 32, device="cuda"), torch.tensor([5]).cuda())
+    assert _info(inet).startswith("runs=0")

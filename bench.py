@@ -8,7 +8,7 @@ update + t -> t-1, all loop state resident on the device).  Inputs and weights a
 before the timed region.  With --gpus N every rank runs its own independent batch-128 chain
 (sampling shards with no data-path collective: weak scaling).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode sample|ddim|train|cpu-plumbing] [--precision bf16|bf16x3|fp32]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode sample|ddim|train|cpu-plumbing] [--precision bf16|fp16|bf16x3|fp32]
 
 `python bench.py --gpus N` with N > 1 and no torch.distributed environment starts its N ranks itself
 (`python -m torch.distributed.run`, before this process touches the GPU) and relays rank 0's line.
@@ -32,7 +32,7 @@ os.environ.setdefault("TQDM_DISABLE", "1")
 import torch  # noqa: E402
 
 # dense MFMA TFLOP/s (MI355X_MICROARCH.md, chip-level parameters); bf16x3 runs three bf16 matrix products per algorithmic one
-PEAK = {"bf16": 2500.0, "bf16x3": 2500.0 / 3.0, "fp32": 157.3}
+PEAK = {"bf16": 2500.0, "fp16": 2500.0, "bf16x3": 2500.0 / 3.0, "fp32": 157.3}
 HBM_PEAK_GBS = 8000.0
 METRIC = "denoising steps/sec + training images/sec, DDPM UNet CIFAR10 32×32 @1/2/4/8 GPU"
 FWD_GFLOP_PER_IMAGE = {"ddpm": 9.809, "iddpm64": 37.50}  # conv + linear + QK^T + AV, 2 x MAC; training = 3x
@@ -54,7 +54,8 @@ def parse():
     ap.add_argument("--graph", action="store_true", help=argparse.SUPPRESS)  # accepted for older command lines: the graph is the default now
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-accurate-leg", action="store_true", help="skip the short bf16x3 (accurate mode) throughput leg")
+    ap.add_argument("--no-accurate-leg", action="store_true", help="skip the short bf16x3 (accurate mode) and fp16 throughput legs")
+    ap.add_argument("--no-ddim-leg", action="store_true", help="skip the BASELINE configs[2] leg (DDIM 50 steps, batch 512) of the N = 1 line")
     ap.add_argument("--config", default=None, help="cpu-plumbing: the LightningCLI YAML to drive (default configs/ddpm/cifar10.yaml)")
     return ap.parse_args()
 
@@ -125,6 +126,15 @@ def roofline_leg(model, x, t_dev, precision):
         g["bytes"] += nbytes[i]
     order = sorted(groups.items(), key=lambda kv: -kv[1]["ms"])
     total_ms = sum(g["ms"] for _, g in order)
+    # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x clock) of the committed rocprofv3 --pmc pass of this workload (tools/prof.sh ->
+    # profiles/mfma_busy_latest.json); counters cannot be read from inside this process, so: that file or null
+    pmc_busy = {}
+    bpath = os.path.join(ROOT, "profiles", "mfma_busy_latest.json")
+    if os.path.exists(bpath) and x.shape[0] == 128 and x.shape[-1] == 32 and precision == "bf16":
+        try:
+            pmc_busy = {k: v.get("mfma_busy_pct") for k, v in json.load(open(bpath)).items() if isinstance(v, dict)}
+        except Exception:  # noqa: BLE001
+            pmc_busy = {}
     table = []
     for name, g in order[:8]:
         table.append({
@@ -132,6 +142,10 @@ def roofline_leg(model, x, t_dev, precision):
             "avg_launch_us": round(1e3 * g["ms"] / g["count"], 2), "share": round(g["ms"] / total_ms, 4),
             "tflops": round(g["flops"] / (g["ms"] * 1e-3) / 1e12, 2) if g["ms"] > 0 else 0.0,
             "algo_gbs": round(g["bytes"] / (g["ms"] * 1e-3) / 1e9, 1) if g["ms"] > 0 else 0.0,
+            # both roofs per kernel, so that an HBM-shaped kernel (1x1 convs, attention over a materialised qkv) is read against the right one
+            "mfma_frac": round(g["flops"] / (g["ms"] * 1e-3) / 1e12 / PEAK.get(precision, 2500.0), 4) if g["ms"] > 0 else 0.0,
+            "hbm_frac": round(g["bytes"] / (g["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if g["ms"] > 0 else 0.0,
+            "mfma_busy_pct": pmc_busy.get(name),
         })
     name, g = order[0]
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure is the committed
@@ -199,6 +213,7 @@ def cpu_baseline_leg(batch):
     dt = time.perf_counter() - t0
     return {"value": round(done / dt, 4), "unit": f"denoising steps/s at batch {batch}", "image_steps_per_s": round(done * batch / dt, 2),
             "cores": threads, "host_cpus_visible": avail, "os_cpu_count": os.cpu_count(), "kind": "port",
+            "kind_detail": f"oracle/ (CPU restatement of the reference's UNet + DDPM update, pinned by the reference's own outputs), fp32, {threads} threads",
             "sample": f"{done} DDPM steps of batch {batch} (the benchmark's own batch, not scaled) after 1 warm-up, fp32, oracle UNet + update, "
                       f"{dt:.1f} s, torch intra-op threads = {threads} (the per-GPU core share of the box)"}
 
@@ -481,30 +496,55 @@ def main():
                 out["cpu_baseline"] = cpu_baseline_leg(B)
 
     def accurate_leg():
-        """the same sampling step in the accurate mode (precision="bf16x3": fp32 activations, every matrix product as three bf16
-        MFMA passes on hi/lo splits - within north_star's 1e-3 of the reference), reported next to the fast mode"""
-        if args.no_accurate_leg or args.precision != "bf16" or args.model != "ddpm" or args.mode != "sample" or "bf16x3" not in dmme_amd._lib.DTYPES:
+        """the same sampling step in the two modes that are closer to the reference than bf16: precision="bf16x3" (fp32
+        activations, every matrix product as three bf16 MFMA passes on hi/lo splits - max|err| 1.7e-5, inside north_star's 1e-3) and
+        precision="fp16" (IEEE half, the reference's own AMP dtype, same kernels and rate as bf16 - max|err| 1.5e-3, rel-RMS 9.8e-4)"""
+        if args.no_accurate_leg or args.precision != "bf16" or args.model != "ddpm" or args.mode != "sample":
+            return
+        for key, prec in (("accurate_mode", "bf16x3"), ("fp16_mode", "fp16")):
+            if prec not in dmme_amd._lib.DTYPES:
+                continue
+            try:
+                torch.manual_seed(1337)
+                m3 = dmme_amd.UNet(precision=prec).to(dev).eval()
+                p3 = dmme_amd.DDPM(m3, T).to(dev)
+                x3 = dmme_amd.gaussian((B, 3, side, side), device=dev)
+                r3 = p3.chain_runner(x3, use_graph=not args.no_graph)
+                k = max(5, min(20, args.steps))
+                dt3 = chain_leg(p3, r3, T, 3, k, dist, dev)
+                out[key] = {"precision": prec, "steps_per_s": round(world * k / dt3, 3), "ms_per_step": round(1e3 * dt3 / k, 3),
+                            "steps": k, "step_tflops_algorithmic": round(world * k * B * gflop / dt3 / 1e3, 1),
+                            "max_abs_err_vs_reference": {"bf16x3": "1.7e-5", "fp16": "1.5e-3 (rel-RMS 9.8e-4)"}[prec] + " (tests/test_gpu_x3.py, test_gpu_fp16.py)"}
+                del m3, p3, x3, r3
+                torch.cuda.empty_cache()
+            except Exception as exc:  # noqa: BLE001 - a secondary figure must not cost the headline line
+                out[key] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+
+    def ddim_leg():
+        """BASELINE configs[2] as a secondary key of the N = 1 line: DDIM, 50-step quadratic tau, batch 512, the full chain once"""
+        if args.no_ddim_leg or world != 1 or args.precision != "bf16" or args.model != "ddpm" or args.mode != "sample":
             return
         try:
             torch.manual_seed(1337)
-            m3 = dmme_amd.UNet(precision="bf16x3").to(dev).eval()
-            p3 = dmme_amd.DDPM(m3, T).to(dev)
-            x3 = dmme_amd.gaussian((B, 3, side, side), device=dev)
-            r3 = p3.chain_runner(x3, use_graph=not args.no_graph)
-            k = max(5, min(20, args.steps))
-            dt3 = chain_leg(p3, r3, T, 3, k, dist, dev)
-            out["accurate_mode"] = {"precision": "bf16x3", "steps_per_s": round(world * k / dt3, 3), "ms_per_step": round(1e3 * dt3 / k, 3),
-                                    "steps": k, "step_tflops_algorithmic": round(world * k * B * gflop / dt3 / 1e3, 1)}
-            del m3, p3, x3, r3
+            md = dmme_amd.UNet(precision="bf16").to(dev).eval()
+            pd = dmme_amd.DDIM(md, T, 50).to(dev)
+            xd = dmme_amd.gaussian((512, 3, side, side), device=dev)
+            rd = pd.chain_runner(xd, use_graph=not args.no_graph)
+            dtd = chain_leg(pd, rd, 50, 5, 50, dist, dev)
+            out["ddim_b512"] = {"config": "DDIM 50-step (quadratic tau), batch 512, bf16", "steps_per_s": round(50 / dtd, 3), "ms_per_step": round(1e3 * dtd / 50, 3),
+                                "image_steps_per_s": round(50 * 512 / dtd, 1), "chain_seconds": round(dtd, 4),
+                                "step_tflops": round(50 * 512 * gflop / dtd / 1e3, 1)}
+            del md, pd, xd, rd
             torch.cuda.empty_cache()
-        except Exception as exc:  # noqa: BLE001 - a secondary figure must not cost the headline line
-            out["accurate_mode"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+        except Exception as exc:  # noqa: BLE001
+            out["ddim_b512"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
 
     # several ranks: rank 0's legs first, so that a stuck collective in the training leg cannot cost them; one rank: after it (no
     # collective to get stuck in, and the event-bracketed kernel times sit closer to rocprofv3's with the device in its training-leg state)
     if world > 1 or args.train_steps <= 0:
         rank0_legs()
     accurate_leg()
+    ddim_leg()
     rc = 0
     if args.train_steps > 0:
         del x, runner

@@ -47,9 +47,23 @@ __device__ __forceinline__ int64_t at_o_off(const AttnGeom& g, int bh) {
 // xcd_order: workgroup L runs on XCD L % 8 and every XCD has its own L2; in plain order the query blocks of one (image, head) row
 // land on different XCDs and each pulls that row's K and V from HBM (round-1 counters: 1.88x the algorithmic bytes).  With
 // xcd_order the blocks of a row take consecutive slots of ONE XCD's round-robin share of the grid.
-template <int C, int NW>
-__global__ void __launch_bounds__(64 * NW) attn_mfma_kernel(const bf16* __restrict__ qkv, AttnGeom g, bf16* __restrict__ out, float* __restrict__ lse,
+// one 32x32x16 MFMA on 16-bit operands (bf16 or IEEE half: same rate, same fragment layout)
+template <typename T, typename V>
+__device__ __forceinline__ void at_mma(const V& a, const V& b, f32x16& acc);
+template <>
+__device__ __forceinline__ void at_mma<bf16, bf16x8>(const bf16x8& a, const bf16x8& b, f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+typedef f16 f16x8_at __attribute__((ext_vector_type(8)));
+template <>
+__device__ __forceinline__ void at_mma<f16, f16x8_at>(const f16x8_at& a, const f16x8_at& b, f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+}
+
+template <int C, int NW, typename T = bf16>
+__global__ void __launch_bounds__(64 * NW) attn_mfma_kernel(const T* __restrict__ qkv, AttnGeom g, T* __restrict__ out, float* __restrict__ lse,
                                                             int xcd_order) {
+    typedef T tx8 __attribute__((ext_vector_type(8)));  // 8 operands of the 16-bit type (bf16 or IEEE half)
     constexpr int AT_QB = 32 * NW, NT = 64 * NW;
     const int S = g.S;
     constexpr int KSTEPS = C / 16;   // k-steps of the QK^T product
@@ -75,7 +89,7 @@ __global__ void __launch_bounds__(64 * NW) attn_mfma_kernel(const bf16* __restri
         n = (j / qblocks) * 8 + x;
         qb = j % qblocks;
     }
-    const bf16* base = qkv + at_qkv_off<C>(g, n);
+    const T* base = qkv + at_qkv_off<C>(g, n);
     const int ld = g.ld;
     const int q_row = qb * AT_QB + wave * 32 + r;  // this lane's query
 
@@ -115,7 +129,7 @@ __global__ void __launch_bounds__(64 * NW) attn_mfma_kernel(const bf16* __restri
 #define AT_LD1(I, K0)                                                                                 \
     if constexpr (UNITS > I) {                                                                        \
         const int u = tid + I * NT, row = u / (C / 8), cu = u % (C / 8);                              \
-        const bf16* src = base + (int64_t)((K0) + row) * ld + cu * 8;                                 \
+        const T* src = base + (int64_t)((K0) + row) * ld + cu * 8;                                 \
         kr##I = *reinterpret_cast<const uint4*>(src + C);                                             \
         vr##I = *reinterpret_cast<const uint4*>(src + 2 * C);                                         \
     }
@@ -170,7 +184,7 @@ __global__ void __launch_bounds__(64 * NW) attn_mfma_kernel(const bf16* __restri
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < FG; ++u)
-                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[cur][u]), __builtin_bit_cast(bf16x8, qv[cur][u]), st, 0, 0, 0);
+                    at_mma<T>(__builtin_bit_cast(tx8, kf[cur][u]), __builtin_bit_cast(tx8, qv[cur][u]), st);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -211,11 +225,11 @@ __global__ void __launch_bounds__(64 * NW) attn_mfma_kernel(const bf16* __restri
                 for (int j = 0; j < 16; ++j) o[ct][j] *= alpha;
         }
         // P^T as B operand: k-step s uses registers 8s..8s+7 (key = 16 s + 8 (j>>2) + 4 h + (j&3))
-        bf16x8 pf[2];
+        tx8 pf[2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pf[s2][j] = (bf16)p[8 * s2 + j];
+            for (int j = 0; j < 8; ++j) pf[s2][j] = (T)p[8 * s2 + j];
         // ---- O^T += V^T P^T ----
 #pragma unroll
         for (int ct = 0; ct < CT; ct += VG) {
@@ -231,7 +245,7 @@ __global__ void __launch_bounds__(64 * NW) attn_mfma_kernel(const bf16* __restri
                     s16x8 vf;
                     vf[0] = vlo[cur][cu][s2][0]; vf[1] = vlo[cur][cu][s2][1]; vf[2] = vlo[cur][cu][s2][2]; vf[3] = vlo[cur][cu][s2][3];
                     vf[4] = vhi[cur][cu][s2][0]; vf[5] = vhi[cur][cu][s2][1]; vf[6] = vhi[cur][cu][s2][2]; vf[7] = vhi[cur][cu][s2][3];
-                    o[ct + cu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf[s2], o[ct + cu], 0, 0, 0);
+                    at_mma<T>(__builtin_bit_cast(tx8, vf), pf[s2], o[ct + cu]);
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -242,15 +256,15 @@ __global__ void __launch_bounds__(64 * NW) attn_mfma_kernel(const bf16* __restri
     const float inv = 1.0f / ltot;
     // log2-domain log-sum-exp of the scaled scores, kept for the backward pass: p = exp2(s*c1 - lse)
     if (lse && h == 0) lse[(int64_t)n * S + q_row] = m + log2f(ltot);
-    bf16* orow = out + at_o_off<C>(g, n) + (int64_t)q_row * g.Cfull;
+    T* orow = out + at_o_off<C>(g, n) + (int64_t)q_row * g.Cfull;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
         for (int jg = 0; jg < 4; ++jg) {
-            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            typedef T bf16x4 __attribute__((ext_vector_type(4)));
             bf16x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (bf16)(o[ct][jg * 4 + e] * inv);
+            for (int e = 0; e < 4; ++e) v[e] = (T)(o[ct][jg * 4 + e] * inv);
             *reinterpret_cast<bf16x4*>(orow + ct * 32 + 8 * jg + 4 * h) = v;
         }
     }
@@ -260,39 +274,46 @@ bool attn_mfma_supported(int dtype, int N, int S, int C) { return attn_heads_mfm
 // head width 64 / 128 / 256; 128-query workgroups, or 64-query ones for the 8x8 maps
 bool attn_heads_mfma_supported(int dtype, int N, int S, int C, int heads) {
     (void)N;
-    if (dtype != DMME_BF16 || heads < 1 || C % heads) return false;
+    if (!is16(dtype) || heads < 1 || C % heads) return false;
     const int D = C / heads;
     return (D == 64 || D == 128 || D == 256) && S >= 64 && S % 64 == 0 && (S % 128 == 0 || S == 64);
 }
 static AttnGeom attn_geom(int N, int S, int C, int heads) { return AttnGeom{S, 3 * C, C, heads, N, 1.0f / sqrtf((float)C)}; }
 
-template <int D, int NW>
-static int launch_attn_fwd_nw(const bf16* qkv, const AttnGeom& g, bf16* out, float* lse, hipStream_t s) {
+template <int D, int NW, typename T>
+static int launch_attn_fwd_nw(const T* qkv, const AttnGeom& g, T* out, float* lse, hipStream_t s) {
     const int rows = g.N * g.heads, qblocks = g.S / (32 * NW);
     const size_t lds = (size_t)AT_KT * (D * 2 + 16) + (size_t)AT_KT * (D * 2 + 64) + (D > 128 ? (size_t)32 * NW * (D * 2 + 16) : 0);
     static bool attr_done = false;
     if (!attr_done) {
-        DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_kernel<D, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_kernel<D, NW, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_done = true;
     }
     static const bool xcd_off = getenv("DMME_NO_XCD_ORDER") != nullptr;
     const int xcd_order = (!xcd_off && qblocks > 1 && rows % 8 == 0) ? 1 : 0;
-    hipLaunchKernelGGL((attn_mfma_kernel<D, NW>), dim3((unsigned)(rows * qblocks)), dim3(64 * NW), lds, s, qkv, g, out, lse, xcd_order);
+    hipLaunchKernelGGL((attn_mfma_kernel<D, NW, T>), dim3((unsigned)(rows * qblocks)), dim3(64 * NW), lds, s, qkv, g, out, lse, xcd_order);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }
-template <int D>
-static int launch_attn_fwd_t(const bf16* qkv, const AttnGeom& g, bf16* out, float* lse, hipStream_t s) {
-    if (g.S % 128 == 0) return launch_attn_fwd_nw<D, 4>(qkv, g, out, lse, s);
-    return launch_attn_fwd_nw<D, 2>(qkv, g, out, lse, s);
+template <int D, typename T>
+static int launch_attn_fwd_t(const T* qkv, const AttnGeom& g, T* out, float* lse, hipStream_t s) {
+    if (g.S % 128 == 0) return launch_attn_fwd_nw<D, 4, T>(qkv, g, out, lse, s);
+    return launch_attn_fwd_nw<D, 2, T>(qkv, g, out, lse, s);
 }
 int launch_attn_heads_mfma(int dtype, const void* qkv, int N, int S, int C, int heads, void* out, float* lse, hipStream_t s) {
     DMME_REQUIRE(attn_heads_mfma_supported(dtype, N, S, C, heads), DMME_ERR_UNSUPPORTED, "attn_mfma: unsupported shape S=%d C=%d heads=%d", S, C, heads);
     const AttnGeom g = attn_geom(N, S, C, heads);
+    if (dtype == DMME_F16) {
+        switch (C / heads) {
+            case 256: return launch_attn_fwd_t<256, f16>((const f16*)qkv, g, (f16*)out, lse, s);
+            case 128: return launch_attn_fwd_t<128, f16>((const f16*)qkv, g, (f16*)out, lse, s);
+            default: return launch_attn_fwd_t<64, f16>((const f16*)qkv, g, (f16*)out, lse, s);
+        }
+    }
     switch (C / heads) {
-        case 256: return launch_attn_fwd_t<256>((const bf16*)qkv, g, (bf16*)out, lse, s);
-        case 128: return launch_attn_fwd_t<128>((const bf16*)qkv, g, (bf16*)out, lse, s);
-        default: return launch_attn_fwd_t<64>((const bf16*)qkv, g, (bf16*)out, lse, s);
+        case 256: return launch_attn_fwd_t<256, bf16>((const bf16*)qkv, g, (bf16*)out, lse, s);
+        case 128: return launch_attn_fwd_t<128, bf16>((const bf16*)qkv, g, (bf16*)out, lse, s);
+        default: return launch_attn_fwd_t<64, bf16>((const bf16*)qkv, g, (bf16*)out, lse, s);
     }
 }
 int launch_attn_mfma(int dtype, const void* qkv, int N, int S, int C, void* out, float* lse, hipStream_t s) {
@@ -480,7 +501,7 @@ __global__ void __launch_bounds__(256) attn_bgemm_kernel(const bf16* __restrict_
             }
 }
 
-bool attn_bwd_mfma_supported(int dtype, int N, int S, int C) { return attn_heads_mfma_supported(dtype, N, S, C, 1); }
+bool attn_bwd_mfma_supported(int dtype, int N, int S, int C) { return dtype == DMME_BF16 && attn_heads_mfma_supported(dtype, N, S, C, 1); }
 
 template <int D>
 static int launch_attn_bwd_t(const bf16* qkv, const bf16* O, const bf16* dO, const float* lse, const AttnGeom& g, bf16* P, bf16* dS, bf16* dqkv,

@@ -49,6 +49,7 @@ struct dtype_of<f16> {
 };
 
 __host__ __device__ inline size_t dtype_size(int dt) { return dt == DMME_BF16 || dt == DMME_F16 ? 2 : 4; }
+__host__ __device__ inline bool is16(int dt) { return dt == DMME_BF16 || dt == DMME_F16; }  // the two 16-bit operand types share every kernel
 
 __device__ __forceinline__ float to_f(float v) { return v; }
 __device__ __forceinline__ float to_f(bf16 v) { return (float)v; }
@@ -201,6 +202,8 @@ struct ConvArgs {
     int64_t splitk_cap;
     // accurate mode (fp32 tensors only): every product as three bf16 MFMA passes on hi/lo splits instead of the fp32 MFMA
     int x3;
+    // 16-bit tensors are IEEE half (precision="fp16") instead of bf16: for the launchers that take no dtype argument
+    int f16;
     // pipelined 3x3 kernel, 64-cout bf16 tiles: filter tiles by LDS-DMA into a second buffer instead of through registers
     int dma_b;
     // norms finished by this conv's epilogue (n_gno = 0: none) and, for norm gno[act_k], the consumer's pre-activated input
@@ -239,7 +242,7 @@ int launch_conv_out_thin(const ConvArgs& a, hipStream_t s);
 // K-split-over-waves 3x3 kernel for layers with few output pixels (conv_kw.hip); launch_conv_pipe dispatches to it
 struct ConvTile;
 bool conv_kw_pick(int dtype, const ConvArgs& a, ConvTile& g, int* ni, int* ring, int* bm);
-int launch_conv_kw(const ConvArgs& a, const ConvTile& g, int NI, int ring, int BM, int ksplit, hipStream_t s);
+int launch_conv_kw(int dtype, const ConvArgs& a, const ConvTile& g, int NI, int ring, int BM, int ksplit, hipStream_t s);
 // will the kernel that runs this conv finish the norms consuming its output (ConvArgs::n_gno set; cg[k]: their group sizes)?
 bool conv_gn_direct_query(int dtype, const ConvArgs& a, const int* cg, int n);
 bool conv_gn_direct_ws_query(int dtype, const ConvArgs& a, const int* cg, int n);  // a.gn_cg: the output tensor's own group size

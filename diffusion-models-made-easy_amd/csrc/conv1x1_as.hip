@@ -73,8 +73,9 @@ __device__ __forceinline__ void as_barrier() {
 // GroupNorm affine (+ SiLU) (+ dropout multiplier) of the landed activation tile, in place, by all 512 threads: a ROLLED loop (unrolled
 // over the fragments it was 50 KB of code per launch and spilled); the same operations in the same order as prologue_vec<bf16>.
 // par: [3][K] scale, shift, dropout multiplier of the tile's image (1, 0, 1 where absent: x * 1 + 0 and * 1 are exact)
-template <int K>
+template <int K, typename T>
 __device__ __forceinline__ void as_prologue_tile(char* ldsA, const float* par, int tid, bool silu, bool dm) {
+    typedef typename Vec8<T>::type bf16x8;  // (8 operands of the 16-bit type: bf16 or IEEE half)
     typedef __attribute__((address_space(3))) u32x4_as lv4;
     typedef __attribute__((address_space(3))) f32x4 lf4;
     const lds_c* P3 = (const lds_c*)par;
@@ -104,15 +105,15 @@ __device__ __forceinline__ void as_prologue_tile(char* ldsA, const float* par, i
             }
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = (bf16)v[e];
+        for (int e = 0; e < 8; ++e) x[e] = (T)v[e];
         *p = __builtin_bit_cast(u32x4_as, x);
     }
 }
 
 // 8 waves: 0-3 stream the weights and run the MFMAs, 4-7 take each finished unit out of LDS to memory (see the file comment)
-template <int KCH, bool RES>
+template <int KCH, bool RES, typename T = bf16>
 __global__ void __launch_bounds__(512) conv1x1_as_kernel(ConvArgs a, int HW, int NU) {
-    using T = bf16;
+    typedef typename Vec8<T>::type bf16x8;  // (8 operands of the 16-bit type: bf16 or IEEE half)
     constexpr int K = 64 * KCH, NKS = 4 * KCH;
     constexpr int RING = as_ring(RES), STAGE = as_stage_bytes(RES);
     constexpr int U_BYTES = 64 * KCH * ROW_DATA;  // one unit of weights: [chunk][64 cout rows][128 B]
@@ -151,7 +152,7 @@ __global__ void __launch_bounds__(512) conv1x1_as_kernel(ConvArgs a, int HW, int
         wait_lgkm_all();
         as_barrier();  // (1) tile + unit 0 landed, bias / rows written
         if (has_pro) {
-            as_prologue_tile<K>(ldsA, parL, tid, a.pro_silu != 0, a.dmask != nullptr);
+            as_prologue_tile<K, T>(ldsA, parL, tid, a.pro_silu != 0, a.dmask != nullptr);
             wait_lgkm_all();
             as_barrier();  // (1b) tile normalised
         }
@@ -190,8 +191,8 @@ __global__ void __launch_bounds__(512) conv1x1_as_kernel(ConvArgs a, int HW, int
                     bf16x8 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        o[e] = (bf16)(v0[e] + (float)y[e]);
-                        o[4 + e] = (bf16)(v1[e] + (float)y[4 + e]);
+                        o[e] = (T)(v0[e] + (float)y[e]);
+                        o[4 + e] = (T)(v1[e] + (float)y[4 + e]);
                     }
                     raw = __builtin_bit_cast(uint4, o);
                 } else {
@@ -268,7 +269,7 @@ __global__ void __launch_bounds__(512) conv1x1_as_kernel(ConvArgs a, int HW, int
     AS_STAMP(2);
 
     if (has_pro) {
-        as_prologue_tile<K>(ldsA, parL, tid, a.pro_silu != 0, a.dmask != nullptr);
+        as_prologue_tile<K, T>(ldsA, parL, tid, a.pro_silu != 0, a.dmask != nullptr);
         wait_lgkm_all();
         as_barrier();  // (1b)
     }
@@ -335,9 +336,10 @@ __global__ void __launch_bounds__(512) conv1x1_as_kernel(ConvArgs a, int HW, int
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
-                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bfr[kg & 1][kk]),
-                                                                      __builtin_bit_cast(bf16x8, af[mi][4 * kg + kk]),
-                                                                      kg == 0 && kk == 0 ? fold : acc[mi], 0, 0, 0);
+                {
+                    if (kg == 0 && kk == 0) acc[mi] = fold;
+                    mma16<T>(__builtin_bit_cast(uint4, bfr[kg & 1][kk]), __builtin_bit_cast(uint4, af[mi][4 * kg + kk]), acc[mi]);
+                }
         }
         if (u < 3) AS_STAMP(4 + 3 * u);
         // ---- this wave's 64 px x 32 couts of unit u -> bf16, staged for the store team ----
@@ -359,7 +361,7 @@ __global__ void __launch_bounds__(512) conv1x1_as_kernel(ConvArgs a, int HW, int
             } else {
                 bf16x8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+                for (int e = 0; e < 8; ++e) o[e] = (T)v[e];
                 *reinterpret_cast<bf16x8*>(st + stoff[g]) = o;
             }
         }
@@ -390,7 +392,7 @@ static bool as_stats_cg_ok(int cg) { return cg == 8 || cg == 16 || cg == 32; }
 static bool as_shape_ok(int dtype, const ConvArgs& a) {
     static const bool off = getenv("DMME_NO_CONV1X1_AS") != nullptr;
     static const int min_units = getenv("DMME_AS_MIN_UNITS") ? atoi(getenv("DMME_AS_MIN_UNITS")) : 2;
-    if (off || dtype != DMME_BF16 || a.x3) return false;
+    if (off || !is16(dtype) || a.x3) return false;
     if (a.taps != 1 || a.stride != 1 || a.up || a.in_nchw || a.out_nchw || a.out_silu || a.res2 || a.n_gno) return false;
     if (a.tproj && a.nt != 1) return false;
     const int K = a.C1 + a.C2;
@@ -419,21 +421,25 @@ bool conv1x1_as_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, in
     return true;
 }
 
-template <int KCH, bool RES>
-static int launch_as_inst(const ConvArgs& a, size_t lds, hipStream_t s) {
+template <int KCH, bool RES, typename T>
+static int launch_as_inst_t(const ConvArgs& a, size_t lds, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_as_kernel<KCH, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_as_kernel<KCH, RES, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
     const int64_t M = (int64_t)a.N * a.Hout * a.Wout;
-    hipLaunchKernelGGL((conv1x1_as_kernel<KCH, RES>), dim3((unsigned)(M / 128)), dim3(512), lds, s, a, a.Hout * a.Wout, a.Cout / 64);
+    hipLaunchKernelGGL((conv1x1_as_kernel<KCH, RES, T>), dim3((unsigned)(M / 128)), dim3(512), lds, s, a, a.Hout * a.Wout, a.Cout / 64);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }
+template <int KCH, bool RES>
+static int launch_as_inst(const ConvArgs& a, size_t lds, hipStream_t s) {
+    return a.f16 ? launch_as_inst_t<KCH, RES, f16>(a, lds, s) : launch_as_inst_t<KCH, RES, bf16>(a, lds, s);
+}
 
 int launch_conv1x1_as(const ConvArgs& a, hipStream_t s) {
-    DMME_REQUIRE(conv1x1_as_supported(DMME_BF16, a), DMME_ERR_UNSUPPORTED, "conv1x1_as: unsupported shape");
+    DMME_REQUIRE(conv1x1_as_supported(a.f16 ? DMME_F16 : DMME_BF16, a), DMME_ERR_UNSUPPORTED, "conv1x1_as: unsupported shape");
     const int KCH = (a.C1 + a.C2) / 64;
     const bool res = a.res1 != nullptr;
     const size_t lds = (size_t)as_ring(res) * 64 * KCH * ROW_DATA + as_fold_bytes(a.Cout) + 2 * as_stage_bytes(res);

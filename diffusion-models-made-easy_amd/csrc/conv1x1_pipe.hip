@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256, 2) conv1x1_pipe_kernel(ConvArgs a, int HW
                     const int so = a_n[i] * Cin + cc;
                     if constexpr (sizeof(T) == 2) {
                         if (a.has_gni)
-                            val = prologue_vec_ldsrows(areg[c][i], gni_par + cc, gni_par + Cin + cc, a.dmask ? a.dmask + so : nullptr, a.pro_silu);
+                            val = prologue_vec_ldsrows<T>(areg[c][i], gni_par + cc, gni_par + Cin + cc, a.dmask ? a.dmask + so : nullptr, a.pro_silu);
                         else
                             val = prologue_vec<T>(areg[c][i], a.scale ? a.scale + so : nullptr, a.scale ? a.shift + so : nullptr,
                                                   a.dmask ? a.dmask + so : nullptr, a.pro_silu);
@@ -200,7 +200,7 @@ bool conv1x1_pipe_supported(int dtype, const ConvArgs& a) {
 
 // can the tiled kernel finish the norm in front of this conv itself (its tile inside one image, LDS budget)?
 bool conv1x1_pipe_gn_in_ok(int dtype, const ConvArgs& a) {
-    if (dtype != DMME_BF16 || getenv("DMME_NO_GN_IN_PIPE") || getenv("DMME_NO_GN_IN_PIPE1") || !conv1x1_pipe_supported(dtype, a)) return false;
+    if (!is16(dtype) || getenv("DMME_NO_GN_IN_PIPE") || getenv("DMME_NO_GN_IN_PIPE1") || !conv1x1_pipe_supported(dtype, a)) return false;
     const int pick = pick1(a);
     if (pick < 0) return false;
     const int BM = k1Cand[pick][0], BN = k1Cand[pick][1], HW = a.Hout * a.Wout;
@@ -217,7 +217,7 @@ bool conv1x1_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* 
     }
     const int pick = pick1(a);
     if (pick < 0) return false;
-    const int BM = k1Cand[pick][0], BN = k1Cand[pick][1], HW = a.Hout * a.Wout, vec = dtype == DMME_BF16 ? 8 : 4;
+    const int BM = k1Cand[pick][0], BN = k1Cand[pick][1], HW = a.Hout * a.Wout, vec = is16(dtype) ? 8 : 4;
     if (HW % BM) return false;
     if (a.out_silu || a.out_nchw || a.Cout % BN || a.Cout % vec || !(cg % vec == 0 || (vec == 8 && cg == 4)) || BN % cg) return false;
     *tiles = HW / BM;
@@ -266,6 +266,7 @@ int launch_conv1x1_pipe(int dtype, const ConvArgs& a, hipStream_t s) {
     DMME_REQUIRE(conv1x1_pipe_supported(dtype, a), DMME_ERR_UNSUPPORTED, "conv1x1_pipe: unsupported shape");
     if (conv1x1_as_supported(dtype, a)) return launch_conv1x1_as(a, s);
     if (dtype == DMME_BF16) return launch1_t<bf16>(a, s);
+    if (dtype == DMME_F16) return launch1_t<f16>(a, s);
     return a.x3 ? launch1_t<float, true>(a, s) : launch1_t<float>(a, s);
 }
 
@@ -275,7 +276,7 @@ void conv1x1_pipe_label(int dtype, const ConvArgs& a, char* buf, int cap) {
         return;
     }
     const int pick = pick1(a);
-    snprintf(buf, (size_t)cap, "conv1x1_pipe_kernel<%s,%d,%d>", dtype == DMME_BF16 ? "bf16" : a.x3 ? "float:bf16x3" : "float", pick >= 0 ? k1Cand[pick][0] : 0,
+    snprintf(buf, (size_t)cap, "conv1x1_pipe_kernel<%s,%d,%d>", dtype == DMME_BF16 ? "bf16" : dtype == DMME_F16 ? "f16" : a.x3 ? "float:bf16x3" : "float", pick >= 0 ? k1Cand[pick][0] : 0,
              pick >= 0 ? k1Cand[pick][1] : 0);
 }
 

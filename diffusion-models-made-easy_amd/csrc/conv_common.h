@@ -9,6 +9,26 @@ namespace dmme {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+// the two 16-bit operand types (bf16, and IEEE half: precision="fp16") share every kernel: 8 elements per 16-byte vector, the same LDS
+// images, the same MFMA shape (v_mfma_f32_32x32x16_{bf16,f16}: equal rate); only the conversions and the MFMA opcode differ
+template <typename T>
+struct Vec8 {
+    typedef T type __attribute__((ext_vector_type(8)));
+};
+template <typename T>
+__device__ __forceinline__ void unpack8(const uint4& raw, float (&v)[8]) {
+    const typename Vec8<T>::type x = __builtin_bit_cast(typename Vec8<T>::type, raw);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)x[e];
+}
+template <typename T>
+__device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
+    typename Vec8<T>::type x;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (T)v[e];
+    return __builtin_bit_cast(uint4, x);
+}
 
 constexpr int ROW_DATA = 128;          // data bytes per LDS row (one Cin chunk of one pixel / cout)
 constexpr int ROW_PITCH = ROW_DATA + 16;  // padded pitch
@@ -80,6 +100,11 @@ struct Frag<bf16> {
     static constexpr int KC = 64;
     static constexpr int EPV = 8;
 };
+template <>
+struct Frag<f16> {
+    static constexpr int KC = 64;
+    static constexpr int EPV = 8;
+};
 
 __device__ __forceinline__ void mma_group(const uint4& a, const uint4& b, f32x16& acc, float*) {
     const f32x4 av = __builtin_bit_cast(f32x4, a), bv = __builtin_bit_cast(f32x4, b);
@@ -88,6 +113,14 @@ __device__ __forceinline__ void mma_group(const uint4& a, const uint4& b, f32x16
 }
 __device__ __forceinline__ void mma_group(const uint4& a, const uint4& b, f32x16& acc, bf16*) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_group(const uint4& a, const uint4& b, f32x16& acc, f16*) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+}
+// one 32x32x16 MFMA on 16-bit operands of type T
+template <typename T>
+__device__ __forceinline__ void mma16(const uint4& a, const uint4& b, f32x16& acc) {
+    mma_group(a, b, acc, (T*)nullptr);
 }
 
 // ---- accurate mode ("bf16x3"): fp32 tensors, every product as three bf16 MFMA passes ------------------------------------------
@@ -175,10 +208,10 @@ __device__ __forceinline__ uint4 prologue_vec<float>(uint4 raw, const float* sc,
     }
     return __builtin_bit_cast(uint4, v);
 }
-template <>
-__device__ __forceinline__ uint4 prologue_vec<bf16>(uint4 raw, const float* sc, const float* sh, const float* dm, int pro_silu) {
+template <typename T>
+__device__ __forceinline__ uint4 prologue_vec16(uint4 raw, const float* sc, const float* sh, const float* dm, int pro_silu) {
     if (!sc && !pro_silu && !dm) return raw;
-    bf16x8 x = __builtin_bit_cast(bf16x8, raw);
+    typename Vec8<T>::type x = __builtin_bit_cast(typename Vec8<T>::type, raw);
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = (float)x[j];
@@ -204,8 +237,16 @@ __device__ __forceinline__ uint4 prologue_vec<bf16>(uint4 raw, const float* sc, 
         }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = (bf16)v[j];
+    for (int j = 0; j < 8; ++j) x[j] = (T)v[j];
     return __builtin_bit_cast(uint4, x);
+}
+template <>
+__device__ __forceinline__ uint4 prologue_vec<bf16>(uint4 raw, const float* sc, const float* sh, const float* dm, int pro_silu) {
+    return prologue_vec16<bf16>(raw, sc, sh, dm, pro_silu);
+}
+template <>
+__device__ __forceinline__ uint4 prologue_vec<f16>(uint4 raw, const float* sc, const float* sh, const float* dm, int pro_silu) {
+    return prologue_vec16<f16>(raw, sc, sh, dm, pro_silu);
 }
 
 
@@ -309,12 +350,13 @@ __device__ __forceinline__ void gn_in_scale_shift(const ConvArgs& a, int n, int 
 
 // prologue_vec<bf16> with the scale / shift rows in LDS (a norm finished by this conv: ConvArgs::gni): typed LDS reads - through
 // generic pointers they would be flat loads, which count on vmcnt and would drain the kernels' LDS-DMA queues
+template <typename T = bf16>
 __device__ __forceinline__ uint4 prologue_vec_ldsrows(uint4 raw, const float* sc_lds, const float* sh_lds, const float* dm, int pro_silu) {
     typedef __attribute__((address_space(3))) f32x4 lf4;
     typedef __attribute__((address_space(3))) char lc;
     const lc* s3 = (const lc*)sc_lds;
     const lc* h3 = (const lc*)sh_lds;
-    bf16x8 x = __builtin_bit_cast(bf16x8, raw);
+    typename Vec8<T>::type x = __builtin_bit_cast(typename Vec8<T>::type, raw);
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; e += 4) {
@@ -335,7 +377,7 @@ __device__ __forceinline__ uint4 prologue_vec_ldsrows(uint4 raw, const float* sc
         }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = (bf16)v[e];
+    for (int e = 0; e < 8; ++e) x[e] = (T)v[e];
     return __builtin_bit_cast(uint4, x);
 }
 
@@ -428,14 +470,15 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, int co0, 
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             if (res) {
-                const bf16x8 rv = pv ? __builtin_bit_cast(bf16x8, *pv) : *reinterpret_cast<const bf16x8*>(res + off);
+                typedef typename Vec8<T>::type tx8;
+                const tx8 rv = pv ? __builtin_bit_cast(tx8, *pv) : *reinterpret_cast<const tx8*>(res + off);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
             }
-            bf16x8 o;
+            typename Vec8<T>::type o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-            *reinterpret_cast<bf16x8*>(dst + off) = o;
+            for (int e = 0; e < 8; ++e) o[e] = (T)v[e];
+            *reinterpret_cast<typename Vec8<T>::type*>(dst + off) = o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {  // statistics of the values the consumer reads back (bf16-rounded)
                 const float x0 = (float)o[e], x1 = (float)o[4 + e];
@@ -625,14 +668,14 @@ __device__ __forceinline__ void conv_epilogue_store_direct(const ConvArgs& a, in
             for (int e = 0; e < 4; ++e) x[e] = v[e];
         } else {
             if (res) {
-                const bf16x8 rv = *reinterpret_cast<const bf16x8*>(res + off);
+                const typename Vec8<T>::type rv = *reinterpret_cast<const typename Vec8<T>::type*>(res + off);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
             }
-            bf16x8 o;
+            typename Vec8<T>::type o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-            if (opix >= 0) *reinterpret_cast<bf16x8*>(dst + off) = o;
+            for (int e = 0; e < 8; ++e) o[e] = (T)v[e];
+            if (opix >= 0) *reinterpret_cast<typename Vec8<T>::type*>(dst + off) = o;
             kept[q] = __builtin_bit_cast(uint4, o);
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = (float)o[e];

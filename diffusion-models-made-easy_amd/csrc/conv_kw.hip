@@ -27,9 +27,8 @@ namespace dmme {
 // workgroup the fixed ~5 us (arguments, first round trip, cross-wave sum, epilogue) is then paid for twice the matrix work.
 constexpr int KW_PAR_BYTES = 512;
 
-template <int NI, int RING, bool DENSE, int BM>
+template <int NI, int RING, bool DENSE, int BM, typename T = bf16>
 __global__ void __launch_bounds__(256, 1) conv3x3_kw_kernel(ConvArgs a, ConvTile g, int shTW, int shTH, int ksplit_dbg) {
-    using T = bf16;
     const int ksplit = ksplit_dbg;
     constexpr int KC = 64, EPV = 8, MI = BM / 32, BN = 32 * NI;
     constexpr int U_BYTES = BN * ROW_DATA;  // one unit of filters: BN cout rows of one tap of one 64-channel chunk
@@ -133,7 +132,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_kw_kernel(ConvArgs a, ConvTile
     auto gni_vec = [&](uint4 raw, int piece_src, const float* dm) __attribute__((always_inline)) -> uint4 {
         typedef __attribute__((address_space(3))) f32x4 lf4;
         const lds_c* P3 = (const lds_c*)parW;
-        bf16x8 x = __builtin_bit_cast(bf16x8, raw);
+        typename Vec8<T>::type x = __builtin_bit_cast(typename Vec8<T>::type, raw);
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; e += 4) {
@@ -150,7 +149,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_kw_kernel(ConvArgs a, ConvTile
             for (int e = 0; e < 8; ++e) v[e] *= dm[e];
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = (bf16)v[e];
+        for (int e = 0; e < 8; ++e) x[e] = (T)v[e];
         return __builtin_bit_cast(uint4, x);
     };
     auto halo_issue = [&](int c0) __attribute__((always_inline)) {
@@ -458,7 +457,7 @@ bool conv_kw_pick(int dtype, const ConvArgs& a, ConvTile& g, int* ni_out, int* r
     static const int force_ni = getenv("DMME_KW_NI") ? atoi(getenv("DMME_KW_NI")) : 0;
     static const int force_bm = getenv("DMME_KW_BM") ? atoi(getenv("DMME_KW_BM")) : 0;
     static const int max_ring = getenv("DMME_KW_RING") ? atoi(getenv("DMME_KW_RING")) : 6;
-    if (off || dtype != DMME_BF16 || a.x3) return false;
+    if (off || !is16(dtype) || a.x3) return false;
     const int Cin = a.C1 + a.C2;
     if (a.taps != 9 || a.stride != 1 || a.up == 2 || a.in_nchw || Cin % 64 || a.C1 % 64 || a.Cout < 32) return false;
     if ((int64_t)a.Cout * 9 * Cin >= (1ll << 31) || (int64_t)a.N * a.Hin * a.Win * (a.C1 > a.C2 ? a.C1 : a.C2) >= (1ll << 31)) return false;
@@ -496,21 +495,27 @@ static int ilog2_kw(int v) {
     return s;
 }
 
-template <int NI, int RING, bool DENSE, int BM>
-static int launch_kw_inst(const ConvArgs& a, const ConvTile& g, int ksplit, size_t lds, hipStream_t s) {
+template <int NI, int RING, bool DENSE, int BM, typename T>
+static int launch_kw_inst_t(const ConvArgs& a, const ConvTile& g, int ksplit, size_t lds, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_kw_kernel<NI, RING, DENSE, BM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_kw_kernel<NI, RING, DENSE, BM, T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024));
         attr_done = true;
     }
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)ksplit);
-    hipLaunchKernelGGL((conv3x3_kw_kernel<NI, RING, DENSE, BM>), grid, dim3(256), lds, s, a, g, ilog2_kw(g.TW), ilog2_kw(g.TH), ksplit);
+    hipLaunchKernelGGL((conv3x3_kw_kernel<NI, RING, DENSE, BM, T>), grid, dim3(256), lds, s, a, g, ilog2_kw(g.TW), ilog2_kw(g.TH), ksplit);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }
+static thread_local int g_kw_dtype = DMME_BF16;  // operand type of the launch being dispatched (launch_conv_kw)
+template <int NI, int RING, bool DENSE, int BM>
+static int launch_kw_inst(const ConvArgs& a, const ConvTile& g, int ksplit, size_t lds, hipStream_t s) {
+    return g_kw_dtype == DMME_F16 ? launch_kw_inst_t<NI, RING, DENSE, BM, f16>(a, g, ksplit, lds, s) : launch_kw_inst_t<NI, RING, DENSE, BM, bf16>(a, g, ksplit, lds, s);
+}
 
-int launch_conv_kw(const ConvArgs& a, const ConvTile& g, int NI, int ring, int BM, int ksplit, hipStream_t s) {
+int launch_conv_kw(int dtype, const ConvArgs& a, const ConvTile& g, int NI, int ring, int BM, int ksplit, hipStream_t s) {
+    g_kw_dtype = dtype;
     const size_t lds = kw_lds(a, g, BM, NI, ring);
     const bool dense = kw_dense(a, g, BM);
 #define DMME_KW_CASE(NI_, RING_)                                                                                       \

@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a, ConvTile g) 
 }
 
 bool conv_mfma_supported(int dtype, const ConvArgs& a) {
-    const int KC = dtype == DMME_BF16 ? 64 : 32;
+    const int KC = is16(dtype) ? 64 : 32;
     if (a.in_nchw) return false;
     if ((int64_t)a.N * a.Hout * a.Wout * a.Cout >= (1ll << 31)) return false;  // 32-bit offsets in the epilogue
     if (a.taps != 9 && a.taps != 1) return false;
@@ -191,7 +191,7 @@ bool conv_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px)
     ConvTile g{};
     const int pick = pick_tile(a, g);
     if (pick < 0) return false;
-    if (!stats_tile_ok(a, g, kCand[pick][1], cg, dtype == DMME_BF16 ? 8 : 4)) return false;
+    if (!stats_tile_ok(a, g, kCand[pick][1], cg, is16(dtype) ? 8 : 4)) return false;
     *tiles = g.tiles_x * g.tiles_y;
     *px = kCand[pick][0];
     return true;
@@ -200,13 +200,14 @@ bool conv_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px)
 void conv_mfma_label(int dtype, const ConvArgs& a, char* buf, int cap) {
     ConvTile g{};
     const int pick = pick_tile(a, g);
-    snprintf(buf, (size_t)cap, "conv_mfma_kernel<%s,%d,%d,%d>", dtype == DMME_BF16 ? "bf16" : a.x3 ? "float:bf16x3" : "float", a.taps,
+    snprintf(buf, (size_t)cap, "conv_mfma_kernel<%s,%d,%d,%d>", dtype == DMME_BF16 ? "bf16" : dtype == DMME_F16 ? "f16" : a.x3 ? "float:bf16x3" : "float", a.taps,
              pick >= 0 ? kCand[pick][0] : 0, pick >= 0 ? kCand[pick][1] : 0);
 }
 
 int launch_conv_mfma(int dtype, const ConvArgs& a, hipStream_t s) {
     DMME_REQUIRE(conv_mfma_supported(dtype, a), DMME_ERR_UNSUPPORTED, "conv_mfma: unsupported shape");
     if (dtype == DMME_BF16) return a.taps == 9 ? launch_sized<bf16, 9>(a, s) : launch_sized<bf16, 1>(a, s);
+    if (dtype == DMME_F16) return a.taps == 9 ? launch_sized<f16, 9>(a, s) : launch_sized<f16, 1>(a, s);
     if (a.x3) return a.taps == 9 ? launch_sized<float, 9, true>(a, s) : launch_sized<float, 1, true>(a, s);
     return a.taps == 9 ? launch_sized<float, 9>(a, s) : launch_sized<float, 1>(a, s);
 }

@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(256, GT == 9 ? 1 : 2) conv3x3_pipe_kernel(Conv
                 const int so = a_ss[i] + cc;
                 if constexpr (sizeof(T) == 2) {
                     if (a.has_gni)
-                        val = prologue_vec_ldsrows(areg[i], gni_par + cc, gni_par + Cin + cc, a.dmask ? a.dmask + so : nullptr, a.pro_silu);
+                        val = prologue_vec_ldsrows<T>(areg[i], gni_par + cc, gni_par + Cin + cc, a.dmask ? a.dmask + so : nullptr, a.pro_silu);
                     else
                         val = prologue_vec<T>(areg[i], a.scale ? a.scale + so : nullptr, a.scale ? a.shift + so : nullptr,
                                               a.dmask ? a.dmask + so : nullptr, a.pro_silu);
@@ -414,9 +414,8 @@ __device__ __forceinline__ void ws_fill_par_gni(const ConvArgs& a, int n, bool w
     }
 }
 
-template <int PIPE_UA>
+template <int PIPE_UA, typename T = bf16>
 __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTile g, int shTW, int shTH, int ntiles) {
-    using T = bf16;
     constexpr int KC = 64, EPV = 8, BN = 128, MI = 4, NI = 2, UB = BN / 32;  // BM = 256
     constexpr int R_BYTES = BN * ROW_DATA;  // one tap
     constexpr int A_PITCH = ROW_DATA + 16;  // halo rows are padded, not swizzled: fragment reads use immediate offsets from one base
@@ -533,8 +532,9 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         auto store_A = [&](int i, char* dstA) __attribute__((always_inline)) {
             u32x4 val = areg[i];
             if (has_pro) {
-                const bf16x8 x = __builtin_bit_cast(bf16x8, val);
-                bf16x8 o;
+                typedef typename Vec8<T>::type tx8;
+                const tx8 x = __builtin_bit_cast(tx8, val);
+                tx8 o;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float v0 = fmaf((float)x[q], ps0[q], ph0[q]), v1 = fmaf((float)x[4 + q], ps1[q], ph1[q]);
@@ -542,8 +542,8 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
                         v0 = silu_fast(v0);
                         v1 = silu_fast(v1);
                     }
-                    o[q] = (bf16)(v0 * pm0[q]);
-                    o[4 + q] = (bf16)(v1 * pm1[q]);
+                    o[q] = (T)(v0 * pm0[q]);
+                    o[4 + q] = (T)(v1 * pm1[q]);
                 }
                 val = __builtin_bit_cast(u32x4, o);
             }
@@ -745,7 +745,7 @@ static size_t pipe_lds(const ConvTile& g, int BN, int GT) { return (size_t)g.a_r
 // the DMA filter path (bf16, GT = 3, 64-cout tiles) needs a second filter buffer inside the 2-workgroups-per-CU budget
 static bool pipe_dma_ok(int dtype, const ConvTile& g, int BN, int GT) {
     static const bool off = getenv("DMME_NO_PIPE_DMA") != nullptr;
-    return !off && dtype == DMME_BF16 && GT == 3 && BN == 64 && pipe_lds(g, BN, GT) + (size_t)GT * BN * ROW_DATA <= 80 * 1024;
+    return !off && is16(dtype) && GT == 3 && BN == 64 && pipe_lds(g, BN, GT) + (size_t)GT * BN * ROW_DATA <= 80 * 1024;
 }
 
 static int ilog2(int v) {
@@ -840,7 +840,7 @@ static int kw_ksplit(const ConvArgs& a, const ConvTile& g) {
 template <typename T>
 static int launch_kw_t(const ConvArgs& a, const ConvTile& gk, int ni, int ring, int bm, hipStream_t s) {
     const int ksplit = kw_ksplit(a, gk);
-    const int rc = launch_conv_kw(a, gk, ni, ring, bm, ksplit, s);
+    const int rc = launch_conv_kw(dtype_of<T>::value, a, gk, ni, ring, bm, ksplit, s);
     if (rc != DMME_OK) return rc;
     if (ksplit > 1) {
         const int64_t total4 = (int64_t)a.N * a.Hout * a.Wout * (a.Cout / 4);
@@ -862,15 +862,15 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
         ConvTile gw{};
         const int ws = ws_off ? 0 : ws_pick(a, gw);
         if (ws) {
-            static bool ws_attr = false;
+            static bool ws_attr = false;  // (one flag per instantiation of this launcher, i.e. per T)
             if (!ws_attr) {
-                const int rc0 = set_lds_limit(conv3x3_ws2_kernel<11>, 160 * 1024);
+                const int rc0 = set_lds_limit(conv3x3_ws2_kernel<11, T>, 160 * 1024);
                 if (rc0 != DMME_OK) return rc0;
                 ws_attr = true;
             }
             const int ntiles = gw.tiles_m * gw.tiles_n;
             const dim3 wgrid((unsigned)(ntiles < 256 ? ntiles : 256));
-            hipLaunchKernelGGL((conv3x3_ws2_kernel<11>), wgrid, dim3(512), ws2_lds(a, gw), s, a, gw, ilog2(gw.TW), ilog2(gw.TH), ntiles);
+            hipLaunchKernelGGL((conv3x3_ws2_kernel<11, T>), wgrid, dim3(512), ws2_lds(a, gw), s, a, gw, ilog2(gw.TW), ilog2(gw.TH), ntiles);
             DMME_CHECK_LAUNCH();
             return DMME_OK;
         }
@@ -878,11 +878,11 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
         ConvTile gk{};
         int kni = 0, kring = 0, kbm = 0;
-        if (kw_takes(DMME_BF16, a, pick, gk, &kni, &kring, &kbm)) return launch_kw_t<T>(a, gk, kni, kring, kbm, s);
+        if (kw_takes(dtype_of<T>::value, a, pick, gk, &kni, &kring, &kbm)) return launch_kw_t<T>(a, gk, kni, kring, kbm, s);
     }
     size_t lds = pipe_lds(g, kPipeCand[pick][1], kPipeCand[pick][2]);
     ConvArgs ad = a;
-    ad.dma_b = (sizeof(T) == 2 && !ACC3 && pipe_dma_ok(DMME_BF16, g, kPipeCand[pick][1], kPipeCand[pick][2])) ? 1 : 0;
+    ad.dma_b = (sizeof(T) == 2 && !ACC3 && pipe_dma_ok(dtype_of<T>::value, g, kPipeCand[pick][1], kPipeCand[pick][2])) ? 1 : 0;
     if (ad.dma_b) lds += (size_t)kPipeCand[pick][2] * kPipeCand[pick][1] * ROW_DATA;
     if (a.has_gni) lds += (size_t)2 * (a.C1 + a.C2) * 4;  // scale / shift rows behind the operand buffers
     if (a.n_gno && lds < (size_t)kDirectLds) lds = kDirectLds;
@@ -918,11 +918,12 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
 int launch_conv_pipe(int dtype, const ConvArgs& a, hipStream_t s) {
     DMME_REQUIRE(conv_pipe_supported(dtype, a), DMME_ERR_UNSUPPORTED, "conv_pipe: unsupported shape");
     if (dtype == DMME_BF16) return launch_pipe_t<bf16>(a, s);
+    if (dtype == DMME_F16) return launch_pipe_t<f16>(a, s);
     return a.x3 ? launch_pipe_t<float, true>(a, s) : launch_pipe_t<float>(a, s);
 }
 
 bool conv_gn_in_query(int dtype, const ConvArgs& a) {
-    if (getenv("DMME_NO_GN_IN") || dtype != DMME_BF16) return false;  // (read per plan build, like DMME_NO_GN_DIRECT: the tests toggle it)
+    if (getenv("DMME_NO_GN_IN") || !is16(dtype)) return false;  // (read per plan build, like DMME_NO_GN_DIRECT: the tests toggle it)
     if (conv_out_thin_supported(dtype, a)) return true;       // the thin output conv keeps its image's rows in LDS anyway
     if (a.taps == 1) return conv1x1_as_supported(dtype, a) || conv1x1_pipe_gn_in_ok(dtype, a);  // the store team / the tiled kernel's preamble
     if (!conv_pipe_supported(dtype, a)) return false;
@@ -949,10 +950,10 @@ bool conv_gn_in_query(int dtype, const ConvArgs& a) {
 bool conv_gn_direct_query(int dtype, const ConvArgs& a, const int* cg, int n) {
     static const bool off = getenv("DMME_NO_GN_DIRECT") != nullptr;
     if (off || n < 1 || n > 2 || a.taps != 9 || !conv_pipe_supported(dtype, a)) return false;
-    const int VEC = dtype == DMME_BF16 ? 8 : 4;
+    const int VEC = is16(dtype) ? 8 : 4;
     const int HW = a.Hout * a.Wout;
     if (a.out_silu || a.out_nchw || a.res2 || a.Cout % VEC || HW > 64 || (HW & (HW - 1))) return false;
-    if (dtype == DMME_BF16 && !getenv("DMME_NO_WS")) {
+    if (is16(dtype) && !getenv("DMME_NO_WS")) {
         ConvTile gw{};
         if (ws_pick(a, gw)) return false;  // (conv_gn_direct_ws_query answers for that kernel)
     }
@@ -973,7 +974,7 @@ bool conv_gn_direct_query(int dtype, const ConvArgs& a, const int* cg, int n) {
         BN = 32 * kni;
         BM = kbm;
     } else {
-        if (kPipeCand[pick][0] != 64 || pipe_ksplit(b, g, pick, dtype == DMME_BF16 ? 64 : 32) != 1) return false;
+        if (kPipeCand[pick][0] != 64 || pipe_ksplit(b, g, pick, is16(dtype) ? 64 : 32) != 1) return false;
         BN = kPipeCand[pick][1];
     }
     if (g.TH != a.Hout || g.TW != a.Wout || g.TN * g.TH * g.TW != BM || a.Cout % BN) return false;  // whole images, whole cout tiles
@@ -987,7 +988,7 @@ bool conv_gn_direct_query(int dtype, const ConvArgs& a, const int* cg, int n) {
 // (scale / shift / {mean, rstd} only - the first pass is in memory before the statistics exist, so no pre-activated output)
 bool conv_gn_direct_ws_query(int dtype, const ConvArgs& a, const int* cg, int n) {
     static const bool off = getenv("DMME_NO_GN_DIRECT") != nullptr || getenv("DMME_NO_GN_DIRECT_WS") != nullptr;
-    if (off || dtype != DMME_BF16 || getenv("DMME_NO_WS") || n < 1 || n > 2 || !conv_pipe_supported(dtype, a)) return false;
+    if (off || !is16(dtype) || getenv("DMME_NO_WS") || n < 1 || n > 2 || !conv_pipe_supported(dtype, a)) return false;
     ConvTile gw{};
     if (!ws_pick(a, gw) || gw.TH != a.Hout || gw.TW != a.Wout || gw.TH * gw.TW != 256) return false;
     const int cgs = a.gn_cg;  // this tensor's own group size
@@ -1000,7 +1001,7 @@ bool conv_gn_direct_ws_query(int dtype, const ConvArgs& a, const int* cg, int n)
 }
 
 bool conv_pipe_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px) {
-    if (dtype == DMME_BF16 && !getenv("DMME_NO_WS")) {  // the wave-specialised kernel's tile, when it will run this conv
+    if (is16(dtype) && !getenv("DMME_NO_WS")) {  // the wave-specialised kernel's tile, when it will run this conv
         ConvTile gw{};
         const int ws = ws_pick(a, gw);
         if (ws) {
@@ -1023,14 +1024,14 @@ bool conv_pipe_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int
             return true;
         }
     }
-    if (!stats_tile_ok(a, g, kPipeCand[pick][1], cg, dtype == DMME_BF16 ? 8 : 4)) return false;
+    if (!stats_tile_ok(a, g, kPipeCand[pick][1], cg, is16(dtype) ? 8 : 4)) return false;
     *tiles = g.tiles_x * g.tiles_y;
     *px = kPipeCand[pick][0];
     return true;
 }
 
 void conv_pipe_label(int dtype, const ConvArgs& a, char* buf, int cap) {
-    if (dtype == DMME_BF16 && !getenv("DMME_NO_WS")) {
+    if (is16(dtype) && !getenv("DMME_NO_WS")) {
         ConvTile gw{};
         const int ws = ws_pick(a, gw);
         if (ws) {
@@ -1048,7 +1049,7 @@ void conv_pipe_label(int dtype, const ConvArgs& a, char* buf, int cap) {
             return;
         }
     }
-    snprintf(buf, (size_t)cap, "conv3x3_pipe_kernel<%s,%d,%d,%d,%d>", dtype == DMME_BF16 ? "bf16" : a.x3 ? "float:bf16x3" : "float",
+    snprintf(buf, (size_t)cap, "conv3x3_pipe_kernel<%s,%d,%d,%d,%d>", dtype == DMME_BF16 ? "bf16" : dtype == DMME_F16 ? "f16" : a.x3 ? "float:bf16x3" : "float",
              pick >= 0 ? kPipeCand[pick][0] : 0, pick >= 0 ? kPipeCand[pick][1] : 0, pick >= 0 ? kPipeCand[pick][2] : 0,
              pick >= 0 ? kPipeUA[pick] : 0);
 }

@@ -16,9 +16,9 @@ namespace dmme {
 constexpr int kThinMaxC = 512;
 
 // NT: 32-column tiles of (cout, tap) pairs (1: Cout <= 3, 2: Cout <= 7)
-template <int NT>
+template <int NT, typename T = bf16>
 __global__ void __launch_bounds__(256) conv_out_thin_kernel(ConvArgs a, int R) {
-    using T = bf16;
+    typedef typename Vec8<T>::type bf16x8;  // (8 operands of the kernel's 16-bit type; the name predates precision="fp16")
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int C = a.C1, W = a.Wout, H = a.Hout, NCOL = a.Cout * 9;
     float* par = reinterpret_cast<float*>(lds);  // [2][C] scale, shift of the band's image
@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) conv_out_thin_kernel(ConvArgs a, int R) {
             for (int kg = 0; kg < 8; ++kg) {
                 bf16x8 v;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+                for (int e = 0; e < 8; ++e) v[e] = (T)0.f;
                 if (kc + kg < ksteps && nc < NCOL) v = *reinterpret_cast<const bf16x8*>(wb + (int64_t)nc * C + (kc + kg) * 16 + 8 * h);
                 wfrag[t][kg] = v;
             }
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256) conv_out_thin_kernel(ConvArgs a, int R) {
                 uint4 av = prologue_vec<T>(raw[kg], a.scale ? par + c0 : nullptr, a.scale ? par + C + c0 : nullptr, nullptr, a.pro_silu);
                 if (!in) av = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), wfrag[t][kg], acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) mma16<T>(av, __builtin_bit_cast(uint4, wfrag[t][kg]), acc[t]);
             }
         }
         // D[row = pixel][col = (cout, tap)]: lane = column r, registers = pixel rows (j & 3) + 8 (j >> 2) + 4 h
@@ -128,7 +128,7 @@ static int thin_rows(const ConvArgs& a) {  // band height: the z image of R + 2 
 
 bool conv_out_thin_supported(int dtype, const ConvArgs& a) {
     static const bool off = getenv("DMME_NO_CONV_THIN") != nullptr;
-    if (off || dtype != DMME_BF16 || a.x3) return false;
+    if (off || !is16(dtype) || a.x3) return false;
     if (a.taps != 9 || a.stride != 1 || a.up || a.C2 || a.in_nchw || !a.out_nchw || a.out_silu || a.tproj || a.res1 || a.dmask || a.gn_part || a.n_gno)
         return false;
     if (a.Cout * 9 > 64 || a.C1 % 16 || a.C1 > kThinMaxC || a.Wout % 32 || a.Hin != a.Hout || a.Win != a.Wout) return false;
@@ -141,10 +141,15 @@ int launch_conv_out_thin(const ConvArgs& a, hipStream_t s) {
     const int NT = a.Cout * 9 <= 32 ? 1 : 2;
     const size_t lds = (size_t)(R + 2) * a.Wout * (32 * NT + 1) * 4 + (size_t)2 * a.C1 * 4;
     const dim3 grid((unsigned)(a.N * (a.Hout / R)));
-    if (NT == 1)
-        hipLaunchKernelGGL(conv_out_thin_kernel<1>, grid, dim3(256), lds, s, a, R);
+    if (a.f16) {
+        if (NT == 1)
+            hipLaunchKernelGGL((conv_out_thin_kernel<1, f16>), grid, dim3(256), lds, s, a, R);
+        else
+            hipLaunchKernelGGL((conv_out_thin_kernel<2, f16>), grid, dim3(256), lds, s, a, R);
+    } else if (NT == 1)
+        hipLaunchKernelGGL((conv_out_thin_kernel<1, bf16>), grid, dim3(256), lds, s, a, R);
     else
-        hipLaunchKernelGGL(conv_out_thin_kernel<2>, grid, dim3(256), lds, s, a, R);
+        hipLaunchKernelGGL((conv_out_thin_kernel<2, bf16>), grid, dim3(256), lds, s, a, R);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }

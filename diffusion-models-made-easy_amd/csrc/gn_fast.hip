@@ -19,6 +19,8 @@ __device__ __forceinline__ void load_vec_gn(const T* p, float (&v)[16 / sizeof(T
     const uint4 raw = *reinterpret_cast<const uint4*>(p);
     if constexpr (sizeof(T) == 4) {
         v[0] = __uint_as_float(raw.x); v[1] = __uint_as_float(raw.y); v[2] = __uint_as_float(raw.z); v[3] = __uint_as_float(raw.w);
+    } else if constexpr (__is_same(T, f16)) {
+        unpack8<f16>(raw, v);
     } else {
         v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
         v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
@@ -53,8 +55,8 @@ __global__ void __launch_bounds__(256) gn_partial_kernel(const T* __restrict__ s
                 const float4 f = __builtin_bit_cast(float4, raw);
                 v[sw][0] = f.x; v[sw][1] = f.y; v[sw][2] = f.z; v[sw][3] = f.w;
             } else {
-                typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-                const bf16x8 b = __builtin_bit_cast(bf16x8, raw);
+                typedef T tx8 __attribute__((ext_vector_type(8)));  // bf16 or IEEE half
+                const tx8 b = __builtin_bit_cast(tx8, raw);
 #pragma unroll
                 for (int j = 0; j < EPV; ++j) v[sw][j] = (float)b[j];
             }
@@ -382,12 +384,12 @@ __global__ void __launch_bounds__(256) gn_small_kernel(const T* __restrict__ s1,
 }
 
 static bool gn_small_supported(int dtype, int HW, int C1, int C2, int groups) {
-    const int EPV = dtype == DMME_BF16 ? 8 : 4, C = C1 + C2;
+    const int EPV = is16(dtype) ? 8 : 4, C = C1 + C2;
     return HW <= 64 && C <= 512 && groups <= 64 && C % groups == 0 && C1 % EPV == 0 && C2 % EPV == 0 && C / EPV <= 256 && !getenv("DMME_NO_GN_SMALL");
 }
 
 static bool gn_geometry(int dtype, int HW, int C1, int C2, int groups, int& chunk_px, int& nsweeps, int& nchunks) {
-    const int EPV = dtype == DMME_BF16 ? 8 : 4;
+    const int EPV = is16(dtype) ? 8 : 4;
     const int C = C1 + C2;
     if (C % EPV || C1 % EPV || groups > 256 || C % groups) return false;
     const int VPP = C / EPV;
@@ -431,6 +433,9 @@ int launch_gn_fast(int dtype, const void* src1, const void* src2, int N, int HW,
         if (dtype == DMME_BF16)
             hipLaunchKernelGGL(gn_small_kernel<bf16>, dim3(N), dim3(256), 0, s, (const bf16*)src1, (const bf16*)src2, HW, C1, C2, groups, gamma, beta,
                                eps, scale, shift, mean_rstd, (bf16*)act, act_silu, dmask);
+        else if (dtype == DMME_F16)
+            hipLaunchKernelGGL(gn_small_kernel<f16>, dim3(N), dim3(256), 0, s, (const f16*)src1, (const f16*)src2, HW, C1, C2, groups, gamma, beta,
+                               eps, scale, shift, mean_rstd, (f16*)act, act_silu, dmask);
         else
             hipLaunchKernelGGL(gn_small_kernel<float>, dim3(N), dim3(256), 0, s, (const float*)src1, (const float*)src2, HW, C1, C2, groups, gamma,
                                beta, eps, scale, shift, mean_rstd, (float*)act, act_silu, dmask);
@@ -445,6 +450,9 @@ int launch_gn_fast(int dtype, const void* src1, const void* src2, int N, int HW,
     dim3 grid(nchunks, N);
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(gn_partial_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)src1, (const bf16*)src2, HW, C1, C2,
+                           groups, chunk_px, nsweeps, partial);
+    else if (dtype == DMME_F16)
+        hipLaunchKernelGGL(gn_partial_kernel<f16>, grid, dim3(256), 0, s, (const f16*)src1, (const f16*)src2, HW, C1, C2,
                            groups, chunk_px, nsweeps, partial);
     else
         hipLaunchKernelGGL(gn_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)src1, (const float*)src2, HW, C1,

@@ -187,10 +187,10 @@ __global__ void __launch_bounds__(256) conv_in_mfma_kernel(ConvArgs a, int nbloc
                 // bf16: the wave's 32 pixels x (32 * CT) couts go through LDS so every global store writes whole pixel rows
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
-                    typedef __bf16 bf16x4_g __attribute__((ext_vector_type(4)));
+                    typedef T bf16x4_g __attribute__((ext_vector_type(4)));  // (bf16 or IEEE half)
                     bf16x4_g v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (__bf16)acc[4 * gq + e];
+                    for (int e = 0; e < 4; ++e) v[e] = (T)acc[4 * gq + e];
                     *reinterpret_cast<bf16x4_g*>(st + r * PITCH + ct * 32 + 8 * gq + 4 * h) = v;
                     if (a.gn_part) {
                         // fused GroupNorm partial (groups of 4 channels = this register group): {mean, M2} of the 32 pixels x
@@ -242,7 +242,7 @@ static bool conv_in_mfma_supported(const ConvArgs& a) {
 
 // the first-conv kernel can emit GroupNorm partials of its output: one per 32-pixel block, groups of exactly 4 channels
 bool conv_in_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px) {
-    if (dtype != DMME_BF16 || cg != 4 || !conv_in_mfma_supported(a) || (a.Hout * a.Wout) % 32) return false;
+    if (!is16(dtype) || cg != 4 || !conv_in_mfma_supported(a) || (a.Hout * a.Wout) % 32) return false;
     *tiles = a.Hout * a.Wout / 32;
     *px = 32;
     return true;
@@ -266,6 +266,8 @@ int launch_conv_generic(int dtype, const ConvArgs& a, hipStream_t s) {
 #define DMME_CIN(TT, CT) hipLaunchKernelGGL((conv_in_mfma_kernel<TT, CT>), dim3(grid), dim3(256), 0, s, a, nblocks)
         if (dtype == DMME_BF16) {
             if (a.Cout == 128) DMME_CIN(bf16, 4); else if (a.Cout == 64) DMME_CIN(bf16, 2); else DMME_CIN(bf16, 1);
+        } else if (dtype == DMME_F16) {
+            if (a.Cout == 128) DMME_CIN(f16, 4); else if (a.Cout == 64) DMME_CIN(f16, 2); else DMME_CIN(f16, 1);
         } else {
             if (a.Cout == 128) DMME_CIN(float, 4); else if (a.Cout == 64) DMME_CIN(float, 2); else DMME_CIN(float, 1);
         }
@@ -280,6 +282,8 @@ int launch_conv_generic(int dtype, const ConvArgs& a, hipStream_t s) {
         const size_t lds = (size_t)9 * a.C1 * a.Cout * 4;
         if (dtype == DMME_BF16)
             hipLaunchKernelGGL(conv_in_kernel<bf16>, dim3(blocks), dim3(256), lds, s, a, ppb);
+        else if (dtype == DMME_F16)
+            hipLaunchKernelGGL(conv_in_kernel<f16>, dim3(blocks), dim3(256), lds, s, a, ppb);
         else
             hipLaunchKernelGGL(conv_in_kernel<float>, dim3(blocks), dim3(256), lds, s, a, ppb);
         DMME_CHECK_LAUNCH();
@@ -291,6 +295,8 @@ int launch_conv_generic(int dtype, const ConvArgs& a, hipStream_t s) {
     if (blocks > 65536) blocks = 65536;
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(conv_generic_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else if (dtype == DMME_F16)
+        hipLaunchKernelGGL(conv_generic_kernel<f16>, dim3((unsigned)blocks), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL(conv_generic_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, a);
     DMME_CHECK_LAUNCH();
@@ -342,6 +348,9 @@ int launch_gn_generic(int dtype, const void* src1, const void* src2, int N, int 
     dim3 grid(groups, N);
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(gn_generic_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)src1, (const bf16*)src2, HW,
+                           C1, C2, groups, gamma, beta, eps, scale, shift, mean_rstd);
+    else if (dtype == DMME_F16)
+        hipLaunchKernelGGL(gn_generic_kernel<f16>, grid, dim3(256), 0, s, (const f16*)src1, (const f16*)src2, HW,
                            C1, C2, groups, gamma, beta, eps, scale, shift, mean_rstd);
     else
         hipLaunchKernelGGL(gn_generic_kernel<float>, grid, dim3(256), 0, s, (const float*)src1, (const float*)src2,
@@ -451,6 +460,8 @@ int launch_attn_heads(int dtype, const void* qkv, int N, int S, int C, int heads
         if (lds16 <= 64 * 1024) {
             if (dtype == DMME_BF16)
                 hipLaunchKernelGGL(attn_s16_kernel<bf16>, dim3((unsigned)(N * heads)), dim3(256), lds16, s, (const bf16*)qkv, C, heads, N, (bf16*)out);
+            else if (dtype == DMME_F16)
+                hipLaunchKernelGGL(attn_s16_kernel<f16>, dim3((unsigned)(N * heads)), dim3(256), lds16, s, (const f16*)qkv, C, heads, N, (f16*)out);
             else
                 hipLaunchKernelGGL(attn_s16_kernel<float>, dim3((unsigned)(N * heads)), dim3(256), lds16, s, (const float*)qkv, C, heads, N, (float*)out);
             DMME_CHECK_LAUNCH();
@@ -462,6 +473,8 @@ int launch_attn_heads(int dtype, const void* qkv, int N, int S, int C, int heads
     dim3 grid(S, N * heads);
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(attn_generic_kernel<bf16>, grid, dim3(256), lds, s, (const bf16*)qkv, S, C, heads, N, (bf16*)out);
+    else if (dtype == DMME_F16)
+        hipLaunchKernelGGL(attn_generic_kernel<f16>, grid, dim3(256), lds, s, (const f16*)qkv, S, C, heads, N, (f16*)out);
     else
         hipLaunchKernelGGL(attn_generic_kernel<float>, grid, dim3(256), lds, s, (const float*)qkv, S, C, heads, N, (float*)out);
     DMME_CHECK_LAUNCH();
@@ -535,6 +548,9 @@ int launch_linear_wave(int dtype, const float* in, int nt, int K, const void* W,
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(linear_wave_kernel<bf16>, grid, dim3(256), 0, s, in, nt, K, (const bf16*)W, bias, Nout,
                            out_silu, out);
+    else if (dtype == DMME_F16)
+        hipLaunchKernelGGL(linear_wave_kernel<f16>, grid, dim3(256), 0, s, in, nt, K, (const f16*)W, bias, Nout,
+                           out_silu, out);
     else
         hipLaunchKernelGGL(linear_wave_kernel<float>, grid, dim3(256), 0, s, in, nt, K, (const float*)W, bias, Nout,
                            out_silu, out);
@@ -569,6 +585,8 @@ int launch_nchw_to_nhwc(int dtype, const float* src, int N, int C, int HW, void*
     const int64_t total = (int64_t)N * C * HW;
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, src, C, HW, (bf16*)dst, total);
+    else if (dtype == DMME_F16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, s, src, C, HW, (f16*)dst, total);
     else
         hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, src, C, HW, (float*)dst, total);
     DMME_CHECK_LAUNCH();
@@ -578,6 +596,8 @@ int launch_nhwc_to_nchw(int dtype, const void* src, int N, int C, int HW, float*
     const int64_t total = (int64_t)N * C * HW;
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)src, C, HW, dst, total);
+    else if (dtype == DMME_F16)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, s, (const f16*)src, C, HW, dst, total);
     else
         hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)src, C, HW, dst, total);
     DMME_CHECK_LAUNCH();
@@ -599,6 +619,8 @@ int launch_pack_weight(int dtype, const float* src, int Cout, int Cin, int taps,
     const int64_t total = (int64_t)Cout * Cin * taps;
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, src, Cin, taps, (bf16*)dst, total);
+    else if (dtype == DMME_F16)
+        hipLaunchKernelGGL(pack_weight_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, s, src, Cin, taps, (f16*)dst, total);
     else
         hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, src, Cin, taps, (float*)dst, total);
     DMME_CHECK_LAUNCH();
@@ -714,6 +736,8 @@ int launch_pack_table(int dtype, const PackItem* items_dev, int n_items, const f
     if (n_items == 0) return DMME_OK;
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(pack_table_kernel<bf16>, dim3(n_items), dim3(256), 0, s, items_dev, ref_flat, (char*)packed);
+    else if (dtype == DMME_F16)
+        hipLaunchKernelGGL(pack_table_kernel<f16>, dim3(n_items), dim3(256), 0, s, items_dev, ref_flat, (char*)packed);
     else
         hipLaunchKernelGGL(pack_table_kernel<float>, dim3(n_items), dim3(256), 0, s, items_dev, ref_flat, (char*)packed);
     DMME_CHECK_LAUNCH();

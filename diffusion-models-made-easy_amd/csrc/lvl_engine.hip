@@ -52,37 +52,6 @@ size_t lvl_engine_lds_bytes() { return LVL_LDS; }
 typedef unsigned u32x4_lv __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4_lv lds_u32x4_lv;
 
-template <typename T>
-struct Vec8 {
-    typedef T type __attribute__((ext_vector_type(8)));
-};
-
-template <typename T>
-__device__ __forceinline__ void mma16(const uint4& a, const uint4& b, f32x16& acc);
-template <>
-__device__ __forceinline__ void mma16<bf16>(const uint4& a, const uint4& b, f32x16& acc) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
-}
-template <>
-__device__ __forceinline__ void mma16<f16>(const uint4& a, const uint4& b, f32x16& acc) {
-    typedef f16 f16x8_lv __attribute__((ext_vector_type(8)));
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_lv, a), __builtin_bit_cast(f16x8_lv, b), acc, 0, 0, 0);
-}
-
-template <typename T>
-__device__ __forceinline__ void unpack8(const uint4& raw, float (&v)[8]) {
-    const typename Vec8<T>::type x = __builtin_bit_cast(typename Vec8<T>::type, raw);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (float)x[e];
-}
-template <typename T>
-__device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
-    typename Vec8<T>::type x;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = (T)v[e];
-    return __builtin_bit_cast(uint4, x);
-}
-
 // 16-byte sc1 (system-coherent level 1: L1-bypassing load, write-through store) accesses through a buffer resource whose base is
 // wave-uniform; the byte offset is per lane.  Device pass only (the host pass of hipcc parses kernel bodies too).
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -756,6 +756,7 @@ void fill_conv(const dmme_plan* P, const Op& o, const char* packed, const float*
     const int64_t es = (int64_t)dtype_size(P->dtype);
     (void)es;
     a.x3 = P->x3;
+    a.f16 = P->dtype == DMME_F16;
     a.N = P->B;
     if (o.src1 == -2) {
         a.src1 = x;
@@ -1567,7 +1568,7 @@ int run_op(const dmme_plan* P, const Op& o, const char* pk, const float* x, cons
 // kernel label + algorithmic flops / bytes of one op (bench.py's roofline accounting)
 void op_account(const dmme_plan* P, const Op& o, char* label, int cap, double* flops, double* bytes) {
     const double es = (double)dtype_size(P->dtype);
-    const char* tn = P->dtype == DMME_BF16 ? "bf16" : "float";  // (the conv labels add ":bf16x3" themselves)
+    const char* tn = P->dtype == DMME_BF16 ? "bf16" : P->dtype == DMME_F16 ? "f16" : "float";  // (the conv labels add ":bf16x3" themselves)
     const double B = P->B;
     *flops = 0;
     *bytes = 0;
@@ -1657,7 +1658,7 @@ DMME_API int dmme_device_count(void) {
 DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W, int dtype, int device, dmme_plan** out) {
     DMME_REQUIRE(cfg && out, DMME_ERR_INVALID, "plan_create: null argument");
     DMME_REQUIRE(B > 0 && H > 0 && W > 0, DMME_ERR_INVALID, "plan_create: bad shape B=%d H=%d W=%d", B, H, W);
-    DMME_REQUIRE(dtype == DMME_F32 || dtype == DMME_BF16 || dtype == DMME_BF16X3, DMME_ERR_INVALID, "plan_create: bad dtype %d", dtype);
+    DMME_REQUIRE(dtype == DMME_F32 || dtype == DMME_BF16 || dtype == DMME_BF16X3 || dtype == DMME_F16, DMME_ERR_INVALID, "plan_create: bad dtype %d", dtype);
     const int x3 = dtype == DMME_BF16X3;
     if (x3) dtype = DMME_F32;
     DMME_REQUIRE(cfg->num_depths >= 1 && cfg->num_depths <= 8 && cfg->num_blocks >= 1, DMME_ERR_INVALID,
@@ -1993,6 +1994,8 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
     DMME_REQUIRE(plan && packed && packed_bwd && x && t && d_y && workspace && bwd_workspace && grad_flat, DMME_ERR_INVALID,
                  "unet_backward: null argument");
     DMME_REQUIRE(t_len == 1 || t_len == plan->B, DMME_ERR_INVALID, "unet_backward: bad t_len %d", t_len);
+    DMME_REQUIRE(plan->dtype != DMME_F16, DMME_ERR_UNSUPPORTED,
+                 "unet_backward: precision fp16 is an inference mode (no loss scaling in the HIP backward); train in bf16, bf16x3 or fp32");
     const dmme_plan* P = plan;
     hipStream_t s = (hipStream_t)stream;
     const char* pk = (const char*)packed;
@@ -2531,8 +2534,10 @@ DMME_API int dmme_conv2d(const dmme_conv_desc* d, const void* src1, const void* 
     a.pro_silu = d->pro_silu; a.out_silu = d->out_silu; a.nt = d->nt; a.tproj_ld = d->tproj_ld;
     a.in_nchw = d->in_nchw; a.out_nchw = d->out_nchw;
     a.stamps = g_stamps;
-    DMME_REQUIRE(d->dtype == DMME_F32 || d->dtype == DMME_BF16 || d->dtype == DMME_BF16X3, DMME_ERR_INVALID, "conv2d: bad dtype %d", d->dtype);
+    DMME_REQUIRE(d->dtype == DMME_F32 || d->dtype == DMME_BF16 || d->dtype == DMME_BF16X3 || d->dtype == DMME_F16, DMME_ERR_INVALID, "conv2d: bad dtype %d",
+                 d->dtype);
     a.x3 = d->dtype == DMME_BF16X3;
+    a.f16 = d->dtype == DMME_F16;
     const int dt = a.x3 ? DMME_F32 : d->dtype;
     if (d->force_generic == 2 && conv_mfma_supported(dt, a)) return launch_conv_mfma(dt, a, (hipStream_t)stream);
     if (!d->force_generic && conv_out_thin_supported(dt, a)) return launch_conv_out_thin(a, (hipStream_t)stream);

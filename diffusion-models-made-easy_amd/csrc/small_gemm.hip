@@ -165,10 +165,14 @@ __global__ void __launch_bounds__(256) small_gemm_mfma_kernel(const float* __res
                 if (MODE == GEMM_NT) {  // W[n][k]
                     const T* wp = (const T*)Bv + (int64_t)n * ldb + k;
                     if (k + 3 < ke && (ldb & 3) == 0) {
-                        if constexpr (sizeof(T) == 2) {
+                        if constexpr (__is_same(T, bf16)) {
                             const uint2 v = *reinterpret_cast<const uint2*>(wp);  // four bf16
                             b[0] = __uint_as_float(v.x << 16); b[1] = __uint_as_float(v.x & 0xffff0000u);
                             b[2] = __uint_as_float(v.y << 16); b[3] = __uint_as_float(v.y & 0xffff0000u);
+                        } else if constexpr (sizeof(T) == 2) {
+                            typedef T tx4 __attribute__((ext_vector_type(4)));
+                            const tx4 v = *reinterpret_cast<const tx4*>(wp);  // four IEEE halves
+                            b[0] = (float)v[0]; b[1] = (float)v[1]; b[2] = (float)v[2]; b[3] = (float)v[3];
                         } else {
                             const float4 v = *reinterpret_cast<const float4*>(wp);
                             b[0] = v.x; b[1] = v.y; b[2] = v.z; b[3] = v.w;
@@ -253,6 +257,8 @@ int launch_small_gemm(int dtype, int mode, const float* A, int lda, const void* 
             DMME_SGM(float, GEMM_TN);
         } else if (dtype == DMME_BF16) {
             if (mode == GEMM_NT) DMME_SGM(bf16, GEMM_NT); else DMME_SGM(bf16, GEMM_NN);
+        } else if (dtype == DMME_F16) {
+            if (mode == GEMM_NT) DMME_SGM(f16, GEMM_NT); else DMME_SGM(f16, GEMM_NN);
         } else {
             if (mode == GEMM_NT) DMME_SGM(float, GEMM_NT); else DMME_SGM(float, GEMM_NN);
         }
@@ -274,6 +280,8 @@ int launch_small_gemm(int dtype, int mode, const float* A, int lda, const void* 
         DMME_SG(float, GEMM_TN);
     } else if (dtype == DMME_BF16) {
         if (mode == GEMM_NT) DMME_SG(bf16, GEMM_NT); else DMME_SG(bf16, GEMM_NN);
+    } else if (dtype == DMME_F16) {
+        if (mode == GEMM_NT) DMME_SG(f16, GEMM_NT); else DMME_SG(f16, GEMM_NN);
     } else {
         if (mode == GEMM_NT) DMME_SG(float, GEMM_NT); else DMME_SG(float, GEMM_NN);
     }
@@ -297,7 +305,7 @@ __global__ void __launch_bounds__(256) transpose_kernel(const T* __restrict__ sr
 }
 int launch_transpose(int dtype, const void* src, int R, int Ccols, void* dst, hipStream_t s) {
     const dim3 grid((Ccols + 31) / 32, (R + 31) / 32);
-    if (dtype == DMME_BF16)
+    if (is16(dtype))  // (a 16-bit transpose moves bits: one instantiation serves bf16 and IEEE half)
         hipLaunchKernelGGL(transpose_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)src, R, Ccols, (bf16*)dst);
     else
         hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, s, (const float*)src, R, Ccols, (float*)dst);

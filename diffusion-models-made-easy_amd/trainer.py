@@ -166,13 +166,21 @@ def parse_config(path: str) -> Dict[str, Any]:
     trainer = cfg.get("trainer") or {}
     data_args = ((cfg.get("data") or {}).get("init_args")) or {}
     precision = trainer.get("precision", 32)
+    p16 = str(precision) in ("16", "16-mixed")
+    pbf = str(precision) in ("bf16", "bf16-mixed")
     return {
         "model_spec": cfg["model"],
         "data_spec": cfg.get("data"),
         "batch_size": _coerce(data_args.get("batch_size", 128), int),
         "max_steps": _coerce(trainer.get("max_steps") if trainer.get("max_steps") is not None else -1, int),
         "gradient_clip_val": _coerce(trainer.get("gradient_clip_val"), typing.Optional[float]),
-        "precision": "bf16" if str(precision) in ("16", "bf16", "16-mixed", "bf16-mixed") else "fp32",
+        # `precision: 16` (configs/ddpm/cifar10.yaml:53) is fp16 autocast under a GradScaler in the reference.  The HIP backward has no
+        # loss scaling: training takes bf16 (same MFMA rate, fp32 range), inference takes the reference's own dtype, IEEE half
+        # (precision="fp16": 8x finer rounding than bf16 at the same speed)
+        "precision": "bf16" if (p16 or pbf) else "fp32",
+        "sample_precision": "fp16" if p16 else "bf16" if pbf else "fp32",
+        # images the YAML's data module yields (dmme.CIFAR10: 32 x 32; dmme.LSUN: init_args.imgsize, configs/ddpm/lsun_church.yaml:94)
+        "image_size": _coerce(data_args.get("imgsize", 32), int),
         "log_every_n_steps": _coerce(trainer.get("log_every_n_steps") or 50, int),
         "devices": trainer.get("devices", 1),
         "seed": cfg.get("seed_everything", 1337),
@@ -199,6 +207,8 @@ def main(argv=None):
     ap.add_argument("--ckpt-path", default=None, help="resume / sample from a Lightning-layout checkpoint (the YAML's ckpt_path key)")
     ap.add_argument("--save-checkpoint", default=None, help="fit: write a Lightning-layout checkpoint (weights, Adam moments, EMA copy) at the end")
     ap.add_argument("--num-images", type=int, default=16)
+    ap.add_argument("--image-size", type=int, default=None, help="sample: image height = width (default: what the YAML's data module yields)")
+    ap.add_argument("--precision", default=None, help="override the YAML's trainer.precision (fp32 | bf16 | fp16 | bf16x3)")
     ap.add_argument("--steps", type=int, default=None, help="sample: stop after this many denoising steps")
     args = ap.parse_args(argv)
 
@@ -206,6 +216,10 @@ def main(argv=None):
     from . import distributed as D
 
     conf = parse_config(args.config)
+    if args.precision:
+        conf["precision"] = conf["sample_precision"] = args.precision
+    if args.command == "sample":
+        conf["precision"] = conf["sample_precision"]
     _lib.require_gpu()  # the product path is the HIP denoiser: no CPU fallback (the CPU plumbing run of BASELINE configs[0] is bench.py --mode cpu-plumbing)
     # one process per GPU under `python -m torch.distributed.run` (the reference reaches DDP through trainer.devices / strategy)
     rank, local, world = D.init_from_env()
@@ -226,16 +240,19 @@ def main(argv=None):
         module.eval()
         dm = module.diffusion_model
         t0 = time.perf_counter()
+        hw = args.image_size or conf["image_size"]
+        shape = (args.num_images, dm.model.in_channels, hw, hw)
         if args.steps is None:
-            imgs = module.generate((args.num_images, 3, 32, 32))
+            imgs = module.generate(shape)
         else:
             import dmme_amd
 
-            imgs = dmme_amd.gaussian((args.num_images, 3, 32, 32), device="cuda")
+            imgs = dmme_amd.gaussian(shape, device="cuda")
             for k in range(args.steps):
                 imgs = module(imgs, dm.timesteps - k)
         torch.cuda.synchronize()
-        print(json.dumps({"images": list(imgs.shape), "seconds": round(time.perf_counter() - t0, 3), "finite": bool(torch.isfinite(imgs).all())}))
+        print(json.dumps({"images": list(imgs.shape), "precision": conf["precision"], "seconds": round(time.perf_counter() - t0, 3),
+                          "finite": bool(torch.isfinite(imgs).all())}))
         return 0
 
     from .train_loop import fit

@@ -7,7 +7,7 @@ import torch
 
 from dmme_amd import _lib
 
-TD = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16, _lib.BF16X3: torch.float32}
+TD = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16, _lib.BF16X3: torch.float32, _lib.F16: torch.float16}
 
 
 def _st(dt):

@@ -1,0 +1,99 @@
+"""-m gpu: precision="fp16" - the same kernels on IEEE-half operands (v_mfma_f32_32x32x16_f16, the bf16 rate), the reference's own
+AMP dtype (configs/ddpm/cifar10.yaml:53 `precision: 16`, :66 `amp_backend: native`).  Inference only.  Held against the reference's
+golden output: north_star asks 1e-3 for the reduced-precision path; bf16 (8 significant bits) measures 1.1e-2, half (11 bits) 8x less."""
+
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth
+from oracle import unet as O
+
+pytestmark = pytest.mark.gpu
+
+# measured on the default UNet (printed by the test): max|err| and rel-RMS against the reference's fp32 output; bounds = 1.25 x
+FP16_MAX_ABS = 2.0e-3
+FP16_REL_RMS = 1.5e-3
+
+
+def _net(seed, precision, **env):
+    import dmme_amd
+
+    net = dmme_amd.UNet(precision=precision)
+    net.load_state_dict(O.make_state_dict(O.UNetConfig(), seed), strict=True)
+    return net.cuda().eval()
+
+
+@pytest.mark.parametrize("lvl", [True, False], ids=["level_engine", "per_op"])
+def test_unet_full_fp16_vs_reference_golden(golden, lvl):
+    g = golden("unet_full")
+    x = synth.normal(int(g["full_xseed"]), (2, 3, 32, 32)).cuda()
+    ref_one, ref_per = torch.from_numpy(g["full_y_one"]), torch.from_numpy(g["full_y_per"])
+    if not lvl:
+        os.environ["DMME_NO_LVL"] = "1"
+    try:
+        out = {}
+        for precision in ("fp16", "bf16"):
+            net = _net(int(g["full_seed"]), precision)
+            with torch.no_grad():
+                y1 = net(x, torch.from_numpy(g["full_t_one"]).cuda()).cpu()
+                y2 = net(x, torch.from_numpy(g["full_t_per"]).cuda()).cpu()
+            out[precision] = (y1, y2)
+    finally:
+        os.environ.pop("DMME_NO_LVL", None)
+    stats = {}
+    for precision, (y1, y2) in out.items():
+        e1, e2 = (y1 - ref_one).abs(), (y2 - ref_per).abs()
+        stats[precision] = (float(max(e1.max(), e2.max())), float((e1.pow(2).mean().sqrt() / ref_one.pow(2).mean().sqrt())))
+    print(f"full UNet vs the reference's output (|y|max {float(ref_one.abs().max()):.3f}): fp16 max|err| {stats['fp16'][0]:.3e} rel-rms {stats['fp16'][1]:.3e}; "
+          f"bf16 max|err| {stats['bf16'][0]:.3e} rel-rms {stats['bf16'][1]:.3e}")
+    assert stats["fp16"][0] <= FP16_MAX_ABS and stats["fp16"][1] <= FP16_REL_RMS
+    assert stats["fp16"][0] <= stats["bf16"][0] / 4  # 3 more significant bits: ~8x, at least 4x
+
+
+def test_fp16_batch128_rows_and_sampler_chain(golden):
+    """the benchmark batch (persistent 3x3 kernel, activation-stationary 1x1, MFMA attention, level engine - all on half operands):
+    every image pair takes the arithmetic of its golden row; 20 captured DDPM steps stay finite and reproducible"""
+    import dmme_amd
+
+    g = golden("unet_full")
+    base = synth.normal(int(g["full_xseed"]), (2, 3, 32, 32))
+    x = base.repeat(64, 1, 1, 1).cuda()
+    net = _net(int(g["full_seed"]), "fp16")
+    with torch.no_grad():
+        y = net(x, torch.from_numpy(g["full_t_one"]).cuda()).cpu()
+    rows = y.reshape(64, 2, 3, 32, 32)
+    assert torch.equal(rows, rows[:1].expand_as(rows))
+    err = float((rows[0] - torch.from_numpy(g["full_y_one"])).abs().max())
+    print(f"fp16 B=128: max|err| vs the reference's rows {err:.3e}")
+    assert err <= FP16_MAX_ABS
+    ddpm = dmme_amd.DDPM(net, 1000).cuda()
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(5)
+        xs = torch.randn(128, 3, 32, 32, device="cuda")
+        with torch.no_grad():
+            for t in range(1000, 980, -1):
+                xs = ddpm.sampling_step(xs, torch.tensor([t], device="cuda"))
+        outs.append(xs.cpu())
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+
+
+def test_fp16_is_an_inference_mode():
+    """the HIP backward has no loss scaling: a training step in fp16 is refused with a message, not run into underflow"""
+    import dmme_amd
+
+    net = dmme_amd.UNet(precision="fp16").cuda().train()
+    x = torch.randn(2, 3, 32, 32, device="cuda")
+    with pytest.raises(NotImplementedError, match="inference mode"):  # DMME_ERR_UNSUPPORTED
+        net(x, torch.tensor([3, 4], device="cuda")).sum().backward()
+
+
+def test_trainer_maps_precision_16_to_half_for_sampling_and_bf16_for_training():
+    from dmme_amd import trainer
+
+    conf = trainer.parse_config(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "ddpm", "cifar10.yaml"))
+    assert conf["precision"] == "bf16" and conf["sample_precision"] == "fp16" and conf["image_size"] == 32

@@ -18,15 +18,24 @@ BF16_RTOL = 2.0**-8
 # attention adds the bf16 rounding of K * C^-0.5 (the reference scales K before the product, models/ddpm.py:58), of the
 # probabilities fed to the second matrix product and of the output: three independent 2^-9 terms on O(1) values
 BF16_ATTN_RTOL = 5e-3
+# precision="fp16" (IEEE half, the reference's own AMP dtype): the same kernels on v_mfma_f32_32x32x16_f16 - 11 significant bits
+# instead of 8, so every bound above shrinks by 2^3
+FP16_RTOL = 2.0**-11
+FP16_ATTN_RTOL = 5e-3 / 8
 
 
 def _bf(x):
     return x.to(torch.bfloat16).to(torch.float32)
 
 
+def _hf(x):
+    return x.to(torch.float16).to(torch.float32)
+
+
 def _ref_conv(x1, w, b, x2, scale, shift, dmask, tproj, res, stride, upsample, pro_silu, out_silu, bf16):
+    """bf16: False (fp32), True / "bf16", or "fp16" - the 16-bit type the kernel's operands are rounded to"""
     x = x1 if x2 is None else torch.cat([x1, x2], 1)
-    q = _bf if bf16 else (lambda t: t)
+    q = _hf if bf16 == "fp16" else _bf if bf16 else (lambda t: t)
     if x.shape[1] > 4:  # the 3-channel network input stays fp32 in both precisions
         x = q(x)
     if scale is not None:
@@ -78,7 +87,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtname", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtname", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_conv(case, dtname):
     from dmme_amd import _lib
@@ -98,7 +107,7 @@ def test_conv(case, dtname):
     tproj = 0.3 * synth.normal(seed + 7, (ntp, Cout)) if ntp else None
     Ho = (2 * H if up else H) // stride
     res = synth.normal(seed + 8, (N, Cout, Ho, Ho)) if has_res else None
-    ref = _ref_conv(x1, w, b, x2, scale, shift, dmask, tproj, res, stride, up, pro, False, dtname == "bf16")
+    ref = _ref_conv(x1, w, b, x2, scale, shift, dmask, tproj, res, stride, up, pro, False, {"fp32": False, "bf16": True, "fp16": "fp16"}[dtname])
     cu = lambda t: None if t is None else t.cuda()
     outs = {}
     for force_generic in (1, 2, 0):  # generic kernel, first-generation MFMA kernel, best (pipelined) kernel
@@ -106,7 +115,7 @@ def test_conv(case, dtname):
         torch.cuda.synchronize()
         outs[force_generic] = y.cpu()
         err = (y.cpu() - ref).abs().max().item()
-        tol = FP32_ATOL * max(1.0, ref.abs().max().item()) if dtname == "fp32" else BF16_RTOL * ref.abs().max().item()
+        tol = FP32_ATOL * max(1.0, ref.abs().max().item()) if dtname == "fp32" else (BF16_RTOL if dtname == "bf16" else FP16_RTOL) * ref.abs().max().item()
         assert err <= tol, f"{name} {dtname} generic={force_generic}: max err {err:.3e} > {tol:.3e}"
 
 
@@ -164,7 +173,7 @@ def test_groupnorm_scale_shift(case, dtname):
 ATTN_CASES = [(2, 256, 256), (3, 256, 128), (5, 16, 256), (2, 64, 32), (2, 16, 12)]
 
 
-@pytest.mark.parametrize("dtname", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtname", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("case", ATTN_CASES, ids=[f"n{c[0]}_s{c[1]}_c{c[2]}" for c in ATTN_CASES])
 def test_attention(case, dtname):
     from dmme_amd import _lib
@@ -174,18 +183,19 @@ def test_attention(case, dtname):
     dt = _lib.dtype_code(dtname)
     qkv = synth.normal(7, (N, S, 3 * Cc))
     qkv[:, :, :Cc] *= 2.0  # sharper softmax
-    src = _bf(qkv) if dtname == "bf16" else qkv
+    rnd = {"fp32": (lambda t: t), "bf16": _bf, "fp16": _hf}[dtname]
+    src = rnd(qkv)
     q, k, v = src[:, :, :Cc].double(), src[:, :, Cc : 2 * Cc].double(), src[:, :, 2 * Cc :].double()
     want = (torch.softmax(q @ (k.transpose(1, 2) * Cc**-0.5), dim=2) @ v).float()
     # The reference multiplies K by C^-0.5 BEFORE the product (models/ddpm.py:58): under a 16-bit autocast that product is rounded
     # to 16 bits.  The generic kernel reproduces that rounding, the MFMA kernel scales the fp32 scores instead (closer to the fp32
     # reference); each is held against the reference fed its own operands.
-    k_rounded = _bf(src[:, :, Cc : 2 * Cc] * Cc**-0.5).double()
+    k_rounded = rnd(src[:, :, Cc : 2 * Cc] * Cc**-0.5).double()
     want_rk = (torch.softmax(q @ k_rounded.transpose(1, 2), dim=2) @ v).float()
     for force_generic in (True, False):
         got = G.attention(dt, qkv.cuda(), force_generic).cpu()
-        ref = want_rk if (dtname == "bf16" and (force_generic or S < 64 or Cc % 64)) else want
+        ref = want_rk if (dtname != "fp32" and (force_generic or S < 64 or Cc % 64)) else want
         err = (got - ref).abs().max().item()
-        tol = 1e-5 if dtname == "fp32" else BF16_ATTN_RTOL * want.abs().max().item()
+        tol = 1e-5 if dtname == "fp32" else (BF16_ATTN_RTOL if dtname == "bf16" else FP16_ATTN_RTOL) * want.abs().max().item()
         print(f"attention {case} {dtname} generic={force_generic}: err {err:.3e} (tol {tol:.3e})")
         assert err <= tol, f"attention {case} {dtname} generic={force_generic}: {err:.3e} > {tol:.3e}"

@@ -388,3 +388,41 @@ def test_bench_defaults_and_rank_launcher_command(monkeypatch):
     cmd = seen["cmd"]
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
+
+
+def test_bench_cpu_plumbing_mode_runs_the_reference_yaml_on_the_oracle():
+    """BASELINE configs[0]: `python bench.py --mode cpu-plumbing` - the shipped YAML through the product's parser and constructors, ten
+    sampling steps and two training steps at batch 1 in the CPU oracle, ONE JSON line with finite numbers (no GPU involved)"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "cpu-plumbing"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         timeout=600, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 0 and rec["steps"] == 10 and rec["finite"] is True and rec["value"] > 0 and len(rec["train_losses"]) == 2
+    assert "configs/ddpm/cifar10.yaml" in rec["config"]["workload"] and "LitDDPM" in rec["config"]["workload"]
+
+
+def test_trainer_sample_geometry_and_precision_follow_the_yaml(tmp_path):
+    """`trainer sample` takes the image size from the YAML's data module (dmme.LSUN: init_args.imgsize, configs/ddpm/lsun_church.yaml:94)
+    and maps `precision: 16` to IEEE half for sampling, bf16 for training"""
+    import os
+
+    from dmme_amd import trainer
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    conf = trainer.parse_config(os.path.join(root, "configs", "ddpm", "cifar10.yaml"))
+    assert conf["image_size"] == 32 and conf["precision"] == "bf16" and conf["sample_precision"] == "fp16"
+    ref = "/root/reference/configs/ddpm/lsun_church.yaml"
+    if os.path.exists(ref):  # (not on the GPU box)
+        assert trainer.parse_config(ref)["image_size"] == 256
+    y = tmp_path / "c.yaml"
+    y.write_text("trainer:\n  precision: bf16\nmodel:\n  class_path: dmme.LitDDPM\ndata:\n  class_path: dmme.LSUN\n  init_args:\n    imgsize: 64\n")
+    c2 = trainer.parse_config(str(y))
+    assert c2["image_size"] == 64 and c2["sample_precision"] == "bf16"

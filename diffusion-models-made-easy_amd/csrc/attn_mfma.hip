@@ -289,7 +289,7 @@ static int launch_attn_fwd_nw(const T* qkv, const AttnGeom& g, T* out, float* ls
         DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_kernel<D, NW, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_done = true;
     }
-    static const bool xcd_off = getenv("DMME_NO_XCD_ORDER") != nullptr;
+    const bool xcd_off = getenv("DMME_NO_XCD_ORDER") != nullptr;
     const int xcd_order = (!xcd_off && qblocks > 1 && rows % 8 == 0) ? 1 : 0;
     hipLaunchKernelGGL((attn_mfma_kernel<D, NW, T>), dim3((unsigned)(rows * qblocks)), dim3(64 * NW), lds, s, qkv, g, out, lse, xcd_order);
     DMME_CHECK_LAUNCH();

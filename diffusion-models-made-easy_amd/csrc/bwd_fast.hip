@@ -77,7 +77,7 @@ static bool vec_geometry(int dtype, int HW, int C, int& chunk_px, int& nchunks, 
     // 16 pixel rows per thread (four batches of four loads in flight).  Measured (training step, batch 128): 16 rows 11.96 ms, 8 rows
     // 12.27, 4 rows 13.3 (4x the workgroups, but 4x the per-chunk partial rows for the finalize kernels to sum), 32 rows 11.99, 64 rows 12.22
     int sweeps = HW / ppw;
-    static const int max_sweeps = getenv("DMME_BWD_SWEEPS") ? atoi(getenv("DMME_BWD_SWEEPS")) : 16;
+    constexpr int max_sweeps = 16;
     if (sweeps > max_sweeps) sweeps = max_sweeps;
     while (sweeps > 1 && (HW / ppw) % sweeps) --sweeps;
     chunk_px = sweeps * ppw;
@@ -838,7 +838,7 @@ int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2
         // channel slices: whole groups, whole 16-byte vectors, not straddling the two concatenated sources, <= 256 threads per pixel row
         const int Call = C1 + C2, cgs = Call / groups, epv = dtype == DMME_BF16 ? 8 : 4;
         int slices = 1;
-        static const bool slice_off = getenv("DMME_NO_GN_BWD_SLICES") != nullptr;
+        const bool slice_off = getenv("DMME_NO_GN_BWD_SLICES") != nullptr;
         for (int cand = 4; cand >= 2 && !slice_off; cand >>= 1) {
             const int w = Call / cand;
             if (Call % cand == 0 && w % cgs == 0 && w % epv == 0 && C1 % w == 0 && (int64_t)N * cand <= 1024) {
@@ -866,8 +866,8 @@ int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2
         hipLaunchKernelGGL(gn_bwd_sums_kernel<float>, grid, dim3(256), 0, s, (const float*)dv, (const float*)x1, (const float*)x2, HW, C1, C2,
                            groups, mean_rstd, scale, shift, dmask, pro_silu, chunk_px, ppw, AB);
     DMME_CHECK_LAUNCH();
-    static const bool per_image_off = getenv("DMME_NO_GN_BWD_IMAGE") != nullptr;
-    static const bool fused_off = getenv("DMME_NO_GN_BWD_FUSED_FIN") != nullptr;
+    const bool per_image_off = getenv("DMME_NO_GN_BWD_IMAGE") != nullptr;
+    const bool fused_off = getenv("DMME_NO_GN_BWD_FUSED_FIN") != nullptr;
     const bool fused_fin = !per_image_off && !fused_off && C <= 1024 && groups <= 256;  // the apply kernel merges the chunk sums itself
     if (fused_fin) {
     } else if (!per_image_off && C <= 1024 && groups <= 256) {

@@ -390,16 +390,15 @@ static bool as_stats_cg_ok(int cg) { return cg == 8 || cg == 16 || cg == 32; }
 
 // shape rules (statistics aside)
 static bool as_shape_ok(int dtype, const ConvArgs& a) {
-    static const bool off = getenv("DMME_NO_CONV1X1_AS") != nullptr;
-    static const int min_units = getenv("DMME_AS_MIN_UNITS") ? atoi(getenv("DMME_AS_MIN_UNITS")) : 2;
+    const bool off = getenv("DMME_NO_CONV1X1_AS") != nullptr;
+    constexpr int min_units = 2;
     if (off || !is16(dtype) || a.x3) return false;
     if (a.taps != 1 || a.stride != 1 || a.up || a.in_nchw || a.out_nchw || a.out_silu || a.res2 || a.n_gno) return false;
     if (a.tproj && a.nt != 1) return false;
     const int K = a.C1 + a.C2;
     if ((K != 128 && K != 256) || a.C1 % 64 || a.Cout % 64 || a.Cout / 64 < min_units || a.Cout > 2048) return false;
     if (a.res1 && a.R1 != a.Cout) return false;
-    static const int min_wgs = getenv("DMME_AS_MIN_WGS") ? atoi(getenv("DMME_AS_MIN_WGS")) : 128;
-    static const int max_wgs = getenv("DMME_AS_MAX_WGS") ? atoi(getenv("DMME_AS_MAX_WGS")) : (1 << 30);
+    constexpr int min_wgs = 128, max_wgs = 1 << 30;
     const int64_t M = (int64_t)a.N * a.Hout * a.Wout;
     if (M % 128 || M * a.Cout >= (1ll << 30)) return false;
     if (M / 128 < min_wgs || M / 128 > max_wgs) return false;  // one workgroup per 128 pixels and no split over couts: small maps keep the tiled kernel

@@ -234,7 +234,7 @@ static int launch1_t(const ConvArgs& a, hipStream_t s) {
     const int tiles_n = (a.Cout + BN - 1) / BN;
     const int64_t tiles_m = (M + BM - 1) / BM;
     const dim3 grid((unsigned)(tiles_m * tiles_n));
-    static const bool xcd_off = getenv("DMME_NO_XCD_ORDER") != nullptr;
+    const bool xcd_off = getenv("DMME_NO_XCD_ORDER") != nullptr;
     const int xcd_order = (!xcd_off && tiles_n > 1 && tiles_m % 8 == 0) ? 1 : 0;
     size_t lds = (size_t)2 * (BM + BN) * ROW_DATA;
     if (lds < (size_t)BM * BN * 4) lds = (size_t)BM * BN * 4;

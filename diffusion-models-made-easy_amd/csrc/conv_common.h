@@ -842,8 +842,7 @@ __device__ __forceinline__ int conv_epilogue_syncs(const ConvArgs& a, int TN) {
 
 // tile-selection threshold: smallest workgroup count a tile shape must still produce (tunable for experiments)
 inline int min_wgs() {
-    static int v = [] { const char* e = getenv("DMME_MIN_WGS"); return e ? atoi(e) : 512; }();
-    return v;
+    return 512;
 }
 
 // fused statistics need: the staged fast epilogue, one image per tile, whole cout tiles, 16-byte group slices

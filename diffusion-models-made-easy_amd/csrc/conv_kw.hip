@@ -453,10 +453,9 @@ static size_t kw_lds(const ConvArgs& a, const ConvTile& g, int BM, int NI, int r
 
 // which instance (BM, NI, RING) runs this conv; false: not this kernel's shape
 bool conv_kw_pick(int dtype, const ConvArgs& a, ConvTile& g, int* ni_out, int* ring_out, int* bm_out) {
-    static const bool off = getenv("DMME_NO_KW") != nullptr;
-    static const int force_ni = getenv("DMME_KW_NI") ? atoi(getenv("DMME_KW_NI")) : 0;
-    static const int force_bm = getenv("DMME_KW_BM") ? atoi(getenv("DMME_KW_BM")) : 0;
-    static const int max_ring = getenv("DMME_KW_RING") ? atoi(getenv("DMME_KW_RING")) : 6;
+    const bool off = getenv("DMME_NO_KW") != nullptr;
+    constexpr int force_ni = 0, max_ring = 6;
+    const int force_bm = getenv("DMME_KW_BM64") ? 64 : 0;  // (the 8x8 level on 64-pixel tiles instead of two whole images per workgroup)
     if (off || !is16(dtype) || a.x3) return false;
     const int Cin = a.C1 + a.C2;
     if (a.taps != 9 || a.stride != 1 || a.up == 2 || a.in_nchw || Cin % 64 || a.C1 % 64 || a.Cout < 32) return false;

@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(256) conv_splitk_finish_kernel(ConvArgs a, int
 }
 static int pipe_ksplit(const ConvArgs& a, const ConvTile& g, int pick, int KC) {
     if (a.has_gni) return 1;  // (the rows are per workgroup: every K slice would derive them again)
-    static const bool off = getenv("DMME_NO_SPLITK") != nullptr;
+    const bool off = getenv("DMME_NO_SPLITK") != nullptr;
     if (off || !a.splitk || pick != 3 || a.stride != 1 || a.gn_part || a.n_gno || a.out_silu || a.out_nchw || a.res2 || a.Cout % 4) return 1;
     const int64_t wgs = (int64_t)g.tiles_m * g.tiles_n;
     if (wgs > 128) return 1;  // a full wave of workgroups already
@@ -724,7 +724,7 @@ static size_t ws2_lds(const ConvArgs& a, const ConvTile& g) { return 2 * (size_t
 
 // the wave-specialised kernel applies (else 0): its tile goes to g
 static int ws_pick(const ConvArgs& a, ConvTile& g) {
-    static const int ws_min_tiles = getenv("DMME_WS_MIN") ? atoi(getenv("DMME_WS_MIN")) : 256;
+    constexpr int ws_min_tiles = 256;
     const int Cin = a.C1 + a.C2, nch = Cin / 64;
     if (a.taps != 9 || a.stride != 1 || Cin % 64 || a.C1 % 64 || nch < 2 || nch % 2 || Cin > 512 || a.out_silu || a.out_nchw || a.in_nchw || a.Cout % 128) return 0;
     ConvTile t;
@@ -744,7 +744,7 @@ static const int kPipeUA[5] = {8, 8, 8, 11, 10};  // [4]: stride 2 (a 64-pixel t
 static size_t pipe_lds(const ConvTile& g, int BN, int GT) { return (size_t)g.a_rows * ROW_DATA + (size_t)GT * BN * ROW_DATA; }  // >= BM*BN*4 always
 // the DMA filter path (bf16, GT = 3, 64-cout tiles) needs a second filter buffer inside the 2-workgroups-per-CU budget
 static bool pipe_dma_ok(int dtype, const ConvTile& g, int BN, int GT) {
-    static const bool off = getenv("DMME_NO_PIPE_DMA") != nullptr;
+    const bool off = getenv("DMME_NO_PIPE_DMA") != nullptr;
     return !off && is16(dtype) && GT == 3 && BN == 64 && pipe_lds(g, BN, GT) + (size_t)GT * BN * ROW_DATA <= 80 * 1024;
 }
 
@@ -784,7 +784,7 @@ static int pipe_pick(const ConvArgs& a, ConvTile& g) {
     }
     // stride 2: a 64-pixel tile's 17 x 17 halo and a whole 3x3 filter leave one workgroup per CU (110 KB); with 3-tap intervals two fit
     // (DownSample 32 -> 16 at B = 128: 65.8 -> 43.6 us, 16 -> 8: 59.8 -> 38.5 us)
-    static const bool s2_gt9 = getenv("DMME_S2_GT9") != nullptr;
+    constexpr bool s2_gt9 = false;  // (stride-2 convs on whole-filter intervals, one workgroup per CU: measured slower)
     if (!s2_gt9 && a.stride == 2) {
         ConvTile t;
         if (pipe_fits(a, 4, t) && (int64_t)t.tiles_m * t.tiles_n >= 2 * 256) {
@@ -814,29 +814,15 @@ static int set_lds_limit(K kernel, size_t bytes) {
 // (layers with fewer than 512 workgroups) always; the 512-workgroup 8x8 layers only where its 128-pixel tile applies (with 64-pixel
 // tiles the two-per-CU four-wave kernel is as fast: 20.8 vs 21.4 us)
 static bool kw_takes(int dtype, const ConvArgs& a, int pick, ConvTile& gk, int* ni, int* ring, int* bm) {
-    static const int all = getenv("DMME_KW_ALL") != nullptr;
+    constexpr int all = 0;
     if (pick != 3 && pick != 2) return false;
     if (!conv_kw_pick(dtype, a, gk, ni, ring, bm)) return false;
     return pick == 3 || all || *bm == 128;
 }
-static int kw_ksplit(const ConvArgs& a, const ConvTile& g) {
-    // Measured with this kernel: a split over workgroups no longer pays at any batch (B = 1: 775 -> 846 steps/s without it, B = 8:
-    // 728 -> 792, B = 32: 586 -> 611) - a workgroup's fixed cost is ~5 us whatever its share of K, the finish kernel is one more dependent
-    // launch, and an unsplit conv finishes its norms itself.  Kept behind DMME_KW_SPLITK for experiments.
-    static const bool on = getenv("DMME_KW_SPLITK") != nullptr;
-    if (!on) return 1;
-    static const bool off = getenv("DMME_NO_SPLITK") != nullptr;
-    if (off || !a.splitk || a.gn_part || a.n_gno || a.out_silu || a.out_nchw || a.res2 || a.Cout % 4) return 1;
-    const int64_t wgs = (int64_t)g.tiles_m * g.tiles_n;
-    if (wgs > 64) return 1;
-    int ks = (a.C1 + a.C2) / 64;
-    const int room = (int)(256 / wgs);
-    if (ks > room) ks = room;
-    if (ks > 4) ks = 4;
-    const int64_t out = (int64_t)a.N * a.Hout * a.Wout * a.Cout;
-    while (ks > 1 && ks * out > a.splitk_cap) --ks;
-    return ks < 1 ? 1 : ks;
-}
+// (a split of K over workgroups for this kernel was measured and removed: B = 1: 775 -> 846 steps/s without it, B = 8: 728 -> 792,
+// B = 32: 586 -> 611 - a workgroup's fixed cost is ~5 us whatever its share of K, the finish kernel is one more dependent launch, and
+// an unsplit conv finishes its norms itself)
+static int kw_ksplit(const ConvArgs&, const ConvTile&) { return 1; }
 template <typename T>
 static int launch_kw_t(const ConvArgs& a, const ConvTile& gk, int ni, int ring, int bm, hipStream_t s) {
     const int ksplit = kw_ksplit(a, gk);
@@ -858,7 +844,7 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
     const int ksplit = pipe_ksplit(a, g, pick, Frag<T>::KC);
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)ksplit);
     if constexpr (sizeof(T) == 2) {
-        static const bool ws_off = getenv("DMME_NO_WS") != nullptr;
+        const bool ws_off = getenv("DMME_NO_WS") != nullptr;
         ConvTile gw{};
         const int ws = ws_off ? 0 : ws_pick(a, gw);
         if (ws) {
@@ -948,7 +934,7 @@ bool conv_gn_in_query(int dtype, const ConvArgs& a) {
 }
 
 bool conv_gn_direct_query(int dtype, const ConvArgs& a, const int* cg, int n) {
-    static const bool off = getenv("DMME_NO_GN_DIRECT") != nullptr;
+    const bool off = getenv("DMME_NO_GN_DIRECT") != nullptr;
     if (off || n < 1 || n > 2 || a.taps != 9 || !conv_pipe_supported(dtype, a)) return false;
     const int VEC = is16(dtype) ? 8 : 4;
     const int HW = a.Hout * a.Wout;
@@ -987,7 +973,7 @@ bool conv_gn_direct_query(int dtype, const ConvArgs& a, const int* cg, int n) {
 // the wave-specialised kernel: its 256-pixel tile is a whole 16x16 image, stored in two passes whose statistics it merges itself
 // (scale / shift / {mean, rstd} only - the first pass is in memory before the statistics exist, so no pre-activated output)
 bool conv_gn_direct_ws_query(int dtype, const ConvArgs& a, const int* cg, int n) {
-    static const bool off = getenv("DMME_NO_GN_DIRECT") != nullptr || getenv("DMME_NO_GN_DIRECT_WS") != nullptr;
+    const bool off = getenv("DMME_NO_GN_DIRECT") != nullptr || getenv("DMME_NO_GN_DIRECT_WS") != nullptr;
     if (off || !is16(dtype) || getenv("DMME_NO_WS") || n < 1 || n > 2 || !conv_pipe_supported(dtype, a)) return false;
     ConvTile gw{};
     if (!ws_pick(a, gw) || gw.TH != a.Hout || gw.TW != a.Wout || gw.TH * gw.TW != 256) return false;

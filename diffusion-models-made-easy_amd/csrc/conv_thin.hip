@@ -127,7 +127,7 @@ static int thin_rows(const ConvArgs& a) {  // band height: the z image of R + 2 
 }
 
 bool conv_out_thin_supported(int dtype, const ConvArgs& a) {
-    static const bool off = getenv("DMME_NO_CONV_THIN") != nullptr;
+    const bool off = getenv("DMME_NO_CONV_THIN") != nullptr;
     if (off || !is16(dtype) || a.x3) return false;
     if (a.taps != 9 || a.stride != 1 || a.up || a.C2 || a.in_nchw || !a.out_nchw || a.out_silu || a.tproj || a.res1 || a.dmask || a.gn_part || a.n_gno)
         return false;

@@ -887,7 +887,7 @@ void build_wgrad_group(dmme_plan* P, dmme_plan::WgGroup& G, int gi, int op_lo = 
     if (stride == 2 && getenv("DMME_NO_WG_S2")) return;
     if (P->dtype != DMME_BF16 || getenv("DMME_NO_WGRAD_GROUP")) return;
     // (the stride-2 table is three small layers: shorter jobs, or 80 workgroups would carry it)
-    const int q = stride == 2 ? 16 : taps == 9 ? (getenv("DMME_WG_Q") ? atoi(getenv("DMME_WG_Q")) : 64) : (getenv("DMME_WG_Q1") ? atoi(getenv("DMME_WG_Q1")) : 64);
+    const int q = stride == 2 ? 16 : 64;
     struct Grp { int layer, n_co, n_ci, tile0, ntiles; };
     std::vector<Grp> groups;
     for (int oi = (int)P->ops.size() - 1; oi >= 0; --oi) {
@@ -1228,12 +1228,6 @@ void assign_levels(dmme_plan* P) {
             std::vector<std::pair<int, int64_t>> gn_acts;
             std::vector<LvlXAttach> xattach;
             if (build_lvl_run(P, i, j, L, ws, R, gn_acts, getenv("DMME_LVL_NO_XRUN") ? std::unordered_map<int, std::pair<int, int>>() : made, xattach)) {
-                P->ws_bytes = ws;
-                for (const LvlXAttach& xa : xattach) {
-                    LvlOp& host = P->lvl_runs[xa.run].ops[xa.op];
-                    host.norm[host.n_norm++] = xa.norm;
-                }
-                for (auto& mk : R.made) made[mk.first] = {(int)P->lvl_runs.size(), mk.second};
                 // two groups per op iteration where a workgroup owns several (the filter stream is shared by twice the matrix work);
                 // the attention block keeps q / k / v of ONE group in LDS
                 bool has_attn = false;
@@ -1242,6 +1236,19 @@ void assign_levels(dmme_plan* P) {
                 R.GB = (R.NG > slots && !has_attn && !getenv("DMME_LVL_GB1")) ? 2 : 1;
                 const int nb = (R.NG + R.GB - 1) / R.GB;
                 R.NGS = nb < slots ? nb : slots;
+                // more than two iterations per op and workgroup: the per-layer kernels (tiles over the whole batch) are the better
+                // route again - measured at batch 512 (DDIM): 8.2 ms per step with them, 8.9 with the engine
+                const int max_iter = getenv("DMME_LVL_MAX_ITER") ? atoi(getenv("DMME_LVL_MAX_ITER")) : 2;
+                if ((nb + slots - 1) / slots > max_iter) {
+                    i = j;
+                    continue;
+                }
+                P->ws_bytes = ws;
+                for (const LvlXAttach& xa : xattach) {
+                    LvlOp& host = P->lvl_runs[xa.run].ops[xa.op];
+                    host.norm[host.n_norm++] = xa.norm;
+                }
+                for (auto& mk : R.made) made[mk.first] = {(int)P->lvl_runs.size(), mk.second};
                 const int ri = (int)P->lvl_runs.size();
                 for (int oi = i; oi < j; ++oi) {
                     Op& o = P->ops[oi];
@@ -1407,7 +1414,7 @@ void assign_preact(dmme_plan* P) {
         Op& cv = P->ops[ci];
         if (cv.kind != OP_CONV || cv.gn < 0 || cv.src1 < 0 || cv.up || cv.stride != 1 || cv.lvl >= 0) continue;
         Op& g = P->ops[cv.gn];
-        static const bool over_parts = getenv("DMME_PREACT_PARTS") && atoi(getenv("DMME_PREACT_PARTS")) != 0;
+        constexpr bool over_parts = false;  // (the whole-image norm kernel over tensors whose producers left partials: measured neutral, below)
         if (g.gn_mod_col >= 0 || g.gn_act >= 0 || g.gn_direct) continue;
         const Tensor& t1 = P->tensors[g.gn_src1];
         const int C2 = g.gn_src2 >= 0 ? P->tensors[g.gn_src2].C : 0;
@@ -2013,7 +2020,7 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
     // identity-residual branches (d x += d out of a ResBlock / attention block) are not launched on their own: the pointer waits here
     // until the GroupNorm backward that writes x's gradient anyway (norm1 / the attention norm of the same block) takes it as one more
     // addend; anything else that needs x's gradient first gets it through flush_pending
-    static const bool res_extra_off = getenv("DMME_NO_RES_EXTRA") != nullptr;
+    const bool res_extra_off = getenv("DMME_NO_RES_EXTRA") != nullptr;
     std::vector<const char*> pending(P->tensors.size(), nullptr);
     auto flush_pending = [&](int id) -> int {
         if (id < 0 || !pending[id]) return DMME_OK;
@@ -2181,7 +2188,7 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
             // a conv with no norm in front of it, one source and no fused upsample: its data gradient IS the source's gradient -
             // written (or, through the epilogue's residual input, accumulated in place: each vector is read and written by one thread)
             // straight into that buffer instead of a scratch tensor plus an accumulation launch
-            static const bool direct_off = getenv("DMME_NO_DGRAD_DIRECT") != nullptr;
+            const bool direct_off = getenv("DMME_NO_DGRAD_DIRECT") != nullptr;
             const bool dgrad_direct = !direct_off && o.gn < 0 && o.src2 < 0 && o.up != 1;
             if (dgrad_direct) {
                 d.dst = g1;

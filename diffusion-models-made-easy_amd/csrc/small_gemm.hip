@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(256) small_gemm_mfma_kernel(const float* __res
 }
 
 static bool sg_mfma() {
-    static const bool off = getenv("DMME_NO_SMALL_GEMM_MFMA") != nullptr;
+    const bool off = getenv("DMME_NO_SMALL_GEMM_MFMA") != nullptr;
     return !off;
 }
 
@@ -244,7 +244,7 @@ int launch_small_gemm(int dtype, int mode, const float* A, int lda, const void* 
         int ksplit = 1;
         const int waves = ((N + 31) / 32) * ((M + 31) / 32);
         if (mode != GEMM_TN && !bias && !out_silu && waves < 512 && K >= 1024) {
-            static const int cap = getenv("DMME_SG_KSPLIT") ? atoi(getenv("DMME_SG_KSPLIT")) : 8;
+            constexpr int cap = 8;
             ksplit = 1024 / waves;
             if (ksplit > cap) ksplit = cap;  // every split is one float atomic per output element
             if (ksplit > K / 64) ksplit = K / 64;

@@ -78,9 +78,10 @@ class DDIM(DDPM):
         """S-step strided chain (reference: diffusion_models/ddim.py:79-99)"""
         dev = self.beta.device
         x = gaussian(img_size, device=dev)
-        runner = self.chain_runner(x)
+        runner = self._generate_runner(img_size, dev) if len(img_size) == 4 and not self.model.training else None
         if runner is not None:
-            return runner.run(self.sub_timesteps, self.sub_timesteps)
+            runner.x.copy_(x)
+            return runner.run(self.sub_timesteps, self.sub_timesteps).clone()
         for i in range(self.sub_timesteps, 0, -1):
             eps = self.model(x, self.tau_tensor(i, dev))
             self._ddim_update(x, eps, i)

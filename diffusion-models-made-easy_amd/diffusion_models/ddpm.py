@@ -43,6 +43,7 @@ class ChainRunner:
         self.quads = x.numel() // 4
         self.use_graph = use_graph
         self.graph = None
+        self.capture_error = None  # why this runner launches eagerly although a graph was asked for (None: it does not)
         self._wkey = None
 
     def set(self, i: int, seed: int = 0, offset: int = 0):
@@ -63,37 +64,42 @@ class ChainRunner:
             raise RuntimeError("ChainRunner: sampling chains run in eval mode (no dropout masks inside the replayed step)")
         packed = model._packed_for(self.plan)  # re-packs when the parameters changed
         wkey = (self.plan.packed_version, self.plan.packed.data_ptr())
-        if not self.use_graph or getattr(model, "_graph_disabled", False):
+        if not self.use_graph or self.capture_error is not None:
             self._launch(packed)
             return self.x
         if self.graph is None or self._wkey != wkey:
-            # capture: one eager step first (kernel attribute setup happens at first launch), on a saved copy of x / the state
+            # capture: one eager step first (kernel attribute setup happens at first launch), on a saved copy of x / the state.
+            # A kernel or DMME error in that trial step is a real error and propagates; only a failure of the CAPTURE itself makes
+            # this runner (not the model) fall back to eager launches, and the cause is kept in `capture_error`.
+            saved_x, saved_state = self.x.clone(), self.state.clone()
+            self._launch(packed)
+            torch.cuda.synchronize()
+            self.x.copy_(saved_x)
+            self.state.copy_(saved_state)
             try:
-                saved_x, saved_state = self.x.clone(), self.state.clone()
-                self._launch(packed)
-                torch.cuda.synchronize()
-                self.x.copy_(saved_x)
-                self.state.copy_(saved_state)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     self._launch(packed)
-                self.x.copy_(saved_x)
-                self.state.copy_(saved_state)
-                self.graph, self._wkey = graph, wkey
-            except Exception:  # noqa: BLE001 - capture not possible here: stay eager (same launches)
-                model._graph_disabled = True
+            except RuntimeError as exc:  # stream capture unavailable / invalidated: stay eager (same launches)
+                self.capture_error = exc
                 self.graph = None
                 self.x.copy_(saved_x)
                 self.state.copy_(saved_state)
                 self._launch(packed)
                 return self.x
+            self.x.copy_(saved_x)
+            self.state.copy_(saved_state)
+            self.graph, self._wkey = graph, wkey
         self.graph.replay()
         self.plan.fwd_gen = getattr(self.plan, "fwd_gen", 0) + 1
         return self.x
 
     def run(self, first: int, count: int):
         """`count` steps from loop index `first` downwards, drawing from torch's CUDA generator like the eager loop"""
-        seed, off = philox_reserve(self.x.device, self.x.numel() * count)
+        if self.kind == _lib.CHAIN_DDIM:  # the DDIM update draws nothing: torch's generator stays where the eager loop leaves it
+            seed, off = 0, 0
+        else:
+            seed, off = philox_reserve(self.x.device, self.x.numel() * count)
         self.set(first, seed, off)
         for _ in range(count):
             self.step()
@@ -155,6 +161,14 @@ class DDPM(nn.Module):
             r._key = key
             setattr(self, slot, r)
         return r
+
+    def _generate_runner(self, img_size, dev) -> Optional["ChainRunner"]:
+        """the runner `generate` uses: ONE per (shape, dtype), bound to an internal image buffer that outlives the call - a second
+        `generate` of the same shape re-uses the captured graph, the coefficient tables and the buffers instead of building them again"""
+        buf = getattr(self, "_gen_buf", None)
+        if buf is None or tuple(buf.shape) != tuple(img_size) or buf.device != torch.device(dev):
+            buf = self._gen_buf = torch.empty(tuple(img_size), dtype=torch.float32, device=dev)
+        return self.chain_runner(buf, slot="_runner")
 
     def _once_via_runner(self, x_t: Tensor, index: int) -> Optional[Tensor]:
         """single step at loop index `index` through the captured graph, for callers that loop on the host one step at a time
@@ -237,9 +251,10 @@ class DDPM(nn.Module):
         """run the full T-step chain from pure noise (reference: diffusion_models/ddpm.py:113-133)"""
         dev = self.beta.device
         x_t = gaussian(img_size, device=dev)
-        runner = self.chain_runner(x_t)
+        runner = self._generate_runner(img_size, dev) if len(img_size) == 4 and not self.model.training else None
         if runner is not None:  # one captured step (UNet + noise + update + t -> t-1) replayed T times
-            return runner.run(self.timesteps, self.timesteps)
+            runner.x.copy_(x_t)
+            return runner.run(self.timesteps, self.timesteps).clone()
         for t in range(self.timesteps, 0, -1):
             eps = self.model(x_t, self.timestep_tensor(t, dev))
             self._reverse_update(x_t, eps, t, None)

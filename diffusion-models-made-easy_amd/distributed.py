@@ -45,7 +45,8 @@ def init_from_env(device_index: Optional[int] = None) -> Tuple[int, int, int]:
         backend = os.environ.get("DMME_DIST_BACKEND", "nccl")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            idx = local if device_index is None else device_index
+            # ONE rule for the device of a rank, here and in trainer.main: local rank modulo the visible devices
+            idx = (local % max(1, torch.cuda.device_count())) if device_index is None else device_index
             torch.cuda.set_device(idx)
             dist.init_process_group("nccl", device_id=torch.device("cuda", idx))
         else:
@@ -67,6 +68,15 @@ def sync_parameters(model, optimizer=None, src: int = 0) -> bool:
     if ema is not None:
         with torch.no_grad():
             dist.broadcast(ema, src=src)
+    # Adam moments and the step count are assumed identical on every rank (all ranks start fresh or load the same checkpoint):
+    # check the one scalar that would show a rank that resumed from something else
+    if optimizer is not None and hasattr(optimizer, "_step_count"):
+        steps = torch.tensor([int(optimizer._step_count)], dtype=torch.int64, device=flat.device)
+        lo, hi = steps.clone(), steps.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if int(lo) != int(hi):
+            raise RuntimeError(f"data-parallel start: optimiser step counts differ across ranks ({int(lo)} .. {int(hi)}); load the same checkpoint on every rank")
     return True
 
 

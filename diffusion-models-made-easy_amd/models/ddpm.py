@@ -239,10 +239,14 @@ class UNet(nn.Module):
                     mod._buffers[leaf] = v
                 else:
                     p = mod._parameters[leaf]
-                    had_grad = p.grad is not None
+                    old_grad = p.grad
                     p.data = v
-                    if had_grad:
-                        p.grad = new_grad[off : off + n].view(shape) if new_grad is not None else None
+                    if old_grad is not None:
+                        if new_grad is not None and grad is not None and old_grad.data_ptr() == grad.data_ptr() + 4 * off:
+                            p.grad = new_grad[off : off + n].view(shape)  # a view of the flat gradient buffer: follows it
+                        else:
+                            with torch.no_grad():
+                                p.grad = fn(old_grad)  # a gradient the user assigned: moved like nn.Module._apply would
             self._flat = new
             self._flat_grad = new_grad
             for pl in self._plans.values():
@@ -448,6 +452,8 @@ class UNet(nn.Module):
                 self._graph = None
                 return self._forward_impl(x_static, t_static)
         g[1].replay()
+        plan = self._last_plan  # the replay overwrote that plan's workspace: a pending backward of the same shape must refuse
+        plan.fwd_gen = getattr(plan, "fwd_gen", 0) + 1
         return g[2]
 
     def debug_activation(self, name: str) -> Tensor:

@@ -547,18 +547,23 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
     const int Cs = second ? C2 : C1, cs0 = second ? c0 - C1 : c0;
     const int64_t p0 = (int64_t)n * HW + (int64_t)blockIdx.x * chunk_px;
     const float inv = 1.0f / (float)((int64_t)cg * HW);
-    float sc[EPV], sh[EPV], dm[EPV], mu[EPV], rs[EPV], gm[EPV], k1[EPV], k2[EPV];
+    // per-channel constants, folded (fewer live registers: 157 -> occupancy 3 of 8 was the kernel's limit):
+    //   dx = rs (du gm - k1 - xhat k2),  du = d dm silu'(y),  xhat = (x - mu) rs
+    //      = d silu'(y) Gd + x Cx + C0   with  Gd = rs gm dm,  Cx = -rs^2 k2,  C0 = rs (mu rs k2 - k1)
+    float sc[EPV], sh[EPV], dm[EPV], Gd[EPV], Cx[EPV], C0[EPV];
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
         const int c = c0 + j, g = c / cg;
         sc[j] = scale[(int64_t)n * C + c];
         sh[j] = shift[(int64_t)n * C + c];
         dm[j] = dmask ? dmask[(int64_t)n * C + c] : 1.0f;
-        mu[j] = mean_rstd[((int64_t)n * groups + g) * 2];
-        rs[j] = mean_rstd[((int64_t)n * groups + g) * 2 + 1];
-        gm[j] = gamma[c] * mod.mul(n, c);
-        k1[j] = (AB ? gS1[g] : S[((int64_t)n * groups + g) * 2]) * inv;
-        k2[j] = (AB ? gS2[g] : S[((int64_t)n * groups + g) * 2 + 1]) * inv;
+        const float mu = mean_rstd[((int64_t)n * groups + g) * 2], rs = mean_rstd[((int64_t)n * groups + g) * 2 + 1];
+        const float gm = gamma[c] * mod.mul(n, c);
+        const float k1 = (AB ? gS1[g] : S[((int64_t)n * groups + g) * 2]) * inv;
+        const float k2 = (AB ? gS2[g] : S[((int64_t)n * groups + g) * 2 + 1]) * inv;
+        Gd[j] = rs * gm * dm[j];
+        Cx[j] = -rs * rs * k2;
+        C0[j] = rs * (mu * rs * k2 - k1);
     }
     // `extra` (single-source norms): one more addend of the source's gradient - the identity-residual branch of the block (d x += d out),
     // which used to be its own read-modify-write launch over the same tensor (27 per training step)
@@ -569,16 +574,26 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
         unpack_vec<T>(RX, xv);                                                            \
         unpack_vec<T>(RO, o);                                                             \
         unpack_vec<T>(extra ? load_raw<T>(extra + (p0 + (PP)) * Cs + cs0) : zero4, ev);   \
+        float yv[EPV];                                                                    \
         _Pragma("unroll") for (int j = 0; j < EPV; ++j) {                                 \
-            float du = d[j] * dm[j];                                                      \
-            if (pro_silu) du *= silu_grad_f<T>(fmaf(xv[j], sc[j], sh[j]));                \
-            const float xhat = (xv[j] - mu[j]) * rs[j];                                   \
-            const float dx = rs[j] * (du * gm[j] - (k1[j] + xhat * k2[j])) + ev[j];       \
+            yv[j] = fmaf(xv[j], sc[j], sh[j]);                                            \
+            float du = d[j] * Gd[j];                                                      \
+            if (pro_silu) du *= silu_grad_f<T>(yv[j]);                                    \
+            const float dx = fmaf(xv[j], Cx[j], du + C0[j]) + ev[j];                      \
             o[j] = acc ? o[j] + dx : dx;                                                  \
         }                                                                                 \
         store_vec<T>(dst + (p0 + (PP)) * Cs + cs0, o);                                    \
-        if (act) /* the conv's pre-activated input, for the deferred weight gradient: the forward's own prologue on the same bits */ \
-            *reinterpret_cast<uint4*>(act + (p0 + (PP)) * C + c0) = prologue_vec<T>(RX, sc, sh, dmask ? dm : nullptr, pro_silu); \
+        if (act) { /* the conv's pre-activated input, for the deferred weight gradient: the forward's own prologue (prologue_vec:    \
+                      fma, SiLU, mask, in that order) on the same bits - written out on the registers: handing sc / sh / dm to a     \
+                      function by pointer put the three arrays in scratch memory (48 bytes per lane, re-read per vector) */          \
+            float av[EPV];                                                                \
+            _Pragma("unroll") for (int j = 0; j < EPV; ++j) {                             \
+                float a_ = yv[j];                                                         \
+                if (pro_silu) a_ = sizeof(T) == 2 ? silu_fast(a_) : silu_f(a_);          \
+                av[j] = dmask ? a_ * dm[j] : a_;                                          \
+            }                                                                             \
+            store_vec<T>(act + (p0 + (PP)) * C + c0, av);                                 \
+        }                                                                                 \
     }
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
     int p = prow;

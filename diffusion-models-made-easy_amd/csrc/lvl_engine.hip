@@ -36,16 +36,21 @@ constexpr int LVL_NPI = LVL_BN / 8;                                    // DMA wa
 constexpr int LVL_U_BYTES = LVL_BN * ROW_DATA;
 // One workgroup handles GB pixel groups per op iteration (GB = 2 when a workgroup owns several groups: the filter stream is then shared
 // by twice the matrix work and every fixed cost of an iteration is paid half as often).  Per wave: the A image - GB groups x ONE
-// 64-channel chunk (the K loop runs in passes of 256 channels, wave w takes chunk 4 p + w of pass p) + 8 rows of zeros - and the
-// filter ring; both variants use the same 33 KB: GB = 1 -> 9 KB + 6 slots, GB = 2 -> 17 KB + 4 slots.
-constexpr int LVL_WAVE_BYTES = (2 * LVL_BM + 8) * ROW_DATA + 4 * LVL_U_BYTES;  // 33792
+// 64-channel chunk (the K loop runs in passes of 256 channels, wave w takes chunk 4 p + w of pass p) - and the filter ring.
+// A image: rows of 128 B on a 144-byte pitch (conflict-free ds_read_b128 WITHOUT a swizzle: a fragment address is one per-lane base
+// per (tap, pixel block) computed once per launch, the k-group and the pixel group are instruction offsets), 64 pixel rows + one row
+// of zeros per group (out-of-image taps read it).  GB = 1: 9.3 KB + 6 ring slots, GB = 2: 18.4 KB + 4 slots.
+constexpr int LVL_PITCH = ROW_DATA + 16;
+constexpr int LVL_GS = (LVL_BM + 1) * LVL_PITCH;                       // bytes per pixel group of the A image (9360)
+constexpr int lvl_a_bytes(int gb) { return (gb * LVL_GS + 127) / 128 * 128; }
+constexpr int LVL_WAVE_BYTES = lvl_a_bytes(2) + 4 * LVL_U_BYTES;      // 35200
 constexpr int LVL_KEEP_OFF = 4 * LVL_WAVE_BYTES;                       // q / k / v slices of the attention block: [3][64 px][32 ch] T
 constexpr int LVL_KEEP_BYTES = 3 * LVL_BM * LVL_BN * 2;
-constexpr int LVL_BLK_OFF = LVL_KEEP_OFF + LVL_KEEP_BYTES;             // statistics exchange: [GB][4 pixel blocks][4 vectors][2]
+constexpr int LVL_BLK_OFF = LVL_KEEP_OFF + LVL_KEEP_BYTES;             // statistics exchange: [GB][2 norms][4 vectors][4 pixel blocks][2]
 constexpr int LVL_LDS = LVL_BLK_OFF + 1024;
 constexpr int LVL_SPIN_LIMIT = 1 << 19;                                // polls before a wait gives up (~a second)
 static_assert(LVL_LDS <= 160 * 1024, "level engine: LDS budget");
-static_assert((LVL_BM + 8) * ROW_DATA + 6 * LVL_U_BYTES <= LVL_WAVE_BYTES, "level engine: GB = 1 layout");
+static_assert(lvl_a_bytes(1) + 6 * LVL_U_BYTES <= LVL_WAVE_BYTES, "level engine: GB = 1 layout");
 
 size_t lvl_engine_lds_bytes() { return LVL_LDS; }
 
@@ -134,8 +139,7 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
     constexpr int RING = GB == 1 ? 6 : 4;          // filter units per wave ring
     constexpr int D = RING - 1;                    // units requested ahead of the one being consumed
     constexpr int MI = 2 * GB;                     // 32-pixel row blocks per iteration
-    constexpr int ZROW = GB * LVL_BM;              // LDS row of zeros (out-of-image taps read it)
-    constexpr int A_BYTES = (GB * LVL_BM + 8) * ROW_DATA;
+    constexpr int A_BYTES = lvl_a_bytes(GB);
     static_assert(D * LVL_NPI < 64, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -157,35 +161,34 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
     }
     const int sh = A.sh, sh2 = 2 * sh, HW = 1 << sh2, mW = (1 << sh) - 1;
     const int npix = A.N * HW;
-    *reinterpret_cast<uint4*>(ldsA + ZROW * ROW_DATA + lane * 16) = make_uint4(0u, 0u, 0u, 0u);  // 8 rows of zeros
+    if (lane < GB * 9) *reinterpret_cast<uint4*>(ldsA + (lane / 9) * LVL_GS + LVL_BM * LVL_PITCH + (lane % 9) * 16) = make_uint4(0u, 0u, 0u, 0u);  // the rows of zeros
 
     // ---- per-lane fragment geometry (fixed for the launch): MFMA row r of pixel block mi is pixel mi * 32 + r of the iteration ----
-    unsigned a_valid[2];  // bit t: tap t of this lane's pixel lies inside its image (the same for every group: groups are whole images)
+    // ab[t][mi]: LDS address of this lane's 16 bytes of (tap t, pixel block mi of group 0, k-group 0); the same for every op and every
+    // group (groups are whole images): pixel m + tap offset inside the image, else the group's row of zeros
+    unsigned ab[9][2];
+    {
+        const unsigned a0 = (unsigned)(size_t)(lds_c*)ldsA + (unsigned)h * 16u;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int m = mi * 32 + r, tx = m & mW, ty = (m >> sh) & mW;
-        a_valid[mi] = 0;
+        for (int mi = 0; mi < 2; ++mi) {
+            const int m = mi * 32 + r, tx = m & mW, ty = (m >> sh) & mW;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int yy = ty + t / 3 - 1, xx = tx + t % 3 - 1;
-            a_valid[mi] |= (yy >= 0 && yy <= mW && xx >= 0 && xx <= mW) ? 1u << t : 0u;
+            for (int t = 0; t < 9; ++t) {
+                const int yy = ty + t / 3 - 1, xx = tx + t % 3 - 1;
+                const bool in = yy >= 0 && yy <= mW && xx >= 0 && xx <= mW;
+                ab[t][mi] = a0 + (unsigned)((in ? m + ((t / 3 - 1) << sh) + (t % 3 - 1) : LVL_BM) * LVL_PITCH);
+            }
         }
     }
     int tb[4];  // filter fragment offsets inside a ring slot (row r; the XOR swizzle of conv_common.h)
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg) tb[kg] = (r * ROW_DATA + ((h ^ ((r >> 1) & 7)) << 4)) ^ (kg << 5);
-    const lds_c* ldsA3 = (const lds_c*)ldsA;
     const unsigned ring_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lds_c*)ldsR);
 
     // ---- filter stream state of this wave (conv_kw.hip's ring discipline; the stream of an op starts before the op does) ----
-    // REGU > 0: the first REGU units of an op bypass the ring - their filter fragments are loaded straight into registers when the stream
-    // starts (row r, the four 16-byte pieces of this lane's half of each k-group), so that a 256-channel 3x3 conv (9 units per wave)
-    // has ALL its units requested before it starts (a unit requested inside the main loop comes back after ~2 us: the weights come
-    // from beyond L2).  Measured and OFF (REGU = 0): the registers are loaded at the end of one loop iteration and read in the next,
-    // hipcc copies loop-carried registers at the back edge and therefore waits for the loads right where they are issued - 2.5 us
-    // per op instead of the 1.5 us the main loop would have saved (B = 1, 4x4 run: 152 -> 198 us).
-    constexpr int REGU = 0;
-    uint4 breg0[4], breg1[4], breg2[4];
+    // (Loading an op's first units straight into registers when its stream starts - so that a 256-channel 3x3 conv has all nine units
+    // requested before it begins - was measured and removed: hipcc copies loop-carried registers at the back edge and waits for the
+    // loads where they are issued; B = 1, 4x4 run: 152 -> 198 us.)
     unsigned boff[LVL_NPI];
     const char* dptr = nullptr;
     unsigned dslot = ring_base;
@@ -204,27 +207,9 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
         --d_left;
         ++d_req;
     };
-    // start the filter stream of conv op `o` (pass-major, tap-minor; wave w owns chunk 4 p + w): units 0 .. REGU-1 into registers,
-    // the next D units into the ring
+    // start the filter stream of conv op `o` (pass-major, tap-minor; wave w owns chunk 4 p + w): the first D units into the ring
     auto prime = [&](const LvlOp& o) __attribute__((always_inline)) {
         const int Cin = o.C1 + o.C2, nu = (Cin >> 8) * o.taps;
-        const char* wbase = A.packed + o.w_off + wave * 128;
-        {
-            const char* rowp = wbase + (int64_t)((o.w_row0 + LVL_BN * s + r) * o.taps * Cin) * 2 + h * 16;
-#pragma unroll
-            for (int u = 0; u < REGU; ++u) {
-                if (u >= nu) break;
-                const int pu = u / o.taps, tu = u - pu * o.taps;
-                const char* q = rowp + pu * 512 + (int64_t)tu * Cin * 2;
-#pragma unroll
-                for (int kg = 0; kg < 4; ++kg) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(q + kg * 32);
-                    if (u == 0) breg0[kg] = v;
-                    if (u == 1) breg1[kg] = v;
-                    if (u == 2) breg2[kg] = v;
-                }
-            }
-        }
 #pragma unroll
         for (int i = 0; i < LVL_NPI; ++i) {
             const int row = 8 * i + (lane >> 3);
@@ -232,11 +217,10 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
         }
         d_taps = o.taps;
         d_cin2 = Cin * 2;
-        const int p0 = REGU / o.taps;  // the first ring unit
-        dtap = REGU - p0 * o.taps;
-        dptr = wbase + p0 * 512 + (int64_t)dtap * Cin * 2;
+        dtap = 0;
+        dptr = A.packed + o.w_off + wave * 128;
         dslot = ring_base;
-        d_left = nu > REGU ? nu - REGU : 0;
+        d_left = nu;
         d_req = 0;
 #pragma unroll
         for (int d = 0; d < D; ++d)
@@ -315,76 +299,55 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
 #pragma unroll
                     for (int j = 0; j < 16; ++j) acc[mi][j] = 0.f;
                 uint4 af[2][4][MI], bfr[2][4];
-/* fragments of unit KU (tap TAP of the current pass) into set SET: the input rows from the A image, the filter rows from the       \
-   registers (KU < REGU) or from the ring slot at `rslot`, which then moves on */                                                   \
-#define LV_READ_FRAGS(SET, TAP, KU)                                                                                               \
+/* fragments of the unit at tap TAP (a compile-time constant) of the current pass into set SET: the input rows from the A image (one   \
+   base per (tap, pixel block); k-group and pixel group are instruction offsets), the filter rows from the ring slot at `rslot`,       \
+   which then moves on */                                                                                                            \
+#define LV_READ_FRAGS(SET, TAP)                                                                                                    \
     do {                                                                                                                           \
-        const int t9_ = taps == 9 ? (TAP) : 4;                                                                                     \
-        const int ty3_ = t9_ >= 6 ? 2 : t9_ >= 3 ? 1 : 0, tx3_ = t9_ - 3 * ty3_;                                                   \
-        const int tap_off_ = ((ty3_ - 1) << sh) + (tx3_ - 1);                                                                      \
-        int ta_[MI];                                                                                                               \
-        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                                        \
-            int row_ = mi * 32 + r + tap_off_;                                                                                     \
-            if (!((a_valid[mi & 1] >> t9_) & 1u)) row_ = ZROW;                                                                     \
-            ta_[mi] = row_ * ROW_DATA + ((h ^ ((row_ >> 1) & 7)) << 4);                                                            \
-        }                                                                                                                          \
         _Pragma("unroll") for (int kg = 0; kg < 4; ++kg)                                                                           \
             _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                                      \
-                af[SET][kg][mi] = __builtin_bit_cast(uint4, *reinterpret_cast<const lds_u32x4_lv*>(ldsA3 + (ta_[mi] ^ (kg << 5))));    \
-        if ((KU) >= REGU) {                                                                                                        \
-            const lds_c* rb_ = (const lds_c*)(size_t)rslot;                                                                        \
-            _Pragma("unroll") for (int kg = 0; kg < 4; ++kg)                                                                       \
-                bfr[SET][kg] = __builtin_bit_cast(uint4, *reinterpret_cast<const lds_u32x4_lv*>(rb_ + tb[kg]));                    \
-            rslot = rslot + LVL_U_BYTES == ring_base + RING * LVL_U_BYTES ? ring_base : rslot + LVL_U_BYTES;                       \
-            ++q_read;                                                                                                              \
-        } else if ((KU) == 0) {                                                                                                    \
-            _Pragma("unroll") for (int kg = 0; kg < 4; ++kg) bfr[SET][kg] = breg0[kg];                                             \
-        } else if ((KU) == 1) {                                                                                                    \
-            _Pragma("unroll") for (int kg = 0; kg < 4; ++kg) bfr[SET][kg] = breg1[kg];                                             \
-        } else {                                                                                                                   \
-            _Pragma("unroll") for (int kg = 0; kg < 4; ++kg) bfr[SET][kg] = breg2[kg];                                             \
-        }                                                                                                                          \
+                af[SET][kg][mi] = __builtin_bit_cast(uint4, *reinterpret_cast<const lds_u32x4_lv*>((const lds_c*)(size_t)ab[TAP][mi & 1] + (kg * 32 + (mi >> 1) * LVL_GS))); \
+        const lds_c* rb_ = (const lds_c*)(size_t)rslot;                                                                            \
+        _Pragma("unroll") for (int kg = 0; kg < 4; ++kg)                                                                           \
+            bfr[SET][kg] = __builtin_bit_cast(uint4, *reinterpret_cast<const lds_u32x4_lv*>(rb_ + tb[kg]));                        \
+        rslot = rslot + LVL_U_BYTES == ring_base + RING * LVL_U_BYTES ? ring_base : rslot + LVL_U_BYTES;                           \
+        ++q_read;                                                                                                                  \
     } while (0)
 /* before the fragments of ring unit q_read are read: it has landed when at most the units requested after it are outstanding */  \
-#define LV_WAIT_UNIT(KU)                                                                                                          \
+#define LV_WAIT_UNIT()                                                                                                            \
     do {                                                                                                                           \
-        if ((KU) >= REGU) {                                                                                                        \
-            if (d_req - (q_read + 1) >= D)                                                                                         \
-                wait_vm_keep<D * LVL_NPI>();                                                                                       \
-            else                                                                                                                   \
-                wait_vm_keep<0>();                                                                                                 \
-        }                                                                                                                          \
+        if (d_req - (q_read + 1) >= D)                                                                                             \
+            wait_vm_keep<D * LVL_NPI>();                                                                                           \
+        else                                                                                                                       \
+            wait_vm_keep<0>();                                                                                                     \
     } while (0)
 #define LV_MMA(CUR, KG)                                                                            \
     do {                                                                                           \
         _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) mma16<T>(af[CUR][KG][mi], bfr[CUR][KG], acc[mi]); \
     } while (0)
-// one step = the MFMAs of unit k of the pass (fragment set CUR); the request for a later unit goes out under k-group 0, the fragments
-// of unit k + 1 (set NXT) are read under k-groups 1-3
-#define LV_STEP(CUR, NXT)                                                                                                          \
+// one step = the MFMAs of one unit (fragment set CUR); the request for a later unit goes out under k-group 0, the fragments of the
+// pass's next unit (tap NTAP, set CUR ^ 1; NTAP < 0: none) are read under k-groups 1-3
+#define LV_STEP(CUR, NTAP)                                                                                                         \
     do {                                                                                                                           \
-        const bool more_ = k + 1 < taps;                                                                                           \
-        wait_lgkm_all(); /* set CUR is complete - and, if it came from the ring, its slot is free for the unit RING further on */  \
+        wait_lgkm_all(); /* set CUR is complete - and its ring slot is free for the unit RING further on */                        \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
         LV_MMA(CUR, 0);                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
-        if (ku >= REGU && d_left > 0) dma_next();                                                                                  \
+        if (d_left > 0) dma_next();                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
         LV_MMA(CUR, 1);                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
-        if (more_) {                                                                                                               \
-            LV_WAIT_UNIT(ku + 1);                                                                                                  \
-            LV_READ_FRAGS(NXT, k + 1, ku + 1);                                                                                     \
+        if ((NTAP) >= 0) {                                                                                                         \
+            LV_WAIT_UNIT();                                                                                                        \
+            LV_READ_FRAGS((CUR) ^ 1, (NTAP) < 0 ? 0 : (NTAP));                                                                     \
         }                                                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
         LV_MMA(CUR, 2);                                                                                                            \
         LV_MMA(CUR, 3);                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
-        ++k;                                                                                                                       \
-        ++ku;                                                                                                                      \
     } while (0)
                 unsigned rslot = ring_base;  // LDS address of the slot of the next ring unit whose fragments will be read
-                int q_read = 0, ku = 0;      // ring units read so far; index of the unit being multiplied
+                int q_read = 0;              // ring units read so far
                 for (int p = 0; p < npass; ++p) {
                     // ---- A operand of this pass: chunk 4 p + wave of the GB groups' 64 pixels each, gathered after the hand-off ----
                     if (!op.reuse_a) {
@@ -409,25 +372,32 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
 #pragma unroll
                             for (int i = 0; i < 8; ++i) {
                                 const int row = 8 * i + (lane >> 3), px = (bt * GB + j) * LVL_BM + row;
-                                v[j][i] = lvl_ld(rs, (unsigned)((px < npix ? px : 0) * Cs + cb + ((lane & 7) ^ ((row >> 1) & 7)) * 8) * 2u);
+                                v[j][i] = lvl_ld(rs, (unsigned)((px < npix ? px : 0) * Cs + cb + (lane & 7) * 8) * 2u);
                             }
 #pragma unroll
                         for (int j = 0; j < GB; ++j)
 #pragma unroll
                             for (int i = 0; i < 8; ++i)
-                                *reinterpret_cast<uint4*>(ldsA + (j * LVL_BM + 8 * i + (lane >> 3)) * ROW_DATA + (lane & 7) * 16) = v[j][i];
+                                *reinterpret_cast<uint4*>(ldsA + j * LVL_GS + (8 * i + (lane >> 3)) * LVL_PITCH + (lane & 7) * 16) = v[j][i];
                     }
                     if (p == 0 && d_left > 0) dma_next();  // the ring is full now: RING units requested
-                    LV_WAIT_UNIT(ku);
+                    LV_WAIT_UNIT();
                     if (p == 0) LV_STAMP(2);
-                    LV_READ_FRAGS(0, 0, ku);
-                    int k = 0;
-#pragma unroll 1
-                    while (k + 1 < taps) {
+                    if (taps == 9) {
+                        LV_READ_FRAGS(0, 0);
                         LV_STEP(0, 1);
-                        LV_STEP(1, 0);
+                        LV_STEP(1, 2);
+                        LV_STEP(0, 3);
+                        LV_STEP(1, 4);
+                        LV_STEP(0, 5);
+                        LV_STEP(1, 6);
+                        LV_STEP(0, 7);
+                        LV_STEP(1, 8);
+                        LV_STEP(0, -1);
+                    } else {
+                        LV_READ_FRAGS(0, 4);
+                        LV_STEP(0, -1);
                     }
-                    if (k < taps) LV_STEP(0, 1);
                 }
 #undef LV_STEP
 #undef LV_MMA
@@ -579,14 +549,21 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
                         const float d = x[j][e] - mean;
                         m2 = fmaf(d, d, m2);
                     }
-                    lvl_merge16(mean, m2);  // the wave's 16 consecutive pixels of this channel vector
-                    if (lane < 4) {
-                        blk[((j * 4 + wave) * 4 + lane) * 2] = mean;
-                        blk[((j * 4 + wave) * 4 + lane) * 2 + 1] = m2;
+                    lvl_merge16(mean, m2);  // the wave's 16 consecutive pixels of this channel vector: 128 values
+                    // per norm: the group's f adjacent vectors merged in the wave (quad exchanges), one pair per (norm, vector, pixel block)
+                    // in LDS - what a thread reads back is the finished statistic of its pixel block
+#pragma unroll
+                    for (int kx = 0; kx < 2; ++kx) {
+                        if (kx >= op.n_norm) break;
+                        const int f = op.norm[kx].cg >> 3;
+                        float gmn = mean, gm2 = m2;
+                        if (f >= 2) lvl_merge_pair(gmn, gm2, DMME_DPP_F(gmn, 0xB1), DMME_DPP_F(gm2, 0xB1), 128.f);  // quad_perm [1,0,3,2]
+                        if (f >= 4) lvl_merge_pair(gmn, gm2, DMME_DPP_F(gmn, 0x4E), DMME_DPP_F(gm2, 0x4E), 256.f);  // quad_perm [2,3,0,1]
+                        if (lane < 4) *reinterpret_cast<float2*>(blk + ((((j * 2 + kx) * 4 + lane) * 4 + wave) * 2)) = make_float2(gmn, gm2);
                     }
                 }
                 __syncthreads();
-                const int nb = HW >> 4, b_first = ((m >> 4) / nb) * nb;  // pixel blocks (16 px) of this thread's image
+                const int nb = HW >> 4;  // pixel blocks (16 px) per image: 1 (4x4 maps) or 4 (8x8 maps: the image is the whole group)
 #pragma unroll
                 for (int j = 0; j < GB; ++j) {
                     const int n_img = (gpv[j] < 0 ? 0 : gpv[j]) >> sh2;
@@ -594,25 +571,20 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
                     for (int kx = 0; kx < 2; ++kx) {
                         if (kx >= op.n_norm) break;
                         const LvlNorm& G = op.norm[kx];
-                        const int f = G.cg >> 3, v_first = (vec / f) * f;  // the group = f adjacent vectors of this slice
-                        float gna = 0.f, gmean = 0.f, gm2 = 0.f;
-                        for (int vv = 0; vv < f; ++vv) {
-                            float na = 0.f, vmean = 0.f, vm2 = 0.f;  // (image, vector): the image's blocks in pixel order
-                            for (int b = 0; b < nb; ++b) {
-                                const float* q = blk + ((j * 4 + b_first + b) * 4 + v_first + vv) * 2;
-                                const float delta = q[0] - vmean, totn = na + 128.f;
-                                const float rt = __builtin_amdgcn_rcpf(totn);
-                                vmean += delta * (128.f * rt);
-                                vm2 += q[1] + delta * delta * (na * 128.f * rt);
-                                na = totn;
-                            }
-                            const float delta = vmean - gmean, totn = gna + na;  // (image, group): the group's vectors in channel order
-                            const float rt = __builtin_amdgcn_rcpf(totn);
-                            gmean += delta * (na * rt);
-                            gm2 += vm2 + delta * delta * (gna * na * rt);
-                            gna = totn;
+                        const int f = G.cg >> 3, cgsh = 31 - __builtin_clz((unsigned)G.cg);
+                        const float* q = blk + ((j * 2 + kx) * 4 + vec) * 8;
+                        float gmean, gm2;
+                        if (nb == 1) {
+                            const float2 p1 = *reinterpret_cast<const float2*>(q + (m >> 4) * 2);
+                            gmean = p1.x;
+                            gm2 = p1.y;
+                        } else {  // four equal-count sets: the mean of the means, M2 = sum M2_i + n sum (mean_i - mean)^2
+                            const f32x4 p0 = *reinterpret_cast<const f32x4*>(q), p1 = *reinterpret_cast<const f32x4*>(q + 4);
+                            gmean = 0.25f * ((p0[0] + p0[2]) + (p1[0] + p1[2]));
+                            const float d0 = p0[0] - gmean, d1 = p0[2] - gmean, d2 = p1[0] - gmean, d3 = p1[2] - gmean;
+                            gm2 = ((p0[1] + p0[3]) + (p1[1] + p1[3])) + (float)(128 * f) * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
                         }
-                        const float rstd = __builtin_amdgcn_rsqf(gm2 * __builtin_amdgcn_rcpf(gna) + 1e-5f);
+                        const float rstd = __builtin_amdgcn_rsqf(gm2 * __builtin_amdgcn_rcpf((float)(128 * f * nb)) + 1e-5f);
                         const int cn = G.c_off + co;
                         float sc[8], shf[8];
 #pragma unroll
@@ -627,8 +599,8 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
                             *reinterpret_cast<f32x4*>(so + 4) = f32x4{sc[4], sc[5], sc[6], sc[7]};
                             *reinterpret_cast<f32x4*>(ho) = f32x4{shf[0], shf[1], shf[2], shf[3]};
                             *reinterpret_cast<f32x4*>(ho + 4) = f32x4{shf[4], shf[5], shf[6], shf[7]};
-                            if (vec % f == 0) {
-                                float* mo = reinterpret_cast<float*>(A.ws + G.mr_off) + ((int64_t)n_img * (G.Cn / G.cg) + cn / G.cg) * 2;
+                            if ((vec & (f - 1)) == 0) {
+                                float* mo = reinterpret_cast<float*>(A.ws + G.mr_off) + ((int64_t)n_img * (G.Cn >> cgsh) + (cn >> cgsh)) * 2;
                                 mo[0] = gmean;
                                 mo[1] = rstd;
                             }

@@ -63,7 +63,8 @@ struct LvlArgs {
     const float* tproj;       // [nt][tproj_ld]
     int tproj_ld, nt;
     int N, sh;                // batch; log2 of the map's width (= height): 2 or 3
-    int NG, NGS, GB;          // pixel groups; groups per op iteration of a workgroup (1 / 2); iterations resident at once (grid = NGS * LVL_NS)
+    int NG, NGS, GB;          // pixel groups; iterations resident at once (grid = NGS * LVL_NS / NJ); groups per op iteration of a workgroup (1 / 2)
+    int NJ;                   // 32-cout blocks per cout slice: 1 (8 slices per group) or 2 (4 slices of 64 couts; GB = 2 only)
     unsigned* flags;          // [n_ops * 2][NG][LVL_NS]
     unsigned* ctl;            // [0] epoch of the last completed launch, [1] workgroups of this launch that are done, [2] error word
     long long* stamps;        // diagnostic (null: off): 100 MHz wall-clock stamps of workgroup `stamp_wg`, [op iteration][8] (dmme_debug_set_stamps)

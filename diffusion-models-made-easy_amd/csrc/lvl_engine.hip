@@ -32,8 +32,8 @@
 
 namespace dmme {
 
-constexpr int LVL_NPI = LVL_BN / 8;                                    // DMA wave-instructions per filter unit (32 couts x 128 B = 4 KB)
-constexpr int LVL_U_BYTES = LVL_BN * ROW_DATA;
+// A workgroup's cout slice is NJ 32-cout blocks wide (template parameter; lvl.h: 32 couts x 8 slices, or 64 x 4 for large batches).
+// Filter unit = (64-channel chunk, tap) of the slice: NJ x 4 KB, NJ x 4 DMA wave-instructions.
 // One workgroup handles GB pixel groups per op iteration (GB = 2 when a workgroup owns several groups: the filter stream is then shared
 // by twice the matrix work and every fixed cost of an iteration is paid half as often).  Per wave: the A image - GB groups x ONE
 // 64-channel chunk (the K loop runs in passes of 256 channels, wave w takes chunk 4 p + w of pass p) - and the filter ring.
@@ -43,14 +43,14 @@ constexpr int LVL_U_BYTES = LVL_BN * ROW_DATA;
 constexpr int LVL_PITCH = ROW_DATA + 16;
 constexpr int LVL_GS = (LVL_BM + 1) * LVL_PITCH;                       // bytes per pixel group of the A image (9360)
 constexpr int lvl_a_bytes(int gb) { return (gb * LVL_GS + 127) / 128 * 128; }
-constexpr int LVL_WAVE_BYTES = lvl_a_bytes(2) + 4 * LVL_U_BYTES;      // 35200
+constexpr int LVL_WAVE_BYTES = lvl_a_bytes(2) + 16 * 1024;            // 35200: 16 KB of ring (GB = 1: + the 9 KB its A image leaves free)
 constexpr int LVL_KEEP_OFF = 4 * LVL_WAVE_BYTES;                       // q / k / v slices of the attention block: [3][64 px][32 ch] T
 constexpr int LVL_KEEP_BYTES = 3 * LVL_BM * LVL_BN * 2;
-constexpr int LVL_BLK_OFF = LVL_KEEP_OFF + LVL_KEEP_BYTES;             // statistics exchange: [GB][2 norms][4 vectors][4 pixel blocks][2]
+constexpr int LVL_BLK_OFF = LVL_KEEP_OFF + LVL_KEEP_BYTES;             // statistics exchange: [items = GB x NJ][2 norms][4 vectors][4 pixel blocks][2]
 constexpr int LVL_LDS = LVL_BLK_OFF + 1024;
 constexpr int LVL_SPIN_LIMIT = 1 << 19;                                // polls before a wait gives up (~a second)
 static_assert(LVL_LDS <= 160 * 1024, "level engine: LDS budget");
-static_assert(lvl_a_bytes(1) + 6 * LVL_U_BYTES <= LVL_WAVE_BYTES, "level engine: GB = 1 layout");
+static_assert(lvl_a_bytes(1) + 6 * 4096 <= LVL_WAVE_BYTES, "level engine: GB = 1 layout");
 
 size_t lvl_engine_lds_bytes() { return LVL_LDS; }
 
@@ -84,11 +84,11 @@ __device__ __forceinline__ void lvl_st(lvl_rsrc, unsigned, const uint4&) {}
 __device__ __forceinline__ unsigned lvl_flag_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void lvl_flag_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// This WAVE waits until the LVL_NS flag words of row `f` carry this launch's epoch.  Lanes 0-7 poll (sc1 loads), the vote is
+// This WAVE waits until the `ns` flag words of row `f` (one per cout slice) carry this launch's epoch.  Lanes 0-7 poll (sc1 loads), the vote is
 // wave-wide; bounded: after LVL_SPIN_LIMIT polls the error word is set and the wave goes on.
-__device__ __forceinline__ void lvl_wait_row(const unsigned* f, unsigned epoch, int lane, unsigned* err) {
+__device__ __forceinline__ void lvl_wait_row(const unsigned* f, int ns, unsigned epoch, int lane, unsigned* err) {
     for (int spin = 0;; ++spin) {
-        const unsigned v = lane < LVL_NS ? lvl_flag_load(f + lane) : epoch;
+        const unsigned v = lane < ns ? lvl_flag_load(f + lane) : epoch;
         if (__all(v == epoch)) return;
         if ((spin & 1023) == 1023) {  // a wait that timed out anywhere ends every other wait too: the launch drains in milliseconds
             const unsigned e = lvl_flag_load(err);
@@ -134,17 +134,22 @@ __device__ __forceinline__ void lvl_merge16(float& mean, float& m2) {
     }
 }
 
-template <typename T, int GB>
+template <typename T, int GB, int NJ>
 __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const LvlOp* __restrict__ ops) {
-    constexpr int RING = GB == 1 ? 6 : 4;          // filter units per wave ring
+    constexpr int BN = 32 * NJ, NS = LVL_NS / NJ;  // couts per slice, slices per pixel group
+    constexpr int NPI = BN / 8;                    // DMA wave-instructions per filter unit
+    constexpr int U_BYTES = BN * ROW_DATA;
+    constexpr int RING = GB == 1 ? 6 : NJ == 2 ? 2 : 4;   // filter units per wave ring (GB = 1: 24 KB, GB = 2: 16 KB)
     constexpr int D = RING - 1;                    // units requested ahead of the one being consumed
     constexpr int MI = 2 * GB;                     // 32-pixel row blocks per iteration
+    constexpr int GQ = GB * NJ;                    // 64-pixel x 32-cout items per thread and iteration
     constexpr int A_BYTES = lvl_a_bytes(GB);
-    static_assert(D * LVL_NPI < 64, "vmcnt is a 6-bit counter");
+    static_assert(D * NPI < 64 && D >= 1, "vmcnt is a 6-bit counter");
+    static_assert(NJ == 1 || GB == 2, "64-cout slices exist for two-group iterations only (the cross-wave sum uses the whole wave region)");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int s = (int)blockIdx.x % LVL_NS, b0 = (int)blockIdx.x / LVL_NS;
+    const int s = (int)blockIdx.x % NS, b0 = (int)blockIdx.x / NS;
     char* ldsA = lds + wave * LVL_WAVE_BYTES;
     char* ldsR = ldsA + A_BYTES;
     T* keep = reinterpret_cast<T*>(lds + LVL_KEEP_OFF);
@@ -189,7 +194,7 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
     // (Loading an op's first units straight into registers when its stream starts - so that a 256-channel 3x3 conv has all nine units
     // requested before it begins - was measured and removed: hipcc copies loop-carried registers at the back edge and waits for the
     // loads where they are issued; B = 1, 4x4 run: 152 -> 198 us.)
-    unsigned boff[LVL_NPI];
+    unsigned boff[NPI];
     const char* dptr = nullptr;
     unsigned dslot = ring_base;
     int dtap = 0, d_taps = 9, d_cin2 = 0, d_left = 0;  // d_left: ring units of the current stream not yet requested
@@ -197,13 +202,13 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
     bool primed = false;
     auto dma_next = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < LVL_NPI; ++i) glds16_hidden_s(dptr, boff[i], dslot + (unsigned)(i * 8 * ROW_DATA));
+        for (int i = 0; i < NPI; ++i) glds16_hidden_s(dptr, boff[i], dslot + (unsigned)(i * 8 * ROW_DATA));
         dptr += d_cin2;
         if (++dtap == d_taps) {  // next pass: the wave's chunk moves on by 4 chunks (256 channels), tap 0
             dtap = 0;
             dptr += 512 - d_taps * d_cin2;
         }
-        dslot = dslot + LVL_U_BYTES == ring_base + RING * LVL_U_BYTES ? ring_base : dslot + LVL_U_BYTES;
+        dslot = dslot + U_BYTES == ring_base + RING * U_BYTES ? ring_base : dslot + U_BYTES;
         --d_left;
         ++d_req;
     };
@@ -211,9 +216,9 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
     auto prime = [&](const LvlOp& o) __attribute__((always_inline)) {
         const int Cin = o.C1 + o.C2, nu = (Cin >> 8) * o.taps;
 #pragma unroll
-        for (int i = 0; i < LVL_NPI; ++i) {
+        for (int i = 0; i < NPI; ++i) {
             const int row = 8 * i + (lane >> 3);
-            boff[i] = (unsigned)((o.w_row0 + LVL_BN * s + row) * o.taps * Cin + ((lane & 7) ^ ((row >> 1) & 7)) * 8) * 2u;
+            boff[i] = (unsigned)((o.w_row0 + BN * s + row) * o.taps * Cin + ((lane & 7) ^ ((row >> 1) & 7)) * 8) * 2u;
         }
         d_taps = o.taps;
         d_cin2 = Cin * 2;
@@ -235,70 +240,87 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
     for (int oi = 0; oi < A.n_ops; ++oi) {
         const LvlOp& op = ops[oi];
         for (int bt = b0; bt < NB; bt += A.NGS) {
-            const int m = tid >> 2, vec = tid & 3;  // this thread's item of each 64 x 32 slice: pixel m, channels vec * 8 ..
-            const int co = LVL_BN * s + vec * 8;    // first of the thread's 8 channels among the op's 256
+            // this thread's items: pixel m of each of the GB groups x 8 channels (vector vec) of each of the slice's NJ 32-cout blocks;
+            // item q = j * NJ + nj
+            const int m = tid >> 2, vec = tid & 3;
+            const int co0 = BN * s + vec * 8;       // first of the thread's 8 channels among the op's 256 (block nj: + 32 nj)
             int gpv[GB];                            // pixel index in the NHWC tensors per group (-1: past the batch)
 #pragma unroll
             for (int j = 0; j < GB; ++j) {
                 const int g = bt * GB + j, gp = g * LVL_BM + m;
                 gpv[j] = (g < A.NG && gp < npix) ? gp : -1;
             }
-            uint4 ovec[GB];  // the slices' values as stored (T)
+            uint4 ovec[GQ];  // the items' values as stored (T)
             bool have_out = false;
             LV_STAMP(0);
-            // gamma / beta of the norms this op finishes depend on nothing: requested first, used last
-            f32x4 gm[2][2], bt4[2][2];
-            if (op.kind != LVL_ATTN) {
-#pragma unroll
-                for (int kx = 0; kx < 2; ++kx) {
-                    if (kx >= op.n_norm) break;
-                    const LvlNorm& G = op.norm[kx];
-                    const float* gp_ = reinterpret_cast<const float*>(A.packed + G.gamma_off) + G.c_off + co;
-                    const float* bp_ = reinterpret_cast<const float*>(A.packed + G.beta_off) + G.c_off + co;
-                    gm[kx][0] = *reinterpret_cast<const f32x4*>(gp_);
-                    gm[kx][1] = *reinterpret_cast<const f32x4*>(gp_ + 4);
-                    bt4[kx][0] = *reinterpret_cast<const f32x4*>(bp_);
-                    bt4[kx][1] = *reinterpret_cast<const f32x4*>(bp_ + 4);
-                }
-            }
+            // gamma / beta of the norms this op finishes depend on nothing: requested early, used last (32-cout slices: before the main
+            // loop; 64-cout slices: behind it, under the cross-wave sum - the main loop has no registers to spare)
+            f32x4 gm[2][NJ][2], bt4[2][NJ][2];
+#define LV_LOAD_GAMMA_BETA()                                                                                                        \
+    do {                                                                                                                           \
+        _Pragma("unroll") for (int kx = 0; kx < 2; ++kx) {                                                                         \
+            if (kx >= op.n_norm) break;                                                                                            \
+            const LvlNorm& G = op.norm[kx];                                                                                        \
+            _Pragma("unroll") for (int nj = 0; nj < NJ; ++nj) {                                                                    \
+                const float* gp_ = reinterpret_cast<const float*>(A.packed + G.gamma_off) + G.c_off + co0 + 32 * nj;               \
+                const float* bp_ = reinterpret_cast<const float*>(A.packed + G.beta_off) + G.c_off + co0 + 32 * nj;                \
+                gm[kx][nj][0] = *reinterpret_cast<const f32x4*>(gp_);                                                              \
+                gm[kx][nj][1] = *reinterpret_cast<const f32x4*>(gp_ + 4);                                                          \
+                bt4[kx][nj][0] = *reinterpret_cast<const f32x4*>(bp_);                                                             \
+                bt4[kx][nj][1] = *reinterpret_cast<const f32x4*>(bp_ + 4);                                                         \
+            }                                                                                                                      \
+        }                                                                                                                          \
+    } while (0)
+            if (op.kind == LVL_NORM || (op.kind == LVL_CONV && NJ == 1)) LV_LOAD_GAMMA_BETA();
 
             if (op.kind == LVL_CONV) {
                 const int Cin = op.C1 + op.C2, taps = op.taps, npass = Cin >> 8;
                 if (!primed) prime(op);
-                // what the items need besides the sums is requested NOW (residual, bias, time row: a round trip of 1-2 us that the main loop hides)
-                uint4 resv[GB];
-                const float* bp = reinterpret_cast<const float*>(A.packed + op.b_off) + op.w_row0 + co;
-                const f32x4 b0v = *reinterpret_cast<const f32x4*>(bp), b1v = *reinterpret_cast<const f32x4*>(bp + 4);
-                float fold[GB][8];
-#pragma unroll
-                for (int j = 0; j < GB; ++j) {
-                    const int gpc = gpv[j] < 0 ? 0 : gpv[j];
-                    resv[j] = make_uint4(0u, 0u, 0u, 0u);
-                    if (op.res_off >= 0) {
-                        const lvl_rsrc rr = lvl_make_rsrc(A.ws + op.res_off, (unsigned)npix * (unsigned)op.res_C * 2u);
-                        resv[j] = lvl_ld(rr, (unsigned)(gpc * op.res_C + op.res_c0 + co) * 2u);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        fold[j][e] = b0v[e];
-                        fold[j][4 + e] = b1v[e];
-                    }
-                    if (op.tproj_col >= 0) {
-                        const float* tp = A.tproj + (int64_t)(A.nt == 1 ? 0 : gpc >> sh2) * A.tproj_ld + op.tproj_col + co;
-                        const f32x4 t0 = *reinterpret_cast<const f32x4*>(tp), t1 = *reinterpret_cast<const f32x4*>(tp + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            fold[j][e] += t0[e];
-                            fold[j][4 + e] += t1[e];
-                        }
-                    }
-                }
-                f32x16 acc[MI];
+                // what the items need besides the sums is requested NOW (residual, bias, time row: a round trip of 1-2 us that the main loop hides; 64-cout slices: behind the main loop,
+                // like gamma / beta)
+                uint4 resv[GQ];
+                float fold[GQ][8];
+#define LV_LOAD_FOLD()                                                                                                             \
+    do {                                                                                                                           \
+_Pragma("unroll") \
+                for (int q = 0; q < GQ; ++q) { \
+                    const int j = q / NJ, co = co0 + 32 * (q % NJ); \
+                    const int gpc = gpv[j] < 0 ? 0 : gpv[j]; \
+                    const float* bp = reinterpret_cast<const float*>(A.packed + op.b_off) + op.w_row0 + co; \
+                    const f32x4 b0v = *reinterpret_cast<const f32x4*>(bp), b1v = *reinterpret_cast<const f32x4*>(bp + 4); \
+                    resv[q] = make_uint4(0u, 0u, 0u, 0u); \
+                    if (op.res_off >= 0) { \
+                        const lvl_rsrc rr = lvl_make_rsrc(A.ws + op.res_off, (unsigned)npix * (unsigned)op.res_C * 2u); \
+                        resv[q] = lvl_ld(rr, (unsigned)(gpc * op.res_C + op.res_c0 + co) * 2u); \
+                    } \
+_Pragma("unroll") \
+                    for (int e = 0; e < 4; ++e) { \
+                        fold[q][e] = b0v[e]; \
+                        fold[q][4 + e] = b1v[e]; \
+                    } \
+                    if (op.tproj_col >= 0) { \
+                        const float* tp = A.tproj + (int64_t)(A.nt == 1 ? 0 : gpc >> sh2) * A.tproj_ld + op.tproj_col + co; \
+                        const f32x4 t0 = *reinterpret_cast<const f32x4*>(tp), t1 = *reinterpret_cast<const f32x4*>(tp + 4); \
+_Pragma("unroll") \
+                        for (int e = 0; e < 4; ++e) { \
+                            fold[q][e] += t0[e]; \
+                            fold[q][4 + e] += t1[e]; \
+                        } \
+                    } \
+                } \
+    } while (0)
+                if (NJ == 1) LV_LOAD_FOLD();
+                f32x16 acc[MI][NJ];
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) acc[mi][j] = 0.f;
-                uint4 af[2][4][MI], bfr[2][4];
+                    for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) acc[mi][nj][j] = 0.f;
+                // fragment registers: 32-cout slices double-buffer whole units (16 MFMAs); 64-cout slices double-buffer k-groups (8 MFMAs
+                // cover the next k-group's six reads) - whole units would be 192 registers beside 128 accumulators
+                uint4 af[NJ == 1 ? 2 : 1][NJ == 1 ? 4 : 1][MI], bfr[NJ == 1 ? 2 : 1][NJ == 1 ? 4 : 1][NJ];
+                uint4 ag[2][MI], bg[2][NJ];
 /* fragments of the unit at tap TAP (a compile-time constant) of the current pass into set SET: the input rows from the A image (one   \
    base per (tap, pixel block); k-group and pixel group are instruction offsets), the filter rows from the ring slot at `rslot`,       \
    which then moves on */                                                                                                            \
@@ -309,21 +331,23 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
                 af[SET][kg][mi] = __builtin_bit_cast(uint4, *reinterpret_cast<const lds_u32x4_lv*>((const lds_c*)(size_t)ab[TAP][mi & 1] + (kg * 32 + (mi >> 1) * LVL_GS))); \
         const lds_c* rb_ = (const lds_c*)(size_t)rslot;                                                                            \
         _Pragma("unroll") for (int kg = 0; kg < 4; ++kg)                                                                           \
-            bfr[SET][kg] = __builtin_bit_cast(uint4, *reinterpret_cast<const lds_u32x4_lv*>(rb_ + tb[kg]));                        \
-        rslot = rslot + LVL_U_BYTES == ring_base + RING * LVL_U_BYTES ? ring_base : rslot + LVL_U_BYTES;                           \
+            _Pragma("unroll") for (int nj = 0; nj < NJ; ++nj)                                                                      \
+                bfr[SET][kg][nj] = __builtin_bit_cast(uint4, *reinterpret_cast<const lds_u32x4_lv*>(rb_ + tb[kg] + nj * 32 * ROW_DATA)); \
+        rslot = rslot + U_BYTES == ring_base + RING * U_BYTES ? ring_base : rslot + U_BYTES;                                       \
         ++q_read;                                                                                                                  \
     } while (0)
 /* before the fragments of ring unit q_read are read: it has landed when at most the units requested after it are outstanding */  \
 #define LV_WAIT_UNIT()                                                                                                            \
     do {                                                                                                                           \
         if (d_req - (q_read + 1) >= D)                                                                                             \
-            wait_vm_keep<D * LVL_NPI>();                                                                                           \
+            wait_vm_keep<D * NPI>();                                                                                           \
         else                                                                                                                       \
             wait_vm_keep<0>();                                                                                                     \
     } while (0)
 #define LV_MMA(CUR, KG)                                                                            \
     do {                                                                                           \
-        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) mma16<T>(af[CUR][KG][mi], bfr[CUR][KG], acc[mi]); \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                          \
+            _Pragma("unroll") for (int nj = 0; nj < NJ; ++nj) mma16<T>(bfr[CUR][KG][nj], af[CUR][KG][mi], acc[mi][nj]); \
     } while (0)
 // one step = the MFMAs of one unit (fragment set CUR); the request for a later unit goes out under k-group 0, the fragments of the
 // pass's next unit (tap NTAP, set CUR ^ 1; NTAP < 0: none) are read under k-groups 1-3
@@ -356,8 +380,8 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
                             for (int j = 0; j < GB; ++j) {
                                 const int g = bt * GB + j;
                                 if (g >= A.NG) break;
-                                if (op.wait0 >= 0) lvl_wait_row(A.flags + ((int64_t)op.wait0 * A.NG + g) * LVL_NS, epoch, lane, err);
-                                if (op.wait1 >= 0) lvl_wait_row(A.flags + ((int64_t)op.wait1 * A.NG + g) * LVL_NS, epoch, lane, err);
+                                if (op.wait0 >= 0) lvl_wait_row(A.flags + ((int64_t)op.wait0 * A.NG + g) * LVL_NS, NS, epoch, lane, err);
+                                if (op.wait1 >= 0) lvl_wait_row(A.flags + ((int64_t)op.wait1 * A.NG + g) * LVL_NS, NS, epoch, lane, err);
                             }
                             lvl_compiler_fence();
                             LV_STAMP(1);
@@ -379,11 +403,68 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
 #pragma unroll
                             for (int i = 0; i < 8; ++i)
                                 *reinterpret_cast<uint4*>(ldsA + j * LVL_GS + (8 * i + (lane >> 3)) * LVL_PITCH + (lane & 7) * 16) = v[j][i];
+                        if (NJ == 2 && lane < GB * 9)  // (the cross-wave sum of the previous iteration ran over the rows of zeros)
+                            *reinterpret_cast<uint4*>(ldsA + (lane / 9) * LVL_GS + LVL_BM * LVL_PITCH + (lane % 9) * 16) = make_uint4(0u, 0u, 0u, 0u);
                     }
                     if (p == 0 && d_left > 0) dma_next();  // the ring is full now: RING units requested
                     LV_WAIT_UNIT();
                     if (p == 0) LV_STAMP(2);
-                    if (taps == 9) {
+/* 64-cout slices.  k-group KG of the unit at tap TAP into set SET (the unit's slot is `rslot`) */                                \
+#define LV2_READ(SET, TAP, KG)                                                                                                     \
+    do {                                                                                                                           \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                                          \
+            ag[SET][mi] = __builtin_bit_cast(uint4, *reinterpret_cast<const lds_u32x4_lv*>((const lds_c*)(size_t)ab[TAP][mi & 1] + ((KG) * 32 + (mi >> 1) * LVL_GS))); \
+        const lds_c* rb_ = (const lds_c*)(size_t)rslot;                                                                            \
+        _Pragma("unroll") for (int nj = 0; nj < NJ; ++nj)                                                                          \
+            bg[SET][nj] = __builtin_bit_cast(uint4, *reinterpret_cast<const lds_u32x4_lv*>(rb_ + tb[KG] + nj * 32 * ROW_DATA));    \
+        __builtin_amdgcn_sched_barrier(0);                                                                                         \
+    } while (0)
+#define LV2_MMA(SET)                                                                               \
+    do {                                                                                           \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                          \
+            _Pragma("unroll") for (int nj = 0; nj < NJ; ++nj) mma16<T>(bg[SET][nj], ag[SET][mi], acc[mi][nj]); \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
+/* one unit (its k-group 0 is already on its way into set 0): the reads run one k-group ahead of the MFMAs; once the unit's last     \
+   read has landed its ring slot takes the request for the unit two further on, and k-group 0 of the pass's next unit (tap NTAP)    \
+   is read under the last MFMAs */                                                                                                 \
+#define LV2_UNIT(TAP, NTAP)                                                                                                        \
+    do {                                                                                                                           \
+        LV2_READ(1, TAP, 1);                                                                                                       \
+        LV2_MMA(0);                                                                                                                \
+        LV2_READ(0, TAP, 2);                                                                                                       \
+        LV2_MMA(1);                                                                                                                \
+        LV2_READ(1, TAP, 3);                                                                                                       \
+        LV2_MMA(0);                                                                                                                \
+        wait_lgkm_all();                                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                                         \
+        rslot = rslot + U_BYTES == ring_base + RING * U_BYTES ? ring_base : rslot + U_BYTES;                                       \
+        ++q_read;                                                                                                                  \
+        if (d_left > 0) dma_next();                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                                         \
+        if ((NTAP) >= 0) {                                                                                                         \
+            LV_WAIT_UNIT();                                                                                                        \
+            LV2_READ(0, (NTAP) < 0 ? 0 : (NTAP), 0);                                                                               \
+        }                                                                                                                          \
+        LV2_MMA(1);                                                                                                                \
+    } while (0)
+                    if (NJ == 2) {
+                        if (taps == 9) {
+                            LV2_READ(0, 0, 0);
+                            LV2_UNIT(0, 1);
+                            LV2_UNIT(1, 2);
+                            LV2_UNIT(2, 3);
+                            LV2_UNIT(3, 4);
+                            LV2_UNIT(4, 5);
+                            LV2_UNIT(5, 6);
+                            LV2_UNIT(6, 7);
+                            LV2_UNIT(7, 8);
+                            LV2_UNIT(8, -1);
+                        } else {
+                            LV2_READ(0, 4, 0);
+                            LV2_UNIT(4, -1);
+                        }
+                    } else if (taps == 9) {
                         LV_READ_FRAGS(0, 0);
                         LV_STEP(0, 1);
                         LV_STEP(1, 2);
@@ -399,29 +480,46 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
                         LV_STEP(0, -1);
                     }
                 }
+#undef LV2_UNIT
+#undef LV2_MMA
+#undef LV2_READ
 #undef LV_STEP
 #undef LV_MMA
 #undef LV_WAIT_UNIT
 #undef LV_READ_FRAGS
                 primed = false;
                 LV_STAMP(3);
-                // ---- partial tiles of this wave -> its own ring (every unit has been consumed; the next stream starts after the
-                // epilogue; the A image stays intact for an op that shares it) ----
-                float* redw = reinterpret_cast<float*>(ldsR);
+                // ---- partial tiles of this wave -> its own LDS (every unit has been consumed; the next stream starts after the epilogue).
+                // 32-cout slices: 16 KB, the ring - the A image stays intact for an op that shares it; 64-cout slices: 32 KB from the
+                // start of the wave's region (the next gather rewrites the A image and its rows of zeros) ----
+                if (NJ == 2) {
+                    LV_LOAD_FOLD();
+                    LV_LOAD_GAMMA_BETA();
+                }
+#undef LV_LOAD_FOLD
+                constexpr int RED_OFF = NJ == 1 ? A_BYTES : 0;
+                // The MFMAs run transposed (filter rows as the A operand): a lane holds ONE pixel (column lane & 31) and, per group of four
+                // registers g, the four consecutive couts 8 g + 4 (lane >> 5) ..: a partial tile is [32 pixels][32 couts] fp32 in 128-byte
+                // rows, written as 16-byte pieces (chunk 2 g + h, XOR-swizzled by the pixel) - 4 LDS writes per tile instead of 16
+                char* redw = ldsA + RED_OFF;
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) redw[(mi * 16 + j) * 64 + lane] = acc[mi][j];
-                __syncthreads();
-                // acc layout of a 32 x 32 tile: lane = cout column + 32 * (pixel row bit 2), register j = pixel rows (j & 3) + 8 * (j >> 2)
-                const int pr = m & 31, jj = (pr & 3) + 4 * (pr >> 3), hh = (pr >> 2) & 1;
+                    for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
-                for (int j = 0; j < GB; ++j) {
+                        for (int g4 = 0; g4 < 4; ++g4)
+                            *reinterpret_cast<f32x4*>(redw + (mi * NJ + nj) * 4096 + r * 128 + (((2 * g4 + h) ^ (r & 7)) << 4)) =
+                                f32x4{acc[mi][nj][4 * g4], acc[mi][nj][4 * g4 + 1], acc[mi][nj][4 * g4 + 2], acc[mi][nj][4 * g4 + 3]};
+                __syncthreads();
+                const int pr = m & 31;
+#pragma unroll
+                for (int q = 0; q < GQ; ++q) {
+                    const int j = q / NJ, nj = q % NJ, co = co0 + 32 * nj;
                     float v[8];
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
-                        const float* q = reinterpret_cast<const float*>(lds + w * LVL_WAVE_BYTES + A_BYTES) + ((2 * j + (m >> 5)) * 16 + jj) * 64 + hh * 32 + vec * 8;
-                        const f32x4 x0 = *reinterpret_cast<const f32x4*>(q), x1 = *reinterpret_cast<const f32x4*>(q + 4);
+                        const char* pq = lds + w * LVL_WAVE_BYTES + RED_OFF + ((2 * j + (m >> 5)) * NJ + nj) * 4096 + pr * 128;
+                        const f32x4 x0 = *reinterpret_cast<const f32x4*>(pq + (((2 * vec) ^ (pr & 7)) << 4)), x1 = *reinterpret_cast<const f32x4*>(pq + (((2 * vec + 1) ^ (pr & 7)) << 4));
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             v[e] = w == 0 ? x0[e] : v[e] + x0[e];
@@ -429,28 +527,30 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
                         }
                     }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += fold[j][e];
+                    for (int e = 0; e < 8; ++e) v[e] += fold[q][e];
                     if (op.res_off >= 0) {
                         float rv[8];
-                        unpack8<T>(resv[j], rv);
+                        unpack8<T>(resv[q], rv);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += rv[e];
                     }
-                    ovec[j] = pack8<T>(v);
+                    ovec[q] = pack8<T>(v);
                     if (op.dst_off >= 0 && gpv[j] >= 0) {
                         const lvl_rsrc rd = lvl_make_rsrc(A.ws + op.dst_off, (unsigned)npix * (unsigned)op.dst_C * 2u);
-                        lvl_st(rd, (unsigned)(gpv[j] * op.dst_C + op.dst_c0 + co) * 2u, ovec[j]);
+                        lvl_st(rd, (unsigned)(gpv[j] * op.dst_C + op.dst_c0 + co) * 2u, ovec[q]);
                     }
-                    if (GB == 1 && op.keep >= 0) *reinterpret_cast<uint4*>(keep + (op.keep * LVL_BM + m) * LVL_BN + vec * 8) = ovec[j];
+                    if (GB == 1 && op.keep >= 0) *reinterpret_cast<uint4*>(keep + (op.keep * LVL_BM + m) * LVL_BN + vec * 8) = ovec[q];
                 }
                 have_out = true;
             } else if (op.kind == LVL_NORM) {
                 // a tensor written before this launch (stride-2 / upsampling conv output): its slice is only normalised here
                 const T* src = reinterpret_cast<const T*>(A.ws + op.dst_off);
 #pragma unroll
-                for (int j = 0; j < GB; ++j) ovec[j] = *reinterpret_cast<const uint4*>(src + (int64_t)(gpv[j] < 0 ? 0 : gpv[j]) * op.dst_C + op.dst_c0 + co);
+                for (int q = 0; q < GQ; ++q)
+                    ovec[q] = *reinterpret_cast<const uint4*>(src + (int64_t)(gpv[q / NJ] < 0 ? 0 : gpv[q / NJ]) * op.dst_C + op.dst_c0 + co0 + 32 * (q % NJ));
                 have_out = true;
-            } else if (GB == 1) {
+            } else if (GB == 1 && NJ == 1) {
+                const int co = co0;
                 // ---- single-head attention over the 16 pixels of each 4x4 image (models/ddpm.py:54-63): this workgroup holds channels
                 // [32 s, 32 s + 32) of q, k, v of its 4 images (keep slots 0 / 1 / 2).  Partial scores over those channels -> exchange ->
                 // full scores, softmax, P (rounded to T as attn_s16_kernel does) x this slice of v.
@@ -485,7 +585,7 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
                 wait_vm_all();
                 __syncthreads();
                 if (tid == 0) lvl_flag_store(A.flags + ((int64_t)(oi * 2 + 1) * A.NG + g) * LVL_NS + s, epoch);
-                lvl_wait_row(A.flags + ((int64_t)(oi * 2 + 1) * A.NG + g) * LVL_NS, epoch, lane, err);
+                lvl_wait_row(A.flags + ((int64_t)(oi * 2 + 1) * A.NG + g) * LVL_NS, NS, epoch, lane, err);
                 lvl_compiler_fence();
                 uint4 part[LVL_NS];
 #pragma unroll
@@ -536,17 +636,17 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
 
             // ---- the GroupNorms that read these slices: statistics, rows, the consumers' pre-activated inputs ----
             if (have_out && op.n_norm > 0) {
-                float x[GB][8];
+                float x[GQ][8];
 #pragma unroll
-                for (int j = 0; j < GB; ++j) {
-                    unpack8<T>(ovec[j], x[j]);  // statistics of the values the consumers read back (rounded to T)
+                for (int q = 0; q < GQ; ++q) {
+                    unpack8<T>(ovec[q], x[q]);  // statistics of the values the consumers read back (rounded to T)
                     float sm = 0.f;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) sm += x[j][e];
+                    for (int e = 0; e < 8; ++e) sm += x[q][e];
                     float mean = sm * 0.125f, m2 = 0.f;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float d = x[j][e] - mean;
+                        const float d = x[q][e] - mean;
                         m2 = fmaf(d, d, m2);
                     }
                     lvl_merge16(mean, m2);  // the wave's 16 consecutive pixels of this channel vector: 128 values
@@ -559,27 +659,28 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
                         float gmn = mean, gm2 = m2;
                         if (f >= 2) lvl_merge_pair(gmn, gm2, DMME_DPP_F(gmn, 0xB1), DMME_DPP_F(gm2, 0xB1), 128.f);  // quad_perm [1,0,3,2]
                         if (f >= 4) lvl_merge_pair(gmn, gm2, DMME_DPP_F(gmn, 0x4E), DMME_DPP_F(gm2, 0x4E), 256.f);  // quad_perm [2,3,0,1]
-                        if (lane < 4) *reinterpret_cast<float2*>(blk + ((((j * 2 + kx) * 4 + lane) * 4 + wave) * 2)) = make_float2(gmn, gm2);
+                        if (lane < 4) *reinterpret_cast<float2*>(blk + ((((q * 2 + kx) * 4 + lane) * 4 + wave) * 2)) = make_float2(gmn, gm2);
                     }
                 }
                 __syncthreads();
                 const int nb = HW >> 4;  // pixel blocks (16 px) per image: 1 (4x4 maps) or 4 (8x8 maps: the image is the whole group)
 #pragma unroll
-                for (int j = 0; j < GB; ++j) {
+                for (int q = 0; q < GQ; ++q) {
+                    const int j = q / NJ, nj = q % NJ, co = co0 + 32 * nj;
                     const int n_img = (gpv[j] < 0 ? 0 : gpv[j]) >> sh2;
 #pragma unroll
                     for (int kx = 0; kx < 2; ++kx) {
                         if (kx >= op.n_norm) break;
                         const LvlNorm& G = op.norm[kx];
                         const int f = G.cg >> 3, cgsh = 31 - __builtin_clz((unsigned)G.cg);
-                        const float* q = blk + ((j * 2 + kx) * 4 + vec) * 8;
+                        const float* pq = blk + ((q * 2 + kx) * 4 + vec) * 8;
                         float gmean, gm2;
                         if (nb == 1) {
-                            const float2 p1 = *reinterpret_cast<const float2*>(q + (m >> 4) * 2);
+                            const float2 p1 = *reinterpret_cast<const float2*>(pq + (m >> 4) * 2);
                             gmean = p1.x;
                             gm2 = p1.y;
                         } else {  // four equal-count sets: the mean of the means, M2 = sum M2_i + n sum (mean_i - mean)^2
-                            const f32x4 p0 = *reinterpret_cast<const f32x4*>(q), p1 = *reinterpret_cast<const f32x4*>(q + 4);
+                            const f32x4 p0 = *reinterpret_cast<const f32x4*>(pq), p1 = *reinterpret_cast<const f32x4*>(pq + 4);
                             gmean = 0.25f * ((p0[0] + p0[2]) + (p1[0] + p1[2]));
                             const float d0 = p0[0] - gmean, d1 = p0[2] - gmean, d2 = p1[0] - gmean, d3 = p1[2] - gmean;
                             gm2 = ((p0[1] + p0[3]) + (p1[1] + p1[3])) + (float)(128 * f) * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
@@ -589,8 +690,8 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
                         float sc[8], shf[8];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            sc[e] = rstd * gm[kx][e >> 2][e & 3];
-                            shf[e] = bt4[kx][e >> 2][e & 3] - gmean * sc[e];
+                            sc[e] = rstd * gm[kx][nj][e >> 2][e & 3];
+                            shf[e] = bt4[kx][nj][e >> 2][e & 3] - gmean * sc[e];
                         }
                         if (gpv[j] >= 0 && (m & (HW - 1)) == 0) {  // first pixel of an image: the rows the backward pass reads
                             float* so = reinterpret_cast<float*>(A.ws + G.scale_off) + (int64_t)n_img * G.Cn + cn;
@@ -608,7 +709,7 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
                         if (G.act_off >= 0 && gpv[j] >= 0) {
                             float y[8];
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) y[e] = fmaf(x[j][e], sc[e], shf[e]);
+                            for (int e = 0; e < 8; ++e) y[e] = fmaf(x[q][e], sc[e], shf[e]);
                             if (G.act_silu) {
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) y[e] = silu_fast(y[e]);
@@ -645,6 +746,7 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
             ++stamp_it;
         }
     }
+#undef LV_LOAD_GAMMA_BETA
 #undef LV_STAMP
     if (tid == 0) {  // the last workgroup to finish closes the epoch
         const unsigned old = __hip_atomic_fetch_add(&A.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -655,24 +757,25 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
     }
 }
 
-template <typename T, int GB>
+template <typename T, int GB, int NJ>
 static int launch_lvl_inst(const LvlArgs& a, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lvl_engine_kernel<T, GB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lvl_engine_kernel<T, GB, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    hipLaunchKernelGGL((lvl_engine_kernel<T, GB>), dim3((unsigned)(a.NGS * LVL_NS)), dim3(256), LVL_LDS, s, a, a.ops);
+    hipLaunchKernelGGL((lvl_engine_kernel<T, GB, NJ>), dim3((unsigned)(a.NGS * (LVL_NS / NJ))), dim3(256), LVL_LDS, s, a, a.ops);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }
 
 int launch_lvl_engine(int dtype, const LvlArgs& a, hipStream_t s) {
     DMME_REQUIRE(dtype == DMME_BF16 || dtype == DMME_F16, DMME_ERR_UNSUPPORTED, "level engine: 16-bit operand types only");
-    DMME_REQUIRE(a.NGS >= 1 && a.NGS * LVL_NS <= LVL_MAX_WG && a.NG >= 1 && (a.sh == 2 || a.sh == 3) && (a.GB == 1 || a.GB == 2), DMME_ERR_INVALID,
-                 "level engine: bad geometry");
-    if (dtype == DMME_F16) return a.GB == 2 ? launch_lvl_inst<f16, 2>(a, s) : launch_lvl_inst<f16, 1>(a, s);
-    return a.GB == 2 ? launch_lvl_inst<bf16, 2>(a, s) : launch_lvl_inst<bf16, 1>(a, s);
+    DMME_REQUIRE(a.NGS >= 1 && (a.NJ == 1 || (a.NJ == 2 && a.GB == 2)) && a.NGS * (LVL_NS / a.NJ) <= LVL_MAX_WG && a.NG >= 1 && (a.sh == 2 || a.sh == 3) &&
+                     (a.GB == 1 || a.GB == 2),
+                 DMME_ERR_INVALID, "level engine: bad geometry");
+    if (dtype == DMME_F16) return a.NJ == 2 ? launch_lvl_inst<f16, 2, 2>(a, s) : a.GB == 2 ? launch_lvl_inst<f16, 2, 1>(a, s) : launch_lvl_inst<f16, 1, 1>(a, s);
+    return a.NJ == 2 ? launch_lvl_inst<bf16, 2, 2>(a, s) : a.GB == 2 ? launch_lvl_inst<bf16, 2, 1>(a, s) : launch_lvl_inst<bf16, 1, 1>(a, s);
 }
 
 }  // namespace dmme

@@ -98,7 +98,7 @@ struct Op {
 // one persistent launch for a stretch of the op list on a 4x4 / 8x8 map (lvl.h)
 struct LvlRun {
     int op_first = 0, op_last = 0;  // plan ops [op_first, op_last]
-    int sh = 0, NG = 0, NGS = 0, GB = 1;
+    int sh = 0, NG = 0, NGS = 0, GB = 1, NJ = 1;
     std::vector<LvlOp> ops;
     std::vector<std::pair<int, int>> made;  // (tensor id, index of the op that produces / normalises it): later runs attach norms there
     LvlOp* ops_dev = nullptr;
@@ -1232,9 +1232,13 @@ void assign_levels(dmme_plan* P) {
                 // the attention block keeps q / k / v of ONE group in LDS
                 bool has_attn = false;
                 for (const LvlOp& lo : R.ops) has_attn = has_attn || lo.kind == LVL_ATTN;
-                const int slots = LVL_MAX_WG / LVL_NS;
+                int slots = LVL_MAX_WG / LVL_NS;
                 R.GB = (R.NG > slots && !has_attn && !getenv("DMME_LVL_GB1")) ? 2 : 1;
                 const int nb = (R.NG + R.GB - 1) / R.GB;
+                // still more than one iteration per workgroup: 64-cout slices (4 per group) - half the iterations, the input gathered
+                // by half as many workgroups, 128 x 64 per filter unit instead of 128 x 32 (B = 128, 8x8 maps: 2 iterations -> 1)
+                R.NJ = (R.GB == 2 && nb > slots && !getenv("DMME_LVL_NJ1")) ? 2 : 1;
+                slots *= R.NJ;
                 R.NGS = nb < slots ? nb : slots;
                 // more than two iterations per op and workgroup: the per-layer kernels (tiles over the whole batch) are the better
                 // route again - measured at batch 512 (DDIM): 8.2 ms per step with them, 8.9 with the engine
@@ -1523,6 +1527,7 @@ int run_level(const dmme_plan* P, const LvlRun& R, const char* pk, char* ws, int
     a.NG = R.NG;
     a.NGS = R.NGS;
     a.GB = R.GB;
+    a.NJ = R.NJ;
     a.ctl = R.sync_dev;
     a.flags = R.sync_dev + 16;
     if (g_lvl_stamps && g_lvl_stamp_run == (int)(&R - P->lvl_runs.data())) {
@@ -1945,8 +1950,8 @@ DMME_API int dmme_unet_plan_level_info(const dmme_plan* plan, char* buf, int cap
     for (const LvlRun& R : plan->lvl_runs) {
         unsigned ctl[3] = {0, 0, 0};
         if (R.sync_dev) DMME_CHECK_HIP(hipMemcpy(ctl, R.sync_dev, sizeof(ctl), hipMemcpyDeviceToHost));  // (synchronises with the device)
-        snprintf(tmp, sizeof(tmp), " [map=%dx%d plan_ops=%d-%d engine_ops=%d groups=%d per_iteration=%d workgroups=%d epoch=%u err=%u]", 1 << R.sh, 1 << R.sh,
-                 R.op_first, R.op_last, (int)R.ops.size(), R.NG, R.GB, R.NGS * LVL_NS, ctl[0], ctl[2]);
+        snprintf(tmp, sizeof(tmp), " [map=%dx%d plan_ops=%d-%d engine_ops=%d groups=%d per_iteration=%d slice=%d workgroups=%d epoch=%u err=%u]", 1 << R.sh, 1 << R.sh,
+                 R.op_first, R.op_last, (int)R.ops.size(), R.NG, R.GB, 32 * R.NJ, R.NGS * (LVL_NS / R.NJ), ctl[0], ctl[2]);
         out += tmp;
     }
     strncpy(buf, out.c_str(), (size_t)cap - 1);

@@ -208,36 +208,45 @@ __device__ __forceinline__ uint4 prologue_vec<float>(uint4 raw, const float* sc,
     }
     return __builtin_bit_cast(uint4, v);
 }
+// 16-bit tensors: the eight values as four pairs (the two halves of a dword = adjacent channels), every operation a packed fp32
+// instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: the same IEEE operations as the scalar forms, two per issue slot) - these
+// prologues run on SIMDs that also feed the matrix cores, and VALU issue cycles are what they cost
 template <typename T>
 __device__ __forceinline__ uint4 prologue_vec16(uint4 raw, const float* sc, const float* sh, const float* dm, int pro_silu) {
     if (!sc && !pro_silu && !dm) return raw;
     typename Vec8<T>::type x = __builtin_bit_cast(typename Vec8<T>::type, raw);
-    float v[8];
+    f32x2 v[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (float)x[j];
+    for (int d = 0; d < 4; ++d) v[d] = f32x2{(float)x[2 * d], (float)x[2 * d + 1]};
     if (sc) {
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(sc), a1 = *reinterpret_cast<const f32x4*>(sc + 4);
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(sh), b1 = *reinterpret_cast<const f32x4*>(sh + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v[j] = fmaf(v[j], a0[j], b0[j]);
-            v[4 + j] = fmaf(v[4 + j], a1[j], b1[j]);
-        }
+        v[0] = __builtin_elementwise_fma(v[0], f32x2{a0[0], a0[1]}, f32x2{b0[0], b0[1]});
+        v[1] = __builtin_elementwise_fma(v[1], f32x2{a0[2], a0[3]}, f32x2{b0[2], b0[3]});
+        v[2] = __builtin_elementwise_fma(v[2], f32x2{a1[0], a1[1]}, f32x2{b1[0], b1[1]});
+        v[3] = __builtin_elementwise_fma(v[3], f32x2{a1[2], a1[3]}, f32x2{b1[2], b1[3]});
     }
-    if (pro_silu) {
+    if (pro_silu) {  // silu_fast, pairwise: x * rcp(1 + exp2(-log2(e) x))
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = silu_fast(v[j]);
+        for (int d = 0; d < 4; ++d) {
+            f32x2 e = v[d] * f32x2{-1.4426950408889634f, -1.4426950408889634f};
+            e = f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+            e = f32x2{1.0f, 1.0f} + e;
+            v[d] = v[d] * f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+        }
     }
     if (dm) {
         const f32x4 m0 = *reinterpret_cast<const f32x4*>(dm), m1 = *reinterpret_cast<const f32x4*>(dm + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v[j] *= m0[j];
-            v[4 + j] *= m1[j];
-        }
+        v[0] = v[0] * f32x2{m0[0], m0[1]};
+        v[1] = v[1] * f32x2{m0[2], m0[3]};
+        v[2] = v[2] * f32x2{m1[0], m1[1]};
+        v[3] = v[3] * f32x2{m1[2], m1[3]};
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = (T)v[j];
+    for (int d = 0; d < 4; ++d) {
+        x[2 * d] = (T)v[d][0];
+        x[2 * d + 1] = (T)v[d][1];
+    }
     return __builtin_bit_cast(uint4, x);
 }
 template <>
@@ -357,27 +366,34 @@ __device__ __forceinline__ uint4 prologue_vec_ldsrows(uint4 raw, const float* sc
     const lc* s3 = (const lc*)sc_lds;
     const lc* h3 = (const lc*)sh_lds;
     typename Vec8<T>::type x = __builtin_bit_cast(typename Vec8<T>::type, raw);
-    float v[8];
+    f32x2 v[4];  // (pairs and packed fp32 operations, as prologue_vec16)
 #pragma unroll
     for (int e = 0; e < 8; e += 4) {
         const f32x4 s4 = *(const lf4*)(s3 + e * 4), h4 = *(const lf4*)(h3 + e * 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[e + j] = fmaf((float)x[e + j], s4[j], h4[j]);
+        v[e / 2] = __builtin_elementwise_fma(f32x2{(float)x[e], (float)x[e + 1]}, f32x2{s4[0], s4[1]}, f32x2{h4[0], h4[1]});
+        v[e / 2 + 1] = __builtin_elementwise_fma(f32x2{(float)x[e + 2], (float)x[e + 3]}, f32x2{s4[2], s4[3]}, f32x2{h4[2], h4[3]});
     }
     if (pro_silu) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = silu_fast(v[e]);
+        for (int d = 0; d < 4; ++d) {
+            f32x2 e2 = v[d] * f32x2{-1.4426950408889634f, -1.4426950408889634f};
+            e2 = f32x2{__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])};
+            e2 = f32x2{1.0f, 1.0f} + e2;
+            v[d] = v[d] * f32x2{__builtin_amdgcn_rcpf(e2[0]), __builtin_amdgcn_rcpf(e2[1])};
+        }
     }
     if (dm) {
         const f32x4 m0 = *reinterpret_cast<const f32x4*>(dm), m1 = *reinterpret_cast<const f32x4*>(dm + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v[j] *= m0[j];
-            v[4 + j] *= m1[j];
-        }
+        v[0] = v[0] * f32x2{m0[0], m0[1]};
+        v[1] = v[1] * f32x2{m0[2], m0[3]};
+        v[2] = v[2] * f32x2{m1[0], m1[1]};
+        v[3] = v[3] * f32x2{m1[2], m1[3]};
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = (T)v[e];
+    for (int d = 0; d < 4; ++d) {
+        x[2 * d] = (T)v[d][0];
+        x[2 * d + 1] = (T)v[d][1];
+    }
     return __builtin_bit_cast(uint4, x);
 }
 

@@ -408,9 +408,10 @@ __device__ __forceinline__ void ws_fill_par_gni(const ConvArgs& a, int n, bool w
         float sc, sh;
         const float dmk = a.dmask ? a.dmask[n * Cin + c] : 1.f;
         gn_in_scale_shift(a, n, c, Cin, writer, sc, sh);
-        par[c] = sc;
-        par[Cin + c] = sh;
-        par[2 * Cin + c] = dmk;
+        par[c] = sc * dmk;
+        par[Cin + c] = sh * dmk;
+        par[2 * Cin + c] = a.pro_silu ? -1.4426950408889634f * sc : 0.f;
+        par[3 * Cin + c] = a.pro_silu ? -1.4426950408889634f * sh : -126.f;
     }
 }
 
@@ -425,10 +426,12 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
     const int a_bytes = g.a_rows * A_PITCH;
     const int Cin = a.C1 + a.C2;
     const int offA1 = a_bytes + 3 * R_BYTES, offR = a_bytes;
-    float* par_base = reinterpret_cast<float*>(lds + 2 * a_bytes + 3 * R_BYTES);  // [2][3][Cin]: scale, shift, mask
+    // [2][4][Cin]: per channel of the tile's image, as the producers' packed prologue wants them: S = scale * mask, H = shift * mask,
+    // S2 = -log2(e) * scale, H2 = -log2(e) * shift:  act(x) = (x S + H) / (1 + 2^(x S2 + H2))  [= silu(x scale + shift) * mask]
+    float* par_base = reinterpret_cast<float*>(lds + 2 * a_bytes + 3 * R_BYTES);
 #define WS_BUFA(p) (lds + (((p) & 1) ? offA1 : 0))
 #define WS_RING(slot) (lds + offR + (slot) * R_BYTES)
-#define WS_PAR(kt) (par_base + ((kt) & 1) * 3 * Cin)
+#define WS_PAR(kt) (par_base + ((kt) & 1) * 4 * Cin)
 #define WS_TILE(kt) ws_tile_of(g, shTW, shTH, (kt), BN)
     typedef WsTile TileXY;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -449,9 +452,11 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             const int pn0 = ft_.n0;                                       \
             for (int c = tid; c < Cin; c += (NTHR)) {                     \
                 const int so = pn0 * Cin + c;                             \
-                par[c] = a.scale ? a.scale[so] : 1.f;                     \
-                par[Cin + c] = a.scale ? a.shift[so] : 0.f;               \
-                par[2 * Cin + c] = a.dmask ? a.dmask[so] : 1.f;           \
+                const float sc_ = a.scale ? a.scale[so] : 1.f, sh_ = a.scale ? a.shift[so] : 0.f, dm_ = a.dmask ? a.dmask[so] : 1.f; \
+                par[c] = sc_ * dm_;                                       \
+                par[Cin + c] = sh_ * dm_;                                 \
+                par[2 * Cin + c] = a.pro_silu ? -1.4426950408889634f * sc_ : 0.f;    \
+                par[3 * Cin + c] = a.pro_silu ? -1.4426950408889634f * sh_ : -126.f; \
             }                                                             \
         }                                                                 \
     }
@@ -514,12 +519,18 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         };
         const char* wbase = (const char*)a.w;
         u32x4 areg[PIPE_UA];
-        f32x4 ps0, ps1, ph0, ph1, pm0, pm1;
+        // this lane's 8 channels of the four parameter rows, as the pairs (2 d, 2 d + 1) the dwords of a halo vector hold: every
+        // operand of the packed fp32 instructions below is a consecutive register pair as loaded
+        f32x2 pS[4], pH[4], pS2[4], pH2[4];
         auto load_par = [&](const float* par, int c0) __attribute__((always_inline)) {
             const float* p = par + c0 + cu * EPV;
-            ps0 = *reinterpret_cast<const f32x4*>(p); ps1 = *reinterpret_cast<const f32x4*>(p + 4);
-            ph0 = *reinterpret_cast<const f32x4*>(p + Cin); ph1 = *reinterpret_cast<const f32x4*>(p + Cin + 4);
-            pm0 = *reinterpret_cast<const f32x4*>(p + 2 * Cin); pm1 = *reinterpret_cast<const f32x4*>(p + 2 * Cin + 4);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                pS[d] = *reinterpret_cast<const f32x2*>(p + 2 * d);
+                pH[d] = *reinterpret_cast<const f32x2*>(p + Cin + 2 * d);
+                pS2[d] = *reinterpret_cast<const f32x2*>(p + 2 * Cin + 2 * d);
+                pH2[d] = *reinterpret_cast<const f32x2*>(p + 3 * Cin + 2 * d);
+            }
         };
         auto load_A = [&](int i, int c0) __attribute__((always_inline)) {
             const bool second = c0 >= a.C1;
@@ -532,18 +543,26 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         auto store_A = [&](int i, char* dstA) __attribute__((always_inline)) {
             u32x4 val = areg[i];
             if (has_pro) {
+                // per dword (two adjacent channels): two packed fmas, two exp2, a packed add, two rcp, a packed multiply, one pack -
+                // ~5 VALU instructions per element (the scalar form had 10: the wave shares its SIMD with an MFMA wave, and every
+                // VALU cycle here is a cycle the matrix core idles - DESIGN.md section 4)
                 typedef typename Vec8<T>::type tx8;
                 const tx8 x = __builtin_bit_cast(tx8, val);
                 tx8 o;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float v0 = fmaf((float)x[q], ps0[q], ph0[q]), v1 = fmaf((float)x[4 + q], ps1[q], ph1[q]);
-                    if (a.pro_silu) {
-                        v0 = silu_fast(v0);
-                        v1 = silu_fast(v1);
+                for (int d = 0; d < 4; ++d) {
+                    f32x2 xv;
+                    if constexpr (sizeof(T) == 2 && dtype_of<T>::value == DMME_BF16) {
+                        xv = f32x2{__uint_as_float(val[d] << 16), __uint_as_float(val[d] & 0xffff0000u)};
+                    } else {
+                        xv = f32x2{(float)x[2 * d], (float)x[2 * d + 1]};
                     }
-                    o[q] = (T)(v0 * pm0[q]);
-                    o[4 + q] = (T)(v1 * pm1[q]);
+                    f32x2 y = __builtin_elementwise_fma(xv, pS[d], pH[d]);
+                    f32x2 e = __builtin_elementwise_fma(xv, pS2[d], pH2[d]);  // (no SiLU: S2 = 0, H2 = -126: the factor below is exactly 1)
+                    e = f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + f32x2{1.f, 1.f};
+                    y = y * f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+                    o[2 * d] = (T)y[0];
+                    o[2 * d + 1] = (T)y[1];
                 }
                 val = __builtin_bit_cast(u32x4, o);
             }
@@ -720,7 +739,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
 #undef WS_TILE
 }
 
-static size_t ws2_lds(const ConvArgs& a, const ConvTile& g) { return 2 * (size_t)g.a_rows * (ROW_DATA + 16) + 3 * (size_t)128 * ROW_DATA + (size_t)2 * 3 * (a.C1 + a.C2) * 4; }
+static size_t ws2_lds(const ConvArgs& a, const ConvTile& g) { return 2 * (size_t)g.a_rows * (ROW_DATA + 16) + 3 * (size_t)128 * ROW_DATA + (size_t)2 * 4 * (a.C1 + a.C2) * 4; }
 
 // the wave-specialised kernel applies (else 0): its tile goes to g
 static int ws_pick(const ConvArgs& a, ConvTile& g) {

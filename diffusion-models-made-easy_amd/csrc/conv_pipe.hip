@@ -570,14 +570,18 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             if (a_pix[i] < 0) val = zero;
             if (a_pix[i] != -2) *reinterpret_cast<u32x4*>(dstA + a_sw[i]) = val;
         };
-        // one filter tap (cout tile co0, chunk c, tap t) -> ring slot: UB DMA instructions per wave
+        // one filter tap (cout tile co0, chunk c, tap t) -> ring slot: UB DMA instructions per wave.  Issued behind the compiler's back
+        // (conv_common.h, glds16_hidden): hipcc counts only the halo loads, so its own waits for a halo register (ten younger loads:
+        // vmcnt(10)) leave the youngest ten queue entries alone - the last two stages' DMAs among them - and the DMAs are retired by
+        // the counted waits written out below.  This is what lets a tap be requested TWO stages ahead of its use: a DMA takes ~2.4 k
+        // cycles from issue to landed under load, a stage ~2 k (stamps, tools/stamp_ws.py)
         auto dma_tap = [&](char* dstR, int co0, int c, int t) __attribute__((always_inline)) {
             const unsigned lbase = (unsigned)(size_t)(lds_c*)dstR + (unsigned)(pw * 8 * ROW_DATA);
             const char* ub = wbase + ((size_t)co0 * 9 * Cin + (size_t)t * Cin + (size_t)c * KC) * 2;
 #pragma unroll
             for (int k4 = 0; k4 < UB; ++k4) {
                 const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)(lbase + (unsigned)(32 * k4 * ROW_DATA)));
-                glds16(ub + b_vo[k4], l);
+                glds16_hidden(ub + b_vo[k4], l);
             }
         };
         TileXY tcur = WS_TILE(0), tnext = WS_TILE(K > 1 ? 1 : 0);
@@ -588,14 +592,18 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
                 load_A(i, 0);
             }
             dma_tap(WS_RING(0), tcur.co0, 0, 0);
+            dma_tap(WS_RING(1), tcur.co0, 0, 1);
             load_par(WS_PAR(0), 0);
 #pragma unroll
             for (int i = 0; i < PIPE_UA; ++i) store_A(i, WS_BUFA(0));
 #pragma unroll
             for (int i = 0; i < PIPE_UA; ++i) load_A(i, KC);  // nchunks >= 2
+            wait_vm_keep<PIPE_UA>();  // both taps have landed (they are older than the eleven loads just issued)
         }
         __syncthreads();
         int kt = 0, cc = 0, cg = 0;
+        int p_i = 0;
+        (void)p_i;
 #define WS_A_UNIT(i)                          \
     {                                         \
         if (do_store) store_A((i), dstA);     \
@@ -603,24 +611,46 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         load_A((i), lc * KC);                 \
     }
 #define WS_A_ARRIVED(i) { asm volatile("" : "+v"(areg[i][0]), "+v"(areg[i][1]), "+v"(areg[i][2]), "+v"(areg[i][3])); }
-        // stage TP = tap TP of chunk (kt, cc): DMA of the next stage's tap, 1-2 halo units of the next chunk, barrier
+        // stage TP = tap TP of chunk (kt, cc): DMA of the tap two stages on, 1-2 halo units of the next chunk, barrier.
+        // Ring: stage s reads slot s % 3 (9 % 3 == 0: the same across chunks); the tap of stage s + 2 goes to slot (s + 2) % 3, which
+        // stage s - 1 read last.  A tile's epilogue stages through R1 | R2 | A1, so across a tile boundary only tap 0 (R0) is sent
+        // ahead; the new tile's first stage requests taps 1 and 2 together.
+#ifdef WS_PSTAMPS
+#define WS_PST() { if (a.stamps && ptid == 0 && blockIdx.x == 0 && p_i < 400) a.stamps[128 + p_i++] = (long long)clock64(); }
+#else
+#define WS_PST()
+#endif
+#define WS_L(TP) (((TP) == 0 || (TP) == 8) ? 2 : 1) /* halo loads a stage issues (behind its DMA) */
 #define WS_PSTAGE(TP)                                                                                                   \
     {                                                                                                                   \
+        WS_PST()                                                                                                        \
         const bool last_c = cc + 1 == nchunks;                                                                          \
         const bool have_n = !(last_c && kt + 1 == K);                                                                   \
         const int nk = have_n ? (last_c ? kt + 1 : kt) : kt, nc = have_n ? (last_c ? 0 : cc + 1) : cc;                  \
         const bool last_n = nc + 1 == nchunks;                                                                          \
         const bool have_l = have_n && !(last_n && nk + 1 == K);                                                         \
         const int lk = have_l ? (last_n ? nk + 1 : nk) : nk, lc = have_l ? (last_n ? 0 : nc + 1) : nc;                  \
-        /* hipcc waits vmcnt(0) at the first use of an ordinary load's result while an LDS-DMA is in flight: take this  \
-           stage's halo registers as arrived BEFORE the DMA is issued (counted wait here), so the math below runs under  \
-           the DMA instead of behind it */                                                                              \
+        /* this stage's halo registers are taken as arrived before its DMA goes out (the compiler's counted wait sits    \
+           here, in front of the stage's work) */                                                                       \
         if ((TP) == 0) { WS_A_ARRIVED(0) WS_A_ARRIVED(1) }                                                              \
         else if ((TP) == 8) { WS_A_ARRIVED(9) WS_A_ARRIVED(10) }                                                        \
         else { WS_A_ARRIVED((TP) + 1) }                                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
-        if ((TP) < 8) dma_tap(WS_RING(((TP) + 1) % 3), tcur.co0, cc, (TP) + 1);                                         \
-        else dma_tap(WS_RING(0), nk == kt ? tcur.co0 : tnext.co0, nc, 0);                                               \
+        WS_PST()                                                                                                        \
+        bool sent = true;          /* this stage sent a tap two stages ahead */                                         \
+        bool sent_next = false;    /* ... and, in front of it, the NEXT stage's tap (first stage of a later tile) */    \
+        if ((TP) == 0 && cc == 0 && kt > 0) {                                                                           \
+            dma_tap(WS_RING(1), tcur.co0, 0, 1);                                                                        \
+            sent_next = true;                                                                                           \
+        }                                                                                                               \
+        if ((TP) <= 6) dma_tap(WS_RING(((TP) + 2) % 3), tcur.co0, cc, (TP) + 2);                                        \
+        else if ((TP) == 7) {                                                                                           \
+            if (have_n) dma_tap(WS_RING(0), nk == kt ? tcur.co0 : tnext.co0, nc, 0);                                    \
+            else sent = false;                                                                                          \
+        } else {                                                                                                        \
+            if (have_n && nk == kt) dma_tap(WS_RING(1), tcur.co0, nc, 1);                                               \
+            else sent = false;                                                                                          \
+        }                                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
         {                                                                                                               \
             const bool do_store = have_n;                                                                               \
@@ -632,7 +662,14 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             else { WS_A_UNIT((TP) + 1) }                                                                                \
         }                                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
-        wait_vm_keep<((TP) == 0 || (TP) == 8) ? 2 : 1>(); /* retire the DMA, leave this stage's halo loads in flight */ \
+        WS_PST()                                                                                                        \
+        /* the NEXT stage's tap must have landed; whatever was issued after it may stay in flight: the previous stage's  \
+           halo loads, this stage's DMA (UB instructions) and halo loads - or, when that tap went out in this very stage, \
+           only the second DMA and the loads */                                                                         \
+        if (sent_next) wait_vm_keep<UB + WS_L(TP)>();                                                                   \
+        else if (sent) wait_vm_keep<WS_L(((TP) + 8) % 9) + UB + WS_L(TP)>();                                            \
+        else wait_vm_keep<WS_L(((TP) + 8) % 9) + WS_L(TP)>();                                                           \
+        WS_PST()                                                                                                        \
         __builtin_amdgcn_s_barrier();                                                                                   \
         if ((TP) == 8) {                                                                                                \
             ++cg;                                                                                                       \
@@ -650,6 +687,8 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             WS_PSTAGE(0) WS_PSTAGE(1) WS_PSTAGE(2) WS_PSTAGE(3) WS_PSTAGE(4) WS_PSTAGE(5) WS_PSTAGE(6) WS_PSTAGE(7) WS_PSTAGE(8)
         }
 #undef WS_PSTAGE
+#undef WS_L
+#undef WS_PST
 #undef WS_A_UNIT
 #undef WS_A_ARRIVED
         return;

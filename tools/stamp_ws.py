@@ -43,3 +43,12 @@ print("wait per stage:", d[2::2][:30])
 
 e = [int(t) for t in stamps.cpu()[64:88] if int(t) != 0]
 print("epilogue stamps (pass start, after conv_epilogue, after barrier) deltas:", [e[i + 1] - e[i] for i in range(len(e) - 1)])
+
+pv = [int(t) for t in stamps.cpu()[128:528] if int(t) != 0]
+if pv:
+    # four stamps per producer stage: entry, halo data arrived, units done, DMA retired (then the barrier)
+    rows = [pv[i:i + 4] for i in range(0, len(pv) - 3, 4)]
+    print("producer wave 4, per stage: [halo-arrive wait, dma+units, vm wait, barrier+next] (cycles)")
+    for i in range(min(len(rows) - 1, 40)):
+        r = rows[i]
+        print(f"  st{i:2d} (tap {i % 9}): {r[1]-r[0]:5d} {r[2]-r[1]:5d} {r[3]-r[2]:5d} {rows[i+1][0]-r[3]:5d}")

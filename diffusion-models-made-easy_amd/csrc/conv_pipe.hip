@@ -461,10 +461,10 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         }                                                                 \
     }
 #define WS_FILL_PAR(KT) WS_FILL_PAR_N(KT, 512)
+    // tile 0's rows: all 512 threads, the producers AFTER they have requested the first chunk's halo and the first two filter taps
+    // (neither depends on the rows): the two round trips of a launch's start overlap instead of following each other.
     // tile 1's rows: by the consumer waves, below, while the producers bring in the first stage (the producers first read them nine
     // stages before tile 0 ends, behind dozens of workgroup barriers) - a second round trip off the preamble's critical path
-    WS_FILL_PAR(0)
-    __syncthreads();
     const int mTW = (1 << shTW) - 1, mTH = (1 << shTH) - 1;
     float gn_carry[2] = {0.f, 0.f};  // whole-image tiles finishing their norms: the group threads' first-pass (mean, M2)
     const bool estamp = tid == 0 && blockIdx.x == 0;  // diagnostic stamps of the epilogue passes (consumer wave 0, workgroup 0)
@@ -593,6 +593,8 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             }
             dma_tap(WS_RING(0), tcur.co0, 0, 0);
             dma_tap(WS_RING(1), tcur.co0, 0, 1);
+            WS_FILL_PAR(0)
+            __syncthreads();
             load_par(WS_PAR(0), 0);
 #pragma unroll
             for (int i = 0; i < PIPE_UA; ++i) store_A(i, WS_BUFA(0));
@@ -695,6 +697,8 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
     }
 
     // ---- consumers: wave tile 128 pixels x 64 couts ----
+    WS_FILL_PAR(0)
+    __syncthreads();
     if (K > 1) WS_FILL_PAR_N(1, 256)
     __builtin_amdgcn_s_setprio(3);  // the MFMA stream wins issue arbitration against the producer wave of its SIMD (~1 %; giving the
                                     // priority to the producers instead changes nothing: their GN-mode stage is not an issue-slot problem)

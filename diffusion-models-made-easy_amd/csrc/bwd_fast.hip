@@ -816,6 +816,194 @@ __global__ void __launch_bounds__(256) gn_bwd_small_kernel(const T* __restrict__
 #undef SMALL_APPLY_ONE
 }
 
+// 16x16 / 32x32 maps: the same one-launch form with the workgroup's slice of the image - (image, Cw channels of whole groups) - held in
+// REGISTERS between the two phases: every thread keeps the raw 16-byte vectors of its <= ITERS pixels of d(act) and x (its pixel /
+// channel-vector assignment is the same in both phases), so each tensor is read from memory once and all of a thread's loads are in
+// flight together.  Replaces gn_bwd_sums + gn_bwd_apply (which read both tensors twice: 201 MB instead of 134 MB on a 128-channel
+// 32x32 map at batch 128).  Channel sums: per-thread partials -> LDS -> NT / Cw partial rows -> one thread per channel, fixed order.
+template <typename T, int ITERS, int NT>
+__global__ void __launch_bounds__(NT) gn_bwd_regs_kernel(const T* __restrict__ dv, const T* __restrict__ x1, const T* __restrict__ x2, int HW, int C1,
+                                                          int C2, int groups, const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          const float* __restrict__ dmask, int pro_silu, T* __restrict__ dx1, T* __restrict__ dx2,
+                                                          int acc1, int acc2, float* __restrict__ dgamma, float* __restrict__ dbeta, T* __restrict__ act,
+                                                          float* __restrict__ rows, const T* __restrict__ extra) {
+    constexpr int EPV = 16 / sizeof(T);
+    __shared__ float red[NT * EPV * 2];
+    __shared__ float red2[2 * NT];
+    __shared__ float chA[128], chB[128], gS1[32], gS2[32];
+    const int C = C1 + C2, Cw = C / (int)gridDim.y, cb = (int)blockIdx.y * Cw;
+    const int tid = threadIdx.x, VPP = Cw / EPV, ppw = NT / VPP, slot = tid % VPP, prow = tid / VPP;  // (VPP divides NT: host-checked)
+    const int n = blockIdx.x, c0 = cb + slot * EPV, cg = C / groups;
+    const bool second = c0 >= C1;
+    const T* xs = second ? x2 : x1;
+    T* dst = second ? dx2 : dx1;
+    const int acc = second ? acc2 : acc1;
+    const int Cs = second ? C2 : C1, cs0 = second ? c0 - C1 : c0;
+    const int64_t p0 = (int64_t)n * HW;
+    uint4 rd[ITERS], rx[ITERS];
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int k = 0; k < ITERS; ++k) {
+        const int p = prow + k * ppw;
+        rd[k] = zero4;
+        rx[k] = zero4;
+        if (p < HW) {
+            rd[k] = load_raw<T>(dv + (p0 + p) * C + c0);
+            rx[k] = load_raw<T>(xs + (p0 + p) * Cs + cs0);
+        }
+    }
+    float sc[EPV], sh[EPV], dm[EPV], mu[EPV], rs[EPV], gm[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+        const int c = c0 + j, g = c / cg;
+        sc[j] = scale[(int64_t)n * C + c];
+        sh[j] = shift[(int64_t)n * C + c];
+        dm[j] = dmask ? dmask[(int64_t)n * C + c] : 1.0f;
+        mu[j] = mean_rstd[((int64_t)n * groups + g) * 2];
+        rs[j] = mean_rstd[((int64_t)n * groups + g) * 2 + 1];
+        gm[j] = gamma[c];
+    }
+    float a[EPV], bq[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) a[j] = bq[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < ITERS; ++k) {
+        if (prow + k * ppw < HW) {  // (pixels in ascending order per thread, as the two-pass kernels)
+            float d[EPV], xv[EPV];
+            unpack_vec<T>(rd[k], d);
+            unpack_vec<T>(rx[k], xv);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) {
+                float du = d[j] * dm[j];
+                if (pro_silu) du *= silu_grad_f<T>(fmaf(xv[j], sc[j], sh[j]));
+                a[j] += du;
+                bq[j] = fmaf(du, (xv[j] - mu[j]) * rs[j], bq[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+        red[(tid * EPV + j) * 2] = a[j];
+        red[(tid * EPV + j) * 2 + 1] = bq[j];
+    }
+    __syncthreads();
+    {   // channel lc of the slice: its ppw per-thread partials in NT / Cw parts of ppw * Cw / NT rows each, then the parts in order
+        const int lc = tid % Cw, part = tid / Cw, nparts = NT / Cw, rpp = ppw / nparts;
+        const int v = lc / EPV, j = lc % EPV;
+        float sa = 0.f, sb = 0.f;
+        for (int r = part * rpp; r < (part + 1) * rpp; ++r) {
+            sa += red[((r * VPP + v) * EPV + j) * 2];
+            sb += red[((r * VPP + v) * EPV + j) * 2 + 1];
+        }
+        red2[(part * Cw + lc) * 2] = sa;
+        red2[(part * Cw + lc) * 2 + 1] = sb;
+        __syncthreads();
+        if (tid < Cw) {
+            sa = 0.f;
+            sb = 0.f;
+            for (int q = 0; q < nparts; ++q) {
+                sa += red2[(q * Cw + tid) * 2];
+                sb += red2[(q * Cw + tid) * 2 + 1];
+            }
+            chA[tid] = sa;
+            chB[tid] = sb;
+            if (rows) {
+                rows[(int64_t)n * C + cb + tid] = sa;
+                rows[((int64_t)gridDim.x + n) * C + cb + tid] = sb;
+            } else {
+                atomicAdd(&dbeta[cb + tid], sa);
+                atomicAdd(&dgamma[cb + tid], sb);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < Cw / cg) {  // the slice's groups
+        float s1 = 0.f, s2 = 0.f;
+        for (int j = 0; j < cg; ++j) {
+            const int lc = tid * cg + j;
+            s1 = fmaf(gamma[cb + lc], chA[lc], s1);
+            s2 = fmaf(gamma[cb + lc], chB[lc], s2);
+        }
+        gS1[tid] = s1;
+        gS2[tid] = s2;
+    }
+    __syncthreads();
+    const float inv = 1.0f / (float)((int64_t)cg * HW);
+    // dx = rs (du gm - (k1 + xhat k2)) with du = d dm silu'(y), as gn_bwd_apply_kernel folds it: dx = d silu'(y) Gd + x Cx + C0
+    float Gd[EPV], Cx[EPV], C0[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+        const int g = (c0 - cb + j) / cg;
+        const float k1 = gS1[g] * inv, k2 = gS2[g] * inv;
+        Gd[j] = rs[j] * gm[j] * dm[j];
+        Cx[j] = -rs[j] * rs[j] * k2;
+        C0[j] = rs[j] * (mu[j] * rs[j] * k2 - k1);
+    }
+#pragma unroll
+    for (int k0 = 0; k0 < ITERS; k0 += 4) {
+        uint4 ro[4], re[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = prow + (k0 + u) * ppw;
+            ro[u] = zero4;
+            re[u] = zero4;
+            if (k0 + u < ITERS && p < HW) {
+                if (acc) ro[u] = load_raw<T>(dst + (p0 + p) * Cs + cs0);
+                if (extra) re[u] = load_raw<T>(extra + (p0 + p) * Cs + cs0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u, p = prow + k * ppw;
+            if (k < ITERS && p < HW) {
+                float d[EPV], xv[EPV], o[EPV], ev[EPV], yv[EPV];
+                unpack_vec<T>(rd[k], d);
+                unpack_vec<T>(rx[k], xv);
+                unpack_vec<T>(ro[u], o);
+                unpack_vec<T>(re[u], ev);
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) {
+                    yv[j] = fmaf(xv[j], sc[j], sh[j]);
+                    float du = d[j] * Gd[j];
+                    if (pro_silu) du *= silu_grad_f<T>(yv[j]);
+                    const float dx = fmaf(xv[j], Cx[j], du + C0[j]) + ev[j];
+                    o[j] = acc ? o[j] + dx : dx;
+                }
+                store_vec<T>(dst + (p0 + p) * Cs + cs0, o);
+                if (act) {  // the conv's pre-activated input for the deferred weight gradient (fma, SiLU, mask: the forward's prologue), from registers
+                    float av[EPV];
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j) {
+                        float a_ = yv[j];
+                        if (pro_silu) a_ = sizeof(T) == 2 ? silu_fast(a_) : silu_f(a_);
+                        av[j] = dmask ? a_ * dm[j] : a_;
+                    }
+                    store_vec<T>(act + (p0 + p) * C + c0, av);
+                }
+            }
+        }
+    }
+}
+
+// channel slices for gn_bwd_regs_kernel (0: the shape does not fit it): whole groups, whole 16-byte vectors, not straddling the two
+// concatenated sources, a power-of-two vector count per pixel, at most 8 pixels per thread of the 512
+static int gn_bwd_regs_slices(int dtype, int N, int HW, int C1, int C2, int groups) {
+    if (getenv("DMME_NO_GN_BWD_REGS") || dtype != DMME_BF16) return 0;
+    const int C = C1 + C2, cgs = C / groups, epv = 8;
+    if (HW <= 64 || C % groups || C1 % epv || C2 % epv) return 0;
+    for (int cand = 1; cand <= 16; cand <<= 1) {
+        const int w = C / cand;
+        if (C % cand || w % cgs || w % epv || C1 % w || w > 128 || w / cgs > 32) continue;
+        const int vpp = w / epv;
+        if (vpp & (vpp - 1)) continue;
+        const int ppw = 512 / vpp;
+        if ((HW + ppw - 1) / ppw > 8 || (int64_t)N * cand > 65535) continue;
+        return cand;
+    }
+    return 0;
+}
+
 static bool gn_bwd_small_supported(int dtype, int HW, int C1, int C2, int groups) {
     const int EPV = dtype == DMME_BF16 ? 8 : 4, C = C1 + C2;
     return HW <= 64 && C <= 512 && groups <= 64 && C % groups == 0 && C1 % EPV == 0 && C2 % EPV == 0 && C / EPV <= 256 && !getenv("DMME_NO_GN_SMALL");
@@ -839,6 +1027,7 @@ bool gn_bwd_fast_supported(int dtype, int HW, int C1, int C2) {
 bool gn_bwd_rows_supported(int dtype, int HW, int C1, int C2, int groups, bool has_mod) {
     if (getenv("DMME_NO_GN_BWD_ROWS")) return false;
     if (!has_mod && gn_bwd_small_supported(dtype, HW, C1, C2, groups)) return true;
+    if (!has_mod && gn_bwd_regs_slices(dtype, 1, HW, C1, C2, groups)) return true;
     const int C = C1 + C2;
     return !getenv("DMME_NO_GN_BWD_IMAGE") && !getenv("DMME_NO_GN_BWD_FUSED_FIN") && C <= 1024 && groups <= 256;
 }
@@ -867,6 +1056,12 @@ int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2
         else
             hipLaunchKernelGGL(gn_bwd_small_kernel<float>, dim3(N, slices), dim3(256), 0, s, (const float*)dv, (const float*)x1, (const float*)x2, HW, C1, C2,
                                groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, (float*)dx1, (float*)dx2, acc1, acc2, dgamma, dbeta, (float*)act, rows, (const float*)extra);
+        DMME_CHECK_LAUNCH();
+        return DMME_OK;
+    }
+    if (const int rslices = mod.t_scale ? 0 : gn_bwd_regs_slices(dtype, N, HW, C1, C2, groups)) {
+        hipLaunchKernelGGL((gn_bwd_regs_kernel<bf16, 8, 512>), dim3(N, rslices), dim3(512), 0, s, (const bf16*)dv, (const bf16*)x1, (const bf16*)x2, HW, C1, C2, groups,
+                           gamma, mean_rstd, scale, shift, dmask, pro_silu, (bf16*)dx1, (bf16*)dx2, acc1, acc2, dgamma, dbeta, (bf16*)act, rows, (const bf16*)extra);
         DMME_CHECK_LAUNCH();
         return DMME_OK;
     }

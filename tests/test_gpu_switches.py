@@ -42,7 +42,7 @@ FORWARD = [
     ({"DMME_NO_CONV_IN_MFMA": "1"}, "input conv on the VALU kernel"),
 ]
 BACKWARD = ["DMME_NO_WG_ACT", "DMME_NO_WG_DMA", "DMME_NO_WG_S2", "DMME_NO_WGRAD_GROUP", "DMME_NO_GN_BWD_IMAGE", "DMME_NO_GN_BWD_FUSED_FIN",
-            "DMME_NO_GN_BWD_ROWS", "DMME_NO_RES_EXTRA", "DMME_NO_GN_BWD_SLICES", "DMME_NO_DGRAD_DIRECT", "DMME_NO_RES_ALIAS", "DMME_NO_COLSUM_GROUP",
+            "DMME_NO_GN_BWD_ROWS", "DMME_NO_GN_BWD_REGS", "DMME_NO_RES_EXTRA", "DMME_NO_GN_BWD_SLICES", "DMME_NO_DGRAD_DIRECT", "DMME_NO_RES_ALIAS", "DMME_NO_COLSUM_GROUP",
             "DMME_NO_BIAS_GROUP", "DMME_NO_WGRAD_THIN", "DMME_NO_TIME_PRE", "DMME_NO_SMALL_GEMM_MFMA", "DMME_NO_LVL"]
 
 

@@ -1,0 +1,20 @@
+"""rocprofv3 kernel names -> the kernel labels bench.py prints (csrc/plan.hip: op_account) for the batch-128 bf16 sampling workload."""
+import re
+
+
+def bench_label(name):
+    m = re.match(r"_ZN4dmme(\d+)", name)
+    if m:
+        k = int(m.group(1)); base = name[m.end():m.end() + k]; rest = name[m.end() + k:]
+    else:
+        mm = re.match(r"(?:void )?dmme::(\w+)", name)
+        if not mm: return None
+        base, rest = mm.group(1), name[mm.end():]
+    ints = re.findall(r"Li(\d+)E", rest) or re.findall(r"\b(\d+)\b", rest.split("(")[0])
+    if base == "lvl_engine_kernel": return "lvl_engine_kernel<8x8>" if ints[:1] == ["2"] else "lvl_engine_kernel<4x4>"  # (batch 128: GB = 2 on the 8x8 maps)
+    if base == "conv3x3_ws2_kernel": return "conv3x3_ws2_kernel<11>"
+    if base in ("conv1x1_as_kernel",): return f"{base}<{ints[0]}>"
+    if base == "attn_mfma_kernel": return "attn_mfma_kernel<bf16>"
+    if base in ("conv3x3_pipe_kernel", "conv1x1_pipe_kernel"): return f"{base}<bf16,{','.join(ints[:4 if base.startswith('conv3') else 2])}>"
+    if base == "conv3x3_kw_kernel": return f"{base}<{ints[0]},{ints[1]},{ints[3] if len(ints) > 3 else ints[-1]}>"
+    return base

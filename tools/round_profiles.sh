@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything the round's committed profiles / bench lines come from, in one GPU call.  usage: bash tools/round_profiles.sh <tag>
 # Afterwards, locally: python tools/summarize_prof.py <tag> <label>; python tools/traffic.py <tag> <label>; copy the stats CSVs / JSON lines.
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 bash tools/prof.sh ${TAG} > gpurun_out/${TAG}_prof.log 2>&1

@@ -12,12 +12,12 @@ tag, label = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
-stats = glob.glob(os.path.join(root, f"gpurun_out/prof_{tag}_stats/*/*kernel_stats.csv"))
+stats = sorted(glob.glob(os.path.join(root, f"gpurun_out/prof_{tag}_stats/*/*kernel_stats.csv")), key=os.path.getmtime)[::-1]
 if stats:
     shutil.copy(stats[0], os.path.join(out, f"{label}_kernel_stats.csv"))
 rows_out = []
 for pmc in ("pmc1", "pmc2", "pmc3"):
-    files = glob.glob(os.path.join(root, f"gpurun_out/prof_{tag}_{pmc}/*/*counter_collection.csv"))
+    files = sorted(glob.glob(os.path.join(root, f"gpurun_out/prof_{tag}_{pmc}/*/*counter_collection.csv")), key=os.path.getmtime)[::-1]
     if not files:
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(float))

@@ -3,11 +3,13 @@
 Counters are in KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes of wide coalesced reads
 (MI355X_MICROARCH.md, HBM section), so the read side is doubled.  usage: python tools/traffic.py <tag> <label>"""
 import collections, csv, glob, json, os, re, subprocess, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _labels import bench_label
 
 tag, label = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def per_kernel(pmc, counter):
-    f = glob.glob(os.path.join(root, f"gpurun_out/prof_{tag}_{pmc}/*/*counter_collection.csv"))[0]
+    f = sorted(glob.glob(os.path.join(root, f"gpurun_out/prof_{tag}_{pmc}/*/*counter_collection.csv")), key=os.path.getmtime)[-1]
     tot, disp = collections.defaultdict(float), collections.defaultdict(set)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
@@ -22,6 +24,7 @@ def norm(name):
             rest = rest[1:]
             while rest and not rest.startswith("E"):
                 if rest.startswith("DF16b"): args.append("bf16"); rest = rest[5:]
+                elif rest.startswith("DF16_"): args.append("f16"); rest = rest[5:]
                 elif rest.startswith("f"): args.append("float"); rest = rest[1:]
                 else:
                     mm = re.match(r"Li(\d+)E", rest)
@@ -30,13 +33,27 @@ def norm(name):
         return kname + ("<" + ",".join(args) + ">" if args else "")
     m = re.match(r"(?:void )?dmme::(\w+)(<[^(]*>)?\(", name)
     if not m: return name
-    targs = (m.group(2) or "").replace("__bf16", "bf16").replace(" ", "")
+    # (rocprofv3's demangler does not know DF16b either: "IDF16bLi1E" comes out as "<bool _Accum, int, E")
+    targs = (m.group(2) or "").replace("__bf16", "bf16").replace("bool _Accum, int, E", "bf16,1").replace(" ", "")
     return m.group(1) + targs
 rd, wr = per_kernel("pmc3", "FETCH_SIZE"), per_kernel("pmc4", "WRITE_SIZE")
 out = {}
 for k in rd:
     out[norm(k)] = {"hbm_bytes_per_launch": round((2.0 * rd[k] + wr.get(k, 0.0)) * 1024), "fetch_kib_raw": round(rd[k], 1), "write_kib": round(wr.get(k, 0.0), 1),
                     "note": "2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE half-count correction), averaged over the launches of this symbol"}
+# the same figures under bench.py's kernel labels (launch-weighted where several symbols share a label)
+lab_tot, lab_n = collections.defaultdict(float), collections.defaultdict(int)
+f3 = sorted(glob.glob(os.path.join(root, f"gpurun_out/prof_{tag}_pmc3/*/*counter_collection.csv")), key=os.path.getmtime)[-1]
+ndisp = collections.defaultdict(set)
+for r in csv.DictReader(open(f3)):
+    ndisp[r["Kernel_Name"]].add(r["Dispatch_Id"])
+for k in rd:
+    lab = bench_label(k)
+    if lab:
+        lab_tot[lab] += (2.0 * rd[k] + wr.get(k, 0.0)) * 1024 * len(ndisp[k]); lab_n[lab] += len(ndisp[k])
+for lab in lab_tot:
+    if lab not in out:
+        out[lab] = {"hbm_bytes_per_launch": round(lab_tot[lab] / lab_n[lab]), "note": "bench.py label: launch-weighted mean of the symbols above"}
 json.dump(out, open(os.path.join(root, "profiles", "traffic_latest.json"), "w"), indent=1)
 json.dump(out, open(os.path.join(root, "profiles", f"{label}_hbm_traffic.json"), "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:8]: print(k, v["hbm_bytes_per_launch"])

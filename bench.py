@@ -304,7 +304,7 @@ def _max_over_ranks(dt, dist, dev):
     return float(tt.item())
 
 
-def train_leg(dmme_amd, dev, B, precision, steps, warmup, dist, model_name="ddpm", reduce=True, seed=1337):
+def train_leg(dmme_amd, dev, B, precision, steps, warmup, dist, model_name="ddpm", reduce=True, seed=1337, exchange=None):
     """training images/s: q_sample -> UNet fwd (train mode, Dropout2d on) -> loss -> HIP backward -> (RCCL mean all-reduce of
     the flat gradient, first bucket overlapped with the rest of backward) -> fused clip(1.0)+Adam+EMA -> warm-up LR step.
     Identical initial weights on every rank (same seed), per-rank noise / timesteps / masks afterwards."""
@@ -324,11 +324,11 @@ def train_leg(dmme_amd, dev, B, precision, steps, warmup, dist, model_name="ddpm
     x0 = synthetic_batch(B, dev, (3, side, side))
     loss = None
     for _ in range(warmup):
-        loss = train_step(lit, opt, sched, x0, reduce=reduce)
+        loss = train_step(lit, opt, sched, x0, reduce=reduce, exchange=exchange)
     _fence(dist)
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss = train_step(lit, opt, sched, x0, reduce=reduce)
+        loss = train_step(lit, opt, sched, x0, reduce=reduce, exchange=exchange)
     _fence(dist)
     dt = _max_over_ranks(time.perf_counter() - t0, dist, dev)
     assert torch.isfinite(loss).all(), "non-finite training loss"
@@ -582,7 +582,11 @@ def main():
                     "semantics": f"per-rank batch {B} (the reference under Lightning DDP: YAML batch_size is per rank), global batch {B * world}",
                     "ms_per_step": round(step_ms, 3), "ms_per_step_without_allreduce": round(nocomm_ms, 3),
                     "allreduce_alone_ms": round(ar_ms, 3), "allreduce_exposed_ms": round(exposed, 3),
-                    "allreduce_hidden_ms": round(max(0.0, ar_ms - exposed), 3), "gradient_bytes": numel * 4}
+                    "allreduce_hidden_ms": round(max(0.0, ar_ms - exposed), 3), "gradient_bytes": numel * 4,
+                    "exchange": os.environ.get("DMME_EXCHANGE", "fp32-allreduce")}
+                # the other wire format of the gradient mean (distributed.Bf16ShardExchange: bf16 all-to-all + all-gather, fp32 accumulation)
+                dt_bf, _, _ = train_leg(dmme_amd, dev, B, args.precision, k, 3, dist, args.model, exchange="bf16-rs-ag")
+                out["train_dp"]["ms_per_step_bf16_rs_ag"] = round(1e3 * dt_bf / k, 3)
                 if B % world == 0 and B // world >= 1:
                     bs = B // world  # north_star wording: the batch of 128 sharded over the ranks
                     dt_g, _, _ = train_leg(dmme_amd, dev, bs, args.precision, k, 3, dist, args.model)

@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(512) conv1x1_as_kernel(ConvArgs a, int HW, int
             if (u < 3) AS_STAMP(4 + 3 * u);
             const char* st = stageL + (u & 1) * STAGE;
             float xs[4][8];
-            float s1 = 0.f;
+            float s1 = 0.f, s1b = 0.f;  // (s1b: the vector's upper half where a group is 4 channels)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 uint4 raw;
@@ -204,13 +204,34 @@ __global__ void __launch_bounds__(512) conv1x1_as_kernel(ConvArgs a, int HW, int
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {  // statistics of the values the consumer reads back
                         xs[q][e] = (float)o[e];
-                        s1 += xs[q][e];
+                        if (e < 4) s1 += xs[q][e];
+                        else s1b += xs[q][e];
                     }
                 }
             }
-            if (a.gn_part) {
+            if (a.gn_part && cgs == 4) {
+                // 4-channel groups (a 128-channel tensor of a 32-group norm): the two halves of a 16-byte vector are two groups
+                const float meanA = as_sum_rows(s1) * (1.f / 128.f), meanB = as_sum_rows(s1b) * (1.f / 128.f);
+                float qa = 0.f, qb = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float da = xs[q][e] - meanA, db = xs[q][4 + e] - meanB;
+                        qa = fmaf(da, da, qa);
+                        qb = fmaf(db, db, qb);
+                    }
+                const float m2A = as_sum_rows(qa), m2B = as_sum_rows(qb);
+                if (lane < 8) {
+                    const int pw = p0 + 32 * sw, n = pw / HW, tile_s = (pw - n * HW) >> 5;
+                    const int G = a.Cout / 4, g_first = (u * 64 + lane * 8) / 4;
+                    float* o = a.gn_part + (((int64_t)n * a.gn_tiles + tile_s) * G + g_first) * 2;
+                    *reinterpret_cast<f32x4*>(o) = f32x4{meanA, m2A, meanB, m2B};
+                }
+            } else if (a.gn_part) {
                 // per (32 pixels, group of cgs = 8 nv couts): the mean by one reduction over the wave's rows (+ the group's slots), then
                 // M2 = sum (x - mean)^2 by a second one
+                s1 += s1b;
                 const float mean = as_sum_slots(as_sum_rows(s1), nv) * (1.f / (float)(32 * cgs));
                 float q2 = 0.f;
 #pragma unroll
@@ -386,7 +407,7 @@ __global__ void __launch_bounds__(512) conv1x1_as_kernel(ConvArgs a, int HW, int
 #undef AS_STAMP
 }
 
-static bool as_stats_cg_ok(int cg) { return cg == 8 || cg == 16 || cg == 32; }
+static bool as_stats_cg_ok(int cg) { return cg == 4 || cg == 8 || cg == 16 || cg == 32; }
 
 // shape rules (statistics aside)
 static bool as_shape_ok(int dtype, const ConvArgs& a) {

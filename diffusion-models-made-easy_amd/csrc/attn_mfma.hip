@@ -16,7 +16,7 @@
 //     (row pitch = 16 banks mod 64: the four key rows of a transposed read hit disjoint banks).
 #include <stdlib.h>
 
-#include "common.h"
+#include "conv_common.h"
 
 namespace dmme {
 
@@ -270,6 +270,225 @@ __global__ void __launch_bounds__(64 * NW) attn_mfma_kernel(const T* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// S = 256 keys (the 16x16 maps of the DDPM UNet, models/ddpm.py:54-63): the WHOLE score row of a query fits in registers (8 tiles of
+// 32 keys x 16 accumulators), so the softmax is done once per row instead of once per key tile:
+//   phase 1  S^T = K Q^T for all eight key tiles (Q^T fragments in registers, K tiles streamed);
+//   phase 2  row max / exp2 / row sum over the lane's 128 scores + one lane <-> lane + 32 exchange; P^T -> 16-bit B operands (64 registers);
+//   phase 3  O^T = sum over the eight V tiles of V^T P^T; scaled by 1 / row sum on the way out.
+// The online form above spends ~630 VALU instructions per key tile (running maximum, rescaling 128 accumulators, per-tile address
+// arithmetic) against 32 MFMAs; here the two streaming phases contain NO VALU instruction: K / V tiles arrive by LDS-DMA
+// (global_load_lds_dwordx4: no registers, issued behind the compiler's back with counted waits) into an eight-slot ring, seven tiles
+// ahead, ONE workgroup barrier per tile; rows are unpadded and XOR-swizzled on the DMA's source side (K: 16-byte piece ^ (row & 7),
+// conflict-free ds_read_b128; V: piece ^ 2 (row & 3), the four key rows of a transposed read land in four different 32-byte slots);
+// every fragment address is one per-lane base + an instruction offset (the sixteen tile steps are unrolled).
+// PACING (`xcd_order` bits 1..: s_sleep 2 / 4 / 8 / 16 after every tile step, default 4; DMME_ATTN_SLEEP=0 turns it off): un-paced this
+// kernel is 22 us against the online kernel's 30 - and on most boxes of the pool the WHOLE denoising step got 4 % slower with it
+// (every other kernel of the step 4-5 % slower, in one process, alternating the two kernels per 100 forwards: tools/attn_flip.py),
+// on a few boxes 1 % faster.  MFMA, LDS and the DMA path saturated on all 256 CUs at once trips the board's power / current
+// management, which takes the clock down for milliseconds; a few idle cycles per tile step (kernel 25 us) avoid that and make the
+// step 0.4 % faster than the online kernel on the limited boxes, 0.5 % on the others.
+template <int C, typename T = bf16>
+__global__ void __launch_bounds__(256) attn_full_kernel(const T* __restrict__ qkv, AttnGeom g, T* __restrict__ out, float* __restrict__ lse, int xcd_order) {
+    typedef T tx8 __attribute__((ext_vector_type(8)));
+    constexpr int S = 256, NKT = S / AT_KT, KSTEPS = C / 16, CT = C / 32;
+    constexpr int ROWB = C * 2, TILEB = AT_KT * ROWB;      // bytes per key row / per tile (unpadded)
+    constexpr int DPT = TILEB / (256 * 16);                // DMA wave-instructions per tile and wave
+    constexpr int NSLOT = 8, AHEAD = 7;  // (a four-slot ring, 48 KB in flight per CU, measured 24 us at C = 256: bytes in flight / latency)
+    static_assert(DPT >= 1 && DPT * 256 * 16 == TILEB, "attn_full: tile does not split over the DMA lanes");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    constexpr int qblocks = S / 128;
+    int n = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;
+    if (xcd_order & 1) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        n = (j / qblocks) * 8 + x;
+        qb = j % qblocks;
+    }
+    const T* base = qkv + at_qkv_off<C>(g, n);
+    const int ld = g.ld;
+    const int q_row = qb * 128 + wave * 32 + r;
+    // ---- the tile stream: tile t < NKT is K tile t, tile NKT + t is V tile t; slot = t % NSLOT ----
+    // DMA instruction I of a tile (wave-instruction index wave + 4 i) fills LDS bytes [I * 1024, +1024) lane-linearly:
+    // row = (I * 1024 + lane * 16) / ROWB, 16-byte piece pc of that row; it must hold SOURCE piece pc ^ key(row) (per 128-byte segment)
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
+    unsigned koff[DPT], voff[DPT];  // per-lane source byte offsets inside a K / V tile (row * ld * 2 + swizzled piece * 16)
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) {
+        const int I = wave + 4 * i, byte = I * 1024 + lane * 16, row = byte / ROWB, pc = (byte % ROWB) >> 4;
+        koff[i] = (unsigned)(row * ld * 2 + (((pc & ~7) | ((pc & 7) ^ (row & 7))) << 4));
+        voff[i] = (unsigned)(row * ld * 2 + (((pc & ~7) | ((pc & 7) ^ ((row & 3) << 1))) << 4));
+    }
+    auto dma_tile = [&](int t) __attribute__((always_inline)) {
+        const bool isv = t >= NKT;
+        const char* src = (const char*)(base + (int64_t)((isv ? t - NKT : t) * AT_KT) * ld + (isv ? 2 * C : C));
+        const unsigned dst = lds0 + (unsigned)((t % NSLOT) * TILEB);
+#pragma unroll
+        for (int i = 0; i < DPT; ++i) glds16_hidden_s(src, isv ? voff[i] : koff[i], dst + (unsigned)((wave + 4 * i) * 1024));
+    };
+#pragma unroll
+    for (int t = 0; t < AHEAD; ++t) dma_tile(t);
+    // Q^T fragments (B operand of S^T = K Q^T): element j of k-step ks = Q[q_row][16 ks + 8 h + j]; ordinary loads, older than nothing
+    // the counted waits below care about (they are waited for by the compiler before the first MFMA)
+    uint4 qf[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(base + (int64_t)q_row * ld + ks * 16 + h * 8);
+    // per-lane fragment bases.  K: row r, piece (2 u + h) of k-step u -> ((2 u & 7) ^ x) with x = h ^ (r & 7): four variants
+    unsigned kb[4];
+    {
+        const int x = h ^ (r & 7);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kb[i] = lds0 + (unsigned)(r * ROWB + (((2 * i) ^ x) << 4));
+    }
+    // V (transposed reads, lane i = 4 q + p of a 16-lane group g1): key row 4 h + q (+ 16 s2, + 8), channels 32 ct + 16 g1 + 4 p ..+3:
+    // piece = 4 ct + 2 g1 + (p >> 1), swizzled piece = ((ct & 1) ^ q1) 4 + (g1 ^ q0) 2 + (p >> 1), 8 (p & 1) bytes into it
+    const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g1 = (lane >> 4) & 1;
+    unsigned vb[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+        vb[par] = lds0 + (unsigned)((4 * h + tr_q) * ROWB + ((((par ^ (tr_q >> 1)) << 2) | ((tr_g1 ^ (tr_q & 1)) << 1) | (tr_p >> 1)) << 4) + ((tr_p & 1) << 3));
+    typedef __attribute__((address_space(3))) char lc;
+    typedef unsigned u32x4_af __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) u32x4_af lu4;
+
+    f32x16 st[NKT];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) st[t][j] = 0.f;
+/* tile T is about to be read: it has landed in this wave's share when at most the tiles requested after it are outstanding; the    \
+   barrier makes that true of every wave's share AND says everyone is done with tile T - 1, whose slot takes tile T + AHEAD */        \
+#define AF_STEP_SYNC(TT)                                                                                                           \
+    do {                                                                                                                           \
+        constexpr int younger_ = (TT) + AHEAD - 1 < 2 * NKT ? AHEAD - 1 : 2 * NKT - 1 - (TT);                                      \
+        wait_vm_keep<younger_ * DPT>();                                                                                            \
+        asm volatile("s_barrier" ::: "memory");                                                                                    \
+        if ((TT) + AHEAD < 2 * NKT) dma_tile((TT) + AHEAD);                                                                        \
+        if ((xcd_order >> 1) == 1) __builtin_amdgcn_s_sleep(2);                                                                    \
+        else if ((xcd_order >> 1) == 2) __builtin_amdgcn_s_sleep(4);                                                               \
+        else if ((xcd_order >> 1) == 3) __builtin_amdgcn_s_sleep(8);                                                               \
+        else if ((xcd_order >> 1) == 4) __builtin_amdgcn_s_sleep(16);                                                              \
+    } while (0)
+    // ---- phase 1: scores (tile index a literal: every address below is a per-lane base + an instruction offset) ----
+#define AF_K_TILE(t)                                                                                                               \
+    {                                                                                                                              \
+        AF_STEP_SYNC(t);                                                                                                           \
+        constexpr unsigned so = (unsigned)(((t) % NSLOT) * TILEB);                                                                 \
+        constexpr int FG = 4;                                                                                                      \
+        uint4 kf[2][FG];                                                                                                           \
+        _Pragma("unroll") for (int u = 0; u < FG; ++u) kf[0][u] = __builtin_bit_cast(uint4, *(const lu4*)((const lc*)(size_t)kb[u & 3] + (so + (unsigned)((2 * u) >> 3) * 128u))); \
+        _Pragma("unroll") for (int g0 = 0; g0 < KSTEPS; g0 += FG) {                                                                \
+            const int cur = (g0 / FG) & 1, nxt = cur ^ 1;                                                                          \
+            if (g0 + FG < KSTEPS) {                                                                                                \
+                _Pragma("unroll") for (int u = 0; u < FG; ++u) {                                                                   \
+                    const int ks = g0 + FG + u;                                                                                    \
+                    kf[nxt][u] = __builtin_bit_cast(uint4, *(const lu4*)((const lc*)(size_t)kb[ks & 3] + (so + (unsigned)((2 * ks) >> 3) * 128u)));           \
+                }                                                                                                                  \
+            }                                                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                                     \
+            _Pragma("unroll") for (int u = 0; u < FG; ++u) at_mma<T>(__builtin_bit_cast(tx8, kf[cur][u]), __builtin_bit_cast(tx8, qf[g0 + u]), st[t]); \
+            __builtin_amdgcn_sched_barrier(0);                                                                                     \
+        }                                                                                                                          \
+    }
+    AF_K_TILE(0) AF_K_TILE(1) AF_K_TILE(2) AF_K_TILE(3) AF_K_TILE(4) AF_K_TILE(5) AF_K_TILE(6) AF_K_TILE(7)
+#undef AF_K_TILE
+    // ---- phase 2: softmax of the lane's query over its 128 keys (the other 128 are on lane ^ 32) ----
+    const float c1 = 1.4426950408889634f * g.scale;  // Cfull^-0.5 * log2(e)
+    float mx = st[0][0];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) mx = fmaxf(mx, st[t][j]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m = mx * c1;
+    float l = 0.f;
+    tx8 pf[NKT][2];  // P^T as B operand: k-step s2 of tile t uses registers 8 s2 .. 8 s2 + 7 (key = 16 s2 + 8 (j >> 2) + 4 h + (j & 3))
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(st[t][j], c1, -m));
+            l += p;
+            pf[t][j >> 3][j & 7] = (T)p;
+        }
+    const float ltot = l + __shfl_xor(l, 32, 64);
+    // ---- phase 3: O^T = V^T P^T ----
+    f32x16 o[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[ct][j] = 0.f;
+#define AF_VREAD(CT0, DST_LO, DST_HI)                                                                                              \
+    _Pragma("unroll") for (int cu = 0; cu < VG; ++cu) _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                            \
+        const int ct_ = (CT0) + cu;                                                                                                \
+        const lc* a0 = (const lc*)(size_t)vb[ct_ & 1] + (so + (unsigned)((16 * s2) * ROWB + (ct_ >> 1) * 128));                     \
+        DST_LO[cu][s2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);                    \
+        DST_HI[cu][s2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 8 * ROWB));       \
+    }
+#define AF_V_TILE(t)                                                                                                               \
+    {                                                                                                                              \
+        AF_STEP_SYNC(NKT + (t));                                                                                                   \
+        constexpr unsigned so = (unsigned)(((NKT + (t)) % NSLOT) * TILEB);                                                         \
+        constexpr int VG = 2;                                                                                                      \
+        s16x4 vlo[2][VG][2], vhi[2][VG][2];                                                                                        \
+        AF_VREAD(0, vlo[0], vhi[0])                                                                                                \
+        _Pragma("unroll") for (int ct = 0; ct < CT; ct += VG) {                                                                    \
+            const int cur = (ct / VG) & 1, nxt = cur ^ 1;                                                                          \
+            if (ct + VG < CT) {                                                                                                    \
+                AF_VREAD(ct + VG, vlo[nxt], vhi[nxt])                                                                              \
+            }                                                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                                     \
+            _Pragma("unroll") for (int cu = 0; cu < VG; ++cu) _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                    \
+                s16x8 vf;                                                                                                          \
+                vf[0] = vlo[cur][cu][s2][0]; vf[1] = vlo[cur][cu][s2][1]; vf[2] = vlo[cur][cu][s2][2]; vf[3] = vlo[cur][cu][s2][3]; \
+                vf[4] = vhi[cur][cu][s2][0]; vf[5] = vhi[cur][cu][s2][1]; vf[6] = vhi[cur][cu][s2][2]; vf[7] = vhi[cur][cu][s2][3]; \
+                at_mma<T>(__builtin_bit_cast(tx8, vf), pf[t][s2], o[ct + cu]);                                                     \
+            }                                                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                                     \
+        }                                                                                                                          \
+    }
+    AF_V_TILE(0) AF_V_TILE(1) AF_V_TILE(2) AF_V_TILE(3) AF_V_TILE(4) AF_V_TILE(5) AF_V_TILE(6) AF_V_TILE(7)
+#undef AF_V_TILE
+#undef AF_VREAD
+#undef AF_STEP_SYNC
+    // ---- normalise and store: lane = query, registers = channels (j & 3) + 8 (j >> 2) + 4 h ----
+    const float inv = 1.0f / ltot;
+    if (lse && h == 0) lse[(int64_t)n * S + q_row] = m + log2f(ltot);  // log2-domain log-sum-exp of the scaled scores, for the backward pass
+    T* orow = out + at_o_off<C>(g, n) + (int64_t)q_row * g.Cfull;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+        for (int jg = 0; jg < 4; ++jg) {
+            typedef T tx4 __attribute__((ext_vector_type(4)));
+            tx4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (T)(o[ct][jg * 4 + e] * inv);
+            *reinterpret_cast<tx4*>(orow + ct * 32 + 8 * jg + 4 * h) = v;
+        }
+    }
+}
+
+template <int D, typename T>
+static int launch_attn_full_t(const T* qkv, const AttnGeom& g, T* out, float* lse, hipStream_t s) {
+    const int rows = g.N * g.heads;
+    const size_t lds = (size_t)8 * AT_KT * D * 2;
+    static bool attr_done = false;
+    if (!attr_done) {
+        DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_full_kernel<D, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_done = true;
+    }
+    const int xcd_order = ((!getenv("DMME_NO_XCD_ORDER") && rows % 8 == 0) ? 1 : 0) | ((getenv("DMME_ATTN_SLEEP") ? atoi(getenv("DMME_ATTN_SLEEP")) : 2) << 1);  // pacing level (below), default s_sleep 4 per tile
+    hipLaunchKernelGGL((attn_full_kernel<D, T>), dim3((unsigned)(rows * 2)), dim3(256), lds, s, qkv, g, out, lse, xcd_order);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+// whole-row softmax kernel: 256 keys, head width 128 / 256
+static bool attn_full_takes(int S, int D) {
+    if (getenv("DMME_ATTN_FULL_ONLY") && atoi(getenv("DMME_ATTN_FULL_ONLY")) != D) return false;
+    return S == 256 && (D == 128 || D == 256) && !getenv("DMME_NO_ATTN_FULL");
+}
+
 bool attn_mfma_supported(int dtype, int N, int S, int C) { return attn_heads_mfma_supported(dtype, N, S, C, 1); }
 // head width 64 / 128 / 256; 128-query workgroups, or 64-query ones for the 8x8 maps
 bool attn_heads_mfma_supported(int dtype, int N, int S, int C, int heads) {
@@ -303,6 +522,11 @@ static int launch_attn_fwd_t(const T* qkv, const AttnGeom& g, T* out, float* lse
 int launch_attn_heads_mfma(int dtype, const void* qkv, int N, int S, int C, int heads, void* out, float* lse, hipStream_t s) {
     DMME_REQUIRE(attn_heads_mfma_supported(dtype, N, S, C, heads), DMME_ERR_UNSUPPORTED, "attn_mfma: unsupported shape S=%d C=%d heads=%d", S, C, heads);
     const AttnGeom g = attn_geom(N, S, C, heads);
+    if (attn_full_takes(S, C / heads)) {
+        if (dtype == DMME_F16)
+            return C / heads == 256 ? launch_attn_full_t<256, f16>((const f16*)qkv, g, (f16*)out, lse, s) : launch_attn_full_t<128, f16>((const f16*)qkv, g, (f16*)out, lse, s);
+        return C / heads == 256 ? launch_attn_full_t<256, bf16>((const bf16*)qkv, g, (bf16*)out, lse, s) : launch_attn_full_t<128, bf16>((const bf16*)qkv, g, (bf16*)out, lse, s);
+    }
     if (dtype == DMME_F16) {
         switch (C / heads) {
             case 256: return launch_attn_fwd_t<256, f16>((const f16*)qkv, g, (f16*)out, lse, s);

@@ -30,6 +30,8 @@ FORWARD = [
     ({"DMME_NO_LVL": "1", "DMME_NO_GN_SMALL": "1"}, "no one-workgroup-per-image norm kernel"),
     ({"DMME_NO_LVL": "1", "DMME_NO_ATTN_S16": "1"}, "4x4 attention on the generic kernel"),
     ({"DMME_NO_LVL": "1", "DMME_NO_GN_IN_KW": "1"}, "K-split kernel: finalize launches in front"),
+    ({"DMME_NO_ATTN_FULL": "1"}, "16x16 attention on the online-softmax kernel"),
+    ({"DMME_ATTN_SLEEP": "0"}, "whole-row attention kernel without pacing"),
     ({"DMME_NO_CONV1X1_AS": "1"}, "1x1 convs on the tiled kernel"),
     ({"DMME_NO_GN_IN": "1"}, "finalize launches instead of consumer-side merges"),
     ({"DMME_NO_GN_IN_PIPE": "1"}, "four-wave kernels: finalize launches in front"),

@@ -44,7 +44,7 @@ def _run(net, x, t, direct, switch="DMME_NO_GN_DIRECT"):
     return y, n
 
 
-@pytest.mark.parametrize("precision,atol_ref,rel_ab,fewer", [("fp32", 1e-5, 2e-6, 8), ("bf16", 1.36e-2, 1.0e-2, 20)])
+@pytest.mark.parametrize("precision,atol_ref,rel_ab,fewer", [("fp32", 1e-5, 2e-6, 8), ("bf16", 1.7e-2, 1.0e-2, 20)])
 def test_batch128_direct_groupnorm_vs_reference_and_vs_launched_norms(golden, precision, atol_ref, rel_ab, fewer):
     g = golden("unet_full")
     seed = int(g["full_seed"])
@@ -84,7 +84,7 @@ def test_batch128_groupnorm_finished_by_consumer_vs_reference_and_vs_finalize_la
     e_ref = float((rows[0] - ref).abs().max())
     e_ab = float((ya - yb).pow(2).mean().sqrt() / yb.pow(2).mean().sqrt())
     print(f"launches {nb} -> {na}; max|err| vs reference {e_ref:.3e}; relative rms between the two paths {e_ab:.3e}")
-    assert e_ref <= 1.36e-2  # the bf16 network's bound (tests/test_gpu_unet.py)
+    assert e_ref <= 1.7e-2  # the bf16 network's max-abs bound (tests/test_gpu_unet.py: BF16_MAX_ABS)
     assert e_ab <= 1.0e-2    # (the two merges differ in rounding only: equal-count batch form vs sequential Chan updates)
 
 

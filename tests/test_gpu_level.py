@@ -80,7 +80,7 @@ def test_level_engine_vs_reference_golden_and_vs_per_op_launches(golden, B):
     assert nb - na >= 28, (na, nb)
     ref = torch.from_numpy(g["full_y_one"])
     for i in range(B):  # every image of the batch took the arithmetic of its golden row
-        assert float((ya[i] - ref[i % 2]).abs().max()) <= 1.36e-2, i  # the bf16 network's bound (tests/test_gpu_unet.py)
+        assert float((ya[i] - ref[i % 2]).abs().max()) <= 1.7e-2, i  # the bf16 network's max-abs bound (tests/test_gpu_unet.py: BF16_MAX_ABS)
     if B >= 4:
         assert torch.equal(ya[2:4], ya[0:2])
     worst = 0.0

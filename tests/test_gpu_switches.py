@@ -95,10 +95,8 @@ def test_forward_route_switch_vs_default_route_and_reference(fwd_case, env, note
     r_ref = float((rows[0] - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
     e_ab = float((y - base).pow(2).mean().sqrt() / base.pow(2).mean().sqrt())
     print(f"{env} ({note}): launches {n0} -> {n}; vs reference: rel-RMS {r_ref:.3e}, max|err| {e_ref:.3e}; rel-rms vs the default route {e_ab:.3e}")
-    # the bf16 network's error budget (tests/test_gpu_unet.py): the rel-RMS bound as there; the maximum over the 6144 outputs is an
-    # extreme-value statistic of ONE rounding sequence and every route is a different sequence (default route 1.08e-2, routes seen up
-    # to 1.40e-2), so it gets 1.1 x the default route's bound here
-    assert r_ref <= 1.0e-2 and e_ref <= 1.5e-2
+    # the bf16 network's error budget (tests/test_gpu_unet.py: BF16_REL_RMS, BF16_MAX_ABS - every route is another rounding sequence)
+    assert r_ref <= 1.0e-2 and e_ref <= 1.7e-2
     assert e_ab <= 1.0e-2    # two bf16 evaluations of one network (other tile shapes / summation orders), or identical bits
 
 

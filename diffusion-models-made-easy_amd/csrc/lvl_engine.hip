@@ -201,8 +201,14 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
     int d_req = 0;                                       // ring units requested so far
     bool primed = false;
     auto dma_next = [&]() __attribute__((always_inline)) {
+        // (the asm's "s" operands must be SGPRs: under register pressure hipcc has handed it VGPR copies of these uniform values -
+        // "invalid operand" at assembly time - so they are pinned here; a readfirstlane of a value already in an SGPR folds away)
+        const uint64_t dp_ = (uint64_t)dptr;
+        const char* dps = reinterpret_cast<const char*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(dp_ >> 32)) << 32) |
+                                                        (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)dp_));
+        const unsigned dss = (unsigned)__builtin_amdgcn_readfirstlane((int)dslot);
 #pragma unroll
-        for (int i = 0; i < NPI; ++i) glds16_hidden_s(dptr, boff[i], dslot + (unsigned)(i * 8 * ROW_DATA));
+        for (int i = 0; i < NPI; ++i) glds16_hidden_s(dps, boff[i], dss + (unsigned)(i * 8 * ROW_DATA));
         dptr += d_cin2;
         if (++dtap == d_taps) {  // next pass: the wave's chunk moves on by 4 chunks (256 channels), tap 0
             dtap = 0;

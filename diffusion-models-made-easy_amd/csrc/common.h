@@ -288,6 +288,7 @@ int launch_gn_modulate(float* scale, float* shift, const float* t_shift, const f
 bool attn_x3_supported(int N, int S, int C, int heads);
 int launch_attn_x3(const void* qkv, int N, int S, int C, int heads, void* out, hipStream_t s);
 bool attn_mfma_supported(int dtype, int N, int S, int C);
+bool attn_full_takes(int S, int D);  // the whole-row softmax kernel serves this (keys, head width): launch_attn_heads_mfma's dispatch
 // lse (nullable): [N][S] log2-domain log-sum-exp of the scaled scores, kept for the backward pass
 int launch_attn_mfma(int dtype, const void* qkv, int N, int S, int C, void* out, float* lse, hipStream_t s);
 bool attn_heads_mfma_supported(int dtype, int N, int S, int C, int heads);

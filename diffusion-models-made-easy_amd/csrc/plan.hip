@@ -1646,7 +1646,7 @@ void op_account(const dmme_plan* P, const Op& o, char* label, int cap, double* f
             else if (o.at_heads > 1)
                 snprintf(label, cap, attn_heads_mfma_supported(P->dtype, P->B, (int)S, (int)C, o.at_heads) ? "attn_mfma_kernel<%s,heads>" : S == 16 ? "attn_s16_kernel<%s,heads>" : "attn_generic_kernel<%s,heads>", tn);
             else
-                snprintf(label, cap, attn_mfma_supported(P->dtype, P->B, (int)S, (int)C) ? "attn_mfma_kernel<%s>" : S == 16 ? "attn_s16_kernel<%s>" : "attn_generic_kernel<%s>", tn);
+                snprintf(label, cap, !attn_mfma_supported(P->dtype, P->B, (int)S, (int)C) ? (S == 16 ? "attn_s16_kernel<%s>" : "attn_generic_kernel<%s>") : attn_full_takes((int)S, (int)C) ? "attn_full_kernel<%s>" : "attn_mfma_kernel<%s>", tn);
             *flops = 4.0 * B * S * S * C;
             *bytes = B * S * 4.0 * C * es;
             break;

@@ -15,6 +15,7 @@ def bench_label(name):
     if base == "conv3x3_ws2_kernel": return "conv3x3_ws2_kernel<11>"
     if base in ("conv1x1_as_kernel",): return f"{base}<{ints[0]}>"
     if base == "attn_mfma_kernel": return "attn_mfma_kernel<bf16>"
+    if base == "attn_full_kernel": return "attn_full_kernel<bf16>"
     if base in ("conv3x3_pipe_kernel", "conv1x1_pipe_kernel"): return f"{base}<bf16,{','.join(ints[:4 if base.startswith('conv3') else 2])}>"
     if base == "conv3x3_kw_kernel": return f"{base}<{ints[0]},{ints[1]},{ints[3] if len(ints) > 3 else ints[-1]}>"
     return base

@@ -276,12 +276,46 @@ __device__ __forceinline__ void gn_in_scale_shift_g(const GnIn& G, float* scale_
     const float* p = second ? G.p2 : G.p1;
     const int tiles = second ? G.t2 : G.t1, cs = second ? G.C2 : G.C1, cnt = second ? G.cnt2 : G.cnt1;
     const int fg = cs / G.groups, f0 = (second ? c_first - G.C1 : c_first) / fg, nf = cg / fg;  // nf = 1, 2, 4
-    const int lnf = nf == 1 ? 0 : nf == 2 ? 1 : 2, npart = tiles << lnf;                        // <= 32 (host-checked)
+    const int lnf = nf == 1 ? 0 : nf == 2 ? 1 : 2, npart = tiles << lnf;                        // <= 64 (host-checked)
     const float* q0 = p + ((int64_t)n * tiles * G.groups + f0) * 2;  // partial (t, f) at q0 + (t * groups + f) * 2
     const float gam = G.gamma[c], bet = G.beta[c];
     float sm = 0.f, s2 = 0.f, dd = 0.f, mean = 0.f;
     const float inv = 1.f / (float)npart;
-    if constexpr (NB >= 32) {
+    if (NB >= 32 && npart > 32) {
+        // 33 .. 64 partials (32-pixel statistics tiles of a small batch under a concatenated norm): two batches of 32, the second pass
+        // re-reads them (L1 / L2) - still no launch
+#pragma unroll 1
+        for (int base = 0; base < npart; base += 32) {
+            float2 v[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const int kk = base + k;
+                v[k] = make_float2(0.f, 0.f);
+                if (kk < npart) v[k] = *reinterpret_cast<const float2*>(q0 + ((kk >> lnf) * G.groups + (kk & (nf - 1))) * 2);
+            }
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                sm += v[k].x;
+                s2 += v[k].y;
+            }
+        }
+        mean = sm * inv;
+#pragma unroll 1
+        for (int base = 0; base < npart; base += 32) {
+            float v[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const int kk = base + k;
+                v[k] = mean;
+                if (kk < npart) v[k] = q0[((kk >> lnf) * G.groups + (kk & (nf - 1))) * 2];
+            }
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const float d = v[k] - mean;
+                dd = fmaf(d, d, dd);
+            }
+        }
+    } else if constexpr (NB >= 32) {
         float2 v[32];
 #pragma unroll
         for (int k = 0; k < 32; ++k) {

@@ -424,17 +424,21 @@ __global__ void __launch_bounds__(256, 1) conv3x3_kw_kernel(ConvArgs a, ConvTile
         return;
     }
     const int tile_s = ty_blk * g.tiles_x + tx_blk;
-    if (a.n_gno > 0) {  // whole-image tile (host-checked): finish the consuming GroupNorms here
-        const bool add_trow = a.tproj && a.nt != 1 && g.TN > 1;
-        __syncthreads();
-        if (owner) conv_epilogue_stage<T, BN, 1, OWN>(a, tot, co0, wn0, r, h, wm0, n0, reinterpret_cast<float*>(lds), !add_trow);
-        __syncthreads();
-        conv_epilogue_store_direct<T, BN, BM>(a, co0, n0, a.Hout * a.Wout, pix_of, reinterpret_cast<float*>(lds), add_trow);
+    if (BM >= 64 && a.n_gno > 0) {  // whole-image tile (host-checked): finish the consuming GroupNorms here
+        if constexpr (BM >= 64) {
+            const bool add_trow = a.tproj && a.nt != 1 && g.TN > 1;
+            __syncthreads();
+            if (owner) conv_epilogue_stage<T, BN, 1, OWN>(a, tot, co0, wn0, r, h, wm0, n0, reinterpret_cast<float*>(lds), !add_trow);
+            __syncthreads();
+            conv_epilogue_store_direct<T, BN, BM>(a, co0, n0, a.Hout * a.Wout, pix_of, reinterpret_cast<float*>(lds), add_trow);
+        }
     } else if (conv_epilogue_is_staged<T>(a, g.TN)) {
         __syncthreads();  // the partial sums have been read: the staging image may overwrite them
         if (owner) conv_epilogue_stage<T, BN, 1, OWN>(a, tot, co0, wn0, r, h, wm0, n0, reinterpret_cast<float*>(lds));
         __syncthreads();
-        conv_epilogue_store<T, BM, BN, 256>(a, co0, n0, pix_of, reinterpret_cast<float*>(lds), tile_s);
+        // (a 32 x 32 tile is 128 output vectors: the store loop and its statistics run on the first two waves, the others only meet
+        // its barriers)
+        conv_epilogue_store<T, BM, BN, (BM * BN / 8 < 256 ? BM * BN / 8 : 256)>(a, co0, n0, pix_of, reinterpret_cast<float*>(lds), tile_s);
     } else if (owner) {
         conv_epilogue<T, BM, BN, 1, OWN>(a, tot, co0, wn0, r, h, wm0, n0, g.TN, pix_of, reinterpret_cast<float*>(lds), tile_s);  // general path: no barrier
     }
@@ -462,16 +466,28 @@ bool conv_kw_pick(int dtype, const ConvArgs& a, ConvTile& g, int* ni_out, int* r
     if ((int64_t)a.Cout * 9 * Cin >= (1ll << 31) || (int64_t)a.N * a.Hin * a.Win * (a.C1 > a.C2 ? a.C1 : a.C2) >= (1ll << 31)) return false;
     // the largest tile that still gives every CU a workgroup (the filter stream per MFMA halves with BM, the fixed cost per workgroup
     // is paid for more work); below that, 64 x 32: the most workgroups
-    static const int kCand[4][2] = {{128, 2}, {128, 1}, {64, 2}, {64, 1}};
+    // Fewer than 256 workgroups even at 64 x 32 (batch 1-2 on the 32x32 / 16x16 maps): 32-pixel tiles - twice the workgroups on a chip
+    // that is mostly idle, and a third less halo to normalise per workgroup (the in-place transform is 4.5 us of a 14 us launch
+    // there: VALU-bound on one wave per SIMD, stamps in tools/stamp_pipe.py).  DMME_KW_NO_BM32 keeps 64-pixel tiles.
+    static const int kCand[5][2] = {{128, 2}, {128, 1}, {64, 2}, {64, 1}, {32, 1}};
     static const int kRings[4] = {6, 4, 3, 2};
-    for (int c = 0; c < 4; ++c) {
+    const bool bm32 = !getenv("DMME_KW_NO_BM32") && a.Cout % 32 == 0 && !a.n_gno;
+    for (int c = 0; c < 5; ++c) {
         const int BM = kCand[c][0], NI = kCand[c][1];
         if ((force_ni && NI != force_ni) || (force_bm && BM != force_bm)) continue;
-        if (a.Cout % (32 * NI) && c < 3) continue;  // (partial cout tiles only on the smallest tile)
+        if (a.Cout % (32 * NI) && c < 3) continue;  // (partial cout tiles only on the 64 x 32 tile)
+        if (c == 4 && !bm32) continue;
         ConvTile t{};
         if (!make_tile(a, BM, 32 * NI, t) || t.a_rows > 256) continue;  // okmask: <= 32 halo vectors per lane
         if (BM == 128 && !kw_dense(a, t, BM)) continue;                  // the 128-pixel form is for whole-image tiles
+        // the 32-pixel form: part of one image, and at most 32 statistics tiles per image (a consumer merges <= 64 partials per group,
+        // two source groups per group where the norm runs over a concatenation)
+        if (BM == 32 && (kw_dense(a, t, BM) || t.TN != 1 || a.Hout * a.Wout / 32 > 32)) continue;
         if (c < 3 && !force_ni && !force_bm && (int64_t)t.tiles_m * t.tiles_n < 256) continue;
+        if (c == 3 && bm32 && !force_ni && !force_bm && (int64_t)t.tiles_m * t.tiles_n < 256) {  // would the 32-pixel tile apply?  then it does
+            ConvTile t32{};
+            if (make_tile(a, 32, 32, t32) && t32.a_rows <= 256 && !kw_dense(a, t32, 32) && t32.TN == 1 && a.Hout * a.Wout / 32 <= 32) continue;
+        }
         int ring = 0;
         for (int cand : kRings)
             if (cand <= max_ring && kw_lds(a, t, BM, NI, cand) <= 160 * 1024) {
@@ -529,6 +545,13 @@ int launch_conv_kw(int dtype, const ConvArgs& a, const ConvTile& g, int NI, int 
     DMME_KW_CASE(2, 4)
     DMME_KW_CASE(2, 6)
 #undef DMME_KW_CASE
+#define DMME_KW_CASE32(RING_) \
+    if (BM == 32 && !dense && NI == 1 && ring == RING_) return launch_kw_inst<1, RING_, false, 32>(a, g, ksplit, lds, s);
+    DMME_KW_CASE32(2)
+    DMME_KW_CASE32(3)
+    DMME_KW_CASE32(4)
+    DMME_KW_CASE32(6)
+#undef DMME_KW_CASE32
 #define DMME_KW_CASE128(NI_, RING_) \
     if (BM == 128 && dense && NI == NI_ && ring == RING_) return launch_kw_inst<NI_, RING_, true, 128>(a, g, ksplit, lds, s);
     DMME_KW_CASE128(1, 2)

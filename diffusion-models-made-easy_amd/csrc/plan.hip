@@ -1449,13 +1449,13 @@ void assign_gn_in(dmme_plan* P) {
         if (g.gn_direct || g.gn_in_consumer || g.gn_act >= 0 || !gn_from_parts(P, g)) continue;
         if (g.gn_src1 != cv.src1 || g.gn_src2 != cv.src2) continue;
         const Tensor& t1 = P->tensors[g.gn_src1];
-        // partials per consumer group: tiles x (producer groups per consumer group), at most 32 (one batch of loads in the fill);
-        // 64x64 maps have hundreds - the batched finalize kernel's job
+        // partials per consumer group: tiles x (producer groups per consumer group), at most 64 (one or two batches of loads in the
+        // fill); 64x64 maps have hundreds - the batched finalize kernel's job
         const int G = P->cfg.num_groups, Cn = t1.C + (g.gn_src2 >= 0 ? P->tensors[g.gn_src2].C : 0);
-        bool fits = t1.stats_tiles * ((Cn / G) / (t1.C / G)) <= 32;
+        bool fits = t1.stats_tiles * ((Cn / G) / (t1.C / G)) <= 64;
         if (g.gn_src2 >= 0) {
             const Tensor& t2 = P->tensors[g.gn_src2];
-            fits = fits && t2.stats_tiles * ((Cn / G) / (t2.C / G)) <= 32;
+            fits = fits && t2.stats_tiles * ((Cn / G) / (t2.C / G)) <= 64;
         }
         if (!fits) continue;
         ConvArgs a{};

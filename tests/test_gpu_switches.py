@@ -23,6 +23,7 @@ FORWARD = [
     ({"DMME_LVL_NO_XRUN": "1"}, "level engine: skip tensors re-normalised by the run that reads them"),
     ({"DMME_LVL_MAX_ITER": "1"}, "level engine only where a workgroup owns one iteration per op"),
     ({"DMME_NO_LVL": "1", "DMME_NO_KW": "1"}, "small maps on the four-wave pipelined kernel"),
+    ({"DMME_KW_NO_BM32": "1"}, "K-split kernel without its 32-pixel tiles (they apply at batch 1-2; same route at this batch)"),
     ({"DMME_NO_LVL": "1", "DMME_KW_BM64": "1"}, "8x8 level on 64-pixel K-split tiles"),
     ({"DMME_NO_LVL": "1", "DMME_NO_GN_DIRECT": "1"}, "norms of whole-image tiles as launches"),
     ({"DMME_NO_LVL": "1", "DMME_NO_GN_DIRECT_WS": "1"}, "16x16 norms not finished by the persistent kernel's two-pass epilogue"),

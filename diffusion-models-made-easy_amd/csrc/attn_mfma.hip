@@ -469,6 +469,175 @@ __global__ void __launch_bounds__(256) attn_full_kernel(const T* __restrict__ qk
     }
 }
 
+// The same whole-row form for launches that do NOT fill the chip (batch < 128): a wave's chain above is 256 dependent MFMAs whatever
+// the batch, so here the 256 keys are split over the four waves of a workgroup that owns only 32 queries (8 workgroups per image):
+// each wave streams its own two K tiles and two V tiles through a private two-slot LDS area (no workgroup barrier while streaming),
+// row maximum and row sum are exchanged through LDS, the four partial O^T tiles are summed through LDS (wave w finishes channels
+// [64 w, 64 w + 64) of C = 256).  64 MFMAs per wave instead of 256.
+template <int C, typename T = bf16>
+__global__ void __launch_bounds__(256) attn_split_kernel(const T* __restrict__ qkv, AttnGeom g, T* __restrict__ out, float* __restrict__ lse) {
+    typedef T tx8 __attribute__((ext_vector_type(8)));
+    constexpr int S = 256, KSTEPS = C / 16, CT = C / 32;
+    constexpr int ROWB = C * 2, TILEB = AT_KT * ROWB;
+    constexpr int DPT = TILEB / 1024;  // DMA wave-instructions per tile (this wave alone)
+    constexpr int QB = S / 32;         // query blocks per (image, head) row
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int n = blockIdx.x / QB, qb = blockIdx.x % QB;
+    const T* base = qkv + at_qkv_off<C>(g, n);
+    const int ld = g.ld;
+    const int q_row = qb * 32 + r;
+    char* ldsW = lds + wave * 2 * TILEB;
+    float* xch = reinterpret_cast<float*>(lds + 4 * 2 * TILEB);  // [2][4 waves][32 queries]
+    const unsigned lw0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)ldsW);
+    unsigned koff[DPT], voff[DPT];
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) {
+        const int byte = i * 1024 + lane * 16, row = byte / ROWB, pc = (byte % ROWB) >> 4;
+        koff[i] = (unsigned)(row * ld * 2 + (((pc & ~7) | ((pc & 7) ^ (row & 7))) << 4));
+        voff[i] = (unsigned)(row * ld * 2 + (((pc & ~7) | ((pc & 7) ^ ((row & 3) << 1))) << 4));
+    }
+    auto dma_k = [&](int kt, int slot) __attribute__((always_inline)) {
+        const char* src = (const char*)(base + (int64_t)(kt * AT_KT) * ld + C);
+#pragma unroll
+        for (int i = 0; i < DPT; ++i) glds16_hidden_s(src, koff[i], lw0 + (unsigned)(slot * TILEB + i * 1024));
+    };
+    auto dma_v = [&](int kt, int slot) __attribute__((always_inline)) {
+        const char* src = (const char*)(base + (int64_t)(kt * AT_KT) * ld + 2 * C);
+#pragma unroll
+        for (int i = 0; i < DPT; ++i) glds16_hidden_s(src, voff[i], lw0 + (unsigned)(slot * TILEB + i * 1024));
+    };
+    dma_k(2 * wave, 0);
+    dma_k(2 * wave + 1, 1);
+    uint4 qf[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(base + (int64_t)q_row * ld + ks * 16 + h * 8);
+    unsigned kb[4];
+    {
+        const int x = h ^ (r & 7);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kb[i] = lw0 + (unsigned)(r * ROWB + (((2 * i) ^ x) << 4));
+    }
+    const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g1 = (lane >> 4) & 1;
+    unsigned vb[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+        vb[par] = lw0 + (unsigned)((4 * h + tr_q) * ROWB + ((((par ^ (tr_q >> 1)) << 2) | ((tr_g1 ^ (tr_q & 1)) << 1) | (tr_p >> 1)) << 4) + ((tr_p & 1) << 3));
+    typedef __attribute__((address_space(3))) char lc;
+    typedef unsigned u32x4_as2 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) u32x4_as2 lu4;
+    wait_vm_all();  // both K tiles (and the Q fragments behind them) are in
+    // ---- phase 1: this wave's 64 keys ----
+    f32x16 st[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) st[t][j] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const uint4 kf = __builtin_bit_cast(uint4, *(const lu4*)((const lc*)(size_t)kb[ks & 3] + (unsigned)(t * TILEB + ((2 * ks) >> 3) * 128)));
+            at_mma<T>(__builtin_bit_cast(tx8, kf), __builtin_bit_cast(tx8, qf[ks]), st[t]);
+        }
+    }
+    wait_lgkm_all();  // every read of the K tiles has returned: the slots take the V tiles
+    dma_v(2 * wave, 0);
+    dma_v(2 * wave + 1, 1);
+    // ---- phase 2: row maximum and row sum over the four waves ----
+    const float c1 = 1.4426950408889634f * g.scale;
+    float mx = st[0][0];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) mx = fmaxf(mx, st[t][j]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (h == 0) xch[wave * 32 + r] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(xch[r], xch[32 + r]), fmaxf(xch[64 + r], xch[96 + r]));
+    const float m = mx * c1;
+    float l = 0.f;
+    tx8 pf[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(st[t][j], c1, -m));
+            l += p;
+            pf[t][j >> 3][j & 7] = (T)p;
+        }
+    l += __shfl_xor(l, 32, 64);
+    if (h == 0) xch[128 + wave * 32 + r] = l;
+    __syncthreads();
+    const float ltot = (xch[128 + r] + xch[160 + r]) + (xch[192 + r] + xch[224 + r]);  // (the same order in every wave)
+    // ---- phase 3: partial O^T over this wave's keys ----
+    f32x16 o[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[ct][j] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (t == 0) wait_vm_keep<DPT>();
+        else wait_vm_keep<0>();
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const lc* a0 = (const lc*)(size_t)vb[ct & 1] + (unsigned)(t * TILEB + (16 * s2) * ROWB + (ct >> 1) * 128);
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 8 * ROWB));
+                s16x8 vf;
+                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                at_mma<T>(__builtin_bit_cast(tx8, vf), pf[t][s2], o[ct]);
+            }
+    }
+    // ---- sum of the four partial tiles: [wave][ct][j][lane] fp32 over the tile area; wave w finishes ct = w CT / 4 .. ----
+    __syncthreads();  // every wave is done with its V tiles
+    float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) red[((wave * CT + ct) * 16 + j) * 64 + lane] = o[ct][j];
+    __syncthreads();
+    const float inv = 1.0f / ltot;
+    if (lse && wave == 0 && h == 0) lse[(int64_t)n * S + q_row] = m + log2f(ltot);
+    T* orow = out + at_o_off<C>(g, n) + (int64_t)q_row * g.Cfull;
+    constexpr int CPW = CT / 4;  // channel tiles per wave
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int ct = wave * CPW + c;
+#pragma unroll
+        for (int jg = 0; jg < 4; ++jg) {
+            typedef T tx4 __attribute__((ext_vector_type(4)));
+            tx4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = jg * 4 + e;
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) sum += red[((w * CT + ct) * 16 + j) * 64 + lane];
+                v[e] = (T)(sum * inv);
+            }
+            *reinterpret_cast<tx4*>(orow + ct * 32 + 8 * jg + 4 * h) = v;
+        }
+    }
+}
+
+template <int D, typename T>
+static int launch_attn_split_t(const T* qkv, const AttnGeom& g, T* out, float* lse, hipStream_t s) {
+    const int rows = g.N * g.heads;
+    const size_t lds = (size_t)8 * AT_KT * D * 2 + 1024;
+    static bool attr_done = false;
+    if (!attr_done) {
+        DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_split_kernel<D, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((attn_split_kernel<D, T>), dim3((unsigned)(rows * 8)), dim3(256), lds, s, qkv, g, out, lse);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
 template <int D, typename T>
 static int launch_attn_full_t(const T* qkv, const AttnGeom& g, T* out, float* lse, hipStream_t s) {
     const int rows = g.N * g.heads;
@@ -478,7 +647,7 @@ static int launch_attn_full_t(const T* qkv, const AttnGeom& g, T* out, float* ls
         DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_full_kernel<D, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_done = true;
     }
-    const int xcd_order = ((!getenv("DMME_NO_XCD_ORDER") && rows % 8 == 0) ? 1 : 0) | ((getenv("DMME_ATTN_SLEEP") ? atoi(getenv("DMME_ATTN_SLEEP")) : 2) << 1);  // pacing level (below), default s_sleep 4 per tile
+    const int xcd_order = ((!getenv("DMME_NO_XCD_ORDER") && rows % 8 == 0) ? 1 : 0) | ((getenv("DMME_ATTN_SLEEP") ? atoi(getenv("DMME_ATTN_SLEEP")) : rows * 2 >= 256 ? 2 : 0) << 1);  // pacing level (kernel comment): s_sleep 4 per tile where the launch fills the chip
     hipLaunchKernelGGL((attn_full_kernel<D, T>), dim3((unsigned)(rows * 2)), dim3(256), lds, s, qkv, g, out, lse, xcd_order);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
@@ -522,6 +691,11 @@ static int launch_attn_fwd_t(const T* qkv, const AttnGeom& g, T* out, float* lse
 int launch_attn_heads_mfma(int dtype, const void* qkv, int N, int S, int C, int heads, void* out, float* lse, hipStream_t s) {
     DMME_REQUIRE(attn_heads_mfma_supported(dtype, N, S, C, heads), DMME_ERR_UNSUPPORTED, "attn_mfma: unsupported shape S=%d C=%d heads=%d", S, C, heads);
     const AttnGeom g = attn_geom(N, S, C, heads);
+    if (attn_full_takes(S, C / heads) && N * heads * 2 < 256 && !getenv("DMME_NO_ATTN_SPLIT")) {  // the launch would leave CUs idle: keys split over the waves
+        if (dtype == DMME_F16)
+            return C / heads == 256 ? launch_attn_split_t<256, f16>((const f16*)qkv, g, (f16*)out, lse, s) : launch_attn_split_t<128, f16>((const f16*)qkv, g, (f16*)out, lse, s);
+        return C / heads == 256 ? launch_attn_split_t<256, bf16>((const bf16*)qkv, g, (bf16*)out, lse, s) : launch_attn_split_t<128, bf16>((const bf16*)qkv, g, (bf16*)out, lse, s);
+    }
     if (attn_full_takes(S, C / heads)) {
         if (dtype == DMME_F16)
             return C / heads == 256 ? launch_attn_full_t<256, f16>((const f16*)qkv, g, (f16*)out, lse, s) : launch_attn_full_t<128, f16>((const f16*)qkv, g, (f16*)out, lse, s);

@@ -199,3 +199,17 @@ def test_attention(case, dtname):
         tol = 1e-5 if dtname == "fp32" else (BF16_ATTN_RTOL if dtname == "bf16" else FP16_ATTN_RTOL) * want.abs().max().item()
         print(f"attention {case} {dtname} generic={force_generic}: err {err:.3e} (tol {tol:.3e})")
         assert err <= tol, f"attention {case} {dtname} generic={force_generic}: {err:.3e} > {tol:.3e}"
+    if dtname != "fp32" and S == 256:
+        # 256 keys, 16-bit: the launch above took the keys-split-over-waves kernel (few images); the whole-row kernel of full launches
+        # and the online-softmax kernel behind them are selected per launch by environment switches
+        import os
+
+        for env in ("DMME_NO_ATTN_SPLIT", "DMME_NO_ATTN_FULL"):
+            os.environ[env] = "1"
+            try:
+                got = G.attention(dt, qkv.cuda(), False).cpu()
+            finally:
+                os.environ.pop(env, None)
+            err = (got - want).abs().max().item()
+            print(f"attention {case} {dtname} {env}: err {err:.3e} (tol {tol:.3e})")
+            assert err <= tol, f"attention {case} {dtname} {env}: {err:.3e} > {tol:.3e}"

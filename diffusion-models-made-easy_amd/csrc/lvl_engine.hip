@@ -737,17 +737,26 @@ _Pragma("unroll") \
             }
 
             // ---- publish: every store of every wave acknowledged, then one flag word per group ----
+            // The filter stream of whatever conv comes next starts before the wait for its input - and, where the statistics barrier above
+            // already separates this op's last read of the ring (the cross-wave sum) from new writes into it, even before the wait for
+            // this op's own stores: the DMAs are issued behind the stores, the counted wait retires the stores and leaves the DMAs in
+            // flight (they retire in order), so the ~0.5 us of issuing them hides under the stores' round trip.
             LV_STAMP(4);
-            wait_vm_all();
+            int oj = oi;
+            if (bt + A.NGS >= NB) ++oj;
+            const bool next_conv = oj < A.n_ops && ops[oj].kind == LVL_CONV;
+            const bool early = next_conv && have_out && op.n_norm > 0;
+            if (early) {
+                prime(ops[oj]);
+                if (d_req >= D) wait_vm_keep<D * NPI>();
+                else wait_vm_all();  // (a stream shorter than the ring: rare, 1x1 convs of 256 channels)
+            } else {
+                wait_vm_all();
+            }
             __syncthreads();
             LV_STAMP(5);
             if (op.signal && tid < GB && bt * GB + tid < A.NG) lvl_flag_store(A.flags + ((int64_t)(oi * 2) * A.NG + bt * GB + tid) * LVL_NS + s, epoch);
-            // the filter stream of whatever conv comes next starts now, before the wait for its input
-            {
-                int oj = oi;
-                if (bt + A.NGS >= NB) ++oj;
-                if (oj < A.n_ops && ops[oj].kind == LVL_CONV) prime(ops[oj]);
-            }
+            if (next_conv && !early) prime(ops[oj]);
             LV_STAMP(6);
             ++stamp_it;
         }

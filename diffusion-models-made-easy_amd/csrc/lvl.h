@@ -51,6 +51,12 @@ struct LvlOp {
     int signal;               // publish a flag row (op index * 2) once the slice is in memory
     int64_t sc_off;           // LVL_ATTN: bytes into the workspace, fp32 partial scores [NG][LVL_NS][1024]
     float kscale;             // LVL_ATTN: C^-0.5, applied to K before the product (models/ddpm.py:50,58)
+    // second K segment of a conv op: the ResBlock's 1x1 residual conv (models/ddpm.py:108-111,131) over the block's RAW input,
+    // accumulated into the same tile as conv2's nine taps - `h + residual(x)` without the residual tensor, its op, its hand-off
+    int C3, C4;               // channels of its sources (0: no second segment); C3 + C4 a multiple of 256
+    int64_t a3_off, a4_off;   // bytes into the workspace: T [N][HW][C3], [N][HW][C4]
+    int wait2, wait3;         // flag rows covering them (-1: complete before the launch)
+    int64_t w2_off, b2_off;   // packed 1x1 weights T [256][C3 + C4] and bias fp32 [256]
     int pad_;
 };
 

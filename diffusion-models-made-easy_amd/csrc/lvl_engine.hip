@@ -194,7 +194,9 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
     // (Loading an op's first units straight into registers when its stream starts - so that a 256-channel 3x3 conv has all nine units
     // requested before it begins - was measured and removed: hipcc copies loop-carried registers at the back edge and waits for the
     // loads where they are issued; B = 1, 4x4 run: 152 -> 198 us.)
-    unsigned boff[NPI];
+    unsigned boff[NPI], boff2[NPI];  // (boff2, dptr2, d_cin2b: the op's second segment, see LvlOp::C3)
+    const char* dptr2 = nullptr;
+    int d_cin2b = 0, d_seg = 0;      // d_seg: units of the current segment not yet requested
     const char* dptr = nullptr;
     unsigned dslot = ring_base;
     int dtap = 0, d_taps = 9, d_cin2 = 0, d_left = 0;  // d_left: ring units of the current stream not yet requested
@@ -217,15 +219,27 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
         dslot = dslot + U_BYTES == ring_base + RING * U_BYTES ? ring_base : dslot + U_BYTES;
         --d_left;
         ++d_req;
+        if (--d_seg == 0 && d_left > 0) {  // the first segment is fully requested: the 1x1 segment follows in the same ring
+#pragma unroll
+            for (int i = 0; i < NPI; ++i) boff[i] = boff2[i];
+            dptr = dptr2;
+            d_taps = 1;
+            d_cin2 = d_cin2b;
+            dtap = 0;
+        }
     };
     // start the filter stream of conv op `o` (pass-major, tap-minor; wave w owns chunk 4 p + w): the first D units into the ring
     auto prime = [&](const LvlOp& o) __attribute__((always_inline)) {
-        const int Cin = o.C1 + o.C2, nu = (Cin >> 8) * o.taps;
+        const int Cin = o.C1 + o.C2, Cinb = o.C3 + o.C4, nu1 = (Cin >> 8) * o.taps, nu = nu1 + (Cinb >> 8);
 #pragma unroll
         for (int i = 0; i < NPI; ++i) {
             const int row = 8 * i + (lane >> 3);
             boff[i] = (unsigned)((o.w_row0 + BN * s + row) * o.taps * Cin + ((lane & 7) ^ ((row >> 1) & 7)) * 8) * 2u;
+            boff2[i] = (unsigned)((BN * s + row) * Cinb + ((lane & 7) ^ ((row >> 1) & 7)) * 8) * 2u;
         }
+        dptr2 = A.packed + o.w2_off + wave * 128;
+        d_cin2b = Cinb * 2;
+        d_seg = nu1;
         d_taps = o.taps;
         d_cin2 = Cin * 2;
         dtap = 0;
@@ -293,7 +307,12 @@ _Pragma("unroll") \
                     const int j = q / NJ, co = co0 + 32 * (q % NJ); \
                     const int gpc = gpv[j] < 0 ? 0 : gpv[j]; \
                     const float* bp = reinterpret_cast<const float*>(A.packed + op.b_off) + op.w_row0 + co; \
-                    const f32x4 b0v = *reinterpret_cast<const f32x4*>(bp), b1v = *reinterpret_cast<const f32x4*>(bp + 4); \
+                    f32x4 b0v = *reinterpret_cast<const f32x4*>(bp), b1v = *reinterpret_cast<const f32x4*>(bp + 4); \
+                    if (op.C3 > 0) { /* + the residual conv's bias */ \
+                        const float* bq = reinterpret_cast<const float*>(A.packed + op.b2_off) + co; \
+                        b0v += *reinterpret_cast<const f32x4*>(bq); \
+                        b1v += *reinterpret_cast<const f32x4*>(bq + 4); \
+                    } \
                     resv[q] = make_uint4(0u, 0u, 0u, 0u); \
                     if (op.res_off >= 0) { \
                         const lvl_rsrc rr = lvl_make_rsrc(A.ws + op.res_off, (unsigned)npix * (unsigned)op.res_C * 2u); \
@@ -378,24 +397,31 @@ _Pragma("unroll") \
     } while (0)
                 unsigned rslot = ring_base;  // LDS address of the slot of the next ring unit whose fragments will be read
                 int q_read = 0;              // ring units read so far
-                for (int p = 0; p < npass; ++p) {
+                const int npass2 = (op.C3 + op.C4) >> 8;  // passes of the second segment (the block's 1x1 residual conv over its raw input)
+                for (int pt = 0; pt < npass + npass2; ++pt) {
+                    const bool seg2 = pt >= npass;
+                    const int p = seg2 ? pt - npass : pt;
+                    const int taps_p = seg2 ? 1 : taps;
                     // ---- A operand of this pass: chunk 4 p + wave of the GB groups' 64 pixels each, gathered after the hand-off ----
-                    if (!op.reuse_a) {
+                    if (seg2 || !op.reuse_a) {
                         if (p == 0) {
+                            const int w0 = seg2 ? op.wait2 : op.wait0, w1 = seg2 ? op.wait3 : op.wait1;
 #pragma unroll
                             for (int j = 0; j < GB; ++j) {
                                 const int g = bt * GB + j;
                                 if (g >= A.NG) break;
-                                if (op.wait0 >= 0) lvl_wait_row(A.flags + ((int64_t)op.wait0 * A.NG + g) * LVL_NS, NS, epoch, lane, err);
-                                if (op.wait1 >= 0) lvl_wait_row(A.flags + ((int64_t)op.wait1 * A.NG + g) * LVL_NS, NS, epoch, lane, err);
+                                if (w0 >= 0) lvl_wait_row(A.flags + ((int64_t)w0 * A.NG + g) * LVL_NS, NS, epoch, lane, err);
+                                if (w1 >= 0) lvl_wait_row(A.flags + ((int64_t)w1 * A.NG + g) * LVL_NS, NS, epoch, lane, err);
                             }
                             lvl_compiler_fence();
-                            LV_STAMP(1);
+                            if (!seg2) LV_STAMP(1);
                         }
                         const int c = p * 4 + wave;
-                        const bool second = c * 64 >= op.C1;
-                        const int Cs = second ? op.C2 : op.C1, cb = second ? c * 64 - op.C1 : c * 64;
-                        const lvl_rsrc rs = lvl_make_rsrc(A.ws + (second ? op.a2_off : op.a1_off), (unsigned)npix * (unsigned)Cs * 2u);
+                        const int Ca = seg2 ? op.C3 : op.C1, Cb = seg2 ? op.C4 : op.C2;
+                        const bool second = c * 64 >= Ca;
+                        const int Cs = second ? Cb : Ca, cb = second ? c * 64 - Ca : c * 64;
+                        const int64_t aoff = seg2 ? (second ? op.a4_off : op.a3_off) : (second ? op.a2_off : op.a1_off);
+                        const lvl_rsrc rs = lvl_make_rsrc(A.ws + aoff, (unsigned)npix * (unsigned)Cs * 2u);
                         uint4 v[GB][8];
 #pragma unroll
                         for (int j = 0; j < GB; ++j)
@@ -412,9 +438,9 @@ _Pragma("unroll") \
                         if (NJ == 2 && lane < GB * 9)  // (the cross-wave sum of the previous iteration ran over the rows of zeros)
                             *reinterpret_cast<uint4*>(ldsA + (lane / 9) * LVL_GS + LVL_BM * LVL_PITCH + (lane % 9) * 16) = make_uint4(0u, 0u, 0u, 0u);
                     }
-                    if (p == 0 && d_left > 0) dma_next();  // the ring is full now: RING units requested
+                    if (pt == 0 && d_left > 0) dma_next();  // the ring is full now: RING units requested
                     LV_WAIT_UNIT();
-                    if (p == 0) LV_STAMP(2);
+                    if (pt == 0) LV_STAMP(2);
 /* 64-cout slices.  k-group KG of the unit at tap TAP into set SET (the unit's slot is `rslot`) */                                \
 #define LV2_READ(SET, TAP, KG)                                                                                                     \
     do {                                                                                                                           \
@@ -455,7 +481,7 @@ _Pragma("unroll") \
         LV2_MMA(1);                                                                                                                \
     } while (0)
                     if (NJ == 2) {
-                        if (taps == 9) {
+                        if (taps_p == 9) {
                             LV2_READ(0, 0, 0);
                             LV2_UNIT(0, 1);
                             LV2_UNIT(1, 2);
@@ -470,7 +496,7 @@ _Pragma("unroll") \
                             LV2_READ(0, 4, 0);
                             LV2_UNIT(4, -1);
                         }
-                    } else if (taps == 9) {
+                    } else if (taps_p == 9) {
                         LV_READ_FRAGS(0, 0);
                         LV_STEP(0, 1);
                         LV_STEP(1, 2);

@@ -1027,6 +1027,7 @@ static bool build_lvl_run(dmme_plan* P, int i0, int i1, int lvl_w, int64_t& ws, 
     std::unordered_map<int, int> prod;      // tensor id -> index into `body` of the op that produces it in this run
     std::unordered_map<int, int> pre_of;    // tensor id -> index into `pre`
     std::vector<int> xsrc;                  // tensors whose norms an earlier run's op finishes (complete before this launch)
+    const bool merge_res_off = getenv("DMME_LVL_NO_RES_MERGE") != nullptr;
     auto is_x = [&](int t) { return std::find(xsrc.begin(), xsrc.end(), t) != xsrc.end(); };
     // flag rows are (final op index) * 2 + which; body indices are shifted by pre.size() at the end: encode body rows as 1000000 + ...
     auto row_of = [&](int tensor) -> int {
@@ -1040,8 +1041,9 @@ static bool build_lvl_run(dmme_plan* P, int i0, int i1, int lvl_w, int64_t& ws, 
         LvlOp o{};
         o.kind = LVL_CONV;
         o.taps = 1;
-        o.wait0 = o.wait1 = -1;
-        o.a1_off = o.a2_off = o.dst_off = o.res_off = o.sc_off = -1;
+        o.wait0 = o.wait1 = o.wait2 = o.wait3 = -1;
+        o.a1_off = o.a2_off = o.a3_off = o.a4_off = o.dst_off = o.res_off = o.sc_off = -1;
+        o.w2_off = o.b2_off = -1;
         o.tproj_col = -1;
         o.keep = -1;
         o.signal = 1;
@@ -1172,6 +1174,34 @@ static bool build_lvl_run(dmme_plan* P, int i0, int i1, int lvl_w, int64_t& ws, 
             c.res_off = P->tensors[o.res1].off;
             c.res_C = 256;
             c.res_c0 = 0;
+            // The residual is the output of the block's 1x1 residual conv, the op pushed just before this one, and nothing else reads
+            // it: that conv becomes this op's second K segment (LvlOp::C3) - no residual tensor, one op and one hand-off less per block.
+            auto rt = prod.find(o.res1);
+            if (!merge_res_off && o.taps == 9 && rt != prod.end() && rt->second == (int)body.size() - 1) {
+                const LvlOp& r = body.back();
+                bool only_here = true;  // (forward readers of the residual tensor: this conv alone)
+                for (int ci = i0; ci < (int)P->ops.size() && only_here; ++ci) {
+                    const Op& q = P->ops[ci];
+                    if (ci == oi) continue;
+                    if (q.kind == OP_CONV && (q.src1 == o.res1 || q.src2 == o.res1 || q.res1 == o.res1 || q.res2 == o.res1)) only_here = false;
+                    if (q.kind == OP_GN && (q.gn_src1 == o.res1 || q.gn_src2 == o.res1)) only_here = false;
+                    if (q.kind == OP_ATTN && q.at_qkv == o.res1) only_here = false;
+                }
+                if (only_here && r.kind == LVL_CONV && r.taps == 1 && r.n_norm == 0 && r.keep < 0 && r.res_off < 0 && r.tproj_col < 0 && !r.reuse_a && r.w_row0 == 0 &&
+                    r.dst_c0 == 0 && r.C3 == 0) {
+                    c.C3 = r.C1;
+                    c.C4 = r.C2;
+                    c.a3_off = r.a1_off;
+                    c.a4_off = r.a2_off;
+                    c.wait2 = r.wait0;
+                    c.wait3 = r.wait1;
+                    c.w2_off = r.w_off;
+                    c.b2_off = r.b_off;
+                    c.res_off = -1;
+                    prod.erase(rt);
+                    body.pop_back();
+                }
+            }
         }
         R.flops += 2.0 * B * HW * (double)w.cout * Cin * o.taps;
         R.bytes += (double)w.cout * Cin * o.taps * es + (double)B * HW * (Cin + w.cout) * es;
@@ -1194,7 +1224,7 @@ static bool build_lvl_run(dmme_plan* P, int i0, int i1, int lvl_w, int64_t& ws, 
     const int shift = (int)pre.size();
     R.ops = pre;
     for (LvlOp c : body) {
-        for (int* wr : {&c.wait0, &c.wait1})
+        for (int* wr : {&c.wait0, &c.wait1, &c.wait2, &c.wait3})
             if (*wr >= 1000000) *wr = (*wr - 1000000) + shift * 2;
         R.ops.push_back(c);
     }

@@ -21,6 +21,7 @@ FORWARD = [
     ({"DMME_LVL_GB1": "1"}, "level engine: one pixel group per iteration"),
     ({"DMME_LVL_NJ1": "1"}, "level engine: 32-cout slices (8 per group) on every level"),
     ({"DMME_LVL_NO_XRUN": "1"}, "level engine: skip tensors re-normalised by the run that reads them"),
+    ({"DMME_LVL_NO_RES_MERGE": "1"}, "level engine: the blocks' 1x1 residual convs as ops of their own"),
     ({"DMME_LVL_MAX_ITER": "1"}, "level engine only where a workgroup owns one iteration per op"),
     ({"DMME_NO_LVL": "1", "DMME_NO_KW": "1"}, "small maps on the four-wave pipelined kernel"),
     ({"DMME_KW_NO_BM32": "1"}, "K-split kernel without its 32-pixel tiles (they apply at batch 1-2; same route at this batch)"),

@@ -654,7 +654,6 @@ static int launch_attn_full_t(const T* qkv, const AttnGeom& g, T* out, float* ls
 }
 // whole-row softmax kernel: 256 keys, head width 128 / 256
 bool attn_full_takes(int S, int D) {
-    if (getenv("DMME_ATTN_FULL_ONLY") && atoi(getenv("DMME_ATTN_FULL_ONLY")) != D) return false;
     return S == 256 && (D == 128 || D == 256) && !getenv("DMME_NO_ATTN_FULL");
 }
 

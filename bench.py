@@ -585,8 +585,11 @@ def main():
                     "allreduce_hidden_ms": round(max(0.0, ar_ms - exposed), 3), "gradient_bytes": numel * 4,
                     "exchange": os.environ.get("DMME_EXCHANGE", "fp32-allreduce")}
                 # the other wire format of the gradient mean (distributed.Bf16ShardExchange: bf16 all-to-all + all-gather, fp32 accumulation)
-                dt_bf, _, _ = train_leg(dmme_amd, dev, B, args.precision, k, 3, dist, args.model, exchange="bf16-rs-ag")
-                out["train_dp"]["ms_per_step_bf16_rs_ag"] = round(1e3 * dt_bf / k, 3)
+                try:
+                    dt_bf, _, _ = train_leg(dmme_amd, dev, B, args.precision, k, 3, dist, args.model, exchange="bf16-rs-ag")
+                    out["train_dp"]["ms_per_step_bf16_rs_ag"] = round(1e3 * dt_bf / k, 3)
+                except Exception as exc:  # noqa: BLE001  (a secondary figure: the legs behind it still run)
+                    out["train_dp"]["bf16_rs_ag_error"] = f"{type(exc).__name__}: {exc}"[:200]
                 if B % world == 0 and B // world >= 1:
                     bs = B // world  # north_star wording: the batch of 128 sharded over the ranks
                     dt_g, _, _ = train_leg(dmme_amd, dev, bs, args.precision, k, 3, dist, args.model)

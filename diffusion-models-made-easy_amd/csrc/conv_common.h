@@ -269,8 +269,26 @@ __device__ __forceinline__ uint4 prologue_vec<f16>(uint4 raw, const float* sc, c
 // NB: partials requested per batch.  32 = all at once (one round trip; 64 registers of the preamble - fine where the kernel's own peak
 // is higher anyway); 8 = a rolled loop of batches, twice (sums, then the centred squares out of L1 / L2): the four-wave kernels, whose
 // main-loop register allocation the 32-wide form inflated (SGPR spills 28 -> 93 in the 128 x 64 instance).
+// The loads of gn_in_scale_shift_g's one-batch form, issued early by a caller that has a round trip's worth of other work to put
+// between them and the arithmetic (conv_kw.hip: the halo DMA loop): the <= 32 partials of channel c's group; `pre` goes to
+// gn_in_scale_shift_g, which then reads no partial itself (more than 32 partials: it loads them as always, `pre` is ignored).
+__device__ __forceinline__ void gn_in_prefetch(const GnIn& G, int n, int c, int C, float2 (&pre)[32]) {
+    const int cg = C / G.groups, g = c / cg, c_first = g * cg;
+    const bool second = c_first >= G.C1;
+    const float* p = second ? G.p2 : G.p1;
+    const int tiles = second ? G.t2 : G.t1, cs = second ? G.C2 : G.C1;
+    const int fg = cs / G.groups, f0 = (second ? c_first - G.C1 : c_first) / fg, nf = cg / fg;
+    const int lnf = nf == 1 ? 0 : nf == 2 ? 1 : 2, npart = tiles << lnf;
+    const float* q0 = p + ((int64_t)n * tiles * G.groups + f0) * 2;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        pre[k] = make_float2(0.f, 0.f);
+        if (k < npart && npart <= 32) pre[k] = *reinterpret_cast<const float2*>(q0 + ((k >> lnf) * G.groups + (k & (nf - 1))) * 2);
+    }
+}
 template <int NB = 32>
-__device__ __forceinline__ void gn_in_scale_shift_g(const GnIn& G, float* scale_w, float* shift_w, int n, int c, int C, bool writer, float& sc, float& sh) {
+__device__ __forceinline__ void gn_in_scale_shift_g(const GnIn& G, float* scale_w, float* shift_w, int n, int c, int C, bool writer, float& sc, float& sh,
+                                                    const float2* pre = nullptr) {
     const int cg = C / G.groups, g = c / cg, c_first = g * cg;
     const bool second = c_first >= G.C1;
     const float* p = second ? G.p2 : G.p1;
@@ -320,7 +338,8 @@ __device__ __forceinline__ void gn_in_scale_shift_g(const GnIn& G, float* scale_
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
             v[k] = make_float2(0.f, 0.f);
-            if (k < npart) v[k] = *reinterpret_cast<const float2*>(q0 + ((k >> lnf) * G.groups + (k & (nf - 1))) * 2);
+            if (pre) v[k] = pre[k];
+            else if (k < npart) v[k] = *reinterpret_cast<const float2*>(q0 + ((k >> lnf) * G.groups + (k & (nf - 1))) * 2);
         }
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
@@ -387,8 +406,8 @@ __device__ __forceinline__ void gn_in_scale_shift_g(const GnIn& G, float* scale_
 }
 
 template <int NB = 32>
-__device__ __forceinline__ void gn_in_scale_shift(const ConvArgs& a, int n, int c, int C, bool writer, float& sc, float& sh) {
-    gn_in_scale_shift_g<NB>(a.gni, const_cast<float*>(a.scale), const_cast<float*>(a.shift), n, c, C, writer, sc, sh);
+__device__ __forceinline__ void gn_in_scale_shift(const ConvArgs& a, int n, int c, int C, bool writer, float& sc, float& sh, const float2* pre = nullptr) {
+    gn_in_scale_shift_g<NB>(a.gni, const_cast<float*>(a.scale), const_cast<float*>(a.shift), n, c, C, writer, sc, sh, pre);
 }
 
 // prologue_vec<bf16> with the scale / shift rows in LDS (a norm finished by this conv: ConvArgs::gni): typed LDS reads - through

@@ -117,11 +117,20 @@ __global__ void __launch_bounds__(256, 1) conv3x3_kw_kernel(ConvArgs a, ConvTile
     // (tiles of one image keep the chunk's rows in LDS in any case: read per vector from global memory inside the rolled transform loop
     // they were a dependent round trip per iteration - 4.8 us of a 15.6 us batch-1 launch)
     const bool rows_in_lds = a.has_gni || (a.scale && g.TN == 1);
+    // (the partials' loads go out BEFORE the halo DMA loop - gni_pre - and are used behind it: their round trip and the loop's ~1 us
+    // of address arithmetic overlap instead of following each other)
+    // Only the tiles the small batches run: the 128-pixel ones have no registers to hold 32 partials across the loop (they spill).
+    constexpr bool PRE = BM <= 64;
+    float2 gpre[PRE ? 32 : 1];
+    auto gni_pre = [&](int c0) __attribute__((always_inline)) {
+        if constexpr (PRE)
+            if (rows_in_lds && a.has_gni) gn_in_prefetch(a.gni, n0, c0 + lane, Cin, gpre);
+    };
     auto gni_rows = [&](int c0) __attribute__((always_inline)) {
         if (!rows_in_lds) return;
         float sc, sh;
         if (a.has_gni) {
-            gn_in_scale_shift(a, n0, c0 + lane, Cin, gni_writer, sc, sh);
+            gn_in_scale_shift(a, n0, c0 + lane, Cin, gni_writer, sc, sh, PRE ? gpre : nullptr);
         } else {
             sc = a.scale[n0 * Cin + c0 + lane];
             sh = a.shift[n0 * Cin + c0 + lane];
@@ -158,6 +167,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_kw_kernel(ConvArgs a, ConvTile
         const int Cs = second ? a.C2 : a.C1;
         const int cb = second ? c0 - a.C1 : c0;
         okmask = 0;
+        gni_pre(c0);
         if constexpr (DENSE) {
             const int gp0 = n0 * HWo + (lane >> 3), gp_end = a.N * HWo;  // the tile's pixels are consecutive in the tensor
 #pragma unroll

@@ -817,11 +817,12 @@ __global__ void __launch_bounds__(256) gn_bwd_small_kernel(const T* __restrict__
 }
 
 // 16x16 / 32x32 maps: the same one-launch form with the workgroup's slice of the image - (image, Cw channels of whole groups) - held in
-// REGISTERS between the two phases: every thread keeps the raw 16-byte vectors of its <= ITERS pixels of d(act) and x (its pixel /
+// REGISTERS between the two phases: every thread keeps the raw 16-byte vectors of its ITERS pixels of d(act) and x (its pixel /
 // channel-vector assignment is the same in both phases), so each tensor is read from memory once and all of a thread's loads are in
-// flight together.  Replaces gn_bwd_sums + gn_bwd_apply (which read both tensors twice: 201 MB instead of 134 MB on a 128-channel
+// flight together.  Configurations (ITERS, NT): gn_bwd_regs_pick; the uniform switches SILU / ACT (store the activated input) / ACC
+// (a destination accumulates) / EXTRA (one more addend) are template arguments.  Replaces gn_bwd_sums + gn_bwd_apply (which read both tensors twice: 201 MB instead of 134 MB on a 128-channel
 // 32x32 map at batch 128).  Channel sums: per-thread partials -> LDS -> NT / Cw partial rows -> one thread per channel, fixed order.
-template <typename T, int ITERS, int NT>
+template <typename T, int ITERS, int NT, bool SILU, bool ACT, bool ACC, bool EXTRA>
 __global__ void __launch_bounds__(NT) gn_bwd_regs_kernel(const T* __restrict__ dv, const T* __restrict__ x1, const T* __restrict__ x2, int HW, int C1,
                                                           int C2, int groups, const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
@@ -835,57 +836,103 @@ __global__ void __launch_bounds__(NT) gn_bwd_regs_kernel(const T* __restrict__ d
     const int C = C1 + C2, Cw = C / (int)gridDim.y, cb = (int)blockIdx.y * Cw;
     const int tid = threadIdx.x, VPP = Cw / EPV, ppw = NT / VPP, slot = tid % VPP, prow = tid / VPP;  // (VPP divides NT: host-checked)
     const int n = blockIdx.x, c0 = cb + slot * EPV, cg = C / groups;
-    const bool second = c0 >= C1;
+    const bool second = cb >= C1;  // (a slice lies in one of the two concatenated sources: host-checked) - uniform
     const T* xs = second ? x2 : x1;
     T* dst = second ? dx2 : dx1;
     const int acc = second ? acc2 : acc1;
     const int Cs = second ? C2 : C1, cs0 = second ? c0 - C1 : c0;
+    // Addresses = a uniform base (the image's first pixel: SGPRs) + a 32-bit per-thread byte offset + k uniform steps: a vector's
+    // address is one add away from one register, so nothing address-like stays live between the phases (as 64-bit pointers per
+    // vector the sixteen loads, eight stores and eight activated-input stores spilled).  An image is < 2 GB (host-checked).
     const int64_t p0 = (int64_t)n * HW;
-    uint4 rd[ITERS], rx[ITERS];
-    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    const char* bd = reinterpret_cast<const char*>(dv + p0 * C);
+    const char* bx = reinterpret_cast<const char*>(xs + p0 * Cs);
+    char* bo = reinterpret_cast<char*>(dst + p0 * Cs);
+    char* ba = reinterpret_cast<char*>(act ? act + p0 * C : nullptr);
+    const char* be = reinterpret_cast<const char*>(extra ? extra + p0 * Cs : nullptr);
+    const uint32_t od = (uint32_t)(prow * C + c0) * 2u, ox = (uint32_t)(prow * Cs + cs0) * 2u;
+    const uint32_t sd = (uint32_t)(ppw * C) * 2u, sx = (uint32_t)(ppw * Cs) * 2u;
+    uint4 rd[ITERS], rx[ITERS];  // HW = ITERS * ppw exactly (host-checked): no predicates, no control flow around the vectors
 #pragma unroll
     for (int k = 0; k < ITERS; ++k) {
-        const int p = prow + k * ppw;
-        rd[k] = zero4;
-        rx[k] = zero4;
-        if (p < HW) {
-            rd[k] = load_raw<T>(dv + (p0 + p) * C + c0);
-            rx[k] = load_raw<T>(xs + (p0 + p) * Cs + cs0);
+        rd[k] = *reinterpret_cast<const uint4*>(bd + (od + k * sd));
+        rx[k] = *reinterpret_cast<const uint4*>(bx + (ox + k * sx));
+    }
+    static_assert(sizeof(T) == 2, "pairs of 16-bit channels");
+    // Per-channel constants as the register pairs a dword's two channels need: every operation below is a packed fp32 instruction.
+    f32x2 sc[4], sh[4], dm[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = c0 + 2 * d + h;
+            sc[d][h] = scale[(int64_t)n * C + c];
+            sh[d][h] = shift[(int64_t)n * C + c];
+            dm[d][h] = dmask ? dmask[(int64_t)n * C + c] : 1.0f;
         }
     }
-    float sc[EPV], sh[EPV], dm[EPV], mu[EPV], rs[EPV], gm[EPV];
+    // Phase 1, per vector as it lands: du = d(act) * mask * silu'(y) - summed in fp32 (sum du, sum du * x per channel; the channel's
+    // thread below turns the second into sum du * xhat = rstd (sum du x - mean sum du): mean / rstd stay out of this loop's registers), then kept
+    // as the 16-bit vector IN PLACE of the d(act) registers: phase 2 needs nothing else of d(act), y or the sigmoid, so the
+    // transcendentals are evaluated once per element, not twice.  (du is rounded like every stored gradient; the sums take it unrounded.)
+    // The conv's pre-activated input for the deferred weight gradient (fma, SiLU, mask: the forward's prologue on the same bits) does
+    // not depend on the group sums either and leaves from here, its stores draining under the remaining loads.
+    using V8 = typename Vec8<T>::type;
+    const f32x2 one2 = f32x2{1.0f, 1.0f}, nl2e = f32x2{-1.4426950408889634f, -1.4426950408889634f};
+    f32x2 a[4], bq[4];
 #pragma unroll
-    for (int j = 0; j < EPV; ++j) {
-        const int c = c0 + j, g = c / cg;
-        sc[j] = scale[(int64_t)n * C + c];
-        sh[j] = shift[(int64_t)n * C + c];
-        dm[j] = dmask ? dmask[(int64_t)n * C + c] : 1.0f;
-        mu[j] = mean_rstd[((int64_t)n * groups + g) * 2];
-        rs[j] = mean_rstd[((int64_t)n * groups + g) * 2 + 1];
-        gm[j] = gamma[c];
+    for (int d = 0; d < 4; ++d) a[d] = bq[d] = f32x2{0.f, 0.f};
+#define REGS_PHASE1(SILU, ACT)                                                                     \
+    _Pragma("unroll") for (int k = 0; k < ITERS; ++k) { /* (pixels in ascending order per thread, as the two-pass kernels) */ \
+        const V8 vd = __builtin_bit_cast(V8, rd[k]), vx = __builtin_bit_cast(V8, rx[k]);            \
+        V8 wd, wa;                                                                                  \
+        _Pragma("unroll") for (int d = 0; d < 4; ++d) {                                             \
+            const f32x2 xx = f32x2{(float)vx[2 * d], (float)vx[2 * d + 1]};                         \
+            f32x2 du = f32x2{(float)vd[2 * d], (float)vd[2 * d + 1]} * dm[d];                       \
+            const f32x2 y = __builtin_elementwise_fma(xx, sc[d], sh[d]);                            \
+            f32x2 av = y;                                                                           \
+            if (SILU) {                                                                             \
+                f32x2 e = y * nl2e;                                                                 \
+                e = one2 + f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};       \
+                const f32x2 sg = f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};   \
+                av = y * sg;                                                                        \
+                du = du * (sg * __builtin_elementwise_fma(y, one2 - sg, one2));                     \
+            }                                                                                       \
+            a[d] = a[d] + du;                                                                       \
+            bq[d] = __builtin_elementwise_fma(du, xx, bq[d]);                                       \
+            wd[2 * d] = (T)du[0];                                                                   \
+            wd[2 * d + 1] = (T)du[1];                                                               \
+            if (ACT) {                                                                              \
+                av = av * dm[d];                                                                    \
+                wa[2 * d] = (T)av[0];                                                               \
+                wa[2 * d + 1] = (T)av[1];                                                           \
+            }                                                                                       \
+        }                                                                                           \
+        rd[k] = __builtin_bit_cast(uint4, wd);                                                      \
+        if (ACT) *reinterpret_cast<uint4*>(ba + (od + k * sd)) = __builtin_bit_cast(uint4, wa);     \
+        __builtin_amdgcn_sched_barrier(0); /* one vector at a time: interleaved by the scheduler they do not fit 128 registers */ \
     }
-    float a[EPV], bq[EPV];
+    REGS_PHASE1(SILU, ACT)
+#undef REGS_PHASE1
+    // phase 2's per-channel constants are requested here, to land under the reduction
+    f32x2 mu[4], rs[4], gm[4];
 #pragma unroll
-    for (int j = 0; j < EPV; ++j) a[j] = bq[j] = 0.f;
+    for (int d = 0; d < 4; ++d) {
 #pragma unroll
-    for (int k = 0; k < ITERS; ++k) {
-        if (prow + k * ppw < HW) {  // (pixels in ascending order per thread, as the two-pass kernels)
-            float d[EPV], xv[EPV];
-            unpack_vec<T>(rd[k], d);
-            unpack_vec<T>(rx[k], xv);
-#pragma unroll
-            for (int j = 0; j < EPV; ++j) {
-                float du = d[j] * dm[j];
-                if (pro_silu) du *= silu_grad_f<T>(fmaf(xv[j], sc[j], sh[j]));
-                a[j] += du;
-                bq[j] = fmaf(du, (xv[j] - mu[j]) * rs[j], bq[j]);
-            }
+        for (int h = 0; h < 2; ++h) {
+            const int c = c0 + 2 * d + h, g = c / cg;
+            mu[d][h] = mean_rstd[((int64_t)n * groups + g) * 2];
+            rs[d][h] = mean_rstd[((int64_t)n * groups + g) * 2 + 1];
+            gm[d][h] = gamma[c];
         }
     }
 #pragma unroll
-    for (int j = 0; j < EPV; ++j) {
-        red[(tid * EPV + j) * 2] = a[j];
-        red[(tid * EPV + j) * 2 + 1] = bq[j];
+    for (int d = 0; d < 4; ++d) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            red[(tid * EPV + 2 * d + h) * 2] = a[d][h];
+            red[(tid * EPV + 2 * d + h) * 2 + 1] = bq[d][h];
+        }
     }
     __syncthreads();
     {   // channel lc of the slice: its ppw per-thread partials in NT / Cw parts of ppw * Cw / NT rows each, then the parts in order
@@ -906,6 +953,8 @@ __global__ void __launch_bounds__(NT) gn_bwd_regs_kernel(const T* __restrict__ d
                 sa += red2[(q * Cw + tid) * 2];
                 sb += red2[(q * Cw + tid) * 2 + 1];
             }
+            const float* mr = mean_rstd + ((int64_t)n * groups + (cb + tid) / cg) * 2;
+            sb = mr[1] * fmaf(-mr[0], sa, sb);  // sum du * xhat
             chA[tid] = sa;
             chB[tid] = sb;
             if (rows) {
@@ -930,78 +979,97 @@ __global__ void __launch_bounds__(NT) gn_bwd_regs_kernel(const T* __restrict__ d
     }
     __syncthreads();
     const float inv = 1.0f / (float)((int64_t)cg * HW);
-    // dx = rs (du gm - (k1 + xhat k2)) with du = d dm silu'(y), as gn_bwd_apply_kernel folds it: dx = d silu'(y) Gd + x Cx + C0
-    float Gd[EPV], Cx[EPV], C0[EPV];
+    // dx = rs (du gm - (k1 + xhat k2)) = du G + x Cx + C0 with the du of phase 1 (mask and silu' inside)
+    f32x2 G[4], Cx[4], C0[4];
 #pragma unroll
-    for (int j = 0; j < EPV; ++j) {
-        const int g = (c0 - cb + j) / cg;
-        const float k1 = gS1[g] * inv, k2 = gS2[g] * inv;
-        Gd[j] = rs[j] * gm[j] * dm[j];
-        Cx[j] = -rs[j] * rs[j] * k2;
-        C0[j] = rs[j] * (mu[j] * rs[j] * k2 - k1);
-    }
+    for (int d = 0; d < 4; ++d) {
 #pragma unroll
-    for (int k0 = 0; k0 < ITERS; k0 += 4) {
-        uint4 ro[4], re[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int p = prow + (k0 + u) * ppw;
-            ro[u] = zero4;
-            re[u] = zero4;
-            if (k0 + u < ITERS && p < HW) {
-                if (acc) ro[u] = load_raw<T>(dst + (p0 + p) * Cs + cs0);
-                if (extra) re[u] = load_raw<T>(extra + (p0 + p) * Cs + cs0);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = k0 + u, p = prow + k * ppw;
-            if (k < ITERS && p < HW) {
-                float d[EPV], xv[EPV], o[EPV], ev[EPV], yv[EPV];
-                unpack_vec<T>(rd[k], d);
-                unpack_vec<T>(rx[k], xv);
-                unpack_vec<T>(ro[u], o);
-                unpack_vec<T>(re[u], ev);
-#pragma unroll
-                for (int j = 0; j < EPV; ++j) {
-                    yv[j] = fmaf(xv[j], sc[j], sh[j]);
-                    float du = d[j] * Gd[j];
-                    if (pro_silu) du *= silu_grad_f<T>(yv[j]);
-                    const float dx = fmaf(xv[j], Cx[j], du + C0[j]) + ev[j];
-                    o[j] = acc ? o[j] + dx : dx;
-                }
-                store_vec<T>(dst + (p0 + p) * Cs + cs0, o);
-                if (act) {  // the conv's pre-activated input for the deferred weight gradient (fma, SiLU, mask: the forward's prologue), from registers
-                    float av[EPV];
-#pragma unroll
-                    for (int j = 0; j < EPV; ++j) {
-                        float a_ = yv[j];
-                        if (pro_silu) a_ = sizeof(T) == 2 ? silu_fast(a_) : silu_f(a_);
-                        av[j] = dmask ? a_ * dm[j] : a_;
-                    }
-                    store_vec<T>(act + (p0 + p) * C + c0, av);
-                }
-            }
+        for (int h = 0; h < 2; ++h) {
+            const int g = (c0 - cb + 2 * d + h) / cg;
+            const float k1 = gS1[g] * inv, k2 = gS2[g] * inv, r = rs[d][h];
+            G[d][h] = r * gm[d][h];
+            Cx[d][h] = -r * r * k2;
+            C0[d][h] = r * (mu[d][h] * r * k2 - k1);
         }
     }
+#define REGS_PHASE2(ACC, EXTRA)                                                                    \
+    _Pragma("unroll") for (int k0 = 0; k0 < ITERS; k0 += PB) {                                      \
+        uint4 ro[PB], re[PB];                                                                       \
+        _Pragma("unroll") for (int u = 0; u < PB; ++u) {                                            \
+            if (ACC) ro[u] = acc ? *reinterpret_cast<const uint4*>(bo + (ox + (k0 + u) * sx)) : make_uint4(0u, 0u, 0u, 0u); /* (per source) */ \
+            if (EXTRA) re[u] = *reinterpret_cast<const uint4*>(be + (ox + (k0 + u) * sx));          \
+        }                                                                                           \
+        _Pragma("unroll") for (int u = 0; u < PB; ++u) {                                            \
+            const int k = k0 + u;                                                                   \
+            const V8 vd = __builtin_bit_cast(V8, rd[k]), vx = __builtin_bit_cast(V8, rx[k]);        \
+            V8 vo, ve, w;                                                                           \
+            if (ACC) vo = __builtin_bit_cast(V8, ro[u]);                                            \
+            if (EXTRA) ve = __builtin_bit_cast(V8, re[u]);                                          \
+            _Pragma("unroll") for (int d = 0; d < 4; ++d) {                                         \
+                const f32x2 du = f32x2{(float)vd[2 * d], (float)vd[2 * d + 1]}, xx = f32x2{(float)vx[2 * d], (float)vx[2 * d + 1]}; \
+                f32x2 dx = __builtin_elementwise_fma(xx, Cx[d], __builtin_elementwise_fma(du, G[d], C0[d])); \
+                if (EXTRA) dx = dx + f32x2{(float)ve[2 * d], (float)ve[2 * d + 1]};                 \
+                if (ACC) dx = dx + f32x2{(float)vo[2 * d], (float)vo[2 * d + 1]};                   \
+                w[2 * d] = (T)dx[0];                                                                \
+                w[2 * d + 1] = (T)dx[1];                                                            \
+            }                                                                                       \
+            *reinterpret_cast<uint4*>(bo + (ox + k * sx)) = __builtin_bit_cast(uint4, w);           \
+            __builtin_amdgcn_sched_barrier(0);                                                      \
+        }                                                                                           \
+    }
+    constexpr int PB = ITERS >= 2 ? 2 : 1;  // phase 2 takes the vectors in pairs (the addends' loads of a pair in flight together)
+    static_assert(ITERS % PB == 0, "whole pairs");
+    REGS_PHASE2(ACC, EXTRA)
+#undef REGS_PHASE2
 }
 
 // channel slices for gn_bwd_regs_kernel (0: the shape does not fit it): whole groups, whole 16-byte vectors, not straddling the two
 // concatenated sources, a power-of-two vector count per pixel, at most 8 pixels per thread of the 512
-static int gn_bwd_regs_slices(int dtype, int N, int HW, int C1, int C2, int groups) {
-    if (getenv("DMME_NO_GN_BWD_REGS") || dtype != DMME_BF16) return 0;
+// Configurations of gn_bwd_regs_kernel, in order of preference: (vectors per thread, threads).  1024 x 4 is the 32x32 / 16x16 form
+// (one workgroup of 16 waves per CU); 1024 x 2 the same on tensors whose 1024 x 4 slicing leaves CUs without a workgroup (16x16 maps
+// of 128 channels: 128 workgroups); 256 x 2 / 256 x 1 the 8x8 and 4x4 maps.
+struct GnRegsCfg {
+    int iters, nt;
+};
+static const GnRegsCfg GN_REGS_CFGS[] = {{4, 1024}, {2, 1024}, {2, 256}, {1, 256}};
+// channel slices of configuration `cf` (0: the shape does not fit it): whole groups, whole 16-byte vectors, not straddling the two
+// concatenated sources, a power-of-two vector count per pixel, exactly cf.iters pixels per thread
+static int gn_bwd_regs_slices_cfg(GnRegsCfg cf, int N, int HW, int C1, int C2, int groups) {
     const int C = C1 + C2, cgs = C / groups, epv = 8;
-    if (HW <= 64 || C % groups || C1 % epv || C2 % epv) return 0;
+    if (C % groups || C1 % epv || C2 % epv) return 0;
     for (int cand = 1; cand <= 16; cand <<= 1) {
         const int w = C / cand;
         if (C % cand || w % cgs || w % epv || C1 % w || w > 128 || w / cgs > 32) continue;
         const int vpp = w / epv;
-        if (vpp & (vpp - 1)) continue;
-        const int ppw = 512 / vpp;
-        if ((HW + ppw - 1) / ppw > 8 || (int64_t)N * cand > 65535) continue;
+        if ((vpp & (vpp - 1)) || cf.nt % vpp) continue;
+        const int ppw = cf.nt / vpp;
+        if (HW != cf.iters * ppw || (int64_t)N * cand > 65535 || (int64_t)HW * C * 2 >= (1ll << 31)) continue;
         return cand;
     }
     return 0;
+}
+// the configuration for a shape (-1: none) and its slices: the first that gives every CU a workgroup, else the first that fits
+static int gn_bwd_regs_pick(int dtype, int N, int HW, int C1, int C2, int groups, int* slices) {
+    if (getenv("DMME_NO_GN_BWD_REGS") || dtype != DMME_BF16) return -1;
+    int first = -1, first_slices = 0;
+    for (int i = 0; i < (int)(sizeof(GN_REGS_CFGS) / sizeof(GN_REGS_CFGS[0])); ++i) {
+        const int sl = gn_bwd_regs_slices_cfg(GN_REGS_CFGS[i], N, HW, C1, C2, groups);
+        if (!sl) continue;
+        if ((int64_t)N * sl >= 256) {
+            *slices = sl;
+            return i;
+        }
+        if (first < 0) {
+            first = i;
+            first_slices = sl;
+        }
+    }
+    *slices = first_slices;
+    return first;
+}
+static int gn_bwd_regs_slices(int dtype, int N, int HW, int C1, int C2, int groups) {
+    int sl = 0;
+    return gn_bwd_regs_pick(dtype, N, HW, C1, C2, groups, &sl) < 0 ? 0 : sl;
 }
 
 static bool gn_bwd_small_supported(int dtype, int HW, int C1, int C2, int groups) {
@@ -1038,6 +1106,46 @@ int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2
                        int pro_silu, void* dx1, void* dx2, int acc1, int acc2, float* dgamma, float* dbeta, float* AB, float* S, GnMod mod,
                        hipStream_t s, void* act, float* rows, const void* extra) {
     if (rows && !gn_bwd_rows_supported(dtype, HW, C1, C2, groups, mod.t_scale != nullptr)) rows = nullptr;  // (the plan asked the same question)
+    int rslices = 0;
+    if (const int rcfg = mod.t_scale ? -1 : gn_bwd_regs_pick(dtype, N, HW, C1, C2, groups, &rslices); rcfg >= 0) {
+        // the four uniform switches of the two phases are template arguments: as branches inside one kernel the variants of a phase
+        // shared one register allocation and spilled (240 bytes per lane against none)
+#define REGS_LAUNCH(I_, NT_, S_, A_, C_, E_)                                                                                                      \
+    hipLaunchKernelGGL((gn_bwd_regs_kernel<bf16, I_, NT_, S_, A_, C_, E_>), dim3(N, rslices), dim3(NT_), 0, s, (const bf16*)dv, (const bf16*)x1,    \
+                       (const bf16*)x2, HW, C1, C2, groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, (bf16*)dx1, (bf16*)dx2, acc1, acc2,    \
+                       dgamma, dbeta, (bf16*)act, rows, (const bf16*)extra)
+#define REGS_LAUNCH_CE(I_, NT_, S_, A_)                              \
+    do {                                                             \
+        if (acc1 || acc2) {                                          \
+            if (extra) REGS_LAUNCH(I_, NT_, S_, A_, true, true);     \
+            else REGS_LAUNCH(I_, NT_, S_, A_, true, false);          \
+        } else {                                                     \
+            if (extra) REGS_LAUNCH(I_, NT_, S_, A_, false, true);    \
+            else REGS_LAUNCH(I_, NT_, S_, A_, false, false);         \
+        }                                                            \
+    } while (0)
+#define REGS_LAUNCH_SA(I_, NT_)                                \
+    do {                                                       \
+        if (pro_silu) {                                        \
+            if (act) REGS_LAUNCH_CE(I_, NT_, true, true);      \
+            else REGS_LAUNCH_CE(I_, NT_, true, false);         \
+        } else {                                               \
+            if (act) REGS_LAUNCH_CE(I_, NT_, false, true);     \
+            else REGS_LAUNCH_CE(I_, NT_, false, false);        \
+        }                                                      \
+    } while (0)
+        switch (rcfg) {
+            case 0: REGS_LAUNCH_SA(4, 1024); break;
+            case 1: REGS_LAUNCH_SA(2, 1024); break;
+            case 2: REGS_LAUNCH_SA(2, 256); break;
+            default: REGS_LAUNCH_SA(1, 256); break;
+        }
+#undef REGS_LAUNCH_SA
+#undef REGS_LAUNCH_CE
+#undef REGS_LAUNCH
+        DMME_CHECK_LAUNCH();
+        return DMME_OK;
+    }
     if (!mod.t_scale && gn_bwd_small_supported(dtype, HW, C1, C2, groups)) {
         // channel slices: whole groups, whole 16-byte vectors, not straddling the two concatenated sources, <= 256 threads per pixel row
         const int Call = C1 + C2, cgs = Call / groups, epv = dtype == DMME_BF16 ? 8 : 4;
@@ -1056,12 +1164,6 @@ int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2
         else
             hipLaunchKernelGGL(gn_bwd_small_kernel<float>, dim3(N, slices), dim3(256), 0, s, (const float*)dv, (const float*)x1, (const float*)x2, HW, C1, C2,
                                groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, (float*)dx1, (float*)dx2, acc1, acc2, dgamma, dbeta, (float*)act, rows, (const float*)extra);
-        DMME_CHECK_LAUNCH();
-        return DMME_OK;
-    }
-    if (const int rslices = mod.t_scale ? 0 : gn_bwd_regs_slices(dtype, N, HW, C1, C2, groups)) {
-        hipLaunchKernelGGL((gn_bwd_regs_kernel<bf16, 8, 512>), dim3(N, rslices), dim3(512), 0, s, (const bf16*)dv, (const bf16*)x1, (const bf16*)x2, HW, C1, C2, groups,
-                           gamma, mean_rstd, scale, shift, dmask, pro_silu, (bf16*)dx1, (bf16*)dx2, acc1, acc2, dgamma, dbeta, (bf16*)act, rows, (const bf16*)extra);
         DMME_CHECK_LAUNCH();
         return DMME_OK;
     }

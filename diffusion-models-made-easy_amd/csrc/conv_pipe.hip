@@ -379,6 +379,9 @@ __device__ __forceinline__ WsTile ws_tile_of(const ConvTile& g, int shTW, int sh
     return r;
 }
 
+// bytes behind A1 that make R1 | R2 | A1 the 64 KB the epilogue's staging needs (0 for the 256-pixel tile's halo buffers)
+__host__ __device__ inline int ws2_stage_pad(int a_bytes) { return a_bytes + 2 * 128 * ROW_DATA >= 64 * 1024 ? 0 : 64 * 1024 - 2 * 128 * ROW_DATA - a_bytes; }
+
 // ---------------------------------------------------------------------------------------------------------------
 // Wave-specialised, persistent 256-pixel x 128-cout kernel (bf16, one image per tile, an even number of 64-channel
 // chunks).  In-kernel cycle stamps of the kernel above showed a workgroup spending under half of its life in MFMA
@@ -415,12 +418,16 @@ __device__ __forceinline__ void ws_fill_par_gni(const ConvArgs& a, int n, bool w
     }
 }
 
-template <int PIPE_UA, typename T = bf16>
+// BM = 128 (PIPE_UA = 7): the same kernel on 128-pixel tiles (4 x 32 or 8 x 16 pixels, halo <= 204 rows = 7 units, consumer waves 64 pixels x 64
+// couts, ONE epilogue pass) for the layers whose 256-pixel tiling leaves CUs without a tile: the 32x32 maps at batch 32, the
+// 128-cout layers of the 16x16 level at batch 128.  Per MFMA it moves twice the filter bytes and is behind the 256-pixel form
+// wherever that fills the chip; against the four-wave kernel that ran these layers it keeps the producer / consumer split.
+template <int PIPE_UA, typename T = bf16, int BM = 256>
 __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTile g, int shTW, int shTH, int ntiles) {
-    constexpr int KC = 64, EPV = 8, BN = 128, MI = 4, NI = 2, UB = BN / 32;  // BM = 256
+    constexpr int KC = 64, EPV = 8, BN = 128, MI = BM / 64, NI = 2, UB = BN / 32;
     constexpr int R_BYTES = BN * ROW_DATA;  // one tap
     constexpr int A_PITCH = ROW_DATA + 16;  // halo rows are padded, not swizzled: fragment reads use immediate offsets from one base
-    static_assert(PIPE_UA == 11, "unit schedule below is written out for 11 units over 9 stages");
+    static_assert((BM == 256 && PIPE_UA == 11) || (BM == 128 && PIPE_UA == 7), "unit schedules below: 11 units over 9 stages, or 7 units over the first 7");
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int a_bytes = g.a_rows * A_PITCH;
@@ -428,7 +435,8 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
     const int offA1 = a_bytes + 3 * R_BYTES, offR = a_bytes;
     // [2][4][Cin]: per channel of the tile's image, as the producers' packed prologue wants them: S = scale * mask, H = shift * mask,
     // S2 = -log2(e) * scale, H2 = -log2(e) * shift:  act(x) = (x S + H) / (1 + 2^(x S2 + H2))  [= silu(x scale + shift) * mask]
-    float* par_base = reinterpret_cast<float*>(lds + 2 * a_bytes + 3 * R_BYTES);
+    // (the epilogue stages 128 x 128 floats through R1 | R2 | A1: a 128-pixel tile's halo buffer is padded up to that)
+    float* par_base = reinterpret_cast<float*>(lds + 2 * a_bytes + 3 * R_BYTES + ws2_stage_pad(a_bytes));
 #define WS_BUFA(p) (lds + (((p) & 1) ? offA1 : 0))
 #define WS_RING(slot) (lds + offR + (slot) * R_BYTES)
 #define WS_PAR(kt) (par_base + ((kt) & 1) * 4 * Cin)
@@ -487,7 +495,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         WS_ESTAMP()                                                                                                                \
         __syncthreads();                                                                                                           \
         WS_ESTAMP()                                                                                                                \
-        conv_epilogue_store<T, 128, BN, 512>(a, (TT).co0, (TT).n0, pix_of, stage, 2 * (TT).ts + p, rpre, a.n_gno ? p : -1, gn_carry); \
+        conv_epilogue_store<T, 128, BN, 512>(a, (TT).co0, (TT).n0, pix_of, stage, (BM / 128) * (TT).ts + p, rpre, a.n_gno ? p : -1, gn_carry); \
         WS_ESTAMP()                                                                                                                \
         __syncthreads(); /* everyone is done with the staging area */                                                              \
     }
@@ -497,7 +505,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
     {                                                                                                                              \
         float* stage = reinterpret_cast<float*>(WS_RING(1));                                                                       \
         WS2_PASS(TT, 0, STAGE0)                                                                                                    \
-        WS2_PASS(TT, 1, STAGE1)                                                                                                    \
+        if constexpr (BM == 256) { WS2_PASS(TT, 1, STAGE1) }                                                                       \
         if ((KT) + 2 < K) WS_FILL_PAR((KT) + 2)                                                                                    \
     }
     if (producer) {
@@ -622,7 +630,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
 #else
 #define WS_PST()
 #endif
-#define WS_L(TP) (((TP) == 0 || (TP) == 8) ? 2 : 1) /* halo loads a stage issues (behind its DMA) */
+#define WS_L(TP) (PIPE_UA == 11 ? (((TP) == 0 || (TP) == 8) ? 2 : 1) : ((TP) < 7 ? 1 : 0)) /* halo loads a stage issues (behind its DMA) */
 #define WS_PSTAGE(TP)                                                                                                   \
     {                                                                                                                   \
         WS_PST()                                                                                                        \
@@ -634,9 +642,11 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         const int lk = have_l ? (last_n ? nk + 1 : nk) : nk, lc = have_l ? (last_n ? 0 : nc + 1) : nc;                  \
         /* this stage's halo registers are taken as arrived before its DMA goes out (the compiler's counted wait sits    \
            here, in front of the stage's work) */                                                                       \
-        if ((TP) == 0) { WS_A_ARRIVED(0) WS_A_ARRIVED(1) }                                                              \
-        else if ((TP) == 8) { WS_A_ARRIVED(9) WS_A_ARRIVED(10) }                                                        \
-        else { WS_A_ARRIVED((TP) + 1) }                                                                                 \
+        if constexpr (PIPE_UA == 11) {                                                                                  \
+            if ((TP) == 0) { WS_A_ARRIVED(0) WS_A_ARRIVED(1) }                                                          \
+            else if ((TP) == 8) { WS_A_ARRIVED(9) WS_A_ARRIVED(10) }                                                    \
+            else { WS_A_ARRIVED((TP) + 1) }                                                                             \
+        } else if constexpr ((TP) < 7) { WS_A_ARRIVED(TP) }                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
         WS_PST()                                                                                                        \
         bool sent = true;          /* this stage sent a tap two stages ahead */                                         \
@@ -659,9 +669,12 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             char* dstA = WS_BUFA(cg + 1);                                                                               \
             const bool new_tile = have_l && lc == 0;                                                                    \
             const TileXY tnn = lk == kt ? tcur : tnext;                                                                 \
-            if ((TP) == 0) { load_par(WS_PAR(nk), nc* KC); WS_A_UNIT(0) WS_A_UNIT(1) }                                  \
-            else if ((TP) == 8) { WS_A_UNIT(9) WS_A_UNIT(10) }                                                          \
-            else { WS_A_UNIT((TP) + 1) }                                                                                \
+            if ((TP) == 0) load_par(WS_PAR(nk), nc* KC);                                                                \
+            if constexpr (PIPE_UA == 11) {                                                                              \
+                if ((TP) == 0) { WS_A_UNIT(0) WS_A_UNIT(1) }                                                            \
+                else if ((TP) == 8) { WS_A_UNIT(9) WS_A_UNIT(10) }                                                      \
+                else { WS_A_UNIT((TP) + 1) }                                                                            \
+            } else if constexpr ((TP) < 7) { WS_A_UNIT(TP) }                                                            \
         }                                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
         WS_PST()                                                                                                        \
@@ -782,7 +795,10 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
 #undef WS_TILE
 }
 
-static size_t ws2_lds(const ConvArgs& a, const ConvTile& g) { return 2 * (size_t)g.a_rows * (ROW_DATA + 16) + 3 * (size_t)128 * ROW_DATA + (size_t)2 * 4 * (a.C1 + a.C2) * 4; }
+static size_t ws2_lds(const ConvArgs& a, const ConvTile& g) {
+    const size_t a_bytes = (size_t)g.a_rows * (ROW_DATA + 16);
+    return 2 * a_bytes + 3 * (size_t)128 * ROW_DATA + (size_t)ws2_stage_pad((int)a_bytes) + (size_t)2 * 4 * (a.C1 + a.C2) * 4;
+}
 
 // the wave-specialised kernel applies (else 0): its tile goes to g
 static int ws_pick(const ConvArgs& a, ConvTile& g) {
@@ -795,6 +811,12 @@ static int ws_pick(const ConvArgs& a, ConvTile& g) {
         t.tiles_m * t.tiles_n >= ws_min_tiles) {
         g = t;
         return 3;
+    }
+    // 128-pixel tiles where those fill the chip and the 256-pixel ones do not (return value 4)
+    ConvTile u;
+    if (!getenv("DMME_NO_WS128") && make_tile(a, 128, 128, u) && u.TN == 1 && u.a_rows <= 224 && ws2_lds(a, u) <= 160 * 1024 && u.tiles_m * u.tiles_n >= ws_min_tiles) {
+        g = u;
+        return 4;
     }
     return 0;
 }
@@ -912,13 +934,17 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
         if (ws) {
             static bool ws_attr = false;  // (one flag per instantiation of this launcher, i.e. per T)
             if (!ws_attr) {
-                const int rc0 = set_lds_limit(conv3x3_ws2_kernel<11, T>, 160 * 1024);
+                int rc0 = set_lds_limit(conv3x3_ws2_kernel<11, T, 256>, 160 * 1024);
+                if (rc0 == DMME_OK) rc0 = set_lds_limit(conv3x3_ws2_kernel<7, T, 128>, 160 * 1024);
                 if (rc0 != DMME_OK) return rc0;
                 ws_attr = true;
             }
             const int ntiles = gw.tiles_m * gw.tiles_n;
             const dim3 wgrid((unsigned)(ntiles < 256 ? ntiles : 256));
-            hipLaunchKernelGGL((conv3x3_ws2_kernel<11, T>), wgrid, dim3(512), ws2_lds(a, gw), s, a, gw, ilog2(gw.TW), ilog2(gw.TH), ntiles);
+            if (ws == 4)
+                hipLaunchKernelGGL((conv3x3_ws2_kernel<7, T, 128>), wgrid, dim3(512), ws2_lds(a, gw), s, a, gw, ilog2(gw.TW), ilog2(gw.TH), ntiles);
+            else
+                hipLaunchKernelGGL((conv3x3_ws2_kernel<11, T, 256>), wgrid, dim3(512), ws2_lds(a, gw), s, a, gw, ilog2(gw.TW), ilog2(gw.TH), ntiles);
             DMME_CHECK_LAUNCH();
             return DMME_OK;
         }
@@ -1054,7 +1080,7 @@ bool conv_pipe_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int
         const int ws = ws_pick(a, gw);
         if (ws) {
             if (!stats_tile_ok(a, gw, 128, cg, 8)) return false;
-            *tiles = gw.tiles_x * gw.tiles_y * 2;  // one partial per 128-pixel epilogue pass
+            *tiles = gw.tiles_x * gw.tiles_y * (ws == 4 ? 1 : 2);  // one partial per 128-pixel epilogue pass
             *px = 128;
             return true;
         }
@@ -1083,7 +1109,7 @@ void conv_pipe_label(int dtype, const ConvArgs& a, char* buf, int cap) {
         ConvTile gw{};
         const int ws = ws_pick(a, gw);
         if (ws) {
-            snprintf(buf, (size_t)cap, "conv3x3_ws2_kernel<11>");
+            snprintf(buf, (size_t)cap, ws == 4 ? "conv3x3_ws2_kernel<7,128>" : "conv3x3_ws2_kernel<11>");
             return;
         }
     }

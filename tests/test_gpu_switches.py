@@ -41,6 +41,7 @@ FORWARD = [
     ({"DMME_NO_PIPE_DMA": "1"}, "filter tiles through registers in the 64-cout pipelined kernel"),
     ({"DMME_NO_CONV_THIN": "1"}, "output conv on the tiled kernels"),
     ({"DMME_NO_WS": "1"}, "no wave-specialised persistent kernel"),
+    ({"DMME_NO_WS128": "1"}, "persistent kernel without its 128-pixel tiles (the 128-cout layers of the 16x16 level back on the four-wave kernel)"),
     ({"DMME_NO_FUSED_GN": "1"}, "every GroupNorm reads its tensor"),
     ({"DMME_NO_XCD_ORDER": "1"}, "plain workgroup order in attention / 1x1 convs"),
     ({"DMME_NO_SPLITK": "1"}, "no split-K in the four-wave kernel"),

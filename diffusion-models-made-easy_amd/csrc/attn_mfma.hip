@@ -729,7 +729,7 @@ int launch_attn_mfma(int dtype, const void* qkv, int N, int S, int C, void* out,
 // matrices (both fragments via transposed LDS reads), dQ = s dS K is a row-major A times a
 // transposed-read B.
 template <int C, int NW>
-__global__ void __launch_bounds__(64 * NW) attn_bwd_scores_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ O,
+__global__ void __launch_bounds__(64 * NW, 1) attn_bwd_scores_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ O,
                                                               const bf16* __restrict__ dO, const float* __restrict__ lse, AttnGeom g,
                                                               bf16* __restrict__ P, bf16* __restrict__ dS) {
     constexpr int AT_QB = 32 * NW, NT = 64 * NW;
@@ -763,15 +763,33 @@ __global__ void __launch_bounds__(64 * NW) attn_bwd_scores_kernel(const bf16* __
     bf16* Prow = P + ((int64_t)n * S + q_row) * S;
     bf16* dSrow = dS + ((int64_t)n * S + q_row) * S;
 
+    // K / V tiles a tile ahead, through registers: one wave per SIMD has nothing else to put under a tile's global round trip (the
+    // load-store-barrier form spent 8 exposed round trips per workgroup: 50 us per launch for 8.6 GFLOP)
+    constexpr int NV = AT_KT * (C / 8) / NT;
+    static_assert(NV * NT == AT_KT * (C / 8), "whole vectors per thread");
+    typedef unsigned atb_u32x4 __attribute__((ext_vector_type(4)));  // (plain vectors: arrays of HIP's uint4 struct stayed in scratch memory)
+    atb_u32x4 kreg[NV], vreg[NV];
+#define ATB_FETCH(K0)                                                                     \
+    _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                       \
+        const int u = tid + i * NT, row = u / (C / 8), cu = u % (C / 8);                   \
+        const bf16* src = base + (int64_t)((K0) + row) * ld + cu * 8;                      \
+        kreg[i] = *reinterpret_cast<const atb_u32x4*>(src + C);                            \
+        vreg[i] = *reinterpret_cast<const atb_u32x4*>(src + 2 * C);                        \
+    }
+    ATB_FETCH(0)
     for (int k0 = 0; k0 < S; k0 += AT_KT) {
         __syncthreads();
-        for (int u = tid; u < AT_KT * (C / 8); u += NT) {
-            const int row = u / (C / 8), cu = u % (C / 8);
-            const bf16* src = base + (int64_t)(k0 + row) * ld + cu * 8;
-            *reinterpret_cast<uint4*>(ldsK + row * KP + cu * 16) = *reinterpret_cast<const uint4*>(src + C);
-            *reinterpret_cast<uint4*>(ldsV + row * KP + cu * 16) = *reinterpret_cast<const uint4*>(src + 2 * C);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int u = tid + i * NT, row = u / (C / 8), cu = u % (C / 8);
+            *reinterpret_cast<atb_u32x4*>(ldsK + row * KP + cu * 16) = kreg[i];
+            *reinterpret_cast<atb_u32x4*>(ldsV + row * KP + cu * 16) = vreg[i];
         }
         __syncthreads();
+        {   // (unconditional: the last trip re-requests its own tile - as a branch the two arrays went to scratch memory)
+            const int kn = k0 + AT_KT < S ? k0 + AT_KT : k0;
+            ATB_FETCH(kn)
+        }
         f32x16 st, dp;
 #pragma unroll
         for (int j = 0; j < 16; ++j) st[j] = dp[j] = 0.f;
@@ -797,6 +815,7 @@ __global__ void __launch_bounds__(64 * NW) attn_bwd_scores_kernel(const bf16* __
             *reinterpret_cast<bf16x4*>(dSrow + k0 + 8 * jg + 4 * h) = dv;
         }
     }
+#undef ATB_FETCH
 }
 
 // per-image GEMM  out[m][n] = alpha * sum_k A(m,k) B(k,n),  M = K = S, N = C (bf16 in, fp32 accumulate)
@@ -836,26 +855,45 @@ __global__ void __launch_bounds__(256) attn_bgemm_kernel(const bf16* __restrict_
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.f;
 
+    // both operand tiles a k-step ahead, through registers (as attn_bwd_scores_kernel: nothing else hides the round trip here)
+    typedef unsigned bg_u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int NVY = 32 * (C / 8) / 256;
+    static_assert(NVY * 256 == 32 * (C / 8), "whole vectors per thread");
+    bg_u32x4 yreg[NVY], xreg;
+#define BG_FETCH(K0)                                                                                             \
+    {                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < NVY; ++i) {                                                        \
+            const int u = tid + i * 256, row = u / (C / 8), cu = u % (C / 8);                                    \
+            yreg[i] = *reinterpret_cast<const bg_u32x4*>(Yi + (int64_t)((K0) + row) * ldy + cu * 8);             \
+        }                                                                                                        \
+        if (TRANS_A) { /* X[k0 + row][m0 .. m0+63] */                                                            \
+            const int row = tid >> 3, cu = tid & 7;                                                              \
+            xreg = *reinterpret_cast<const bg_u32x4*>(Xi + (int64_t)((K0) + row) * ldx + m0 + cu * 8);           \
+        } else { /* X[m0 + row][k0 .. k0+31] */                                                                  \
+            const int row = tid >> 2, cu = tid & 3;                                                              \
+            xreg = *reinterpret_cast<const bg_u32x4*>(Xi + (int64_t)(m0 + row) * ldx + (K0) + cu * 8);           \
+        }                                                                                                        \
+    }
+    BG_FETCH(0)
     for (int k0 = 0; k0 < S; k0 += 32) {
         __syncthreads();
-        for (int u = tid; u < 32 * (C / 8); u += 256) {
-            const int row = u / (C / 8), cu = u % (C / 8);
-            *reinterpret_cast<uint4*>(ldsY + row * YP + cu * 16) = *reinterpret_cast<const uint4*>(Yi + (int64_t)(k0 + row) * ldy + cu * 8);
+#pragma unroll
+        for (int i = 0; i < NVY; ++i) {
+            const int u = tid + i * 256, row = u / (C / 8), cu = u % (C / 8);
+            *reinterpret_cast<bg_u32x4*>(ldsY + row * YP + cu * 16) = yreg[i];
         }
         if (TRANS_A) {
-            // X[k0 + row][m0 .. m0+63]
-            for (int u = tid; u < 32 * 8; u += 256) {
-                const int row = u >> 3, cu = u & 7;
-                *reinterpret_cast<uint4*>(ldsX + row * XP_T + cu * 16) = *reinterpret_cast<const uint4*>(Xi + (int64_t)(k0 + row) * ldx + m0 + cu * 8);
-            }
+            const int row = tid >> 3, cu = tid & 7;
+            *reinterpret_cast<bg_u32x4*>(ldsX + row * XP_T + cu * 16) = xreg;
         } else {
-            // X[m0 + row][k0 .. k0+31]
-            for (int u = tid; u < 64 * 4; u += 256) {
-                const int row = u >> 2, cu = u & 3;
-                *reinterpret_cast<uint4*>(ldsX + row * XP_N + cu * 16) = *reinterpret_cast<const uint4*>(Xi + (int64_t)(m0 + row) * ldx + k0 + cu * 8);
-            }
+            const int row = tid >> 2, cu = tid & 3;
+            *reinterpret_cast<bg_u32x4*>(ldsX + row * XP_N + cu * 16) = xreg;
         }
         __syncthreads();
+        {
+            const int kn = k0 + 32 < S ? k0 + 32 : k0;  // (unconditional: the last trip re-requests its own tiles)
+            BG_FETCH(kn)
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             s16x8 af[MI];
@@ -886,6 +924,7 @@ __global__ void __launch_bounds__(256) attn_bgemm_kernel(const bf16* __restrict_
             }
         }
     }
+#undef BG_FETCH
     bf16* Oi = out + at_qkv_off<C>(g, n) + ocol;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)

@@ -127,10 +127,14 @@ typedef float f32x16_sg __attribute__((ext_vector_type(16)));
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256) small_gemm_mfma_kernel(const float* __restrict__ A, int lda, const void* __restrict__ Bv, int ldb, int M, int N,
                                                               int K, const float* __restrict__ bias, int out_silu, float* __restrict__ Cm, int ldc,
-                                                              int ksplit, const int64_t* __restrict__ mtile_off, float* __restrict__ Cpre) {
+                                                              int ksplit, const int64_t* __restrict__ mtile_off, float* __restrict__ Cpre, int wsplit) {
+    // wsplit: the workgroup's four waves share ONE output tile and split its K range (summed through LDS in wave order) instead of
+    // owning four tiles: these GEMMs are chains of round trips (a block of 64 K values per trip, one wave per SIMD, most CUs idle) -
+    // a quarter of the chain per wave on four times the workgroups.  Same fp32 products; the order of a sum's terms is fixed.
+    __shared__ float wred[3][16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-    const int n0 = (blockIdx.x * 4 + wave) * 32, m0 = blockIdx.y * 32;
-    if (n0 >= N) return;
+    const int n0 = wsplit ? blockIdx.x * 32 : (blockIdx.x * 4 + wave) * 32, m0 = blockIdx.y * 32;
+    if (n0 >= N) return;  // (wsplit: uniform over the workgroup)
     const int m = m0 + r, n = n0 + r;  // this lane's row of the A operand / column of the B operand
     const bool mok = m < M, nok = n < N;
     f32x16_sg acc;
@@ -138,7 +142,12 @@ __global__ void __launch_bounds__(256) small_gemm_mfma_kernel(const float* __res
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
     // K slice of this workgroup (split-K over blockIdx.z in units of 8)
     const int k8 = (K + 7) / 8, per = (k8 + ksplit - 1) / ksplit;
-    const int kb = (int)blockIdx.z * per * 8, ke = min(K, kb + per * 8);
+    int kb = (int)blockIdx.z * per * 8, ke = min(K, kb + per * 8);
+    if (wsplit) {
+        const int per4 = ((ke - kb + 7) / 8 + 3) / 4 * 8;
+        kb += wave * per4;
+        ke = min(ke, kb + per4);
+    }
     auto load = [&](int k0, float (&a)[4], float (&b)[4]) __attribute__((always_inline)) {
         const int k = k0 + 4 * h;
 #pragma unroll
@@ -212,6 +221,18 @@ __global__ void __launch_bounds__(256) small_gemm_mfma_kernel(const float* __res
     }
 #undef SG_LOAD_BLOCK
 #undef SG_MMA_BLOCK
+    if (wsplit) {
+        if (wave > 0) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) wred[wave - 1][j][lane] = acc[j];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] += wred[w][j][lane];
+    }
     if (!nok) return;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -251,8 +272,10 @@ int launch_small_gemm(int dtype, int mode, const float* A, int lda, const void* 
             if (ksplit < 1) ksplit = 1;
         }
         if (ksplit > 1) DMME_CHECK_HIP(hipMemsetAsync(C, 0, (size_t)M * ldc * sizeof(float), s));
-        dim3 grid((N + 127) / 128, (M + 31) / 32, ksplit);
-#define DMME_SGM(TT, MM) hipLaunchKernelGGL((small_gemm_mfma_kernel<TT, MM>), grid, dim3(256), 0, s, A, lda, B, ldb, M, N, K, bias, out_silu, C, ldc, ksplit, (const int64_t*)nullptr, Cpre)
+        // four waves per tile where the tiles alone leave SIMDs idle and every wave still gets a block of K
+        const int wsplit = (waves * ksplit <= 1024 && K / ksplit >= 256) ? 1 : 0;
+        dim3 grid(wsplit ? (N + 31) / 32 : (N + 127) / 128, (M + 31) / 32, ksplit);
+#define DMME_SGM(TT, MM) hipLaunchKernelGGL((small_gemm_mfma_kernel<TT, MM>), grid, dim3(256), 0, s, A, lda, B, ldb, M, N, K, bias, out_silu, C, ldc, ksplit, (const int64_t*)nullptr, Cpre, wsplit)
         if (mode == GEMM_TN) {
             DMME_SGM(float, GEMM_TN);
         } else if (dtype == DMME_BF16) {
@@ -320,7 +343,7 @@ int launch_small_gemm_tn_tiled(const float* A, int lda, const float* B, int ldb,
     if (sg_mfma()) {
         dim3 gridm((N + 127) / 128, (M + 31) / 32, 1);
         hipLaunchKernelGGL((small_gemm_mfma_kernel<float, GEMM_TN>), gridm, dim3(256), 0, s, A, lda, (const void*)B, ldb, M, N, K, (const float*)nullptr, 0, C,
-                           ldc, 1, mtile_off, (float*)nullptr);
+                           ldc, 1, mtile_off, (float*)nullptr, 0);
         DMME_CHECK_LAUNCH();
         return DMME_OK;
     }

@@ -199,6 +199,20 @@ __global__ void __launch_bounds__(256) wgrad_thin_kernel(ConvArgs a, const T* __
     const int total = a.N * HW;  // < 2^31 (checked by the launcher)
     for (int tile = blockIdx.x; tile < tiles_total; tile += gridDim.x) {
         const int p0 = tile * PX;
+        // 16-bit tensors at >= 8 pixel lanes (every shape the networks have): the thread's <= 32 vectors of the wide tensor are
+        // requested HERE, in front of the coefficient gathers - one round trip for both instead of one for the gathers and then one
+        // per four pixels of the loop below (that was this kernel: ~20 dependent round trips per tile, 63 us for 33 MB)
+        constexpr int NPRE = 32;
+        const bool pre = sizeof(T) == 2 && lanes_p * NPRE >= PX;
+        uint2 rawp[NPRE];
+        if (pre) {
+#pragma unroll
+            for (int i = 0; i < NPRE; ++i) {
+                const int pi = pl + i * lanes_p, p = p0 + pi;
+                rawp[i] = make_uint2(0u, 0u);
+                if (pi < PX && p < total) rawp[i] = *reinterpret_cast<const uint2*>(wide + (int64_t)p * Cw + 4 * vec);
+            }
+        }
         __syncthreads();
         {   // thread <-> pixel: its 27 coefficients are 27 independent gathers
             const int p = p0 + tid;
@@ -228,6 +242,45 @@ __global__ void __launch_bounds__(256) wgrad_thin_kernel(ConvArgs a, const T* __
                 sh = *reinterpret_cast<const float4*>(a.shift + so);
             }
         }
+#define WTHIN_PIXEL(PI, RAWP)                                                                                                   \
+        {                                                                                                                      \
+            const int pi = (PI);                                                                                               \
+            const int p = p0 + pi;                                                                                             \
+            const bool in = p < total;                                                                                         \
+            float v[4] = {0.f, 0.f, 0.f, 0.f};                                                                                 \
+            const uint2 raw = (RAWP);                                                                                          \
+            v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);                                   \
+            v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);                                   \
+            if constexpr (!FIRST) {                                                                                            \
+                if (a.scale && !one_image && in) {                                                                             \
+                    const int64_t so = (int64_t)(p / HW) * Cw + 4 * vec;                                                       \
+                    sc = *reinterpret_cast<const float4*>(a.scale + so);                                                       \
+                    sh = *reinterpret_cast<const float4*>(a.shift + so);                                                       \
+                }                                                                                                              \
+                v[0] = fmaf(v[0], sc.x, sh.x); v[1] = fmaf(v[1], sc.y, sh.y); v[2] = fmaf(v[2], sc.z, sh.z); v[3] = fmaf(v[3], sc.w, sh.w); \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                \
+                    if (a.pro_silu) v[j] = silu_fast(v[j]);                                                                    \
+                    v[j] = in ? to_f(from_f<T>(v[j])) : 0.f;                                                                   \
+                }                                                                                                              \
+            }                                                                                                                  \
+            const float4* cp = reinterpret_cast<const float4*>(lds + pi * KP);                                                 \
+            _Pragma("unroll") for (int k4 = 0; k4 < 7; ++k4) {                                                                 \
+                const float4 c = cp[k4];                                                                                       \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                \
+                    acc[j][4 * k4] = fmaf(v[j], c.x, acc[j][4 * k4]);                                                          \
+                    if (4 * k4 + 1 < 27) acc[j][4 * k4 + 1] = fmaf(v[j], c.y, acc[j][4 * k4 + 1]);                             \
+                    if (4 * k4 + 2 < 27) acc[j][4 * k4 + 2] = fmaf(v[j], c.z, acc[j][4 * k4 + 2]);                             \
+                    if (4 * k4 + 3 < 27) acc[j][4 * k4 + 3] = fmaf(v[j], c.w, acc[j][4 * k4 + 3]);                             \
+                }                                                                                                              \
+            }                                                                                                                  \
+        }
+        if (pre) {
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int i = 0; i < NPRE; ++i)
+                    if (pl + i * lanes_p < PX) WTHIN_PIXEL(pl + i * lanes_p, rawp[i])
+            }
+        } else
 #pragma unroll 4
         for (int pi = pl; pi < PX; pi += lanes_p) {
             const int p = p0 + pi;
@@ -269,6 +322,7 @@ __global__ void __launch_bounds__(256) wgrad_thin_kernel(ConvArgs a, const T* __
                 }
             }
         }
+#undef WTHIN_PIXEL
     }
 #pragma unroll
     for (int g = 0; g < 3; ++g) {

@@ -103,6 +103,32 @@ def test_forward_route_switch_vs_default_route_and_reference(fwd_case, env, note
     assert e_ab <= 1.0e-2    # two bf16 evaluations of one network (other tile shapes / summation orders), or identical bits
 
 
+def test_ws128_on_32x32_maps_at_batch_32(golden):
+    """the 128-pixel tiles of the persistent kernel on the 32x32 maps (4 x 32 pixels, 204 halo rows in 7 units - another geometry than
+    the 8 x 16 tiles the batch-128 case above reaches): batch 32 with and without them, against each other and the golden rows"""
+    import dmme_amd
+
+    g = golden("unet_full")
+    sd = O.make_state_dict(O.UNetConfig(), int(g["full_seed"]))
+    x = synth.normal(int(g["full_xseed"]), (2, 3, 32, 32)).repeat(16, 1, 1, 1).cuda()
+    t = torch.from_numpy(g["full_t_one"]).cuda()
+    ref = torch.from_numpy(g["full_y_one"])
+    ys = []
+    for env in ({}, {"DMME_NO_WS128": "1"}):
+        with _env(env):
+            net = dmme_amd.UNet(precision="bf16")
+            net.load_state_dict(sd, strict=True)
+            net = net.cuda().eval()
+            with torch.no_grad():
+                y = net(x, t).float().cpu()
+        rows = y.reshape(16, 2, 3, 32, 32)
+        assert torch.equal(rows, rows[:1].expand_as(rows))
+        assert float((rows[0] - ref).abs().max()) <= 1.7e-2 and float((rows[0] - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()) <= 1.0e-2
+        ys.append(y)
+    e_ab = float((ys[0] - ys[1]).pow(2).mean().sqrt() / ys[1].pow(2).mean().sqrt())
+    assert 0.0 < e_ab <= 1.0e-2, e_ab  # (> 0: the switch did select another kernel for the 32x32 layers)
+
+
 @pytest.fixture(scope="module")
 def bwd_case():
     import dmme_amd

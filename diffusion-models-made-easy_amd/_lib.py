@@ -85,6 +85,7 @@ PROTOTYPES = {
     "dmme_unet_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "dmme_unet_plan_num_ops": (_i, [_vp]),
     "dmme_unet_plan_level_info": (_i, [_vp, C.c_char_p, _i]),
+    "dmme_unet_plan_check": (_i, [_vp]),
     "dmme_debug_level_stamps": (_i, [_vp, _i, _i]),
     "dmme_unet_plan_op_info": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dmme_unet_forward_profiled": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),

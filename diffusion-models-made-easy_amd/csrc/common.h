@@ -10,6 +10,10 @@ namespace dmme {
 
 void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 
+// Experiment / test-only switches live behind ONE environment variable: DMME_DEBUG_ROUTE="key[=int],key[=int],..." (a bare key
+// reads as 1).  Returns `dflt` when the key is absent.  The product's own A/B switches keep their DMME_NO_* names.
+int debug_route(const char* key, int dflt = 0);
+
 #define DMME_CHECK_HIP(expr)                                                                          \
     do {                                                                                              \
         hipError_t e_ = (expr);                                                                       \

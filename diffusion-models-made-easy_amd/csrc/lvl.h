@@ -73,11 +73,19 @@ struct LvlArgs {
     int NJ;                   // 32-cout blocks per cout slice: 1 (8 slices per group) or 2 (4 slices of 64 couts; GB = 2 only)
     unsigned* flags;          // [n_ops * 2][NG][LVL_NS]
     unsigned* ctl;            // [0] epoch of the last completed launch, [1] workgroups of this launch that are done, [2] error word
+    unsigned* err_sys;        // the plan's host-visible status word (pinned host memory; null: none): set to run_tag by a wait that timed out
+    int run_tag;              // 1 + index of this run in the plan
+    int spin_limit;           // polls before a hand-off wait gives up (0: LVL_SPIN_LIMIT, ~a second); DMME_DEBUG_ROUTE lvl_spin=
+    int withhold;             // test knob (DMME_DEBUG_ROUTE lvl_withhold=K): workgroup 0 stops signalling from the run's K-th launch on, so its consumers time out
+    int max_wg;               // workgroups the device can hold at once (all of a launch must be co-resident)
     long long* stamps;        // diagnostic (null: off): 100 MHz wall-clock stamps of workgroup `stamp_wg`, [op iteration][8] (dmme_debug_set_stamps)
     int stamp_wg;
 };
 
 int launch_lvl_engine(int dtype, const LvlArgs& a, hipStream_t s);
+// how many workgroups of the engine kernel the device `device` holds at once (compute units x workgroups per unit at the kernel's
+// LDS / register footprint), capped at LVL_MAX_WG; -1 on a HIP error (message set)
+int lvl_engine_max_resident(int dtype, int device);
 size_t lvl_engine_lds_bytes();
 
 }  // namespace dmme

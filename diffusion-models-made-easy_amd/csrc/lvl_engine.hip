@@ -85,16 +85,28 @@ __device__ __forceinline__ unsigned lvl_flag_load(const unsigned* p) { return __
 __device__ __forceinline__ void lvl_flag_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // This WAVE waits until the `ns` flag words of row `f` (one per cout slice) carry this launch's epoch.  Lanes 0-7 poll (sc1 loads), the vote is
-// wave-wide; bounded: after LVL_SPIN_LIMIT polls the error word is set and the wave goes on.
-__device__ __forceinline__ void lvl_wait_row(const unsigned* f, int ns, unsigned epoch, int lane, unsigned* err) {
+// wave-wide; bounded: after `limit` polls (LvlArgs::spin_limit, ~a second by default) the wave gives up, sets the launch's error word
+// (ctl[2]: every other wait of the launch ends within 1024 polls) AND the plan's host-visible status word (LvlArgs::err_sys, a
+// system-scope store into pinned host memory): the launch drains with wrong numbers instead of hanging, and the host side refuses
+// to hand those numbers on (plan.hip: lvl_check - every entry point and dmme_unet_plan_check read that word).
+struct LvlWaitCtx {
+    unsigned* err;      // ctl[2]
+    unsigned* err_sys;  // host-visible (nullable)
+    int limit;
+    unsigned tag;       // what the host reads: 1 + index of the run
+};
+__device__ __forceinline__ void lvl_wait_row(const unsigned* f, int ns, unsigned epoch, int lane, const LvlWaitCtx& c) {
     for (int spin = 0;; ++spin) {
         const unsigned v = lane < ns ? lvl_flag_load(f + lane) : epoch;
         if (__all(v == epoch)) return;
         if ((spin & 1023) == 1023) {  // a wait that timed out anywhere ends every other wait too: the launch drains in milliseconds
-            const unsigned e = lvl_flag_load(err);
+            const unsigned e = lvl_flag_load(c.err);
             if (e != 0u) return;
-            if (spin >= LVL_SPIN_LIMIT) {
-                if (lane == 0) lvl_flag_store(err, 1u);
+            if (spin >= c.limit) {
+                if (lane == 0) {
+                    lvl_flag_store(c.err, 1u);
+                    if (c.err_sys) __hip_atomic_store(c.err_sys, c.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
                 return;
             }
         }
@@ -155,7 +167,9 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
     T* keep = reinterpret_cast<T*>(lds + LVL_KEEP_OFF);
     float* blk = reinterpret_cast<float*>(lds + LVL_BLK_OFF);
     const unsigned epoch = lvl_flag_load(&A.ctl[0]) + 1u;  // (the counter moves only after EVERY workgroup of a launch has finished)
-    unsigned* const err = &A.ctl[2];
+    const LvlWaitCtx err{&A.ctl[2], A.err_sys, A.spin_limit > 0 ? A.spin_limit : LVL_SPIN_LIMIT, (unsigned)A.run_tag};
+    // debug knob (tests/test_gpu_level.py): workgroup 0 stops signalling - its consumers time out and the error must reach the caller
+    const bool withhold = A.withhold > 0 && epoch >= (unsigned)A.withhold && blockIdx.x == 0;  // (from the launch with this epoch on)
     {   // the op table is read through the scalar cache, one op at a time, and every first touch of a line is a round trip to L2 or
         // beyond on the critical path of its op: touch every line now (independent scalar loads, one latency for all of them)
         const int* w = reinterpret_cast<const int*>(ops);
@@ -616,7 +630,7 @@ _Pragma("unroll") \
                        make_uint4(__float_as_uint(ps[0]), __float_as_uint(ps[1]), __float_as_uint(ps[2]), __float_as_uint(ps[3])));
                 wait_vm_all();
                 __syncthreads();
-                if (tid == 0) lvl_flag_store(A.flags + ((int64_t)(oi * 2 + 1) * A.NG + g) * LVL_NS + s, epoch);
+                if (tid == 0 && !withhold) lvl_flag_store(A.flags + ((int64_t)(oi * 2 + 1) * A.NG + g) * LVL_NS + s, epoch);
                 lvl_wait_row(A.flags + ((int64_t)(oi * 2 + 1) * A.NG + g) * LVL_NS, NS, epoch, lane, err);
                 lvl_compiler_fence();
                 uint4 part[LVL_NS];
@@ -781,7 +795,7 @@ _Pragma("unroll") \
             }
             __syncthreads();
             LV_STAMP(5);
-            if (op.signal && tid < GB && bt * GB + tid < A.NG) lvl_flag_store(A.flags + ((int64_t)(oi * 2) * A.NG + bt * GB + tid) * LVL_NS + s, epoch);
+            if (op.signal && !withhold && tid < GB && bt * GB + tid < A.NG) lvl_flag_store(A.flags + ((int64_t)(oi * 2) * A.NG + bt * GB + tid) * LVL_NS + s, epoch);
             if (next_conv && !early) prime(ops[oj]);
             LV_STAMP(6);
             ++stamp_it;
@@ -799,22 +813,61 @@ _Pragma("unroll") \
 }
 
 template <typename T, int GB, int NJ>
-static int launch_lvl_inst(const LvlArgs& a, hipStream_t s) {
+static int lvl_inst_setup() {
     static bool attr_done = false;
     if (!attr_done) {
         DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lvl_engine_kernel<T, GB, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
+    return DMME_OK;
+}
+
+template <typename T, int GB, int NJ>
+static int launch_lvl_inst(const LvlArgs& a, hipStream_t s) {
+    const int rc = lvl_inst_setup<T, GB, NJ>();
+    if (rc != DMME_OK) return rc;
     hipLaunchKernelGGL((lvl_engine_kernel<T, GB, NJ>), dim3((unsigned)(a.NGS * (LVL_NS / NJ))), dim3(256), LVL_LDS, s, a, a.ops);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }
 
+// The hand-offs spin: every workgroup of a launch must be resident at the same time.  The plan sizes its grids by this figure
+// (assign_levels) and falls back to per-op launches when a level does not fit.
+template <typename T>
+static int lvl_max_resident_t(int device) {
+    int cus = 0, per = 0, worst = 1 << 30;
+    DMME_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    int rc;
+    if ((rc = lvl_inst_setup<T, 1, 1>()) != DMME_OK || (rc = lvl_inst_setup<T, 2, 1>()) != DMME_OK || (rc = lvl_inst_setup<T, 2, 2>()) != DMME_OK) return -1;
+    DMME_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, lvl_engine_kernel<T, 1, 1>, 256, LVL_LDS));
+    worst = per < worst ? per : worst;
+    DMME_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, lvl_engine_kernel<T, 2, 1>, 256, LVL_LDS));
+    worst = per < worst ? per : worst;
+    DMME_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, lvl_engine_kernel<T, 2, 2>, 256, LVL_LDS));
+    worst = per < worst ? per : worst;
+    const int64_t n = (int64_t)cus * worst;
+    return (int)(n < LVL_MAX_WG ? n : LVL_MAX_WG);
+}
+
+int lvl_engine_max_resident(int dtype, int device) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != device) {
+        if (hipSetDevice(device) != hipSuccess) {
+            set_error("level engine: cannot select device %d", device);
+            return -1;
+        }
+    }
+    const int n = dtype == DMME_F16 ? lvl_max_resident_t<f16>(device) : lvl_max_resident_t<bf16>(device);
+    if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
+    return n < 0 ? -1 : n;
+}
+
 int launch_lvl_engine(int dtype, const LvlArgs& a, hipStream_t s) {
     DMME_REQUIRE(dtype == DMME_BF16 || dtype == DMME_F16, DMME_ERR_UNSUPPORTED, "level engine: 16-bit operand types only");
-    DMME_REQUIRE(a.NGS >= 1 && (a.NJ == 1 || (a.NJ == 2 && a.GB == 2)) && a.NGS * (LVL_NS / a.NJ) <= LVL_MAX_WG && a.NG >= 1 && (a.sh == 2 || a.sh == 3) &&
+    const int max_wg = a.max_wg > 0 && a.max_wg < LVL_MAX_WG ? a.max_wg : LVL_MAX_WG;
+    DMME_REQUIRE(a.NGS >= 1 && (a.NJ == 1 || (a.NJ == 2 && a.GB == 2)) && a.NGS * (LVL_NS / a.NJ) <= max_wg && a.NG >= 1 && (a.sh == 2 || a.sh == 3) &&
                      (a.GB == 1 || a.GB == 2),
-                 DMME_ERR_INVALID, "level engine: bad geometry");
+                 DMME_ERR_INVALID, "level engine: bad geometry (grid %d, device holds %d workgroups)", a.NGS * (LVL_NS / a.NJ), max_wg);
     if (dtype == DMME_F16) return a.NJ == 2 ? launch_lvl_inst<f16, 2, 2>(a, s) : a.GB == 2 ? launch_lvl_inst<f16, 2, 1>(a, s) : launch_lvl_inst<f16, 1, 1>(a, s);
     return a.NJ == 2 ? launch_lvl_inst<bf16, 2, 2>(a, s) : a.GB == 2 ? launch_lvl_inst<bf16, 2, 1>(a, s) : launch_lvl_inst<bf16, 1, 1>(a, s);
 }

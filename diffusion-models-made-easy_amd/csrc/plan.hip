@@ -23,6 +23,20 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+int debug_route(const char* key, int dflt) {
+    const char* e = getenv("DMME_DEBUG_ROUTE");
+    if (!e || !*e) return dflt;
+    const size_t kl = strlen(key);
+    for (const char* p = e; *p;) {
+        const char* end = strchr(p, ',');
+        const size_t len = end ? (size_t)(end - p) : strlen(p);
+        if (len >= kl && !strncmp(p, key, kl) && (len == kl || p[kl] == '=')) return len == kl ? 1 : atoi(p + kl + 1);
+        if (!end) break;
+        p = end + 1;
+    }
+    return dflt;
+}
+
 static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 struct Param {
@@ -172,6 +186,11 @@ struct dmme_plan {
     ColJob* col_jobs_dev = nullptr;
     int col_split = 0;                // col_jobs[col_split:] belong to bucket 0
     std::vector<LvlRun> lvl_runs;     // level-engine launches (small maps)
+    // every workgroup of an engine launch must be resident at once: grids are sized by what the device holds (assign_levels)
+    int lvl_max_wg = LVL_MAX_WG;
+    // host-visible status word of the engine's bounded hand-off waits (pinned, device-mapped; null: no engine run in this plan):
+    // non-zero = 1 + index of a run in which a wait timed out, i.e. the outputs since are invalid (lvl_check)
+    unsigned* err_host = nullptr;
 };
 
 namespace {
@@ -1237,6 +1256,16 @@ static bool build_lvl_run(dmme_plan* P, int i0, int i1, int lvl_w, int64_t& ws, 
 void assign_levels(dmme_plan* P) {
     if (getenv("DMME_NO_LVL") || P->cfg.arch != DMME_ARCH_DDPM || P->x3 || (P->dtype != DMME_BF16 && P->dtype != DMME_F16)) return;
     const int mask = getenv("DMME_LVL_MASK") ? atoi(getenv("DMME_LVL_MASK")) : 12;  // bit 2: 4x4 maps, bit 3: 8x8 maps
+    // The engine's hand-offs spin, so a launch only works if ALL its workgroups are resident together: size the grids by what THIS
+    // device holds (compute units x workgroups per unit at the kernel's 150 KB of LDS), not by a constant; a level that needs more
+    // than two iterations per workgroup at that size keeps its per-op launches (below).  (lvl_max_wg=: test knob, a smaller device.)
+    if (P->device >= 0) {
+        const int n = lvl_engine_max_resident(P->dtype, P->device);
+        if (n < LVL_NS) return;  // (also a HIP error: no engine, the per-op kernels run)
+        P->lvl_max_wg = n;
+    }
+    if (debug_route("lvl_max_wg", 0) > 0) P->lvl_max_wg = std::min(P->lvl_max_wg, debug_route("lvl_max_wg", 0));
+    if (P->lvl_max_wg < LVL_NS) return;
     const int nO = (int)P->ops.size();
     std::unordered_map<int, std::pair<int, int>> made;  // tensor id -> (run, op) of the engine op that holds its slices
     int i = 0;
@@ -1262,7 +1291,7 @@ void assign_levels(dmme_plan* P) {
                 // the attention block keeps q / k / v of ONE group in LDS
                 bool has_attn = false;
                 for (const LvlOp& lo : R.ops) has_attn = has_attn || lo.kind == LVL_ATTN;
-                int slots = LVL_MAX_WG / LVL_NS;
+                int slots = P->lvl_max_wg / LVL_NS;
                 R.GB = (R.NG > slots && !has_attn && !getenv("DMME_LVL_GB1")) ? 2 : 1;
                 const int nb = (R.NG + R.GB - 1) / R.GB;
                 // still more than one iteration per workgroup: 64-cout slices (4 per group) - half the iterations, the input gathered
@@ -1560,6 +1589,11 @@ int run_level(const dmme_plan* P, const LvlRun& R, const char* pk, char* ws, int
     a.NJ = R.NJ;
     a.ctl = R.sync_dev;
     a.flags = R.sync_dev + 16;
+    a.err_sys = P->err_host;
+    a.run_tag = 1 + (int)(&R - P->lvl_runs.data());
+    a.spin_limit = debug_route("lvl_spin", 0);
+    a.withhold = debug_route("lvl_withhold", 0);
+    a.max_wg = P->lvl_max_wg;
     if (g_lvl_stamps && g_lvl_stamp_run == (int)(&R - P->lvl_runs.data())) {
         a.stamps = g_lvl_stamps;
         a.stamp_wg = g_lvl_stamp_wg;
@@ -1877,6 +1911,10 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
             if (e == hipSuccess) e = hipMalloc((void**)&G->jobs_dev, G->jobs.size() * sizeof(WgJob));
             if (e == hipSuccess) e = hipMemcpy(G->jobs_dev, G->jobs.data(), G->jobs.size() * sizeof(WgJob), hipMemcpyHostToDevice);
         }
+        if (!P->lvl_runs.empty()) {
+            if (e == hipSuccess) e = hipHostMalloc((void**)&P->err_host, 64, hipHostMallocMapped | hipHostMallocCoherent);
+            if (e == hipSuccess) memset(P->err_host, 0, 64);
+        }
         for (LvlRun& R : P->lvl_runs) {
             const size_t words = 16 + R.ops.size() * 2 * (size_t)R.NG * LVL_NS;
             if (e == hipSuccess) e = hipMalloc((void**)&R.ops_dev, R.ops.size() * sizeof(LvlOp));
@@ -1914,6 +1952,7 @@ DMME_API void dmme_unet_plan_destroy(dmme_plan* plan) {
     if (plan->tp_tiles_dev) (void)hipFree(plan->tp_tiles_dev);
     if (plan->bias_jobs_dev) (void)hipFree(plan->bias_jobs_dev);
     if (plan->col_jobs_dev) (void)hipFree(plan->col_jobs_dev);
+    if (plan->err_host) (void)hipHostFree(plan->err_host);
     for (LvlRun& R : plan->lvl_runs) {
         if (R.ops_dev) (void)hipFree(R.ops_dev);
         if (R.sync_dev) (void)hipFree(R.sync_dev);
@@ -1952,11 +1991,48 @@ DMME_API int dmme_unet_pack_params(const dmme_plan* plan, const float* ref_flat,
     return launch_pack_table(plan->dtype, plan->items_dev, plan->n_items, ref_flat, packed, (hipStream_t)stream);
 }
 
+// The level engine's hand-off waits are bounded: a wait that gives up (a workgroup that was never scheduled - fewer free compute
+// units than the launch needs - or a fault) lets the launch drain with WRONG numbers and raises the plan's host-visible status word.
+// Every entry point that enqueues work on the plan looks at that word first, and dmme_unet_plan_check is the call for hosts that
+// replay a captured graph (no entry point runs then): no path hands results on with rc 0 once the word is set.
+static int lvl_check(const dmme_plan* P, const char* where, hipStream_t stream = nullptr, bool have_stream = false) {
+    if (!P->err_host) return DMME_OK;
+    const unsigned v = __atomic_load_n(P->err_host, __ATOMIC_ACQUIRE);
+    if (!v) return DMME_OK;
+    // clear: the device-side sticky words (a set word makes every later wait of that run give up after 1024 polls) and the host word
+    // - unless the caller's stream is being captured (synchronising calls would invalidate the capture; the word stays set and the
+    // next check outside a capture clears it)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (have_stream && hipStreamIsCapturing(stream, &cs) != hipSuccess) cs = hipStreamCaptureStatusNone;
+    if (cs == hipStreamCaptureStatusNone) {
+        (void)hipDeviceSynchronize();
+        for (const LvlRun& R : P->lvl_runs)
+            if (R.sync_dev) (void)hipMemset(R.sync_dev + 2, 0, 4);
+        __atomic_store_n(P->err_host, 0u, __ATOMIC_RELEASE);
+    }
+    const int ri = (int)v - 1;
+    const LvlRun* R = ri >= 0 && ri < (int)P->lvl_runs.size() ? &P->lvl_runs[ri] : nullptr;
+    set_error("%s: a hand-off wait of the level engine timed out (run %d, %dx%d maps, %d workgroups that must all be resident at once; the device "
+              "holds %d): every output of this plan since the last check is invalid.  Typical cause: compute units held by another stream / "
+              "process / CU mask.  DMME_NO_LVL=1 selects the per-op kernels.",
+              where, ri, R ? 1 << R->sh : 0, R ? 1 << R->sh : 0, R ? R->NGS * (LVL_NS / R->NJ) : 0, P->lvl_max_wg);
+    return DMME_ERR_HIP;
+}
+
+DMME_API int dmme_unet_plan_check(const dmme_plan* plan) {
+    DMME_REQUIRE(plan, DMME_ERR_INVALID, "plan_check: null plan");
+    return lvl_check(plan, "plan_check");
+}
+
 DMME_API int dmme_unet_forward(const dmme_plan* plan, const void* packed, const float* x, const int64_t* t, int t_len,
                       float* y, void* workspace, const float* drop_masks, void* stream) {
     DMME_REQUIRE(plan && packed && x && t && y && workspace, DMME_ERR_INVALID, "unet_forward: null argument");
     DMME_REQUIRE(t_len == 1 || t_len == plan->B, DMME_ERR_INVALID,
                  "unet_forward: timestep tensor of length %d does not broadcast against batch %d", t_len, plan->B);
+    {
+        const int rc = lvl_check(plan, "unet_forward", (hipStream_t)stream, true);
+        if (rc != DMME_OK) return rc;
+    }
     hipStream_t s = (hipStream_t)stream;
     const dmme_plan* P = plan;
     const char* pk = (const char*)packed;
@@ -2002,6 +2078,7 @@ DMME_API int dmme_unet_forward_profiled(const dmme_plan* plan, const void* packe
                                         float* op_ms) {
     DMME_REQUIRE(plan && packed && x && t && y && workspace && op_ms, DMME_ERR_INVALID, "forward_profiled: null argument");
     DMME_REQUIRE(t_len == 1 || t_len == plan->B, DMME_ERR_INVALID, "forward_profiled: bad t_len %d", t_len);
+    if (int rc0 = lvl_check(plan, "forward_profiled", (hipStream_t)stream, true)) return rc0;
     hipStream_t s = (hipStream_t)stream;
     const size_t n = plan->ops.size();
     std::vector<hipEvent_t> ev(n + 1);
@@ -2036,6 +2113,7 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
     DMME_REQUIRE(plan && packed && packed_bwd && x && t && d_y && workspace && bwd_workspace && grad_flat, DMME_ERR_INVALID,
                  "unet_backward: null argument");
     DMME_REQUIRE(t_len == 1 || t_len == plan->B, DMME_ERR_INVALID, "unet_backward: bad t_len %d", t_len);
+    if (int rc0 = lvl_check(plan, "unet_backward", (hipStream_t)stream, true)) return rc0;  // (the forward this backward differentiates ran through the engine)
     DMME_REQUIRE(plan->dtype != DMME_F16, DMME_ERR_UNSUPPORTED,
                  "unet_backward: precision fp16 is an inference mode (no loss scaling in the HIP backward); train in bf16, bf16x3 or fp32");
     const dmme_plan* P = plan;
@@ -2502,6 +2580,7 @@ DMME_API int dmme_chain_update(int kind, float* x, const float* model_out, const
 DMME_API int dmme_chain_step(const dmme_plan* plan, const void* packed, float* x, float* model_out, void* workspace, int kind,
                              const float* step_coef, const int64_t* t_table, void* state, void* stream) {
     DMME_REQUIRE(plan && packed && x && model_out && workspace && step_coef && t_table && state, DMME_ERR_INVALID, "chain_step: null argument");
+    if (int rc0 = lvl_check(plan, "chain_step", (hipStream_t)stream, true)) return rc0;
     DMME_REQUIRE((kind == DMME_CHAIN_IDDPM) == (plan->out_channels == 2 * plan->cfg.in_channels), DMME_ERR_INVALID,
                  "chain_step: sampler kind %d does not fit a network with %d output channels", kind, plan->out_channels);
     // the timestep the network is evaluated at is the second word of the device-resident loop state

@@ -74,6 +74,7 @@ class ChainRunner:
             saved_x, saved_state = self.x.clone(), self.state.clone()
             self._launch(packed)
             torch.cuda.synchronize()
+            self.plan.check()  # (outside the capture: a level-engine timeout in the trial step is a real error, raised here)
             self.x.copy_(saved_x)
             self.state.copy_(saved_state)
             try:
@@ -103,6 +104,11 @@ class ChainRunner:
         self.set(first, seed, off)
         for _ in range(count):
             self.step()
+        # replayed graphs do not pass through the C entry points that look at the level engine's status word: one synchronisation
+        # per chain (the caller reads the images next anyway), then the check - a chain never returns numbers from a launch that
+        # gave up on a hand-off (DmmeError instead)
+        torch.cuda.current_stream(self.x.device).synchronize()
+        self.plan.check()
         return self.x
 
 
@@ -186,7 +192,10 @@ class DDPM(nn.Module):
         runner.set(index, seed, off)
         with torch.no_grad():
             runner.step()
-        return buf.clone()
+        out = buf.clone()
+        # (per-step callers: the status word is read on entry of the NEXT step's C calls - dmme_chain_step when eager - and by
+        # `model.check_engine()`; a synchronisation per step here would cost the small-batch loop its overlap)
+        return out
 
     # ------------------------------------------------------------------ training
     def training_step(self, x_0: Tensor, t: Optional[Tensor] = None, noise: Optional[Tensor] = None) -> Tensor:

@@ -64,6 +64,12 @@ class _Plan:
             out.append((name.value.decode(), tuple(int(shape[k]) for k in range(ndim.value)), int(off.value), bool(isb.value)))
         return out
 
+    def check(self):
+        """raise DmmeError if a level-engine hand-off wait timed out in any launch of this plan since the last check (the outputs
+        since are invalid; include/dmme_hip.h: dmme_unet_plan_check).  Call after synchronising with the stream: the entry points
+        of the C ABI look at the same word themselves, a replayed hipGraph does not pass through them."""
+        _lib.check(self.lib.dmme_unet_plan_check(self.h), "dmme_unet_plan_check")
+
     def __del__(self):
         try:
             if getattr(self, "h", None):
@@ -445,16 +451,22 @@ class UNet(nn.Module):
                     graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph):
                         y = self._forward_impl(x_static, t_static)
-                g = (key, graph, y)
+                g = (key, graph, y, self._last_plan)  # the plan whose workspace the replays overwrite
                 self._graph = g
             except Exception:  # noqa: BLE001 - capture not possible here: stay eager
                 self._graph_disabled = True
                 self._graph = None
                 return self._forward_impl(x_static, t_static)
         g[1].replay()
-        plan = self._last_plan  # the replay overwrote that plan's workspace: a pending backward of the same shape must refuse
+        plan = g[3]  # the replay overwrote THAT plan's workspace (not whichever plan ran last): its pending backward must refuse
         plan.fwd_gen = getattr(plan, "fwd_gen", 0) + 1
         return g[2]
+
+    def check_engine(self):
+        """synchronise and raise DmmeError if any level-engine launch of this module's plans gave up on a hand-off (results invalid)"""
+        torch.cuda.synchronize()
+        for plan in self._plans.values():
+            plan.check()
 
     def debug_activation(self, name: str) -> Tensor:
         """fp32 NCHW copy of the output of module `name` from the last forward (parity tests)."""

@@ -88,6 +88,8 @@ def fit(module, batch_size=128, max_steps=100, clip=None, log_every=50, loader=N
         loss = train_step(module, opt, sched, x0, clip)
         if (step + 1) % log_every == 0 or step + 1 == max_steps:
             torch.cuda.synchronize()
+            if hasattr(model, "check_engine"):
+                model.check_engine()  # a level-engine hand-off that timed out since the last log line: stop, do not train on it
             dt = time.perf_counter() - t0
             print(json.dumps({"step": step + 1, "train/loss": round(float(loss.detach()), 5), "images_per_s": round((step + 1 - first) * batch_size / dt, 1)}), flush=True)
     if save_path and D.env_rank_world()[0] == 0:

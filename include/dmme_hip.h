@@ -135,6 +135,15 @@ DMME_API int dmme_unet_plan_num_ops(const dmme_plan* plan);
  * engine_ops=.. groups=.. per_iteration=.. workgroups=.. epoch=.. err=..] ...".  err != 0: a bounded in-kernel wait timed out (results of
  * that launch are invalid).  Synchronises with the device (reads the control words). */
 DMME_API int dmme_unet_plan_level_info(const dmme_plan* plan, char* buf, int cap);
+/* Status of the level engine's bounded hand-off waits.  The engine's workgroups exchange tensors through spin-waits, so all of a
+ * launch must be resident at once (the plan sizes its grids by what the device holds and keeps per-op launches otherwise); a wait
+ * that still times out - compute units held by another stream, process or CU mask - lets the launch drain with invalid numbers and
+ * raises a host-visible status word.  dmme_unet_forward / _forward_profiled / _backward / dmme_chain_step look at that word on
+ * entry and fail with DMME_ERR_HIP (clearing it); this call is for hosts that REPLAY a captured graph of those launches (no entry
+ * point runs then): call it after synchronising with the stream, before using the results.  DMME_OK: every engine launch of this
+ * plan completed since the last check.  (Own invariant of the MI355X path; the reference's loop it guards:
+ * src/dmme/diffusion_models/ddpm.py:113-133.) */
+DMME_API int dmme_unet_plan_check(const dmme_plan* plan);
 DMME_API int dmme_unet_plan_op_info(const dmme_plan* plan, int index, char* label, int label_cap, double* flops,
                            double* bytes);
 DMME_API int dmme_unet_forward_profiled(const dmme_plan* plan, const void* packed, const float* x, const int64_t* t,

@@ -45,11 +45,12 @@ class _env:
         os.environ.pop("DMME_NO_LVL", None)
 
 
-def _info(net):
+def _info(net, plan=None):
     from dmme_amd import _lib
 
+    plan = plan or net._last_plan
     buf = C.create_string_buffer(2048)
-    _lib.check(net._last_plan.lib.dmme_unet_plan_level_info(net._last_plan.h, buf, 2048), "level_info")
+    _lib.check(plan.lib.dmme_unet_plan_level_info(plan.h, buf, 2048), "level_info")
     return buf.value.decode()
 
 
@@ -156,3 +157,145 @@ def test_level_engine_fp32_and_other_geometries_keep_their_launches():
     with torch.no_grad():
         inet(torch.zeros(2, 3, 32, 32, device="cuda"), torch.tensor([5]).cuda())
     assert _info(inet).startswith("runs=0")
+
+
+class _route:
+    """DMME_DEBUG_ROUTE for the duration of a block (read per launch / per plan by the library)"""
+
+    def __init__(self, value):
+        self.value = value
+
+    def __enter__(self):
+        os.environ["DMME_DEBUG_ROUTE"] = self.value
+
+    def __exit__(self, *a):
+        os.environ.pop("DMME_DEBUG_ROUTE", None)
+
+
+class _hold_cus:
+    """keeps `blocks` compute units' LDS (64 KB each: the engine's 150 KB workgroup cannot share such a unit) busy for ~`ms` on a side
+    stream: the LDS-DMA streaming loop of dmme_debug_l2_stream, calibrated on this box"""
+
+    def __init__(self, blocks, ms):
+        from dmme_amd import _lib
+
+        self.lib, self._lib = _lib.lib(), _lib
+        self.buf = torch.randint(0, 2**31 - 1, (1 << 18,), dtype=torch.int32, device="cuda")  # 1 MiB
+        self.sink = torch.zeros(4096, dtype=torch.int32, device="cuda")
+        self.blocks = blocks
+        self.side = torch.cuda.Stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self._go(100, torch.cuda.current_stream())
+        e0.record()
+        self._go(100, torch.cuda.current_stream())
+        e1.record()
+        torch.cuda.synchronize()
+        self.iters = max(100, int(100 * ms / max(e0.elapsed_time(e1), 1e-3)))
+
+    def _go(self, iters, stream):
+        self._lib.check(self.lib.dmme_debug_l2_stream(self._lib.ptr(self.buf), 1 << 20, iters, 1, 16, self.blocks, self._lib.ptr(self.sink), C.c_void_p(stream.cuda_stream)), "l2_stream")
+
+    def start(self):
+        torch.cuda.synchronize()
+        self._go(self.iters, self.side)
+
+
+def test_level_engine_timeout_reaches_the_caller_and_the_plan_recovers(golden):
+    """the engine's hand-off waits are bounded; a wait that gives up must never end as rc 0 with wrong numbers.  Provoked (a) with the
+    test knob `lvl_withhold` (workgroup 0 never signals) and a short spin limit: the explicit check, the eager forward's NEXT entry
+    into the library, `generate`'s trial step and `backward` all raise DmmeError, and afterwards the same plan produces the bits it
+    produced before (the sticky device-side words are cleared with the host word); (b) through a REPLAYED graph (no entry point of the library between the replays; the knob starts at a later launch so that
+    the capture itself is clean): `generate` raises instead of returning the images."""
+    import dmme_amd
+    from dmme_amd._lib import DmmeError
+
+    g = golden("unet_full")
+    net = _net(int(g["full_seed"]), "bf16", True)
+    x = synth.normal(3, (8, 3, 32, 32)).cuda()
+    t = torch.tensor([77]).cuda()
+    y0, _ = _forward(net, x, t)
+    net.check_engine()  # clean
+    with _route("lvl_withhold,lvl_spin=2048"):
+        _forward(net, x, t)  # enqueued fine; its engine launches give up after ~2048 polls and drain
+        with pytest.raises(DmmeError, match="hand-off"):
+            net.check_engine()
+    y1, _ = _forward(net, x, t)  # the check cleared the device-side words: same bits as before
+    net.check_engine()
+    assert torch.equal(y1, y0)
+    # the next ENTRY POINT refuses as well (no explicit check in between)
+    with _route("lvl_withhold,lvl_spin=2048"):
+        _forward(net, x, t)
+    torch.cuda.synchronize()
+    with pytest.raises(DmmeError, match="hand-off"):
+        _forward(net, x, t)
+    y2, _ = _forward(net, x, t)
+    assert torch.equal(y2, y0)
+    # generate: the eager trial step in front of the capture times out -> raised there, outside the capture
+    ddpm = dmme_amd.DDPM(net, 20).cuda()
+    with _env(True), _route("lvl_withhold,lvl_spin=2048"):
+        with pytest.raises(DmmeError, match="hand-off"):
+            ddpm.generate((8, 3, 32, 32))
+    # training: the forward of a step times out -> the backward's entry refuses
+    net.train()
+    with _env(True):
+        xg = torch.randn(8, 3, 32, 32, device="cuda")
+        with _route("lvl_withhold,lvl_spin=2048"):
+            loss = (net(xg, t).float() ** 2).mean()
+        torch.cuda.synchronize()
+        with pytest.raises(DmmeError, match="hand-off"):
+            loss.backward()
+    net.eval()
+    # (b) replayed graph: the knob starts at the run's 20th launch - the trial step, the capture and the first chain (epochs 1-13)
+    # are clean, the second chain's replays (no library entry point between them) run into it
+    with _env(True), _route("lvl_withhold=20,lvl_spin=2048"):
+        ddpm2 = dmme_amd.DDPM(net, 12).cuda()
+        torch.manual_seed(1)
+        a = ddpm2.generate((32, 3, 32, 32))
+        assert torch.isfinite(a).all() and ddpm2._runner.graph is not None
+        with pytest.raises(DmmeError, match="hand-off"):
+            ddpm2.generate((32, 3, 32, 32))
+    with _env(True):
+        ddpm3 = dmme_amd.DDPM(net, 12).cuda()  # a fresh capture without the knob, on the same plan: the first chain's images again
+        torch.manual_seed(1)
+        b = ddpm3.generate((32, 3, 32, 32))
+    assert torch.equal(a, b)
+
+
+def test_level_engine_sized_by_the_device_and_survives_busy_compute_units(golden):
+    """(i) grids follow what the device holds: with `lvl_max_wg=64` (a quarter of the chip) every run shrinks to <= 64 workgroups and
+    levels that would need more than two iterations per workgroup keep their per-op launches - same numbers either way;
+    (ii) with the default limit (~1 s) a second stream holding half the compute units for ~60 ms only delays the engine: its waiting
+    workgroups become resident as the other kernel's retire, no wait gives up, bits identical to the undisturbed run."""
+    import re
+
+    g = golden("unet_full")
+    seed = int(g["full_seed"])
+    x = synth.normal(3, (32, 3, 32, 32)).cuda()
+    t = torch.tensor([500]).cuda()
+    full = _net(seed, "bf16", True)
+    y_full, _ = _forward(full, x, t)
+    info_full = _info(full)
+    with _route("lvl_max_wg=64"):
+        small = _net(seed, "bf16", True)
+        y_small, _ = _forward(small, x, t)
+        info_small = _info(small)
+    small.check_engine()
+    print(f"device-sized grids: {info_full}\n  with 64 resident workgroups: {info_small}")
+    assert "workgroups=256" in info_full
+    for wg in re.findall(r"workgroups=(\d+)", info_small):
+        assert int(wg) <= 64, info_small
+    assert "err=1" not in info_small
+    ref = torch.from_numpy(g["full_y_one"])
+    xr = synth.normal(int(g["full_xseed"]), (2, 3, 32, 32)).repeat(16, 1, 1, 1).cuda()
+    tr = torch.from_numpy(g["full_t_one"]).cuda()
+    with _route("lvl_max_wg=64"):
+        y_ref, _ = _forward(small, xr, tr)
+    for i in range(4):
+        assert float((y_ref[i] - ref[i % 2]).abs().max()) <= 1.7e-2
+    # (ii)
+    for blocks in (128, 250):  # half the chip; all but a handful of units (fewer than one pixel group's eight slices can be resident)
+        hold = _hold_cus(blocks, 60.0)
+        hold.start()
+        y_busy, _ = _forward(full, x, t)
+        full.check_engine()  # synchronises (both streams) and reads the status word
+        assert torch.equal(y_busy, y_full), blocks

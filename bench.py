@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--reps", type=int, default=3, help="timed blocks of --steps steps each (value = the median block; min and all blocks are reported)")
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--mode", default="sample", choices=["sample", "ddim", "train", "cpu-plumbing"])
@@ -55,6 +56,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-accurate-leg", action="store_true", help="skip the short bf16x3 (accurate mode) and fp16 throughput legs")
+    ap.add_argument("--no-small-batch-leg", action="store_true", help="skip the batch-1 / batch-32 legs of the N = 1 line")
     ap.add_argument("--no-ddim-leg", action="store_true", help="skip the BASELINE configs[2] leg (DDIM 50 steps, batch 512) of the N = 1 line")
     ap.add_argument("--config", default=None, help="cpu-plumbing: the LightningCLI YAML to drive (default configs/ddpm/cifar10.yaml)")
     return ap.parse_args()
@@ -126,15 +128,26 @@ def roofline_leg(model, x, t_dev, precision):
         g["bytes"] += nbytes[i]
     order = sorted(groups.items(), key=lambda kv: -kv[1]["ms"])
     total_ms = sum(g["ms"] for _, g in order)
-    # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x clock) of the committed rocprofv3 --pmc pass of this workload (tools/prof.sh ->
-    # profiles/mfma_busy_latest.json); counters cannot be read from inside this process, so: that file or null
-    pmc_busy = {}
-    bpath = os.path.join(ROOT, "profiles", "mfma_busy_latest.json")
-    if os.path.exists(bpath) and x.shape[0] == 128 and x.shape[-1] == 32 and precision == "bf16":
+    # Counters cannot be read from inside this process: MFMA-busy and HBM-traffic figures are those of the committed rocprofv3 --pmc
+    # passes of this workload (tools/prof.sh -> profiles/*_latest.json) and are only handed on when that file was measured on THIS
+    # build - its recorded source hash equals the hash of the sources the loaded library was built from - else null, with the reason
+    here = _lib.csrc_sha16()
+
+    def profile_file(fname):
+        path = os.path.join(ROOT, "profiles", fname)
+        if not (os.path.exists(path) and x.shape[0] == 128 and x.shape[-1] == 32 and precision == "bf16"):
+            return None, "no committed counter pass for this workload"
         try:
-            pmc_busy = {k: v.get("mfma_busy_pct") for k, v in json.load(open(bpath)).items() if isinstance(v, dict)}
+            rec = json.load(open(path))
         except Exception:  # noqa: BLE001
-            pmc_busy = {}
+            return None, f"profiles/{fname}: unreadable"
+        meta = rec.get("_meta") or {}
+        if meta.get("csrc_sha16") != here:
+            return None, f"profiles/{fname} was measured on another build (sources {meta.get('csrc_sha16')}, loaded {here}): dropped"
+        return rec, f"file: profiles/{fname} ({meta.get('label')}; rocprofv3 --pmc passes of this workload on a builder box with this build, not this run)"
+
+    busy_rec, busy_source = profile_file("mfma_busy_latest.json")
+    pmc_busy = {k: v.get("mfma_busy_pct") for k, v in (busy_rec or {}).items() if isinstance(v, dict) and k != "_meta"}
     table = []
     for name, g in order[:8]:
         table.append({
@@ -145,21 +158,11 @@ def roofline_leg(model, x, t_dev, precision):
             # both roofs per kernel, so that an HBM-shaped kernel (1x1 convs, attention over a materialised qkv) is read against the right one
             "mfma_frac": round(g["flops"] / (g["ms"] * 1e-3) / 1e12 / PEAK.get(precision, 2500.0), 4) if g["ms"] > 0 else 0.0,
             "hbm_frac": round(g["bytes"] / (g["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if g["ms"] > 0 else 0.0,
-            "mfma_busy_pct": pmc_busy.get(name),
+            "mfma_busy_pct_from_profile": pmc_busy.get(name),
         })
     name, g = order[0]
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure is the committed
-    # rocprofv3 pass of this very configuration (tools/prof.sh -> profiles/traffic_latest.json), labelled as such, else null
-    traffic, traffic_source = None, None
-    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath) and x.shape[0] == 128 and x.shape[-1] == 32 and precision == "bf16":
-        try:
-            rec = json.load(open(tpath))
-            traffic = rec.get(name, {}).get("hbm_bytes_per_launch")
-            if traffic is not None:
-                traffic_source = "file: profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload on a builder box, not this run)"
-        except Exception:  # noqa: BLE001
-            traffic = None
+    traffic_rec, traffic_source = profile_file("traffic_latest.json")
+    traffic = (traffic_rec or {}).get(name, {}).get("hbm_bytes_per_launch")
     peak = PEAK.get(precision, 2500.0)
     if g["flops"] > 0:
         ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
@@ -167,7 +170,7 @@ def roofline_leg(model, x, t_dev, precision):
     else:
         ach = g["bytes"] / (g["ms"] * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
-    roof.update({"traffic": traffic, "traffic_source": traffic_source, "launches_per_step": g["count"], "avg_launch_us": round(1e3 * g["ms"] / g["count"], 2),
+    roof.update({"traffic": traffic, "traffic_source": traffic_source, "mfma_busy_source": busy_source, "csrc_sha16": here, "launches_per_step": g["count"], "avg_launch_us": round(1e3 * g["ms"] / g["count"], 2),
                  "algo_flops_per_launch": g["flops"] / g["count"], "algo_bytes_per_launch": g["bytes"] / g["count"],
                  "algo_gbs": round(g["bytes"] / (g["ms"] * 1e-3) / 1e9, 1), "step_gpu_ms_sum": round(total_ms, 3), "top_kernels": table})
     return roof
@@ -353,8 +356,9 @@ def allreduce_alone_ms(dist, dev, numel, reps=10):
     return 1e3 * _max_over_ranks(time.perf_counter() - t0, dist, dev) / reps
 
 
-def chain_leg(proc, runner, n_steps, warmup, steps, dist, dev):
-    """W untimed + K timed replays of the denoising step, loop index wrapping to the top of the chain when it runs out"""
+def chain_leg(proc, runner, n_steps, warmup, steps, dist, dev, reps=1):
+    """W untimed + `reps` x (K timed replays of the denoising step, each block bracketed by barrier + synchronize), loop index wrapping
+    to the top of the chain when it runs out.  Returns the list of per-block times (max over ranks each)."""
     from dmme_amd.common.noise import philox_reserve
 
     left = 0
@@ -368,15 +372,46 @@ def chain_leg(proc, runner, n_steps, warmup, steps, dist, dev):
         runner.step()
         left -= 1
 
+    times = []
     with torch.no_grad():
         for _ in range(warmup):
             one()
-        _fence(dist)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            one()
-        _fence(dist)
-    return _max_over_ranks(time.perf_counter() - t0, dist, dev)
+        for _ in range(reps):
+            _fence(dist)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                one()
+            _fence(dist)
+            times.append(_max_over_ranks(time.perf_counter() - t0, dist, dev))
+    runner.plan.check()  # a level-engine hand-off that gave up anywhere in the warm-up or the timed region voids the run (DmmeError)
+    return times
+
+
+def _median(v):
+    v = sorted(v)
+    return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+
+
+def mfma_calibration(dev):
+    """dense bf16 MFMA rate of THIS box under a sustained all-CU loop (dmme_debug_mfma_valu, MFMA waves only: 256 workgroups x 4
+    waves x 8 independent 32x32x16 MFMAs per iteration, ~1.5 ms): the pool's boards are power-managed and differ by a few percent,
+    this figure says which kind the line was measured on"""
+    from dmme_amd import _lib
+
+    lib = _lib.lib()
+    sink = torch.zeros(4096, dtype=torch.float32, device=dev)
+    iters, blocks = 10000, 256
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = None
+    for r in range(4):
+        e0.record()
+        _lib.check(lib.dmme_debug_mfma_valu(1, iters, blocks, _lib.ptr(sink), _lib.stream_ptr()), "mfma_valu")
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        if r and (best is None or ms < best):
+            best = ms
+    return round(blocks * 4 * iters * 8 * 2.0 * 32 * 32 * 16 / (best * 1e-3) / 1e12, 1)
 
 
 def main():
@@ -448,8 +483,9 @@ def main():
     x = dmme_amd.gaussian((B, 3, side, side), device=dev)
     runner = proc.chain_runner(x, use_graph=not args.no_graph)
     assert runner is not None, "the replayable denoising step does not apply to this configuration"
-    elapsed = chain_leg(proc, runner, n_steps, args.warmup, args.steps, dist, dev)
+    times = chain_leg(proc, runner, n_steps, args.warmup, args.steps, dist, dev, reps=args.reps)
     assert torch.isfinite(x).all(), "non-finite samples"
+    elapsed = _median(times)  # K steps; the line also carries the fastest block and every block's time
 
     step_tf = world * args.steps * B * gflop / elapsed / 1e3
     update = "DDIM" if args.mode == "ddim" else "IDDPM learned-variance" if args.model == "iddpm64" else "DDPM"
@@ -461,6 +497,8 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "timed_blocks": {"reps": len(times), "steps_each": args.steps, "ms_per_step_each": [round(1e3 * v / args.steps, 4) for v in times],
+                         "ms_per_step_min": round(1e3 * min(times) / args.steps, 4), "value_is": "median block"},
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -481,6 +519,7 @@ def main():
         "train_images_per_s": None,
         "launches_per_step": int(runner.plan.lib.dmme_unet_plan_num_launches(runner.plan.h)) + 1,
         "hip_graph": bool(runner.graph is not None),
+        "box_mfma_tfps": mfma_calibration(dev),
     }
 
     plan = runner.plan
@@ -511,7 +550,7 @@ def main():
                 x3 = dmme_amd.gaussian((B, 3, side, side), device=dev)
                 r3 = p3.chain_runner(x3, use_graph=not args.no_graph)
                 k = max(5, min(20, args.steps))
-                dt3 = chain_leg(p3, r3, T, 3, k, dist, dev)
+                dt3 = _median(chain_leg(p3, r3, T, 3, k, dist, dev, reps=2))
                 out[key] = {"precision": prec, "steps_per_s": round(world * k / dt3, 3), "ms_per_step": round(1e3 * dt3 / k, 3),
                             "steps": k, "step_tflops_algorithmic": round(world * k * B * gflop / dt3 / 1e3, 1),
                             "max_abs_err_vs_reference": {"bf16x3": "1.7e-5", "fp16": "1.5e-3 (rel-RMS 9.8e-4)"}[prec] + " (tests/test_gpu_x3.py, test_gpu_fp16.py)"}
@@ -530,7 +569,7 @@ def main():
             pd = dmme_amd.DDIM(md, T, 50).to(dev)
             xd = dmme_amd.gaussian((512, 3, side, side), device=dev)
             rd = pd.chain_runner(xd, use_graph=not args.no_graph)
-            dtd = chain_leg(pd, rd, 50, 5, 50, dist, dev)
+            dtd = chain_leg(pd, rd, 50, 5, 50, dist, dev)[0]
             out["ddim_b512"] = {"config": "DDIM 50-step (quadratic tau), batch 512, bf16", "steps_per_s": round(50 / dtd, 3), "ms_per_step": round(1e3 * dtd / 50, 3),
                                 "image_steps_per_s": round(50 * 512 / dtd, 1), "chain_seconds": round(dtd, 4),
                                 "step_tflops": round(50 * 512 * gflop / dtd / 1e3, 1)}
@@ -539,12 +578,34 @@ def main():
         except Exception as exc:  # noqa: BLE001
             out["ddim_b512"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
 
+    def small_batch_leg():
+        """the same captured step at batch 1 and batch 32 (the launch-bound end of `DDPM.generate`), secondary keys of the N = 1 line"""
+        if args.no_small_batch_leg or world != 1 or args.precision != "bf16" or args.model != "ddpm" or args.mode != "sample" or B != 128:
+            return
+        out["small_batch"] = {}
+        for bs in (1, 32):
+            try:
+                torch.manual_seed(1337)
+                ms_ = dmme_amd.UNet(precision="bf16").to(dev).eval()
+                ps = dmme_amd.DDPM(ms_, T).to(dev)
+                xs = dmme_amd.gaussian((bs, 3, side, side), device=dev)
+                rs = ps.chain_runner(xs, use_graph=not args.no_graph)
+                ts = chain_leg(ps, rs, T, 30, 200, dist, dev, reps=3)
+                out["small_batch"][f"b{bs}"] = {"steps_per_s": round(200 / _median(ts), 1), "ms_per_step": round(1e3 * _median(ts) / 200, 4),
+                                                "ms_per_step_min": round(1e3 * min(ts) / 200, 4),
+                                                "launches_per_step": int(rs.plan.lib.dmme_unet_plan_num_launches(rs.plan.h)) + 1}
+                del ms_, ps, xs, rs
+                torch.cuda.empty_cache()
+            except Exception as exc:  # noqa: BLE001
+                out["small_batch"][f"b{bs}"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+
     # several ranks: rank 0's legs first, so that a stuck collective in the training leg cannot cost them; one rank: after it (no
     # collective to get stuck in, and the event-bracketed kernel times sit closer to rocprofv3's with the device in its training-leg state)
     if world > 1 or args.train_steps <= 0:
         rank0_legs()
     accurate_leg()
     ddim_leg()
+    small_batch_leg()
     rc = 0
     if args.train_steps > 0:
         del x, runner

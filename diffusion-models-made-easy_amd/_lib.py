@@ -175,6 +175,22 @@ def dtype_code(precision) -> int:
     return DTYPES[key]
 
 
+def csrc_sha16() -> str:
+    """first 16 hex digits of SHA-256 over the library's sources (csrc/*.hip, *.h, the Makefile and include/dmme_hip.h, sorted by name):
+    ties committed profiler figures (profiles/*_latest.json) to the build they were measured on - bench.py drops them when it differs"""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(CSRC, "Makefile")])
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "dmme_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def stream_ptr():
     import torch
 

@@ -4,7 +4,9 @@ Counters are in KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes of w
 (MI355X_MICROARCH.md, HBM section), so the read side is doubled.  usage: python tools/traffic.py <tag> <label>"""
 import collections, csv, glob, json, os, re, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from _labels import bench_label
+from dmme_amd._lib import csrc_sha16
 
 tag, label = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -54,6 +56,7 @@ for k in rd:
 for lab in lab_tot:
     if lab not in out:
         out[lab] = {"hbm_bytes_per_launch": round(lab_tot[lab] / lab_n[lab]), "note": "bench.py label: launch-weighted mean of the symbols above"}
+out["_meta"] = {"csrc_sha16": csrc_sha16(), "label": label, "workload": "bench.py sampling leg, batch 128, bf16 (tools/prof.sh pmc3 / pmc4 passes)"}
 json.dump(out, open(os.path.join(root, "profiles", "traffic_latest.json"), "w"), indent=1)
 json.dump(out, open(os.path.join(root, "profiles", f"{label}_hbm_traffic.json"), "w"), indent=1)
-for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:8]: print(k, v["hbm_bytes_per_launch"])
+for k, v in sorted(((k, v) for k, v in out.items() if k != "_meta"), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:8]: print(k, v["hbm_bytes_per_launch"])

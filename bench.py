@@ -32,7 +32,7 @@ os.environ.setdefault("TQDM_DISABLE", "1")
 import torch  # noqa: E402
 
 # dense MFMA TFLOP/s (MI355X_MICROARCH.md, chip-level parameters); bf16x3 runs three bf16 matrix products per algorithmic one
-PEAK = {"bf16": 2500.0, "fp16": 2500.0, "bf16x3": 2500.0 / 3.0, "fp32": 157.3}
+PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp16r32": 2500.0, "bf16x3": 2500.0 / 3.0, "fp32": 157.3}
 HBM_PEAK_GBS = 8000.0
 METRIC = "denoising steps/sec + training images/sec, DDPM UNet CIFAR10 32×32 @1/2/4/8 GPU"
 FWD_GFLOP_PER_IMAGE = {"ddpm": 9.809, "iddpm64": 37.50}  # conv + linear + QK^T + AV, 2 x MAC; training = 3x
@@ -535,12 +535,13 @@ def main():
                 out["cpu_baseline"] = cpu_baseline_leg(B)
 
     def accurate_leg():
-        """the same sampling step in the two modes that are closer to the reference than bf16: precision="bf16x3" (fp32
-        activations, every matrix product as three bf16 MFMA passes on hi/lo splits - max|err| 1.7e-5, inside north_star's 1e-3) and
-        precision="fp16" (IEEE half, the reference's own AMP dtype, same kernels and rate as bf16 - max|err| 1.5e-3, rel-RMS 9.8e-4)"""
+        """the same sampling step in the modes that are closer to the reference than bf16: precision="fp16r32" (`accurate_mode`:
+        fp16 with the full-resolution level in fp32 tensors and three-pass split-fp16 products - max|err| 6-7e-4, INSIDE north_star's 1e-3),
+        precision="bf16x3" (fp32 tensors everywhere, three bf16 passes - 1.7e-5) and precision="fp16" (IEEE half, the reference's own AMP
+        dtype, same kernels and rate as bf16 - 1.5e-3)"""
         if args.no_accurate_leg or args.precision != "bf16" or args.model != "ddpm" or args.mode != "sample":
             return
-        for key, prec in (("accurate_mode", "bf16x3"), ("fp16_mode", "fp16")):
+        for key, prec in (("accurate_mode", "fp16r32"), ("bf16x3_mode", "bf16x3"), ("fp16_mode", "fp16")):
             if prec not in dmme_amd._lib.DTYPES:
                 continue
             try:
@@ -553,7 +554,8 @@ def main():
                 dt3 = _median(chain_leg(p3, r3, T, 3, k, dist, dev, reps=2))
                 out[key] = {"precision": prec, "steps_per_s": round(world * k / dt3, 3), "ms_per_step": round(1e3 * dt3 / k, 3),
                             "steps": k, "step_tflops_algorithmic": round(world * k * B * gflop / dt3 / 1e3, 1),
-                            "max_abs_err_vs_reference": {"bf16x3": "1.7e-5", "fp16": "1.5e-3 (rel-RMS 9.8e-4)"}[prec] + " (tests/test_gpu_x3.py, test_gpu_fp16.py)"}
+                            "max_abs_err_vs_reference": {"fp16r32": "6.0e-4 at batch 2, 7.2e-4 at batch 128 (rel-RMS 3.6e-4): inside north_star's 1e-3", "bf16x3": "1.7e-5",
+                                                         "fp16": "1.5e-3 (rel-RMS 9.8e-4)"}[prec] + " (tests/test_gpu_fp16.py, test_gpu_x3.py)"}
                 del m3, p3, x3, r3
                 torch.cuda.empty_cache()
             except Exception as exc:  # noqa: BLE001 - a secondary figure must not cost the headline line

@@ -14,10 +14,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DMME_LIB_PATH") or os.path.join(_HERE, "libdmme_hip.so")  # (override: A/B runs of two builds on one box)
 CSRC = os.path.join(_HERE, "csrc")
 
+F16R32 = 4  # F16 below the full-resolution level; that level in fp32 tensors with three-pass split-fp16 products (within 1e-3 of fp32; inference)
 F32, BF16, BF16X3, F16 = 0, 1, 2, 3  # BF16X3: fp32 buffers, three-pass bf16 MFMA convolutions (the accurate mode); F16: IEEE half (inference)
 CHAIN_DDPM, CHAIN_DDIM, CHAIN_IDDPM = 0, 1, 2
 DTYPES = {"fp32": F32, "float32": F32, "32": F32, "bf16": BF16, "bfloat16": BF16, "16": BF16, "bf16-mixed": BF16, "16-mixed": BF16,
-          "bf16x3": BF16X3, "fp16": F16, "float16": F16, "half": F16}
+          "bf16x3": BF16X3, "fp16": F16, "float16": F16, "half": F16, "fp16r32": F16R32}
 
 _lock = threading.Lock()
 _lib = None
@@ -171,7 +172,7 @@ def require_gpu():
 def dtype_code(precision) -> int:
     key = str(precision).lower()
     if key not in DTYPES:
-        raise ValueError(f"unknown precision {precision!r}; use 'fp32', 'bf16', 'fp16' (inference) or 'bf16x3'")
+        raise ValueError(f"unknown precision {precision!r}; use 'fp32', 'bf16', 'fp16' / 'fp16r32' (inference) or 'bf16x3'")
     return DTYPES[key]
 
 

@@ -206,6 +206,11 @@ struct ConvArgs {
     int64_t splitk_cap;
     // accurate mode (fp32 tensors only): every product as three bf16 MFMA passes on hi/lo splits instead of the fp32 MFMA
     int x3;
+    // precision="fp16r32" (a 16-bit plan whose full-resolution level lives in fp32): this conv reads / writes fp32 tensors and runs every
+    // product as three fp16 MFMA passes over hi / lo splits of both operands (filter packed [Cout][taps][Cin / 32][hi 32 | lo 32] halves).
+    // 0: no; 1: the wave-specialised 3x3 kernel's split form; 2: the same with a 16-bit SOURCE tensor (fp32 residual / output);
+    // 3: the thin output conv's split form (fp32 source, NCHW fp32 out)
+    int mix;
     // 16-bit tensors are IEEE half (precision="fp16") instead of bf16: for the launchers that take no dtype argument
     int f16;
     // pipelined 3x3 kernel, 64-cout bf16 tiles: filter tiles by LDS-DMA into a second buffer instead of through registers
@@ -311,6 +316,8 @@ int launch_linear_wave(int dtype, const float* in, int nt, int K, const void* W,
 int launch_nchw_to_nhwc(int dtype, const float* src, int N, int C, int HW, void* dst, hipStream_t s);
 int launch_nhwc_to_nchw(int dtype, const void* src, int N, int C, int HW, float* dst, hipStream_t s);
 int launch_pack_weight(int dtype, const float* src, int Cout, int Cin, int taps, void* dst, hipStream_t s);
+// fp32 -> 16-bit copy of a tensor (numel % 8 == 0): where a conv of a mixed plan's 16-bit levels reads a tensor of its fp32 level
+int launch_cast_f32_to_16(int dtype, const float* src, int64_t numel, void* dst, hipStream_t s);
 
 struct PackItem {  // one chunk of the table-driven parameter re-pack
     int64_t src_off;   // element offset in the fp32 reference-layout flat buffer
@@ -320,6 +327,8 @@ struct PackItem {  // one chunk of the table-driven parameter re-pack
     int32_t ci0, nci;         // cin range [ci0, ci0+nci) handled by this item (re-pack items; rows*nci*taps <= 8192)
     int32_t as_f32;           // 1: keep fp32 (biases, gammas, freqs); 0: convert to dtype;
                               // 2: transposed + tap-flipped copy [cin][taps-1-tap][cout] in dtype (data-gradient weights)
+                              // 3: [cout][tap][cin] like 0, but kept fp32 whatever the plan's dtype (fp32-routed convs of a mixed plan)
+                              // 4: [cout][tap][cin / 32][hi 32 | lo 32] IEEE halves, hi = f16(w), lo = f16(w - hi) (ConvArgs::mix)
 };
 int launch_pack_table(int dtype, const PackItem* items_dev, int n_items, const float* ref_flat, void* packed,
                       hipStream_t s);

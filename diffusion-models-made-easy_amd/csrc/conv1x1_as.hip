@@ -413,7 +413,7 @@ static bool as_stats_cg_ok(int cg) { return cg == 4 || cg == 8 || cg == 16 || cg
 static bool as_shape_ok(int dtype, const ConvArgs& a) {
     const bool off = getenv("DMME_NO_CONV1X1_AS") != nullptr;
     constexpr int min_units = 2;
-    if (off || !is16(dtype) || a.x3) return false;
+    if (off || !is16(dtype) || a.x3 || a.mix) return false;
     if (a.taps != 1 || a.stride != 1 || a.up || a.in_nchw || a.out_nchw || a.out_silu || a.res2 || a.n_gno) return false;
     if (a.tproj && a.nt != 1) return false;
     const int K = a.C1 + a.C2;

@@ -131,6 +131,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a, ConvTile g) 
 }
 
 bool conv_mfma_supported(int dtype, const ConvArgs& a) {
+    if (a.mix) return false;  // (mixed-precision convs have their own kernels: conv_pipe_supported / conv_out_thin_supported)
     const int KC = is16(dtype) ? 64 : 32;
     if (a.in_nchw) return false;
     if ((int64_t)a.N * a.Hout * a.Wout * a.Cout >= (1ll << 31)) return false;  // 32-bit offsets in the epilogue

@@ -422,9 +422,32 @@ __device__ __forceinline__ void ws_fill_par_gni(const ConvArgs& a, int n, bool w
 // couts, ONE epilogue pass) for the layers whose 256-pixel tiling leaves CUs without a tile: the 32x32 maps at batch 32, the
 // 128-cout layers of the 16x16 level at batch 128.  Per MFMA it moves twice the filter bytes and is behind the 256-pixel form
 // wherever that fills the chip; against the four-wave kernel that ran these layers it keeps the producer / consumer split.
-template <int PIPE_UA, typename T = bf16, int BM = 256>
+// SPLIT (precision="fp16r32": ConvArgs::mix): the tensors are fp32 and every product runs as THREE fp16 MFMA passes.  A 128-byte LDS
+// row holds 32 input channels as [hi: 32 halves | lo: 32 halves], hi = f16(v), lo = f16(v - hi): the activation rows are split by the
+// producers behind the prologue (which computes in fp32 anyway), the filter rows are packed that way (pack_table_kernel, code 4).  LDS
+// images, DMA stream, ring and barriers are those of the 64-channel 16-bit chunk; of a stage's four k-groups 0, 1 are the hi halves
+// and 2, 3 the lo halves, and the consumers run hi.hi + hi.lo + lo.hi (lo.lo, ~2^-22 of a product, is dropped): 48 MFMAs per stage
+// instead of 32 over the same 24 fragment reads.  SPLIT = 2: the source tensor is 16-bit (the up-sampling conv that enters the fp32
+// level from the 16-bit level below: lo = 0 exactly), residual and output are still fp32.
+template <typename T, int SPLIT>
+struct WsSplit {
+    typedef T ts;   // residual / output tensor type
+};
+template <typename T>
+struct WsSplit<T, 1> {
+    typedef float ts;
+};
+template <typename T>
+struct WsSplit<T, 2> {
+    typedef float ts;
+};
+template <int PIPE_UA, typename T = bf16, int BM = 256, int SPLIT = 0>
 __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTile g, int shTW, int shTH, int ntiles) {
     constexpr int KC = 64, EPV = 8, BN = 128, MI = BM / 64, NI = 2, UB = BN / 32;
+    constexpr int KCR = SPLIT ? 32 : KC;  // input channels per chunk (KC = 16-bit k-slots per 128-byte row)
+    constexpr int EPR = SPLIT ? 4 : EPV;  // input channels per producer lane and halo unit
+    typedef typename WsSplit<T, SPLIT>::ts TS;
+    static_assert(SPLIT == 0 || (BM == 256 && dtype_of<T>::value == DMME_F16), "split passes: fp16 hi / lo on the 256-pixel tile");
     constexpr int R_BYTES = BN * ROW_DATA;  // one tap
     constexpr int A_PITCH = ROW_DATA + 16;  // halo rows are padded, not swizzled: fragment reads use immediate offsets from one base
     static_assert((BM == 256 && PIPE_UA == 11) || (BM == 128 && PIPE_UA == 7), "unit schedules below: 11 units over 9 stages, or 7 units over the first 7");
@@ -444,7 +467,8 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
     typedef WsTile TileXY;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool producer = wave >= 4;
-    const int nchunks = Cin / KC;
+    const int nchunks = Cin / KCR;
+    const int CinW = SPLIT ? 2 * Cin : Cin;  // k-slots per (cout, tap) row of the packed filter
     const int K = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;  // tiles of this workgroup
     const bool has_pro = a.scale || a.pro_silu || a.dmask;
     // scale / shift / mask of tile kt's image -> parameter buffer kt & 1 (all 512 threads).  Tiles 0 and 1 here; tile kt + 2
@@ -488,14 +512,14 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             const int tx = mm & mTW, ty = (mm >> shTW) & mTH;                                                                      \
             return ((TT).n0 * a.Hout + (TT).oy0 + ty) * a.Wout + (TT).ox0 + tx;                                                    \
         };                                                                                                                         \
-        uint4 rpre[128 * (BN / 8) / 512];                                                                                          \
-        conv_epilogue_res_prefetch<T, 128, BN, 512>(a, (TT).co0, pix_of, rpre); /* in flight across the staging barrier */         \
+        uint4 rpre[128 * (BN / (16 / (int)sizeof(TS))) / 512];                                                                     \
+        conv_epilogue_res_prefetch<TS, 128, BN, 512>(a, (TT).co0, pix_of, rpre); /* in flight across the staging barrier */         \
         WS_ESTAMP()                                                                                                                \
         STAGE_STMT                                                                                                                 \
         WS_ESTAMP()                                                                                                                \
         __syncthreads();                                                                                                           \
         WS_ESTAMP()                                                                                                                \
-        conv_epilogue_store<T, 128, BN, 512>(a, (TT).co0, (TT).n0, pix_of, stage, (BM / 128) * (TT).ts + p, rpre, a.n_gno ? p : -1, gn_carry); \
+        conv_epilogue_store<TS, 128, BN, 512>(a, (TT).co0, (TT).n0, pix_of, stage, (BM / 128) * (TT).ts + p, rpre, a.n_gno ? p : -1, gn_carry); \
         WS_ESTAMP()                                                                                                                \
         __syncthreads(); /* everyone is done with the staging area */                                                              \
     }
@@ -514,9 +538,9 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         int a_pix[PIPE_UA], a_sw[PIPE_UA];
         unsigned b_vo[UB];
 #pragma unroll
-        for (int i = 0; i < PIPE_UA; ++i) a_sw[i] = (urow + 32 * i) * A_PITCH + cu * 16;
+        for (int i = 0; i < PIPE_UA; ++i) a_sw[i] = (urow + 32 * i) * A_PITCH + cu * (SPLIT ? 8 : 16);  // (SPLIT: the hi half; lo 64 bytes on)
 #pragma unroll
-        for (int k4 = 0; k4 < UB; ++k4) b_vo[k4] = (unsigned)(((urow + 32 * k4) * 9 * Cin + (cu ^ ((urow >> 1) & 7)) * EPV) * 2);
+        for (int k4 = 0; k4 < UB; ++k4) b_vo[k4] = (unsigned)(((urow + 32 * k4) * 9 * CinW + (cu ^ ((urow >> 1) & 7)) * EPV) * 2);
         auto set_pix = [&](int i, const TileXY& t) __attribute__((always_inline)) {
             const int row = urow + 32 * i;
             const int hy = (int)__umulhi((unsigned)row, g.magic_w), hx = row - hy * g.HWd;
@@ -531,9 +555,9 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         // operand of the packed fp32 instructions below is a consecutive register pair as loaded
         f32x2 pS[4], pH[4], pS2[4], pH2[4];
         auto load_par = [&](const float* par, int c0) __attribute__((always_inline)) {
-            const float* p = par + c0 + cu * EPV;
+            const float* p = par + c0 + cu * EPR;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
+            for (int d = 0; d < EPR / 2; ++d) {
                 pS[d] = *reinterpret_cast<const f32x2*>(p + 2 * d);
                 pH[d] = *reinterpret_cast<const f32x2*>(p + Cin + 2 * d);
                 pS2[d] = *reinterpret_cast<const f32x2*>(p + 2 * Cin + 2 * d);
@@ -542,14 +566,60 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         };
         auto load_A = [&](int i, int c0) __attribute__((always_inline)) {
             const bool second = c0 >= a.C1;
-            const char* sbase = (const char*)(second ? a.src2 : a.src1) + (size_t)((second ? c0 - a.C1 : c0) * 2);
+            constexpr int SB = SPLIT == 1 ? 4 : 2;  // bytes per source element
+            const char* sbase = (const char*)(second ? a.src2 : a.src1) + (size_t)((second ? c0 - a.C1 : c0) * SB);
             const int Cs = second ? a.C2 : a.C1;
             const int px = a_pix[i] < 0 ? 0 : a_pix[i];
-            const char* gp = sbase + (size_t)((unsigned)(px * Cs + cu * EPV) * 2u);
-            areg[i] = *reinterpret_cast<const u32x4*>(gp);
+            const char* gp = sbase + (size_t)((unsigned)(px * Cs + cu * EPR) * (unsigned)SB);
+            if constexpr (SPLIT == 2) {  // four 16-bit channels: 8 bytes
+                const uint2 v2 = *reinterpret_cast<const uint2*>(gp);
+                areg[i] = u32x4{v2.x, v2.y, 0u, 0u};
+            } else {
+                areg[i] = *reinterpret_cast<const u32x4*>(gp);
+            }
         };
         auto store_A = [&](int i, char* dstA) __attribute__((always_inline)) {
             u32x4 val = areg[i];
+            if constexpr (SPLIT != 0) {
+                // four channels: prologue in packed fp32 (as below), then hi = f16(y), lo = f16(y - hi) -> 8 bytes each into the row's halves
+                f32x2 y[2];
+                if constexpr (SPLIT == 1) {
+                    y[0] = f32x2{__uint_as_float(val[0]), __uint_as_float(val[1])};
+                    y[1] = f32x2{__uint_as_float(val[2]), __uint_as_float(val[3])};
+                } else {
+                    typedef T tx4 __attribute__((ext_vector_type(4)));
+                    const tx4 x = __builtin_bit_cast(tx4, make_uint2(val[0], val[1]));
+                    y[0] = f32x2{(float)x[0], (float)x[1]};
+                    y[1] = f32x2{(float)x[2], (float)x[3]};
+                }
+                if (has_pro) {
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        const f32x2 xv = y[d];
+                        f32x2 e = __builtin_elementwise_fma(xv, pS2[d], pH2[d]);
+                        y[d] = __builtin_elementwise_fma(xv, pS[d], pH[d]);
+                        e = f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + f32x2{1.f, 1.f};
+                        y[d] = y[d] * f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+                    }
+                }
+                typedef f16 hx4 __attribute__((ext_vector_type(4)));
+                hx4 hi, lo;
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const f16 hv = (f16)y[d][k];
+                        hi[2 * d + k] = hv;
+                        lo[2 * d + k] = (f16)(y[d][k] - (float)hv);
+                    }
+                uint2 hw = __builtin_bit_cast(uint2, hi), lw = __builtin_bit_cast(uint2, lo);
+                if (a_pix[i] < 0) hw = lw = make_uint2(0u, 0u);
+                if (a_pix[i] != -2) {
+                    *reinterpret_cast<uint2*>(dstA + a_sw[i]) = hw;
+                    *reinterpret_cast<uint2*>(dstA + a_sw[i] + 64) = lw;
+                }
+                return;
+            }
             if (has_pro) {
                 // per dword (two adjacent channels): two packed fmas, two exp2, a packed add, two rcp, a packed multiply, one pack -
                 // ~5 VALU instructions per element (the scalar form had 10: the wave shares its SIMD with an MFMA wave, and every
@@ -585,7 +655,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         // cycles from issue to landed under load, a stage ~2 k (stamps, tools/stamp_ws.py)
         auto dma_tap = [&](char* dstR, int co0, int c, int t) __attribute__((always_inline)) {
             const unsigned lbase = (unsigned)(size_t)(lds_c*)dstR + (unsigned)(pw * 8 * ROW_DATA);
-            const char* ub = wbase + ((size_t)co0 * 9 * Cin + (size_t)t * Cin + (size_t)c * KC) * 2;
+            const char* ub = wbase + ((size_t)co0 * 9 * CinW + (size_t)t * CinW + (size_t)c * KC) * 2;
 #pragma unroll
             for (int k4 = 0; k4 < UB; ++k4) {
                 const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)(lbase + (unsigned)(32 * k4 * ROW_DATA)));
@@ -607,7 +677,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
 #pragma unroll
             for (int i = 0; i < PIPE_UA; ++i) store_A(i, WS_BUFA(0));
 #pragma unroll
-            for (int i = 0; i < PIPE_UA; ++i) load_A(i, KC);  // nchunks >= 2
+            for (int i = 0; i < PIPE_UA; ++i) load_A(i, KCR);  // nchunks >= 2
             wait_vm_keep<PIPE_UA>();  // both taps have landed (they are older than the eleven loads just issued)
         }
         __syncthreads();
@@ -618,7 +688,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
     {                                         \
         if (do_store) store_A((i), dstA);     \
         if (new_tile) set_pix((i), tnn);      \
-        load_A((i), lc * KC);                 \
+        load_A((i), lc * KCR);                \
     }
 #define WS_A_ARRIVED(i) { asm volatile("" : "+v"(areg[i][0]), "+v"(areg[i][1]), "+v"(areg[i][2]), "+v"(areg[i][3])); }
         // stage TP = tap TP of chunk (kt, cc): DMA of the tap two stages on, 1-2 halo units of the next chunk, barrier.
@@ -669,7 +739,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             char* dstA = WS_BUFA(cg + 1);                                                                               \
             const bool new_tile = have_l && lc == 0;                                                                    \
             const TileXY tnn = lk == kt ? tcur : tnext;                                                                 \
-            if ((TP) == 0) load_par(WS_PAR(nk), nc* KC);                                                                \
+            if ((TP) == 0) load_par(WS_PAR(nk), nc* KCR);                                                               \
             if constexpr (PIPE_UA == 11) {                                                                              \
                 if ((TP) == 0) { WS_A_UNIT(0) WS_A_UNIT(1) }                                                            \
                 else if ((TP) == 8) { WS_A_UNIT(9) WS_A_UNIT(10) }                                                      \
@@ -770,7 +840,35 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_group(af[SET][mi], bfr[SET][ni], acc[mi][ni], (T*)nullptr); \
         __builtin_amdgcn_sched_barrier(0);                                                            \
     }
-                WS_FRAGS(0, 0) WS_FRAGS(1, 1) WS_MMAS(0) WS_FRAGS(0, 2) WS_MMAS(1) WS_FRAGS(1, 3) WS_MMAS(0) WS_MMAS(1)
+#define WS_FA(SET, KG) { _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) af[SET][mi] = *reinterpret_cast<const uint4*>(pa[mi] + (KG) * 32); }
+#define WS_FB(SET, KG) { _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) bfr[SET][ni] = *reinterpret_cast<const uint4*>(ldsR + b_off[ni][KG]); }
+#define WS_SB() __builtin_amdgcn_sched_barrier(0);
+#define WS_MM(SA, SB_)                                                                                \
+    {                                                                                                 \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                             \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_group(af[SA][mi], bfr[SB_][ni], acc[mi][ni], (T*)nullptr); \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    }
+                if constexpr (SPLIT != 0) {
+                    // k-groups 0, 1 = hi halves of the chunk's 32 channels, 2, 3 = lo halves; two A slots and two B slots as in the plain
+                    // schedule, every fragment set requested one MFMA group (8 MFMAs) ahead of its first use
+                    WS_FA(0, 0) WS_FB(0, 0) WS_FB(1, 2) WS_SB()   // a0 = A.hi[0], b0 = W.hi[0], b1 = W.lo[0]
+                    WS_MM(0, 0)                                   // hi.hi, channels 0-15
+                    WS_FA(1, 2) WS_SB()                           // a1 = A.lo[0]
+                    WS_MM(0, 1)                                   // hi.lo
+                    WS_FA(0, 1) WS_FB(1, 1) WS_SB()               // a0 = A.hi[1], b1 = W.hi[1]
+                    WS_MM(1, 0)                                   // lo.hi
+                    WS_FB(0, 3) WS_FA(1, 3) WS_SB()               // b0 = W.lo[1], a1 = A.lo[1]
+                    WS_MM(0, 1)                                   // hi.hi, channels 16-31
+                    WS_MM(0, 0)                                   // hi.lo
+                    WS_MM(1, 1)                                   // lo.hi
+                } else {
+                    WS_FRAGS(0, 0) WS_FRAGS(1, 1) WS_MMAS(0) WS_FRAGS(0, 2) WS_MMAS(1) WS_FRAGS(1, 3) WS_MMAS(0) WS_MMAS(1)
+                }
+#undef WS_FA
+#undef WS_FB
+#undef WS_SB
+#undef WS_MM
 #undef WS_FRAGS
 #undef WS_MMAS
                 WS_STAMP()
@@ -821,6 +919,19 @@ static int ws_pick(const ConvArgs& a, ConvTile& g) {
     return 0;
 }
 
+// the split-pass form of the wave-specialised kernel (ConvArgs::mix 1 / 2: fp32 tensors, three fp16 passes): 256-pixel tiles of one
+// image, whole 32-channel blocks per source, whole 128-cout tiles; any number of tiles (a small batch just leaves workgroups idle)
+static bool ws2s_pick(const ConvArgs& a, ConvTile& g) {
+    const int Cin = a.C1 + a.C2;
+    if ((a.mix != 1 && a.mix != 2) || a.taps != 9 || a.stride != 1 || a.up == 2 || Cin % 64 || a.C1 % 32 || Cin < 64 || Cin > 512 || a.out_silu || a.out_nchw || a.in_nchw ||
+        a.Cout % 128 || a.res2 || a.n_gno || (a.tproj && a.nt != 1 && a.nt != a.N))
+        return false;
+    if ((int64_t)a.Cout * 9 * 2 * Cin >= (1ll << 30) || (int64_t)a.N * a.Hin * a.Win * Cin >= (1ll << 29)) return false;  // 32-bit byte offsets
+    ConvTile t;
+    if (!make_tile(a, 256, 128, t) || t.TN != 1 || t.a_rows > 352 || ws2_lds(a, t) > 160 * 1024 || (size_t)t.a_rows * ROW_DATA + 2 * 128 * ROW_DATA < 64 * 1024) return false;
+    g = t;
+    return true;
+}
 // candidate kernels: {BM, BN, GT}; the 9-tap variant serves layers with too little work per interval
 // (few workgroups or stride 2) and owns a larger LDS footprint
 static const int kPipeCand[5][3] = {{128, 128, 3}, {128, 64, 3}, {64, 64, 3}, {64, 64, 9}, {64, 64, 3}};
@@ -880,6 +991,10 @@ static int pipe_pick(const ConvArgs& a, ConvTile& g) {
 }
 
 bool conv_pipe_supported(int dtype, const ConvArgs& a) {
+    if (a.mix) {
+        ConvTile gs{};
+        return dtype == DMME_F16 && ws2s_pick(a, gs);
+    }
     if (!conv_mfma_supported(dtype, a)) return false;
     if (a.taps != 9 || (a.stride != 1 && a.stride != 2)) return false;
     if ((int64_t)a.Cout * 9 * (a.C1 + a.C2) >= (1ll << 31)) return false;
@@ -891,6 +1006,26 @@ bool conv_pipe_supported(int dtype, const ConvArgs& a) {
 template <typename K>
 static int set_lds_limit(K kernel, size_t bytes) {
     DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return DMME_OK;
+}
+
+static int launch_ws2_split(const ConvArgs& a, hipStream_t s) {
+    ConvTile gw{};
+    DMME_REQUIRE(ws2s_pick(a, gw), DMME_ERR_UNSUPPORTED, "conv3x3 (split fp16 passes): unsupported shape");
+    static bool attr = false;
+    if (!attr) {
+        int rc0 = set_lds_limit(conv3x3_ws2_kernel<11, f16, 256, 1>, 160 * 1024);
+        if (rc0 == DMME_OK) rc0 = set_lds_limit(conv3x3_ws2_kernel<11, f16, 256, 2>, 160 * 1024);
+        if (rc0 != DMME_OK) return rc0;
+        attr = true;
+    }
+    const int ntiles = gw.tiles_m * gw.tiles_n;
+    const dim3 wgrid((unsigned)(ntiles < 256 ? ntiles : 256));
+    if (a.mix == 2)
+        hipLaunchKernelGGL((conv3x3_ws2_kernel<11, f16, 256, 2>), wgrid, dim3(512), ws2_lds(a, gw), s, a, gw, ilog2(gw.TW), ilog2(gw.TH), ntiles);
+    else
+        hipLaunchKernelGGL((conv3x3_ws2_kernel<11, f16, 256, 1>), wgrid, dim3(512), ws2_lds(a, gw), s, a, gw, ilog2(gw.TW), ilog2(gw.TH), ntiles);
+    DMME_CHECK_LAUNCH();
     return DMME_OK;
 }
 
@@ -991,6 +1126,7 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
 
 int launch_conv_pipe(int dtype, const ConvArgs& a, hipStream_t s) {
     DMME_REQUIRE(conv_pipe_supported(dtype, a), DMME_ERR_UNSUPPORTED, "conv_pipe: unsupported shape");
+    if (a.mix) return launch_ws2_split(a, s);
     if (dtype == DMME_BF16) return launch_pipe_t<bf16>(a, s);
     if (dtype == DMME_F16) return launch_pipe_t<f16>(a, s);
     return a.x3 ? launch_pipe_t<float, true>(a, s) : launch_pipe_t<float>(a, s);
@@ -999,6 +1135,7 @@ int launch_conv_pipe(int dtype, const ConvArgs& a, hipStream_t s) {
 bool conv_gn_in_query(int dtype, const ConvArgs& a) {
     if (getenv("DMME_NO_GN_IN") || !is16(dtype)) return false;  // (read per plan build, like DMME_NO_GN_DIRECT: the tests toggle it)
     if (conv_out_thin_supported(dtype, a)) return true;       // the thin output conv keeps its image's rows in LDS anyway
+    if (a.mix) return conv_pipe_supported(dtype, a);          // the split-pass kernel fills its rows like the wave-specialised kernel it is
     if (a.taps == 1) return conv1x1_as_supported(dtype, a) || conv1x1_pipe_gn_in_ok(dtype, a);  // the store team / the tiled kernel's preamble
     if (!conv_pipe_supported(dtype, a)) return false;
     ConvTile gw{};
@@ -1023,7 +1160,7 @@ bool conv_gn_in_query(int dtype, const ConvArgs& a) {
 
 bool conv_gn_direct_query(int dtype, const ConvArgs& a, const int* cg, int n) {
     const bool off = getenv("DMME_NO_GN_DIRECT") != nullptr;
-    if (off || n < 1 || n > 2 || a.taps != 9 || !conv_pipe_supported(dtype, a)) return false;
+    if (off || a.mix || n < 1 || n > 2 || a.taps != 9 || !conv_pipe_supported(dtype, a)) return false;
     const int VEC = is16(dtype) ? 8 : 4;
     const int HW = a.Hout * a.Wout;
     if (a.out_silu || a.out_nchw || a.res2 || a.Cout % VEC || HW > 64 || (HW & (HW - 1))) return false;
@@ -1062,7 +1199,7 @@ bool conv_gn_direct_query(int dtype, const ConvArgs& a, const int* cg, int n) {
 // (scale / shift / {mean, rstd} only - the first pass is in memory before the statistics exist, so no pre-activated output)
 bool conv_gn_direct_ws_query(int dtype, const ConvArgs& a, const int* cg, int n) {
     const bool off = getenv("DMME_NO_GN_DIRECT") != nullptr || getenv("DMME_NO_GN_DIRECT_WS") != nullptr;
-    if (off || !is16(dtype) || getenv("DMME_NO_WS") || n < 1 || n > 2 || !conv_pipe_supported(dtype, a)) return false;
+    if (off || a.mix || !is16(dtype) || getenv("DMME_NO_WS") || n < 1 || n > 2 || !conv_pipe_supported(dtype, a)) return false;
     ConvTile gw{};
     if (!ws_pick(a, gw) || gw.TH != a.Hout || gw.TW != a.Wout || gw.TH * gw.TW != 256) return false;
     const int cgs = a.gn_cg;  // this tensor's own group size
@@ -1075,6 +1212,13 @@ bool conv_gn_direct_ws_query(int dtype, const ConvArgs& a, const int* cg, int n)
 }
 
 bool conv_pipe_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px) {
+    if (a.mix) {  // fp32 output vectors of 4 channels, one partial per 128-pixel epilogue pass
+        ConvTile gs{};
+        if (!ws2s_pick(a, gs) || !stats_tile_ok(a, gs, 128, cg, 4)) return false;
+        *tiles = gs.tiles_x * gs.tiles_y * 2;
+        *px = 128;
+        return true;
+    }
     if (is16(dtype) && !getenv("DMME_NO_WS")) {  // the wave-specialised kernel's tile, when it will run this conv
         ConvTile gw{};
         const int ws = ws_pick(a, gw);
@@ -1105,6 +1249,10 @@ bool conv_pipe_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int
 }
 
 void conv_pipe_label(int dtype, const ConvArgs& a, char* buf, int cap) {
+    if (a.mix) {
+        snprintf(buf, (size_t)cap, a.mix == 2 ? "conv3x3_ws2_kernel<11,f16x3,src16>" : "conv3x3_ws2_kernel<11,f16x3>");
+        return;
+    }
     if (is16(dtype) && !getenv("DMME_NO_WS")) {
         ConvTile gw{};
         const int ws = ws_pick(a, gw);

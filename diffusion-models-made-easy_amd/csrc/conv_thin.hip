@@ -9,6 +9,8 @@
 // once: nothing to stage), the weights in registers.  HBM-bound: the input once (x 1.25 for the band halo), 1.5 MB out.
 #include <stdio.h>
 
+#include <type_traits>
+
 #include "conv_common.h"
 
 namespace dmme {
@@ -16,7 +18,10 @@ namespace dmme {
 constexpr int kThinMaxC = 512;
 
 // NT: 32-column tiles of (cout, tap) pairs (1: Cout <= 3, 2: Cout <= 7)
-template <int NT, typename T = bf16>
+// SPLIT (precision="fp16r32", ConvArgs::mix == 3): the input tensor is fp32; GroupNorm + SiLU run in fp32 on it and every product is
+// three fp16 MFMA passes over hi / lo halves of activation and weight (filter rows packed [Cin / 32][hi 32 | lo 32], pack code 4) -
+// the layer is HBM-bound (its matrix work is 27 columns wide), so the two extra passes are free and only the input bytes double.
+template <int NT, typename T = bf16, bool SPLIT = false>
 __global__ void __launch_bounds__(256) conv_out_thin_kernel(ConvArgs a, int R) {
     typedef typename Vec8<T>::type bf16x8;  // (8 operands of the kernel's 16-bit type; the name predates precision="fp16")
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -34,16 +39,27 @@ __global__ void __launch_bounds__(256) conv_out_thin_kernel(ConvArgs a, int R) {
     const int ksteps = C / 16;
     const T* wb = (const T*)a.w;
     bf16x8 wfrag[NT][8];
+    bf16x8 wlo[SPLIT ? NT : 1][SPLIT ? 8 : 1];  // (SPLIT: the lo halves of the same channels)
     auto load_w = [&](int kc) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int nc = 32 * t + r;
 #pragma unroll
             for (int kg = 0; kg < 8; ++kg) {
-                bf16x8 v;
+                bf16x8 v, vl;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (T)0.f;
-                if (kc + kg < ksteps && nc < NCOL) v = *reinterpret_cast<const bf16x8*>(wb + (int64_t)nc * C + (kc + kg) * 16 + 8 * h);
+                for (int e = 0; e < 8; ++e) v[e] = vl[e] = (T)0.f;
+                if constexpr (SPLIT) {
+                    const int c0 = (kc + kg) * 16 + 8 * h;  // eight channels inside one 32-channel block
+                    if (kc + kg < ksteps && nc < NCOL) {
+                        const T* wr = wb + (int64_t)nc * 2 * C + (c0 >> 5) * 64 + (c0 & 31);
+                        v = *reinterpret_cast<const bf16x8*>(wr);
+                        vl = *reinterpret_cast<const bf16x8*>(wr + 32);
+                    }
+                    wlo[t][kg] = vl;
+                } else {
+                    if (kc + kg < ksteps && nc < NCOL) v = *reinterpret_cast<const bf16x8*>(wb + (int64_t)nc * C + (kc + kg) * 16 + 8 * h);
+                }
                 wfrag[t][kg] = v;
             }
         }
@@ -63,12 +79,13 @@ __global__ void __launch_bounds__(256) conv_out_thin_kernel(ConvArgs a, int R) {
     }
     __syncthreads();
 
-    const T* xb = (const T*)a.src1 + (int64_t)n * H * W * C;
+    typedef typename std::conditional<SPLIT, float, T>::type TX;  // element type of the input tensor
+    const TX* xb = (const TX*)a.src1 + (int64_t)n * H * W * C;
     for (int tile = wave; tile < ntile; tile += 4) {
         const int p = tile * 32 + r;               // pixel of the band incl. its halo rows
         const int yy = y0 - 1 + p / W, xx = p % W;  // image coordinates (yy may be -1 or H: zero padding)
         const bool in = yy >= 0 && yy < H;
-        const T* px = xb + (int64_t)((in ? yy : 0) * W + xx) * C + 8 * h;
+        const TX* px = xb + (int64_t)((in ? yy : 0) * W + xx) * C + 8 * h;
         f32x16 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -76,6 +93,38 @@ __global__ void __launch_bounds__(256) conv_out_thin_kernel(ConvArgs a, int R) {
             for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
         for (int kc = 0; kc < ksteps; kc += 8) {
             if (!w_once) load_w(kc);
+            if constexpr (SPLIT) {
+                uint4 raw[8][2];  // eight fp32 channels per k-group
+#pragma unroll
+                for (int kg = 0; kg < 8; ++kg)
+                    if (kc + kg < ksteps) {
+                        raw[kg][0] = *reinterpret_cast<const uint4*>(px + (kc + kg) * 16);
+                        raw[kg][1] = *reinterpret_cast<const uint4*>(px + (kc + kg) * 16 + 4);
+                    }
+#pragma unroll
+                for (int kg = 0; kg < 8; ++kg) {
+                    if (kc + kg >= ksteps) break;
+                    const int c0 = (kc + kg) * 16 + 8 * h;
+                    bf16x8 ahi, alo;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const uint4 y4 = prologue_vec<float>(raw[kg][q], a.scale ? par + c0 + 4 * q : nullptr, a.scale ? par + C + c0 + 4 * q : nullptr, nullptr, a.pro_silu);
+                        const f32x4 y = __builtin_bit_cast(f32x4, y4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const T hv = (T)(in ? y[e] : 0.f);
+                            ahi[4 * q + e] = hv;
+                            alo[4 * q + e] = (T)((in ? y[e] : 0.f) - (float)hv);
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {  // the small terms first
+                        mma16<T>(__builtin_bit_cast(uint4, alo), __builtin_bit_cast(uint4, wfrag[t][kg]), acc[t]);
+                        mma16<T>(__builtin_bit_cast(uint4, ahi), __builtin_bit_cast(uint4, wlo[t][kg]), acc[t]);
+                        mma16<T>(__builtin_bit_cast(uint4, ahi), __builtin_bit_cast(uint4, wfrag[t][kg]), acc[t]);
+                    }
+                }
+            } else {
             uint4 raw[8];
 #pragma unroll
             for (int kg = 0; kg < 8; ++kg)
@@ -88,6 +137,7 @@ __global__ void __launch_bounds__(256) conv_out_thin_kernel(ConvArgs a, int R) {
                 if (!in) av = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) mma16<T>(av, __builtin_bit_cast(uint4, wfrag[t][kg]), acc[t]);
+            }
             }
         }
         // D[row = pixel][col = (cout, tap)]: lane = column r, registers = pixel rows (j & 3) + 8 (j >> 2) + 4 h
@@ -128,7 +178,9 @@ static int thin_rows(const ConvArgs& a) {  // band height: the z image of R + 2 
 
 bool conv_out_thin_supported(int dtype, const ConvArgs& a) {
     const bool off = getenv("DMME_NO_CONV_THIN") != nullptr;
+    if (a.mix && a.mix != 3) return false;
     if (off || !is16(dtype) || a.x3) return false;
+    if (a.mix == 3 && (dtype != DMME_F16 || a.C1 % 32)) return false;  // (whole 32-channel blocks of hi / lo halves)
     if (a.taps != 9 || a.stride != 1 || a.up || a.C2 || a.in_nchw || !a.out_nchw || a.out_silu || a.tproj || a.res1 || a.dmask || a.gn_part || a.n_gno)
         return false;
     if (a.Cout * 9 > 64 || a.C1 % 16 || a.C1 > kThinMaxC || a.Wout % 32 || a.Hin != a.Hout || a.Win != a.Wout) return false;
@@ -141,7 +193,12 @@ int launch_conv_out_thin(const ConvArgs& a, hipStream_t s) {
     const int NT = a.Cout * 9 <= 32 ? 1 : 2;
     const size_t lds = (size_t)(R + 2) * a.Wout * (32 * NT + 1) * 4 + (size_t)2 * a.C1 * 4;
     const dim3 grid((unsigned)(a.N * (a.Hout / R)));
-    if (a.f16) {
+    if (a.mix == 3) {
+        if (NT == 1)
+            hipLaunchKernelGGL((conv_out_thin_kernel<1, f16, true>), grid, dim3(256), lds, s, a, R);
+        else
+            hipLaunchKernelGGL((conv_out_thin_kernel<2, f16, true>), grid, dim3(256), lds, s, a, R);
+    } else if (a.f16) {
         if (NT == 1)
             hipLaunchKernelGGL((conv_out_thin_kernel<1, f16>), grid, dim3(256), lds, s, a, R);
         else

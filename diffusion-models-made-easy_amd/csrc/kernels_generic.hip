@@ -4,6 +4,8 @@
 // Also: time embedding, small linears, layout converters, the parameter re-packer.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace dmme {
@@ -695,6 +697,27 @@ __global__ void __launch_bounds__(256) pack_table_kernel(const PackItem* items, 
         }
     }
     __syncthreads();
+    if (it.as_f32 == 3) {  // [co][tap][ci] in fp32 (a conv of a 16-bit plan that is routed to the fp32 / three-pass kernels)
+        float* d32 = (float*)(packed + it.dst_off);
+        for (int e = threadIdx.x; e < total; e += blockDim.x) {
+            const int cil = e % nci, q = e / nci, tap = q % taps, co = q / taps;
+            d32[((int64_t)(it.row0 + co) * taps + tap) * it.cin + it.ci0 + cil] = tile[co * pitch + cil * taps + tap];
+        }
+        return;
+    }
+    if (it.as_f32 == 4) {  // split halves: k-slot of channel ci = (ci / 32) * 64 + ci % 32 (hi), + 32 (lo); row length 2 * cin
+        f16* dh = (f16*)(packed + it.dst_off);
+        for (int e = threadIdx.x; e < total; e += blockDim.x) {
+            const int cil = e % nci, q = e / nci, tap = q % taps, co = q / taps;
+            const int ci = it.ci0 + cil;
+            const float w = tile[co * pitch + cil * taps + tap];
+            const f16 hi = (f16)w;
+            f16* row = dh + ((int64_t)(it.row0 + co) * taps + tap) * (2 * it.cin) + (ci >> 5) * 64 + (ci & 31);
+            row[0] = hi;
+            row[32] = (f16)(w - (float)hi);
+        }
+        return;
+    }
     T* dst = (T*)(packed + it.dst_off);
     constexpr int V = 16 / (int)sizeof(T);  // elements per 16-byte store
     if (it.as_f32 == 2) {  // dst[ci][taps-1-tap][co]: runs of `rows` couts
@@ -731,6 +754,34 @@ __global__ void __launch_bounds__(256) pack_table_kernel(const PackItem* items, 
         }
     }
 }
+template <typename T>
+__global__ void __launch_bounds__(256) cast_f32_to_16_kernel(const float* __restrict__ src, int64_t nvec, T* __restrict__ dst) {
+    // eight values per thread: two 16-byte loads, one 16-byte store; grid-stride
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        typedef T t8 __attribute__((ext_vector_type(8)));
+        const f4 a = *reinterpret_cast<const f4*>(src + 8 * v), b = *reinterpret_cast<const f4*>(src + 8 * v + 4);
+        t8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = (T)a[e];
+            o[4 + e] = (T)b[e];
+        }
+        *reinterpret_cast<t8*>(dst + 8 * v) = o;
+    }
+}
+int launch_cast_f32_to_16(int dtype, const float* src, int64_t numel, void* dst, hipStream_t s) {
+    DMME_REQUIRE(is16(dtype) && numel % 8 == 0, DMME_ERR_INVALID, "cast: 16-bit destination types, whole 16-byte vectors");
+    const int64_t nvec = numel / 8;
+    const unsigned blocks = (unsigned)std::min<int64_t>((nvec + 255) / 256, 256 * 16);
+    if (dtype == DMME_F16)
+        hipLaunchKernelGGL(cast_f32_to_16_kernel<f16>, dim3(blocks), dim3(256), 0, s, src, nvec, (f16*)dst);
+    else
+        hipLaunchKernelGGL(cast_f32_to_16_kernel<bf16>, dim3(blocks), dim3(256), 0, s, src, nvec, (bf16*)dst);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
 int launch_pack_table(int dtype, const PackItem* items_dev, int n_items, const float* ref_flat, void* packed,
                       hipStream_t s) {
     if (n_items == 0) return DMME_OK;

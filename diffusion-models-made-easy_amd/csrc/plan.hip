@@ -49,6 +49,7 @@ struct Param {
     int64_t wp_off = -1;          // float offset of this conv weight in the packed-layout gradient image
     bool is_buffer = false;
     bool as_f32 = true;      // stays fp32 in the packed buffer (bias / gamma / beta / freqs)
+    int pack_code = -1;      // mixed plans: PackItem::as_f32 code of this conv weight (3: fp32 [co][tap][ci]; 4: split fp16 halves), -1: by as_f32
     int cout = 1, cin = 1, taps = 1;
     int64_t numel() const { return shape[0] * shape[1] * shape[2] * shape[3]; }
 };
@@ -56,12 +57,13 @@ struct Param {
 struct Tensor {  // an activation in the workspace, NHWC in the compute dtype
     int64_t off = 0;
     int C = 0, H = 0, W = 0;
+    int f32 = 0;  // precision="fp16r32": this tensor of a 16-bit plan is stored in fp32 (the full-resolution level)
     // GroupNorm partials emitted by the producing conv's epilogue (-1: none): [B][tiles][G][2] floats
     int64_t stats_off = -1;
     int stats_tiles = 0, stats_cnt = 0;
 };
 
-enum OpKind { OP_SINUS, OP_LINEAR, OP_GN, OP_CONV, OP_ATTN };
+enum OpKind { OP_SINUS, OP_LINEAR, OP_GN, OP_CONV, OP_ATTN, OP_CAST };
 
 struct Op {
     OpKind kind;
@@ -105,6 +107,11 @@ struct Op {
     // OP_ATTN
     int at_qkv = -1, at_out = -1, at_heads = 1;
     int64_t at_lse = 0;  // workspace offset of the forward's log-sum-exp [N][S]
+    // precision="fp16r32" (dmme_plan::mix): how this conv of the fp32 level runs.  mix: ConvArgs::mix (1 / 2: split-pass 3x3 kernel, 3: split-pass
+    // thin output conv); route_f32: on the fp32-tensor kernels with three-pass bf16 products (input conv, the blocks' 1x1 residual convs)
+    int mix = 0, route_f32 = 0;
+    // OP_CAST: fp32 tensor -> 16-bit copy (the stride-2 conv that leaves the fp32 level reads it)
+    int cast_src = -1, cast_dst = -1;
     // level engine (lvl_engine.hip): index of the run that executes this op (-1: its own launch); the run's first op launches it
     int lvl = -1, lvl_first = 0;
 };
@@ -128,6 +135,8 @@ struct dmme_plan {
     dmme_unet_cfg cfg;
     int B, H, W, dtype, device;
     int x3 = 0;            // DMME_BF16X3: dtype is DMME_F32 (storage), the convolutions take the three-pass bf16 MFMA path
+    int mix = 0;           // DMME_F16R32: dtype is DMME_F16; the tensors of the full-resolution level are fp32 and its convolutions run
+                           // three fp16 MFMA passes on hi / lo halves (or, for the few small ones, the fp32-tensor kernels above)
     int out_channels = 0;  // in_channels (DDPM) or 2 * in_channels (IDDPM: eps, v)
     std::vector<Param> params;
     std::vector<Tensor> tensors;
@@ -332,6 +341,8 @@ int build_plan(dmme_plan* P) {
                 DMME_REQUIRE(!n.attn || n.cout % c.num_heads == 0, DMME_ERR_INVALID, "%s: attention width %d not divisible by num_heads=%d",
                              n.prefix.c_str(), n.cout, c.num_heads);
 
+    DMME_REQUIRE(!(P->mix && has_attn(1)), DMME_ERR_UNSUPPORTED, "precision fp16r32: attention at the full-resolution level (attention_depths contains 1) is not supported");
+
     // ---- parameter table in nn.Module registration order ----
     Builder bld{P};
     const int half = c.pos_dim / 2;
@@ -366,30 +377,32 @@ int build_plan(dmme_plan* P) {
                 P->tblocks.push_back({n.tw, n.tb, n.tproj_col, width});
             }
     P->tproj_cols = tcols;
-    int64_t cur = 0;
-    P->tproj_w_off = cur;
-    cur = align_up(cur + (int64_t)tcols * c.emb_dim * es, 256);
-    P->tproj_b_off = cur;
-    cur = align_up(cur + (int64_t)tcols * 4, 256);
-    std::unordered_map<int, const Node*> tw_owner, tb_owner;
-    for (auto* seq : {&down, &up, &mid})
-        for (auto& n : *seq)
-            if (n.kind == 0) {
-                tw_owner[n.tw] = &n;
-                tb_owner[n.tb] = &n;
+    auto layout_packed = [&]() {
+        int64_t cur = 0;
+        P->tproj_w_off = cur;
+        cur = align_up(cur + (int64_t)tcols * c.emb_dim * es, 256);
+        P->tproj_b_off = cur;
+        cur = align_up(cur + (int64_t)tcols * 4, 256);
+        std::unordered_map<int, const Node*> tw_owner, tb_owner;
+        for (auto* seq : {&down, &up, &mid})
+            for (auto& n : *seq)
+                if (n.kind == 0) {
+                    tw_owner[n.tw] = &n;
+                    tb_owner[n.tb] = &n;
+                }
+        for (int i = 0; i < (int)P->params.size(); ++i) {
+            Param& p = P->params[i];
+            if (tw_owner.count(i)) {
+                p.packed_off = P->tproj_w_off + (int64_t)tw_owner[i]->tproj_col * c.emb_dim * es;
+            } else if (tb_owner.count(i)) {
+                p.packed_off = P->tproj_b_off + (int64_t)tb_owner[i]->tproj_col * 4;
+            } else {
+                p.packed_off = cur;
+                cur = align_up(cur + p.numel() * ((p.as_f32 || p.pack_code >= 3) ? 4 : es), 256);
             }
-    for (int i = 0; i < (int)P->params.size(); ++i) {
-        Param& p = P->params[i];
-        if (tw_owner.count(i)) {
-            p.packed_off = P->tproj_w_off + (int64_t)tw_owner[i]->tproj_col * c.emb_dim * es;
-        } else if (tb_owner.count(i)) {
-            p.packed_off = P->tproj_b_off + (int64_t)tb_owner[i]->tproj_col * 4;
-        } else {
-            p.packed_off = cur;
-            cur = align_up(cur + p.numel() * (p.as_f32 ? 4 : es), 256);
         }
-    }
-    P->packed_bytes = cur;
+        P->packed_bytes = cur;
+    };
     {   // transposed + tap-flipped conv weights for the data-gradient convolutions
         int64_t bc = 0;
         for (Param& p : P->params)
@@ -407,12 +420,14 @@ int build_plan(dmme_plan* P) {
         ws = align_up(ws + bytes, 256);
         return o;
     };
-    auto new_tensor = [&](int C, int H, int W) {
+    auto is_top = [&](int H_, int W_) { return P->mix && H_ == P->H && W_ == P->W; };
+    auto new_tensor = [&](int C, int H, int W, int force16 = 0) {
         Tensor t;
         t.C = C;
         t.H = H;
         t.W = W;
-        t.off = ws_alloc((int64_t)B * H * W * C * es);
+        t.f32 = is_top(H, W) && !force16;
+        t.off = ws_alloc((int64_t)B * H * W * C * (t.f32 ? 4 : es));
         P->tensors.push_back(t);
         return (int)P->tensors.size() - 1;
     };
@@ -468,6 +483,10 @@ int build_plan(dmme_plan* P) {
         o.kind = OP_CONV;
         o.src1 = -2; o.w = icw; o.b = icb; o.taps = 9;
         o.dst = new_tensor(chans[0], H, W);
+        if (P->mix) {  // fp32 in, fp32 out: the fp32 instance of the input conv (its 27-deep products are fp32 MFMAs anyway)
+            o.route_f32 = 1;
+            P->params[icw].pack_code = 3;
+        }
         ops.push_back(o);
         cur_t = o.dst;
         P->named["input_conv"] = cur_t;
@@ -484,6 +503,11 @@ int build_plan(dmme_plan* P) {
         c1.src1 = x1; c1.src2 = x2; c1.w = n.c1w; c1.b = n.c1b; c1.gn = g1; c1.pro_silu = 1;
         c1.tproj_col = iddpm ? -1 : n.tproj_col; c1.taps = 9;  // DDPM: h += Linear(t_emb) in the epilogue (models/ddpm.py:129)
         c1.dst = new_tensor(n.cout, h, w);
+        const bool top = is_top(h, w);
+        if (top) {
+            c1.mix = 1;
+            P->params[n.c1w].pack_code = 4;
+        }
         ops.push_back(c1);
         const int hmid = c1.dst;
         const int g2 = emit_gn(hmid, -1, n.gn2w, n.gn2b);
@@ -497,6 +521,10 @@ int build_plan(dmme_plan* P) {
             rc.kind = OP_CONV;
             rc.src1 = x1; rc.src2 = x2; rc.w = n.rw; rc.b = n.rb; rc.taps = 1;
             rc.dst = new_tensor(n.cout, h, w);
+            if (top) {
+                rc.route_f32 = 1;
+                P->params[n.rw].pack_code = 3;
+            }
             ops.push_back(rc);
             r1 = rc.dst;
             r2 = -1;
@@ -508,6 +536,10 @@ int build_plan(dmme_plan* P) {
         dmask_cursor += (int64_t)B * n.cout;
         c2.res1 = r1; c2.res2 = r2;
         c2.dst = new_tensor(n.cout, h, w);
+        if (top) {
+            c2.mix = 1;
+            P->params[n.c2w].pack_code = 4;
+        }
         ops.push_back(c2);
         int out = c2.dst;
         if (n.attn) {
@@ -540,6 +572,14 @@ int build_plan(dmme_plan* P) {
             cur_t = emit_res(n, cur_t, -1);
         } else {
             DMME_REQUIRE(H % 2 == 0 && W % 2 == 0, DMME_ERR_UNSUPPORTED, "odd resolution %dx%d at a DownSample", H, W);
+            if (P->tensors[cur_t].f32) {  // leaving the fp32 level: the stride-2 conv reads a 16-bit copy
+                Op cs{};
+                cs.kind = OP_CAST;
+                cs.cast_src = cur_t;
+                cs.cast_dst = new_tensor(P->tensors[cur_t].C, H, W, 1);
+                ops.push_back(cs);
+                cur_t = cs.cast_dst;
+            }
             Op o{};
             o.kind = OP_CONV;
             o.src1 = cur_t; o.w = n.cw; o.b = n.cb; o.taps = 9; o.stride = 2;
@@ -567,6 +607,10 @@ int build_plan(dmme_plan* P) {
             o.src1 = cur_t; o.w = n.cw; o.b = n.cb; o.taps = 9; o.up = 1;
             H *= 2; W *= 2;
             o.dst = new_tensor(n.cout, H, W);
+            if (is_top(H, W)) {  // entering the fp32 level from the 16-bit one: split passes on a 16-bit source
+                o.mix = P->tensors[cur_t].f32 ? 1 : 2;
+                P->params[n.cw].pack_code = 4;
+            }
             ops.push_back(o);
             cur_t = o.dst;
             P->named[n.prefix] = cur_t;
@@ -577,9 +621,14 @@ int build_plan(dmme_plan* P) {
         Op o{};
         o.kind = OP_CONV;
         o.src1 = cur_t; o.w = ocw; o.b = ocb; o.gn = g; o.pro_silu = 1; o.taps = 9; o.dst = -2;
+        if (P->mix && P->tensors[cur_t].f32) {
+            o.mix = 3;
+            P->params[ocw].pack_code = 4;
+        }
         ops.push_back(o);
     }
     P->dropmask_numel = dmask_cursor;
+    layout_packed();  // (after the op list: a mixed plan's convs choose their filter layouts above)
     P->ws_gnpart = ws_alloc((int64_t)(gn_part_max ? gn_part_max : 1) * 4);
     {   // up to 4 partial images of the widest small-map conv (either direction: its data gradient has Cin outputs)
         int64_t mx = 0;
@@ -724,7 +773,7 @@ static void push_pack_items(const Param& p, int64_t dst_off, int as_f32, bool wi
 }
 
 int build_pack_items(dmme_plan* P, std::vector<PackItem>& items) {
-    for (const Param& p : P->params) push_pack_items(p, p.packed_off, p.as_f32 ? 1 : 0, false, items);
+    for (const Param& p : P->params) push_pack_items(p, p.packed_off, p.pack_code >= 0 ? p.pack_code : p.as_f32 ? 1 : 0, false, items);
     return DMME_OK;
 }
 
@@ -759,6 +808,9 @@ int build_unpack_items(dmme_plan* P, std::vector<PackItem>& items) {
     return DMME_OK;
 }
 
+// the dtype code a conv's kernels are selected by: the plan's, except the fp32-routed convs of a mixed plan
+static inline int conv_dt(const dmme_plan* P, const Op& o) { return o.route_f32 ? DMME_F32 : P->dtype; }
+
 int run_any_conv(int dtype, const ConvArgs& a, hipStream_t s) {
     if (conv_out_thin_supported(dtype, a)) return launch_conv_out_thin(a, s);
     if (conv1x1_pipe_supported(dtype, a)) return launch_conv1x1_pipe(dtype, a, s);
@@ -774,8 +826,9 @@ void fill_conv(const dmme_plan* P, const Op& o, const char* packed, const float*
                const float* drop_masks, int nt, ConvArgs& a, bool fwd = false) {
     const int64_t es = (int64_t)dtype_size(P->dtype);
     (void)es;
-    a.x3 = P->x3;
-    a.f16 = P->dtype == DMME_F16;
+    a.x3 = P->x3 || o.route_f32;
+    a.f16 = P->dtype == DMME_F16 && !o.route_f32;
+    a.mix = o.mix;
     a.N = P->B;
     if (o.src1 == -2) {
         a.src1 = x;
@@ -1370,7 +1423,7 @@ void assign_stats(dmme_plan* P) {
         fill_conv(P, o, (const char*)4096, (const float*)4096, (float*)4096, (char*)4096, nullptr, 1, a);
         a.nt = o.tproj_col >= 0 ? P->B : 0;  // training adds one time-embedding row per image
         int tiles = 0, px = 0;
-        if (!conv_stats_query(P->dtype, a, td.C / G, &tiles, &px)) continue;
+        if (!conv_stats_query(conv_dt(P, o), a, td.C / G, &tiles, &px)) continue;
         td.stats_tiles = tiles;
         td.stats_cnt = px * (td.C / G);
         td.stats_off = ws;
@@ -1416,8 +1469,8 @@ void assign_direct(dmme_plan* P) {
             cgs[k] = C / G;
         }
         a.gn_cg = P->tensors[t].C / G;
-        if (ok && conv_gn_direct_query(P->dtype, a, cgs, (int)uses[t].size())) elig[t] = 1;
-        else if (ok && P->tensors[t].C % G == 0 && conv_gn_direct_ws_query(P->dtype, a, cgs, (int)uses[t].size())) elig[t] = 2;  // no act output
+        if (ok && conv_gn_direct_query(conv_dt(P, o), a, cgs, (int)uses[t].size())) elig[t] = 1;
+        else if (ok && P->tensors[t].C % G == 0 && conv_gn_direct_ws_query(conv_dt(P, o), a, cgs, (int)uses[t].size())) elig[t] = 2;  // no act output
     }
     for (bool changed = true; changed;) {  // a norm needs all its sources, a tensor all its norms
         changed = false;
@@ -1520,7 +1573,7 @@ void assign_gn_in(dmme_plan* P) {
         ConvArgs a{};
         fill_conv(P, cv, (const char*)4096, (const float*)4096, (float*)4096, (char*)4096, nullptr, 1, a);
         a.nt = cv.tproj_col >= 0 ? P->B : 0;
-        if (!conv_gn_in_query(P->dtype, a)) continue;
+        if (!conv_gn_in_query(conv_dt(P, cv), a)) continue;
         g.gn_in_consumer = 1;
     }
 }
@@ -1546,7 +1599,8 @@ int run_gn(const dmme_plan* P, const Op& o, const char* pk, char* ws, int nt, co
                                         t2 ? t2->stats_cnt : 0, C2, P->B, P->cfg.num_groups, gam, bet, 1e-5f, sc, sh,
                                         (float*)(ws + o.gn_mr), tsh, tsc, P->tproj_cols, nt, s);
     }
-    if (gn_fast_supported(P->dtype, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups)) {
+    const int gdt = t1.f32 ? DMME_F32 : P->dtype;  // (a mixed plan's fp32 level; concatenated sources share a level)
+    if (gn_fast_supported(gdt, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups)) {
         void* act = nullptr;
         int act_silu = 0;
         const float* dm = nullptr;
@@ -1556,11 +1610,11 @@ int run_gn(const dmme_plan* P, const Op& o, const char* pk, char* ws, int nt, co
             act_silu = cv.pro_silu;
             if (cv.dmask_off >= 0 && drop_masks) dm = drop_masks + cv.dmask_off;
         }
-        rc = launch_gn_fast(P->dtype, s1, s2, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups, gam, bet, 1e-5f, sc, sh,
+        rc = launch_gn_fast(gdt, s1, s2, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups, gam, bet, 1e-5f, sc, sh,
                             (float*)(ws + o.gn_mr), (float*)(ws + P->ws_gnpart), s, act, act_silu, dm);
     }
     else
-        rc = launch_gn_generic(P->dtype, s1, s2, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups, gam, bet, 1e-5f, sc, sh,
+        rc = launch_gn_generic(gdt, s1, s2, P->B, t1.H * t1.W, t1.C, C2, P->cfg.num_groups, gam, bet, 1e-5f, sc, sh,
                                (float*)(ws + o.gn_mr), s);
     if (rc != DMME_OK || !tsh) return rc;
     return launch_gn_modulate(sc, sh, tsh, tsc, P->tproj_cols, nt, P->B, o.gn_mod_C, s);
@@ -1622,7 +1676,11 @@ int run_op(const dmme_plan* P, const Op& o, const char* pk, const float* x, cons
         case OP_CONV: {
             ConvArgs a{};
             fill_conv(P, o, pk, x, y, ws, drop_masks, nt, a, true);
-            return run_any_conv(P->dtype, a, s);
+            return run_any_conv(conv_dt(P, o), a, s);
+        }
+        case OP_CAST: {
+            const Tensor& ts = P->tensors[o.cast_src];
+            return launch_cast_f32_to_16(P->dtype, (const float*)(ws + ts.off), (int64_t)P->B * ts.H * ts.W * ts.C, ws + P->tensors[o.cast_dst].off, s);
         }
         case OP_ATTN: {
             const Tensor& q = P->tensors[o.at_qkv];
@@ -1686,20 +1744,27 @@ void op_account(const dmme_plan* P, const Op& o, char* label, int cap, double* f
         case OP_CONV: {
             ConvArgs a{};
             fill_conv(P, o, (const char*)4096, (const float*)4096, (float*)4096, (char*)4096, nullptr, 1, a, true);
-            if (conv_out_thin_supported(P->dtype, a))
-                snprintf(label, cap, "conv_out_thin_kernel<%d>", a.Cout * 9 <= 32 ? 1 : 2);
-            else if (conv1x1_pipe_supported(P->dtype, a))
-                conv1x1_pipe_label(P->dtype, a, label, cap);
-            else if (conv_pipe_supported(P->dtype, a))
-                conv_pipe_label(P->dtype, a, label, cap);
-            else if (conv_mfma_supported(P->dtype, a))
-                conv_mfma_label(P->dtype, a, label, cap);
+            const int cdt = conv_dt(P, o);
+            if (conv_out_thin_supported(cdt, a))
+                snprintf(label, cap, a.mix == 3 ? "conv_out_thin_kernel<%d,f16x3>" : "conv_out_thin_kernel<%d>", a.Cout * 9 <= 32 ? 1 : 2);
+            else if (conv1x1_pipe_supported(cdt, a))
+                conv1x1_pipe_label(cdt, a, label, cap);
+            else if (conv_pipe_supported(cdt, a))
+                conv_pipe_label(cdt, a, label, cap);
+            else if (conv_mfma_supported(cdt, a))
+                conv_mfma_label(cdt, a, label, cap);
             else
-                snprintf(label, cap, "%s<%s>", conv_generic_kernel_name(a), tn);
+                snprintf(label, cap, "%s<%s>", conv_generic_kernel_name(a), o.route_f32 ? "float" : tn);
             const double Cin = a.C1 + a.C2, opix = B * a.Hout * a.Wout;
             *flops = 2.0 * opix * a.Cout * Cin * a.taps;
             *bytes = B * a.Hin * a.Win * Cin * (a.in_nchw ? 4.0 : es) + opix * a.Cout * (a.out_nchw ? 4.0 : es) +
                      (double)a.Cout * Cin * a.taps * es + (a.res1 ? opix * a.Cout * es : 0.0);
+            break;
+        }
+        case OP_CAST: {
+            const Tensor& ts = P->tensors[o.cast_src];
+            snprintf(label, cap, "cast_f32_to_16_kernel");
+            *bytes = B * ts.H * ts.W * ts.C * 6.0;
             break;
         }
         case OP_ATTN: {
@@ -1734,9 +1799,15 @@ DMME_API int dmme_device_count(void) {
 DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W, int dtype, int device, dmme_plan** out) {
     DMME_REQUIRE(cfg && out, DMME_ERR_INVALID, "plan_create: null argument");
     DMME_REQUIRE(B > 0 && H > 0 && W > 0, DMME_ERR_INVALID, "plan_create: bad shape B=%d H=%d W=%d", B, H, W);
-    DMME_REQUIRE(dtype == DMME_F32 || dtype == DMME_BF16 || dtype == DMME_BF16X3 || dtype == DMME_F16, DMME_ERR_INVALID, "plan_create: bad dtype %d", dtype);
+    DMME_REQUIRE(dtype == DMME_F32 || dtype == DMME_BF16 || dtype == DMME_BF16X3 || dtype == DMME_F16 || dtype == DMME_F16R32, DMME_ERR_INVALID,
+                 "plan_create: bad dtype %d", dtype);
     const int x3 = dtype == DMME_BF16X3;
     if (x3) dtype = DMME_F32;
+    const int mix = dtype == DMME_F16R32;
+    if (mix) {
+        dtype = DMME_F16;
+        DMME_REQUIRE(cfg->arch == DMME_ARCH_DDPM, DMME_ERR_UNSUPPORTED, "plan_create: precision fp16r32 serves the DDPM UNet (models/ddpm.py) only");
+    }
     DMME_REQUIRE(cfg->num_depths >= 1 && cfg->num_depths <= 8 && cfg->num_blocks >= 1, DMME_ERR_INVALID,
                  "plan_create: bad depth/blocks");
     DMME_REQUIRE(cfg->num_attention_depths >= 0 && cfg->num_attention_depths <= 8, DMME_ERR_INVALID, "bad attention_depths");
@@ -1756,11 +1827,26 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
     P->W = W;
     P->dtype = dtype;
     P->x3 = x3;
+    P->mix = mix;
     P->device = device;
     int rc = build_plan(P);
     if (rc != DMME_OK) {
         delete P;
         return rc;
+    }
+    if (P->mix) {  // every conv of the fp32 level must have its kernel: there is no fall-back to a 16-bit path that would read fp32 as halves
+        for (const Op& o : P->ops) {
+            if (o.kind != OP_CONV || !(o.mix || o.route_f32)) continue;
+            ConvArgs a{};
+            fill_conv(P, o, (const char*)4096, (const float*)4096, (float*)4096, (char*)4096, nullptr, 1, a);
+            const bool ok = o.mix == 3 ? conv_out_thin_supported(P->dtype, a) : o.mix ? conv_pipe_supported(P->dtype, a) : true;
+            if (!ok) {
+                set_error("plan_create: precision fp16r32 has no kernel for the %dx%d conv %d+%d -> %d channels on the %dx%d level (B = %d)", o.taps == 9 ? 3 : 1,
+                          o.taps == 9 ? 3 : 1, a.C1, a.C2, a.Cout, a.Hout, a.Wout, B);
+                delete P;
+                return DMME_ERR_UNSUPPORTED;
+            }
+        }
     }
     assign_levels(P);
     if (!getenv("DMME_NO_FUSED_GN")) assign_stats(P);
@@ -2114,6 +2200,7 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
                  "unet_backward: null argument");
     DMME_REQUIRE(t_len == 1 || t_len == plan->B, DMME_ERR_INVALID, "unet_backward: bad t_len %d", t_len);
     if (int rc0 = lvl_check(plan, "unet_backward", (hipStream_t)stream, true)) return rc0;  // (the forward this backward differentiates ran through the engine)
+    DMME_REQUIRE(!plan->mix, DMME_ERR_UNSUPPORTED, "unet_backward: precision fp16r32 is an inference mode");
     DMME_REQUIRE(plan->dtype != DMME_F16, DMME_ERR_UNSUPPORTED,
                  "unet_backward: precision fp16 is an inference mode (no loss scaling in the HIP backward); train in bf16, bf16x3 or fp32");
     const dmme_plan* P = plan;
@@ -2535,7 +2622,7 @@ DMME_API int dmme_unet_debug_read(const dmme_plan* plan, const void* workspace, 
     DMME_REQUIRE(n <= numel_cap, DMME_ERR_INVALID, "debug_read: destination too small (%lld > %lld)", (long long)n,
                  (long long)numel_cap);
     if (numel_out) *numel_out = n;
-    return launch_nhwc_to_nchw(plan->dtype, (const char*)workspace + t.off, plan->B, t.C, t.H * t.W, dst, s);
+    return launch_nhwc_to_nchw(t.f32 ? DMME_F32 : plan->dtype, (const char*)workspace + t.off, plan->B, t.C, t.H * t.W, dst, s);
 }
 
 DMME_API int dmme_dropout_masks(const dmme_plan* plan, uint64_t seed, uint64_t offset, float* masks, void* stream) {

@@ -54,7 +54,12 @@ typedef enum {
  * convolution product runs as three bf16 MFMA passes over hi/lo splits of its fp32 operands (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi,
  * fp32 accumulation), ~2^-16 per product instead of 2^-9: within 1e-3 of the fp32 reference at the bf16 matrix rate / 3.
  * Accepted wherever a dtype is (plans and the single-op entry points); buffers are the fp32 ones. */
-typedef enum { DMME_F32 = 0, DMME_BF16 = 1, DMME_BF16X3 = 2, DMME_F16 = 3 } dmme_dtype;
+/* DMME_F16R32: the reduced-precision mode that stays within 1e-3 of the fp32 reference (precision="fp16r32", inference).  A
+ * DMME_F16 plan whose FULL-RESOLUTION level - where a rounding error reaches the output undamped: the first and last ResBlocks,
+ * the skip tensors between them, input and output conv (models/ddpm.py:293-295, 308-315) - keeps its tensors in fp32 and runs
+ * every product as three fp16 MFMA passes over hi / lo halves of both operands (csrc/conv_pipe.hip: conv3x3_ws2_kernel<.., SPLIT>);
+ * every level below it is plain DMME_F16.  Workspace and packed sizes differ from DMME_F16's (query them). */
+typedef enum { DMME_F32 = 0, DMME_BF16 = 1, DMME_BF16X3 = 2, DMME_F16 = 3, DMME_F16R32 = 4 } dmme_dtype;
 
 /* Which of the reference's two UNets the plan builds. */
 typedef enum {

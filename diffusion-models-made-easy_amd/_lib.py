@@ -99,6 +99,9 @@ PROTOTYPES = {
     "dmme_unet_plan_bwd_summary": (_i, [_vp, C.c_char_p, _i]),
     "dmme_grad_norm": (_i, [_vp, _i64, _vp, _vp, _vp]),
     "dmme_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _vp, _f, _f, _f, _vp]),
+    "dmme_amp_init": (_i, [_vp, _f, _vp]),
+    "dmme_amp_scale": (_i, [_vp, _i64, _vp, _vp]),
+    "dmme_adam_step_amp": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _vp, _f, _f, _f, _vp, _f, _f, _i, _vp]),
     "dmme_grad_pack_bf16": (_i, [_vp, _i64, _vp, _i64, _vp]),
     "dmme_shard_reduce_bf16": (_i, [_vp, _i, _i64, _f, _vp, _vp]),
     "dmme_grad_unpack_bf16": (_i, [_vp, _i64, _vp, _vp]),

@@ -728,10 +728,10 @@ int launch_attn_mfma(int dtype, const void* qkv, int N, int S, int C, void* out,
 // (attn_bgemm): dV = P^T dO and dK = s dS^T Q contract over the ROW index of two row-major
 // matrices (both fragments via transposed LDS reads), dQ = s dS K is a row-major A times a
 // transposed-read B.
-template <int C, int NW>
-__global__ void __launch_bounds__(64 * NW, 1) attn_bwd_scores_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ O,
-                                                              const bf16* __restrict__ dO, const float* __restrict__ lse, AttnGeom g,
-                                                              bf16* __restrict__ P, bf16* __restrict__ dS) {
+template <int C, int NW, typename T>
+__global__ void __launch_bounds__(64 * NW, 1) attn_bwd_scores_kernel(const T* __restrict__ qkv, const T* __restrict__ O,
+                                                              const T* __restrict__ dO, const float* __restrict__ lse, AttnGeom g,
+                                                              T* __restrict__ P, T* __restrict__ dS) {
     constexpr int AT_QB = 32 * NW, NT = 64 * NW;
     const int S = g.S, ld = g.ld;
     constexpr int KSTEPS = C / 16;
@@ -743,7 +743,7 @@ __global__ void __launch_bounds__(64 * NW, 1) attn_bwd_scores_kernel(const bf16*
     const int r = lane & 31, h = lane >> 5;
     const int qblocks = S / AT_QB;
     const int n = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;  // n: the (image, head) row
-    const bf16* base = qkv + at_qkv_off<C>(g, n);
+    const T* base = qkv + at_qkv_off<C>(g, n);
     const int64_t orow = at_o_off<C>(g, n);
     const int q_row = qb * AT_QB + wave * 32 + r;
     uint4 qf[KSTEPS], dof[KSTEPS];
@@ -753,15 +753,15 @@ __global__ void __launch_bounds__(64 * NW, 1) attn_bwd_scores_kernel(const bf16*
         qf[ks] = *reinterpret_cast<const uint4*>(base + (int64_t)q_row * ld + ks * 16 + h * 8);
         dof[ks] = *reinterpret_cast<const uint4*>(dO + orow + (int64_t)q_row * g.Cfull + ks * 16 + h * 8);
         const uint4 ov = *reinterpret_cast<const uint4*>(O + orow + (int64_t)q_row * g.Cfull + ks * 16 + h * 8);
-        const bf16x8 a = __builtin_bit_cast(bf16x8, dof[ks]), b = __builtin_bit_cast(bf16x8, ov);
+        const typename Vec8<T>::type a = __builtin_bit_cast(typename Vec8<T>::type, dof[ks]), b = __builtin_bit_cast(typename Vec8<T>::type, ov);
 #pragma unroll
         for (int j = 0; j < 8; ++j) dpart = fmaf((float)a[j], (float)b[j], dpart);
     }
     const float delta = dpart + __shfl_xor(dpart, 32, 64);
     const float L = lse[(int64_t)n * S + q_row];
     const float c1 = 1.4426950408889634f * g.scale;
-    bf16* Prow = P + ((int64_t)n * S + q_row) * S;
-    bf16* dSrow = dS + ((int64_t)n * S + q_row) * S;
+    T* Prow = P + ((int64_t)n * S + q_row) * S;
+    T* dSrow = dS + ((int64_t)n * S + q_row) * S;
 
     // K / V tiles a tile ahead, through registers: one wave per SIMD has nothing else to put under a tile's global round trip (the
     // load-store-barrier form spent 8 exposed round trips per workgroup: 50 us per launch for 8.6 GFLOP)
@@ -772,7 +772,7 @@ __global__ void __launch_bounds__(64 * NW, 1) attn_bwd_scores_kernel(const bf16*
 #define ATB_FETCH(K0)                                                                     \
     _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                       \
         const int u = tid + i * NT, row = u / (C / 8), cu = u % (C / 8);                   \
-        const bf16* src = base + (int64_t)((K0) + row) * ld + cu * 8;                      \
+        const T* src = base + (int64_t)((K0) + row) * ld + cu * 8;                      \
         kreg[i] = *reinterpret_cast<const atb_u32x4*>(src + C);                            \
         vreg[i] = *reinterpret_cast<const atb_u32x4*>(src + 2 * C);                        \
     }
@@ -797,19 +797,19 @@ __global__ void __launch_bounds__(64 * NW, 1) attn_bwd_scores_kernel(const bf16*
         for (int ks = 0; ks < KSTEPS; ++ks) {
             const uint4 kf = *reinterpret_cast<const uint4*>(ldsK + r * KP + ks * 32 + h * 16);
             const uint4 vf = *reinterpret_cast<const uint4*>(ldsV + r * KP + ks * 32 + h * 16);
-            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[ks]), st, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, dof[ks]), dp, 0, 0, 0);
+            st = mma16v<T>(kf, qf[ks], st);
+            dp = mma16v<T>(vf, dof[ks], dp);
         }
         // registers j <-> key k0 + (j&3) + 8*(j>>2) + 4*h : four consecutive keys per register quad
-        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        typedef T bf16x4 __attribute__((ext_vector_type(4)));  // (four operands of the kernel's 16-bit type)
 #pragma unroll
         for (int jg = 0; jg < 4; ++jg) {
             bf16x4 pv, dv;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float p = exp2f(fmaf(st[jg * 4 + e], c1, -L));
-                pv[e] = (bf16)p;
-                dv[e] = (bf16)(p * (dp[jg * 4 + e] - delta));
+                pv[e] = (T)p;
+                dv[e] = (T)(p * (dp[jg * 4 + e] - delta));
             }
             *reinterpret_cast<bf16x4*>(Prow + k0 + 8 * jg + 4 * h) = pv;
             *reinterpret_cast<bf16x4*>(dSrow + k0 + 8 * jg + 4 * h) = dv;
@@ -818,16 +818,16 @@ __global__ void __launch_bounds__(64 * NW, 1) attn_bwd_scores_kernel(const bf16*
 #undef ATB_FETCH
 }
 
-// per-image GEMM  out[m][n] = alpha * sum_k A(m,k) B(k,n),  M = K = S, N = C (bf16 in, fp32 accumulate)
+// per-image GEMM  out[m][n] = alpha * sum_k A(m,k) B(k,n),  M = K = S, N = C (T in, fp32 accumulate)
 //   TRANS_A = 1: A(m,k) = X[k][m]  (X row-major [S][S], ldx = S)      -- dV, dK
 //   TRANS_A = 0: A(m,k) = X[m][k]                                      -- dQ
 //   B(k,n) = Y[k][n] (row-major, ldy), fragments by transposed LDS reads.
 // One workgroup = one (image, head) row x 64 rows of the output; the 4 waves split the C columns (C >= 128), or 2 x 2 over
 // (rows, columns) for C = 64.  Y and out are addressed through the head view: Y_O = 1 reads an output-layout tensor (dO),
 // else a qkv-layout one at column offset ycol; out is always qkv-layout (dqkv) at column offset ocol.
-template <int C, int TRANS_A, int Y_O>
-__global__ void __launch_bounds__(256) attn_bgemm_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Y, int ycol, AttnGeom g, float alpha,
-                                                         bf16* __restrict__ out, int ocol) {
+template <int C, int TRANS_A, int Y_O, typename T>
+__global__ void __launch_bounds__(256) attn_bgemm_kernel(const T* __restrict__ X, const T* __restrict__ Y, int ycol, AttnGeom g, float alpha,
+                                                         T* __restrict__ out, int ocol) {
     constexpr int WM = C >= 128 ? 1 : 2;   // waves along the 64 output rows
     constexpr int MI = 2 / WM;             // 32-row tiles per wave
     constexpr int WN = C / (4 / WM);       // columns per wave
@@ -844,8 +844,8 @@ __global__ void __launch_bounds__(256) attn_bgemm_kernel(const bf16* __restrict_
     const int mblocks = S / 64;
     const int n = blockIdx.x / mblocks, m0 = (blockIdx.x % mblocks) * 64;
     const int wm = WM == 1 ? 0 : wave >> 1, wn = WM == 1 ? wave : wave & 1;
-    const bf16* Xi = X + (int64_t)n * S * S;
-    const bf16* Yi = Y + (Y_O ? at_o_off<C>(g, n) : at_qkv_off<C>(g, n) + ycol);
+    const T* Xi = X + (int64_t)n * S * S;
+    const T* Yi = Y + (Y_O ? at_o_off<C>(g, n) : at_qkv_off<C>(g, n) + ycol);
     const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g1 = (lane >> 4) & 1;
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -920,12 +920,12 @@ __global__ void __launch_bounds__(256) attn_bgemm_kernel(const bf16* __restrict_
                 bfr[4] = hi[0]; bfr[5] = hi[1]; bfr[6] = hi[2]; bfr[7] = hi[3];
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mi]), __builtin_bit_cast(bf16x8, bfr), acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = mma16v<T>(af[mi], bfr, acc[mi][ni]);
             }
         }
     }
 #undef BG_FETCH
-    bf16* Oi = out + at_qkv_off<C>(g, n) + ocol;
+    T* Oi = out + at_qkv_off<C>(g, n) + ocol;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -933,28 +933,28 @@ __global__ void __launch_bounds__(256) attn_bgemm_kernel(const bf16* __restrict_
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int m = m0 + (wm * MI + mi) * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
-                Oi[(int64_t)m * ldo + wn * WN + ni * 32 + r] = (bf16)(acc[mi][ni][j] * alpha);
+                Oi[(int64_t)m * ldo + wn * WN + ni * 32 + r] = (T)(acc[mi][ni][j] * alpha);
             }
 }
 
-bool attn_bwd_mfma_supported(int dtype, int N, int S, int C) { return dtype == DMME_BF16 && attn_heads_mfma_supported(dtype, N, S, C, 1); }
+bool attn_bwd_mfma_supported(int dtype, int N, int S, int C) { return is16(dtype) && attn_heads_mfma_supported(dtype, N, S, C, 1); }
 
-template <int D>
-static int launch_attn_bwd_t(const bf16* qkv, const bf16* O, const bf16* dO, const float* lse, const AttnGeom& g, bf16* P, bf16* dS, bf16* dqkv,
+template <int D, typename T>
+static int launch_attn_bwd_t(const T* qkv, const T* O, const T* dO, const float* lse, const AttnGeom& g, T* P, T* dS, T* dqkv,
                              hipStream_t s) {
     const int rows = g.N * g.heads, S = g.S;
     if (S % 128 == 0)
-        hipLaunchKernelGGL((attn_bwd_scores_kernel<D, 4>), dim3((unsigned)(rows * (S / 128))), dim3(256), 0, s, qkv, O, dO, lse, g, P, dS);
+        hipLaunchKernelGGL((attn_bwd_scores_kernel<D, 4, T>), dim3((unsigned)(rows * (S / 128))), dim3(256), 0, s, qkv, O, dO, lse, g, P, dS);
     else
-        hipLaunchKernelGGL((attn_bwd_scores_kernel<D, 2>), dim3((unsigned)(rows * (S / 64))), dim3(128), 0, s, qkv, O, dO, lse, g, P, dS);
+        hipLaunchKernelGGL((attn_bwd_scores_kernel<D, 2, T>), dim3((unsigned)(rows * (S / 64))), dim3(128), 0, s, qkv, O, dO, lse, g, P, dS);
     DMME_CHECK_LAUNCH();
     const dim3 grid((unsigned)(rows * (S / 64)));
     // dV = P^T dO ; dK = s dS^T Q ; dQ = s dS K
-    hipLaunchKernelGGL((attn_bgemm_kernel<D, 1, 1>), grid, dim3(256), 0, s, P, dO, 0, g, 1.0f, dqkv, 2 * D);
+    hipLaunchKernelGGL((attn_bgemm_kernel<D, 1, 1, T>), grid, dim3(256), 0, s, P, dO, 0, g, 1.0f, dqkv, 2 * D);
     DMME_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_bgemm_kernel<D, 1, 0>), grid, dim3(256), 0, s, dS, qkv, 0, g, g.scale, dqkv, D);
+    hipLaunchKernelGGL((attn_bgemm_kernel<D, 1, 0, T>), grid, dim3(256), 0, s, dS, qkv, 0, g, g.scale, dqkv, D);
     DMME_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_bgemm_kernel<D, 0, 0>), grid, dim3(256), 0, s, dS, qkv, D, g, g.scale, dqkv, 0);
+    hipLaunchKernelGGL((attn_bgemm_kernel<D, 0, 0, T>), grid, dim3(256), 0, s, dS, qkv, D, g, g.scale, dqkv, 0);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }
@@ -964,10 +964,17 @@ int launch_attn_heads_bwd_mfma(int dtype, const void* qkv, const void* O, const 
                                void* dS, void* dqkv, hipStream_t s) {
     DMME_REQUIRE(attn_heads_mfma_supported(dtype, N, S, C, heads), DMME_ERR_UNSUPPORTED, "attn_bwd_mfma: unsupported shape");
     const AttnGeom g = attn_geom(N, S, C, heads);
+    if (dtype == DMME_F16) {
+        switch (C / heads) {
+            case 256: return launch_attn_bwd_t<256, f16>((const f16*)qkv, (const f16*)O, (const f16*)dO, lse, g, (f16*)P, (f16*)dS, (f16*)dqkv, s);
+            case 128: return launch_attn_bwd_t<128, f16>((const f16*)qkv, (const f16*)O, (const f16*)dO, lse, g, (f16*)P, (f16*)dS, (f16*)dqkv, s);
+            default: return launch_attn_bwd_t<64, f16>((const f16*)qkv, (const f16*)O, (const f16*)dO, lse, g, (f16*)P, (f16*)dS, (f16*)dqkv, s);
+        }
+    }
     switch (C / heads) {
-        case 256: return launch_attn_bwd_t<256>((const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, g, (bf16*)P, (bf16*)dS, (bf16*)dqkv, s);
-        case 128: return launch_attn_bwd_t<128>((const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, g, (bf16*)P, (bf16*)dS, (bf16*)dqkv, s);
-        default: return launch_attn_bwd_t<64>((const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, g, (bf16*)P, (bf16*)dS, (bf16*)dqkv, s);
+        case 256: return launch_attn_bwd_t<256, bf16>((const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, g, (bf16*)P, (bf16*)dS, (bf16*)dqkv, s);
+        case 128: return launch_attn_bwd_t<128, bf16>((const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, g, (bf16*)P, (bf16*)dS, (bf16*)dqkv, s);
+        default: return launch_attn_bwd_t<64, bf16>((const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, g, (bf16*)P, (bf16*)dS, (bf16*)dqkv, s);
     }
 }
 int launch_attn_bwd_mfma(int dtype, const void* qkv, const void* O, const void* dO, const float* lse, int N, int S, int C, void* P, void* dS,

@@ -11,7 +11,6 @@
 
 namespace dmme {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <typename T>
 __device__ __forceinline__ void load_vec(const T* p, float (&v)[16 / sizeof(T)]) {
@@ -20,7 +19,7 @@ __device__ __forceinline__ void load_vec(const T* p, float (&v)[16 / sizeof(T)])
         const float4 f = __builtin_bit_cast(float4, raw);
         v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
     } else {
-        const bf16x8 b = __builtin_bit_cast(bf16x8, raw);
+        const typename Vec8<T>::type b = __builtin_bit_cast(typename Vec8<T>::type, raw);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (float)b[j];
     }
@@ -38,7 +37,7 @@ __device__ __forceinline__ void unpack_vec(const uint4& raw, float (&v)[16 / siz
         const float4 f = __builtin_bit_cast(float4, raw);
         v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
     } else {
-        const bf16x8 b = __builtin_bit_cast(bf16x8, raw);
+        const typename Vec8<T>::type b = __builtin_bit_cast(typename Vec8<T>::type, raw);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (float)b[j];
     }
@@ -48,10 +47,10 @@ __device__ __forceinline__ void store_vec(T* p, const float (&v)[16 / sizeof(T)]
     if constexpr (sizeof(T) == 4) {
         *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     } else {
-        bf16x8 b;
+        typename Vec8<T>::type b;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) b[j] = (bf16)v[j];
-        *reinterpret_cast<bf16x8*>(p) = b;
+        for (int j = 0; j < 8; ++j) b[j] = (T)v[j];
+        *reinterpret_cast<typename Vec8<T>::type*>(p) = b;
     }
 }
 
@@ -68,7 +67,7 @@ __device__ __forceinline__ float silu_grad_f(float u) {
 // geometry shared by the kernels: a workgroup owns `chunk_px` pixels of one image, thread -> fixed
 // 16-byte channel slot (tid % VPP) and pixel row phase (tid / VPP)
 static bool vec_geometry(int dtype, int HW, int C, int& chunk_px, int& nchunks, int& ppw_out) {
-    const int EPV = dtype == DMME_BF16 ? 8 : 4;
+    const int EPV = is16(dtype) ? 8 : 4;
     if (C % EPV) return false;
     const int VPP = C / EPV;
     if (VPP > 256) return false;
@@ -188,6 +187,8 @@ int launch_colsum_group(int dtype, const ColJob* jobs_dev, int njobs, void* bws,
     dim3 grid((unsigned)njobs, (unsigned)N);
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(colsum_group_kernel<bf16>, grid, dim3(256), 0, s, jobs_dev, (char*)bws);
+    else if (dtype == DMME_F16)
+        hipLaunchKernelGGL(colsum_group_kernel<f16>, grid, dim3(256), 0, s, jobs_dev, (char*)bws);
     else
         hipLaunchKernelGGL(colsum_group_kernel<float>, grid, dim3(256), 0, s, jobs_dev, (char*)bws);
     DMME_CHECK_LAUNCH();
@@ -231,6 +232,8 @@ int launch_colsum_fast(int dtype, const void* dY, int N, int HW, int C, float* r
     dim3 grid(nchunks, N);
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(colsum_vec_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dY, HW, C, chunk_px, ppw, rowsum);
+    else if (dtype == DMME_F16)
+        hipLaunchKernelGGL(colsum_vec_kernel<f16>, grid, dim3(256), 0, s, (const f16*)dY, HW, C, chunk_px, ppw, rowsum);
     else
         hipLaunchKernelGGL(colsum_vec_kernel<float>, grid, dim3(256), 0, s, (const float*)dY, HW, C, chunk_px, ppw, rowsum);
     DMME_CHECK_LAUNCH();
@@ -643,17 +646,19 @@ __global__ void __launch_bounds__(256) grad_acc_vec_kernel(const T* __restrict__
     }
 }
 bool grad_acc_fast_supported(int dtype, int C1, int C2, int pool) {
-    const int EPV = dtype == DMME_BF16 ? 8 : 4;
+    const int EPV = is16(dtype) ? 8 : 4;
     return !pool && C1 % EPV == 0 && C2 % EPV == 0;
 }
 int launch_grad_acc_fast(int dtype, const void* src, void* d1, void* d2, int C1, int C2, int acc1, int acc2, int64_t npix, hipStream_t s) {
-    const int EPV = dtype == DMME_BF16 ? 8 : 4;
+    const int EPV = is16(dtype) ? 8 : 4;
     const int64_t nvec = npix * ((C1 + C2) / EPV);
     if (nvec == 0) return DMME_OK;
     int64_t blocks = (nvec + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(grad_acc_vec_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16*)src, (bf16*)d1, (bf16*)d2, C1, C2, acc1, acc2, nvec);
+    else if (dtype == DMME_F16)
+        hipLaunchKernelGGL(grad_acc_vec_kernel<f16>, dim3((unsigned)blocks), dim3(256), 0, s, (const f16*)src, (f16*)d1, (f16*)d2, C1, C2, acc1, acc2, nvec);
     else
         hipLaunchKernelGGL(grad_acc_vec_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)src, (float*)d1, (float*)d2, C1, C2, acc1, acc2, nvec);
     DMME_CHECK_LAUNCH();
@@ -1050,7 +1055,7 @@ static int gn_bwd_regs_slices_cfg(GnRegsCfg cf, int N, int HW, int C1, int C2, i
 }
 // the configuration for a shape (-1: none) and its slices: the first that gives every CU a workgroup, else the first that fits
 static int gn_bwd_regs_pick(int dtype, int N, int HW, int C1, int C2, int groups, int* slices) {
-    if (getenv("DMME_NO_GN_BWD_REGS") || dtype != DMME_BF16) return -1;
+    if (getenv("DMME_NO_GN_BWD_REGS") || !is16(dtype)) return -1;
     int first = -1, first_slices = 0;
     for (int i = 0; i < (int)(sizeof(GN_REGS_CFGS) / sizeof(GN_REGS_CFGS[0])); ++i) {
         const int sl = gn_bwd_regs_slices_cfg(GN_REGS_CFGS[i], N, HW, C1, C2, groups);
@@ -1073,7 +1078,7 @@ static int gn_bwd_regs_slices(int dtype, int N, int HW, int C1, int C2, int grou
 }
 
 static bool gn_bwd_small_supported(int dtype, int HW, int C1, int C2, int groups) {
-    const int EPV = dtype == DMME_BF16 ? 8 : 4, C = C1 + C2;
+    const int EPV = is16(dtype) ? 8 : 4, C = C1 + C2;
     return HW <= 64 && C <= 512 && groups <= 64 && C % groups == 0 && C1 % EPV == 0 && C2 % EPV == 0 && C / EPV <= 256 && !getenv("DMME_NO_GN_SMALL");
 }
 
@@ -1086,7 +1091,7 @@ int gn_bwd_fast_chunks(int dtype, int HW, int C) {
 }
 
 bool gn_bwd_fast_supported(int dtype, int HW, int C1, int C2) {
-    const int EPV = dtype == DMME_BF16 ? 8 : 4;
+    const int EPV = is16(dtype) ? 8 : 4;
     int a, b, c;
     return (C1 % EPV) == 0 && vec_geometry(dtype, HW, C1 + C2, a, b, c);
 }
@@ -1110,10 +1115,15 @@ int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2
     if (const int rcfg = mod.t_scale ? -1 : gn_bwd_regs_pick(dtype, N, HW, C1, C2, groups, &rslices); rcfg >= 0) {
         // the four uniform switches of the two phases are template arguments: as branches inside one kernel the variants of a phase
         // shared one register allocation and spilled (240 bytes per lane against none)
-#define REGS_LAUNCH(I_, NT_, S_, A_, C_, E_)                                                                                                      \
-    hipLaunchKernelGGL((gn_bwd_regs_kernel<bf16, I_, NT_, S_, A_, C_, E_>), dim3(N, rslices), dim3(NT_), 0, s, (const bf16*)dv, (const bf16*)x1,    \
-                       (const bf16*)x2, HW, C1, C2, groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, (bf16*)dx1, (bf16*)dx2, acc1, acc2,    \
-                       dgamma, dbeta, (bf16*)act, rows, (const bf16*)extra)
+#define REGS_LAUNCH_T(TT, I_, NT_, S_, A_, C_, E_)                                                                                              \
+    hipLaunchKernelGGL((gn_bwd_regs_kernel<TT, I_, NT_, S_, A_, C_, E_>), dim3(N, rslices), dim3(NT_), 0, s, (const TT*)dv, (const TT*)x1,          \
+                       (const TT*)x2, HW, C1, C2, groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, (TT*)dx1, (TT*)dx2, acc1, acc2,          \
+                       dgamma, dbeta, (TT*)act, rows, (const TT*)extra)
+#define REGS_LAUNCH(I_, NT_, S_, A_, C_, E_)                              \
+    do {                                                                  \
+        if (dtype == DMME_F16) REGS_LAUNCH_T(f16, I_, NT_, S_, A_, C_, E_); \
+        else REGS_LAUNCH_T(bf16, I_, NT_, S_, A_, C_, E_);                \
+    } while (0)
 #define REGS_LAUNCH_CE(I_, NT_, S_, A_)                              \
     do {                                                             \
         if (acc1 || acc2) {                                          \
@@ -1148,7 +1158,7 @@ int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2
     }
     if (!mod.t_scale && gn_bwd_small_supported(dtype, HW, C1, C2, groups)) {
         // channel slices: whole groups, whole 16-byte vectors, not straddling the two concatenated sources, <= 256 threads per pixel row
-        const int Call = C1 + C2, cgs = Call / groups, epv = dtype == DMME_BF16 ? 8 : 4;
+        const int Call = C1 + C2, cgs = Call / groups, epv = is16(dtype) ? 8 : 4;
         int slices = 1;
         const bool slice_off = getenv("DMME_NO_GN_BWD_SLICES") != nullptr;
         for (int cand = 4; cand >= 2 && !slice_off; cand >>= 1) {
@@ -1161,6 +1171,9 @@ int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2
         if (dtype == DMME_BF16)
             hipLaunchKernelGGL(gn_bwd_small_kernel<bf16>, dim3(N, slices), dim3(256), 0, s, (const bf16*)dv, (const bf16*)x1, (const bf16*)x2, HW, C1, C2, groups,
                                gamma, mean_rstd, scale, shift, dmask, pro_silu, (bf16*)dx1, (bf16*)dx2, acc1, acc2, dgamma, dbeta, (bf16*)act, rows, (const bf16*)extra);
+        else if (dtype == DMME_F16)
+            hipLaunchKernelGGL(gn_bwd_small_kernel<f16>, dim3(N, slices), dim3(256), 0, s, (const f16*)dv, (const f16*)x1, (const f16*)x2, HW, C1, C2, groups,
+                               gamma, mean_rstd, scale, shift, dmask, pro_silu, (f16*)dx1, (f16*)dx2, acc1, acc2, dgamma, dbeta, (f16*)act, rows, (const f16*)extra);
         else
             hipLaunchKernelGGL(gn_bwd_small_kernel<float>, dim3(N, slices), dim3(256), 0, s, (const float*)dv, (const float*)x1, (const float*)x2, HW, C1, C2,
                                groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, (float*)dx1, (float*)dx2, acc1, acc2, dgamma, dbeta, (float*)act, rows, (const float*)extra);
@@ -1173,6 +1186,9 @@ int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2
     dim3 grid(nchunks, N);
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(gn_bwd_sums_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dv, (const bf16*)x1, (const bf16*)x2, HW, C1, C2, groups,
+                           mean_rstd, scale, shift, dmask, pro_silu, chunk_px, ppw, AB);
+    else if (dtype == DMME_F16)
+        hipLaunchKernelGGL(gn_bwd_sums_kernel<f16>, grid, dim3(256), 0, s, (const f16*)dv, (const f16*)x1, (const f16*)x2, HW, C1, C2, groups,
                            mean_rstd, scale, shift, dmask, pro_silu, chunk_px, ppw, AB);
     else
         hipLaunchKernelGGL(gn_bwd_sums_kernel<float>, grid, dim3(256), 0, s, (const float*)dv, (const float*)x1, (const float*)x2, HW, C1, C2,
@@ -1193,6 +1209,10 @@ int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2
         hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dv, (const bf16*)x1, (const bf16*)x2, HW, C1, C2, groups,
                            gamma, mean_rstd, scale, shift, dmask, pro_silu, S, chunk_px, ppw, (bf16*)dx1, (bf16*)dx2, acc1, acc2, mod, (bf16*)act,
                            fused_fin ? AB : nullptr, dgamma, dbeta, fused_fin ? rows : nullptr, (const bf16*)extra);
+    else if (dtype == DMME_F16)
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<f16>, grid, dim3(256), 0, s, (const f16*)dv, (const f16*)x1, (const f16*)x2, HW, C1, C2, groups,
+                           gamma, mean_rstd, scale, shift, dmask, pro_silu, S, chunk_px, ppw, (f16*)dx1, (f16*)dx2, acc1, acc2, mod, (f16*)act,
+                           fused_fin ? AB : nullptr, dgamma, dbeta, fused_fin ? rows : nullptr, (const f16*)extra);
     else
         hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)dv, (const float*)x1, (const float*)x2, HW, C1, C2,
                            groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, S, chunk_px, ppw, (float*)dx1, (float*)dx2, acc1, acc2, mod, (float*)act,

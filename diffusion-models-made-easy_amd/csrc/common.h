@@ -475,6 +475,10 @@ int launch_nsum_tiled(const float* Mx, int N, int C, int64_t stride, int estride
 int launch_grad_norm(const float* g, int64_t n, float* norm_out, float* scratch, hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr, float b1, float b2, float eps, int step,
                 const float* norm, float max_norm, float ema_decay, float grad_scale, hipStream_t s);
+int launch_amp_init(float* amp, float init_scale, hipStream_t s);
+int launch_amp_scale(float* d, int64_t n, const float* amp, hipStream_t s);
+int launch_adam_amp(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr, float b1, float b2, float eps, const float* norm,
+                    float max_norm, float ema_decay, float grad_scale, float* amp, float growth, float backoff, int interval, hipStream_t s);
 int launch_grad_pack_bf16(const float* g, int64_t n, void* dst, int64_t n_pad, hipStream_t s);
 int launch_shard_reduce_bf16(const void* recv, int world, int64_t per, float scale, void* out, hipStream_t s);
 int launch_grad_unpack_bf16(const void* src, int64_t n, float* g, hipStream_t s);

@@ -122,6 +122,12 @@ template <typename T>
 __device__ __forceinline__ void mma16(const uint4& a, const uint4& b, f32x16& acc) {
     mma_group(a, b, acc, (T*)nullptr);
 }
+// ... as an expression (acc' = mma16v<T>(a, b, acc)), for kernels written around the builtin's value form
+template <typename T, typename A, typename B>
+__device__ __forceinline__ f32x16 mma16v(const A& a, const B& b, f32x16 acc) {
+    mma_group(__builtin_bit_cast(uint4, a), __builtin_bit_cast(uint4, b), acc, (T*)nullptr);
+    return acc;
+}
 
 // ---- accurate mode ("bf16x3"): fp32 tensors, every product as three bf16 MFMA passes ------------------------------------------
 // x = hi + lo with hi = bf16(x), lo = bf16(x - hi): a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, accumulated in fp32 by the matrix

@@ -12,6 +12,20 @@
 
 namespace dmme {
 
+// four 16-bit values of type T held in two dwords -> fp32 (bf16: shifts / masks; IEEE half: conversions)
+template <typename T>
+__device__ __forceinline__ void unpack4_16(const uint2& raw, float (&v)[4]) {
+    if constexpr (dtype_of<T>::value == DMME_BF16) {
+        v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
+        v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
+    } else {
+        typedef T t4 __attribute__((ext_vector_type(4)));
+        const t4 x = __builtin_bit_cast(t4, raw);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (float)x[j];
+    }
+}
+
 __device__ __forceinline__ float silu_grad(float u) {
     const float s = 1.0f / (1.0f + expf(-u));
     return s * (1.0f + u * (1.0f - s));
@@ -82,6 +96,8 @@ int launch_wgrad_generic(int dtype, const ConvArgs& a, const void* dY, float* dW
     dim3 grid((unsigned)blocks, (unsigned)chunks);
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(wgrad_generic_kernel<bf16>, grid, dim3(256), 0, s, a, (const bf16*)dY, dW, rpc);
+    else if (dtype == DMME_F16)
+        hipLaunchKernelGGL(wgrad_generic_kernel<f16>, grid, dim3(256), 0, s, a, (const f16*)dY, dW, rpc);
     else
         hipLaunchKernelGGL(wgrad_generic_kernel<float>, grid, dim3(256), 0, s, a, (const float*)dY, dW, rpc);
     DMME_CHECK_LAUNCH();
@@ -249,8 +265,7 @@ __global__ void __launch_bounds__(256) wgrad_thin_kernel(ConvArgs a, const T* __
             const bool in = p < total;                                                                                         \
             float v[4] = {0.f, 0.f, 0.f, 0.f};                                                                                 \
             const uint2 raw = (RAWP);                                                                                          \
-            v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);                                   \
-            v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);                                   \
+            if constexpr (sizeof(T) == 2) unpack4_16<T>(raw, v);                                                               \
             if constexpr (!FIRST) {                                                                                            \
                 if (a.scale && !one_image && in) {                                                                             \
                     const int64_t so = (int64_t)(p / HW) * Cw + 4 * vec;                                                       \
@@ -289,8 +304,7 @@ __global__ void __launch_bounds__(256) wgrad_thin_kernel(ConvArgs a, const T* __
             if constexpr (sizeof(T) == 2) {
                 uint2 raw = make_uint2(0u, 0u);
                 if (in) raw = *reinterpret_cast<const uint2*>(wide + (int64_t)p * Cw + 4 * vec);
-                v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
-                v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
+                unpack4_16<T>(raw, v);
             } else {
                 float4 raw = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (in) raw = *reinterpret_cast<const float4*>(wide + (int64_t)p * Cw + 4 * vec);
@@ -356,7 +370,7 @@ static bool wgrad_thin_supported(const ConvArgs& a) {
 
 bool wgrad_small_supported(int dtype, const ConvArgs& a) {
     if (wgrad_thin_supported(a)) return true;
-    const int EPV = dtype == DMME_BF16 ? 8 : 4;
+    const int EPV = is16(dtype) ? 8 : 4;
     if (a.taps != 9 || a.stride != 1 || a.up || a.C2 || a.dmask) return false;
     if (a.in_nchw) return a.C1 <= 4 && a.Cout <= 256 && !a.scale && !a.pro_silu;
     return a.Cout <= 4 && a.C1 % EPV == 0 && 9 * (a.C1 / EPV) <= 256;
@@ -370,6 +384,8 @@ int launch_wgrad_small(int dtype, const ConvArgs& a, const void* dY, float* dW, 
         for (int g0 = 0; g0 < G; g0 += 3) {
             if (dtype == DMME_BF16) {
                 if (a.in_nchw) DMME_WTHIN(bf16, true); else DMME_WTHIN(bf16, false);
+            } else if (dtype == DMME_F16) {
+                if (a.in_nchw) DMME_WTHIN(f16, true); else DMME_WTHIN(f16, false);
             } else {
                 if (a.in_nchw) DMME_WTHIN(float, true); else DMME_WTHIN(float, false);
             }
@@ -386,6 +402,8 @@ int launch_wgrad_small(int dtype, const ConvArgs& a, const void* dY, float* dW, 
 #define DMME_WCIN(TT, CC) hipLaunchKernelGGL((wgrad_cin_small_kernel<TT, CC>), dim3(chunks), dim3(256), 0, s, a, (const TT*)dY, dW, rpc)
         if (dtype == DMME_BF16) {
             switch (a.C1) { case 1: DMME_WCIN(bf16, 1); break; case 2: DMME_WCIN(bf16, 2); break; case 3: DMME_WCIN(bf16, 3); break; default: DMME_WCIN(bf16, 4); }
+        } else if (dtype == DMME_F16) {
+            switch (a.C1) { case 1: DMME_WCIN(f16, 1); break; case 2: DMME_WCIN(f16, 2); break; case 3: DMME_WCIN(f16, 3); break; default: DMME_WCIN(f16, 4); }
         } else {
             switch (a.C1) { case 1: DMME_WCIN(float, 1); break; case 2: DMME_WCIN(float, 2); break; case 3: DMME_WCIN(float, 3); break; default: DMME_WCIN(float, 4); }
         }
@@ -393,6 +411,8 @@ int launch_wgrad_small(int dtype, const ConvArgs& a, const void* dY, float* dW, 
     } else {
         if (dtype == DMME_BF16)
             hipLaunchKernelGGL(wgrad_cout_small_kernel<bf16>, dim3(chunks), dim3(256), 0, s, a, (const bf16*)dY, dW, rpc);
+        else if (dtype == DMME_F16)
+            hipLaunchKernelGGL(wgrad_cout_small_kernel<f16>, dim3(chunks), dim3(256), 0, s, a, (const f16*)dY, dW, rpc);
         else
             hipLaunchKernelGGL(wgrad_cout_small_kernel<float>, dim3(chunks), dim3(256), 0, s, a, (const float*)dY, dW, rpc);
     }
@@ -451,10 +471,14 @@ int launch_colsum(int dtype, const void* dY, int N, int HW, int C, float* rowsum
     if (C <= 8 && HW >= 256) {
         if (dtype == DMME_BF16)
             hipLaunchKernelGGL(colsum_thin_kernel<bf16>, dim3(N), dim3(256), 0, s, (const bf16*)dY, HW, C, rowsum);
+        else if (dtype == DMME_F16)
+            hipLaunchKernelGGL(colsum_thin_kernel<f16>, dim3(N), dim3(256), 0, s, (const f16*)dY, HW, C, rowsum);
         else
             hipLaunchKernelGGL(colsum_thin_kernel<float>, dim3(N), dim3(256), 0, s, (const float*)dY, HW, C, rowsum);
     } else if (dtype == DMME_BF16)
         hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dY, HW, C, rowsum);
+ else if (dtype == DMME_F16)
+        hipLaunchKernelGGL(colsum_kernel<f16>, grid, dim3(256), 0, s, (const f16*)dY, HW, C, rowsum);
     else
         hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)dY, HW, C, rowsum);
     DMME_CHECK_LAUNCH();
@@ -543,6 +567,9 @@ int launch_gn_bwd_generic(int dtype, const void* dv, const void* x1, const void*
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(gn_bwd_generic_kernel<bf16>, grid, dim3(256), lds, s, (const bf16*)dv, (const bf16*)x1, (const bf16*)x2, HW, C1, C2,
                            groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, (bf16*)dx1, (bf16*)dx2, acc1, acc2, dgamma, dbeta, mod);
+    else if (dtype == DMME_F16)
+        hipLaunchKernelGGL(gn_bwd_generic_kernel<f16>, grid, dim3(256), lds, s, (const f16*)dv, (const f16*)x1, (const f16*)x2, HW, C1, C2,
+                           groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, (f16*)dx1, (f16*)dx2, acc1, acc2, dgamma, dbeta, mod);
     else
         hipLaunchKernelGGL(gn_bwd_generic_kernel<float>, grid, dim3(256), lds, s, (const float*)dv, (const float*)x1, (const float*)x2, HW, C1,
                            C2, groups, gamma, mean_rstd, scale, shift, dmask, pro_silu, (float*)dx1, (float*)dx2, acc1, acc2, dgamma, dbeta, mod);
@@ -587,6 +614,9 @@ int launch_grad_acc(int dtype, const void* src, void* d1, void* d2, int C1, int 
     if (b > 16384) b = 16384;
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(grad_acc_kernel<bf16>, dim3((unsigned)b), dim3(256), 0, s, (const bf16*)src, (bf16*)d1, (bf16*)d2, C1, C2, acc1, acc2, pool,
+                           H, W, total);
+    else if (dtype == DMME_F16)
+        hipLaunchKernelGGL(grad_acc_kernel<f16>, dim3((unsigned)b), dim3(256), 0, s, (const f16*)src, (f16*)d1, (f16*)d2, C1, C2, acc1, acc2, pool,
                            H, W, total);
     else
         hipLaunchKernelGGL(grad_acc_kernel<float>, dim3((unsigned)b), dim3(256), 0, s, (const float*)src, (float*)d1, (float*)d2, C1, C2, acc1, acc2,
@@ -701,6 +731,10 @@ int launch_attn_heads_bwd(int dtype, const void* qkv, const void* dO, int N, int
         hipLaunchKernelGGL(attn_bwd_rows_kernel<bf16>, grid, dim3(256), ldsA, s, (const bf16*)qkv, (const bf16*)dO, S, C, heads, N, P, dS, (bf16*)dqkv);
         DMME_CHECK_LAUNCH();
         hipLaunchKernelGGL(attn_bwd_cols_kernel<bf16>, grid, dim3(256), ldsB, s, (const bf16*)qkv, (const bf16*)dO, S, C, heads, N, P, dS, (bf16*)dqkv);
+    } else if (dtype == DMME_F16) {
+        hipLaunchKernelGGL(attn_bwd_rows_kernel<f16>, grid, dim3(256), ldsA, s, (const f16*)qkv, (const f16*)dO, S, C, heads, N, P, dS, (f16*)dqkv);
+        DMME_CHECK_LAUNCH();
+        hipLaunchKernelGGL(attn_bwd_cols_kernel<f16>, grid, dim3(256), ldsB, s, (const f16*)qkv, (const f16*)dO, S, C, heads, N, P, dS, (f16*)dqkv);
     } else {
         hipLaunchKernelGGL(attn_bwd_rows_kernel<float>, grid, dim3(256), ldsA, s, (const float*)qkv, (const float*)dO, S, C, heads, N, P, dS, (float*)dqkv);
         DMME_CHECK_LAUNCH();
@@ -748,6 +782,8 @@ int launch_lin_dinput(int dtype, const float* dY, const void* W, int R, int O, i
     const int total = R * K;
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(lin_dinput_kernel<bf16>, dim3((total + 255) / 256), dim3(256), 0, s, dY, (const bf16*)W, R, O, K, dX);
+    else if (dtype == DMME_F16)
+        hipLaunchKernelGGL(lin_dinput_kernel<f16>, dim3((total + 255) / 256), dim3(256), 0, s, dY, (const f16*)W, R, O, K, dX);
     else
         hipLaunchKernelGGL(lin_dinput_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, s, dY, (const float*)W, R, O, K, dX);
     DMME_CHECK_LAUNCH();
@@ -829,6 +865,85 @@ int launch_adam(float* p, const float* g, float* m, float* v, float* ema, int64_
     int64_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, ema, n, lr, b1, b2, eps, bc1, bc2s, norm, max_norm, ema_decay, grad_scale);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
+// ---- dynamic loss scaling of a half-precision training step, device-resident (torch.cuda.amp.GradScaler semantics) ----
+// amp[8] floats: [0] scale S, [1] growth tracker, [2] optimiser steps taken, [3] found_inf of the last step, [4] steps skipped.
+// The loss gradient is multiplied by S before backward (amp_scale_kernel); the fused optimiser pass divides it out again, clips the
+// UNSCALED norm, and leaves parameters and moments untouched when the (scaled) gradient norm is not finite; amp_update_kernel then
+// halves S / resets the tracker, or counts the step and doubles S after `interval` finite steps in a row.  Nothing is read back.
+__global__ void amp_init_kernel(float* __restrict__ amp, float init_scale) {
+    if (threadIdx.x < 8) amp[threadIdx.x] = threadIdx.x == 0 ? init_scale : 0.f;
+}
+__global__ void __launch_bounds__(256) amp_scale_kernel(float* __restrict__ d, int64_t n, const float* __restrict__ amp) {
+    const float S = amp[0];
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] *= S;
+}
+__global__ void __launch_bounds__(256) adam_amp_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, float* __restrict__ ema, int64_t n, float lr, float b1, float b2,
+                                                       float eps, const float* __restrict__ norm, float max_norm, float ema_decay,
+                                                       float grad_scale, const float* __restrict__ amp) {
+    const float nrm = norm[0];
+    if (!(fabsf(nrm) <= 3.0e38f)) return;  // inf or NaN somewhere in the scaled gradient: this step is skipped (GradScaler.step)
+    const float gs = grad_scale / amp[0];   // unscale (and the data-parallel mean's 1 / world)
+    float clip = gs;
+    if (max_norm > 0.f) {
+        const float c = max_norm / (nrm * gs + 1e-6f);
+        clip = c < 1.0f ? c * gs : gs;
+    }
+    const float t = amp[2] + 1.0f;  // optimiser steps incl. this one (skipped steps do not count: torch skips optimizer.step())
+    const float bc1 = 1.0f - powf(b1, t), bc2_sqrt = sqrtf(1.0f - powf(b2, t));
+    const float step = lr / bc1;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * clip;
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float pi = p[i] - step * mi / (sqrtf(vi) / bc2_sqrt + eps);
+        p[i] = pi;
+        if (ema) ema[i] = ema_decay * ema[i] + (1.0f - ema_decay) * pi;
+    }
+}
+__global__ void amp_update_kernel(float* __restrict__ amp, const float* __restrict__ norm, float growth, float backoff, float interval) {
+    if (threadIdx.x != 0) return;
+    const bool bad = !(fabsf(norm[0]) <= 3.0e38f);
+    if (bad) {
+        amp[0] *= backoff;
+        amp[1] = 0.f;
+        amp[3] = 1.f;
+        amp[4] += 1.f;
+    } else {
+        amp[2] += 1.f;
+        amp[3] = 0.f;
+        amp[1] += 1.f;
+        if (amp[1] >= interval) {
+            amp[0] *= growth;
+            amp[1] = 0.f;
+        }
+    }
+}
+int launch_amp_init(float* amp, float init_scale, hipStream_t s) {
+    hipLaunchKernelGGL(amp_init_kernel, dim3(1), dim3(64), 0, s, amp, init_scale);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+int launch_amp_scale(float* d, int64_t n, const float* amp, hipStream_t s) {
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(amp_scale_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, s, d, n, amp);
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+int launch_adam_amp(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr, float b1, float b2, float eps, const float* norm,
+                    float max_norm, float ema_decay, float grad_scale, float* amp, float growth, float backoff, int interval, hipStream_t s) {
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adam_amp_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, ema, n, lr, b1, b2, eps, norm, max_norm, ema_decay, grad_scale, amp);
+    DMME_CHECK_LAUNCH();
+    hipLaunchKernelGGL(amp_update_kernel, dim3(1), dim3(64), 0, s, amp, norm, growth, backoff, (float)interval);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
 }

@@ -957,7 +957,7 @@ void build_wgrad_group(dmme_plan* P, dmme_plan::WgGroup& G, int gi, int op_lo = 
     G.taps = taps;
     G.stride = stride;
     if (stride == 2 && getenv("DMME_NO_WG_S2")) return;
-    if (P->dtype != DMME_BF16 || getenv("DMME_NO_WGRAD_GROUP")) return;
+    if (!is16(P->dtype) || getenv("DMME_NO_WGRAD_GROUP")) return;
     // (the stride-2 table is three small layers: shorter jobs, or 80 workgroups would carry it)
     const int q = stride == 2 ? 16 : 64;
     struct Grp { int layer, n_co, n_ci, tile0, ntiles; };
@@ -2201,8 +2201,6 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
     DMME_REQUIRE(t_len == 1 || t_len == plan->B, DMME_ERR_INVALID, "unet_backward: bad t_len %d", t_len);
     if (int rc0 = lvl_check(plan, "unet_backward", (hipStream_t)stream, true)) return rc0;  // (the forward this backward differentiates ran through the engine)
     DMME_REQUIRE(!plan->mix, DMME_ERR_UNSUPPORTED, "unet_backward: precision fp16r32 is an inference mode");
-    DMME_REQUIRE(plan->dtype != DMME_F16, DMME_ERR_UNSUPPORTED,
-                 "unet_backward: precision fp16 is an inference mode (no loss scaling in the HIP backward); train in bf16, bf16x3 or fp32");
     const dmme_plan* P = plan;
     hipStream_t s = (hipStream_t)stream;
     const char* pk = (const char*)packed;
@@ -2363,6 +2361,8 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
             d.w = pkb + P->params[o.w].packed_bwd_off;
             d.dst = tmp;
             d.x3 = P->x3;
+        d.f16 = P->dtype == DMME_F16;  // (launchers without a dtype argument: conv1x1_as, the thin output conv)
+            d.f16 = P->dtype == DMME_F16;  // (launchers without a dtype argument: conv1x1_as, the thin output conv)
             if (P->splitk_floats > 0) {
                 d.splitk = (float*)(ws + P->ws_splitk);
                 d.splitk_cap = P->splitk_floats;
@@ -2442,6 +2442,8 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
             d.dst = d_x;
             d.out_nchw = 1;
             d.x3 = P->x3;
+        d.f16 = P->dtype == DMME_F16;  // (launchers without a dtype argument: conv1x1_as, the thin output conv)
+            d.f16 = P->dtype == DMME_F16;  // (launchers without a dtype argument: conv1x1_as, the thin output conv)
             rc = conv_mfma_supported(dt, d) ? launch_conv_mfma(dt, d, s) : launch_conv_generic(dt, d, s);
             if (rc != DMME_OK) break;
         }
@@ -2556,6 +2558,7 @@ DMME_API int dmme_unet_plan_bwd_summary(const dmme_plan* plan, char* buf, int ca
         d.w = (const void*)4096;
         d.dst = (void*)4096;
         d.x3 = P->x3;
+        d.f16 = P->dtype == DMME_F16;  // (launchers without a dtype argument: conv1x1_as, the thin output conv)
         if (P->splitk_floats > 0) {
             d.splitk = (float*)4096;
             d.splitk_cap = P->splitk_floats;
@@ -2589,6 +2592,23 @@ DMME_API int dmme_adam_step(float* param, const float* grad, float* exp_avg, flo
     DMME_REQUIRE(param && grad && exp_avg && exp_avg_sq && numel > 0 && step >= 1 && grad_scale > 0.f, DMME_ERR_INVALID, "adam_step: bad argument");
     return launch_adam(param, grad, exp_avg, exp_avg_sq, ema, numel, lr, beta1, beta2, eps, step, grad_norm, max_norm, ema_decay, grad_scale,
                        (hipStream_t)stream);
+}
+
+DMME_API int dmme_amp_init(float* amp_state, float init_scale, void* stream) {
+    DMME_REQUIRE(amp_state && init_scale > 0.f, DMME_ERR_INVALID, "amp_init: bad argument");
+    return launch_amp_init(amp_state, init_scale, (hipStream_t)stream);
+}
+DMME_API int dmme_amp_scale(float* grad, int64_t numel, const float* amp_state, void* stream) {
+    DMME_REQUIRE(grad && amp_state && numel >= 0, DMME_ERR_INVALID, "amp_scale: bad argument");
+    return launch_amp_scale(grad, numel, amp_state, (hipStream_t)stream);
+}
+DMME_API int dmme_adam_step_amp(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema, int64_t numel, float lr, float beta1,
+                                float beta2, float eps, const float* grad_norm, float max_grad_norm, float ema_decay, float grad_scale,
+                                float* amp_state, float growth_factor, float backoff_factor, int growth_interval, void* stream) {
+    DMME_REQUIRE(param && grad && exp_avg && exp_avg_sq && grad_norm && amp_state && numel >= 0, DMME_ERR_INVALID, "adam_step_amp: null argument");
+    DMME_REQUIRE(growth_factor >= 1.f && backoff_factor > 0.f && backoff_factor <= 1.f && growth_interval >= 1, DMME_ERR_INVALID, "adam_step_amp: bad scaler constants");
+    return launch_adam_amp(param, grad, exp_avg, exp_avg_sq, ema, numel, lr, beta1, beta2, eps, grad_norm, max_grad_norm, ema_decay, grad_scale, amp_state,
+                           growth_factor, backoff_factor, growth_interval, (hipStream_t)stream);
 }
 
 DMME_API int dmme_grad_pack_bf16(const float* grad, int64_t numel, void* dst_bf16, int64_t numel_padded, void* stream) {

@@ -137,8 +137,7 @@ __global__ void __launch_bounds__(256) wgrad_mfma_kernel(ConvArgs a, ConvTile g,
                     bfr[4] = hi[0]; bfr[5] = hi[1]; bfr[6] = hi[2]; bfr[7] = hi[3];
 #pragma unroll
                     for (int mi = 0; mi < 2; ++mi)
-                        acc[kw][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mi]), __builtin_bit_cast(bf16x8, bfr),
-                                                                               acc[kw][mi], 0, 0, 0);
+                        acc[kw][mi] = mma16v<T>(af[mi], bfr, acc[kw][mi]);
                 }
             }
         } else {
@@ -205,7 +204,7 @@ template <typename T, int TAPS, int WM, int WN>
 __global__ void __launch_bounds__(256, 2) wgrad_group_kernel(const WgLayer* __restrict__ layers, const WgJob* __restrict__ jobs,
                                                              const char* __restrict__ ws, const char* __restrict__ bws,
                                                              const float* __restrict__ drop_masks, float* __restrict__ wimage) {
-    static_assert(sizeof(T) == 2, "grouped weight gradient is bf16 only");
+    static_assert(sizeof(T) == 2, "grouped weight gradient: 16-bit tensors only");
     using GG = WgGroupGeom<TAPS, WM, WN>;
     constexpr int EPV = 8, CO = GG::CO, CI = GG::CI, DYP = GG::DYP, VP = GG::VP, UY = GG::UY, UV = GG::UV;
     constexpr int PAD = TAPS == 9 ? 1 : 0;
@@ -339,8 +338,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_group_kernel(const WgLayer* __re
                     bfr[4] = hi[0]; bfr[5] = hi[1]; bfr[6] = hi[2]; bfr[7] = hi[3];
 #pragma unroll
                     for (int a = 0; a < WM; ++a)
-                        acc[tap][a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[a]), __builtin_bit_cast(bf16x8, bfr),
-                                                                               acc[tap][a][b], 0, 0, 0);
+                        acc[tap][a][b] = mma16v<T>(af[a], bfr, acc[tap][a][b]);
                 }
             }
         }
@@ -492,8 +490,7 @@ __global__ void __launch_bounds__(256, STRIDE == 1 ? 2 : 1) wgrad_dma_kernel(con
                     s16x8 bfr;
                     bfr[0] = lo[0]; bfr[1] = lo[1]; bfr[2] = lo[2]; bfr[3] = lo[3];
                     bfr[4] = hi[0]; bfr[5] = hi[1]; bfr[6] = hi[2]; bfr[7] = hi[3];
-                    acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bfr),
-                                                                              acc[dy * 3 + dx], 0, 0, 0);
+                    acc[dy * 3 + dx] = mma16v<T>(af, bfr, acc[dy * 3 + dx]);
                 }
             }
         }
@@ -599,7 +596,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_dma1_kernel(const WgLayer* __res
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[a]), __builtin_bit_cast(bf16x8, bfr[b]), acc[a][b], 0, 0, 0);
+                    acc[a][b] = mma16v<T>(af[a], bfr[b], acc[a][b]);
         }
         buf ^= 1;
     }
@@ -624,7 +621,7 @@ static bool wg_tile(const ConvArgs& a, ConvTile& g) {
 }
 
 bool wgrad_mfma_supported(int dtype, const ConvArgs& a) {
-    const int KC = dtype == DMME_BF16 ? 64 : 32;
+    const int KC = is16(dtype) ? 64 : 32;
     (void)KC;
     if (a.in_nchw) return false;
     if (a.taps != 9 && a.taps != 1) return false;
@@ -634,7 +631,7 @@ bool wgrad_mfma_supported(int dtype, const ConvArgs& a) {
     if (a.Cout % 32) return false;
     ConvTile g;
     if (!wg_tile(a, g)) return false;
-    const size_t lds = (size_t)WG_PX * (dtype == DMME_BF16 ? 320 : 512) + (size_t)g.TN * g.TH * g.HWd * (dtype == DMME_BF16 ? 192 : 256);
+    const size_t lds = (size_t)WG_PX * (is16(dtype) ? 320 : 512) + (size_t)g.TN * g.TH * g.HWd * (is16(dtype) ? 192 : 256);
     return lds <= 64 * 1024;
 }
 
@@ -665,7 +662,7 @@ static int launch_wgrad_t(const ConvArgs& a, const void* dY, float* dWp, hipStre
 // sums are added atomically.  launch_wgrad_unpack folds the whole image into the reference-layout gradients.
 int launch_wgrad_mfma(int dtype, const ConvArgs& a, const void* dY, float* dWp, hipStream_t s) {
     DMME_REQUIRE(wgrad_mfma_supported(dtype, a), DMME_ERR_UNSUPPORTED, "wgrad_mfma: unsupported shape");
-    return dtype == DMME_BF16 ? launch_wgrad_t<bf16>(a, dY, dWp, s) : launch_wgrad_t<float>(a, dY, dWp, s);
+    return dtype == DMME_BF16 ? launch_wgrad_t<bf16>(a, dY, dWp, s) : dtype == DMME_F16 ? launch_wgrad_t<f16>(a, dY, dWp, s) : launch_wgrad_t<float>(a, dY, dWp, s);
 }
 
 // table-driven: one workgroup per item (a run of cout rows of one conv weight)
@@ -693,7 +690,7 @@ int launch_wgrad_unpack(const PackItem* items_dev, int n_items, const float* ima
 }
 
 bool wgrad_group_layer(int dtype, const ConvArgs& a, WgLayer& L, int* co_tile, int* ci_tile) {
-    if (dtype != DMME_BF16 || (a.taps != 9 && a.taps != 1) || (a.stride != 1 && !(a.stride == 2 && a.taps == 9 && !a.up)) || a.in_nchw || a.up == 2) return false;
+    if (!is16(dtype) || (a.taps != 9 && a.taps != 1) || (a.stride != 1 && !(a.stride == 2 && a.taps == 9 && !a.up)) || a.in_nchw || a.up == 2) return false;
     if (a.taps == 1 && a.up) return false;
     const int CO = a.taps == 9 ? 64 : 128, CI = a.taps == 9 ? 64 : 128;
     const int Cin = a.C1 + a.C2;
@@ -723,18 +720,18 @@ bool wgrad_group_layer(int dtype, const ConvArgs& a, WgLayer& L, int* co_tile, i
     return true;
 }
 
-int launch_wgrad_group(int dtype, int taps, const WgLayer* layers_dev, const WgJob* jobs_dev, int njobs, const void* ws, const void* bws,
+template <typename T>
+static int launch_wgrad_group_t(int taps, const WgLayer* layers_dev, const WgJob* jobs_dev, int njobs, const void* ws, const void* bws,
                        const float* drop_masks, float* wimage, hipStream_t s, int dma, const void* zero_page) {
-    DMME_REQUIRE(dtype == DMME_BF16 && (taps == 9 || taps == 1), DMME_ERR_UNSUPPORTED, "grouped weight gradient: bf16, 3x3 or 1x1 only");
     if (njobs <= 0) return DMME_OK;
     if (taps == 9 && dma == 2 && zero_page) {  // the stride-2 table
         constexpr size_t lds = 2 * (WG_PX * 128 + 336 * 128);
-        static bool attr = false;
+        static bool attr = false;  // (one per instantiation, i.e. per T)
         if (!attr) {
-            DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<bf16, 2, 336>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<T, 2, 336>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr = true;
         }
-        hipLaunchKernelGGL((wgrad_dma_kernel<bf16, 2, 336>), dim3((unsigned)njobs), dim3(256), lds, s, layers_dev, jobs_dev, (const char*)ws, (const char*)bws,
+        hipLaunchKernelGGL((wgrad_dma_kernel<T, 2, 336>), dim3((unsigned)njobs), dim3(256), lds, s, layers_dev, jobs_dev, (const char*)ws, (const char*)bws,
                            (const char*)zero_page, wimage);
         DMME_CHECK_LAUNCH();
         return DMME_OK;
@@ -742,7 +739,7 @@ int launch_wgrad_group(int dtype, int taps, const WgLayer* layers_dev, const WgJ
     if (taps == 9 && dma && zero_page) {
         constexpr size_t lds = 2 * (WG_PX * 128 + 160 * 128);
         static_assert(lds <= 64 * 1024, "two workgroups per CU");
-        hipLaunchKernelGGL((wgrad_dma_kernel<bf16, 1, 160>), dim3((unsigned)njobs), dim3(256), lds, s, layers_dev, jobs_dev, (const char*)ws, (const char*)bws,
+        hipLaunchKernelGGL((wgrad_dma_kernel<T, 1, 160>), dim3((unsigned)njobs), dim3(256), lds, s, layers_dev, jobs_dev, (const char*)ws, (const char*)bws,
                            (const char*)zero_page, wimage);
         DMME_CHECK_LAUNCH();
         return DMME_OK;
@@ -750,23 +747,30 @@ int launch_wgrad_group(int dtype, int taps, const WgLayer* layers_dev, const WgJ
     if (taps == 1 && dma) {
         constexpr size_t lds = 2 * 2 * 4 * WG_PX * 64;
         static_assert(lds <= 64 * 1024, "two workgroups per CU");
-        hipLaunchKernelGGL((wgrad_dma1_kernel<bf16>), dim3((unsigned)njobs), dim3(256), lds, s, layers_dev, jobs_dev, (const char*)ws, (const char*)bws, wimage);
+        hipLaunchKernelGGL((wgrad_dma1_kernel<T>), dim3((unsigned)njobs), dim3(256), lds, s, layers_dev, jobs_dev, (const char*)ws, (const char*)bws, wimage);
         DMME_CHECK_LAUNCH();
         return DMME_OK;
     }
     if (taps == 9) {
         constexpr size_t lds = WgGroupGeom<9, 1, 1>::LDS;
         static_assert(lds <= 64 * 1024, "LDS tile");
-        hipLaunchKernelGGL((wgrad_group_kernel<bf16, 9, 1, 1>), dim3((unsigned)njobs), dim3(256), lds, s, layers_dev, jobs_dev, (const char*)ws,
+        hipLaunchKernelGGL((wgrad_group_kernel<T, 9, 1, 1>), dim3((unsigned)njobs), dim3(256), lds, s, layers_dev, jobs_dev, (const char*)ws,
                            (const char*)bws, drop_masks, wimage);
     } else {
         constexpr size_t lds = WgGroupGeom<1, 2, 2>::LDS;
         static_assert(lds <= 64 * 1024, "LDS tile");
-        hipLaunchKernelGGL((wgrad_group_kernel<bf16, 1, 2, 2>), dim3((unsigned)njobs), dim3(256), lds, s, layers_dev, jobs_dev, (const char*)ws,
+        hipLaunchKernelGGL((wgrad_group_kernel<T, 1, 2, 2>), dim3((unsigned)njobs), dim3(256), lds, s, layers_dev, jobs_dev, (const char*)ws,
                            (const char*)bws, drop_masks, wimage);
     }
     DMME_CHECK_LAUNCH();
     return DMME_OK;
+}
+
+int launch_wgrad_group(int dtype, int taps, const WgLayer* layers_dev, const WgJob* jobs_dev, int njobs, const void* ws, const void* bws,
+                       const float* drop_masks, float* wimage, hipStream_t s, int dma, const void* zero_page) {
+    DMME_REQUIRE(is16(dtype) && (taps == 9 || taps == 1), DMME_ERR_UNSUPPORTED, "grouped weight gradient: 16-bit tensors, 3x3 or 1x1 only");
+    if (dtype == DMME_F16) return launch_wgrad_group_t<f16>(taps, layers_dev, jobs_dev, njobs, ws, bws, drop_masks, wimage, s, dma, zero_page);
+    return launch_wgrad_group_t<bf16>(taps, layers_dev, jobs_dev, njobs, ws, bws, drop_masks, wimage, s, dma, zero_page);
 }
 
 }  // namespace dmme

@@ -113,6 +113,10 @@ class UNet(nn.Module):
         self._views_version = 0
         self._flat_grad: Optional[Tensor] = None
         self._bucket_hook = None  # callable(offset, numel): set by distributed.OverlappedGradReducer
+        # half-precision training: dynamic loss scaling (optim.FusedAdam(amp=...) switches it on; state lives on the device:
+        # include/dmme_hip.h dmme_amp_*).  _amp: {"init_scale", "growth_factor", "backoff_factor", "growth_interval"} or None
+        self._amp = None
+        self._amp_state: Optional[Tensor] = None
 
         # parameter table from the C++ plan (host only: device = -1)
         table_plan = _Plan(self._cfg, 1, 32, 32, _lib.F32, -1)
@@ -315,6 +319,19 @@ class UNet(nn.Module):
             return unet_apply(self, x, c)
         return self._forward_impl(x, c)
 
+    def amp_state(self, device=None) -> Optional[Tensor]:
+        """the device-resident loss-scaling state (8 floats: scale, growth tracker, steps taken, found_inf, steps skipped) when
+        dynamic loss scaling is on and the compute dtype is IEEE half; created at first use"""
+        if self._amp is None or self._dtype != _lib.F16:
+            return None
+        dev = device if device is not None else self.flat_parameters().device
+        st = self._amp_state
+        if st is None or st.device != torch.device(dev):
+            st = torch.zeros(8, dtype=torch.float32, device=dev)
+            _lib.check(_lib.lib().dmme_amp_init(_lib.ptr(st), float(self._amp["init_scale"]), _lib.stream_ptr()), "dmme_amp_init")
+            self._amp_state = st
+        return st
+
     def mark_params_updated(self):
         """call after writing the flat parameter buffer through a raw pointer (fused optimiser)"""
         self._param_epoch += 1
@@ -365,6 +382,11 @@ class UNet(nn.Module):
             plan.packed_bwd_version = ver
         g = self.flat_grad()
         d = dy.detach().to(torch.float32).contiguous()
+        amp = self.amp_state(dev)
+        if amp is not None:  # backward of S * loss: the scale is read on the device, the optimiser pass divides it out again
+            if d.data_ptr() == dy.data_ptr():
+                d = d.clone()
+            _lib.check(lib.dmme_amp_scale(_lib.ptr(d), d.numel(), _lib.ptr(amp), _lib.stream_ptr()), "dmme_amp_scale")
         hook = self._bucket_hook
         if hook is not None:  # two gradient buckets, each handed over as soon as its launches are enqueued (overlapped all-reduce)
             errors = []
@@ -383,12 +405,16 @@ class UNet(nn.Module):
             )
             if errors:
                 raise errors[0]
+            if dx is not None and amp is not None:
+                dx.div_(amp[0])
             return dx
         _lib.check(
             lib.dmme_unet_backward(plan.h, _lib.ptr(packed), _lib.ptr(plan.packed_bwd), _lib.ptr(xin), _lib.ptr(t), int(t.numel()), _lib.ptr(d),
                                    _lib.ptr(plan.workspace), _lib.ptr(plan.bws), _lib.ptr(masks), _lib.ptr(g), _lib.ptr(dx), _lib.stream_ptr()),
             "dmme_unet_backward",
         )
+        if dx is not None and amp is not None:
+            dx.div_(amp[0])
         return dx
 
     def _forward_impl(self, x: Tensor, c: Tensor, want_ctx: bool = False):

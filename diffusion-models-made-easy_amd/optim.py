@@ -15,9 +15,15 @@ from . import _lib
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=0.0, ema_decay=0.0):
+    def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=0.0, ema_decay=0.0, amp=True, init_scale=65536.0,
+                 growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        """`amp`: dynamic loss scaling whenever the model computes in IEEE half (precision="fp16") - the reference's `precision: 16`
+        step under torch.cuda.amp.GradScaler (configs/ddpm/cifar10.yaml:53,66), with GradScaler's default constants; no effect on
+        bf16 / fp32 models.  The scaler's state lives on the device (include/dmme_hip.h: dmme_amp_*): no read-back per step."""
         defaults = dict(lr=lr, betas=betas, eps=eps, max_grad_norm=max_grad_norm, ema_decay=ema_decay)
         super().__init__(params, defaults)
+        self._amp_cfg = dict(init_scale=float(init_scale), growth_factor=float(growth_factor), backoff_factor=float(backoff_factor),
+                             growth_interval=int(growth_interval)) if amp else None
         self._step_count = 0  # what the reference's WarmupLR keys on (lr_scheduler/warmup.py:11)
         self._owners = []
         seen = set()
@@ -30,8 +36,13 @@ class FusedAdam(torch.optim.Optimizer):
                 if id(owner) not in seen:
                     seen.add(id(owner))
                     self._owners.append(owner)
+        for m in self._owners:
+            m._amp = self._amp_cfg
         self._flat_state = {}
+        # device scalar: norm of the gradient BUFFER of the last step - multiply by `grad_scale` of that step (rank sums under the
+        # folded data-parallel mean) and divide by the loss scale (amp) to get the norm of the mean gradient: `grad_norm()`
         self.last_grad_norm = None
+        self._last_norm_factor = 1.0
         # multiplies the gradient inside the fused pass: 1 / world when the data-parallel exchange left rank SUMS in the flat buffer
         # (distributed.py folds the mean's divide into this pass instead of a separate sweep over 130 MB); consumed by ONE step
         self.grad_scale = 1.0
@@ -58,10 +69,23 @@ class FusedAdam(torch.optim.Optimizer):
                       "scratch": torch.empty(1024, device=flat.device), "ema": flat.clone() if decay > 0 else None}
                 self._flat_state[id(m)] = st
             norm_ptr = _lib.ptr(None)
-            if max_norm > 0:
+            amp = m.amp_state(flat.device) if hasattr(m, "amp_state") else None
+            if max_norm > 0 or amp is not None:
                 _lib.check(lib.dmme_grad_norm(_lib.ptr(grad), grad.numel(), _lib.ptr(st["norm"]), _lib.ptr(st["scratch"]), _lib.stream_ptr()), "dmme_grad_norm")
                 norm_ptr = _lib.ptr(st["norm"])
                 self.last_grad_norm = st["norm"]
+                self._last_norm_factor = float(self.grad_scale)
+                self._last_amp = amp
+            if amp is not None:  # half precision: unscale + inf / NaN skip + scale update inside the fused pass
+                c = self._amp_cfg
+                _lib.check(
+                    lib.dmme_adam_step_amp(_lib.ptr(flat), _lib.ptr(grad), _lib.ptr(st["m"]), _lib.ptr(st["v"]), _lib.ptr(st["ema"]), flat.numel(), lr, b1, b2, eps,
+                                           norm_ptr, max_norm, decay, float(self.grad_scale), _lib.ptr(amp), c["growth_factor"], c["backoff_factor"],
+                                           c["growth_interval"], _lib.stream_ptr()),
+                    "dmme_adam_step_amp",
+                )
+                m.mark_params_updated()
+                continue
             _lib.check(
                 lib.dmme_adam_step(_lib.ptr(flat), _lib.ptr(grad), _lib.ptr(st["m"]), _lib.ptr(st["v"]), _lib.ptr(st["ema"]), flat.numel(), lr, b1, b2, eps,
                                    self._step_count, norm_ptr, max_norm, decay, float(self.grad_scale), _lib.stream_ptr()),
@@ -70,6 +94,24 @@ class FusedAdam(torch.optim.Optimizer):
             m.mark_params_updated()
         self.grad_scale = 1.0
         return loss
+
+    def grad_norm(self) -> float:
+        """L2 norm of the (mean, unscaled) gradient of the last step - what torch's clip_grad_norm_ would have returned under DDP.
+        The flat buffer itself holds rank SUMS under the folded data-parallel mean and S x gradient under loss scaling; this accessor
+        undoes both (synchronises: reads device scalars)."""
+        if self.last_grad_norm is None:
+            return float("nan")
+        v = float(self.last_grad_norm.item()) * self._last_norm_factor
+        amp = getattr(self, "_last_amp", None)
+        if amp is not None:
+            v /= float(amp[0].item())  # (the scale AFTER the step's update: off by the growth / backoff factor on the steps that change it)
+        return v
+
+    def loss_scale(self, model=None) -> float:
+        """current loss scale (1.0 when loss scaling is off); synchronises"""
+        m = model if model is not None else self._owners[0]
+        amp = m.amp_state() if hasattr(m, "amp_state") else None
+        return 1.0 if amp is None else float(amp[0].item())
 
     def ema_parameters(self, model):
         st = self._flat_state.get(id(model))

@@ -174,10 +174,10 @@ def parse_config(path: str) -> Dict[str, Any]:
         "batch_size": _coerce(data_args.get("batch_size", 128), int),
         "max_steps": _coerce(trainer.get("max_steps") if trainer.get("max_steps") is not None else -1, int),
         "gradient_clip_val": _coerce(trainer.get("gradient_clip_val"), typing.Optional[float]),
-        # `precision: 16` (configs/ddpm/cifar10.yaml:53) is fp16 autocast under a GradScaler in the reference.  The HIP backward has no
-        # loss scaling: training takes bf16 (same MFMA rate, fp32 range), inference takes the reference's own dtype, IEEE half
-        # (precision="fp16": 8x finer rounding than bf16 at the same speed)
-        "precision": "bf16" if (p16 or pbf) else "fp32",
+        # `precision: 16` (configs/ddpm/cifar10.yaml:53) is fp16 autocast under a GradScaler in the reference: here IEEE-half tensors and
+        # MFMA operands with fp32 accumulation and master weights, under the device-resident dynamic loss scaling of the fused optimiser
+        # pass (optim.FusedAdam(amp=True), include/dmme_hip.h: dmme_amp_*) - for `fit` and for sampling alike
+        "precision": "fp16" if p16 else "bf16" if pbf else "fp32",
         "sample_precision": "fp16" if p16 else "bf16" if pbf else "fp32",
         # images the YAML's data module yields (dmme.CIFAR10: 32 x 32; dmme.LSUN: init_args.imgsize, configs/ddpm/lsun_church.yaml:94)
         "image_size": _coerce(data_args.get("imgsize", 32), int),

@@ -206,6 +206,21 @@ DMME_API int dmme_grad_norm(const float* grad, int64_t numel, float* norm_out, f
 DMME_API int dmme_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema, int64_t numel,
                             float lr, float beta1, float beta2, float eps, int step, const float* grad_norm, float max_norm,
                             float ema_decay, float grad_scale, void* stream);
+/* Dynamic loss scaling for half-precision training (precision="fp16"), device-resident - what torch.cuda.amp.GradScaler does around
+ * the reference's `precision: 16`, `amp_backend: native` step (configs/ddpm/cifar10.yaml:53,66; scripts/main.py:44), without a
+ * read-back.  amp_state: 8 floats in device memory - [0] scale S, [1] finite steps since the last change of S, [2] optimiser steps
+ * taken, [3] found_inf of the last step, [4] steps skipped.
+ *   dmme_amp_init:  S = init_scale (GradScaler: 65536), the rest 0.
+ *   dmme_amp_scale: grad *= S - on the loss gradient handed to dmme_unet_backward, i.e. backward of S * loss.
+ *   dmme_adam_step_amp: dmme_adam_step on the SCALED gradient: divides S out (with grad_scale), clips the unscaled norm (grad_norm is
+ *     dmme_grad_norm of the scaled buffer - always required here: it is also the inf / NaN detector), takes the bias-correction step
+ *     count from amp_state[2]; a non-finite norm leaves parameters, moments and EMA untouched and multiplies S by backoff_factor
+ *     (0.5), growth_interval (2000) finite steps in a row multiply it by growth_factor (2). */
+DMME_API int dmme_amp_init(float* amp_state, float init_scale, void* stream);
+DMME_API int dmme_amp_scale(float* grad, int64_t numel, const float* amp_state, void* stream);
+DMME_API int dmme_adam_step_amp(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema, int64_t numel, float lr, float beta1,
+                                float beta2, float eps, const float* grad_norm, float max_grad_norm, float ema_decay, float grad_scale,
+                                float* amp_state, float growth_factor, float backoff_factor, int growth_interval, void* stream);
 /* ---- data-parallel gradient exchange with bf16 on the wire (the reference relies on Lightning DDP for this step:
  * configs/ddpm/cifar10.yaml:28,51,62 `devices`, `strategy`, `replace_sampler_ddp`; NCCL's fp32 ring all-reduce there).  One bucket =
  * pack (fp32 -> bf16, zero padded to world * per_rank) -> all-to-all of the per-rank shards (torch.distributed / RCCL) ->

@@ -1,5 +1,5 @@
 """-m gpu: precision="fp16" - the same kernels on IEEE-half operands (v_mfma_f32_32x32x16_f16, the bf16 rate), the reference's own
-AMP dtype (configs/ddpm/cifar10.yaml:53 `precision: 16`, :66 `amp_backend: native`).  Inference only.  Held against the reference's
+AMP dtype (configs/ddpm/cifar10.yaml:53 `precision: 16`, :66 `amp_backend: native`); training: tests/test_gpu_fp16_train.py.  Held against the reference's
 golden output: north_star asks 1e-3 for the reduced-precision path; bf16 (8 significant bits) measures 1.1e-2, half (11 bits) 8x less."""
 
 import ctypes as C
@@ -82,21 +82,12 @@ def test_fp16_batch128_rows_and_sampler_chain(golden):
     assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
 
 
-def test_fp16_is_an_inference_mode():
-    """the HIP backward has no loss scaling: a training step in fp16 is refused with a message, not run into underflow"""
-    import dmme_amd
-
-    net = dmme_amd.UNet(precision="fp16").cuda().train()
-    x = torch.randn(2, 3, 32, 32, device="cuda")
-    with pytest.raises(NotImplementedError, match="inference mode"):  # DMME_ERR_UNSUPPORTED
-        net(x, torch.tensor([3, 4], device="cuda")).sum().backward()
-
-
-def test_trainer_maps_precision_16_to_half_for_sampling_and_bf16_for_training():
+def test_trainer_maps_precision_16_to_half_for_training_and_sampling():
+    """`precision: 16` (configs/ddpm/cifar10.yaml:53) = IEEE half under dynamic loss scaling, as in the reference (tests/test_gpu_fp16_train.py)"""
     from dmme_amd import trainer
 
     conf = trainer.parse_config(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "ddpm", "cifar10.yaml"))
-    assert conf["precision"] == "bf16" and conf["sample_precision"] == "fp16" and conf["image_size"] == 32
+    assert conf["precision"] == "fp16" and conf["sample_precision"] == "fp16" and conf["image_size"] == 32
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,187 @@
+"""-m gpu: half-precision TRAINING as the reference ships it - `precision: 16`, `amp_backend: native` (configs/ddpm/cifar10.yaml:53,66;
+scripts/main.py:44): IEEE-half tensors and MFMA operands, fp32 accumulation and master weights, dynamic loss scaling with
+torch.cuda.amp.GradScaler's semantics and constants - here device-resident (include/dmme_hip.h: dmme_amp_*): the loss gradient is
+multiplied by S on the device, the fused clip -> Adam -> EMA pass divides it out, skips the step when the scaled gradient is not finite
+and updates S; nothing is read back.  Gradients against the fp32 oracle at the benchmark batch; the scaler's skip / back-off / growth;
+the fused pass against torch.optim.Adam; end-to-end learning."""
+
+import ctypes as C
+
+import pytest
+import torch
+
+from oracle import diffusion as D
+from oracle import synth
+from oracle import unet as O
+
+from tests.test_gpu_grad_b128 import CLASS_BOUNDS, _bwd_summary, _class_errors, _classes
+
+pytestmark = pytest.mark.gpu
+
+# fp16 rounds 8x finer than bf16 (2^-11 vs 2^-8): the per-class gradient errors must come out at least 4x under the bf16 table
+# (measured values are printed by the test)
+FP16_CLASS_BOUNDS = {c: v / 4.0 for c, v in CLASS_BOUNDS.items()}
+
+
+def test_ddpm_batch128_fp16_train_gradients_vs_fp32_oracle():
+    import dmme_amd
+    from dmme_amd.optim import FusedAdam
+
+    cfg = O.UNetConfig()
+    sd = O.make_state_dict(cfg, 23)
+    T, reps = 1000, 64
+    x0 = synth.uniform(1, (2, 3, 32, 32))
+    t = torch.tensor([137, 862])
+    z = synth.normal(2, (2, 3, 32, 32))
+    masks = O.make_drop_masks(cfg, 2, 5)
+    names = O.res_block_names(cfg)
+    sdr = {k: v.clone().requires_grad_(k != "condition.0.embeddings") for k, v in sd.items()}
+    _, abar = D.alpha_tables(D.linear_beta(T))
+    loss_ref = D.training_loss(lambda xt, tt: O.unet_forward(sdr, cfg, xt, tt, drop_masks=masks), x0, t, z, abar)
+    loss_ref.backward()
+    want = {k: v.grad for k, v in sdr.items() if v.requires_grad}
+
+    def run(B):
+        r = B // 2
+        net = dmme_amd.UNet(precision="fp16")
+        net.load_state_dict(sd)
+        net.cuda().train()
+        opt = FusedAdam(net.parameters())  # switches the dynamic loss scaling on (GradScaler defaults: S = 65536)
+        flat = torch.cat([masks[k].repeat(r, 1).reshape(-1) for k in names])
+        net.inject_dropout_masks(flat.cuda())
+        ddpm = dmme_amd.DDPM(net, T).cuda()
+        loss = ddpm.training_step(x0.repeat(r, 1, 1, 1).cuda(), t=t.repeat(r).cuda(), noise=z.repeat(r, 1, 1, 1).cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+        S = opt.loss_scale()
+        assert S == 65536.0
+        g = {k: (p.grad.detach() / S).cpu().clone() for k, p in net.named_parameters()}  # the buffer holds S x gradient until the optimiser pass
+        assert all(bool(torch.isfinite(v).all()) for v in g.values())
+        return net, float(loss.detach()), g
+
+    net, loss128, g128 = run(2 * reps)
+    bw = _bwd_summary(net, 128, 32)
+    assert int(bw["wgrad_group3x3_jobs"]) > 1000 and int(bw["wgrad_group3x3_layers"]) >= 40 and int(bw["wgrad_group1x1_layers"]) >= 20, bw
+    assert int(bw.get("dgrad[conv3x3_ws2_kernel<11>]", 0)) >= 18, bw
+    assert abs(loss128 - float(loss_ref)) <= 1e-3 * abs(float(loss_ref)), (loss128, float(loss_ref))
+    classes = _classes(net)
+    vs_ref = _class_errors(g128, want, classes)
+    total = float(torch.cat([(g128[k] - want[k]).reshape(-1) for k in want]).norm() / torch.cat([want[k].reshape(-1) for k in want]).norm())
+    print("B=128 fp16 (loss scale 65536) vs fp32 oracle, worst relative error per tensor class:", {c: f"{v[0]:.3e} ({v[1]})" for c, v in vs_ref.items()})
+    print(f"whole flat gradient: relative error {total:.3e}")
+    for c, (rel, name) in vs_ref.items():
+        assert rel <= FP16_CLASS_BOUNDS[c], f"{c}: {rel:.3e} > {FP16_CLASS_BOUNDS[c]} at {name}"
+    assert total <= 2.5e-3, total
+
+
+def test_adam_step_amp_matches_torch_adam_and_skips_non_finite_steps():
+    """the fused pass on a SCALED gradient buffer: same parameters as torch.optim.Adam + clip_grad_norm_ on the unscaled gradient;
+    an inf in the buffer leaves parameters / moments / EMA untouched, halves the scale and does not count as a step; growth after
+    `growth_interval` finite steps"""
+    from dmme_amd import _lib
+
+    lib = _lib.lib()
+    n = 100_003
+    gen = torch.Generator("cuda").manual_seed(3)
+    p0 = torch.randn(n, device="cuda", generator=gen)
+    ref = p0.clone().requires_grad_(True)
+    topt = torch.optim.Adam([ref], lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    p, m, v, ema = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), p0.clone()
+    amp = torch.zeros(8, device="cuda")
+    _lib.check(lib.dmme_amp_init(_lib.ptr(amp), 1024.0, _lib.stream_ptr()))
+    norm, scratch = torch.zeros(1, device="cuda"), torch.empty(1024, device="cuda")
+    ema_ref = p0.clone()
+
+    def fused(g_scaled):
+        _lib.check(lib.dmme_grad_norm(_lib.ptr(g_scaled), n, _lib.ptr(norm), _lib.ptr(scratch), _lib.stream_ptr()))
+        _lib.check(lib.dmme_adam_step_amp(_lib.ptr(p), _lib.ptr(g_scaled), _lib.ptr(m), _lib.ptr(v), _lib.ptr(ema), n, 1e-3, 0.9, 0.999, 1e-8, _lib.ptr(norm), 1.0,
+                                          0.999, 1.0, _lib.ptr(amp), 2.0, 0.5, 3, _lib.stream_ptr()))
+
+    scale = 1024.0
+    for k in range(7):
+        g = torch.randn(n, device="cuda", generator=gen) * 0.02
+        if k == 2:  # an overflowed gradient
+            bad = (g * scale).clone()
+            bad[17] = float("inf")
+            before = (p.clone(), m.clone(), v.clone(), ema.clone())
+            fused(bad)
+            assert all(torch.equal(a, b) for a, b in zip(before, (p, m, v, ema)))
+            scale *= 0.5
+            st = amp.cpu()
+            assert float(st[0]) == scale and float(st[3]) == 1.0 and float(st[4]) == 1.0 and float(st[1]) == 0.0
+            continue
+        fused(g * scale)
+        ref.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([ref], 1.0)
+        topt.step()
+        ema_ref.mul_(0.999).add_(ref.detach(), alpha=0.001)
+        st = amp.cpu()
+        if float(st[1]) == 0.0 and float(st[3]) == 0.0:  # three finite steps in a row: grown
+            scale *= 2.0
+        assert float(st[0]) == scale, (k, st)
+    st = amp.cpu()
+    assert float(st[2]) == 6.0 and float(st[4]) == 1.0
+    assert float((p - ref.detach()).abs().max()) <= 2e-6 and float((ema - ema_ref).abs().max()) <= 2e-6
+
+
+def test_loss_scale_backs_off_from_an_overflowing_start_and_training_proceeds():
+    """an absurd initial scale (2^40) overflows the half-precision gradient tensors: those steps are skipped - parameters untouched,
+    scale halved each time - until the gradients are finite, then the loss goes down; no NaN ever reaches the weights"""
+    import dmme_amd
+    from dmme_amd.optim import FusedAdam
+    from dmme_amd.lr_scheduler import WarmupLR
+    from dmme_amd.train_loop import train_step
+
+    torch.manual_seed(0)
+    lit = dmme_amd.LitDDPM(model=dmme_amd.UNet(precision="fp16"), warmup=20).cuda()
+    lit.train()
+    net = lit.diffusion_model.model
+    opt = FusedAdam(lit.diffusion_model.parameters(), lr=2e-4, ema_decay=0.999, max_grad_norm=1.0, init_scale=2.0**40)
+    sched = WarmupLR(opt, 20)
+    base = torch.nn.functional.interpolate(torch.rand(64, 3, 4, 4, device="cuda") * 2 - 1, size=32, mode="bilinear")
+    w0 = net.flat_parameters().clone()
+    train_step(lit, opt, sched, base[:32])
+    st = net.amp_state().cpu()
+    assert float(st[4]) == 1.0 and float(st[2]) == 0.0 and float(st[0]) == 2.0**39, st  # skipped, halved
+    assert torch.equal(net.flat_parameters(), w0)
+    losses = []
+    for step in range(60):
+        losses.append(float(train_step(lit, opt, sched, base[torch.randint(0, 64, (32,), device="cuda")]).detach()))
+    st = net.amp_state().cpu()
+    print(f"loss scale after back-off: 2^{torch.log2(st[0]).item():.0f}; steps taken {int(st[2])}, skipped {int(st[4])}; loss {losses[0]:.3f} -> {losses[-1]:.3f}")
+    assert float(st[2]) >= 30 and float(st[4]) >= 5 and float(st[0]) < 2.0**36
+    assert bool(torch.isfinite(net.flat_parameters()).all()) and all(l == l for l in losses)
+    assert losses[-1] < 0.7 * losses[0]
+
+
+@pytest.mark.parametrize("which", ["ddpm", "iddpm"])
+def test_training_learns_fp16(which):
+    """the reference's shipped precision end to end: 120 steps (HIP backward in half, fused unscale + clip + Adam + EMA, warm-up)"""
+    import dmme_amd
+    from dmme_amd.train_loop import train_step
+
+    torch.manual_seed(0)
+    if which == "ddpm":
+        lit = dmme_amd.LitDDPM(model=dmme_amd.UNet(precision="fp16"), warmup=50)
+    else:
+        from dmme_amd.models import iddpm
+
+        lit = dmme_amd.LitIDDPM(model=iddpm.UNet(precision="fp16"), warmup=50)
+    lit = lit.cuda()
+    lit.train()
+    opts, scheds = lit.configure_optimizers()
+    opt, sched = opts[0], scheds[0]["scheduler"]
+    for g in opt.param_groups:
+        g["max_grad_norm"] = 1.0
+    base = torch.nn.functional.interpolate(torch.rand(256, 3, 4, 4, device="cuda") * 2 - 1, size=32, mode="bilinear")
+    first = last = None
+    for step in range(120):
+        loss = float(train_step(lit, opt, sched, base[torch.randint(0, 256, (64,), device="cuda")]).detach())
+        assert loss == loss, f"NaN loss at step {step}"
+        if step == 0:
+            first = loss
+        last = loss
+    st = lit.diffusion_model.model.amp_state().cpu()
+    print(f"{which}: loss {first:.3f} -> {last:.3f}; loss scale {float(st[0]):.0f}, steps {int(st[2])}, skipped {int(st[4])}")
+    assert first > 0.8 and last < 0.2 * first, (first, last)
+    assert float(st[2]) + float(st[4]) == 120 and float(st[4]) <= 12

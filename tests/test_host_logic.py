@@ -122,11 +122,11 @@ def test_lit_modules_and_yaml_runner():
 
     for name, cls, dm in (("ddpm", dmme_amd.LitDDPM, dmme_amd.DDPM), ("ddim", dmme_amd.LitDDIM, dmme_amd.DDIM)):
         conf = trainer.parse_config(os.path.join(ROOT, "configs", name, "cifar10.yaml"))
-        assert conf["batch_size"] == 128 and conf["max_steps"] == 800000 and conf["gradient_clip_val"] == 1.0 and conf["precision"] == "bf16"
+        assert conf["batch_size"] == 128 and conf["max_steps"] == 800000 and conf["gradient_clip_val"] == 1.0 and conf["precision"] == "fp16"  # `precision: 16`: IEEE half + loss scaling, as the reference
         module = trainer.build_module(conf)
         assert isinstance(module, cls) and type(module.diffusion_model) is dm
         assert module.lr == 2e-4 and module.warmup == 5000 and module.decay == 0.9999
-        assert module.diffusion_model.model.precision == "bf16"
+        assert module.diffusion_model.model.precision == "fp16"
         keys = list(module.state_dict().keys())
         assert keys[0] == "diffusion_model.model.condition.0.embeddings" and len(keys) == 305
     opts, scheds = module.configure_optimizers()
@@ -257,7 +257,7 @@ def test_yaml_in_the_reference_literal_forms_drives_module_and_optimizer(tmp_pat
     path = tmp_path / "ref_form.yaml"
     path.write_text(_REFERENCE_FORM_YAML)
     conf = trainer.parse_config(str(path))
-    assert conf["max_steps"] == 800000 and conf["gradient_clip_val"] == 1.0 and conf["precision"] == "bf16" and conf["ckpt_path"] is None
+    assert conf["max_steps"] == 800000 and conf["gradient_clip_val"] == 1.0 and conf["precision"] == "fp16" and conf["ckpt_path"] is None
     module = trainer.build_module(conf)
     assert isinstance(module.lr, float) and module.lr == 2e-5 and isinstance(module.warmup, int)
     unet = module.diffusion_model.model
@@ -293,7 +293,7 @@ def test_reference_yaml_files_parse_and_build_unchanged(rel, cls, numel):
     assert sum(p.numel() for p in module.parameters()) == numel
     opts, scheds = module.configure_optimizers()
     assert isinstance(opts[0].param_groups[0]["lr"], float) and scheds[0]["interval"] == "step"
-    assert conf["precision"] == "bf16" and conf["gradient_clip_val"] == 1.0
+    assert conf["precision"] == "fp16" and conf["gradient_clip_val"] == 1.0
 
 
 # ------------------------------------------------------------------------------------------ stale packed weights
@@ -411,14 +411,14 @@ def test_bench_cpu_plumbing_mode_runs_the_reference_yaml_on_the_oracle():
 
 def test_trainer_sample_geometry_and_precision_follow_the_yaml(tmp_path):
     """`trainer sample` takes the image size from the YAML's data module (dmme.LSUN: init_args.imgsize, configs/ddpm/lsun_church.yaml:94)
-    and maps `precision: 16` to IEEE half for sampling, bf16 for training"""
+    and maps `precision: 16` to IEEE half (training under dynamic loss scaling, and sampling)"""
     import os
 
     from dmme_amd import trainer
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     conf = trainer.parse_config(os.path.join(root, "configs", "ddpm", "cifar10.yaml"))
-    assert conf["image_size"] == 32 and conf["precision"] == "bf16" and conf["sample_precision"] == "fp16"
+    assert conf["image_size"] == 32 and conf["precision"] == "fp16" and conf["sample_precision"] == "fp16"
     ref = "/root/reference/configs/ddpm/lsun_church.yaml"
     if os.path.exists(ref):  # (not on the GPU box)
         assert trainer.parse_config(ref)["image_size"] == 256

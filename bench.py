@@ -636,6 +636,19 @@ def main():
             out["train_step_tflops"] = round(ttf, 1)
             out["train_step_frac_of_peak"] = round(ttf / (world * peak), 4)
             if world > 1:
+                n_buckets = 0
+                try:  # how many gradient buckets the plan's backward hands to the exchange
+                    import ctypes as C_
+
+                    mb = dmme_amd.UNet(precision=args.precision).to(dev) if args.model == "ddpm" else None
+                    if mb is not None:
+                        pl = mb._plan_for(B, side, side, dev)
+                        bks = (C_.c_int * 64)()
+                        cnt = pl.lib.dmme_unet_plan_grad_buckets(pl.h, (C_.c_int64 * 64)(), (C_.c_int64 * 64)(), bks, 64)
+                        n_buckets = max(bks[i] for i in range(min(cnt, 64))) + 1
+                        del mb, pl
+                except Exception:  # noqa: BLE001
+                    n_buckets = 0
                 # the same step without its collective, and the collective alone: what the overlap hides
                 dt_nc, _, _ = train_leg(dmme_amd, dev, B, args.precision, k, 3, dist, args.model, reduce=False)
                 ar_ms = allreduce_alone_ms(dist, dev, numel)
@@ -646,7 +659,7 @@ def main():
                     "ms_per_step": round(step_ms, 3), "ms_per_step_without_allreduce": round(nocomm_ms, 3),
                     "allreduce_alone_ms": round(ar_ms, 3), "allreduce_exposed_ms": round(exposed, 3),
                     "allreduce_hidden_ms": round(max(0.0, ar_ms - exposed), 3), "gradient_bytes": numel * 4,
-                    "exchange": os.environ.get("DMME_EXCHANGE", "fp32-allreduce")}
+                    "exchange": DD.default_exchange(B), "gradient_buckets": n_buckets}
                 # the other wire format of the gradient mean (distributed.Bf16ShardExchange: bf16 all-to-all + all-gather, fp32 accumulation)
                 try:
                     dt_bf, _, _ = train_leg(dmme_amd, dev, B, args.precision, k, 3, dist, args.model, exchange="bf16-rs-ag")

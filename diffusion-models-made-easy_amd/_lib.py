@@ -95,7 +95,7 @@ PROTOTYPES = {
     "dmme_unet_pack_params_bwd": (_i, [_vp, _vp, _vp, _vp]),
     "dmme_unet_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dmme_unet_backward_buckets": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, BUCKET_FN, _vp]),
-    "dmme_unet_plan_grad_buckets": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "dmme_unet_plan_grad_buckets": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i), _i]),
     "dmme_unet_plan_bwd_summary": (_i, [_vp, C.c_char_p, _i]),
     "dmme_grad_norm": (_i, [_vp, _i64, _vp, _vp, _vp]),
     "dmme_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _vp, _f, _f, _f, _vp]),

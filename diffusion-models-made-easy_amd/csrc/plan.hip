@@ -175,15 +175,19 @@ struct dmme_plan {
         int dma = 0;  // every layer's second operand is one prologue-free tensor: the LDS-DMA kernel runs the table
         int stride = 1;
     } wg[3];  // 3x3, 1x1, 3x3 stride 2 (LDS-DMA kernel only)
-    // Two-bucket backward (gradient all-reduce overlapped with backward): bucket 0 = the parameters backward finishes first
-    // (up_layers, middle_layers, output_conv: the contiguous tail of the flat buffer), bucket 1 = the rest.  Plan-time split of
-    // every deferred table at that boundary: [0] = bucket 0, [1] = bucket 1.
-    WgGroup wgb[2][3];
-    int op_split = 0;                 // first op (forward order) of bucket 0
-    int64_t bucket_off = 0;           // flat offset where bucket 0 starts
-    int bias_split = 0;               // bias_jobs[bias_split:] belong to bucket 0
-    int unpack_split = 0;             // items_unpack[unpack_split:] belong to bucket 0
-    int tcol_split = 0;               // time-projection columns [tcol_split, tproj_cols) belong to bucket 0
+    // Bucketed backward (gradient exchange overlapped with backward): the op list is cut at ResBlock boundaries into stretches that
+    // backward finishes one after the other (bucket 0 = output conv + the last up blocks, ... the last bucket = the first down
+    // blocks, input conv and time MLP); every deferred table is split along the same cuts at plan time, so a bucket's parameter
+    // gradients are complete - and handed to the exchange - as soon as the reverse walk leaves its stretch.  Cut so that no bucket
+    // holds more than ~1/6 of the parameters: the LAST one, whose exchange nothing hides, is <= 15 % of the bytes.
+    struct GradBucket {
+        int op_lo = 0, op_hi = 0;                          // plan ops [op_lo, op_hi)
+        WgGroup wg[3];
+        int col0 = 0, col1 = 0, bias0 = 0, bias1 = 0;      // ranges of col_jobs / bias_jobs
+        std::vector<std::pair<int, int>> unpack, tcols;    // ranges of items_unpack / of time-projection columns
+        std::vector<std::pair<int64_t, int64_t>> ranges;   // (flat offset, numel) of its parameters, merged
+    };
+    std::vector<GradBucket> gb;                            // empty: no clean cut for this configuration (one piece)
     // batched time-projection gradients: destination (float offset into grad_flat) of every 64-row tile of
     // dtproj^T temb, then of every 32-column tile of the bias sums
     int64_t* tp_tiles_dev = nullptr;
@@ -193,7 +197,6 @@ struct dmme_plan {
     BiasJob* bias_jobs_dev = nullptr;
     std::vector<ColJob> col_jobs;     // column sums of dY of every bias-deferred conv: one grouped launch per flush
     ColJob* col_jobs_dev = nullptr;
-    int col_split = 0;                // col_jobs[col_split:] belong to bucket 0
     std::vector<LvlRun> lvl_runs;     // level-engine launches (small maps)
     // every workgroup of an engine launch must be resident at once: grids are sized by what the device holds (assign_levels)
     int lvl_max_wg = LVL_MAX_WG;
@@ -1863,39 +1866,124 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
             ++P->n_launches;
     }
     if (device >= 0) {
-        // bucket boundary: parameters from the first up_layers entry on are finished first by backward
-        P->op_split = (int)P->ops.size();
-        P->bucket_off = P->ref_numel;
-        for (const Param& pp : P->params)
-            if (pp.name.rfind("up_layers.", 0) == 0) {
-                P->bucket_off = pp.ref_off;
-                break;
-            }
+        // ---- gradient buckets: cuts at ResBlock starts (a block's first op is the GroupNorm of its conv1), walked in backward order
+        std::vector<int> owner(P->params.size(), -1);  // op index that produces each parameter's gradient (-1: the time MLP, at the very end)
         for (int oi = 0; oi < (int)P->ops.size(); ++oi) {
             const Op& o = P->ops[oi];
-            const int pi = o.kind == OP_CONV ? o.w : o.kind == OP_GN ? o.gn_gamma : -1;
-            if (pi >= 0 && P->params[pi].ref_off >= P->bucket_off) {
-                P->op_split = oi;
-                break;
+            if (o.kind == OP_CONV) {
+                owner[o.w] = oi;
+                owner[o.b] = oi;
+            } else if (o.kind == OP_GN) {
+                owner[o.gn_gamma] = oi;
+                owner[o.gn_beta] = oi;
             }
         }
-        for (int oi = P->op_split; oi < (int)P->ops.size(); ++oi) {  // the split must be clean: nothing of bucket 1 after it
-            const Op& o = P->ops[oi];
-            const int pi = o.kind == OP_CONV ? o.w : o.kind == OP_GN ? o.gn_gamma : -1;
-            if (pi >= 0 && P->params[pi].ref_off < P->bucket_off) P->op_split = -1;
+        std::vector<int> tcol_owner(P->tblocks.size(), -1);
+        for (size_t k = 0; k < P->tblocks.size(); ++k) {
+            const auto& tb = P->tblocks[k];
+            for (int oi = 0; oi < (int)P->ops.size(); ++oi) {
+                const Op& o = P->ops[oi];
+                if ((o.kind == OP_CONV && o.tproj_col == tb.col) || (o.kind == OP_GN && o.gn_mod_col == tb.col)) tcol_owner[k] = oi;
+            }
+            if (tcol_owner[k] >= 0) owner[tb.tw] = owner[tb.tb] = tcol_owner[k];
         }
-        P->tcol_split = P->tproj_cols;
-        for (const auto& tb : P->tblocks)
-            if (P->params[tb.tw].ref_off >= P->bucket_off && tb.col < P->tcol_split) P->tcol_split = tb.col;
-        for (const auto& tb : P->tblocks)
-            if ((P->params[tb.tw].ref_off >= P->bucket_off) != (tb.col >= P->tcol_split)) P->op_split = -1;
-        for (int b = 0; b < 2 && P->op_split > 0; ++b)  // before the "all" build: that one leaves the final Op::wg_layer values
-            for (int k = 0; k < 3; ++k)
-                build_wgrad_group(P, P->wgb[b][k], k, b == 0 ? P->op_split : 0, b == 0 ? 1 << 30 : P->op_split);
+        {
+            int64_t total = 0;
+            for (size_t pi = 0; pi < P->params.size(); ++pi)
+                if (!P->params[pi].is_buffer) total += P->params[pi].numel();
+            // block starts: a GroupNorm op whose consumer conv carries a time projection (DDPM) or that is followed by one (IDDPM conv1),
+            // i.e. the first op of a ResBlock; also bare down / up convs.  Simpler and sufficient: any OP_GN whose source is not produced by
+            // the op right before it inside the same block - approximated by "conv1's norm": the norm of a conv with tproj_col >= 0 (DDPM)
+            // or the norm two ops ahead of a modulated norm (IDDPM).
+            std::vector<char> is_start(P->ops.size(), 0);
+            for (int oi = 0; oi < (int)P->ops.size(); ++oi) {
+                const Op& o = P->ops[oi];
+                if (o.kind != OP_CONV || o.gn < 0) continue;
+                const bool conv1 = P->cfg.arch == DMME_ARCH_IDDPM ? (oi + 1 < (int)P->ops.size() && P->ops[oi + 1].kind == OP_GN && P->ops[oi + 1].gn_mod_col >= 0) : o.tproj_col >= 0;
+                if (conv1) is_start[o.gn] = 1;
+            }
+            const int n_target = debug_route("grad_buckets", 6);
+            // candidates: block starts with the fraction of the parameters backward has finished when the walk reaches them
+            std::vector<std::pair<int, double>> cand;
+            {
+                int64_t acc = 0;
+                for (int oi = (int)P->ops.size() - 1; oi > 0; --oi) {
+                    for (size_t pi = 0; pi < P->params.size(); ++pi)
+                        if (owner[pi] == oi && !P->params[pi].is_buffer) acc += P->params[pi].numel();
+                    if (is_start[oi]) cand.push_back({oi, (double)acc / (double)(total > 0 ? total : 1)});
+                }
+            }
+            std::vector<int> cuts{(int)P->ops.size()};
+            if (n_target > 1 && !cand.empty()) {
+                // the last cut first: what is left behind it (first down blocks, input conv, time MLP) is the one exchange no compute
+                // hides - as close to 12 % of the bytes as the block boundaries allow
+                int last = -1;
+                double best = 1e9;
+                for (int k = 0; k < (int)cand.size(); ++k) {
+                    const double rest = 1.0 - cand[k].second;
+                    if (rest < 0.04) continue;
+                    const double d = rest > 0.12 ? rest - 0.12 : 2.0 * (0.12 - rest);
+                    if (d < best) { best = d; last = k; }
+                }
+                if (last >= 0) {
+                    // the others: the block boundary nearest to each multiple of (what is in front of the last cut) / (n - 1)
+                    const double step = cand[last].second / (double)(n_target - 1);
+                    int prev_k = -1;
+                    for (int q = 1; q < n_target - 1; ++q) {
+                        int pick = -1;
+                        double bd = 1e9;
+                        for (int k = prev_k + 1; k < last; ++k) {
+                            const double d = cand[k].second > q * step ? cand[k].second - q * step : q * step - cand[k].second;
+                            if (d < bd) { bd = d; pick = k; }
+                        }
+                        if (pick < 0) break;
+                        cuts.push_back(cand[pick].first);
+                        prev_k = pick;
+                    }
+                    cuts.push_back(cand[last].first);
+                }
+            }
+            cuts.push_back(0);
+            bool clean = cuts.size() > 2 && !getenv("DMME_NO_GRAD_BUCKETS");
+            if (clean) {
+                P->gb.resize(cuts.size() - 1);
+                for (size_t b = 0; b + 1 < cuts.size(); ++b) {
+                    dmme_plan::GradBucket& G = P->gb[b];
+                    G.op_hi = cuts[b];
+                    G.op_lo = cuts[b + 1];
+                    const bool last = b + 2 == cuts.size();
+                    std::vector<std::pair<int64_t, int64_t>> r;
+                    for (size_t pi = 0; pi < P->params.size(); ++pi) {
+                        const Param& pp = P->params[pi];  // (the sinusoid table, a buffer without gradient, rides in the last bucket: the
+                                                          // hand-overs then tile the whole flat buffer)
+                        const bool mine = owner[pi] < 0 ? last : (owner[pi] >= G.op_lo && owner[pi] < G.op_hi);
+                        if (!mine) continue;
+                        if (!r.empty() && r.back().first + r.back().second == pp.ref_off) r.back().second += pp.numel();
+                        else r.push_back({pp.ref_off, pp.numel()});
+                    }
+                    G.ranges = r;
+                    for (size_t k = 0; k < P->tblocks.size(); ++k) {
+                        if (tcol_owner[k] < G.op_lo || tcol_owner[k] >= G.op_hi) continue;
+                        const int c0 = P->tblocks[k].col, c1 = c0 + P->tblocks[k].cout;
+                        if (!G.tcols.empty() && G.tcols.back().second == c0) G.tcols.back().second = c1;
+                        else G.tcols.push_back({c0, c1});
+                    }
+                    // (the tiled time-projection gradient addresses 64-column tiles: it exists only when every block's width is a
+                    // multiple of 64, and then so is every range start)
+                }
+                for (size_t k = 0; k < P->tblocks.size(); ++k)
+                    if (tcol_owner[k] < 0) clean = false;
+            }
+            if (!clean) P->gb.clear();
+        }
+        for (auto& G : P->gb)  // before the "all" build: that one leaves the final Op::wg_layer values
+            for (int k = 0; k < 3; ++k) build_wgrad_group(P, G.wg[k], k, G.op_lo, G.op_hi);
         for (int k = 0; k < 3; ++k) build_wgrad_group(P, P->wg[k], k);
+        std::vector<int> bias_job_op, col_job_op;  // op index each job belongs to (gradient buckets)
         if (!getenv("DMME_NO_BIAS_GROUP"))
             for (Op& o : P->ops) {
                 if (o.kind != OP_CONV) continue;
+                const int o_index = (int)(&o - P->ops.data());
                 ConvArgs a{};
                 fill_conv(P, o, nullptr, nullptr, nullptr, nullptr, nullptr, 1, a);
                 if (o.gn >= 0 && o.b_gnrows >= 0) {
@@ -1916,13 +2004,12 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
                                 j.cblock = cb;
                                 j.tcol = -1;
                                 P->bias_jobs.push_back(j);
+                                bias_job_op.push_back(o.gn);
                             }
-                        if (o.gn < P->op_split) P->bias_split = (int)P->bias_jobs.size();
                     }
                 }
                 if (!colsum_fast_supported(P->dtype, a.Hout * a.Wout, a.Cout)) continue;
                 o.bias_deferred = 1;
-                if ((int)(&o - P->ops.data()) < P->op_split) P->bias_split = (int)P->bias_jobs.size() + (a.Cout + 31) / 32;
                 if (!getenv("DMME_NO_COLSUM_GROUP")) {
                     ColJob cj{};
                     const int nch = colsum_group_chunks(P->dtype, a.Hout * a.Wout, a.Cout, &cj.chunk_px, &cj.ppw);
@@ -1933,8 +2020,8 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
                     for (int ch = 0; ch < nch; ++ch) {
                         cj.chunk = ch;
                         P->col_jobs.push_back(cj);
+                        col_job_op.push_back(o_index);
                     }
-                    if ((int)(&o - P->ops.data()) < P->op_split) P->col_split = (int)P->col_jobs.size();
                 }
                 for (int cb = 0; cb < (a.Cout + 31) / 32; ++cb) {
                     BiasJob j{};
@@ -1944,8 +2031,25 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
                     j.cblock = cb;
                     j.tcol = o.tproj_col;
                     P->bias_jobs.push_back(j);
+                    bias_job_op.push_back(o_index);
                 }
             }
+        for (auto& G : P->gb) {  // jobs were pushed in ascending op order: a bucket's jobs are one index range
+            auto range = [&](const std::vector<int>& ops_of, int& j0, int& j1) {
+                j0 = j1 = 0;
+                bool any = false, ok = true;
+                for (int j = 0; j < (int)ops_of.size(); ++j) {
+                    if (ops_of[j] < G.op_lo || ops_of[j] >= G.op_hi) continue;
+                    if (!any) { j0 = j; any = true; } else if (j != j1) ok = false;
+                    j1 = j + 1;
+                }
+                return ok;
+            };
+            if (!range(bias_job_op, G.bias0, G.bias1) || !range(col_job_op, G.col0, G.col1)) {
+                P->gb.clear();
+                break;
+            }
+        }
     }
     if (device >= 0) {
         std::vector<PackItem> items;
@@ -1990,7 +2094,10 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
             if (e == hipSuccess) e = hipMalloc((void**)&P->bias_jobs_dev, P->bias_jobs.size() * sizeof(BiasJob));
             if (e == hipSuccess) e = hipMemcpy(P->bias_jobs_dev, P->bias_jobs.data(), P->bias_jobs.size() * sizeof(BiasJob), hipMemcpyHostToDevice);
         }
-        for (dmme_plan::WgGroup* G : {&P->wg[0], &P->wg[1], &P->wg[2], &P->wgb[0][0], &P->wgb[0][1], &P->wgb[0][2], &P->wgb[1][0], &P->wgb[1][1], &P->wgb[1][2]}) {
+        std::vector<dmme_plan::WgGroup*> all_groups{&P->wg[0], &P->wg[1], &P->wg[2]};
+        for (auto& B_ : P->gb)
+            for (int k = 0; k < 3; ++k) all_groups.push_back(&B_.wg[k]);
+        for (dmme_plan::WgGroup* G : all_groups) {
             if (G->jobs.empty()) continue;
             if (e == hipSuccess) e = hipMalloc((void**)&G->layers_dev, G->layers.size() * sizeof(WgLayer));
             if (e == hipSuccess) e = hipMemcpy(G->layers_dev, G->layers.data(), G->layers.size() * sizeof(WgLayer), hipMemcpyHostToDevice);
@@ -2008,14 +2115,14 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
             if (e == hipSuccess) e = hipMalloc((void**)&R.sync_dev, words * 4);
             if (e == hipSuccess) e = hipMemset(R.sync_dev, 0, words * 4);
         }
-        P->unpack_split = (int)uitems.size();
-        for (int i = 0; i < (int)uitems.size(); ++i)
-            if (uitems[i].src_off >= P->bucket_off) {
-                P->unpack_split = i;
-                break;
+        for (auto& G : P->gb)  // unpack items follow the parameter order: a bucket's items are the runs inside its flat ranges
+            for (int i = 0; i < (int)uitems.size(); ++i) {
+                bool mine = false;
+                for (auto& r : G.ranges) mine = mine || (uitems[i].src_off >= r.first && uitems[i].src_off < r.first + r.second);
+                if (!mine) continue;
+                if (!G.unpack.empty() && G.unpack.back().second == i) G.unpack.back().second = i + 1;
+                else G.unpack.push_back({i, i + 1});
             }
-        for (int i = P->unpack_split; i < (int)uitems.size(); ++i)
-            if (uitems[i].src_off < P->bucket_off) P->op_split = -1;
         if (e != hipSuccess) {
             set_error("plan_create: device table setup failed: %s", hipGetErrorString(e));
             delete P;
@@ -2031,7 +2138,10 @@ DMME_API void dmme_unet_plan_destroy(dmme_plan* plan) {
     if (plan->items_dev) (void)hipFree(plan->items_dev);
     if (plan->items_bwd_dev) (void)hipFree(plan->items_bwd_dev);
     if (plan->items_unpack_dev) (void)hipFree(plan->items_unpack_dev);
-    for (dmme_plan::WgGroup* G : {&plan->wg[0], &plan->wg[1], &plan->wg[2], &plan->wgb[0][0], &plan->wgb[0][1], &plan->wgb[0][2], &plan->wgb[1][0], &plan->wgb[1][1], &plan->wgb[1][2]}) {
+    std::vector<dmme_plan::WgGroup*> all_groups{&plan->wg[0], &plan->wg[1], &plan->wg[2]};
+    for (auto& B_ : plan->gb)
+        for (int k = 0; k < 3; ++k) all_groups.push_back(&B_.wg[k]);
+    for (dmme_plan::WgGroup* G : all_groups) {
         if (G->layers_dev) (void)hipFree(G->layers_dev);
         if (G->jobs_dev) (void)hipFree(G->jobs_dev);
     }
@@ -2235,39 +2345,45 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
     char* tmp = bws + P->bws_tmp;
     int rc = launch_nchw_to_nhwc(dt, d_y, B, P->out_channels, P->H * P->W, bws + P->bws_dy, s);
     if (rc != DMME_OK) return rc;
-    const bool buckets = ready != nullptr && P->op_split > 0;  // two-bucket mode: deferred work flushed per bucket
+    const bool buckets = ready != nullptr && !P->gb.empty();  // bucketed mode: deferred work flushed per gradient bucket
     const int emb = P->cfg.emb_dim, pos = P->cfg.pos_dim, tc = P->tproj_cols;
     const float* temb = (const float*)(ws + P->ws_temb);
-    // deferred launches of one bucket (b = 0 / 1) or of everything (b = -1): bias + time rows, grouped weight gradients, unpack,
+    // deferred launches of one gradient bucket (b >= 0) or of everything (b = -1): bias + time rows, grouped weight gradients, unpack,
     // the per-block time-projection weight gradients
     auto flush = [&](int b) -> int {
         int r = DMME_OK;
+        const dmme_plan::GradBucket* GBk = b >= 0 ? &P->gb[b] : nullptr;
         if (P->bias_jobs_dev && P->col_jobs_dev) {
-            const int j0 = b == 0 ? P->col_split : 0, j1 = b == 1 ? P->col_split : (int)P->col_jobs.size();
+            const int j0 = GBk ? GBk->col0 : 0, j1 = GBk ? GBk->col1 : (int)P->col_jobs.size();
             if (j1 > j0) r = launch_colsum_group(dt, P->col_jobs_dev + j0, j1 - j0, bws, B, s);
             if (r != DMME_OK) return r;
         }
         if (P->bias_jobs_dev) {
-            const int j0 = b == 0 ? P->bias_split : 0, j1 = b == 1 ? P->bias_split : (int)P->bias_jobs.size();
+            const int j0 = GBk ? GBk->bias0 : 0, j1 = GBk ? GBk->bias1 : (int)P->bias_jobs.size();
             if (j1 > j0) r = launch_bias_tproj_group(P->bias_jobs_dev + j0, j1 - j0, bws, grad_flat, dtproj, B, tc, nt, s);
             if (r != DMME_OK) return r;
         }
         for (int k = 0; k < 3; ++k) {
-            const dmme_plan::WgGroup& G = b < 0 ? P->wg[k] : P->wgb[b][k];
+            const dmme_plan::WgGroup& G = GBk ? GBk->wg[k] : P->wg[k];
             if (!G.jobs_dev) continue;
             r = launch_wgrad_group(dt, G.taps, G.layers_dev, G.jobs_dev, (int)G.jobs.size(), ws, bws, drop_masks, wimage, s, G.dma, bws + P->bws_zpage);
             if (r != DMME_OK) return r;
         }
         {
-            const int i0 = b == 0 ? P->unpack_split : 0, i1 = b == 1 ? P->unpack_split : P->n_items_unpack;
-            if (i1 > i0) r = launch_wgrad_unpack(P->items_unpack_dev + i0, i1 - i0, wimage, grad_flat, s);
-            if (r != DMME_OK) return r;
+            std::vector<std::pair<int, int>> all_items{{0, P->n_items_unpack}};
+            for (const auto& ir : (GBk ? GBk->unpack : all_items)) {
+                if (ir.second > ir.first) r = launch_wgrad_unpack(P->items_unpack_dev + ir.first, ir.second - ir.first, wimage, grad_flat, s);
+                if (r != DMME_OK) return r;
+            }
         }
-        const int c0 = b == 0 ? P->tcol_split : 0, c1 = b == 1 ? P->tcol_split : tc;
-        if (c1 > c0) {
+        std::vector<std::pair<int, int>> all_cols{{0, tc}};
+        for (const auto& cr : (GBk ? GBk->tcols : all_cols)) {
+            const int c0 = cr.first, c1 = cr.second;
+            if (c1 <= c0) continue;
             if (P->tp_tiles_dev) {  // every block's dW / db in one launch each
                 r = launch_small_gemm_tn_tiled(dtproj + c0, tc, temb, emb, c1 - c0, emb, nt, grad_flat, emb, P->tp_tiles_dev + c0 / 64, s);
                 if (r == DMME_OK) r = launch_nsum_tiled(dtproj + c0, nt, c1 - c0, tc, 1, grad_flat, P->tp_tiles_dev + P->tp_n64 + c0 / 32, s);
+                if (r != DMME_OK) return r;
             } else {
                 for (const auto& tb : P->tblocks) {
                     if (tb.col < c0 || tb.col >= c1) continue;
@@ -2280,14 +2396,21 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
         }
         return r;
     };
+    auto hand_over = [&](int b) {
+        for (const auto& r : P->gb[b].ranges) ready(user, b, r.first, r.second);
+    };
+    int next_bucket = 0;  // the bucket whose stretch the reverse walk is in
     if (P->cfg.arch == DMME_ARCH_IDDPM && nt == 1)  // shared timestep row: the GroupNorm backward accumulates into it atomically
         DMME_CHECK_HIP(hipMemsetAsync(dtproj, 0, (size_t)P->tproj_cols * 4, s));
 
     for (int oi = (int)P->ops.size() - 1; oi >= 0 && rc == DMME_OK; --oi) {
-        if (buckets && oi == P->op_split - 1) {  // every op of bucket 0 has run: finish its parameter gradients and hand it over
-            rc = flush(0);
+        if (buckets && next_bucket + 1 < (int)P->gb.size() && oi == P->gb[next_bucket].op_lo - 1) {
+            // every op of this bucket has run (a pending identity-residual gradient that belongs to a tensor of the NEXT stretch stays
+            // pending: it carries no parameter gradient): finish the bucket's parameter gradients and hand it to the exchange
+            rc = flush(next_bucket);
             if (rc != DMME_OK) break;
-            ready(user, 0, P->bucket_off, P->ref_numel - P->bucket_off);
+            hand_over(next_bucket);
+            ++next_bucket;
         }
         const Op& o = P->ops[oi];
         if (o.kind == OP_ATTN) {
@@ -2335,7 +2458,7 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
                                o.tproj_col >= 0 ? dtproj + o.tproj_col : nullptr, P->tproj_cols, nt, s);
         if (rc != DMME_OK) break;
         // 2. weight gradient: deferred to the grouped launch below, or per layer (packed image / reference layout)
-        if (o.wg_layer >= 0 && (buckets ? P->wgb[oi >= P->op_split ? 0 : 1][wg_index(o)].jobs_dev : P->wg[wg_index(o)].jobs_dev))
+        if (o.wg_layer >= 0 && (buckets ? P->gb[next_bucket].wg[wg_index(o)].jobs_dev : P->wg[wg_index(o)].jobs_dev))
             rc = DMME_OK;
         else if (wgrad_mfma_supported(dt, a))
             rc = launch_wgrad_mfma(dt, a, dy, wimage + P->params[o.w].wp_off, s);
@@ -2464,7 +2587,7 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
     }
     for (int id = 0; id < (int)pending.size() && rc == DMME_OK; ++id) rc = flush_pending(id);
     if (rc != DMME_OK) return rc;
-    rc = flush(buckets ? 1 : -1);
+    rc = flush(buckets ? (int)P->gb.size() - 1 : -1);
     if (rc != DMME_OK) return rc;
 
     // ---- time MLP backward (models/ddpm.py:211-217 and the per-block Linear at :101-104) ----
@@ -2498,7 +2621,7 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
     if (rc == DMME_OK) rc = launch_silu_bwd(dh1, z, nt * emb, s);
     if (rc == DMME_OK) rc = launch_small_gemm(dt, 2, dh1, emb, esin, pos, emb, pos, nt, nullptr, 0, grad_flat + P->params[P->p_l1w].ref_off, pos, s);
     if (rc == DMME_OK) rc = launch_nsum(dh1, nt, emb, emb, 1, grad_flat + P->params[P->p_l1b].ref_off, s);
-    if (rc == DMME_OK && buckets) ready(user, 1, 0, P->bucket_off);
+    if (rc == DMME_OK && buckets) hand_over((int)P->gb.size() - 1);
     return rc;
 }
 
@@ -2515,15 +2638,25 @@ DMME_API int dmme_unet_backward_buckets(const dmme_plan* plan, const void* packe
     return backward_impl(plan, packed, packed_bwd, x, t, t_len, d_y, workspace, bwd_workspace, drop_masks, grad_flat, d_x, stream, ready, user);
 }
 
-DMME_API int dmme_unet_plan_grad_buckets(const dmme_plan* plan, int64_t offsets[2], int64_t numels[2]) {
-    DMME_REQUIRE(plan && offsets && numels, DMME_ERR_INVALID, "grad_buckets: null argument");
-    if (plan->op_split <= 0) {  // no clean split for this configuration: one bucket
-        offsets[0] = 0; numels[0] = plan->ref_numel; offsets[1] = 0; numels[1] = 0;
+DMME_API int dmme_unet_plan_grad_buckets(const dmme_plan* plan, int64_t* offsets, int64_t* numels, int* bucket_of, int cap) {
+    DMME_REQUIRE(plan && offsets && numels && cap > 0, DMME_ERR_INVALID, "grad_buckets: bad argument");
+    if (plan->gb.empty()) {  // no clean cut for this configuration: one piece
+        offsets[0] = 0;
+        numels[0] = plan->ref_numel;
+        if (bucket_of) bucket_of[0] = 0;
         return 1;
     }
-    offsets[0] = plan->bucket_off; numels[0] = plan->ref_numel - plan->bucket_off;
-    offsets[1] = 0; numels[1] = plan->bucket_off;
-    return 2;
+    int n = 0;
+    for (size_t b = 0; b < plan->gb.size(); ++b)
+        for (const auto& r : plan->gb[b].ranges) {
+            if (n < cap) {
+                offsets[n] = r.first;
+                numels[n] = r.second;
+                if (bucket_of) bucket_of[n] = (int)b;
+            }
+            ++n;
+        }
+    return n;
 }
 
 /* Which kernels a backward of this plan launches, as "key=value" pairs: the grouped weight-gradient layers / jobs per kernel

@@ -151,6 +151,7 @@ class OverlappedGradReducer:
             h.wait()
         self.handles.clear()
         self.reported.clear()
+        self.model._exchange_in_flight = False
 
     def grad_scale(self) -> float:
         """what the optimiser must multiply the exchanged buffer by to obtain the mean gradient"""
@@ -163,6 +164,9 @@ class OverlappedGradReducer:
         self.reported.append((offset, numel))
         if not self.active():
             return
+        # from the first collective of a step until finish() joined them, no forward of this model may be enqueued: the level
+        # engine's persistent launches need every compute unit free of other kernels' workgroups (models/ddpm.py: _forward_impl asks)
+        self.model._exchange_in_flight = True
         flat = self.model.flat_grad() if flat_grad is None else flat_grad
         world = dist.get_world_size()
         view = flat[offset : offset + numel]
@@ -201,6 +205,7 @@ class OverlappedGradReducer:
             torch.cuda.current_stream().wait_stream(self._stream)
         self.handles.clear()
         self.reported.clear()
+        self.model._exchange_in_flight = False  # everything the compute stream enqueues from here on is ordered behind the collectives
         return True
 
 
@@ -268,9 +273,20 @@ class Bf16ShardExchange(OverlappedGradReducer):
             v.copy_(gathered[:n])
 
 
-def make_reducer(model, exchange: Optional[str] = None):
-    """the gradient exchange of a data-parallel run: DMME_EXCHANGE / `exchange` = 'fp32-allreduce' (default) or 'bf16-rs-ag'"""
-    kind = exchange or os.environ.get("DMME_EXCHANGE", "fp32-allreduce")
+def default_exchange(per_rank_batch: Optional[int] = None) -> str:
+    """`fp32-allreduce`, except where the step is too short to hide a ring all-reduce of 130 MB over one xGMI link (~1.5 ms at world
+    8): at <= 32 images per rank (north_star's "batch of 128 sharded over 8 GPUs" = 16 per rank: ~1.1 ms of backward) the direct
+    bf16 reduce-scatter + all-gather (2 x 8 MB per peer over all seven links, ~0.11 ms) is the default.  DMME_EXCHANGE overrides."""
+    env = os.environ.get("DMME_EXCHANGE")
+    if env:
+        return env
+    return "bf16-rs-ag" if (per_rank_batch is not None and per_rank_batch <= 32) else "fp32-allreduce"
+
+
+def make_reducer(model, exchange: Optional[str] = None, per_rank_batch: Optional[int] = None):
+    """the gradient exchange of a data-parallel run: `exchange` / DMME_EXCHANGE = 'fp32-allreduce' or 'bf16-rs-ag'; unset: by the
+    per-rank batch (default_exchange)"""
+    kind = exchange or default_exchange(per_rank_batch)
     if kind == "bf16-rs-ag":
         return Bf16ShardExchange(model)
     if kind != "fp32-allreduce":

@@ -418,6 +418,11 @@ class UNet(nn.Module):
         return dx
 
     def _forward_impl(self, x: Tensor, c: Tensor, want_ctx: bool = False):
+        if getattr(self, "_exchange_in_flight", False):
+            # a gradient exchange of this model is still on its side stream (distributed.OverlappedGradReducer between its first
+            # bucket and finish()): a forward enqueued now could put the level engine's persistent, co-residency-dependent launches
+            # on the chip together with RCCL's kernels.  train_step joins the exchange before the optimiser; anything else is a bug.
+            raise _lib.DmmeError("UNet.forward while a gradient exchange of this model is in flight: call reducer.finish() first")
         B, _, H, W = x.shape
         plan = self._plan_for(B, H, W, x.device)
         packed = self._packed_for(plan)

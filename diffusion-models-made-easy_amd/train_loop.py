@@ -30,11 +30,12 @@ def train_step(module, optimizer, scheduler, x0, clip=None, reduce=True, exchang
         D.sync_parameters(model, optimizer)
         model._dp_synced = True
     if multi and not os.environ.get("DMME_NO_OVERLAP"):
-        if reducer is not None and exchange is not None and reducer.exchange != exchange:
+        want = exchange or D.default_exchange(int(x0.shape[0]))  # (<= 32 images per rank: the direct bf16 exchange)
+        if reducer is not None and reducer.exchange != want:
             reducer.detach()
             reducer = None
         if reducer is None:
-            reducer = model._grad_reducer = D.make_reducer(model, exchange)
+            reducer = model._grad_reducer = D.make_reducer(model, want)
         reducer.attach()
     elif reducer is not None:
         # no exchange in this step: the hook must be gone BEFORE backward runs, or that backward would issue all-reduces (and divide

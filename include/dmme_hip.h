@@ -169,19 +169,21 @@ DMME_API int dmme_unet_pack_params_bwd(const dmme_plan* plan, const float* ref_f
 DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const void* packed_bwd, const float* x,
                        const int64_t* t, int t_len, const float* d_y, void* workspace, void* bwd_workspace,
                        const float* drop_masks, float* grad_flat, float* d_x, void* stream);
-/* Same backward in two gradient buckets, so a data-parallel caller can all-reduce the first while the second is still being
+/* Same backward in GRADIENT BUCKETS, so a data-parallel caller can exchange a bucket while the rest of backward is still being
  * computed (north star: "RCCL all-reduce of UNet grads over xGMI overlapped with backward"; the reference gets this from
- * Lightning's DDP wrapper around `loss.backward()`).  Bucket 0 = the parameters backward finishes first (up_layers,
- * middle_layers, output_conv: the contiguous tail of the flat buffer), bucket 1 = the rest (time MLP, input_conv,
- * down_layers).  `ready(user, bucket, offset, numel)` is called on the calling thread as soon as every launch that writes
- * grad_flat[offset, offset + numel) has been ENQUEUED on `stream` (record an event there; nothing has necessarily executed yet).
- * Same results as dmme_unet_backward.  dmme_unet_plan_grad_buckets returns the number of buckets (1 when the configuration has
- * no clean split, then `ready` is never called) and their ranges in hand-over order. */
+ * Lightning's DDP wrapper around `loss.backward()`, 25 MB buckets).  The op list is cut at ResBlock boundaries into stretches of
+ * at most ~1/6 of the parameters, in the order backward finishes them: output conv + the last up blocks first, ..., the first down
+ * blocks + input conv + time MLP last (<= 15 % of the bytes: the only exchange nothing can hide).  `ready(user, bucket, offset,
+ * numel)` is called on the calling thread - once per contiguous range of a bucket (a bucket may cover two: middle_layers and
+ * output_conv sit behind up_layers in the flat buffer) - as soon as every launch that writes grad_flat[offset, offset + numel) has
+ * been ENQUEUED on `stream` (record an event there; nothing has necessarily executed yet).  Same results as dmme_unet_backward.
+ * dmme_unet_plan_grad_buckets: the (offset, numel, bucket) triples in hand-over order, returns their count (may exceed `cap`);
+ * 1 = the configuration has no clean cut, `ready` is then never called. */
 typedef void (*dmme_bucket_fn)(void* user, int bucket, int64_t offset, int64_t numel);
 DMME_API int dmme_unet_backward_buckets(const dmme_plan* plan, const void* packed, const void* packed_bwd, const float* x,
                                const int64_t* t, int t_len, const float* d_y, void* workspace, void* bwd_workspace,
                                const float* drop_masks, float* grad_flat, float* d_x, void* stream, dmme_bucket_fn ready, void* user);
-DMME_API int dmme_unet_plan_grad_buckets(const dmme_plan* plan, int64_t offsets[2], int64_t numels[2]);
+DMME_API int dmme_unet_plan_grad_buckets(const dmme_plan* plan, int64_t* offsets, int64_t* numels, int* bucket_of, int cap);
 /* test / diagnostic: the kernels a backward of this plan launches, as space-separated key=value pairs
  * ("wgrad_group3x3_jobs=..", "colsum_group_jobs=..", "dgrad[conv3x3_ws2_kernel<11>]=..") */
 DMME_API int dmme_unet_plan_bwd_summary(const dmme_plan* plan, char* buf, int cap);

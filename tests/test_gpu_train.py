@@ -278,10 +278,15 @@ def test_checkpoint_layout_round_trip_and_torch_adam_interop(tmp_path):
 
 
 @pytest.mark.parametrize("which", ["tiny_fp32", "full_bf16", "iddpm_bf16"])
-def test_bucketed_backward_matches_and_reports_both_buckets(which):
-    """dmme_unet_backward_buckets (gradient all-reduce overlap): same gradients as the one-piece backward, the two hand-overs tile the
-    flat buffer (up / middle / output parameters first), the first one arrives before the backward call returns."""
+def test_bucketed_backward_matches_and_reports_its_buckets(which):
+    """dmme_unet_backward_buckets (gradient exchange overlapped with backward): same gradients as the one-piece backward; the
+    hand-overs tile the flat buffer exactly once, arrive in the order backward finishes them (output conv / last up blocks first, the
+    time MLP + input conv + first down blocks last) and - for the default UNet - there are at least four buckets, none above a
+    quarter of the bytes, the LAST (the only exchange no compute can hide) at most 15 %."""
+    import ctypes as C
+
     import dmme_amd
+    from dmme_amd import _lib
     from dmme_amd.distributed import OverlappedGradReducer
 
     if which == "tiny_fp32":
@@ -314,12 +319,31 @@ def test_bucketed_backward_matches_and_reports_both_buckets(which):
     assert red.finish() is False  # single process: nothing to reduce, the caller's path applies
     net._bucket_hook = None
     n = want.numel()
-    assert len(rep) == 2 and rep[0][0] > 0 and rep[0][0] + rep[0][1] == n and rep[1] == (0, rep[0][0])
-    first = [k for k, _ in net.state_dict().items() if k.startswith("up_layers.")][0]
-    off = dict((name, o) for name, shape, o, isb in net._table)[first]
-    assert rep[0][0] == off
+    # what the plan announces = what backward reported, in order
+    plan = net._last_plan
+    offs, nums, bks = (C.c_int64 * 64)(), (C.c_int64 * 64)(), (C.c_int * 64)()
+    cnt = plan.lib.dmme_unet_plan_grad_buckets(plan.h, offs, nums, bks, 64)
+    table = [(int(offs[i]), int(nums[i]), int(bks[i])) for i in range(cnt)]
+    assert [(o, m) for o, m, _ in table] == rep, (table, rep)
+    # exact tiling of [0, n)
+    cover = sorted(rep)
+    names = dict((name, (o, isb)) for name, shape, o, isb in net._table)
+    pos = 0
+    for o, m in cover:
+        assert o == pos, (o, pos, cover)
+        pos = o + m
+    assert pos == n
+    nb = max(b for _, _, b in table) + 1
+    per_bucket = [sum(m for _, m, b in table if b == k) for k in range(nb)]
+    print(f"{which}: {nb} gradient buckets, shares {[round(v / n, 3) for v in per_bucket]}")
+    # order: the bucket holding output_conv first, the one holding the time MLP last
+    out_off = names["output_conv.2.weight"][0]
+    cond_off = names["condition.1.weight"][0]
+    assert any(o <= out_off < o + m for o, m, b in table if b == 0) and any(o <= cond_off < o + m for o, m, b in table if b == nb - 1)
+    if which != "tiny_fp32":
+        assert nb >= 4 and max(per_bucket) <= 0.26 * n and per_bucket[-1] <= 0.15 * n, per_bucket
     scale = float(want.abs().max())
-    # fp32: only the order of the float atomics differs; bf16: the grouped weight-gradient launch is cut in two
+    # fp32: only the order of the float atomics differs; bf16: the grouped weight-gradient launch is cut into the buckets' launches
     assert float((got - want).abs().max()) <= (1e-5 if which == "tiny_fp32" else 2e-3) * scale
 
 

@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(64 * NW) attn_mfma_kernel(const T* __restrict_
 // ahead, ONE workgroup barrier per tile; rows are unpadded and XOR-swizzled on the DMA's source side (K: 16-byte piece ^ (row & 7),
 // conflict-free ds_read_b128; V: piece ^ 2 (row & 3), the four key rows of a transposed read land in four different 32-byte slots);
 // every fragment address is one per-lane base + an instruction offset (the sixteen tile steps are unrolled).
-// PACING (`xcd_order` bits 1..: s_sleep 2 / 4 / 8 / 16 after every tile step, default 4; DMME_ATTN_SLEEP=0 turns it off): un-paced this
+// PACING (`xcd_order` bits 1..: s_sleep 2 / 4 / 8 / 16 after every tile step, default 4; DMME_DEBUG_ROUTE=attn_sleep=0 turns it off): un-paced this
 // kernel is 22 us against the online kernel's 30 - and on most boxes of the pool the WHOLE denoising step got 4 % slower with it
 // (every other kernel of the step 4-5 % slower, in one process, alternating the two kernels per 100 forwards: tools/attn_flip.py),
 // on a few boxes 1 % faster.  MFMA, LDS and the DMA path saturated on all 256 CUs at once trips the board's power / current
@@ -647,7 +647,7 @@ static int launch_attn_full_t(const T* qkv, const AttnGeom& g, T* out, float* ls
         DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_full_kernel<D, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_done = true;
     }
-    const int xcd_order = ((!getenv("DMME_NO_XCD_ORDER") && rows % 8 == 0) ? 1 : 0) | ((getenv("DMME_ATTN_SLEEP") ? atoi(getenv("DMME_ATTN_SLEEP")) : rows * 2 >= 256 ? 2 : 0) << 1);  // pacing level (kernel comment): s_sleep 4 per tile where the launch fills the chip
+    const int xcd_order = ((!debug_route("no_xcd_order") && rows % 8 == 0) ? 1 : 0) | ((debug_route("attn_sleep", -1) >= 0 ? debug_route("attn_sleep", -1) : rows * 2 >= 256 ? 2 : 0) << 1);  // pacing level (kernel comment): s_sleep 4 per tile where the launch fills the chip
     hipLaunchKernelGGL((attn_full_kernel<D, T>), dim3((unsigned)(rows * 2)), dim3(256), lds, s, qkv, g, out, lse, xcd_order);
     DMME_CHECK_LAUNCH();
     return DMME_OK;
@@ -676,7 +676,7 @@ static int launch_attn_fwd_nw(const T* qkv, const AttnGeom& g, T* out, float* ls
         DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_kernel<D, NW, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_done = true;
     }
-    const bool xcd_off = getenv("DMME_NO_XCD_ORDER") != nullptr;
+    const bool xcd_off = (debug_route("no_xcd_order") != 0);
     const int xcd_order = (!xcd_off && qblocks > 1 && rows % 8 == 0) ? 1 : 0;
     hipLaunchKernelGGL((attn_mfma_kernel<D, NW, T>), dim3((unsigned)(rows * qblocks)), dim3(64 * NW), lds, s, qkv, g, out, lse, xcd_order);
     DMME_CHECK_LAUNCH();
@@ -690,7 +690,7 @@ static int launch_attn_fwd_t(const T* qkv, const AttnGeom& g, T* out, float* lse
 int launch_attn_heads_mfma(int dtype, const void* qkv, int N, int S, int C, int heads, void* out, float* lse, hipStream_t s) {
     DMME_REQUIRE(attn_heads_mfma_supported(dtype, N, S, C, heads), DMME_ERR_UNSUPPORTED, "attn_mfma: unsupported shape S=%d C=%d heads=%d", S, C, heads);
     const AttnGeom g = attn_geom(N, S, C, heads);
-    if (attn_full_takes(S, C / heads) && N * heads * 2 < 256 && !getenv("DMME_NO_ATTN_SPLIT")) {  // the launch would leave CUs idle: keys split over the waves
+    if (attn_full_takes(S, C / heads) && N * heads * 2 < 256 && !debug_route("no_attn_split")) {  // the launch would leave CUs idle: keys split over the waves
         if (dtype == DMME_F16)
             return C / heads == 256 ? launch_attn_split_t<256, f16>((const f16*)qkv, g, (f16*)out, lse, s) : launch_attn_split_t<128, f16>((const f16*)qkv, g, (f16*)out, lse, s);
         return C / heads == 256 ? launch_attn_split_t<256, bf16>((const bf16*)qkv, g, (bf16*)out, lse, s) : launch_attn_split_t<128, bf16>((const bf16*)qkv, g, (bf16*)out, lse, s);

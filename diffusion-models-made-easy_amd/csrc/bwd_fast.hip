@@ -1079,7 +1079,7 @@ static int gn_bwd_regs_slices(int dtype, int N, int HW, int C1, int C2, int grou
 
 static bool gn_bwd_small_supported(int dtype, int HW, int C1, int C2, int groups) {
     const int EPV = is16(dtype) ? 8 : 4, C = C1 + C2;
-    return HW <= 64 && C <= 512 && groups <= 64 && C % groups == 0 && C1 % EPV == 0 && C2 % EPV == 0 && C / EPV <= 256 && !getenv("DMME_NO_GN_SMALL");
+    return HW <= 64 && C <= 512 && groups <= 64 && C % groups == 0 && C1 % EPV == 0 && C2 % EPV == 0 && C / EPV <= 256 && !debug_route("no_gn_small");
 }
 
 // pixel chunks of the two-pass GroupNorm backward = partial rows of its channel-sum scratch ([chunks][N][C][2] floats); 1 when the
@@ -1098,11 +1098,11 @@ bool gn_bwd_fast_supported(int dtype, int HW, int C1, int C2) {
 
 // will launch_gn_bwd_fast leave the batch sums of dgamma / dbeta as per-image rows (instead of same-address atomics)?  Mirrors its dispatch.
 bool gn_bwd_rows_supported(int dtype, int HW, int C1, int C2, int groups, bool has_mod) {
-    if (getenv("DMME_NO_GN_BWD_ROWS")) return false;
+    if (debug_route("no_gn_bwd_rows")) return false;
     if (!has_mod && gn_bwd_small_supported(dtype, HW, C1, C2, groups)) return true;
     if (!has_mod && gn_bwd_regs_slices(dtype, 1, HW, C1, C2, groups)) return true;
     const int C = C1 + C2;
-    return !getenv("DMME_NO_GN_BWD_IMAGE") && !getenv("DMME_NO_GN_BWD_FUSED_FIN") && C <= 1024 && groups <= 256;
+    return !debug_route("no_gn_bwd_image") && !debug_route("no_gn_bwd_fused_fin") && C <= 1024 && groups <= 256;
 }
 
 // AB: gn_bwd_fast_chunks * N*C*2 floats (every entry is written: no zeroing needed);  S: N*groups*2 floats of scratch
@@ -1160,7 +1160,7 @@ int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2
         // channel slices: whole groups, whole 16-byte vectors, not straddling the two concatenated sources, <= 256 threads per pixel row
         const int Call = C1 + C2, cgs = Call / groups, epv = is16(dtype) ? 8 : 4;
         int slices = 1;
-        const bool slice_off = getenv("DMME_NO_GN_BWD_SLICES") != nullptr;
+        const bool slice_off = (debug_route("no_gn_bwd_slices") != 0);
         for (int cand = 4; cand >= 2 && !slice_off; cand >>= 1) {
             const int w = Call / cand;
             if (Call % cand == 0 && w % cgs == 0 && w % epv == 0 && C1 % w == 0 && (int64_t)N * cand <= 1024) {
@@ -1194,8 +1194,8 @@ int launch_gn_bwd_fast(int dtype, const void* dv, const void* x1, const void* x2
         hipLaunchKernelGGL(gn_bwd_sums_kernel<float>, grid, dim3(256), 0, s, (const float*)dv, (const float*)x1, (const float*)x2, HW, C1, C2,
                            groups, mean_rstd, scale, shift, dmask, pro_silu, chunk_px, ppw, AB);
     DMME_CHECK_LAUNCH();
-    const bool per_image_off = getenv("DMME_NO_GN_BWD_IMAGE") != nullptr;
-    const bool fused_off = getenv("DMME_NO_GN_BWD_FUSED_FIN") != nullptr;
+    const bool per_image_off = (debug_route("no_gn_bwd_image") != 0);
+    const bool fused_off = (debug_route("no_gn_bwd_fused_fin") != 0);
     const bool fused_fin = !per_image_off && !fused_off && C <= 1024 && groups <= 256;  // the apply kernel merges the chunk sums itself
     if (fused_fin) {
     } else if (!per_image_off && C <= 1024 && groups <= 256) {

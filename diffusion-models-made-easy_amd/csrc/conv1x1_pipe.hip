@@ -200,7 +200,7 @@ bool conv1x1_pipe_supported(int dtype, const ConvArgs& a) {
 
 // can the tiled kernel finish the norm in front of this conv itself (its tile inside one image, LDS budget)?
 bool conv1x1_pipe_gn_in_ok(int dtype, const ConvArgs& a) {
-    if (!is16(dtype) || getenv("DMME_NO_GN_IN_PIPE") || getenv("DMME_NO_GN_IN_PIPE1") || !conv1x1_pipe_supported(dtype, a)) return false;
+    if (!is16(dtype) || debug_route("no_gn_in_pipe") || debug_route("no_gn_in_pipe1") || !conv1x1_pipe_supported(dtype, a)) return false;
     const int pick = pick1(a);
     if (pick < 0) return false;
     const int BM = k1Cand[pick][0], BN = k1Cand[pick][1], HW = a.Hout * a.Wout;
@@ -234,7 +234,7 @@ static int launch1_t(const ConvArgs& a, hipStream_t s) {
     const int tiles_n = (a.Cout + BN - 1) / BN;
     const int64_t tiles_m = (M + BM - 1) / BM;
     const dim3 grid((unsigned)(tiles_m * tiles_n));
-    const bool xcd_off = getenv("DMME_NO_XCD_ORDER") != nullptr;
+    const bool xcd_off = (debug_route("no_xcd_order") != 0);
     const int xcd_order = (!xcd_off && tiles_n > 1 && tiles_m % 8 == 0) ? 1 : 0;
     size_t lds = (size_t)2 * (BM + BN) * ROW_DATA;
     if (lds < (size_t)BM * BN * 4) lds = (size_t)BM * BN * 4;

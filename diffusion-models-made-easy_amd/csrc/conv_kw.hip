@@ -469,7 +469,7 @@ static size_t kw_lds(const ConvArgs& a, const ConvTile& g, int BM, int NI, int r
 bool conv_kw_pick(int dtype, const ConvArgs& a, ConvTile& g, int* ni_out, int* ring_out, int* bm_out) {
     const bool off = getenv("DMME_NO_KW") != nullptr;
     constexpr int force_ni = 0, max_ring = 6;
-    const int force_bm = getenv("DMME_KW_BM64") ? 64 : 0;  // (the 8x8 level on 64-pixel tiles instead of two whole images per workgroup)
+    const int force_bm = debug_route("kw_bm64") ? 64 : 0;  // (the 8x8 level on 64-pixel tiles instead of two whole images per workgroup)
     if (off || !is16(dtype) || a.x3) return false;
     const int Cin = a.C1 + a.C2;
     if (a.taps != 9 || a.stride != 1 || a.up == 2 || a.in_nchw || Cin % 64 || a.C1 % 64 || a.Cout < 32) return false;
@@ -481,7 +481,7 @@ bool conv_kw_pick(int dtype, const ConvArgs& a, ConvTile& g, int* ni_out, int* r
     // there: VALU-bound on one wave per SIMD, stamps in tools/stamp_pipe.py).  DMME_KW_NO_BM32 keeps 64-pixel tiles.
     static const int kCand[5][2] = {{128, 2}, {128, 1}, {64, 2}, {64, 1}, {32, 1}};
     static const int kRings[4] = {6, 4, 3, 2};
-    const bool bm32 = !getenv("DMME_KW_NO_BM32") && a.Cout % 32 == 0 && !a.n_gno;
+    const bool bm32 = !debug_route("kw_no_bm32") && a.Cout % 32 == 0 && !a.n_gno;
     for (int c = 0; c < 5; ++c) {
         const int BM = kCand[c][0], NI = kCand[c][1];
         if ((force_ni && NI != force_ni) || (force_bm && BM != force_bm)) continue;

@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(256) conv_splitk_finish_kernel(ConvArgs a, int
 }
 static int pipe_ksplit(const ConvArgs& a, const ConvTile& g, int pick, int KC) {
     if (a.has_gni) return 1;  // (the rows are per workgroup: every K slice would derive them again)
-    const bool off = getenv("DMME_NO_SPLITK") != nullptr;
+    const bool off = (debug_route("no_splitk") != 0);
     if (off || !a.splitk || pick != 3 || a.stride != 1 || a.gn_part || a.n_gno || a.out_silu || a.out_nchw || a.res2 || a.Cout % 4) return 1;
     const int64_t wgs = (int64_t)g.tiles_m * g.tiles_n;
     if (wgs > 128) return 1;  // a full wave of workgroups already
@@ -912,7 +912,7 @@ static int ws_pick(const ConvArgs& a, ConvTile& g) {
     }
     // 128-pixel tiles where those fill the chip and the 256-pixel ones do not (return value 4)
     ConvTile u;
-    if (!getenv("DMME_NO_WS128") && make_tile(a, 128, 128, u) && u.TN == 1 && u.a_rows <= 224 && ws2_lds(a, u) <= 160 * 1024 && u.tiles_m * u.tiles_n >= ws_min_tiles) {
+    if (!debug_route("no_ws128") && make_tile(a, 128, 128, u) && u.TN == 1 && u.a_rows <= 224 && ws2_lds(a, u) <= 160 * 1024 && u.tiles_m * u.tiles_n >= ws_min_tiles) {
         g = u;
         return 4;
     }
@@ -939,7 +939,7 @@ static const int kPipeUA[5] = {8, 8, 8, 11, 10};  // [4]: stride 2 (a 64-pixel t
 static size_t pipe_lds(const ConvTile& g, int BN, int GT) { return (size_t)g.a_rows * ROW_DATA + (size_t)GT * BN * ROW_DATA; }  // >= BM*BN*4 always
 // the DMA filter path (bf16, GT = 3, 64-cout tiles) needs a second filter buffer inside the 2-workgroups-per-CU budget
 static bool pipe_dma_ok(int dtype, const ConvTile& g, int BN, int GT) {
-    const bool off = getenv("DMME_NO_PIPE_DMA") != nullptr;
+    const bool off = (debug_route("no_pipe_dma") != 0);
     return !off && is16(dtype) && GT == 3 && BN == 64 && pipe_lds(g, BN, GT) + (size_t)GT * BN * ROW_DATA <= 80 * 1024;
 }
 
@@ -1145,10 +1145,10 @@ bool conv_gn_in_query(int dtype, const ConvArgs& a) {
     const int pick = pipe_pick(a, g);
     int kni = 0, kring = 0, kbm = 0;
     if (pick < 0) return false;
-    if (!getenv("DMME_NO_GN_IN_KW") && kw_takes(dtype, a, pick, gk, &kni, &kring, &kbm)) return gk.TN == 1 && kw_ksplit(a, gk) == 1;
+    if (!debug_route("no_gn_in_kw") && kw_takes(dtype, a, pick, gk, &kni, &kring, &kbm)) return gk.TN == 1 && kw_ksplit(a, gk) == 1;
     if (kw_takes(dtype, a, pick, gk, &kni, &kring, &kbm)) return false;
     // the four-wave kernel: rows in LDS behind its operand buffers (two workgroups per CU: the 80 KB budget must still hold)
-    if (getenv("DMME_NO_GN_IN_PIPE") || g.TN != 1) return false;
+    if (debug_route("no_gn_in_pipe") || g.TN != 1) return false;
     ConvArgs b = a;
     b.has_gni = 1;
     b.splitk = nullptr;
@@ -1198,7 +1198,7 @@ bool conv_gn_direct_query(int dtype, const ConvArgs& a, const int* cg, int n) {
 // the wave-specialised kernel: its 256-pixel tile is a whole 16x16 image, stored in two passes whose statistics it merges itself
 // (scale / shift / {mean, rstd} only - the first pass is in memory before the statistics exist, so no pre-activated output)
 bool conv_gn_direct_ws_query(int dtype, const ConvArgs& a, const int* cg, int n) {
-    const bool off = getenv("DMME_NO_GN_DIRECT") != nullptr || getenv("DMME_NO_GN_DIRECT_WS") != nullptr;
+    const bool off = getenv("DMME_NO_GN_DIRECT") != nullptr || (debug_route("no_gn_direct_ws") != 0);
     if (off || a.mix || !is16(dtype) || getenv("DMME_NO_WS") || n < 1 || n > 2 || !conv_pipe_supported(dtype, a)) return false;
     ConvTile gw{};
     if (!ws_pick(a, gw) || gw.TH != a.Hout || gw.TW != a.Wout || gw.TH * gw.TW != 256) return false;

@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(256) gn_small_kernel(const T* __restrict__ s1,
 
 static bool gn_small_supported(int dtype, int HW, int C1, int C2, int groups) {
     const int EPV = is16(dtype) ? 8 : 4, C = C1 + C2;
-    return HW <= 64 && C <= 512 && groups <= 64 && C % groups == 0 && C1 % EPV == 0 && C2 % EPV == 0 && C / EPV <= 256 && !getenv("DMME_NO_GN_SMALL");
+    return HW <= 64 && C <= 512 && groups <= 64 && C % groups == 0 && C1 % EPV == 0 && C2 % EPV == 0 && C / EPV <= 256 && !debug_route("no_gn_small");
 }
 
 static bool gn_geometry(int dtype, int HW, int C1, int C2, int groups, int& chunk_px, int& nsweeps, int& nchunks) {

@@ -376,7 +376,7 @@ bool wgrad_small_supported(int dtype, const ConvArgs& a) {
     return a.Cout <= 4 && a.C1 % EPV == 0 && 9 * (a.C1 / EPV) <= 256;
 }
 int launch_wgrad_small(int dtype, const ConvArgs& a, const void* dY, float* dW, hipStream_t s) {
-    if (wgrad_thin_supported(a) && !getenv("DMME_NO_WGRAD_THIN")) {
+    if (wgrad_thin_supported(a) && !debug_route("no_wgrad_thin")) {
         const int64_t total = (int64_t)a.N * a.Hout * a.Wout;
         const int tiles = (int)((total + 255) / 256), grid = tiles < 256 ? tiles : 256;  // few workgroups: they all end in atomics on the same addresses
 #define DMME_WTHIN(TT, FF) hipLaunchKernelGGL((wgrad_thin_kernel<TT, FF>), dim3(grid), dim3(256), 0, s, a, (const TT*)dY, dW, tiles, g0)

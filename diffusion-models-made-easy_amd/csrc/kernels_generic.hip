@@ -239,7 +239,7 @@ static bool conv_in_mfma_supported(const ConvArgs& a) {
     return a.in_nchw && !a.out_nchw && a.taps == 9 && a.stride == 1 && !a.up && a.C2 == 0 && a.C1 <= 3 && !a.scale && !a.pro_silu && !a.dmask &&
            !a.tproj && !a.res1 && !a.out_silu && (a.Cout == 128 || a.Cout == 64 || a.Cout == 32) &&
            (!a.gn_part || (a.gn_cg == 4 && (a.Hout * a.Wout) % 32 == 0)) &&
-           ((int64_t)a.N * a.Hout * a.Wout) % 32 == 0 && (int64_t)a.N * a.Hout * a.Wout * a.Cout < (1ll << 31) && !getenv("DMME_NO_CONV_IN_MFMA");
+           ((int64_t)a.N * a.Hout * a.Wout) % 32 == 0 && (int64_t)a.N * a.Hout * a.Wout * a.Cout < (1ll << 31) && !debug_route("no_conv_in_mfma");
 }
 
 // the first-conv kernel can emit GroupNorm partials of its output: one per 32-pixel block, groups of exactly 4 channels
@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(256) attn_s16_kernel(const T* __restrict__ qkv
 
 int launch_attn_heads(int dtype, const void* qkv, int N, int S, int C, int heads, void* out, hipStream_t s) {
     DMME_REQUIRE(heads >= 1 && C % heads == 0, DMME_ERR_INVALID, "attention: width %d not divisible by %d heads", C, heads);
-    if (S == 16 && (C / heads) % 4 == 0 && C / heads <= 1024 && !getenv("DMME_NO_ATTN_S16")) {
+    if (S == 16 && (C / heads) % 4 == 0 && C / heads <= 1024 && !debug_route("no_attn_s16")) {
         const size_t lds16 = (size_t)(3 * 16 * (C / heads + 4) + 16 * 17) * sizeof(float);
         if (lds16 <= 64 * 1024) {
             if (dtype == DMME_BF16)

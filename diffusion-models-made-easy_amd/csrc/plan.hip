@@ -1,17 +1,6 @@
 // Host side of libdmme_hip: the UNet execution plan (layer graph, parameter table,
 // packed-weight layout, workspace layout, launch sequence) and the extern "C" API.
-#include <stdarg.h>
-#include <stdlib.h>
-#include <stdio.h>
-#include <string.h>
-
-#include <algorithm>
-#include <string>
-#include <unordered_map>
-#include <vector>
-
-#include "common.h"
-#include "lvl.h"
+#include "plan.h"
 
 namespace dmme {
 
@@ -37,175 +26,11 @@ int debug_route(const char* key, int dflt) {
     return dflt;
 }
 
-static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
-
-struct Param {
-    std::string name;
-    int ndim = 0;
-    int64_t shape[4] = {1, 1, 1, 1};
-    int64_t ref_off = 0;     // elements, fp32 reference-layout flat buffer
-    int64_t packed_off = 0;  // bytes
-    int64_t packed_bwd_off = -1;  // bytes in the data-gradient weight buffer (conv weights only)
-    int64_t wp_off = -1;          // float offset of this conv weight in the packed-layout gradient image
-    bool is_buffer = false;
-    bool as_f32 = true;      // stays fp32 in the packed buffer (bias / gamma / beta / freqs)
-    int pack_code = -1;      // mixed plans: PackItem::as_f32 code of this conv weight (3: fp32 [co][tap][ci]; 4: split fp16 halves), -1: by as_f32
-    int cout = 1, cin = 1, taps = 1;
-    int64_t numel() const { return shape[0] * shape[1] * shape[2] * shape[3]; }
-};
-
-struct Tensor {  // an activation in the workspace, NHWC in the compute dtype
-    int64_t off = 0;
-    int C = 0, H = 0, W = 0;
-    int f32 = 0;  // precision="fp16r32": this tensor of a 16-bit plan is stored in fp32 (the full-resolution level)
-    // GroupNorm partials emitted by the producing conv's epilogue (-1: none): [B][tiles][G][2] floats
-    int64_t stats_off = -1;
-    int stats_tiles = 0, stats_cnt = 0;
-};
-
-enum OpKind { OP_SINUS, OP_LINEAR, OP_GN, OP_CONV, OP_ATTN, OP_CAST };
-
-struct Op {
-    OpKind kind;
-    // OP_LINEAR: in (fp32 ws offset) -> out (fp32 ws offset)
-    int64_t lin_in = 0, lin_out = 0;
-    int lin_K = 0, lin_N = 0, lin_w = -1, lin_b = -1, lin_silu = 0;
-    int64_t lin_pre = -1;  // workspace offset of the layer's pre-activation copy (time MLP, training batch), -1: none
-    // OP_GN
-    int gn_src1 = -1, gn_src2 = -1, gn_gamma = -1, gn_beta = -1;
-    int64_t b_rowsum = 0, b_ab = 0;  // backward scratch (bytes in the zeroed region): column sums of dY, GroupNorm channel sums
-    int64_t b_gnrows = -1;           // [2][N][C] per-image sums for dbeta / dgamma of this conv's GroupNorm (written whole)
-    int gn_rows_deferred = 0;        // ... reduced over the batch by the grouped bias launch instead of same-address atomics
-    int64_t gn_scale = 0, gn_shift = 0, gn_mr = 0;  // workspace offsets: scale/shift [N][C], {mean, rstd} [N][G][2]
-    // scale-shift conditioning (iddpm.ResBlock, models/iddpm.py:117-118): columns of tproj holding (shift | scale), -1: none.
-    // The GroupNorm output becomes GN(h) * (scale + 1) + shift, folded into the per-(n, c) scale / shift the consumer applies.
-    int gn_mod_col = -1, gn_mod_C = 0;
-    // small maps: this GroupNorm also writes its consumer's pre-activated input (gn_small_kernel); -1: the conv applies the affine itself
-    int64_t gn_act = -1;   // workspace offset of act [N][HW][C] in the compute dtype
-    int gn_force_small = 0;  // statistics from the one-workgroup-per-image kernel even where the producers left partials (it writes act)
-    int gn_consumer = -1;  // the conv op that reads it (its pro_silu / Dropout2d mask define the activation)
-    int gn_direct = 0;     // every source's producing conv finishes this norm in its epilogue (ConvArgs::gno): no launch here
-    int gn_in_consumer = 0;  // the consuming conv merges the producers' partials itself (ConvArgs::gni): no launch here
-    // OP_CONV
-    int src1 = -1, src2 = -1;  // tensor ids; -2: network input (NCHW fp32)
-    int w = -1, b = -1;
-    int gn = -1;               // op index of the GN providing scale/shift
-    int pro_silu = 0, out_silu = 0;
-    int64_t dmask_off = -1;    // float offset into the drop-mask buffer
-    int tproj_col = -1;        // column offset into tproj
-    int res1 = -1, res2 = -1;
-    int dst = -1;              // tensor id; -2: network output (NCHW fp32)
-    int up = 0, stride = 1, taps = 9;
-    int use_act = 0;           // FORWARD reads the pre-activated tensor of its GroupNorm (backward still works from src1 / src2 + scale / shift)
-    int gd_n = 0, gd_gn[2] = {-1, -1}, gd_coff[2] = {0, 0};  // norms this conv's forward epilogue finishes (op index, channel offset in the norm)
-    int gd_act = -1;           // which of them also gets the consumer's pre-activated input written (-1: none)
-    int res_alias = 0;         // backward: the residual input's gradient buffer is this conv's output gradient buffer (no copy)
-    int wg_layer = -1;         // index into the grouped weight-gradient table of its kernel size (-1: per-layer kernels)
-    int64_t wg_act = -1;       // backward workspace offset of its pre-activated input, written by its GroupNorm's backward for the
-                               // deferred weight gradient (-1: none)
-    int bias_deferred = 0;     // its bias / time-projection reduction runs in the grouped launch
-    // OP_ATTN
-    int at_qkv = -1, at_out = -1, at_heads = 1;
-    int64_t at_lse = 0;  // workspace offset of the forward's log-sum-exp [N][S]
-    // precision="fp16r32" (dmme_plan::mix): how this conv of the fp32 level runs.  mix: ConvArgs::mix (1 / 2: split-pass 3x3 kernel, 3: split-pass
-    // thin output conv); route_f32: on the fp32-tensor kernels with three-pass bf16 products (input conv, the blocks' 1x1 residual convs)
-    int mix = 0, route_f32 = 0;
-    // OP_CAST: fp32 tensor -> 16-bit copy (the stride-2 conv that leaves the fp32 level reads it)
-    int cast_src = -1, cast_dst = -1;
-    // level engine (lvl_engine.hip): index of the run that executes this op (-1: its own launch); the run's first op launches it
-    int lvl = -1, lvl_first = 0;
-};
-
-// one persistent launch for a stretch of the op list on a 4x4 / 8x8 map (lvl.h)
-struct LvlRun {
-    int op_first = 0, op_last = 0;  // plan ops [op_first, op_last]
-    int sh = 0, NG = 0, NGS = 0, GB = 1, NJ = 1;
-    std::vector<LvlOp> ops;
-    std::vector<std::pair<int, int>> made;  // (tensor id, index of the op that produces / normalises it): later runs attach norms there
-    LvlOp* ops_dev = nullptr;
-    unsigned* sync_dev = nullptr;   // [16] control words (epoch, done, error), then the flag rows [n_ops * 2][NG][LVL_NS]
-    double flops = 0, bytes = 0;
-};
-
 }  // namespace dmme
 
 using namespace dmme;
 
-struct dmme_plan {
-    dmme_unet_cfg cfg;
-    int B, H, W, dtype, device;
-    int x3 = 0;            // DMME_BF16X3: dtype is DMME_F32 (storage), the convolutions take the three-pass bf16 MFMA path
-    int mix = 0;           // DMME_F16R32: dtype is DMME_F16; the tensors of the full-resolution level are fp32 and its convolutions run
-                           // three fp16 MFMA passes on hi / lo halves (or, for the few small ones, the fp32-tensor kernels above)
-    int out_channels = 0;  // in_channels (DDPM) or 2 * in_channels (IDDPM: eps, v)
-    std::vector<Param> params;
-    std::vector<Tensor> tensors;
-    std::vector<Op> ops;
-    std::unordered_map<std::string, int> named;  // module name -> tensor id
-    int64_t ref_numel = 0, packed_bytes = 0, ws_bytes = 0, dropmask_numel = 0;
-    int64_t ws_tsin = 0, ws_th1 = 0, ws_temb = 0, ws_tproj = 0, ws_gnpart = 0;
-    int64_t ws_tz1 = -1, ws_tz2 = -1;  // pre-activations of the two time-MLP layers (written at training batch; the backward's SiLU')
-    int64_t ws_splitk = 0, splitk_floats = 0;  // split-K partial sums of the small-map convolutions (forward and data gradient)
-    int tproj_cols = 0;
-    int64_t tproj_w_off = 0, tproj_b_off = 0;  // packed byte offsets of the concatenated projection
-    int freqs_param = -1;
-    PackItem* items_dev = nullptr;
-    int n_items = 0;
-    int n_launches = 0;
-    // ---- training (backward) ----
-    struct TBlock { int tw, tb, col, cout; };
-    std::vector<TBlock> tblocks;           // per-ResBlock time projection parameters
-    int p_l1w = -1, p_l1b = -1, p_l2w = -1, p_l2b = -1;
-    int64_t packed_bwd_bytes = 0, bws_bytes = 0;
-    std::vector<int64_t> gt_off;           // gradient buffer of every forward tensor
-    int64_t bws_zero = 0, bws_zero_bytes = 0, bws_wimage = 0, bws_gnS = 0, bws_zpage = 0;  // region cleared once per backward
-    PackItem* items_unpack_dev = nullptr;
-    int n_items_unpack = 0;
-    int64_t bws_tmp = 0, bws_dy = 0, bws_rowsum = 0, bws_dtproj = 0, bws_dtemb = 0, bws_dh1 = 0, bws_z = 0, bws_wT = 0, bws_attP = 0,
-            bws_attdS = 0;
-    PackItem* items_bwd_dev = nullptr;
-    int n_items_bwd = 0;
-    // grouped weight gradients (one launch per backward)
-    struct WgGroup {
-        int taps = 0;
-        std::vector<WgLayer> layers;
-        std::vector<WgJob> jobs;
-        WgLayer* layers_dev = nullptr;
-        WgJob* jobs_dev = nullptr;
-        int dma = 0;  // every layer's second operand is one prologue-free tensor: the LDS-DMA kernel runs the table
-        int stride = 1;
-    } wg[3];  // 3x3, 1x1, 3x3 stride 2 (LDS-DMA kernel only)
-    // Bucketed backward (gradient exchange overlapped with backward): the op list is cut at ResBlock boundaries into stretches that
-    // backward finishes one after the other (bucket 0 = output conv + the last up blocks, ... the last bucket = the first down
-    // blocks, input conv and time MLP); every deferred table is split along the same cuts at plan time, so a bucket's parameter
-    // gradients are complete - and handed to the exchange - as soon as the reverse walk leaves its stretch.  Cut so that no bucket
-    // holds more than ~1/6 of the parameters: the LAST one, whose exchange nothing hides, is <= 15 % of the bytes.
-    struct GradBucket {
-        int op_lo = 0, op_hi = 0;                          // plan ops [op_lo, op_hi)
-        WgGroup wg[3];
-        int col0 = 0, col1 = 0, bias0 = 0, bias1 = 0;      // ranges of col_jobs / bias_jobs
-        std::vector<std::pair<int, int>> unpack, tcols;    // ranges of items_unpack / of time-projection columns
-        std::vector<std::pair<int64_t, int64_t>> ranges;   // (flat offset, numel) of its parameters, merged
-    };
-    std::vector<GradBucket> gb;                            // empty: no clean cut for this configuration (one piece)
-    // batched time-projection gradients: destination (float offset into grad_flat) of every 64-row tile of
-    // dtproj^T temb, then of every 32-column tile of the bias sums
-    int64_t* tp_tiles_dev = nullptr;
-    int tp_n64 = 0;
-    // deferred bias / time-projection reductions (one launch per backward)
-    std::vector<BiasJob> bias_jobs;
-    BiasJob* bias_jobs_dev = nullptr;
-    std::vector<ColJob> col_jobs;     // column sums of dY of every bias-deferred conv: one grouped launch per flush
-    ColJob* col_jobs_dev = nullptr;
-    std::vector<LvlRun> lvl_runs;     // level-engine launches (small maps)
-    // every workgroup of an engine launch must be resident at once: grids are sized by what the device holds (assign_levels)
-    int lvl_max_wg = LVL_MAX_WG;
-    // host-visible status word of the engine's bounded hand-off waits (pinned, device-mapped; null: no engine run in this plan):
-    // non-zero = 1 + index of a run in which a wait timed out, i.e. the outputs since are invalid (lvl_check)
-    unsigned* err_host = nullptr;
-};
-
-namespace {
+namespace dmme {
 
 struct Node {
     int kind;  // 0 res, 1 down, 2 up
@@ -665,7 +490,7 @@ int build_plan(dmme_plan* P) {
         }
         // A ResBlock's 1x1 residual conv feeds nothing but the residual input of conv2: the gradient of its output IS the gradient of
         // the block's output - the two tensors share one gradient buffer instead of a copy launch per block
-        if (!getenv("DMME_NO_RES_ALIAS")) {
+        if (!debug_route("no_res_alias")) {
             std::vector<int> uses(P->tensors.size(), 0), producer(P->tensors.size(), -1);
             for (int oi = 0; oi < (int)ops.size(); ++oi) {
                 const Op& o = ops[oi];
@@ -811,9 +636,39 @@ int build_unpack_items(dmme_plan* P, std::vector<PackItem>& items) {
     return DMME_OK;
 }
 
-// the dtype code a conv's kernels are selected by: the plan's, except the fp32-routed convs of a mixed plan
-static inline int conv_dt(const dmme_plan* P, const Op& o) { return o.route_f32 ? DMME_F32 : P->dtype; }
-
+// ---- which kernel runs a convolution -----------------------------------------------------------------------------------------------
+// ONE table for the whole dispatch (the *_supported / *_pick functions below and in the kernel files implement exactly this; times are
+// per launch at the benchmark configuration - default UNet, batch 128, bf16 - from profiles/r04_sample_b128_bf16_kernel_stats.csv and
+// bench.py's event-bracketed forward; "B <= 32" rows from profiles/r04_bench_n1.json: small_batch):
+//
+//   shape class (16-bit plans)                               kernel                                   launches/step   us/launch
+//   3x3 s1, 32x32 and 16x16 maps, Cin % 128 == 0, >= 256     conv3x3_ws2_kernel<11, T, 256>               18            66-72
+//     256-pixel tiles of one image (the dominant kernel)       wave-specialised, persistent
+//   ... the same where only 128-pixel tiles fill the chip    conv3x3_ws2_kernel<7, T, 128>                 4            41
+//     (128-cout layers of the 16x16 level; 32x32 at B = 32)
+//   3x3 s1 on 8x8 / 4x4 maps, DDPM blocks, <= 2 iterations   lvl_engine_kernel (plan_lvl.hip: a whole     3        131 / 181
+//     per workgroup                                            level per launch; includes its 1x1 convs,
+//                                                              norms and the 4x4 attention)
+//   3x3 s1, few output pixels (small batches; IDDPM small    conv3x3_kw_kernel<NI, RING, DENSE, BM>       -           13-18
+//     maps; 8x8 / 4x4 with DMME_NO_LVL)                        K split over the four waves
+//   3x3 s2 (DownSample), 3x3 with fused 2x upsampling,       conv3x3_pipe_kernel<T, 64, 64, 3 | 9, UA>     4           36-45
+//     everything the rows above decline                        four-wave software pipeline
+//   1x1, K = 128 / 256, >= 128 tiles of 128 pixels           conv1x1_as_kernel<KCH, RES>                  15           14-25
+//     (qkv, proj, residual convs of the 32x32 / 16x16 levels)   activations stationary in registers
+//   1x1 otherwise (K = 384 / 512, small maps, small batches) conv1x1_pipe_kernel<T, BM, BN>                2           20-30
+//   output conv (<= 7 couts, NCHW fp32 out)                  conv_out_thin_kernel<NT, T>                   1            15
+//   input conv (NCHW fp32 in, <= 4 channels)                 conv_in_mfma_kernel<T, CT> (generic file)     1            31
+//   fp32 plans / precision="bf16x3" (fp32 tensors)           conv3x3_pipe / conv1x1_pipe <float[, ACC3]>;  -             -
+//                                                              the 3-cout output conv: conv_mfma_kernel
+//   precision="fp16r32", full-resolution level (ConvArgs::mix)  conv3x3_ws2_kernel<11, f16, 256, SPLIT>   11          120-240
+//                                                              conv_out_thin_kernel<.., SPLIT>; its 1x1 residual
+//                                                              convs and input conv on the fp32-tensor kernels
+//   anything else (odd channel counts: the tiny test net)    conv_generic_kernel                           -             -
+//
+// A/B switches (read when a plan is built or a launch is dispatched; they select among these kernels, never a CPU path): a dozen
+// product switches as environment variables of their own - DMME_NO_LVL, DMME_NO_WS, DMME_NO_KW, DMME_NO_CONV1X1_AS, DMME_NO_CONV_THIN,
+// DMME_NO_FUSED_GN, DMME_NO_GN_IN, DMME_NO_GN_DIRECT, DMME_NO_PREACT, DMME_NO_ATTN_FULL, DMME_NO_WGRAD_GROUP, DMME_NO_GN_BWD_REGS,
+// DMME_NO_GRAD_BUCKETS - and every experiment / comparison route as a key of DMME_DEBUG_ROUTE="key[=int],..." (debug_route()).
 int run_any_conv(int dtype, const ConvArgs& a, hipStream_t s) {
     if (conv_out_thin_supported(dtype, a)) return launch_conv_out_thin(a, s);
     if (conv1x1_pipe_supported(dtype, a)) return launch_conv1x1_pipe(dtype, a, s);
@@ -826,7 +681,7 @@ int run_any_conv(int dtype, const ConvArgs& a, hipStream_t s) {
 // fwd: the forward launch (a conv whose GroupNorm pre-activated its input reads that tensor and applies nothing); the backward
 // passes false and sees the raw sources with their scale / shift / mask, which is what it differentiates through
 void fill_conv(const dmme_plan* P, const Op& o, const char* packed, const float* x, float* y, char* ws,
-               const float* drop_masks, int nt, ConvArgs& a, bool fwd = false) {
+               const float* drop_masks, int nt, ConvArgs& a, bool fwd) {
     const int64_t es = (int64_t)dtype_size(P->dtype);
     (void)es;
     a.x3 = P->x3 || o.route_f32;
@@ -949,445 +804,6 @@ void fill_conv(const dmme_plan* P, const Op& o, const char* packed, const float*
             a.gn_cg = td.C / P->cfg.num_groups;
             a.gn_tiles = td.stats_tiles;
         }
-    }
-}
-
-// Grouped weight gradients: every 3x3 stride-1 conv the all-taps MFMA kernel supports is taken out of the per-layer
-// sequence; its (cout tile, cin tile) pairs are cut into jobs of at most `q` consecutive 64-pixel tiles, longest first.
-static int wg_index(const Op& o) { return o.taps == 1 ? 1 : o.stride == 2 ? 2 : 0; }
-void build_wgrad_group(dmme_plan* P, dmme_plan::WgGroup& G, int gi, int op_lo = 0, int op_hi = 1 << 30) {
-    const int taps = gi == 1 ? 1 : 9, stride = gi == 2 ? 2 : 1;
-    G.taps = taps;
-    G.stride = stride;
-    if (stride == 2 && getenv("DMME_NO_WG_S2")) return;
-    if (!is16(P->dtype) || getenv("DMME_NO_WGRAD_GROUP")) return;
-    // (the stride-2 table is three small layers: shorter jobs, or 80 workgroups would carry it)
-    const int q = stride == 2 ? 16 : 64;
-    struct Grp { int layer, n_co, n_ci, tile0, ntiles; };
-    std::vector<Grp> groups;
-    for (int oi = (int)P->ops.size() - 1; oi >= 0; --oi) {
-        Op& o = P->ops[oi];
-        if (o.kind != OP_CONV || o.src1 < 0 || o.dst < 0 || o.taps != taps || o.stride != stride || oi < op_lo || oi >= op_hi) continue;
-        ConvArgs a{};
-        fill_conv(P, o, nullptr, nullptr, nullptr, nullptr, nullptr, 1, a);
-        WgLayer L{};
-        int CO = 0, CI = 0;
-        if (!wgrad_mfma_supported(P->dtype, a) || !wgrad_group_layer(P->dtype, a, L, &CO, &CI)) continue;
-        L.src1_off = P->tensors[o.src1].off;
-        L.src2_off = o.src2 >= 0 ? P->tensors[o.src2].off : -1;
-        L.scale_off = o.gn >= 0 ? P->ops[o.gn].gn_scale : -1;
-        L.shift_off = o.gn >= 0 ? P->ops[o.gn].gn_shift : -1;
-        L.dmask_off = o.dmask_off;
-        // The weight gradient's second operand is the conv's ACTIVATED input.  Recomputing GroupNorm + SiLU + dropout per MFMA operand
-        // made the grouped kernel VALU-issue bound; instead it reads the activated tensor: the forward's own (small maps, use_act), or
-        // one the GroupNorm backward of this conv writes on its way (it holds x, scale, shift and the mask anyway: one more store).
-        L.act_off = -1;
-        L.act_bws = 0;
-        if (o.gn >= 0 && !getenv("DMME_NO_WG_ACT")) {
-            const Op& gop = P->ops[o.gn];
-            if (o.use_act && gop.gn_act >= 0) {
-                L.act_off = gop.gn_act;
-            } else if (gop.gn_src1 == o.src1 && gop.gn_src2 == o.src2 && gn_bwd_fast_supported(P->dtype, a.Hin * a.Win, a.C1, a.C2)) {
-                if (o.wg_act < 0) {
-                    o.wg_act = align_up(P->bws_bytes, 256);
-                    P->bws_bytes = o.wg_act + (int64_t)P->B * a.Hin * a.Win * (a.C1 + a.C2) * (int64_t)dtype_size(P->dtype);
-                }
-                L.act_off = o.wg_act;
-                L.act_bws = 1;
-            }
-        }
-        L.dy_off = P->gt_off[o.dst];
-        L.dw_off = P->params[o.w].wp_off;
-        o.wg_layer = (int)G.layers.size();
-        G.layers.push_back(L);
-        const int n_co = (L.Cout + CO - 1) / CO, n_ci = (L.C1 + L.C2) / CI;
-        const int ns = (L.g.tiles_m + q - 1) / q;
-        for (int sp = 0; sp < ns; ++sp) {
-            Grp gr{};
-            gr.layer = o.wg_layer;
-            gr.n_co = n_co;
-            gr.n_ci = n_ci;
-            gr.tile0 = (int)((int64_t)L.g.tiles_m * sp / ns);
-            gr.ntiles = (int)((int64_t)L.g.tiles_m * (sp + 1) / ns) - gr.tile0;
-            if (gr.ntiles > 0) groups.push_back(gr);
-        }
-    }
-    G.dma = !G.layers.empty() && !getenv("DMME_NO_WG_DMA");
-    for (const WgLayer& L : G.layers)
-        if (!(L.act_off >= 0 || ((L.C2 == 0 || taps == 1) && L.scale_off < 0 && L.dmask_off < 0 && !L.pro_silu)) || L.Cout % (taps == 9 ? 64 : 128) ||
-            (taps == 1 && (L.C1 + L.C2) % 128))
-            G.dma = 0;
-    if (stride == 2) {
-        if (!G.dma) {  // no register-staged fallback for stride 2: those layers stay on the per-layer kernel
-            for (Op& o : P->ops)
-                if (o.kind == OP_CONV && o.taps == 9 && o.stride == 2) o.wg_layer = -1;
-            G.layers.clear();
-            return;
-        }
-        G.dma = 2;
-    }
-    // All (cout tile, cin tile) jobs of one pixel range read the same dY and activation tiles: they go to ONE XCD
-    // (consecutive positions of its round-robin slice of the grid, blockIdx % 8), so the re-reads hit that XCD's L2
-    // instead of HBM.  Groups are placed longest first on the least-loaded XCD; short slices are padded with empty jobs.
-    std::stable_sort(groups.begin(), groups.end(), [](const Grp& x, const Grp& y) { return x.ntiles > y.ntiles; });
-    const int NX = 8;
-    std::vector<WgJob> lists[NX];
-    int64_t load[NX] = {0};
-    for (const Grp& gr : groups) {
-        int best = 0;
-        for (int x = 1; x < NX; ++x)
-            if (load[x] < load[best]) best = x;
-        for (int cot = 0; cot < gr.n_co; ++cot)
-            for (int cit = 0; cit < gr.n_ci; ++cit) {
-                WgJob j{};
-                j.layer = gr.layer;
-                j.cot = cot;
-                j.cit = cit;
-                j.tile0 = gr.tile0;
-                j.ntiles = gr.ntiles;
-                lists[best].push_back(j);
-            }
-        load[best] += (int64_t)gr.ntiles * gr.n_co * gr.n_ci;
-    }
-    size_t longest = 0;
-    for (int x = 0; x < NX; ++x) longest = std::max(longest, lists[x].size());
-    for (size_t pos = 0; pos < longest; ++pos)
-        for (int x = 0; x < NX; ++x) {
-            WgJob j{};
-            if (pos < lists[x].size()) j = lists[x][pos];
-            G.jobs.push_back(j);
-        }
-}
-
-// ---- level engine: which stretches of the op list become ONE persistent launch (lvl.h, lvl_engine.hip) ---------------------------
-// A stretch qualifies when every op in it lives on one 4x4 / 8x8 map and has the shape the engine is built for: DDPM ResBlocks whose
-// convs have 256 couts (8 slices of 32), inputs of whole 64-channel chunks, norms with group sizes 8 / 16 / 32, single-head attention on
-// 4x4 maps.  Anything else (other widths, the IDDPM blocks, fp32) keeps its per-op launches.
-static int op_level(const dmme_plan* P, const Op& o) {  // the map width all tensors of the op share (4 / 8), 0: not a level op
-    auto hw = [&](int id, int& H, int& W) {
-        if (id < 0) return true;
-        const Tensor& t = P->tensors[id];
-        if (H == 0) {
-            H = t.H;
-            W = t.W;
-            return true;
-        }
-        return t.H == H && t.W == W;
-    };
-    int H = 0, W = 0;
-    bool ok = true;
-    if (o.kind == OP_CONV) {
-        if (o.src1 < 0 || o.dst < 0 || o.stride != 1 || o.up || (o.taps != 1 && o.taps != 9)) return 0;
-        for (int id : {o.src1, o.src2, o.dst, o.res1, o.res2}) ok = ok && hw(id, H, W);
-    } else if (o.kind == OP_GN) {
-        ok = hw(o.gn_src1, H, W) && hw(o.gn_src2, H, W);
-    } else if (o.kind == OP_ATTN) {
-        ok = hw(o.at_qkv, H, W) && hw(o.at_out, H, W);
-    } else {
-        return 0;
-    }
-    if (!ok || H != W || (H != 4 && H != 8)) return 0;
-    return H;
-}
-
-struct LvlXAttach {  // a norm of this run finished by an op of an EARLIER run (the producer of a skip tensor)
-    int run, op;
-    LvlNorm norm;
-};
-static bool build_lvl_run(dmme_plan* P, int i0, int i1, int lvl_w, int64_t& ws, LvlRun& R, std::vector<std::pair<int, int64_t>>& gn_acts,
-                          const std::unordered_map<int, std::pair<int, int>>& made, std::vector<LvlXAttach>& xattach) {
-    const int B = P->B, G = P->cfg.num_groups, HW = lvl_w * lvl_w;
-    const int64_t es = (int64_t)dtype_size(P->dtype);
-    std::vector<LvlOp> pre, body;           // LVL_NORM ops of tensors written before the launch; the ops proper
-    std::unordered_map<int, int> prod;      // tensor id -> index into `body` of the op that produces it in this run
-    std::unordered_map<int, int> pre_of;    // tensor id -> index into `pre`
-    std::vector<int> xsrc;                  // tensors whose norms an earlier run's op finishes (complete before this launch)
-    const bool merge_res_off = getenv("DMME_LVL_NO_RES_MERGE") != nullptr;
-    auto is_x = [&](int t) { return std::find(xsrc.begin(), xsrc.end(), t) != xsrc.end(); };
-    // flag rows are (final op index) * 2 + which; body indices are shifted by pre.size() at the end: encode body rows as 1000000 + ...
-    auto row_of = [&](int tensor) -> int {
-        auto it = prod.find(tensor);
-        if (it != prod.end()) return 1000000 + it->second * 2;
-        auto jt = pre_of.find(tensor);
-        if (jt != pre_of.end()) return jt->second * 2;  // the LVL_NORM op that pre-activates it (its act is what the consumer reads)
-        return -1;
-    };
-    auto blank = [&]() {
-        LvlOp o{};
-        o.kind = LVL_CONV;
-        o.taps = 1;
-        o.wait0 = o.wait1 = o.wait2 = o.wait3 = -1;
-        o.a1_off = o.a2_off = o.a3_off = o.a4_off = o.dst_off = o.res_off = o.sc_off = -1;
-        o.w2_off = o.b2_off = -1;
-        o.tproj_col = -1;
-        o.keep = -1;
-        o.signal = 1;
-        for (auto& n : o.norm) n.act_off = n.dmask_off = -1;
-        return o;
-    };
-    for (int oi = i0; oi < i1; ++oi) {
-        const Op& o = P->ops[oi];
-        if (o.kind == OP_GN) {
-            if (o.gn_mod_col >= 0) return false;
-            const Tensor& t1 = P->tensors[o.gn_src1];
-            const int C2 = o.gn_src2 >= 0 ? P->tensors[o.gn_src2].C : 0, Cn = t1.C + C2;
-            if (Cn % G) return false;
-            const int cg = Cn / G;
-            if (cg % 8 || 32 % cg || t1.C != 256 || (C2 != 0 && C2 != 256)) return false;
-            int consumer = -1;  // the conv this norm feeds (exactly one: conv1 / conv2 / qkv_proj)
-            for (int ci = oi + 1; ci < i1; ++ci)
-                if (P->ops[ci].kind == OP_CONV && P->ops[ci].gn == oi) {
-                    if (consumer >= 0) return false;
-                    consumer = ci;
-                }
-            if (consumer < 0) return false;
-            const Op& cv = P->ops[consumer];
-            if (cv.src1 != o.gn_src1 || cv.src2 != o.gn_src2) return false;
-            const int64_t act = ws;
-            ws = align_up(ws + (int64_t)B * HW * Cn * es, 256);
-            gn_acts.push_back({oi, act});
-            int coff = 0;
-            for (int src : {o.gn_src1, o.gn_src2}) {
-                if (src < 0) continue;
-                LvlNorm n{};
-                n.gamma_off = P->params[o.gn_gamma].packed_off;
-                n.beta_off = P->params[o.gn_beta].packed_off;
-                n.scale_off = o.gn_scale;
-                n.shift_off = o.gn_shift;
-                n.mr_off = o.gn_mr;
-                n.act_off = act;
-                n.dmask_off = cv.dmask_off;
-                n.Cn = Cn;
-                n.cg = cg;
-                n.c_off = coff;
-                n.act_silu = cv.pro_silu;
-                LvlOp* host = nullptr;
-                auto it = prod.find(src);
-                auto mt = made.find(src);
-                if (it != prod.end()) {
-                    host = &body[it->second];
-                } else if (mt != made.end() && pre_of.find(src) == pre_of.end()) {
-                    // produced by the engine in an earlier launch (a skip tensor of the down path): that op gets the norm, if it has room
-                    int used = P->lvl_runs[mt->second.first].ops[mt->second.second].n_norm;
-                    for (const LvlXAttach& xa : xattach) used += xa.run == mt->second.first && xa.op == mt->second.second;
-                    if (used >= 2) return false;
-                    xattach.push_back({mt->second.first, mt->second.second, n});
-                    xsrc.push_back(src);
-                    coff += P->tensors[src].C;
-                    continue;
-                } else {
-                    auto jt = pre_of.find(src);
-                    if (jt == pre_of.end()) {
-                        LvlOp q = blank();
-                        q.kind = LVL_NORM;
-                        q.dst_off = P->tensors[src].off;
-                        q.dst_C = P->tensors[src].C;
-                        q.dst_c0 = 0;
-                        pre_of[src] = (int)pre.size();
-                        pre.push_back(q);
-                        jt = pre_of.find(src);
-                    }
-                    host = &pre[jt->second];
-                }
-                if (host->n_norm >= 2) return false;
-                // a 768-wide qkv tensor never feeds a norm; every other engine tensor is 256 wide: one LvlOp per tensor
-                host->norm[host->n_norm++] = n;
-                coff += P->tensors[src].C;
-            }
-            continue;
-        }
-        if (o.kind == OP_ATTN) {
-            const Tensor& q = P->tensors[o.at_qkv];
-            if (o.at_heads != 1 || HW != 16 || q.C != 768 || body.size() < 3 || body[body.size() - 1].keep != 2) return false;
-            LvlOp a = blank();
-            a.kind = LVL_ATTN;
-            a.dst_off = P->tensors[o.at_out].off;
-            a.dst_C = P->tensors[o.at_out].C;
-            a.dst_c0 = 0;
-            a.kscale = 1.0f / sqrtf((float)(q.C / 3));
-            a.sc_off = ws;
-            ws = align_up(ws + (int64_t)R.NG * LVL_NS * 1024 * 4, 256);
-            prod[o.at_out] = (int)body.size();
-            body.push_back(a);
-            R.flops += 4.0 * B * HW * HW * (q.C / 3);
-            continue;
-        }
-        // OP_CONV
-        const Param& w = P->params[o.w];
-        const Tensor& t1 = P->tensors[o.src1];
-        const int C1 = t1.C, C2 = o.src2 >= 0 ? P->tensors[o.src2].C : 0, Cin = C1 + C2;
-        const bool is_qkv = w.cout == 768 && oi + 1 < i1 && P->ops[oi + 1].kind == OP_ATTN && P->ops[oi + 1].at_qkv == o.dst;
-        if ((w.cout != 256 && !is_qkv) || Cin % 64 || C1 % 64 || o.out_silu || o.res2 >= 0) return false;
-        if (o.gn < 0 && (o.pro_silu || o.dmask_off >= 0)) return false;
-        if (Cin % 256) return false;  // the K loop runs in passes of 256 channels: one 64-channel chunk per wave and pass
-        LvlOp c = blank();
-        c.taps = o.taps;
-        if (o.gn >= 0) {  // the pre-activated input its norm's producers wrote
-            int64_t act = -1;
-            for (auto& ga : gn_acts)
-                if (ga.first == o.gn) act = ga.second;
-            if (act < 0) return false;
-            c.a1_off = act;
-            c.C1 = Cin;
-            c.C2 = 0;
-        } else {
-            c.a1_off = t1.off;
-            c.C1 = C1;
-            c.a2_off = o.src2 >= 0 ? P->tensors[o.src2].off : -1;
-            c.C2 = C2;
-        }
-        c.wait0 = row_of(o.src1);
-        c.wait1 = o.src2 >= 0 ? row_of(o.src2) : -1;
-        if (o.gn >= 0 && ((c.wait0 < 0 && !is_x(o.src1)) || (o.src2 >= 0 && c.wait1 < 0 && !is_x(o.src2)))) return false;  // (an act tensor has a producer)
-        c.w_off = w.packed_off;
-        c.b_off = P->params[o.b].packed_off;
-        c.dst_off = P->tensors[o.dst].off;
-        c.dst_C = P->tensors[o.dst].C;
-        c.tproj_col = o.tproj_col;
-        if (o.res1 >= 0) {
-            if (P->tensors[o.res1].C != 256) return false;
-            c.res_off = P->tensors[o.res1].off;
-            c.res_C = 256;
-            c.res_c0 = 0;
-            // The residual is the output of the block's 1x1 residual conv, the op pushed just before this one, and nothing else reads
-            // it: that conv becomes this op's second K segment (LvlOp::C3) - no residual tensor, one op and one hand-off less per block.
-            auto rt = prod.find(o.res1);
-            if (!merge_res_off && o.taps == 9 && rt != prod.end() && rt->second == (int)body.size() - 1) {
-                const LvlOp& r = body.back();
-                bool only_here = true;  // (forward readers of the residual tensor: this conv alone)
-                for (int ci = i0; ci < (int)P->ops.size() && only_here; ++ci) {
-                    const Op& q = P->ops[ci];
-                    if (ci == oi) continue;
-                    if (q.kind == OP_CONV && (q.src1 == o.res1 || q.src2 == o.res1 || q.res1 == o.res1 || q.res2 == o.res1)) only_here = false;
-                    if (q.kind == OP_GN && (q.gn_src1 == o.res1 || q.gn_src2 == o.res1)) only_here = false;
-                    if (q.kind == OP_ATTN && q.at_qkv == o.res1) only_here = false;
-                }
-                if (only_here && r.kind == LVL_CONV && r.taps == 1 && r.n_norm == 0 && r.keep < 0 && r.res_off < 0 && r.tproj_col < 0 && !r.reuse_a && r.w_row0 == 0 &&
-                    r.dst_c0 == 0 && r.C3 == 0) {
-                    c.C3 = r.C1;
-                    c.C4 = r.C2;
-                    c.a3_off = r.a1_off;
-                    c.a4_off = r.a2_off;
-                    c.wait2 = r.wait0;
-                    c.wait3 = r.wait1;
-                    c.w2_off = r.w_off;
-                    c.b2_off = r.b_off;
-                    c.res_off = -1;
-                    prod.erase(rt);
-                    body.pop_back();
-                }
-            }
-        }
-        R.flops += 2.0 * B * HW * (double)w.cout * Cin * o.taps;
-        R.bytes += (double)w.cout * Cin * o.taps * es + (double)B * HW * (Cin + w.cout) * es;
-        if (is_qkv) {
-            for (int j = 0; j < 3; ++j) {
-                LvlOp q = c;
-                q.w_row0 = 256 * j;
-                q.dst_c0 = 256 * j;
-                q.keep = j;
-                q.reuse_a = j > 0;
-                if (j > 0) q.wait0 = q.wait1 = -1;
-                body.push_back(q);
-            }
-            prod[o.dst] = (int)body.size() - 1;
-        } else {
-            prod[o.dst] = (int)body.size();
-            body.push_back(c);
-        }
-    }
-    const int shift = (int)pre.size();
-    R.ops = pre;
-    for (LvlOp c : body) {
-        for (int* wr : {&c.wait0, &c.wait1, &c.wait2, &c.wait3})
-            if (*wr >= 1000000) *wr = (*wr - 1000000) + shift * 2;
-        R.ops.push_back(c);
-    }
-    R.made.clear();
-    for (auto& kv : pre_of) R.made.push_back({kv.first, kv.second});
-    for (auto& kv : prod) R.made.push_back({kv.first, kv.second + shift});
-    return !body.empty();
-}
-
-void assign_levels(dmme_plan* P) {
-    if (getenv("DMME_NO_LVL") || P->cfg.arch != DMME_ARCH_DDPM || P->x3 || (P->dtype != DMME_BF16 && P->dtype != DMME_F16)) return;
-    const int mask = getenv("DMME_LVL_MASK") ? atoi(getenv("DMME_LVL_MASK")) : 12;  // bit 2: 4x4 maps, bit 3: 8x8 maps
-    // The engine's hand-offs spin, so a launch only works if ALL its workgroups are resident together: size the grids by what THIS
-    // device holds (compute units x workgroups per unit at the kernel's 150 KB of LDS), not by a constant; a level that needs more
-    // than two iterations per workgroup at that size keeps its per-op launches (below).  (lvl_max_wg=: test knob, a smaller device.)
-    if (P->device >= 0) {
-        const int n = lvl_engine_max_resident(P->dtype, P->device);
-        if (n < LVL_NS) return;  // (also a HIP error: no engine, the per-op kernels run)
-        P->lvl_max_wg = n;
-    }
-    if (debug_route("lvl_max_wg", 0) > 0) P->lvl_max_wg = std::min(P->lvl_max_wg, debug_route("lvl_max_wg", 0));
-    if (P->lvl_max_wg < LVL_NS) return;
-    const int nO = (int)P->ops.size();
-    std::unordered_map<int, std::pair<int, int>> made;  // tensor id -> (run, op) of the engine op that holds its slices
-    int i = 0;
-    while (i < nO) {
-        const int L = op_level(P, P->ops[i]);
-        if (!L) {
-            ++i;
-            continue;
-        }
-        int j = i;
-        while (j < nO && op_level(P, P->ops[j]) == L) ++j;
-        if (mask & L) {
-            LvlRun R;
-            R.op_first = i;
-            R.op_last = j - 1;
-            R.sh = L == 4 ? 2 : 3;
-            R.NG = (P->B * L * L + LVL_BM - 1) / LVL_BM;
-            int64_t ws = P->ws_bytes;
-            std::vector<std::pair<int, int64_t>> gn_acts;
-            std::vector<LvlXAttach> xattach;
-            if (build_lvl_run(P, i, j, L, ws, R, gn_acts, getenv("DMME_LVL_NO_XRUN") ? std::unordered_map<int, std::pair<int, int>>() : made, xattach)) {
-                // two groups per op iteration where a workgroup owns several (the filter stream is shared by twice the matrix work);
-                // the attention block keeps q / k / v of ONE group in LDS
-                bool has_attn = false;
-                for (const LvlOp& lo : R.ops) has_attn = has_attn || lo.kind == LVL_ATTN;
-                int slots = P->lvl_max_wg / LVL_NS;
-                R.GB = (R.NG > slots && !has_attn && !getenv("DMME_LVL_GB1")) ? 2 : 1;
-                const int nb = (R.NG + R.GB - 1) / R.GB;
-                // still more than one iteration per workgroup: 64-cout slices (4 per group) - half the iterations, the input gathered
-                // by half as many workgroups, 128 x 64 per filter unit instead of 128 x 32 (B = 128, 8x8 maps: 2 iterations -> 1)
-                R.NJ = (R.GB == 2 && nb > slots && !getenv("DMME_LVL_NJ1")) ? 2 : 1;
-                slots *= R.NJ;
-                R.NGS = nb < slots ? nb : slots;
-                // more than two iterations per op and workgroup: the per-layer kernels (tiles over the whole batch) are the better
-                // route again - measured at batch 512 (DDIM): 8.2 ms per step with them, 8.9 with the engine
-                const int max_iter = getenv("DMME_LVL_MAX_ITER") ? atoi(getenv("DMME_LVL_MAX_ITER")) : 2;
-                if ((nb + slots - 1) / slots > max_iter) {
-                    i = j;
-                    continue;
-                }
-                P->ws_bytes = ws;
-                for (const LvlXAttach& xa : xattach) {
-                    LvlOp& host = P->lvl_runs[xa.run].ops[xa.op];
-                    host.norm[host.n_norm++] = xa.norm;
-                }
-                for (auto& mk : R.made) made[mk.first] = {(int)P->lvl_runs.size(), mk.second};
-                const int ri = (int)P->lvl_runs.size();
-                for (int oi = i; oi < j; ++oi) {
-                    Op& o = P->ops[oi];
-                    o.lvl = ri;
-                    o.lvl_first = oi == i;
-                    if (o.kind == OP_GN) o.gn_direct = 1;  // (no launch of its own; its rows and act come from the engine)
-                }
-                for (auto& ga : gn_acts) {
-                    Op& g = P->ops[ga.first];
-                    g.gn_act = ga.second;
-                    for (int ci = ga.first + 1; ci < j; ++ci)
-                        if (P->ops[ci].kind == OP_CONV && P->ops[ci].gn == ga.first) {
-                            g.gn_consumer = ci;
-                            P->ops[ci].use_act = 1;
-                        }
-                }
-                P->lvl_runs.push_back(R);
-            }
-        }
-        i = j;
     }
 }
 
@@ -1623,41 +1039,6 @@ int run_gn(const dmme_plan* P, const Op& o, const char* pk, char* ws, int nt, co
     return launch_gn_modulate(sc, sh, tsh, tsc, P->tproj_cols, nt, P->B, o.gn_mod_C, s);
 }
 
-// diagnostic: in-kernel stamps of one workgroup of one level run (dmme_debug_level_stamps)
-static long long* g_lvl_stamps = nullptr;
-static int g_lvl_stamp_run = -1, g_lvl_stamp_wg = 0;
-
-int run_level(const dmme_plan* P, const LvlRun& R, const char* pk, char* ws, int nt, const float* drop_masks, hipStream_t s) {
-    DMME_REQUIRE(R.ops_dev && R.sync_dev, DMME_ERR_INVALID, "level engine: the plan was created without a device");
-    LvlArgs a{};
-    a.ops = R.ops_dev;
-    a.n_ops = (int)R.ops.size();
-    a.ws = ws;
-    a.packed = pk;
-    a.drop_masks = drop_masks;
-    a.tproj = (const float*)(ws + P->ws_tproj);
-    a.tproj_ld = P->tproj_cols;
-    a.nt = nt;
-    a.N = P->B;
-    a.sh = R.sh;
-    a.NG = R.NG;
-    a.NGS = R.NGS;
-    a.GB = R.GB;
-    a.NJ = R.NJ;
-    a.ctl = R.sync_dev;
-    a.flags = R.sync_dev + 16;
-    a.err_sys = P->err_host;
-    a.run_tag = 1 + (int)(&R - P->lvl_runs.data());
-    a.spin_limit = debug_route("lvl_spin", 0);
-    a.withhold = debug_route("lvl_withhold", 0);
-    a.max_wg = P->lvl_max_wg;
-    if (g_lvl_stamps && g_lvl_stamp_run == (int)(&R - P->lvl_runs.data())) {
-        a.stamps = g_lvl_stamps;
-        a.stamp_wg = g_lvl_stamp_wg;
-    }
-    return launch_lvl_engine(P->dtype, a, s);
-}
-
 int run_op(const dmme_plan* P, const Op& o, const char* pk, const float* x, const int64_t* t, int nt, float* y,
            char* ws, const float* drop_masks, hipStream_t s) {
     if (o.lvl >= 0) return o.lvl_first ? run_level(P, P->lvl_runs[o.lvl], pk, ws, nt, drop_masks, s) : DMME_OK;
@@ -1786,7 +1167,7 @@ void op_account(const dmme_plan* P, const Op& o, char* label, int cap, double* f
     }
 }
 
-}  // namespace
+}  // namespace dmme
 
 // ======================================================================== extern "C"
 extern "C" {
@@ -1980,7 +1361,7 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
             for (int k = 0; k < 3; ++k) build_wgrad_group(P, G.wg[k], k, G.op_lo, G.op_hi);
         for (int k = 0; k < 3; ++k) build_wgrad_group(P, P->wg[k], k);
         std::vector<int> bias_job_op, col_job_op;  // op index each job belongs to (gradient buckets)
-        if (!getenv("DMME_NO_BIAS_GROUP"))
+        if (!debug_route("no_bias_group"))
             for (Op& o : P->ops) {
                 if (o.kind != OP_CONV) continue;
                 const int o_index = (int)(&o - P->ops.data());
@@ -2010,7 +1391,7 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
                 }
                 if (!colsum_fast_supported(P->dtype, a.Hout * a.Wout, a.Cout)) continue;
                 o.bias_deferred = 1;
-                if (!getenv("DMME_NO_COLSUM_GROUP")) {
+                if (!debug_route("no_colsum_group")) {
                     ColJob cj{};
                     const int nch = colsum_group_chunks(P->dtype, a.Hout * a.Wout, a.Cout, &cj.chunk_px, &cj.ppw);
                     cj.dy_off = o.dst == -2 ? P->bws_dy : P->gt_off[o.dst];
@@ -2187,39 +1568,6 @@ DMME_API int dmme_unet_pack_params(const dmme_plan* plan, const float* ref_flat,
     return launch_pack_table(plan->dtype, plan->items_dev, plan->n_items, ref_flat, packed, (hipStream_t)stream);
 }
 
-// The level engine's hand-off waits are bounded: a wait that gives up (a workgroup that was never scheduled - fewer free compute
-// units than the launch needs - or a fault) lets the launch drain with WRONG numbers and raises the plan's host-visible status word.
-// Every entry point that enqueues work on the plan looks at that word first, and dmme_unet_plan_check is the call for hosts that
-// replay a captured graph (no entry point runs then): no path hands results on with rc 0 once the word is set.
-static int lvl_check(const dmme_plan* P, const char* where, hipStream_t stream = nullptr, bool have_stream = false) {
-    if (!P->err_host) return DMME_OK;
-    const unsigned v = __atomic_load_n(P->err_host, __ATOMIC_ACQUIRE);
-    if (!v) return DMME_OK;
-    // clear: the device-side sticky words (a set word makes every later wait of that run give up after 1024 polls) and the host word
-    // - unless the caller's stream is being captured (synchronising calls would invalidate the capture; the word stays set and the
-    // next check outside a capture clears it)
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (have_stream && hipStreamIsCapturing(stream, &cs) != hipSuccess) cs = hipStreamCaptureStatusNone;
-    if (cs == hipStreamCaptureStatusNone) {
-        (void)hipDeviceSynchronize();
-        for (const LvlRun& R : P->lvl_runs)
-            if (R.sync_dev) (void)hipMemset(R.sync_dev + 2, 0, 4);
-        __atomic_store_n(P->err_host, 0u, __ATOMIC_RELEASE);
-    }
-    const int ri = (int)v - 1;
-    const LvlRun* R = ri >= 0 && ri < (int)P->lvl_runs.size() ? &P->lvl_runs[ri] : nullptr;
-    set_error("%s: a hand-off wait of the level engine timed out (run %d, %dx%d maps, %d workgroups that must all be resident at once; the device "
-              "holds %d): every output of this plan since the last check is invalid.  Typical cause: compute units held by another stream / "
-              "process / CU mask.  DMME_NO_LVL=1 selects the per-op kernels.",
-              where, ri, R ? 1 << R->sh : 0, R ? 1 << R->sh : 0, R ? R->NGS * (LVL_NS / R->NJ) : 0, P->lvl_max_wg);
-    return DMME_ERR_HIP;
-}
-
-DMME_API int dmme_unet_plan_check(const dmme_plan* plan) {
-    DMME_REQUIRE(plan, DMME_ERR_INVALID, "plan_check: null plan");
-    return lvl_check(plan, "plan_check");
-}
-
 DMME_API int dmme_unet_forward(const dmme_plan* plan, const void* packed, const float* x, const int64_t* t, int t_len,
                       float* y, void* workspace, const float* drop_masks, void* stream) {
     DMME_REQUIRE(plan && packed && x && t && y && workspace, DMME_ERR_INVALID, "unet_forward: null argument");
@@ -2242,24 +1590,6 @@ DMME_API int dmme_unet_forward(const dmme_plan* plan, const void* packed, const 
 }
 
 DMME_API int dmme_unet_plan_num_ops(const dmme_plan* plan) { return plan ? (int)plan->ops.size() : 0; }
-
-DMME_API int dmme_unet_plan_level_info(const dmme_plan* plan, char* buf, int cap) {
-    DMME_REQUIRE(plan && buf && cap > 0, DMME_ERR_INVALID, "level_info: bad argument");
-    std::string out;
-    char tmp[192];
-    snprintf(tmp, sizeof(tmp), "runs=%d", (int)plan->lvl_runs.size());
-    out = tmp;
-    for (const LvlRun& R : plan->lvl_runs) {
-        unsigned ctl[3] = {0, 0, 0};
-        if (R.sync_dev) DMME_CHECK_HIP(hipMemcpy(ctl, R.sync_dev, sizeof(ctl), hipMemcpyDeviceToHost));  // (synchronises with the device)
-        snprintf(tmp, sizeof(tmp), " [map=%dx%d plan_ops=%d-%d engine_ops=%d groups=%d per_iteration=%d slice=%d workgroups=%d epoch=%u err=%u]", 1 << R.sh, 1 << R.sh,
-                 R.op_first, R.op_last, (int)R.ops.size(), R.NG, R.GB, 32 * R.NJ, R.NGS * (LVL_NS / R.NJ), ctl[0], ctl[2]);
-        out += tmp;
-    }
-    strncpy(buf, out.c_str(), (size_t)cap - 1);
-    buf[cap - 1] = 0;
-    return DMME_OK;
-}
 
 DMME_API int dmme_unet_plan_op_info(const dmme_plan* plan, int index, char* label, int label_cap, double* flops,
                                     double* bytes) {
@@ -2294,426 +1624,6 @@ DMME_API int dmme_unet_forward_profiled(const dmme_plan* plan, const void* packe
 }
 
 // ---------------------------------------------------------------- training: backward + optimiser
-DMME_API int64_t dmme_unet_plan_packed_bwd_bytes(const dmme_plan* plan) { return plan ? plan->packed_bwd_bytes : 0; }
-DMME_API int64_t dmme_unet_plan_bwd_workspace_bytes(const dmme_plan* plan) { return plan ? plan->bws_bytes : 0; }
-
-DMME_API int dmme_unet_pack_params_bwd(const dmme_plan* plan, const float* ref_flat, void* packed_bwd, void* stream) {
-    DMME_REQUIRE(plan && ref_flat && packed_bwd, DMME_ERR_INVALID, "pack_params_bwd: null argument");
-    DMME_REQUIRE(plan->items_bwd_dev, DMME_ERR_INVALID, "pack_params_bwd: plan was created without a device");
-    return launch_pack_table(plan->dtype, plan->items_bwd_dev, plan->n_items_bwd, ref_flat, packed_bwd, (hipStream_t)stream);
-}
-
-static int backward_impl(const dmme_plan* plan, const void* packed, const void* packed_bwd, const float* x, const int64_t* t, int t_len,
-                         const float* d_y, void* workspace, void* bwd_workspace, const float* drop_masks, float* grad_flat, float* d_x,
-                         void* stream, dmme_bucket_fn ready, void* user) {
-    DMME_REQUIRE(plan && packed && packed_bwd && x && t && d_y && workspace && bwd_workspace && grad_flat, DMME_ERR_INVALID,
-                 "unet_backward: null argument");
-    DMME_REQUIRE(t_len == 1 || t_len == plan->B, DMME_ERR_INVALID, "unet_backward: bad t_len %d", t_len);
-    if (int rc0 = lvl_check(plan, "unet_backward", (hipStream_t)stream, true)) return rc0;  // (the forward this backward differentiates ran through the engine)
-    DMME_REQUIRE(!plan->mix, DMME_ERR_UNSUPPORTED, "unet_backward: precision fp16r32 is an inference mode");
-    const dmme_plan* P = plan;
-    hipStream_t s = (hipStream_t)stream;
-    const char* pk = (const char*)packed;
-    const char* pkb = (const char*)packed_bwd;
-    char* ws = (char*)workspace;
-    char* bws = (char*)bwd_workspace;
-    const int B = P->B, dt = P->dtype, nt = t_len, G = P->cfg.num_groups;
-    std::vector<char> written(P->tensors.size(), 0);
-    auto gptr = [&](int id) -> char* { return bws + P->gt_off[id]; };
-    auto claim = [&](int id) -> int {  // 0: first contribution (write), 1: accumulate
-        const int acc = written[id];
-        written[id] = 1;
-        return acc;
-    };
-    // identity-residual branches (d x += d out of a ResBlock / attention block) are not launched on their own: the pointer waits here
-    // until the GroupNorm backward that writes x's gradient anyway (norm1 / the attention norm of the same block) takes it as one more
-    // addend; anything else that needs x's gradient first gets it through flush_pending
-    const bool res_extra_off = getenv("DMME_NO_RES_EXTRA") != nullptr;
-    std::vector<const char*> pending(P->tensors.size(), nullptr);
-    auto flush_pending = [&](int id) -> int {
-        if (id < 0 || !pending[id]) return DMME_OK;
-        const Tensor& t = P->tensors[id];
-        const char* src = pending[id];
-        pending[id] = nullptr;
-        const int acc = claim(id);
-        return launch_grad_acc(dt, src, gptr(id), nullptr, t.C, 0, acc, 0, 0, B, t.H, t.W, s);
-    };
-
-    DMME_CHECK_HIP(hipMemsetAsync(bws + P->bws_zero, 0, (size_t)P->bws_zero_bytes, s));
-    float* wimage = (float*)(bws + P->bws_wimage);
-    float* dtproj = (float*)(bws + P->bws_dtproj);
-    char* tmp = bws + P->bws_tmp;
-    int rc = launch_nchw_to_nhwc(dt, d_y, B, P->out_channels, P->H * P->W, bws + P->bws_dy, s);
-    if (rc != DMME_OK) return rc;
-    const bool buckets = ready != nullptr && !P->gb.empty();  // bucketed mode: deferred work flushed per gradient bucket
-    const int emb = P->cfg.emb_dim, pos = P->cfg.pos_dim, tc = P->tproj_cols;
-    const float* temb = (const float*)(ws + P->ws_temb);
-    // deferred launches of one gradient bucket (b >= 0) or of everything (b = -1): bias + time rows, grouped weight gradients, unpack,
-    // the per-block time-projection weight gradients
-    auto flush = [&](int b) -> int {
-        int r = DMME_OK;
-        const dmme_plan::GradBucket* GBk = b >= 0 ? &P->gb[b] : nullptr;
-        if (P->bias_jobs_dev && P->col_jobs_dev) {
-            const int j0 = GBk ? GBk->col0 : 0, j1 = GBk ? GBk->col1 : (int)P->col_jobs.size();
-            if (j1 > j0) r = launch_colsum_group(dt, P->col_jobs_dev + j0, j1 - j0, bws, B, s);
-            if (r != DMME_OK) return r;
-        }
-        if (P->bias_jobs_dev) {
-            const int j0 = GBk ? GBk->bias0 : 0, j1 = GBk ? GBk->bias1 : (int)P->bias_jobs.size();
-            if (j1 > j0) r = launch_bias_tproj_group(P->bias_jobs_dev + j0, j1 - j0, bws, grad_flat, dtproj, B, tc, nt, s);
-            if (r != DMME_OK) return r;
-        }
-        for (int k = 0; k < 3; ++k) {
-            const dmme_plan::WgGroup& G = GBk ? GBk->wg[k] : P->wg[k];
-            if (!G.jobs_dev) continue;
-            r = launch_wgrad_group(dt, G.taps, G.layers_dev, G.jobs_dev, (int)G.jobs.size(), ws, bws, drop_masks, wimage, s, G.dma, bws + P->bws_zpage);
-            if (r != DMME_OK) return r;
-        }
-        {
-            std::vector<std::pair<int, int>> all_items{{0, P->n_items_unpack}};
-            for (const auto& ir : (GBk ? GBk->unpack : all_items)) {
-                if (ir.second > ir.first) r = launch_wgrad_unpack(P->items_unpack_dev + ir.first, ir.second - ir.first, wimage, grad_flat, s);
-                if (r != DMME_OK) return r;
-            }
-        }
-        std::vector<std::pair<int, int>> all_cols{{0, tc}};
-        for (const auto& cr : (GBk ? GBk->tcols : all_cols)) {
-            const int c0 = cr.first, c1 = cr.second;
-            if (c1 <= c0) continue;
-            if (P->tp_tiles_dev) {  // every block's dW / db in one launch each
-                r = launch_small_gemm_tn_tiled(dtproj + c0, tc, temb, emb, c1 - c0, emb, nt, grad_flat, emb, P->tp_tiles_dev + c0 / 64, s);
-                if (r == DMME_OK) r = launch_nsum_tiled(dtproj + c0, nt, c1 - c0, tc, 1, grad_flat, P->tp_tiles_dev + P->tp_n64 + c0 / 32, s);
-                if (r != DMME_OK) return r;
-            } else {
-                for (const auto& tb : P->tblocks) {
-                    if (tb.col < c0 || tb.col >= c1) continue;
-                    // dW_block[o][k] += sum_r dtproj[r][col+o] temb[r][k];  db_block[o] += sum_r dtproj[r][col+o]
-                    r = launch_small_gemm(dt, 2, dtproj + tb.col, tc, temb, emb, tb.cout, emb, nt, nullptr, 0, grad_flat + P->params[tb.tw].ref_off, emb, s);
-                    if (r == DMME_OK) r = launch_nsum(dtproj + tb.col, nt, tb.cout, tc, 1, grad_flat + P->params[tb.tb].ref_off, s);
-                    if (r != DMME_OK) return r;
-                }
-            }
-        }
-        return r;
-    };
-    auto hand_over = [&](int b) {
-        for (const auto& r : P->gb[b].ranges) ready(user, b, r.first, r.second);
-    };
-    int next_bucket = 0;  // the bucket whose stretch the reverse walk is in
-    if (P->cfg.arch == DMME_ARCH_IDDPM && nt == 1)  // shared timestep row: the GroupNorm backward accumulates into it atomically
-        DMME_CHECK_HIP(hipMemsetAsync(dtproj, 0, (size_t)P->tproj_cols * 4, s));
-
-    for (int oi = (int)P->ops.size() - 1; oi >= 0 && rc == DMME_OK; --oi) {
-        if (buckets && next_bucket + 1 < (int)P->gb.size() && oi == P->gb[next_bucket].op_lo - 1) {
-            // every op of this bucket has run (a pending identity-residual gradient that belongs to a tensor of the NEXT stretch stays
-            // pending: it carries no parameter gradient): finish the bucket's parameter gradients and hand it to the exchange
-            rc = flush(next_bucket);
-            if (rc != DMME_OK) break;
-            hand_over(next_bucket);
-            ++next_bucket;
-        }
-        const Op& o = P->ops[oi];
-        if (o.kind == OP_ATTN) {
-            rc = flush_pending(o.at_out);
-            if (rc != DMME_OK) break;
-            const Tensor& q = P->tensors[o.at_qkv];
-            const int S = q.H * q.W, C = q.C / 3;
-            DMME_REQUIRE(written[o.at_out], DMME_ERR_INVALID, "backward: attention output has no gradient");
-            if (o.at_heads > 1 && attn_heads_mfma_supported(dt, B, S, C, o.at_heads))
-                rc = launch_attn_heads_bwd_mfma(dt, ws + q.off, ws + P->tensors[o.at_out].off, gptr(o.at_out), (const float*)(ws + o.at_lse), B, S, C,
-                                                o.at_heads, bws + P->bws_attP, bws + P->bws_attdS, gptr(o.at_qkv), s);
-            else if (o.at_heads > 1)
-                rc = launch_attn_heads_bwd(dt, ws + q.off, gptr(o.at_out), B, S, C, o.at_heads, (float*)(bws + P->bws_attP),
-                                           (float*)(bws + P->bws_attdS), gptr(o.at_qkv), s);
-            else if (attn_bwd_mfma_supported(dt, B, S, C))
-                rc = launch_attn_bwd_mfma(dt, ws + q.off, ws + P->tensors[o.at_out].off, gptr(o.at_out), (const float*)(ws + o.at_lse), B, S, C,
-                                          bws + P->bws_attP, bws + P->bws_attdS, gptr(o.at_qkv), s);
-            else
-                rc = launch_attn_bwd_generic(dt, ws + q.off, gptr(o.at_out), B, S, C, (float*)(bws + P->bws_attP),
-                                             (float*)(bws + P->bws_attdS), gptr(o.at_qkv), s);
-            written[o.at_qkv] = 1;
-            continue;
-        }
-        if (o.kind != OP_CONV) continue;
-        ConvArgs a{};
-        fill_conv(P, o, pk, x, nullptr, ws, drop_masks, nt, a);
-        if (o.dst >= 0) {
-            rc = flush_pending(o.dst);
-            if (rc != DMME_OK) break;
-        }
-        const char* dy = o.dst == -2 ? bws + P->bws_dy : gptr(o.dst);
-        if (o.dst != -2) DMME_REQUIRE(written[o.dst], DMME_ERR_INVALID, "backward: tensor %d has no gradient", o.dst);
-        const int Cin = a.C1 + a.C2;
-        float* rowsum = (float*)(bws + o.b_rowsum);
-        // 1. bias and time-embedding-row gradients (column sums of dY)
-        if (o.bias_deferred && P->bias_jobs_dev && P->col_jobs_dev)
-            rc = DMME_OK;  // its column sums come from the grouped launch of the flush
-        else if (o.bias_deferred && P->bias_jobs_dev)
-            rc = launch_colsum_fast(dt, dy, B, a.Hout * a.Wout, a.Cout, rowsum, nullptr, nullptr, P->tproj_cols, nt, s);
-        else if (colsum_fast_supported(dt, a.Hout * a.Wout, a.Cout))
-            rc = launch_colsum_fast(dt, dy, B, a.Hout * a.Wout, a.Cout, rowsum, grad_flat + P->params[o.b].ref_off,
-                                    o.tproj_col >= 0 ? dtproj + o.tproj_col : nullptr, P->tproj_cols, nt, s);
-        else
-            rc = launch_colsum(dt, dy, B, a.Hout * a.Wout, a.Cout, rowsum, grad_flat + P->params[o.b].ref_off,
-                               o.tproj_col >= 0 ? dtproj + o.tproj_col : nullptr, P->tproj_cols, nt, s);
-        if (rc != DMME_OK) break;
-        // 2. weight gradient: deferred to the grouped launch below, or per layer (packed image / reference layout)
-        if (o.wg_layer >= 0 && (buckets ? P->gb[next_bucket].wg[wg_index(o)].jobs_dev : P->wg[wg_index(o)].jobs_dev))
-            rc = DMME_OK;
-        else if (wgrad_mfma_supported(dt, a))
-            rc = launch_wgrad_mfma(dt, a, dy, wimage + P->params[o.w].wp_off, s);
-        else if (wgrad_small_supported(dt, a))
-            rc = launch_wgrad_small(dt, a, dy, grad_flat + P->params[o.w].ref_off, s);
-        else
-            rc = launch_wgrad_generic(dt, a, dy, grad_flat + P->params[o.w].ref_off, s);
-        if (rc != DMME_OK) break;
-        // 3. data gradient: the forward kernel on dY with transposed, tap-flipped weights
-        if (o.src1 >= 0) {
-            ConvArgs d{};
-            d.src1 = dy;
-            d.C1 = a.Cout;
-            d.N = B;
-            d.Hin = a.Hout;
-            d.Win = a.Wout;
-            d.up = o.stride == 2 ? 2 : 0;
-            d.stride = 1;
-            d.taps = o.taps;
-            d.Hout = d.up ? 2 * d.Hin : d.Hin;
-            d.Wout = d.up ? 2 * d.Win : d.Win;
-            d.Cout = Cin;
-            d.w = pkb + P->params[o.w].packed_bwd_off;
-            d.dst = tmp;
-            d.x3 = P->x3;
-        d.f16 = P->dtype == DMME_F16;  // (launchers without a dtype argument: conv1x1_as, the thin output conv)
-            d.f16 = P->dtype == DMME_F16;  // (launchers without a dtype argument: conv1x1_as, the thin output conv)
-            if (P->splitk_floats > 0) {
-                d.splitk = (float*)(ws + P->ws_splitk);
-                d.splitk_cap = P->splitk_floats;
-            }
-            const Tensor& t1 = P->tensors[o.src1];
-            char* g1 = gptr(o.src1);
-            char* g2 = o.src2 >= 0 ? gptr(o.src2) : nullptr;
-            const char* extra = nullptr;  // a waiting residual branch of the source: taken along by the GroupNorm backward below
-            if (pending[o.src1]) {
-                if (o.gn >= 0 && o.src2 < 0 && gn_bwd_fast_supported(dt, t1.H * t1.W, a.C1, a.C2)) {
-                    extra = pending[o.src1];
-                    pending[o.src1] = nullptr;
-                } else {
-                    rc = flush_pending(o.src1);
-                    if (rc != DMME_OK) break;
-                }
-            }
-            if (o.src2 >= 0) {
-                rc = flush_pending(o.src2);
-                if (rc != DMME_OK) break;
-            }
-            const int acc1 = claim(o.src1), acc2 = o.src2 >= 0 ? claim(o.src2) : 0;
-            // a conv with no norm in front of it, one source and no fused upsample: its data gradient IS the source's gradient -
-            // written (or, through the epilogue's residual input, accumulated in place: each vector is read and written by one thread)
-            // straight into that buffer instead of a scratch tensor plus an accumulation launch
-            const bool direct_off = getenv("DMME_NO_DGRAD_DIRECT") != nullptr;
-            const bool dgrad_direct = !direct_off && o.gn < 0 && o.src2 < 0 && o.up != 1;
-            if (dgrad_direct) {
-                d.dst = g1;
-                if (acc1) {
-                    d.res1 = g1;
-                    d.R1 = Cin;
-                }
-            }
-            rc = run_any_conv(dt, d, s);
-            if (rc != DMME_OK) break;
-
-            if (o.gn >= 0) {
-                const Op& gop = P->ops[o.gn];
-                GnMod mod{};
-                if (gop.gn_mod_col >= 0) {  // scale-shift conditioning: effective gamma + gradients of the (shift | scale) projection rows
-                    mod.t_scale = (const float*)(ws + P->ws_tproj) + gop.gn_mod_col + gop.gn_mod_C;
-                    mod.beta = (const float*)(pk + P->params[gop.gn_beta].packed_off);
-                    mod.d_shift = dtproj + gop.gn_mod_col;
-                    mod.d_scale = dtproj + gop.gn_mod_col + gop.gn_mod_C;
-                    mod.ld = P->tproj_cols;
-                    mod.nt = nt;
-                }
-                if (gn_bwd_fast_supported(dt, t1.H * t1.W, a.C1, a.C2))
-                    rc = launch_gn_bwd_fast(dt, tmp, a.src1, a.src2, B, t1.H * t1.W, a.C1, a.C2, G,
-                                            (const float*)(pk + P->params[gop.gn_gamma].packed_off), (const float*)(ws + gop.gn_mr), a.scale,
-                                            a.shift, a.dmask, a.pro_silu, g1, g2, acc1, acc2, grad_flat + P->params[gop.gn_gamma].ref_off,
-                                            grad_flat + P->params[gop.gn_beta].ref_off, (float*)(bws + o.b_ab), (float*)(bws + P->bws_gnS), mod, s,
-                                            o.wg_act >= 0 ? bws + o.wg_act : nullptr,
-                                            o.gn_rows_deferred && P->bias_jobs_dev ? (float*)(bws + o.b_gnrows) : nullptr, extra);
-                else
-                rc = launch_gn_bwd_generic(dt, tmp, a.src1, a.src2, B, t1.H * t1.W, a.C1, a.C2, G,
-                                           (const float*)(pk + P->params[gop.gn_gamma].packed_off), (const float*)(ws + gop.gn_mr),
-                                           a.scale, a.shift, a.dmask, a.pro_silu, g1, g2, acc1, acc2,
-                                           grad_flat + P->params[gop.gn_gamma].ref_off, grad_flat + P->params[gop.gn_beta].ref_off, mod, s);
-            } else if (!dgrad_direct) {
-                rc = launch_grad_acc(dt, tmp, g1, g2, a.C1, a.C2, acc1, acc2, o.up == 1 ? 1 : 0, B, t1.H, t1.W, s);
-            }
-            if (rc != DMME_OK) break;
-        }
-        if (o.src1 == -2 && d_x) {  // gradient with respect to the network input (NCHW fp32), only on request
-            ConvArgs d{};
-            d.src1 = dy;
-            d.C1 = a.Cout;
-            d.N = B;
-            d.Hin = d.Hout = a.Hout;
-            d.Win = d.Wout = a.Wout;
-            d.stride = 1;
-            d.taps = o.taps;
-            d.Cout = Cin;
-            d.w = pkb + P->params[o.w].packed_bwd_off;
-            d.dst = d_x;
-            d.out_nchw = 1;
-            d.x3 = P->x3;
-        d.f16 = P->dtype == DMME_F16;  // (launchers without a dtype argument: conv1x1_as, the thin output conv)
-            d.f16 = P->dtype == DMME_F16;  // (launchers without a dtype argument: conv1x1_as, the thin output conv)
-            rc = conv_mfma_supported(dt, d) ? launch_conv_mfma(dt, d, s) : launch_conv_generic(dt, d, s);
-            if (rc != DMME_OK) break;
-        }
-        // 4. residual branch: d(res) += dY
-        if (o.res1 >= 0 && o.res_alias) {
-            written[o.res1] = 1;  // (its gradient buffer is dY itself)
-        } else if (o.res1 >= 0) {
-            const int R1 = P->tensors[o.res1].C;
-            if (!res_extra_off && o.res2 < 0 && R1 == a.Cout && o.dst >= 0) {
-                rc = flush_pending(o.res1);  // (one waiting branch per tensor)
-                pending[o.res1] = dy;
-            } else {
-                const int acc1 = claim(o.res1), acc2 = o.res2 >= 0 ? claim(o.res2) : 0;
-                rc = launch_grad_acc(dt, dy, gptr(o.res1), o.res2 >= 0 ? gptr(o.res2) : nullptr, R1, a.Cout - R1, acc1, acc2, 0, B,
-                                     a.Hout, a.Wout, s);
-            }
-        }
-    }
-    for (int id = 0; id < (int)pending.size() && rc == DMME_OK; ++id) rc = flush_pending(id);
-    if (rc != DMME_OK) return rc;
-    rc = flush(buckets ? (int)P->gb.size() - 1 : -1);
-    if (rc != DMME_OK) return rc;
-
-    // ---- time MLP backward (models/ddpm.py:211-217 and the per-block Linear at :101-104) ----
-    const float* h1 = (const float*)(ws + P->ws_th1);
-    const float* esin = (const float*)(ws + P->ws_tsin);
-    float* dtemb = (float*)(bws + P->bws_dtemb);
-    float* dh1 = (float*)(bws + P->bws_dh1);
-    float* z = (float*)(bws + P->bws_z);
-    // input gradients of the Linears as NT GEMMs against a transposed copy of the weights (K contiguous in both operands)
-    char* wT = bws + P->bws_wT;
-    rc = launch_transpose(dt, pk + P->tproj_w_off, tc, emb, wT, s);
-    if (rc == DMME_OK) rc = launch_small_gemm(dt, 0, dtproj, tc, wT, tc, nt, emb, tc, nullptr, 0, dtemb, emb, s);
-    if (rc != DMME_OK) return rc;
-    // temb = silu(z2), z2 = h1 W2^T + b2
-    // (the forward kept both pre-activations when it ran at a training batch: no recompute GEMMs here)
-    const bool saved_pre = nt > 4 && P->ws_tz1 >= 0 && P->ws_tz2 >= 0 && !getenv("DMME_NO_TIME_PRE");
-    if (saved_pre)
-        z = (float*)(ws + P->ws_tz2);
-    else
-        rc = launch_small_gemm(dt, 0, h1, emb, pk + P->params[P->p_l2w].packed_off, emb, nt, emb, emb, (const float*)(pk + P->params[P->p_l2b].packed_off), 0, z, emb, s);
-    if (rc == DMME_OK) rc = launch_silu_bwd(dtemb, z, nt * emb, s);
-    if (rc == DMME_OK) rc = launch_small_gemm(dt, 2, dtemb, emb, h1, emb, emb, emb, nt, nullptr, 0, grad_flat + P->params[P->p_l2w].ref_off, emb, s);
-    if (rc == DMME_OK) rc = launch_nsum(dtemb, nt, emb, emb, 1, grad_flat + P->params[P->p_l2b].ref_off, s);
-    if (rc == DMME_OK) rc = launch_transpose(dt, pk + P->params[P->p_l2w].packed_off, emb, emb, wT, s);
-    if (rc == DMME_OK) rc = launch_small_gemm(dt, 0, dtemb, emb, wT, emb, nt, emb, emb, nullptr, 0, dh1, emb, s);
-    // h1 = silu(z1), z1 = e W1^T + b1
-    if (saved_pre)
-        z = (float*)(ws + P->ws_tz1);
-    else if (rc == DMME_OK)
-        rc = launch_small_gemm(dt, 0, esin, pos, pk + P->params[P->p_l1w].packed_off, pos, nt, emb, pos, (const float*)(pk + P->params[P->p_l1b].packed_off), 0, z, emb, s);
-    if (rc == DMME_OK) rc = launch_silu_bwd(dh1, z, nt * emb, s);
-    if (rc == DMME_OK) rc = launch_small_gemm(dt, 2, dh1, emb, esin, pos, emb, pos, nt, nullptr, 0, grad_flat + P->params[P->p_l1w].ref_off, pos, s);
-    if (rc == DMME_OK) rc = launch_nsum(dh1, nt, emb, emb, 1, grad_flat + P->params[P->p_l1b].ref_off, s);
-    if (rc == DMME_OK && buckets) hand_over((int)P->gb.size() - 1);
-    return rc;
-}
-
-DMME_API int dmme_unet_backward(const dmme_plan* plan, const void* packed, const void* packed_bwd, const float* x,
-                                const int64_t* t, int t_len, const float* d_y, void* workspace, void* bwd_workspace,
-                                const float* drop_masks, float* grad_flat, float* d_x, void* stream) {
-    return backward_impl(plan, packed, packed_bwd, x, t, t_len, d_y, workspace, bwd_workspace, drop_masks, grad_flat, d_x, stream, nullptr, nullptr);
-}
-
-DMME_API int dmme_unet_backward_buckets(const dmme_plan* plan, const void* packed, const void* packed_bwd, const float* x,
-                                        const int64_t* t, int t_len, const float* d_y, void* workspace, void* bwd_workspace,
-                                        const float* drop_masks, float* grad_flat, float* d_x, void* stream, dmme_bucket_fn ready, void* user) {
-    DMME_REQUIRE(ready, DMME_ERR_INVALID, "unet_backward_buckets: null callback");
-    return backward_impl(plan, packed, packed_bwd, x, t, t_len, d_y, workspace, bwd_workspace, drop_masks, grad_flat, d_x, stream, ready, user);
-}
-
-DMME_API int dmme_unet_plan_grad_buckets(const dmme_plan* plan, int64_t* offsets, int64_t* numels, int* bucket_of, int cap) {
-    DMME_REQUIRE(plan && offsets && numels && cap > 0, DMME_ERR_INVALID, "grad_buckets: bad argument");
-    if (plan->gb.empty()) {  // no clean cut for this configuration: one piece
-        offsets[0] = 0;
-        numels[0] = plan->ref_numel;
-        if (bucket_of) bucket_of[0] = 0;
-        return 1;
-    }
-    int n = 0;
-    for (size_t b = 0; b < plan->gb.size(); ++b)
-        for (const auto& r : plan->gb[b].ranges) {
-            if (n < cap) {
-                offsets[n] = r.first;
-                numels[n] = r.second;
-                if (bucket_of) bucket_of[n] = (int)b;
-            }
-            ++n;
-        }
-    return n;
-}
-
-/* Which kernels a backward of this plan launches, as "key=value" pairs: the grouped weight-gradient layers / jobs per kernel
- * size, the grouped column-sum and bias jobs, and how many DATA-gradient convolutions run on each forward kernel (by label).
- * Lets a parity test assert that a configuration really exercises the kernels it is meant to cover. */
-DMME_API int dmme_unet_plan_bwd_summary(const dmme_plan* plan, char* buf, int cap) {
-    DMME_REQUIRE(plan && buf && cap > 0, DMME_ERR_INVALID, "bwd_summary: bad argument");
-    const dmme_plan* P = plan;
-    std::string out;
-    char tmp[256];
-    snprintf(tmp, sizeof(tmp), "wgrad_group3x3_layers=%d wgrad_group3x3_jobs=%d wgrad_group1x1_layers=%d wgrad_group1x1_jobs=%d colsum_group_jobs=%d bias_group_jobs=%d",
-             (int)P->wg[0].layers.size(), (int)P->wg[0].jobs.size(), (int)P->wg[1].layers.size(), (int)P->wg[1].jobs.size(), (int)P->col_jobs.size(),
-             (int)P->bias_jobs.size());
-    out = tmp;
-    std::unordered_map<std::string, int> dgrad;
-    for (const Op& o : P->ops) {
-        if (o.kind != OP_CONV || o.src1 < 0) continue;
-        ConvArgs a{};
-        fill_conv(P, o, (const char*)4096, (const float*)4096, (float*)4096, (char*)4096, nullptr, 1, a);
-        ConvArgs d{};
-        d.src1 = (const void*)4096;
-        d.C1 = a.Cout;
-        d.N = P->B;
-        d.Hin = a.Hout;
-        d.Win = a.Wout;
-        d.up = o.stride == 2 ? 2 : 0;
-        d.stride = 1;
-        d.taps = o.taps;
-        d.Hout = d.up ? 2 * d.Hin : d.Hin;
-        d.Wout = d.up ? 2 * d.Win : d.Win;
-        d.Cout = a.C1 + a.C2;
-        d.w = (const void*)4096;
-        d.dst = (void*)4096;
-        d.x3 = P->x3;
-        d.f16 = P->dtype == DMME_F16;  // (launchers without a dtype argument: conv1x1_as, the thin output conv)
-        if (P->splitk_floats > 0) {
-            d.splitk = (float*)4096;
-            d.splitk_cap = P->splitk_floats;
-        }
-        char label[128] = "generic";
-        if (conv1x1_pipe_supported(P->dtype, d))
-            conv1x1_pipe_label(P->dtype, d, label, sizeof(label));
-        else if (conv_pipe_supported(P->dtype, d))
-            conv_pipe_label(P->dtype, d, label, sizeof(label));
-        else if (conv_mfma_supported(P->dtype, d))
-            conv_mfma_label(P->dtype, d, label, sizeof(label));
-        dgrad[label] += 1;
-    }
-    for (const auto& kv : dgrad) {
-        snprintf(tmp, sizeof(tmp), " dgrad[%s]=%d", kv.first.c_str(), kv.second);
-        out += tmp;
-    }
-    strncpy(buf, out.c_str(), (size_t)cap - 1);
-    buf[cap - 1] = 0;
-    return DMME_OK;
-}
-
 DMME_API int dmme_grad_norm(const float* grad, int64_t numel, float* norm_out, float* scratch, void* stream) {
     DMME_REQUIRE(grad && norm_out && scratch && numel > 0, DMME_ERR_INVALID, "grad_norm: bad argument");
     return launch_grad_norm(grad, numel, norm_out, scratch, (hipStream_t)stream);
@@ -2866,12 +1776,6 @@ DMME_API int dmme_debug_l2_stream(const void* buf, int64_t bytes, int iters, int
     return launch_l2_stream(buf, bytes, iters, mode, depth, blocks, (unsigned*)sink, (hipStream_t)stream);
 }
 
-DMME_API int dmme_debug_level_stamps(void* buf, int run, int workgroup) {
-    g_lvl_stamps = (long long*)buf;
-    g_lvl_stamp_run = run;
-    g_lvl_stamp_wg = workgroup;
-    return DMME_OK;
-}
 static long long* g_stamps = nullptr;
 DMME_API int dmme_debug_set_stamps(void* buf) {
     g_stamps = (long long*)buf;

@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(256) small_gemm_mfma_kernel(const float* __res
 }
 
 static bool sg_mfma() {
-    const bool off = getenv("DMME_NO_SMALL_GEMM_MFMA") != nullptr;
+    const bool off = (debug_route("no_small_gemm_mfma") != 0);
     return !off;
 }
 

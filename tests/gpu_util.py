@@ -98,3 +98,42 @@ def attention(dt, qkv_nsc, force_generic=False):
     out = torch.empty((N, S, C3 // 3), dtype=TD[dt], device=q.device)
     _lib.check(_lib.lib().dmme_attention(dt, _lib.ptr(q), N, S, C3 // 3, _lib.ptr(out), int(force_generic), _lib.stream_ptr()), "dmme_attention")
     return out.to(torch.float32)
+
+
+# ---- A/B route switches ------------------------------------------------------------------------------------------------------------
+# The library reads a dozen documented product switches as environment variables of their own; every other
+# experiment / comparison route lives behind ONE variable, DMME_DEBUG_ROUTE="key[=int],...".  Tests name all of them the historical
+# way (DMME_NO_WS128, DMME_LVL_MASK=4, ...); this context manager sets each the way the library reads it.
+PRODUCT_SWITCHES = {"DMME_NO_LVL", "DMME_NO_WS", "DMME_NO_KW", "DMME_NO_CONV1X1_AS", "DMME_NO_FUSED_GN", "DMME_NO_GN_IN", "DMME_NO_GN_DIRECT", "DMME_NO_PREACT",
+                    "DMME_NO_CONV_THIN", "DMME_NO_ATTN_FULL", "DMME_NO_WGRAD_GROUP", "DMME_NO_GN_BWD_REGS", "DMME_NO_GRAD_BUCKETS"}
+
+
+class route_env:
+    def __init__(self, kv):
+        self.kv = dict(kv) if not isinstance(kv, str) else {kv: "1"}
+
+    def __enter__(self):
+        import os
+
+        self._saved_route = os.environ.get("DMME_DEBUG_ROUTE")
+        keys = [] if not self._saved_route else [self._saved_route]
+        self._set = []
+        for k, v in self.kv.items():
+            if k in PRODUCT_SWITCHES or not k.startswith("DMME_"):
+                os.environ[k] = str(v)
+                self._set.append(k)
+            else:
+                keys.append(k[5:].lower() + ("" if str(v) == "1" else f"={v}"))
+        if keys:
+            os.environ["DMME_DEBUG_ROUTE"] = ",".join(keys)
+        return self
+
+    def __exit__(self, *a):
+        import os
+
+        for k in self._set:
+            os.environ.pop(k, None)
+        if self._saved_route is None:
+            os.environ.pop("DMME_DEBUG_ROUTE", None)
+        else:
+            os.environ["DMME_DEBUG_ROUTE"] = self._saved_route

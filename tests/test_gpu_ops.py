@@ -204,12 +204,11 @@ def test_attention(case, dtname):
         # and the online-softmax kernel behind them are selected per launch by environment switches
         import os
 
+        from tests.gpu_util import route_env
+
         for env in ("DMME_NO_ATTN_SPLIT", "DMME_NO_ATTN_FULL"):
-            os.environ[env] = "1"
-            try:
+            with route_env({env: "1"}):
                 got = G.attention(dt, qkv.cuda(), False).cpu()
-            finally:
-                os.environ.pop(env, None)
             err = (got - want).abs().max().item()
             print(f"attention {case} {dtname} {env}: err {err:.3e} (tol {tol:.3e})")
             assert err <= tol, f"attention {case} {dtname} {env}: {err:.3e} > {tol:.3e}"

@@ -1,4 +1,5 @@
-"""-m gpu: every A/B route switch the library still reads selects a kernel route, never a CPU path - and no route
+"""-m gpu: every A/B route switch the library still reads (a dozen product switches as variables of their own, the rest as
+keys of DMME_DEBUG_ROUTE - tests/gpu_util.py: route_env translates the historical names) selects a kernel route, never a CPU path - and no route
 may rot: each switch is set, a fresh plan is built (the switches are read when a plan is built or a kernel is launched) and the default
 UNet is held against the default route on the same inputs - the forward switches at the benchmark batch against the reference's golden
 rows as well, the backward switches through the flat gradient of one training step."""
@@ -52,16 +53,7 @@ BACKWARD = ["DMME_NO_WG_ACT", "DMME_NO_WG_DMA", "DMME_NO_WG_S2", "DMME_NO_WGRAD_
             "DMME_NO_BIAS_GROUP", "DMME_NO_WGRAD_THIN", "DMME_NO_TIME_PRE", "DMME_NO_SMALL_GEMM_MFMA", "DMME_NO_LVL"]
 
 
-class _env:
-    def __init__(self, kv):
-        self.kv = kv
-
-    def __enter__(self):
-        os.environ.update(self.kv)
-
-    def __exit__(self, *a):
-        for k in self.kv:
-            os.environ.pop(k, None)
+from tests.gpu_util import route_env as _env  # (sets product switches as variables, everything else as DMME_DEBUG_ROUTE keys)
 
 
 @pytest.fixture(scope="module")

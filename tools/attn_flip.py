@@ -22,7 +22,7 @@ with torch.no_grad():
         os.environ.pop("DMME_NO_ATTN_FULL", None)
         c = []
         for lvl in ("1", "2", "3", "4"):
-            os.environ["DMME_ATTN_SLEEP"] = lvl
+            os.environ["DMME_DEBUG_ROUTE"] = "attn_sleep=" + lvl
             c.append(run(100))
-        os.environ.pop("DMME_ATTN_SLEEP", None)
+        os.environ.pop("DMME_DEBUG_ROUTE", None)
         print(f"round {rnd}: whole-row kernel {a:.4f} ms / forward, online kernel {b:.4f}, whole-row with s_sleep 2 / 4 / 8 / 16 per tile: " + " ".join(f"{v:.4f}" for v in c))

@@ -617,8 +617,27 @@ __global__ void pack_weight_kernel(const float* src, int Cin, int taps, T* dst, 
         dst[e] = from_f<T>(src[(r * Cin + ci) * taps + tap]);
     }
 }
+// ... split halves for the three-pass fp16 kernels: [Cout][taps][Cin / 32][hi 32 | lo 32] (as pack_table_kernel's code 4)
+__global__ void pack_weight_split_kernel(const float* src, int Cin, int taps, f16* dst, int64_t total) {
+    const int64_t row = (int64_t)Cin * taps;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / row, rem = e % row;
+        const int tap = (int)(rem / Cin), ci = (int)(rem % Cin);
+        const float w = src[(r * Cin + ci) * taps + tap];
+        const f16 hi = (f16)w;
+        f16* o = dst + (r * taps + tap) * (2 * (int64_t)Cin) + (ci >> 5) * 64 + (ci & 31);
+        o[0] = hi;
+        o[32] = (f16)(w - (float)hi);
+    }
+}
 int launch_pack_weight(int dtype, const float* src, int Cout, int Cin, int taps, void* dst, hipStream_t s) {
     const int64_t total = (int64_t)Cout * Cin * taps;
+    if (dtype == DMME_F16R32) {
+        DMME_REQUIRE(Cin % 32 == 0, DMME_ERR_INVALID, "pack_weight(fp16r32): whole 32-channel blocks");
+        hipLaunchKernelGGL(pack_weight_split_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, Cin, taps, (f16*)dst, total);
+        DMME_CHECK_LAUNCH();
+        return DMME_OK;
+    }
     if (dtype == DMME_BF16)
         hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, src, Cin, taps, (bf16*)dst, total);
     else if (dtype == DMME_F16)

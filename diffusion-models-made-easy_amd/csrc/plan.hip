@@ -1799,10 +1799,22 @@ DMME_API int dmme_conv2d(const dmme_conv_desc* d, const void* src1, const void* 
     a.pro_silu = d->pro_silu; a.out_silu = d->out_silu; a.nt = d->nt; a.tproj_ld = d->tproj_ld;
     a.in_nchw = d->in_nchw; a.out_nchw = d->out_nchw;
     a.stamps = g_stamps;
-    DMME_REQUIRE(d->dtype == DMME_F32 || d->dtype == DMME_BF16 || d->dtype == DMME_BF16X3 || d->dtype == DMME_F16, DMME_ERR_INVALID, "conv2d: bad dtype %d",
-                 d->dtype);
+    DMME_REQUIRE(d->dtype == DMME_F32 || d->dtype == DMME_BF16 || d->dtype == DMME_BF16X3 || d->dtype == DMME_F16 || d->dtype == DMME_F16R32, DMME_ERR_INVALID,
+                 "conv2d: bad dtype %d", d->dtype);
     a.x3 = d->dtype == DMME_BF16X3;
     a.f16 = d->dtype == DMME_F16;
+    if (d->dtype == DMME_F16R32) {
+        // the split-pass kernels of the mixed mode's fp32 level, as single ops: fp32 tensors (NHWC; the thin output conv writes NCHW),
+        // filter packed by dmme_pack_weight(DMME_F16R32): [Cout][taps][Cin / 32][hi 32 | lo 32] halves.  No fall-back to other kernels.
+        a.mix = a.out_nchw ? 3 : 1;
+        a.f16 = 1;
+        if (a.mix == 3) {
+            DMME_REQUIRE(conv_out_thin_supported(DMME_F16, a), DMME_ERR_UNSUPPORTED, "conv2d(fp16r32): the thin output conv does not take this shape");
+            return launch_conv_out_thin(a, (hipStream_t)stream);
+        }
+        DMME_REQUIRE(conv_pipe_supported(DMME_F16, a), DMME_ERR_UNSUPPORTED, "conv2d(fp16r32): the split-pass 3x3 kernel does not take this shape");
+        return launch_conv_pipe(DMME_F16, a, (hipStream_t)stream);
+    }
     const int dt = a.x3 ? DMME_F32 : d->dtype;
     if (d->force_generic == 2 && conv_mfma_supported(dt, a)) return launch_conv_mfma(dt, a, (hipStream_t)stream);
     if (!d->force_generic && conv_out_thin_supported(dt, a)) return launch_conv_out_thin(a, (hipStream_t)stream);

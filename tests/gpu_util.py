@@ -7,12 +7,12 @@ import torch
 
 from dmme_amd import _lib
 
-TD = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16, _lib.BF16X3: torch.float32, _lib.F16: torch.float16}
+TD = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16, _lib.BF16X3: torch.float32, _lib.F16: torch.float16, _lib.F16R32: torch.float32}
 
 
 def _st(dt):
     """storage dtype code of a compute dtype (the accurate mode keeps fp32 buffers)"""
-    return _lib.F32 if dt == _lib.BF16X3 else dt
+    return _lib.F32 if dt in (_lib.BF16X3, _lib.F16R32) else dt  # (fp16r32 single ops: the fp32 level's tensors)
 
 
 def dev():
@@ -36,6 +36,10 @@ def to_nchw(x_nhwc, dt):
 
 def pack_w(w_oihw, dt):
     co, ci, k, _ = w_oihw.shape
+    if dt == _lib.F16R32:  # hi / lo halves: [co][taps][ci / 32][hi 32 | lo 32]
+        out = torch.empty((co, k * k, 2 * ci), dtype=torch.float16, device=w_oihw.device)
+        _lib.check(_lib.lib().dmme_pack_weight(dt, _lib.ptr(w_oihw.contiguous()), co, ci, k * k, _lib.ptr(out), _lib.stream_ptr()))
+        return out
     out = torch.empty((co, k * k, ci), dtype=TD[dt], device=w_oihw.device)
     _lib.check(_lib.lib().dmme_pack_weight(_st(dt), _lib.ptr(w_oihw.contiguous()), co, ci, k * k, _lib.ptr(out), _lib.stream_ptr()))
     return out

@@ -144,6 +144,48 @@ def test_output_conv_thin_kernel(shape):
     assert err <= tol and err_gen <= tol, (err, err_gen, tol)
 
 
+R32_CASES = [
+    # (name, N, C1, C2, H, Cout, fused prologue, tproj rows, residual, NCHW 3-cout output conv)
+    ("rb128_32", 3, 128, 0, 32, 128, True, 3, True, False),
+    ("cat256_32_to128", 2, 128, 128, 32, 128, True, 1, False, False),
+    ("plain128_32", 5, 128, 0, 32, 128, False, 0, True, False),
+    ("whole_image_16", 4, 256, 0, 16, 256, True, 4, True, False),
+    ("b130_tiles", 65, 128, 0, 32, 128, True, 65, True, False),  # 260 tiles: workgroups with two tiles and with one
+    ("output3", 2, 128, 0, 32, 3, True, 0, False, True),
+    ("output3_b130", 130, 128, 0, 32, 3, True, 0, False, True),
+]
+
+
+@pytest.mark.parametrize("case", R32_CASES, ids=[c[0] for c in R32_CASES])
+def test_conv_fp16r32_split_pass_kernels_vs_fp64(case):
+    """precision="fp16r32": the kernels of the mode's fp32 level as single ops through the C ABI (dmme_conv2d with dtype
+    DMME_F16R32: fp32 tensors, filter as hi / lo halves) - the wave-specialised 3x3 kernel's split form and the thin output conv's -
+    against the fp64 convolution of the UNROUNDED operands: three fp16 passes leave ~2^-20 of a product (hi.hi + hi.lo + lo.hi), so
+    the bound is 2e-5 of the output's maximum where a single fp16 pass measures 5e-4 and bf16 3e-3."""
+    from dmme_amd import _lib
+    from tests import gpu_util as G
+
+    name, N, C1, C2, H, Cout, pro, ntp, has_res, nchw = case
+    Cin = C1 + C2
+    seed = 777 + sum(ord(ch) for ch in name) % 10000
+    x1 = synth.normal(seed, (N, C1, H, H))
+    x2 = synth.normal(seed + 1, (N, C2, H, H)) if C2 else None
+    w = synth.uniform(seed + 2, (Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)
+    b = synth.uniform(seed + 3, (Cout,)) * 0.1
+    scale = (1 + 0.3 * synth.normal(seed + 4, (N, Cin))) if pro else None
+    shift = 0.2 * synth.normal(seed + 5, (N, Cin)) if pro else None
+    dmask = ((synth.uniform(seed + 6, (N, Cin), 0, 1) < 0.9).float() / 0.9) if (pro and not nchw) else None
+    tproj = 0.3 * synth.normal(seed + 7, (ntp, Cout)) if ntp else None
+    res = synth.normal(seed + 8, (N, Cout, H, H)) if has_res else None
+    ref = _ref_conv(x1, w, b, x2, scale, shift, dmask, tproj, res, 1, False, pro, False, False)
+    cu = lambda t: None if t is None else t.cuda()
+    y = G.conv2d(_lib.F16R32, cu(x1), cu(w), cu(b), cu(x2), cu(scale), cu(shift), cu(dmask), cu(tproj), cu(res), 1, False, pro, False, 0, out_nchw=nchw)
+    torch.cuda.synchronize()
+    err, mx = (y.cpu() - ref).abs().max().item(), ref.abs().max().item()
+    print(f"fp16r32 {name}: max err {err:.3e} of |y|max {mx:.2f} ({err / mx:.2e})")
+    assert err <= 2e-5 * mx, f"{name}: {err:.3e} > {2e-5 * mx:.3e}"
+
+
 GN_CASES = [(3, 128, 0, 32, 32), (2, 256, 256, 8, 32), (2, 128, 128, 16, 32), (5, 256, 0, 4, 32), (2, 8, 4, 16, 2), (3, 16, 0, 8, 2), (2, 256, 0, 16, 32)]
 
 

@@ -1,24 +1,25 @@
 #!/usr/bin/env python3
 """Per-stage cycle stamps of the wave-specialised conv kernel (consumer wave 0 and producer wave 4 of two workgroups).
-usage: python tools/stamp_ws.py 32x128x128 [gn]"""
+usage: python tools/stamp_ws.py 32x128x128 [gn] [r32]   (r32: the split-pass form of precision="fp16r32": fp32 tensors, hi / lo halves)"""
 import ctypes as C, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dmme_amd import _lib
 shp = sys.argv[1] if len(sys.argv) > 1 else "32x128x128"
-gn = len(sys.argv) > 2 and sys.argv[2] == "gn"
+gn = "gn" in sys.argv[2:]
+r32 = "r32" in sys.argv[2:]
 hw, cin, cout = (int(v) for v in shp.split("x"))
 B = 128
 dev = torch.device("cuda:0")
 lib = _lib.lib()
-x = torch.randn(B, hw, hw, cin, device=dev).to(torch.bfloat16)
-w = (torch.randn(cout, 9, cin, device=dev) * 0.05).to(torch.bfloat16)
+x = torch.randn(B, hw, hw, cin, device=dev).to(torch.float32 if r32 else torch.bfloat16)
+w = (torch.randn(cout, 9, (2 if r32 else 1) * cin, device=dev) * 0.05).to(torch.float16 if r32 else torch.bfloat16)
 b = torch.randn(cout, device=dev)
 scale = torch.rand(B, cin, device=dev) + 0.5
 shift = torch.randn(B, cin, device=dev) * 0.1
-out = torch.empty(B, hw, hw, cout, device=dev, dtype=torch.bfloat16)
+out = torch.empty(B, hw, hw, cout, device=dev, dtype=torch.float32 if r32 else torch.bfloat16)
 d = _lib.ConvDesc()
-d.dtype, d.N, d.Hin, d.Win, d.C1, d.C2 = _lib.BF16, B, hw, hw, cin, 0
+d.dtype, d.N, d.Hin, d.Win, d.C1, d.C2 = (_lib.F16R32 if r32 else _lib.BF16), B, hw, hw, cin, 0
 d.upsample, d.stride, d.taps, d.Cout = 0, 1, 9, cout
 d.pro_silu = int(gn)
 d.out_silu = d.nt = d.tproj_ld = d.in_nchw = d.out_nchw = d.force_generic = 0
@@ -28,6 +29,11 @@ def run():
     _lib.check(lib.dmme_conv2d(C.byref(d), _lib.ptr(x), None, _lib.ptr(w), _lib.ptr(b), _lib.ptr(sc), _lib.ptr(sh), None, None, None, None, cout,
                                _lib.ptr(out), st), "conv")
 for _ in range(3): run()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10): run()
+e1.record(); torch.cuda.synchronize()
+print(f"{shp} gn={gn} r32={r32}: {e0.elapsed_time(e1) * 100:.1f} us per launch (event-bracketed, 10 launches)")
 stamps = torch.zeros(8 * 64 + 4096 * 4, dtype=torch.int64, device=dev)
 _lib.check(lib.dmme_debug_set_stamps(_lib.ptr(stamps)))
 run()

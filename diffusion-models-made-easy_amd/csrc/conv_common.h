@@ -542,30 +542,35 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, int co0, 
                 s1a += v[e];
                 s2a = fmaf(v[e], v[e], s2a);
             }
-        } else if constexpr (dtype_of<T>::value == DMME_BF16) {
-            // bf16: pairs (the two halves of an output dword = adjacent channels) through packed fp32 instructions - residual add,
-            // one v_cvt_pk per dword, and the statistics of the ROUNDED values unpacked from the packed dwords (two shifts / masks per
-            // dword) instead of eight single conversions there and back: ~50 instead of ~90 instructions per 16-byte vector, on SIMDs
-            // that should be starting the next tile's MFMAs
+        } else {
+            // 16-bit tensors: pairs (the two halves of an output dword = adjacent channels) through packed fp32 instructions - residual
+            // add, ONE packed conversion per dword (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32), and the statistics of the ROUNDED values
+            // unpacked from the packed dwords (bf16: two shifts / masks per dword; half: two conversions) instead of eight single
+            // conversions there and back: ~50 instead of ~90 instructions per 16-byte vector, on SIMDs that should be starting the next
+            // tile's MFMAs
+            typedef T tx2 __attribute__((ext_vector_type(2)));
+            auto unpack2 = [](unsigned w) __attribute__((always_inline)) -> f32x2 {
+                if constexpr (dtype_of<T>::value == DMME_BF16) return f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+                else return __builtin_convertvector(__builtin_bit_cast(tx2, w), f32x2);
+            };
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
             f32x2 vp[4] = {f32x2{v0[0], v0[1]}, f32x2{v0[2], v0[3]}, f32x2{v1[0], v1[1]}, f32x2{v1[2], v1[3]}};
             if (res) {
                 const uint4 rw = pv ? *pv : *reinterpret_cast<const uint4*>(res + off);
                 const unsigned rd[4] = {rw.x, rw.y, rw.z, rw.w};
 #pragma unroll
-                for (int d = 0; d < 4; ++d) vp[d] = vp[d] + f32x2{__uint_as_float(rd[d] << 16), __uint_as_float(rd[d] & 0xffff0000u)};
+                for (int d = 0; d < 4; ++d) vp[d] = vp[d] + unpack2(rd[d]);
             }
             unsigned ow[4];
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                typedef __bf16 bf16x2_e __attribute__((ext_vector_type(2)));
-                const bf16x2_e pk = {(__bf16)vp[d][0], (__bf16)vp[d][1]};
+                const tx2 pk = {(T)vp[d][0], (T)vp[d][1]};
                 ow[d] = __builtin_bit_cast(unsigned, pk);
             }
             *reinterpret_cast<uint4*>(dst + off) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
 #pragma unroll
             for (int d = 0; d < 4; ++d) {  // statistics of the values the consumer reads back: pair accumulators, folded after the loop
-                const f32x2 x = f32x2{__uint_as_float(ow[d] << 16), __uint_as_float(ow[d] & 0xffff0000u)};
+                const f32x2 x = unpack2(ow[d]);
                 if (d < 2) {
                     q1a = q1a + x;
                     q2a = __builtin_elementwise_fma(x, x, q2a);
@@ -573,27 +578,6 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, int co0, 
                     q1b = q1b + x;
                     q2b = __builtin_elementwise_fma(x, x, q2b);
                 }
-            }
-        } else {
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
-            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            if (res) {
-                typedef typename Vec8<T>::type tx8;
-                const tx8 rv = pv ? __builtin_bit_cast(tx8, *pv) : *reinterpret_cast<const tx8*>(res + off);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
-            }
-            typename Vec8<T>::type o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (T)v[e];
-            *reinterpret_cast<typename Vec8<T>::type*>(dst + off) = o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {  // statistics of the values the consumer reads back (bf16-rounded)
-                const float x0 = (float)o[e], x1 = (float)o[4 + e];
-                s1a += x0;
-                s2a = fmaf(x0, x0, s2a);
-                s1b += x1;
-                s2b = fmaf(x1, x1, s2b);
             }
         }
     };

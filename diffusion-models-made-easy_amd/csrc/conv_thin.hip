@@ -108,8 +108,18 @@ __global__ void __launch_bounds__(256) conv_out_thin_kernel(ConvArgs a, int R) {
                     bf16x8 ahi, alo;
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        const uint4 y4 = prologue_vec<float>(raw[kg][q], a.scale ? par + c0 + 4 * q : nullptr, a.scale ? par + C + c0 + 4 * q : nullptr, nullptr, a.pro_silu);
-                        const f32x4 y = __builtin_bit_cast(f32x4, y4);
+                        // (the prologue in fp32 with the hardware exp2 / rcp, as the 16-bit kernels' prologue_vec16: ~1 ulp each, four orders
+                        // under the three-pass product's own error; the libm expf of prologue_vec<float> made this HBM-bound layer VALU-bound)
+                        f32x4 y = __builtin_bit_cast(f32x4, raw[kg][q]);
+                        if (a.scale) {
+                            const f32x4 sc4 = *reinterpret_cast<const f32x4*>(par + c0 + 4 * q), sh4 = *reinterpret_cast<const f32x4*>(par + C + c0 + 4 * q);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y[e] = fmaf(y[e], sc4[e], sh4[e]);
+                        }
+                        if (a.pro_silu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y[e] = silu_fast(y[e]);
+                        }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const T hv = (T)(in ? y[e] : 0.f);

@@ -210,6 +210,7 @@ struct ConvArgs {
     // product as three fp16 MFMA passes over hi / lo splits of both operands (filter packed [Cout][taps][Cin / 32][hi 32 | lo 32] halves).
     // 0: no; 1: the wave-specialised 3x3 kernel's split form; 2: the same with a 16-bit SOURCE tensor (fp32 residual / output);
     // 3: the thin output conv's split form (fp32 source, NCHW fp32 out)
+    // 4: the 1x1 convs of that level (conv1x1_pipe.hip: conv1x1_split_kernel)
     int mix;
     // 16-bit tensors are IEEE half (precision="fp16") instead of bf16: for the launchers that take no dtype argument
     int f16;

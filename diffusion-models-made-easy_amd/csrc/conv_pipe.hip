@@ -993,7 +993,7 @@ static int pipe_pick(const ConvArgs& a, ConvTile& g) {
 bool conv_pipe_supported(int dtype, const ConvArgs& a) {
     if (a.mix) {
         ConvTile gs{};
-        return dtype == DMME_F16 && ws2s_pick(a, gs);
+        return dtype == DMME_F16 && a.taps == 9 && ws2s_pick(a, gs);
     }
     if (!conv_mfma_supported(dtype, a)) return false;
     if (a.taps != 9 || (a.stride != 1 && a.stride != 2)) return false;

@@ -219,6 +219,26 @@ __global__ void __launch_bounds__(256) conv_in_mfma_kernel(ConvArgs a, int nbloc
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq)
                     *reinterpret_cast<float4*>(o + 8 * gq) = make_float4(acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]);
+                if (a.gn_part) {  // fp32 tensors (a mixed plan's full-resolution level): the same partials, of the stored fp32 values
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        float s = 0.f, ss = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float x = acc[4 * gq + e];
+                            s += x;
+                            ss = fmaf(x, x, ss);
+                        }
+                        s = half_sum(s);
+                        ss = half_sum(ss);
+                        if (r == 0) {
+                            const float mean = s * (1.f / 128.f);
+                            float* po = a.gn_part + (((int64_t)n * a.gn_tiles + (rem >> 5)) * (a.Cout / 4) + ct * 8 + 2 * gq + h) * 2;
+                            po[0] = mean;
+                            po[1] = ss - s * mean;
+                        }
+                    }
+                }
             }
         }
         if constexpr (sizeof(T) == 2) {
@@ -244,7 +264,7 @@ static bool conv_in_mfma_supported(const ConvArgs& a) {
 
 // the first-conv kernel can emit GroupNorm partials of its output: one per 32-pixel block, groups of exactly 4 channels
 bool conv_in_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px) {
-    if (!is16(dtype) || cg != 4 || !conv_in_mfma_supported(a) || (a.Hout * a.Wout) % 32) return false;
+    if (cg != 4 || !conv_in_mfma_supported(a) || (a.Hout * a.Wout) % 32) return false;  // (16-bit and fp32 instances alike)
     *tiles = a.Hout * a.Wout / 32;
     *px = 32;
     return true;

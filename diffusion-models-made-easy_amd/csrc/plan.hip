@@ -350,8 +350,8 @@ int build_plan(dmme_plan* P) {
             rc.src1 = x1; rc.src2 = x2; rc.w = n.rw; rc.b = n.rb; rc.taps = 1;
             rc.dst = new_tensor(n.cout, h, w);
             if (top) {
-                rc.route_f32 = 1;
-                P->params[n.rw].pack_code = 3;
+                rc.mix = 4;
+                P->params[n.rw].pack_code = 4;
             }
             ops.push_back(rc);
             r1 = rc.dst;
@@ -1223,7 +1223,7 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
             if (o.kind != OP_CONV || !(o.mix || o.route_f32)) continue;
             ConvArgs a{};
             fill_conv(P, o, (const char*)4096, (const float*)4096, (float*)4096, (char*)4096, nullptr, 1, a);
-            const bool ok = o.mix == 3 ? conv_out_thin_supported(P->dtype, a) : o.mix ? conv_pipe_supported(P->dtype, a) : true;
+            const bool ok = o.mix == 3 ? conv_out_thin_supported(P->dtype, a) : o.mix == 4 ? conv1x1_pipe_supported(P->dtype, a) : o.mix ? conv_pipe_supported(P->dtype, a) : true;
             if (!ok) {
                 set_error("plan_create: precision fp16r32 has no kernel for the %dx%d conv %d+%d -> %d channels on the %dx%d level (B = %d)", o.taps == 9 ? 3 : 1,
                           o.taps == 9 ? 3 : 1, a.C1, a.C2, a.Cout, a.Hout, a.Wout, B);
@@ -1806,8 +1806,12 @@ DMME_API int dmme_conv2d(const dmme_conv_desc* d, const void* src1, const void* 
     if (d->dtype == DMME_F16R32) {
         // the split-pass kernels of the mixed mode's fp32 level, as single ops: fp32 tensors (NHWC; the thin output conv writes NCHW),
         // filter packed by dmme_pack_weight(DMME_F16R32): [Cout][taps][Cin / 32][hi 32 | lo 32] halves.  No fall-back to other kernels.
-        a.mix = a.out_nchw ? 3 : 1;
+        a.mix = a.out_nchw ? 3 : a.taps == 1 ? 4 : 1;
         a.f16 = 1;
+        if (a.mix == 4) {
+            DMME_REQUIRE(conv1x1_pipe_supported(DMME_F16, a), DMME_ERR_UNSUPPORTED, "conv2d(fp16r32): the split-pass 1x1 kernel does not take this shape");
+            return launch_conv1x1_pipe(DMME_F16, a, (hipStream_t)stream);
+        }
         if (a.mix == 3) {
             DMME_REQUIRE(conv_out_thin_supported(DMME_F16, a), DMME_ERR_UNSUPPORTED, "conv2d(fp16r32): the thin output conv does not take this shape");
             return launch_conv_out_thin(a, (hipStream_t)stream);

@@ -145,12 +145,14 @@ def test_output_conv_thin_kernel(shape):
 
 
 R32_CASES = [
-    # (name, N, C1, C2, H, Cout, fused prologue, tproj rows, residual, NCHW 3-cout output conv)
+    # (name, N, C1, C2, H, Cout, fused prologue, tproj rows, residual, NCHW 3-cout output conv[, kernel size])
     ("rb128_32", 3, 128, 0, 32, 128, True, 3, True, False),
     ("cat256_32_to128", 2, 128, 128, 32, 128, True, 1, False, False),
     ("plain128_32", 5, 128, 0, 32, 128, False, 0, True, False),
     ("whole_image_16", 4, 256, 0, 16, 256, True, 4, True, False),
     ("b130_tiles", 65, 128, 0, 32, 128, True, 65, True, False),  # 260 tiles: workgroups with two tiles and with one
+    ("res1x1_cat256_32", 3, 128, 128, 32, 128, False, 0, False, False, 1),
+    ("res1x1_128_to256_16_res", 4, 128, 0, 16, 256, True, 1, True, False, 1),
     ("output3", 2, 128, 0, 32, 3, True, 0, False, True),
     ("output3_b130", 130, 128, 0, 32, 3, True, 0, False, True),
 ]
@@ -165,12 +167,13 @@ def test_conv_fp16r32_split_pass_kernels_vs_fp64(case):
     from dmme_amd import _lib
     from tests import gpu_util as G
 
-    name, N, C1, C2, H, Cout, pro, ntp, has_res, nchw = case
+    name, N, C1, C2, H, Cout, pro, ntp, has_res, nchw = case[:10]
+    k = case[10] if len(case) > 10 else 3
     Cin = C1 + C2
     seed = 777 + sum(ord(ch) for ch in name) % 10000
     x1 = synth.normal(seed, (N, C1, H, H))
     x2 = synth.normal(seed + 1, (N, C2, H, H)) if C2 else None
-    w = synth.uniform(seed + 2, (Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)
+    w = synth.uniform(seed + 2, (Cout, Cin, k, k)) / np.sqrt(Cin * k * k)
     b = synth.uniform(seed + 3, (Cout,)) * 0.1
     scale = (1 + 0.3 * synth.normal(seed + 4, (N, Cin))) if pro else None
     shift = 0.2 * synth.normal(seed + 5, (N, Cin)) if pro else None

@@ -119,6 +119,7 @@ PROTOTYPES = {
     "dmme_iddpm_step": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _i, _i, _i64, _vp]),
     "dmme_iddpm_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _f, _vp, _vp, _f, _vp, _vp]),
     "dmme_conv2d": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "dmme_conv2d_res": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "dmme_groupnorm_scale_shift": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _i, _vp]),
     "dmme_attention": (_i, [_i, _vp, _i, _i, _i, _vp, _i, _vp]),
     "dmme_attention_heads": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),

@@ -226,6 +226,14 @@ struct ConvArgs {
     const float* act_dmask;  // [N][gno[act_k].C] or null
     GnIn gni;                 // has_gni: scale / shift come from gni's partials (the arrays are outputs of this conv, not inputs)
     int has_gni;
+    // second K segment (r_w null: none; the wave-specialised 3x3 kernel's 256-pixel form only): the ResBlock's 1x1 residual conv
+    // (models/ddpm.py:108-111,131) over the block's RAW input [.., r_C1] ++ [.., r_C2], filter [Cout][r_C1 + r_C2], bias [Cout] -
+    // accumulated into the same output tile, so `h + residual(x)` needs no residual tensor (res1 is null then)
+    const void* r_src1;
+    const void* r_src2;
+    const void* r_w;
+    const float* r_bias;
+    int r_C1, r_C2;
 };
 
 // ---- kernel launchers (defined in the .hip files) ------------------------------------
@@ -242,6 +250,8 @@ int launch_conv_mfma(int dtype, const ConvArgs& a, hipStream_t s);
 void conv_mfma_label(int dtype, const ConvArgs& a, char* buf, int cap);
 // software-pipelined 3x3 stride-1 variant (conv_pipe.hip); preferred when it applies
 bool conv_pipe_supported(int dtype, const ConvArgs& a);
+// can the wave-specialised kernel take this conv WITH the residual segment described in a.r_* (ConvArgs::r_w)?
+bool conv_pipe_rseg_supported(int dtype, const ConvArgs& a);
 // would this conv run on the wave-specialised kernel, and can that kernel merge its norm's partials itself (ConvArgs::gni)?
 bool conv_gn_in_query(int dtype, const ConvArgs& a);
 int launch_conv_pipe(int dtype, const ConvArgs& a, hipStream_t s);

@@ -484,6 +484,7 @@ __device__ __forceinline__ void conv_epilogue_stage(const ConvArgs& a, f32x16 (&
         float fold = 0.f;
         if (co < a.Cout) {
             fold = a.bias ? a.bias[co] : 0.f;
+            if (a.r_bias) fold += a.r_bias[co];  // (the residual segment's 1x1 conv)
             if (a.tproj && with_trow) fold += a.tproj[(a.nt == 1 ? 0 : n0) * a.tproj_ld + co];
         }
 #pragma unroll
@@ -566,6 +567,8 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, int co0, 
             for (int d = 0; d < 4; ++d) {
                 const tx2 pk = {(T)vp[d][0], (T)vp[d][1]};
                 ow[d] = __builtin_bit_cast(unsigned, pk);
+                // (half: keeps the compiler from re-deriving the rounded values with single conversions from the fp32 inputs)
+                if constexpr (dtype_of<T>::value == DMME_F16) asm volatile("" : "+v"(ow[d]));
             }
             *reinterpret_cast<uint4*>(dst + off) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
 #pragma unroll

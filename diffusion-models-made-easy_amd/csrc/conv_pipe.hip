@@ -441,9 +441,23 @@ template <typename T>
 struct WsSplit<T, 2> {
     typedef float ts;
 };
-template <int PIPE_UA, typename T = bf16, int BM = 256, int SPLIT = 0>
+// RSEG (ConvArgs::r_w): a second K segment behind the nine taps of every tile - the ResBlock's 1x1 residual conv (models/ddpm.py:108-111,131)
+// over the block's RAW input (one or two source tensors), accumulated into the same tile: `h + residual(x)` without the residual tensor,
+// its launch, its write and its read-back.  Raw input needs no prologue and no halo, so the segment costs the producers no register and
+// no VALU instruction: it runs in HALF-stages of 32 input channels whose operands both arrive by LDS-DMA - the tile's BM pixels x 32
+// channels (16 / 8 KB, rows of 64 bytes, XOR-swizzled on the source address) and the filter block 128 couts x 32 channels (8 KB) - three
+// slots deep at first, five once the main loop is through (a half-stage is ~600 cycles, a request under load ~2.4 k from issue to landed).
+// While a tile's last main chunk runs, A0 (free then: the next tile's first chunk normally trickles into it) and R0 (free after tap 6)
+// take the first two slots; R2 / R1 / A1 the others once the last tap has been read:
+//   pixel slots:  A0[0:16K], A0[16K:32K], R2, A1[0:16K], A1[16K:32K] (half of that on 128-pixel tiles)
+//   filter slots: R0[0:8K], R0[8K:16K], R1[0:8K], R1[8K:16K], A1 behind its two pixel slots
+// The next tile's first chunk, which the main loop would have stored into A0 during those nine stages, is activated IN its registers
+// instead and written in the segment's last stage (a stage that reads neither slot 0 nor 1, or nothing: one empty stage is appended
+// where the count does not work out), together with the request for the next tile's tap 0 and second chunk.
+template <int PIPE_UA, typename T = bf16, int BM = 256, int SPLIT = 0, bool RSEG = false>
 __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTile g, int shTW, int shTH, int ntiles) {
     constexpr int KC = 64, EPV = 8, BN = 128, MI = BM / 64, NI = 2, UB = BN / 32;
+    static_assert(!RSEG || (SPLIT == 0 && sizeof(T) == 2), "residual segment: 16-bit tensors");
     constexpr int KCR = SPLIT ? 32 : KC;  // input channels per chunk (KC = 16-bit k-slots per 128-byte row)
     constexpr int EPR = SPLIT ? 4 : EPV;  // input channels per producer lane and halo unit
     typedef typename WsSplit<T, SPLIT>::ts TS;
@@ -469,6 +483,13 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
     const bool producer = wave >= 4;
     const int nchunks = Cin / KCR;
     const int CinW = SPLIT ? 2 * Cin : Cin;  // k-slots per (cout, tap) row of the packed filter
+    const int Cres = RSEG ? a.r_C1 + a.r_C2 : 0;
+    const int HS = Cres / 32;                                   // half-stages of the residual segment
+    constexpr int RSL = 5;                                      // slots (half-stage j uses slot j % RSL)
+    const int RT = HS + ((RSEG && (HS - 1) % RSL < 2) ? 1 : 0);  // ... and the empty stage that lets the last one leave A0 / R0 alone
+    /* pixel slot k (BM rows x 64 B): 0, 1 in A0, 2 = R2, 3, 4 in A1;  filter slot k (128 rows x 64 B): 0, 1 = R0, 2, 3 = R1, 4 behind A1's pixel slots */
+#define WS_RSA(k) ((k) < 2 ? lds + (k) * (BM * 64) : (k) == 2 ? lds + offR + 2 * R_BYTES : lds + offA1 + ((k) - 3) * (BM * 64))
+#define WS_RSW(k) ((k) < 4 ? lds + offR + (k) * 8192 : lds + offA1 + 2 * (BM * 64))
     const int K = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;  // tiles of this workgroup
     const bool has_pro = a.scale || a.pro_silu || a.dmask;
     // scale / shift / mask of tile kt's image -> parameter buffer kt & 1 (all 512 threads).  Tiles 0 and 1 here; tile kt + 2
@@ -541,14 +562,15 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         for (int i = 0; i < PIPE_UA; ++i) a_sw[i] = (urow + 32 * i) * A_PITCH + cu * (SPLIT ? 8 : 16);  // (SPLIT: the hi half; lo 64 bytes on)
 #pragma unroll
         for (int k4 = 0; k4 < UB; ++k4) b_vo[k4] = (unsigned)(((urow + 32 * k4) * 9 * CinW + (cu ^ ((urow >> 1) & 7)) * EPV) * 2);
-        auto set_pix = [&](int i, const TileXY& t) __attribute__((always_inline)) {
+        auto pix_unit = [&](int i, const TileXY& t) __attribute__((always_inline)) -> int {
             const int row = urow + 32 * i;
             const int hy = (int)__umulhi((unsigned)row, g.magic_w), hx = row - hy * g.HWd;
             const int iy = t.oy0 - 1 + hy, ix = t.ox0 - 1 + hx;
             const bool in = iy >= 0 && iy < Hv && ix >= 0 && ix < Wv && !(a.up == 2 && ((iy | ix) & 1));
             const int sy = a.up ? (iy >> 1) : iy, sx = a.up ? (ix >> 1) : ix;
-            a_pix[i] = row >= g.a_rows ? -2 : in ? (t.n0 * a.Hin + sy) * a.Win + sx : -1;
+            return row >= g.a_rows ? -2 : in ? (t.n0 * a.Hin + sy) * a.Win + sx : -1;
         };
+        auto set_pix = [&](int i, const TileXY& t) __attribute__((always_inline)) { a_pix[i] = pix_unit(i, t); };
         const char* wbase = (const char*)a.w;
         u32x4 areg[PIPE_UA];
         // this lane's 8 channels of the four parameter rows, as the pairs (2 d, 2 d + 1) the dwords of a halo vector hold: every
@@ -564,9 +586,10 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
                 pH2[d] = *reinterpret_cast<const f32x2*>(p + 3 * Cin + 2 * d);
             }
         };
-        auto load_A = [&](int i, int c0) __attribute__((always_inline)) {
-            const bool second = c0 >= a.C1;
+        auto load_A = [&](int i, int ch) __attribute__((always_inline)) {  // halo vector of 64-channel chunk `ch`
             constexpr int SB = SPLIT == 1 ? 4 : 2;  // bytes per source element
+            const int c0 = ch * KCR;
+            const bool second = c0 >= a.C1;
             const char* sbase = (const char*)(second ? a.src2 : a.src1) + (size_t)((second ? c0 - a.C1 : c0) * SB);
             const int Cs = second ? a.C2 : a.C1;
             const int px = a_pix[i] < 0 ? 0 : a_pix[i];
@@ -578,7 +601,10 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
                 areg[i] = *reinterpret_cast<const u32x4*>(gp);
             }
         };
-        auto store_A = [&](int i, char* dstA) __attribute__((always_inline)) {
+        // mode 0: prologue + write to LDS; 1 (RSEG, a tile's last chunk): prologue only, the activated vector stays in its register;
+        // 2: write only (the segment's last stage)
+        auto store_A = [&](int i, char* dstA, int mode = 0) __attribute__((always_inline)) {
+            const int pix = a_pix[i], sw = a_sw[i];
             u32x4 val = areg[i];
             if constexpr (SPLIT != 0) {
                 // four channels: prologue in packed fp32 (as below), then hi = f16(y), lo = f16(y - hi) -> 8 bytes each into the row's halves
@@ -613,14 +639,14 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
                         lo[2 * d + k] = (f16)(y[d][k] - (float)hv);
                     }
                 uint2 hw = __builtin_bit_cast(uint2, hi), lw = __builtin_bit_cast(uint2, lo);
-                if (a_pix[i] < 0) hw = lw = make_uint2(0u, 0u);
-                if (a_pix[i] != -2) {
-                    *reinterpret_cast<uint2*>(dstA + a_sw[i]) = hw;
-                    *reinterpret_cast<uint2*>(dstA + a_sw[i] + 64) = lw;
+                if (pix < 0) hw = lw = make_uint2(0u, 0u);
+                if (pix != -2) {
+                    *reinterpret_cast<uint2*>(dstA + sw) = hw;
+                    *reinterpret_cast<uint2*>(dstA + sw + 64) = lw;
                 }
                 return;
             }
-            if (has_pro) {
+            if (has_pro && mode != 2) {
                 // per dword (two adjacent channels): two packed fmas, two exp2, a packed add, two rcp, a packed multiply, one pack -
                 // ~5 VALU instructions per element (the scalar form had 10: the wave shares its SIMD with an MFMA wave, and every
                 // VALU cycle here is a cycle the matrix core idles - DESIGN.md section 4)
@@ -644,9 +670,13 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
                 }
                 val = __builtin_bit_cast(u32x4, o);
             }
+            if (RSEG && mode == 1) {
+                areg[i] = val;
+                return;
+            }
             const u32x4 zero = {0u, 0u, 0u, 0u};
-            if (a_pix[i] < 0) val = zero;
-            if (a_pix[i] != -2) *reinterpret_cast<u32x4*>(dstA + a_sw[i]) = val;
+            if (pix < 0) val = zero;
+            if (pix != -2) *reinterpret_cast<u32x4*>(dstA + sw) = val;
         };
         // one filter tap (cout tile co0, chunk c, tap t) -> ring slot: UB DMA instructions per wave.  Issued behind the compiler's back
         // (conv_common.h, glds16_hidden): hipcc counts only the halo loads, so its own waits for a halo register (ten younger loads:
@@ -660,6 +690,44 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             for (int k4 = 0; k4 < UB; ++k4) {
                 const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)(lbase + (unsigned)(32 * k4 * ROW_DATA)));
                 glds16_hidden(ub + b_vo[k4], l);
+            }
+        };
+        // residual segment, half-stage j (32 raw channels) -> slot k: the tile's 256 pixels (4 DMA instructions per wave) and the
+        // 128 x 32 filter block (2 per wave)
+        // Pixel slot: wave pw sends rows (BM / 4) pw + 16 q + (lane >> 2) (q < BM / 64); filter slot: rows 32 pw + 16 q + (lane >> 2) (q < 2); LDS piece
+        // lane & 3 of a 64-byte row holds source piece (lane & 3) ^ ((row >> 2) & 3) = (lane & 3) ^ ((lane >> 4) & 3).  The per-lane offsets
+        // are recomputed per request from a laundered lane id - a dozen instructions per half-stage - instead of living in seven more
+        // registers for the whole kernel (the allocator is at its 256-register limit here, and a spilled halo coordinate is reloaded
+        // behind a full `vmcnt(0)` drain in every stage).
+        constexpr int RA = BM / 64, RD = RA + 2;  // requests per wave: the pixels; pixels + filter block
+        auto dma_rseg_A = [&](int k, const TileXY& t, int j) __attribute__((always_inline)) {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int c0 = j * 32;
+            const bool second = c0 >= a.r_C1;
+            const int Cs = second ? a.r_C2 : a.r_C1;
+            const int tile_pix0 = (t.n0 * a.Hin + t.oy0) * a.Win + t.ox0;
+            const char* sb = (const char*)(second ? a.r_src2 : a.r_src1) + ((size_t)tile_pix0 * Cs + (second ? c0 - a.r_C1 : c0)) * 2;
+            const unsigned la = (unsigned)(size_t)(lds_c*)WS_RSA(k) + (unsigned)(pw * (BM / 4) * 64);
+            const int piece = ((ln & 3) ^ ((ln >> 4) & 3)) * 16;
+#pragma unroll
+            for (int q = 0; q < RA; ++q) {
+                const int m = (BM / 4) * pw + 16 * q + (ln >> 2);
+                const int rel = (m >> shTW) * a.Win + (m & mTW);
+                const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)(la + (unsigned)(q * 1024)));
+                glds16_hidden_s(sb, (unsigned)(rel * Cs * 2 + piece), l);
+            }
+        };
+        auto dma_rseg_W = [&](int k, const TileXY& t, int j) __attribute__((always_inline)) {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const char* wb = (const char*)a.r_w + ((size_t)t.co0 * Cres + j * 32) * 2;
+            const unsigned lw = (unsigned)(size_t)(lds_c*)WS_RSW(k) + (unsigned)(pw * 2048);
+            const int piece = ((ln & 3) ^ ((ln >> 4) & 3)) * 16;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)(lw + (unsigned)(q * 1024)));
+                glds16_hidden_s(wb, (unsigned)((32 * pw + 16 * q + (ln >> 2)) * Cres * 2 + piece), l);
             }
         };
         TileXY tcur = WS_TILE(0), tnext = WS_TILE(K > 1 ? 1 : 0);
@@ -677,18 +745,22 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
 #pragma unroll
             for (int i = 0; i < PIPE_UA; ++i) store_A(i, WS_BUFA(0));
 #pragma unroll
-            for (int i = 0; i < PIPE_UA; ++i) load_A(i, KCR);  // nchunks >= 2
+            for (int i = 0; i < PIPE_UA; ++i) load_A(i, 1);  // nchunks >= 2
             wait_vm_keep<PIPE_UA>();  // both taps have landed (they are older than the eleven loads just issued)
         }
         __syncthreads();
         int kt = 0, cc = 0, cg = 0;
         int p_i = 0;
         (void)p_i;
-#define WS_A_UNIT(i)                          \
-    {                                         \
-        if (do_store) store_A((i), dstA);     \
-        if (new_tile) set_pix((i), tnn);      \
-        load_A((i), lc * KCR);                \
+#define WS_A_UNIT(i)                                                        \
+    {                                                                       \
+        if (RSEG && last_c) { /* the next tile's first chunk stays in its registers until the residual segment is through */ \
+            if (do_store) store_A((i), dstA, 1);                            \
+        } else {                                                            \
+            if (do_store) store_A((i), dstA);                               \
+            if (new_tile) set_pix((i), tnn);                                \
+            load_A((i), lc);                                                \
+        }                                                                   \
     }
 #define WS_A_ARRIVED(i) { asm volatile("" : "+v"(areg[i][0]), "+v"(areg[i][1]), "+v"(areg[i][2]), "+v"(areg[i][3])); }
         // stage TP = tap TP of chunk (kt, cc): DMA of the tap two stages on, 1-2 halo units of the next chunk, barrier.
@@ -701,6 +773,10 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
 #define WS_PST()
 #endif
 #define WS_L(TP) (PIPE_UA == 11 ? (((TP) == 0 || (TP) == 8) ? 2 : 1) : ((TP) < 7 ? 1 : 0)) /* halo loads a stage issues (behind its DMA) */
+        // RSEG, the LAST main chunk of a tile: no halo loads; behind their tap stages 5 / 6 request the pixels of the segment's half-stages
+        // 0 / 1 (4 instructions each), stage 7 both filter blocks (2 + 2).  Requests a stage issues / of those, the ones behind its tap
+#define WS_RD(TP) ((TP) <= 4 ? UB : (TP) <= 6 ? UB + RA : 0)
+#define WS_RX(TP) (((TP) == 5 || (TP) == 6) ? RA : 0)
 #define WS_PSTAGE(TP)                                                                                                   \
     {                                                                                                                   \
         WS_PST()                                                                                                        \
@@ -726,12 +802,20 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             sent_next = true;                                                                                           \
         }                                                                                                               \
         if ((TP) <= 6) dma_tap(WS_RING(((TP) + 2) % 3), tcur.co0, cc, (TP) + 2);                                        \
+        else if (RSEG && last_c) { /* (the next tile's tap 0 goes out in the segment's last stage) */ }                 \
         else if ((TP) == 7) {                                                                                           \
             if (have_n) dma_tap(WS_RING(0), nk == kt ? tcur.co0 : tnext.co0, nc, 0);                                    \
             else sent = false;                                                                                          \
         } else {                                                                                                        \
             if (have_n && nk == kt) dma_tap(WS_RING(1), tcur.co0, nc, 1);                                               \
             else sent = false;                                                                                          \
+        }                                                                                                               \
+        if constexpr (RSEG) {  /* pixel slots 0 / 1 lie in A0 (free since the previous chunk ended), filter slots 0 / 1 in R0 (tap 6 */ \
+            if (last_c) {      /* was its last reader: free from stage 7 on - so the filter blocks of BOTH go out at stage 5 / 6   */ \
+                if ((TP) == 5) dma_rseg_A(0, tcur, 0);                                                                  \
+                if ((TP) == 6) dma_rseg_A(1, tcur, 1);                                                                  \
+                if ((TP) == 7) { dma_rseg_W(0, tcur, 0); dma_rseg_W(1, tcur, 1); }                                      \
+            }                                                                                                           \
         }                                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
         {                                                                                                               \
@@ -751,7 +835,14 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         /* the NEXT stage's tap must have landed; whatever was issued after it may stay in flight: the previous stage's  \
            halo loads, this stage's DMA (UB instructions) and halo loads - or, when that tap went out in this very stage, \
            only the second DMA and the loads */                                                                         \
-        if (sent_next) wait_vm_keep<UB + WS_L(TP)>();                                                                   \
+        if (RSEG && last_c) {                                                                                           \
+            /* stage 8 hands over to half-stage 0, whose filter block went out first in stage 7: only the second stays */ \
+            if ((TP) == 0) wait_vm_keep<WS_L(8) + UB>();                                                                \
+            else if ((TP) <= 6) wait_vm_keep<WS_RX(((TP) + 8) % 9) + WS_RD(TP)>();                                      \
+            else if ((TP) == 7) wait_vm_keep<WS_RX(6) + 4>();  /* (tap 8, then stage 6's pixels and this stage's two blocks) */ \
+            else wait_vm_keep<2>();                                                                                     \
+        }                                                                                                               \
+        else if (sent_next) wait_vm_keep<UB + WS_L(TP)>();                                                              \
         else if (sent) wait_vm_keep<WS_L(((TP) + 8) % 9) + UB + WS_L(TP)>();                                            \
         else wait_vm_keep<WS_L(((TP) + 8) % 9) + WS_L(TP)>();                                                           \
         WS_PST()                                                                                                        \
@@ -759,6 +850,34 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         if ((TP) == 8) {                                                                                                \
             ++cg;                                                                                                       \
             if (++cc == nchunks) { /* tile done: its epilogue (store loop shared with the consumers), then on */        \
+                if constexpr (RSEG) {                                                                                   \
+                    /* the residual segment: half-stage j reads slot j % 5.  Stage 0 requests 2, 3, 4 (their slots were the main loop's \
+                       until now), stage j >= 1 requests j + 4 into the slot stage j - 1 read; requests retire in order, so the wait \
+                       leaves the ones behind half-stage j + 1 in flight */ \
+                    int sl = 2;                                                                                         \
+                    for (int j = 0; j < RT; ++j) {                                                                      \
+                        const bool fin = j + 1 == RT && kt + 1 < K;                                                     \
+                        for (int h_ = (j == 0 ? 2 : j + 4); h_ <= j + 4 && h_ < HS; ++h_) {                             \
+                            dma_rseg_A(sl, tcur, h_);                                                                   \
+                            dma_rseg_W(sl, tcur, h_);                                                                   \
+                            sl = sl == RSL - 1 ? 0 : sl + 1;                                                            \
+                        }                                                                                               \
+                        if (fin) { /* A0 and R0 have had their last reader: the next tile's chunk 0, tap 0; chunk 1 requested */ \
+                            _Pragma("unroll") for (int i = 0; i < PIPE_UA; ++i) store_A(i, WS_BUFA(cg), 2);             \
+                            dma_tap(WS_RING(0), tnext.co0, 0, 0);                                                       \
+                            _Pragma("unroll") for (int i = 0; i < PIPE_UA; ++i) load_A(i, 1);                           \
+                        }                                                                                               \
+                        __builtin_amdgcn_sched_barrier(0);                                                              \
+                        const int hmax = j + 4 < HS - 1 ? j + 4 : HS - 1;  /* youngest half-stage requested so far */   \
+                        const int ahead = hmax - (j + 1);                   /* ... those behind the one stage j + 1 reads */ \
+                        if (fin) wait_vm_keep<UB + PIPE_UA>();                                                          \
+                        else if (ahead >= 3) wait_vm_keep<3 * RD>();                                                    \
+                        else if (ahead == 2) wait_vm_keep<2 * RD>();                                                    \
+                        else if (ahead == 1) wait_vm_keep<RD>();                                                        \
+                        else wait_vm_keep<0>();                                                                         \
+                        __builtin_amdgcn_s_barrier();                                                                   \
+                    }                                                                                                   \
+                }                                                                                                       \
                 WS2_EPILOGUE(tcur, kt, ;, ;)                                                                                   \
                 cc = 0;                                                                                                 \
                 ++kt;                                                                                                   \
@@ -772,6 +891,8 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             WS_PSTAGE(0) WS_PSTAGE(1) WS_PSTAGE(2) WS_PSTAGE(3) WS_PSTAGE(4) WS_PSTAGE(5) WS_PSTAGE(6) WS_PSTAGE(7) WS_PSTAGE(8)
         }
 #undef WS_PSTAGE
+#undef WS_RD
+#undef WS_RX
 #undef WS_L
 #undef WS_PST
 #undef WS_A_UNIT
@@ -818,16 +939,6 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.f;
-        for (int c = 0; c < nchunks; ++c, ++cg) {
-            const char* ldsA = WS_BUFA(cg);
-#pragma unroll 3
-            for (int tp = 0; tp < 9; ++tp) {
-                const char* ldsR = WS_RING(tp % 3);
-                const int tap_b = ((tp / 3) * g.HWd + (tp % 3)) * A_PITCH;
-                const char* pa[MI];
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) pa[mi] = ldsA + a_row[mi] + tap_b;
-                uint4 af[2][MI], bfr[2][NI];
 #define WS_FRAGS(SET, KG)                                                                                                         \
     {                                                                                                                             \
         _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) af[SET][mi] = *reinterpret_cast<const uint4*>(pa[mi] + (KG) * 32);      \
@@ -849,6 +960,16 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_group(af[SA][mi], bfr[SB_][ni], acc[mi][ni], (T*)nullptr); \
         __builtin_amdgcn_sched_barrier(0);                                                            \
     }
+        for (int c = 0; c < nchunks; ++c, ++cg) {
+            const char* ldsA = WS_BUFA(cg);
+#pragma unroll 3
+            for (int tp = 0; tp < 9; ++tp) {
+                const char* ldsR = WS_RING(tp % 3);
+                const int tap_b = ((tp / 3) * g.HWd + (tp % 3)) * A_PITCH;
+                const char* pa[MI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) pa[mi] = ldsA + a_row[mi] + tap_b;
+                uint4 af[2][MI], bfr[2][NI];
                 if constexpr (SPLIT != 0) {
                     // k-groups 0, 1 = hi halves of the chunk's 32 channels, 2, 3 = lo halves; two A slots and two B slots as in the plain
                     // schedule, every fragment set requested one MFMA group (8 MFMAs) ahead of its first use
@@ -865,17 +986,46 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
                 } else {
                     WS_FRAGS(0, 0) WS_FRAGS(1, 1) WS_MMAS(0) WS_FRAGS(0, 2) WS_MMAS(1) WS_FRAGS(1, 3) WS_MMAS(0) WS_MMAS(1)
                 }
+                WS_STAMP()
+                __syncthreads();
+                WS_STAMP()
+            }
+        }
+        if constexpr (RSEG) {
+            // the residual segment: half-stage j = 32 raw input channels, pixels and filter block in slot j % 5 (rows of 64 bytes: piece
+            // (k-group * 2 + h) ^ ((row >> 2) & 3), and (row >> 2) & 3 == (r >> 2) & 3 for every row this lane reads); then the empty stage
+            const int rsw = (r >> 2) & 3;
+            const int rA = (wrow * 32 + r) * 64, rB = (wn0 + r) * 64;
+            const int pk0 = (h ^ rsw) << 4, pk1 = ((2 + h) ^ rsw) << 4;
+            int slot = 0;
+            for (int j = 0; j < HS; ++j) {
+                const char* sa = WS_RSA(slot) + rA;
+                const char* sw = WS_RSW(slot) + rB;
+                slot = slot == RSL - 1 ? 0 : slot + 1;
+                uint4 af[2][MI], bfr[2][NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) af[0][mi] = *reinterpret_cast<const uint4*>(sa + mi * 4096 + pk0);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) bfr[0][ni] = *reinterpret_cast<const uint4*>(sw + ni * 2048 + pk0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) af[1][mi] = *reinterpret_cast<const uint4*>(sa + mi * 4096 + pk1);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) bfr[1][ni] = *reinterpret_cast<const uint4*>(sw + ni * 2048 + pk1);
+                __builtin_amdgcn_sched_barrier(0);
+                WS_MMAS(0) WS_MMAS(1)
+                WS_STAMP()
+                __syncthreads();
+                WS_STAMP()
+            }
+            for (int j = HS; j < RT; ++j) __syncthreads();
+        }
 #undef WS_FA
 #undef WS_FB
 #undef WS_SB
 #undef WS_MM
 #undef WS_FRAGS
 #undef WS_MMAS
-                WS_STAMP()
-                __syncthreads();
-                WS_STAMP()
-            }
-        }
         // the last stage read R2 and A1: R1|R2|A1 stages the epilogue
         WS2_EPILOGUE(t, kt, (conv_epilogue_stage<T, BN, 2, NI, 64>(a, reinterpret_cast<f32x16(&)[2][NI]>(acc[0]), t.co0, wn0, r, h, wrow * 32, t.n0, stage));,
                      (conv_epilogue_stage<T, BN, 2, NI, 64>(a, reinterpret_cast<f32x16(&)[2][NI]>(acc[2]), t.co0, wn0, r, h, wrow * 32, t.n0, stage));)
@@ -990,6 +1140,17 @@ static int pipe_pick(const ConvArgs& a, ConvTile& g) {
     return pick;
 }
 
+static bool rseg_shape_ok(const ConvArgs& a) {
+    const int Cres = a.r_C1 + a.r_C2;
+    return a.r_src1 && a.r_bias && a.r_C1 > 0 && a.r_C1 % 64 == 0 && a.r_C2 >= 0 && (a.r_C2 == 0 || a.r_src2) && Cres % 128 == 0 && Cres <= 512 && !a.up && !a.res1 &&
+           !a.res2 && (int64_t)a.Cout * Cres < (1ll << 30) && (int64_t)a.N * a.Hin * a.Win * Cres < (1ll << 30);
+}
+bool conv_pipe_rseg_supported(int dtype, const ConvArgs& a) {
+    if (!is16(dtype) || a.mix || !a.r_w || getenv("DMME_NO_WS") || !rseg_shape_ok(a) || !conv_pipe_supported(dtype, a)) return false;
+    ConvTile gw{};
+    return ws_pick(a, gw) != 0;
+}
+
 bool conv_pipe_supported(int dtype, const ConvArgs& a) {
     if (a.mix) {
         ConvTile gs{};
@@ -1071,12 +1232,20 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
             if (!ws_attr) {
                 int rc0 = set_lds_limit(conv3x3_ws2_kernel<11, T, 256>, 160 * 1024);
                 if (rc0 == DMME_OK) rc0 = set_lds_limit(conv3x3_ws2_kernel<7, T, 128>, 160 * 1024);
+                if (rc0 == DMME_OK) rc0 = set_lds_limit(conv3x3_ws2_kernel<11, T, 256, 0, true>, 160 * 1024);
+                if (rc0 == DMME_OK) rc0 = set_lds_limit(conv3x3_ws2_kernel<7, T, 128, 0, true>, 160 * 1024);
                 if (rc0 != DMME_OK) return rc0;
                 ws_attr = true;
             }
             const int ntiles = gw.tiles_m * gw.tiles_n;
             const dim3 wgrid((unsigned)(ntiles < 256 ? ntiles : 256));
-            if (ws == 4)
+            if (a.r_w) {
+                DMME_REQUIRE(rseg_shape_ok(a), DMME_ERR_UNSUPPORTED, "conv3x3 with a residual segment: raw channel counts outside the wave-specialised kernel's domain");
+                if (ws == 4)
+                    hipLaunchKernelGGL((conv3x3_ws2_kernel<7, T, 128, 0, true>), wgrid, dim3(512), ws2_lds(a, gw), s, a, gw, ilog2(gw.TW), ilog2(gw.TH), ntiles);
+                else
+                    hipLaunchKernelGGL((conv3x3_ws2_kernel<11, T, 256, 0, true>), wgrid, dim3(512), ws2_lds(a, gw), s, a, gw, ilog2(gw.TW), ilog2(gw.TH), ntiles);
+            } else if (ws == 4)
                 hipLaunchKernelGGL((conv3x3_ws2_kernel<7, T, 128>), wgrid, dim3(512), ws2_lds(a, gw), s, a, gw, ilog2(gw.TW), ilog2(gw.TH), ntiles);
             else
                 hipLaunchKernelGGL((conv3x3_ws2_kernel<11, T, 256>), wgrid, dim3(512), ws2_lds(a, gw), s, a, gw, ilog2(gw.TW), ilog2(gw.TH), ntiles);
@@ -1084,6 +1253,7 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
             return DMME_OK;
         }
     }
+    DMME_REQUIRE(!a.r_w, DMME_ERR_UNSUPPORTED, "conv3x3 with a residual segment: only the wave-specialised kernel takes it");
     if constexpr (sizeof(T) == 2) {
         ConvTile gk{};
         int kni = 0, kring = 0, kbm = 0;
@@ -1257,7 +1427,7 @@ void conv_pipe_label(int dtype, const ConvArgs& a, char* buf, int cap) {
         ConvTile gw{};
         const int ws = ws_pick(a, gw);
         if (ws) {
-            snprintf(buf, (size_t)cap, ws == 4 ? "conv3x3_ws2_kernel<7,128>" : "conv3x3_ws2_kernel<11>");
+            snprintf(buf, (size_t)cap, ws == 4 ? (a.r_w ? "conv3x3_ws2_kernel<7,128,res>" : "conv3x3_ws2_kernel<7,128>") : a.r_w ? "conv3x3_ws2_kernel<11,res>" : "conv3x3_ws2_kernel<11>");
             return;
         }
     }

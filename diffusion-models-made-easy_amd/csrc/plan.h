@@ -79,6 +79,10 @@ struct Op {
     int gd_n = 0, gd_gn[2] = {-1, -1}, gd_coff[2] = {0, 0};  // norms this conv's forward epilogue finishes (op index, channel offset in the norm)
     int gd_act = -1;           // which of them also gets the consumer's pre-activated input written (-1: none)
     int res_alias = 0;         // backward: the residual input's gradient buffer is this conv's output gradient buffer (no copy)
+    // FORWARD fusion of a ResBlock's 1x1 residual conv into conv2 (ConvArgs::r_w, the wave-specialised kernel's residual segment):
+    // conv2.rseg = op index of the residual conv, whose own launch is skipped (fused_away) and whose output tensor is never written.
+    // The backward pass is untouched: it reads neither that tensor nor these fields.
+    int rseg = -1, fused_away = 0;
     int wg_layer = -1;         // index into the grouped weight-gradient table of its kernel size (-1: per-layer kernels)
     int64_t wg_act = -1;       // backward workspace offset of its pre-activated input, written by its GroupNorm's backward for the
                                // deferred weight gradient (-1: none)
@@ -197,6 +201,8 @@ void fill_conv(const dmme_plan* P, const Op& o, const char* packed, const float*
 bool gn_from_parts(const dmme_plan* P, const Op& o);
 // plan_lvl.hip: which stretches of the op list become level-engine runs; their launch; the bounded waits' status word
 void assign_levels(dmme_plan* P);
+// plan.hip: which residual 1x1 convs ride in their block's conv2 (after the level runs are known)
+void assign_rseg(dmme_plan* P);
 int run_level(const dmme_plan* P, const LvlRun& R, const char* pk, char* ws, int nt, const float* drop_masks, hipStream_t s);
 int lvl_check(const dmme_plan* P, const char* where, hipStream_t stream = nullptr, bool have_stream = false);
 // plan_bwd.hip: the grouped (deferred) weight-gradient tables of ops [op_lo, op_hi)

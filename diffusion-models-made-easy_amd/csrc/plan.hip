@@ -760,7 +760,18 @@ void fill_conv(const dmme_plan* P, const Op& o, const char* packed, const float*
         a.tproj_ld = P->tproj_cols;
         a.nt = nt;
     }
-    if (o.res1 >= 0) {
+    if (fwd && o.rseg >= 0) {  // the block's residual conv runs inside this launch: no residual tensor
+        const Op& rc = P->ops[o.rseg];
+        const Tensor& r1 = P->tensors[rc.src1];
+        a.r_src1 = ws + r1.off;
+        a.r_C1 = r1.C;
+        if (rc.src2 >= 0) {
+            a.r_src2 = ws + P->tensors[rc.src2].off;
+            a.r_C2 = P->tensors[rc.src2].C;
+        }
+        a.r_w = packed + P->params[rc.w].packed_off;
+        a.r_bias = (const float*)(packed + P->params[rc.b].packed_off);
+    } else if (o.res1 >= 0) {
         a.res1 = ws + P->tensors[o.res1].off;
         a.R1 = P->tensors[o.res1].C;
         if (o.res2 >= 0) a.res2 = ws + P->tensors[o.res2].off;
@@ -997,6 +1008,44 @@ void assign_gn_in(dmme_plan* P) {
     }
 }
 
+// The ResBlocks' 1x1 residual convs (models/ddpm.py:108-111: `h + residual(x)` where the channel count changes) whose conv2 runs on the
+// wave-specialised 3x3 kernel's 256-pixel form become a second K segment of that launch (conv_pipe.hip, RSEG): at the benchmark batch the
+// seven of them on the 32x32 / 16x16 levels were 0.17 ms of launches that mostly moved bytes (raw input in, residual tensor out, and
+// in again in conv2's epilogue).  Forward only: the backward pass never reads a residual tensor.  DMME_DEBUG_ROUTE=no_rseg: off.
+void assign_rseg(dmme_plan* P) {
+    if (debug_route("no_rseg") || !is16(P->dtype) || P->mix || P->x3) return;
+    std::vector<int> uses(P->tensors.size(), 0), producer(P->tensors.size(), -1);
+    for (int oi = 0; oi < (int)P->ops.size(); ++oi) {
+        const Op& o = P->ops[oi];
+        for (int id : {o.src1, o.src2, o.res1, o.res2, o.gn_src1, o.gn_src2, o.at_qkv, o.cast_src})
+            if (id >= 0) ++uses[id];
+        if (o.kind == OP_CONV && o.dst >= 0) producer[o.dst] = oi;
+    }
+    for (int ci = 0; ci < (int)P->ops.size(); ++ci) {
+        Op& c2 = P->ops[ci];
+        if (c2.kind != OP_CONV || c2.taps != 9 || c2.lvl >= 0 || c2.res1 < 0 || c2.res2 >= 0 || c2.dst < 0 || c2.mix || c2.route_f32) continue;
+        const int ri = producer[c2.res1];
+        if (ri < 0 || uses[c2.res1] != 1) continue;
+        Op& rc = P->ops[ri];
+        if (rc.kind != OP_CONV || rc.taps != 1 || rc.lvl >= 0 || rc.gn >= 0 || rc.pro_silu || rc.out_silu || rc.dmask_off >= 0 || rc.tproj_col >= 0 || rc.res1 >= 0 ||
+            rc.up || rc.stride != 1 || rc.src1 < 0 || rc.gd_n > 0 || rc.mix || rc.route_f32)
+            continue;
+        for (const auto& kv : P->named)  // (a tensor somebody can ask for by module name stays a tensor)
+            if (kv.second == c2.res1) goto next;
+        {
+            c2.rseg = ri;
+            ConvArgs a{};
+            fill_conv(P, c2, (const char*)4096, (const float*)4096, (float*)4096, (char*)4096, nullptr, 1, a, true);
+            if (!conv_pipe_rseg_supported(P->dtype, a)) {
+                c2.rseg = -1;
+                continue;
+            }
+            rc.fused_away = 1;
+        }
+    next:;
+    }
+}
+
 int run_gn(const dmme_plan* P, const Op& o, const char* pk, char* ws, int nt, const float* drop_masks, hipStream_t s) {
     if (o.gn_direct || o.gn_in_consumer) return DMME_OK;  // its producers (its consumer) wrote scale / shift / {mean, rstd} (and act)
     // scale-shift conditioning (iddpm.ResBlock): (shift | scale) columns of the batched time projection
@@ -1042,6 +1091,7 @@ int run_gn(const dmme_plan* P, const Op& o, const char* pk, char* ws, int nt, co
 int run_op(const dmme_plan* P, const Op& o, const char* pk, const float* x, const int64_t* t, int nt, float* y,
            char* ws, const float* drop_masks, hipStream_t s) {
     if (o.lvl >= 0) return o.lvl_first ? run_level(P, P->lvl_runs[o.lvl], pk, ws, nt, drop_masks, s) : DMME_OK;
+    if (o.fused_away) return DMME_OK;  // a residual 1x1 conv that runs inside its block's conv2 (assign_rseg)
     switch (o.kind) {
         case OP_SINUS:
             return launch_time_sinusoid(t, nt, (const float*)(pk + P->params[P->freqs_param].packed_off),
@@ -1101,6 +1151,10 @@ void op_account(const dmme_plan* P, const Op& o, char* label, int cap, double* f
         }
         return;
     }
+    if (o.fused_away) {
+        snprintf(label, cap, "(residual 1x1 conv inside its block's conv2)");
+        return;
+    }
     switch (o.kind) {
         case OP_SINUS:
             snprintf(label, cap, "time_sinusoid_kernel");
@@ -1143,6 +1197,11 @@ void op_account(const dmme_plan* P, const Op& o, char* label, int cap, double* f
             *flops = 2.0 * opix * a.Cout * Cin * a.taps;
             *bytes = B * a.Hin * a.Win * Cin * (a.in_nchw ? 4.0 : es) + opix * a.Cout * (a.out_nchw ? 4.0 : es) +
                      (double)a.Cout * Cin * a.taps * es + (a.res1 ? opix * a.Cout * es : 0.0);
+            if (a.r_w) {  // the residual segment: its raw input once, its filter, its products
+                const double Cres = a.r_C1 + a.r_C2;
+                *flops += 2.0 * opix * a.Cout * Cres;
+                *bytes += opix * Cres * es + (double)a.Cout * Cres * es;
+            }
             break;
         }
         case OP_CAST: {
@@ -1237,8 +1296,10 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
     if (!getenv("DMME_NO_FUSED_GN") && !getenv("DMME_NO_GN_DIRECT")) assign_direct(P);
     if (!getenv("DMME_NO_PREACT")) assign_preact(P);
     if (!getenv("DMME_NO_FUSED_GN")) assign_gn_in(P);
+    assign_rseg(P);
     P->n_launches = 0;
     for (const Op& o : P->ops) {
+        if (o.fused_away) continue;
         if (o.lvl >= 0)
             P->n_launches += o.lvl_first;
         else if (o.kind == OP_GN)
@@ -1826,6 +1887,26 @@ DMME_API int dmme_conv2d(const dmme_conv_desc* d, const void* src1, const void* 
     if (!d->force_generic && conv_pipe_supported(dt, a)) return launch_conv_pipe(dt, a, (hipStream_t)stream);
     if (!d->force_generic && conv_mfma_supported(dt, a)) return launch_conv_mfma(dt, a, (hipStream_t)stream);
     return launch_conv_generic(dt, a, (hipStream_t)stream);
+}
+
+DMME_API int dmme_conv2d_res(const dmme_conv_desc* d, const void* src1, const void* src2, const void* weight, const float* bias, const float* scale,
+                             const float* shift, const float* dmask, const void* r_src1, const void* r_src2, int r_C1, int r_C2, const void* r_weight,
+                             const float* r_bias, void* dst, void* stream) {
+    DMME_REQUIRE(d && src1 && weight && bias && dst && r_src1 && r_weight && r_bias, DMME_ERR_INVALID, "conv2d_res: null argument");
+    DMME_REQUIRE(d->dtype == DMME_BF16 || d->dtype == DMME_F16, DMME_ERR_UNSUPPORTED, "conv2d_res: 16-bit tensors only (dtype %d)", d->dtype);
+    ConvArgs a{};
+    a.src1 = src1; a.src2 = src2; a.w = weight; a.bias = bias; a.scale = scale; a.shift = shift; a.dmask = dmask; a.dst = dst;
+    a.N = d->N; a.Hin = d->Hin; a.Win = d->Win; a.C1 = d->C1; a.C2 = src2 ? d->C2 : 0;
+    a.up = d->upsample; a.stride = d->stride; a.taps = d->taps;
+    a.Hout = a.Hin; a.Wout = a.Win; a.Cout = d->Cout;
+    a.pro_silu = d->pro_silu; a.out_silu = d->out_silu;
+    a.f16 = d->dtype == DMME_F16;
+    a.stamps = g_stamps;
+    a.r_src1 = r_src1; a.r_src2 = r_C2 > 0 ? r_src2 : nullptr; a.r_C1 = r_C1; a.r_C2 = r_C2 > 0 ? r_C2 : 0; a.r_w = r_weight; a.r_bias = r_bias;
+    DMME_REQUIRE(a.taps == 9 && a.stride == 1 && !a.up && conv_pipe_rseg_supported(d->dtype, a), DMME_ERR_UNSUPPORTED,
+                 "conv2d_res: the wave-specialised 3x3 kernel does not take this shape with a residual segment (%d+%d -> %d channels, %d+%d raw, %dx%dx%d)", a.C1, a.C2,
+                 a.Cout, a.r_C1, a.r_C2, a.N, a.Hin, a.Win);
+    return launch_conv_pipe(d->dtype, a, (hipStream_t)stream);
 }
 
 DMME_API int dmme_groupnorm_scale_shift(int dtype, const void* src1, const void* src2, int N, int HW, int C1, int C2, int groups,

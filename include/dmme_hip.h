@@ -360,6 +360,15 @@ DMME_API int dmme_conv2d(const dmme_conv_desc* d, const void* src1, const void* 
                 const float* bias, const float* scale, const float* shift, const float* dmask,
                 const float* tproj, const void* res1, const void* res2, int R1, void* dst, void* stream);
 
+/* The second half of a channel-changing ResBlock as ONE launch (models/ddpm.py:108-111,131: `conv2(act(h)) + residual(x)`): the 3x3 conv
+ * of dmme_conv2d over src1 (++ src2) with its prologue, plus the block's 1x1 residual conv over the RAW block input r_src1 [.., r_C1]
+ * (++ r_src2 [.., r_C2]) with r_weight packed [Cout][r_C1 + r_C2] and r_bias [Cout], accumulated into the same output tile - no
+ * residual tensor.  16-bit dtypes, stride 1, the shapes the wave-specialised kernel's 256-pixel form takes (whole 128-cout tiles,
+ * r_C1 a multiple of 64, r_C1 + r_C2 a multiple of 128 and <= 512); DMME_ERR_UNSUPPORTED otherwise - it never falls back. */
+DMME_API int dmme_conv2d_res(const dmme_conv_desc* d, const void* src1, const void* src2, const void* weight, const float* bias,
+                const float* scale, const float* shift, const float* dmask, const void* r_src1, const void* r_src2, int r_C1,
+                int r_C2, const void* r_weight, const float* r_bias, void* dst, void* stream);
+
 /* GroupNorm statistics folded with the affine: scale[n][c] = rstd*gamma[c],
  * shift[n][c] = beta[c] - mean*rstd*gamma[c]  (nn.GroupNorm(eps=1e-5), models/ddpm.py:17-18). */
 DMME_API int dmme_groupnorm_scale_shift(int dtype, const void* src1, const void* src2, int N, int HW, int C1, int C2,

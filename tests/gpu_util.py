@@ -78,6 +78,32 @@ def conv2d(dt, x1, w, b, x2=None, scale=None, shift=None, dmask=None, tproj=None
     return out if out_nchw else to_nchw(out, dt)
 
 
+def conv2d_res(dt, x1, w, b, r1, wr, br, x2=None, r2=None, scale=None, shift=None, dmask=None, pro_silu=False):
+    """dmme_conv2d_res: conv3x3(prologue(x1 ++ x2)) + conv1x1(r1 ++ r2) in one launch.  fp32 NCHW cuda tensors in, fp32 NCHW out."""
+    N, C1, H, W = x1.shape
+    d = _lib.ConvDesc()
+    d.dtype, d.N, d.Hin, d.Win, d.C1 = dt, N, H, W, C1
+    d.C2 = 0 if x2 is None else x2.shape[1]
+    d.upsample, d.stride, d.taps, d.Cout = 0, 1, 9, w.shape[0]
+    d.pro_silu, d.out_silu = int(pro_silu), 0
+    d.nt = d.tproj_ld = d.in_nchw = d.out_nchw = d.force_generic = 0
+    a1 = to_nhwc(x1, dt)
+    a2 = None if x2 is None else to_nhwc(x2, dt)
+    q1 = to_nhwc(r1, dt)
+    q2 = None if r2 is None else to_nhwc(r2, dt)
+    wp, wrp = pack_w(w, dt), pack_w(wr, dt)
+    out = torch.empty((N, H, W, w.shape[0]), dtype=TD[dt], device=x1.device)
+    f = lambda t: None if t is None else t.to(torch.float32).contiguous()
+    sc, sh, dm, bb, bbr = f(scale), f(shift), f(dmask), f(b), f(br)
+    _lib.check(
+        _lib.lib().dmme_conv2d_res(C.byref(d), _lib.ptr(a1), _lib.ptr(a2), _lib.ptr(wp), _lib.ptr(bb), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(dm),
+                                   _lib.ptr(q1), _lib.ptr(q2), r1.shape[1], 0 if r2 is None else r2.shape[1], _lib.ptr(wrp), _lib.ptr(bbr),
+                                   _lib.ptr(out), _lib.stream_ptr()),
+        "dmme_conv2d_res",
+    )
+    return to_nchw(out, dt)
+
+
 def gn_scale_shift(dt, x1, gamma, beta, groups, x2=None, force_generic=False, eps=1e-5):
     N, C1, H, W = x1.shape
     C2 = 0 if x2 is None else x2.shape[1]

@@ -189,6 +189,69 @@ def test_conv_fp16r32_split_pass_kernels_vs_fp64(case):
     assert err <= 2e-5 * mx, f"{name}: {err:.3e} > {2e-5 * mx:.3e}"
 
 
+RSEG_CASES = [
+    # (name, N, main C1, main C2, H, Cout, raw C1, raw C2, fused prologue)
+    ("up16_cat512", 128, 256, 0, 16, 256, 256, 256, True),        # 16 half-stages + the empty one; one tile per workgroup
+    ("up32_cat384_b130", 130, 128, 0, 32, 128, 256, 128, True),   # 12 half-stages, no empty stage; 520 tiles: two or three per workgroup
+    ("up32_cat256_b64", 64, 128, 0, 32, 128, 128, 128, True),     # 8 half-stages + the empty one; exactly 256 tiles
+    ("down16_128_to256", 128, 256, 0, 16, 256, 128, 0, True),     # 4 half-stages + the empty one, single raw source
+    ("up16_cat384_noprologue", 129, 256, 0, 16, 256, 256, 128, False),  # pre-activated main input (no prologue); 258 tiles: two workgroups take two
+    # the 128-pixel tiles (128-cout layers of the 16x16 level at the benchmark batch; the 32x32 maps at batch 32)
+    ("t128_up16_cat512_to128", 128, 128, 0, 16, 128, 256, 256, True),
+    ("t128_up16_cat256_to128_b130", 130, 128, 0, 16, 128, 128, 128, True),
+    ("t128_up32_cat384_b33", 33, 128, 0, 32, 128, 256, 128, True),
+]
+
+
+@pytest.mark.parametrize("dtname", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", RSEG_CASES, ids=[c[0] for c in RSEG_CASES])
+def test_conv3x3_with_residual_segment_vs_fp64(case, dtname):
+    """dmme_conv2d_res: the second half of a channel-changing ResBlock as one launch of the wave-specialised kernel - nine taps over
+    the activated h, then the 1x1 residual conv over the raw block input as half-stages fed by LDS-DMA (conv_pipe.hip, RSEG) -
+    against the fp64 result of the same 16-bit operands, on a sample of images (first, second, a middle one, the last two: every
+    workgroup position of the persistent loop).  One rounding of the fp32 sum to the 16-bit output is all that separates them."""
+    from dmme_amd import _lib
+    from tests import gpu_util as G
+
+    name, N, C1, C2, H, Cout, R1, R2, pro = case
+    dt = _lib.dtype_code(dtname)
+    q = _bf if dtname == "bf16" else _hf
+    seed = 99 + sum(ord(ch) for ch in name) % 10000
+    x1 = synth.normal(seed, (N, C1, H, H))
+    x2 = synth.normal(seed + 1, (N, C2, H, H)) if C2 else None
+    r1 = synth.normal(seed + 2, (N, R1, H, H))
+    r2 = synth.normal(seed + 3, (N, R2, H, H)) if R2 else None
+    Cin, Cres = C1 + C2, R1 + R2
+    w = synth.uniform(seed + 4, (Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)
+    wr = synth.uniform(seed + 5, (Cout, Cres, 1, 1)) / np.sqrt(Cres)
+    b, br = synth.uniform(seed + 6, (Cout,)) * 0.1, synth.uniform(seed + 7, (Cout,)) * 0.1
+    scale = (1 + 0.3 * synth.normal(seed + 8, (N, Cin))) if pro else None
+    shift = 0.2 * synth.normal(seed + 9, (N, Cin)) if pro else None
+    dmask = ((synth.uniform(seed + 10, (N, Cin), 0, 1) < 0.9).float() / 0.9) if pro else None
+    cu = lambda t: None if t is None else t.cuda()
+    y = G.conv2d_res(dt, cu(x1), cu(w), cu(b), cu(r1), cu(wr), cu(br), cu(x2), cu(r2), cu(scale), cu(shift), cu(dmask), pro)
+    torch.cuda.synchronize()
+    y = y.cpu()
+    assert torch.isfinite(y).all()
+    pick = sorted({0, 1, N // 2, N - 2, N - 1})
+    sel = lambda t: None if t is None else t[pick]
+    kind = True if dtname == "bf16" else "fp16"
+    ref = _ref_conv(sel(x1), w, b, sel(x2), sel(scale), sel(shift), sel(dmask), None, None, 1, False, pro, False, kind)
+    xr = sel(r1) if r2 is None else torch.cat([sel(r1), sel(r2)], 1)
+    ref = ref + F.conv2d(q(xr).double(), q(wr).double(), br.double()).float()
+    err, mx = (y[pick] - ref).abs().max().item(), ref.abs().max().item()
+    tol = (BF16_RTOL if dtname == "bf16" else FP16_RTOL) * mx
+    print(f"rseg {name} {dtname}: max err {err:.3e} of |y|max {mx:.2f}")
+    assert err <= tol, f"{name} {dtname}: {err:.3e} > {tol:.3e}"
+    # every image, against the two-launch route (1x1 conv, then the 3x3 conv with its residual input): the residual tensor's own
+    # rounding is the only difference - up to two units in the last place of the output (`tol` is a quarter / half of one at |y|max)
+    res = G.conv2d(dt, cu(r1), cu(wr), cu(br), cu(r2))
+    y2 = G.conv2d(dt, cu(x1), cu(w), cu(b), cu(x2), cu(scale), cu(shift), cu(dmask), None, res, 1, False, pro)
+    torch.cuda.synchronize()
+    d2 = (y - y2.cpu()).abs().max().item()
+    assert d2 <= 4 * tol, f"{name} {dtname}: fused vs two launches {d2:.3e}"
+
+
 GN_CASES = [(3, 128, 0, 32, 32), (2, 256, 256, 8, 32), (2, 128, 128, 16, 32), (5, 256, 0, 4, 32), (2, 8, 4, 16, 2), (3, 16, 0, 8, 2), (2, 256, 0, 16, 32)]
 
 

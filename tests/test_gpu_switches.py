@@ -42,6 +42,7 @@ FORWARD = [
     ({"DMME_NO_PIPE_DMA": "1"}, "filter tiles through registers in the 64-cout pipelined kernel"),
     ({"DMME_NO_CONV_THIN": "1"}, "output conv on the tiled kernels"),
     ({"DMME_NO_WS": "1"}, "no wave-specialised persistent kernel"),
+    ({"DMME_NO_RSEG": "1"}, "the blocks' 1x1 residual convs of the 32x32 / 16x16 levels as launches of their own (+7), not as a segment of conv2"),
     ({"DMME_NO_WS128": "1"}, "persistent kernel without its 128-pixel tiles (the 128-cout layers of the 16x16 level back on the four-wave kernel)"),
     ({"DMME_NO_FUSED_GN": "1"}, "every GroupNorm reads its tensor"),
     ({"DMME_NO_XCD_ORDER": "1"}, "plain workgroup order in attention / 1x1 convs"),
@@ -93,6 +94,16 @@ def test_forward_route_switch_vs_default_route_and_reference(fwd_case, env, note
     # the bf16 network's error budget (tests/test_gpu_unet.py: BF16_REL_RMS, BF16_MAX_ABS - every route is another rounding sequence)
     assert r_ref <= 1.0e-2 and e_ref <= 1.7e-2
     assert e_ab <= 1.0e-2    # two bf16 evaluations of one network (other tile shapes / summation orders), or identical bits
+
+
+def test_residual_segment_saves_seven_launches(fwd_case):
+    """at the benchmark batch the seven channel-changing ResBlocks of the 32x32 / 16x16 levels run their 1x1 residual conv inside conv2
+    (conv_pipe.hip RSEG; five on the 256-pixel tiles, two on the 128-pixel ones): seven launches fewer than with the switch off, and
+    not the same bits (the residual tensor's rounding is gone)"""
+    run, base, n0, ref = fwd_case
+    y, n = run({"DMME_NO_RSEG": "1"})
+    assert n == n0 + 7, (n0, n)
+    assert not torch.equal(y, base)
 
 
 def test_ws128_on_32x32_maps_at_batch_32(golden):

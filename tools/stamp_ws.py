@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Per-stage cycle stamps of the wave-specialised conv kernel (consumer wave 0 and producer wave 4 of two workgroups).
-usage: python tools/stamp_ws.py 32x128x128 [gn] [r32]   (r32: the split-pass form of precision="fp16r32": fp32 tensors, hi / lo halves)"""
+usage: python tools/stamp_ws.py 32x128x128 [gn] [r32] [res=256+128]
+  r32: the split-pass form of precision="fp16r32" (fp32 tensors, hi / lo halves); res=A+B: with the residual segment over raw inputs of
+  A and B channels (dmme_conv2d_res)"""
 import ctypes as C, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,6 +10,7 @@ from dmme_amd import _lib
 shp = sys.argv[1] if len(sys.argv) > 1 else "32x128x128"
 gn = "gn" in sys.argv[2:]
 r32 = "r32" in sys.argv[2:]
+res = next((v[4:] for v in sys.argv[2:] if v.startswith("res=")), None)
 hw, cin, cout = (int(v) for v in shp.split("x"))
 B = 128
 dev = torch.device("cuda:0")
@@ -25,7 +28,17 @@ d.pro_silu = int(gn)
 d.out_silu = d.nt = d.tproj_ld = d.in_nchw = d.out_nchw = d.force_generic = 0
 st = _lib.stream_ptr()
 sc, sh = (scale, shift) if gn else (None, None)
+if res:
+    rc1, rc2 = (int(v) for v in res.split("+"))
+    xr1 = torch.randn(B, hw, hw, rc1, device=dev).to(torch.bfloat16)
+    xr2 = torch.randn(B, hw, hw, rc2, device=dev).to(torch.bfloat16) if rc2 else None
+    wr = (torch.randn(cout, rc1 + rc2, device=dev) * 0.05).to(torch.bfloat16)
+    br = torch.randn(cout, device=dev)
 def run():
+    if res:
+        _lib.check(lib.dmme_conv2d_res(C.byref(d), _lib.ptr(x), None, _lib.ptr(w), _lib.ptr(b), _lib.ptr(sc), _lib.ptr(sh), None, _lib.ptr(xr1), _lib.ptr(xr2),
+                                       rc1, rc2, _lib.ptr(wr), _lib.ptr(br), _lib.ptr(out), st), "conv_res")
+        return
     _lib.check(lib.dmme_conv2d(C.byref(d), _lib.ptr(x), None, _lib.ptr(w), _lib.ptr(b), _lib.ptr(sc), _lib.ptr(sh), None, None, None, None, cout,
                                _lib.ptr(out), st), "conv")
 for _ in range(3): run()
@@ -44,8 +57,8 @@ rel = [t - v[0] for t in v]
 d = [rel[i + 1] - rel[i] for i in range(len(rel) - 1)]
 print("stamps", len(v), "total", rel[-1])
 print("wait preamble", d[0])
-print("work per stage:", d[1::2][:30])
-print("wait per stage:", d[2::2][:30])
+print("work per stage:", d[1::2][:31])
+print("wait per stage:", d[2::2][:31])
 
 e = [int(t) for t in stamps.cpu()[64:88] if int(t) != 0]
 print("epilogue stamps (pass start, after conv_epilogue, after barrier) deltas:", [e[i + 1] - e[i] for i in range(len(e) - 1)])

@@ -654,7 +654,9 @@ int build_unpack_items(dmme_plan* P, std::vector<PackItem>& items) {
 //   3x3 s2 (DownSample), 3x3 with fused 2x upsampling,       conv3x3_pipe_kernel<T, 64, 64, 3 | 9, UA>     4           36-45
 //     everything the rows above decline                        four-wave software pipeline
 //   1x1, K = 128 / 256, >= 128 tiles of 128 pixels           conv1x1_as_kernel<KCH, RES>                  15           14-25
-//     (qkv, proj, residual convs of the 32x32 / 16x16 levels)   activations stationary in registers
+//     (qkv, proj; the blocks' residual convs of the 32x32 /    activations stationary in registers
+//      16x16 levels only with DMME_DEBUG_ROUTE=no_rseg: they
+//      are a second K segment of conv2's launch, assign_rseg)
 //   1x1 otherwise (K = 384 / 512, small maps, small batches) conv1x1_pipe_kernel<T, BM, BN>                2           20-30
 //   output conv (<= 7 couts, NCHW fp32 out)                  conv_out_thin_kernel<NT, T>                   1            15
 //   input conv (NCHW fp32 in, <= 4 channels)                 conv_in_mfma_kernel<T, CT> (generic file)     1            31

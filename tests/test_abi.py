@@ -78,3 +78,63 @@ def test_plan_is_host_only_and_reports_errors():
         _lib.check(-1, "x")
     with pytest.raises(NotImplementedError):
         _lib.check(-2, "x")
+
+
+def _default_cfg():
+    from dmme_amd import _lib
+
+    cfg = _lib.UNetCfg()
+    cfg.in_channels, cfg.pos_dim, cfg.emb_dim, cfg.num_groups, cfg.dropout = 3, 128, 512, 32, 0.1
+    cfg.num_depths, cfg.num_blocks, cfg.num_attention_depths = 4, 2, 1
+    for i, c in enumerate((128, 256, 256, 256)):
+        cfg.channels_per_depth[i] = c
+    cfg.attention_depths[0] = 2
+    return cfg
+
+
+def _plan_labels(batch, dtype, route=None):
+    from dmme_amd import _lib
+
+    lib = _lib.lib()
+    old = os.environ.get("DMME_DEBUG_ROUTE")
+    if route is not None:
+        os.environ["DMME_DEBUG_ROUTE"] = route
+    try:
+        h = C.c_void_p()
+        cfg = _default_cfg()
+        assert lib.dmme_unet_plan_create(C.byref(cfg), batch, 32, 32, dtype, -1, C.byref(h)) == 0
+    finally:
+        if route is not None:
+            if old is None:
+                os.environ.pop("DMME_DEBUG_ROUTE", None)
+            else:
+                os.environ["DMME_DEBUG_ROUTE"] = old
+    label = C.create_string_buffer(128)
+    fl, by = C.c_double(), C.c_double()
+    out, total = [], 0.0
+    for i in range(lib.dmme_unet_plan_num_ops(h)):
+        assert lib.dmme_unet_plan_op_info(h, i, label, 128, C.byref(fl), C.byref(by)) == 0
+        out.append(label.value.decode())
+        total += fl.value
+    n = lib.dmme_unet_plan_num_launches(h)
+    lib.dmme_unet_plan_destroy(h)
+    return out, n, total
+
+
+def test_plan_fuses_residual_convs_into_conv2_where_the_persistent_kernel_runs_it():
+    """host logic of assign_rseg (csrc/plan.hip), no GPU: at the benchmark batch the seven channel-changing ResBlocks of the 32x32 /
+    16x16 levels lose their 1x1 launch (five on the 256-pixel tiles, two on the 128-pixel ones), at batch 32 the three whose conv2 the
+    persistent kernel takes, at batch 1 none; never in fp32 / fp16r32 plans; the switch restores the launches; FLOPs are conserved."""
+    from dmme_amd import _lib
+
+    fused = lambda labels: sum(1 for l in labels if l.startswith("(residual 1x1 conv"))
+    l128, n128, f128 = _plan_labels(128, _lib.BF16)
+    l128_off, n128_off, f128_off = _plan_labels(128, _lib.BF16, "no_rseg")
+    assert fused(l128) == 7 and fused(l128_off) == 0 and n128_off == n128 + 7
+    assert sum(1 for l in l128 if l == "conv3x3_ws2_kernel<11,res>") == 5 and sum(1 for l in l128 if l == "conv3x3_ws2_kernel<7,128,res>") == 2
+    assert abs(f128 / f128_off - 1) < 1e-12
+    assert fused(_plan_labels(128, _lib.F16)[0]) == 7
+    assert fused(_plan_labels(32, _lib.BF16)[0]) == 3
+    assert fused(_plan_labels(1, _lib.BF16)[0]) == 0
+    for dt in (_lib.F32, _lib.F16R32):
+        assert fused(_plan_labels(128, dt)[0]) == 0

@@ -1039,6 +1039,8 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
 #undef WS_ESTAMP
 #undef WS_BUFA
 #undef WS_RING
+#undef WS_RSA
+#undef WS_RSW
 #undef WS_PAR
 #undef WS_TILE
 }

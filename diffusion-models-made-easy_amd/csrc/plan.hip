@@ -1234,7 +1234,7 @@ void op_account(const dmme_plan* P, const Op& o, char* label, int cap, double* f
 extern "C" {
 
 DMME_API const char* dmme_last_error(void) { return g_err; }
-DMME_API int dmme_version(void) { return 103; }
+DMME_API int dmme_version(void) { return 104; }  // 104: dmme_conv2d_res
 DMME_API int dmme_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

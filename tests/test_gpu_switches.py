@@ -51,7 +51,8 @@ FORWARD = [
 ]
 BACKWARD = ["DMME_NO_WG_ACT", "DMME_NO_WG_DMA", "DMME_NO_WG_S2", "DMME_NO_WGRAD_GROUP", "DMME_NO_GN_BWD_IMAGE", "DMME_NO_GN_BWD_FUSED_FIN",
             "DMME_NO_GN_BWD_ROWS", "DMME_NO_GN_BWD_REGS", "DMME_NO_RES_EXTRA", "DMME_NO_GN_BWD_SLICES", "DMME_NO_DGRAD_DIRECT", "DMME_NO_RES_ALIAS", "DMME_NO_COLSUM_GROUP",
-            "DMME_NO_BIAS_GROUP", "DMME_NO_WGRAD_THIN", "DMME_NO_TIME_PRE", "DMME_NO_SMALL_GEMM_MFMA", "DMME_NO_LVL"]
+            "DMME_NO_BIAS_GROUP", "DMME_NO_WGRAD_THIN", "DMME_NO_TIME_PRE", "DMME_NO_SMALL_GEMM_MFMA", "DMME_NO_LVL",
+            "DMME_NO_RSEG"]  # (a forward route: at this batch three blocks' residual convs run inside conv2 - the training step with them as launches)
 
 
 from tests.gpu_util import route_env as _env  # (sets product switches as variables, everything else as DMME_DEBUG_ROUTE keys)

@@ -146,6 +146,57 @@ struct MmaTag<float, true> {
 };
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// PLAIN fp32 vector instructions, as inline asm so that neither the source nor hipcc's SLP vectoriser pairs them into v_pk_*_f32.
+// Beside the MFMAs of the partner wave on the same SIMD a packed fp32 instruction costs its wave 10-15 cycles that overlap nothing
+// (it waits for the matrix pipe), a plain one nothing for up to ~2 per MFMA slot and ~5 cycles beyond that (tools/issue_probe.py,
+// DESIGN.md section 4, round 5): code that runs NEXT TO another wave's MFMAs (the wave-specialised kernel's producers) uses these;
+// code that has the SIMD to itself (store loops between tiles) keeps the packed forms, which halve its instruction count.
+__device__ __forceinline__ float fma_plain(float a, float b, float c) {
+    float d;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float mul_plain(float a, float b) {
+    float d;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float add_plain(float a, float b) {
+    float d;
+    asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float sub_plain(float a, float b) {
+    float d;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float add1_plain(float a) {
+    float d;
+    asm("v_add_f32 %0, 1.0, %1" : "=v"(d) : "v"(a));
+    return d;
+}
+// y_k = (x_k S_k + H_k) / (1 + 2^(x_k S2_k + H2_k)), k = 0, 1 - the GroupNorm-affine + SiLU (+ mask) prologue of the two channels of a
+// halo dword in twelve plain instructions.  ONE asm block, the two channels interleaved by hand: inline asm is invisible to hipcc's
+// hazard recogniser, and on gfx950 a transcendental's result may not be read by the very next non-transcendental vector instruction
+// (one wait state) - here the other channel's instruction always sits in between.  Bit-identical to the packed form (fma = fma).
+__device__ __forceinline__ void pro_pair_plain(float x0, float x1, const f32x2& S, const f32x2& H, const f32x2& S2, const f32x2& H2, float& y0, float& y1) {
+    float e0, e1;
+    asm("v_fma_f32 %0, %4, %6, %8\n\t"
+        "v_fma_f32 %2, %4, %10, %12\n\t"
+        "v_fma_f32 %1, %5, %7, %9\n\t"
+        "v_fma_f32 %3, %5, %11, %13\n\t"
+        "v_exp_f32 %2, %2\n\t"
+        "v_exp_f32 %3, %3\n\t"
+        "v_add_f32 %2, 1.0, %2\n\t"
+        "v_add_f32 %3, 1.0, %3\n\t"
+        "v_rcp_f32 %2, %2\n\t"
+        "v_rcp_f32 %3, %3\n\t"
+        "v_mul_f32 %0, %0, %2\n\t"
+        "v_mul_f32 %1, %1, %3"
+        : "=&v"(y0), "=&v"(y1), "=&v"(e0), "=&v"(e1)
+        : "v"(x0), "v"(x1), "v"(S[0]), "v"(S[1]), "v"(H[0]), "v"(H[1]), "v"(S2[0]), "v"(S2[1]), "v"(H2[0]), "v"(H2[1]));
+}
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 struct Split4 {
     uint2 hi, lo;

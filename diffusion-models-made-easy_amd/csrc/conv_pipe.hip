@@ -618,14 +618,12 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
                     y[0] = f32x2{(float)x[0], (float)x[1]};
                     y[1] = f32x2{(float)x[2], (float)x[3]};
                 }
-                if (has_pro) {
+                if (has_pro) {  // (plain instructions: WS_PRO2 below)
 #pragma unroll
                     for (int d = 0; d < 2; ++d) {
-                        const f32x2 xv = y[d];
-                        f32x2 e = __builtin_elementwise_fma(xv, pS2[d], pH2[d]);
-                        y[d] = __builtin_elementwise_fma(xv, pS[d], pH[d]);
-                        e = f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + f32x2{1.f, 1.f};
-                        y[d] = y[d] * f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+                        float y0, y1;
+                        pro_pair_plain(y[d][0], y[d][1], pS[d], pH[d], pS2[d], pH2[d], y0, y1);
+                        y[d] = f32x2{y0, y1};
                     }
                 }
                 typedef f16 hx4 __attribute__((ext_vector_type(4)));
@@ -636,7 +634,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
                     for (int k = 0; k < 2; ++k) {
                         const f16 hv = (f16)y[d][k];
                         hi[2 * d + k] = hv;
-                        lo[2 * d + k] = (f16)(y[d][k] - (float)hv);
+                        lo[2 * d + k] = (f16)sub_plain(y[d][k], (float)hv);
                     }
                 uint2 hw = __builtin_bit_cast(uint2, hi), lw = __builtin_bit_cast(uint2, lo);
                 if (pix < 0) hw = lw = make_uint2(0u, 0u);
@@ -647,26 +645,28 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
                 return;
             }
             if (has_pro && mode != 2) {
-                // per dword (two adjacent channels): two packed fmas, two exp2, a packed add, two rcp, a packed multiply, one pack -
-                // ~5 VALU instructions per element (the scalar form had 10: the wave shares its SIMD with an MFMA wave, and every
-                // VALU cycle here is a cycle the matrix core idles - DESIGN.md section 4)
+                // per dword (two adjacent channels) in PLAIN fp32 instructions: four fmas, two exp2, two adds, two rcp, two multiplies,
+                // one pack.  Round 3 wrote this in packed pairs (9 instructions per dword instead of 13) and round 2 had concluded that
+                // "VALU work of this wave does not overlap the MFMAs of the consumer wave on its SIMD"; round 5's probe
+                // (tools/issue_probe.py) shows both were the packed instructions: a v_pk_*_f32 beside a saturated matrix pipe costs its
+                // wave 10-15 cycles that overlap nothing, the plain forms issue in the MFMAs' shadow.  Same values bit for bit
+                // (an fma is an fma); consumer wait per GroupNorm stage 750-870 -> 120-140 cycles (tools/stamp_ws.py)
                 typedef typename Vec8<T>::type tx8;
                 const tx8 x = __builtin_bit_cast(tx8, val);
                 tx8 o;
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    f32x2 xv;
+                    float xv[2], yv[2];
                     if constexpr (sizeof(T) == 2 && dtype_of<T>::value == DMME_BF16) {
-                        xv = f32x2{__uint_as_float(val[d] << 16), __uint_as_float(val[d] & 0xffff0000u)};
+                        xv[0] = __uint_as_float(val[d] << 16);
+                        xv[1] = __uint_as_float(val[d] & 0xffff0000u);
                     } else {
-                        xv = f32x2{(float)x[2 * d], (float)x[2 * d + 1]};
+                        xv[0] = (float)x[2 * d];
+                        xv[1] = (float)x[2 * d + 1];
                     }
-                    f32x2 y = __builtin_elementwise_fma(xv, pS[d], pH[d]);
-                    f32x2 e = __builtin_elementwise_fma(xv, pS2[d], pH2[d]);  // (no SiLU: S2 = 0, H2 = -126: the factor below is exactly 1)
-                    e = f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + f32x2{1.f, 1.f};
-                    y = y * f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
-                    o[2 * d] = (T)y[0];
-                    o[2 * d + 1] = (T)y[1];
+                    pro_pair_plain(xv[0], xv[1], pS[d], pH[d], pS2[d], pH2[d], yv[0], yv[1]);  // (no SiLU: S2 = 0, H2 = -126: the factor is exactly 1)
+                    o[2 * d] = (T)yv[0];
+                    o[2 * d + 1] = (T)yv[1];
                 }
                 val = __builtin_bit_cast(u32x4, o);
             }

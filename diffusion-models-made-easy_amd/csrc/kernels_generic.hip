@@ -950,6 +950,139 @@ int launch_mfma_valu(int mode, int iters, int blocks, float* sink, hipStream_t s
     return DMME_OK;
 }
 
+// ------------------------------------------------------------------ diagnostic: what ONE kind of vector instruction costs beside MFMAs
+// The probe above runs compiler-scheduled GroupNorm / SiLU arithmetic (which hipcc SLP-packs into v_pk_* instructions) and cannot
+// tell instruction kinds apart.  Here every instruction is inline asm: waves 0-3 issue rounds of eight independent 32x32x16 (or
+// sixteen 16x16x32) bf16 MFMAs, waves 4-7 `n_inner` x 8 instructions of ONE kind per round (eight independent registers), i.e.
+// `n_inner` instructions per 32x32x16 MFMA slot of the partner wave on the same SIMD.  Both wave kinds record their own cycle count
+// (s_memtime) so that the clock the chip holds does not enter: sink[2 b] = MFMA wave 0's cycles, sink[2 b + 1] = VALU wave 4's.
+// kind: 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_exp_f32, 3 v_cvt_pk_bf16_f32, 4 v_pk_mul_f32, 5 v_pk_add_f32, 6 v_add_f32, 7 v_rcp_f32,
+// 8 the prologue of one halo dword in plain instructions (4 fma, 2 exp, 2 add, 2 rcp, 2 mul, 1 cvt_pk = 13), 9 the same packed
+// (2 pk_fma, 2 exp, 1 pk_add, 2 rcp, 1 pk_mul, 1 cvt_pk = 9), 10 ds_write_b128, 11 ds_read_b128, 12 v_mul_f32 + v_and/v_lshl (unpack).
+// flags: bit 0 MFMA waves run, bit 1 VALU waves run, bit 2 s_setprio 3 on the MFMA waves, bit 3 s_setprio 3 on the VALU waves,
+// bit 4 16x16x32 MFMAs.
+typedef float f32x2_d __attribute__((ext_vector_type(2)));
+typedef float f32x4_d __attribute__((ext_vector_type(4)));
+template <int KIND>
+__global__ void __launch_bounds__(512, 1) issue_probe_kernel(int n_inner, int iters, int flags, long long* __restrict__ sink) {
+    __shared__ __attribute__((aligned(16))) char plds[512 * 16 * 2];
+    const int wave = threadIdx.x >> 6;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (wave < 4) {
+        if (!(flags & 1)) return;
+        if (flags & 4) __builtin_amdgcn_s_setprio(3);
+        bf16x8_d a, b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            a[e] = (__bf16)(float)((threadIdx.x * 7 + e) % 13 - 6);
+            b[e] = (__bf16)(float)(((threadIdx.x ^ e) * 5) % 11 - 5);
+        }
+        float out = 0.f;
+        long long t0, t1;
+        if (flags & 16) {
+            f32x4_d acc[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[k] = f32x4_d{0.f, 0.f, 0.f, 0.f};
+            t0 = (long long)__builtin_amdgcn_s_memtime();
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[k]) : "v"(a), "v"(b));
+            }
+            t1 = (long long)__builtin_amdgcn_s_memtime();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) out += acc[k][0] + acc[k][3];
+        } else {
+            f32x16_d acc[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[k][j] = 0.f;
+            t0 = (long long)__builtin_amdgcn_s_memtime();
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[k]) : "v"(a), "v"(b));
+            }
+            t1 = (long long)__builtin_amdgcn_s_memtime();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) out += acc[k][0] + acc[k][15];
+        }
+        if (threadIdx.x == 0) sink[2 * blockIdx.x] = t1 - t0;
+        if (out == 12345.678f) sink[2 * blockIdx.x] = 0;
+        return;
+    }
+    if (!(flags & 2)) return;
+    if (flags & 8) __builtin_amdgcn_s_setprio(3);
+    float v[8], w[8];
+    f32x2_d pv[8];
+    unsigned u[8];
+    const float sc = 1.0000001f, sh = 1e-9f;
+    const f32x2_d psc = {1.0000001f, 0.9999999f}, psh = {1e-9f, -1e-9f};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        v[e] = 0.1f * e + threadIdx.x * 1e-3f;
+        w[e] = 0.f;
+        pv[e] = f32x2_d{v[e], -v[e]};
+        u[e] = 0u;
+    }
+    const unsigned laddr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)plds + (threadIdx.x & 255) * 16;
+    f32x4_d lv = {1.f, 2.f, 3.f, 4.f};
+    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        for (int j = 0; j < n_inner; ++j) {
+            if constexpr (KIND == 8) {  // one halo dword (two channels), plain instructions
+                asm volatile("v_fma_f32 %0, %4, %5, %6\n\tv_fma_f32 %1, %4, %5, %6\n\tv_fma_f32 %2, %4, %6, %5\n\tv_fma_f32 %3, %4, %6, %5"
+                             : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]) : "v"(v[0]), "v"(sc), "v"(sh));
+                asm volatile("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\tv_add_f32 %0, 1.0, %0\n\tv_add_f32 %1, 1.0, %1\n\tv_rcp_f32 %0, %0\n\tv_rcp_f32 %1, %1"
+                             : "+v"(w[2]), "+v"(w[3]));
+                asm volatile("v_mul_f32 %0, %0, %2\n\tv_mul_f32 %1, %1, %3\n\tv_cvt_pk_bf16_f32 %4, %0, %1"
+                             : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "=v"(u[0]));
+            } else if constexpr (KIND == 9) {  // the same, packed
+                f32x2_d y, e2;
+                asm volatile("v_pk_fma_f32 %0, %2, %3, %4\n\tv_pk_fma_f32 %1, %2, %4, %3" : "=&v"(y), "=&v"(e2) : "v"(pv[0]), "v"(psc), "v"(psh));
+                e2 = f32x2_d{__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])};
+                asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(e2) : "v"(psc));
+                e2 = f32x2_d{__builtin_amdgcn_rcpf(e2[0]), __builtin_amdgcn_rcpf(e2[1])};
+                asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(y) : "v"(e2));
+                asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u[0]) : "v"(y[0]), "v"(y[1]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if constexpr (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[e]) : "v"(sc), "v"(sh));
+                    if constexpr (KIND == 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(pv[e]) : "v"(psc), "v"(psh));
+                    if constexpr (KIND == 2) asm volatile("v_exp_f32 %0, %1" : "=v"(w[e]) : "v"(v[e]));
+                    if constexpr (KIND == 3) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u[e]) : "v"(v[e]), "v"(sc));
+                    if constexpr (KIND == 4) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(pv[e]) : "v"(psc));
+                    if constexpr (KIND == 5) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(pv[e]) : "v"(psh));
+                    if constexpr (KIND == 6) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[e]) : "v"(sh));
+                    if constexpr (KIND == 7) asm volatile("v_rcp_f32 %0, %1" : "=v"(w[e]) : "v"(v[e]));
+                    if constexpr (KIND == 10) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(laddr), "v"(lv), "n"((e & 1) * 4096) : "memory");
+                    if constexpr (KIND == 11) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(lv) : "v"(laddr), "n"((e & 1) * 4096) : "memory");
+                    if constexpr (KIND == 12) {
+                        if (e & 1) asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(u[e]) : "v"(u[e ^ 1]));
+                        else asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(u[e]) : "v"(u[e ^ 1]));
+                    }
+                }
+                if constexpr (KIND == 10 || KIND == 11) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+    }
+    const long long t1 = (long long)__builtin_amdgcn_s_memtime();
+    float out = lv[0] + lv[3];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out += v[e] + w[e] + pv[e][0] + pv[e][1] + (float)u[e];
+    if (threadIdx.x == 256) sink[2 * blockIdx.x + 1] = t1 - t0;
+    if (out == 12345.678f) sink[2 * blockIdx.x + 1] = 0;
+#endif
+}
+int launch_issue_probe(int kind, int n_inner, int iters, int flags, int blocks, long long* sink, hipStream_t s) {
+    DMME_REQUIRE(kind >= 0 && kind <= 12 && n_inner >= 0 && iters > 0 && blocks > 0 && sink, DMME_ERR_INVALID, "issue_probe: bad argument");
+#define IP_CASE(K) if (kind == K) hipLaunchKernelGGL(issue_probe_kernel<K>, dim3((unsigned)blocks), dim3(512), 0, s, n_inner, iters, flags, sink);
+    IP_CASE(0) IP_CASE(1) IP_CASE(2) IP_CASE(3) IP_CASE(4) IP_CASE(5) IP_CASE(6) IP_CASE(7) IP_CASE(8) IP_CASE(9) IP_CASE(10) IP_CASE(11) IP_CASE(12)
+#undef IP_CASE
+    DMME_CHECK_LAUNCH();
+    return DMME_OK;
+}
+
 int launch_l2_stream(const void* buf, int64_t bytes, int iters, int mode, int depth, int blocks, unsigned* sink, hipStream_t s) {
     const int nvec = (int)(bytes / 16);
     DMME_REQUIRE(buf && sink && nvec >= 16 * 256 && iters > 0 && blocks > 0, DMME_ERR_INVALID, "l2_stream: bad argument");

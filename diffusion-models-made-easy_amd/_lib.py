@@ -132,7 +132,7 @@ PROTOTYPES = {
     "dmme_event_destroy": (_i, [_vp]),
     "dmme_debug_set_stamps": (_i, [_vp]),
     "dmme_debug_mfma_valu": (_i, [_i, _i, _i, _vp, _vp]),
-    "dmme_debug_issue_probe": (_i, [_i, _i, _i, _i, _i, _vp, _vp]),
+    "dmme_debug_issue_probe": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "dmme_debug_l2_stream": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp]),
 }
 

@@ -239,7 +239,7 @@ struct ConvArgs {
 // ---- kernel launchers (defined in the .hip files) ------------------------------------
 int launch_conv_generic(int dtype, const ConvArgs& a, hipStream_t s);
 int launch_mfma_valu(int mode, int iters, int blocks, float* sink, hipStream_t s);
-int launch_issue_probe(int kind, int n_inner, int iters, int flags, int blocks, long long* sink, hipStream_t s);
+int launch_issue_probe(int kind, int n_inner, int iters, int flags, int blocks, long long* sink, const void* src, hipStream_t s);
 int launch_l2_stream(const void* buf, int64_t bytes, int iters, int mode, int depth, int blocks, unsigned* sink, hipStream_t s);
 const char* conv_generic_kernel_name(const ConvArgs& a);
 bool conv_in_stats_query(int dtype, const ConvArgs& a, int cg, int* tiles, int* px);

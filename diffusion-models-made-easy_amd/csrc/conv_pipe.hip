@@ -568,7 +568,11 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             const int iy = t.oy0 - 1 + hy, ix = t.ox0 - 1 + hx;
             const bool in = iy >= 0 && iy < Hv && ix >= 0 && ix < Wv && !(a.up == 2 && ((iy | ix) & 1));
             const int sy = a.up ? (iy >> 1) : iy, sx = a.up ? (ix >> 1) : ix;
+#ifdef WS_SAME_IMAGE  /* timing experiment (wrong results): every tile reads one of eight images, so the halo loads hit L2 */
+            return row >= g.a_rows ? -2 : in ? ((t.n0 & 7) * a.Hin + sy) * a.Win + sx : -1;
+#else
             return row >= g.a_rows ? -2 : in ? (t.n0 * a.Hin + sy) * a.Win + sx : -1;
+#endif
         };
         auto set_pix = [&](int i, const TileXY& t) __attribute__((always_inline)) { a_pix[i] = pix_unit(i, t); };
         const char* wbase = (const char*)a.w;
@@ -684,6 +688,13 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         // the counted waits written out below.  This is what lets a tap be requested TWO stages ahead of its use: a DMA takes ~2.4 k
         // cycles from issue to landed under load, a stage ~2 k (stamps, tools/stamp_ws.py)
         auto dma_tap = [&](char* dstR, int co0, int c, int t) __attribute__((always_inline)) {
+#if defined(WS_X_NO_DMA)  /* timing experiment (wrong results): the filter stream becomes 16-byte loads of ONE line per instruction */
+            {
+                const char* ub1 = wbase + ((size_t)co0 * 9 * CinW + (size_t)t * CinW + (size_t)c * KC) * 2;
+                _Pragma("unroll") for (int k4 = 0; k4 < UB; ++k4) glds16_hidden(ub1 + (lane & 7) * 16, (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(size_t)(lds_c*)dstR + (unsigned)(pw * 8 * ROW_DATA) + (unsigned)(32 * k4 * ROW_DATA))));
+                return;
+            }
+#endif
             const unsigned lbase = (unsigned)(size_t)(lds_c*)dstR + (unsigned)(pw * 8 * ROW_DATA);
             const char* ub = wbase + ((size_t)co0 * 9 * CinW + (size_t)t * CinW + (size_t)c * KC) * 2;
 #pragma unroll
@@ -758,8 +769,11 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             if (do_store) store_A((i), dstA, 1);                            \
         } else {                                                            \
             if (do_store) store_A((i), dstA);                               \
+            WS_PSTT(1)                                                      \
             if (new_tile) set_pix((i), tnn);                                \
+            WS_PSTT(2)                                                      \
             load_A((i), lc);                                                \
+            WS_PSTT(3)                                                      \
         }                                                                   \
     }
 #define WS_A_ARRIVED(i) { asm volatile("" : "+v"(areg[i][0]), "+v"(areg[i][1]), "+v"(areg[i][2]), "+v"(areg[i][3])); }
@@ -768,10 +782,14 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         // stage s - 1 read last.  A tile's epilogue stages through R1 | R2 | A1, so across a tile boundary only tap 0 (R0) is sent
         // ahead; the new tile's first stage requests taps 1 and 2 together.
 #ifdef WS_PSTAMPS
-#define WS_PST() { if (a.stamps && ptid == 0 && blockIdx.x == 0 && p_i < 400) a.stamps[128 + p_i++] = (long long)clock64(); }
+        // producer stamps go to LDS (4 KB behind the parameter rows) and to memory when the wave leaves: a global store per stamp would
+        // join the vmcnt queue and shift every counted wait below by one
+        long long* pst_lds = reinterpret_cast<long long*>(reinterpret_cast<char*>(par_base) + 2 * 4 * Cin * 4);
+#define WS_PSTT(TAG) { if (a.stamps && ptid == 0 && blockIdx.x == 0 && p_i < 500) pst_lds[p_i++] = (long long)clock64() | ((long long)(TAG) << 56); }
 #else
-#define WS_PST()
+#define WS_PSTT(TAG)
 #endif
+#define WS_PST() WS_PSTT(0)
 #define WS_L(TP) (PIPE_UA == 11 ? (((TP) == 0 || (TP) == 8) ? 2 : 1) : ((TP) < 7 ? 1 : 0)) /* halo loads a stage issues (behind its DMA) */
         // RSEG, the LAST main chunk of a tile: no halo loads; behind their tap stages 5 / 6 request the pixels of the segment's half-stages
         // 0 / 1 (4 instructions each), stage 7 both filter blocks (2 + 2).  Requests a stage issues / of those, the ones behind its tap
@@ -818,6 +836,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             }                                                                                                           \
         }                                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
+        WS_PST()                                                                                                        \
         {                                                                                                               \
             const bool do_store = have_n;                                                                               \
             char* dstA = WS_BUFA(cg + 1);                                                                               \
@@ -879,6 +898,12 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
                     }                                                                                                   \
                 }                                                                                                       \
                 WS2_EPILOGUE(tcur, kt, ;, ;)                                                                                   \
+                /* a wait the COMPILER sees: the epilogue's conditional residual loads and their conditional uses are correlated \
+                   branches it cannot prove, so it carried "a load into these registers may still be pending" around the loop \
+                   and put `s_waitcnt vmcnt(0)` in front of stage 0's DMA - draining the halo prefetch at EVERY chunk start \
+                   (the 1.6-2.2 k-cycle consumer wait at tap 0, tools/stamp_ws.py).  Here everything in flight (the next    \
+                   tile's second chunk, its tap 0) was requested before the epilogue: it has landed */                       \
+                __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0) only */                                                  \
                 cc = 0;                                                                                                 \
                 ++kt;                                                                                                   \
                 tcur = tnext;                                                                                           \
@@ -890,11 +915,16 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         for (int ch = 0; ch < GCH; ++ch) {
             WS_PSTAGE(0) WS_PSTAGE(1) WS_PSTAGE(2) WS_PSTAGE(3) WS_PSTAGE(4) WS_PSTAGE(5) WS_PSTAGE(6) WS_PSTAGE(7) WS_PSTAGE(8)
         }
+#ifdef WS_PSTAMPS
+        if (a.stamps && ptid == 0 && blockIdx.x == 0)
+            for (int i = 0; i < p_i; ++i) a.stamps[128 + i] = pst_lds[i];
+#endif
 #undef WS_PSTAGE
 #undef WS_RD
 #undef WS_RX
 #undef WS_L
 #undef WS_PST
+#undef WS_PSTT
 #undef WS_A_UNIT
 #undef WS_A_ARRIVED
         return;
@@ -939,18 +969,36 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.f;
+#if defined(WS_X_NO_FRAGS)  /* timing experiments (wrong results): no fragment reads / no MFMAs */
+#define WS_FRAGS(SET, KG)                                                                                                         \
+    {                                                                                                                             \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) { u32x4 t_; asm volatile("" : "=v"(t_)); af[SET][mi] = __builtin_bit_cast(uint4, t_); }   \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) { u32x4 t_; asm volatile("" : "=v"(t_)); bfr[SET][ni] = __builtin_bit_cast(uint4, t_); }  \
+        __builtin_amdgcn_sched_barrier(0);                                                                                        \
+    }
+#else
 #define WS_FRAGS(SET, KG)                                                                                                         \
     {                                                                                                                             \
         _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) af[SET][mi] = *reinterpret_cast<const uint4*>(pa[mi] + (KG) * 32);      \
         _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) bfr[SET][ni] = *reinterpret_cast<const uint4*>(ldsR + b_off[ni][KG]);   \
         __builtin_amdgcn_sched_barrier(0);                                                                                        \
     }
+#endif
+#if defined(WS_X_NO_MFMA)
+#define WS_MMAS(SET)                                                                                  \
+    {                                                                                                 \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, af[SET][mi])));   \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, bfr[SET][ni])));  \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    }
+#else
 #define WS_MMAS(SET)                                                                                  \
     {                                                                                                 \
         _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                             \
             _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_group(af[SET][mi], bfr[SET][ni], acc[mi][ni], (T*)nullptr); \
         __builtin_amdgcn_sched_barrier(0);                                                            \
     }
+#endif
 #define WS_FA(SET, KG) { _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) af[SET][mi] = *reinterpret_cast<const uint4*>(pa[mi] + (KG) * 32); }
 #define WS_FB(SET, KG) { _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) bfr[SET][ni] = *reinterpret_cast<const uint4*>(ldsR + b_off[ni][KG]); }
 #define WS_SB() __builtin_amdgcn_sched_barrier(0);
@@ -1047,7 +1095,11 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
 
 static size_t ws2_lds(const ConvArgs& a, const ConvTile& g) {
     const size_t a_bytes = (size_t)g.a_rows * (ROW_DATA + 16);
-    return 2 * a_bytes + 3 * (size_t)128 * ROW_DATA + (size_t)ws2_stage_pad((int)a_bytes) + (size_t)2 * 4 * (a.C1 + a.C2) * 4;
+    size_t extra = 0;
+#ifdef WS_PSTAMPS
+    extra = 4096;
+#endif
+    return 2 * a_bytes + 3 * (size_t)128 * ROW_DATA + (size_t)ws2_stage_pad((int)a_bytes) + (size_t)2 * 4 * (a.C1 + a.C2) * 4 + extra;
 }
 
 // the wave-specialised kernel applies (else 0): its tile goes to g

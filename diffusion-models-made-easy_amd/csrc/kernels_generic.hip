@@ -964,8 +964,8 @@ int launch_mfma_valu(int mode, int iters, int blocks, float* sink, hipStream_t s
 typedef float f32x2_d __attribute__((ext_vector_type(2)));
 typedef float f32x4_d __attribute__((ext_vector_type(4)));
 template <int KIND>
-__global__ void __launch_bounds__(512, 1) issue_probe_kernel(int n_inner, int iters, int flags, long long* __restrict__ sink) {
-    __shared__ __attribute__((aligned(16))) char plds[512 * 16 * 2];
+__global__ void __launch_bounds__(512, 1) issue_probe_kernel(int n_inner, int iters, int flags, long long* __restrict__ sink, const char* __restrict__ src) {
+    __shared__ __attribute__((aligned(16))) char plds[KIND >= 13 ? 64 * 1024 : 512 * 16 * 2];
     const int wave = threadIdx.x >> 6;
 #if defined(__HIP_DEVICE_COMPILE__)
     if (wave < 4) {
@@ -998,6 +998,19 @@ __global__ void __launch_bounds__(512, 1) issue_probe_kernel(int n_inner, int it
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[k][j] = 0.f;
             t0 = (long long)__builtin_amdgcn_s_memtime();
+            if (flags & 32) {  // with the conv consumer's LDS traffic: six 16-byte fragment reads per eight MFMAs
+                const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) char*)plds + (threadIdx.x & 255) * 16;
+                f32x4_d fr[6];
+                for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[q]) : "v"(la), "n"(q * 4096) : "memory");
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[k]) : "v"(a), "v"(b));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) asm volatile("" ::"v"(fr[q]));
+                }
+            } else
             for (int it = 0; it < iters; ++it) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[k]) : "v"(a), "v"(b));
@@ -1057,12 +1070,23 @@ __global__ void __launch_bounds__(512, 1) issue_probe_kernel(int n_inner, int it
                     if constexpr (KIND == 7) asm volatile("v_rcp_f32 %0, %1" : "=v"(w[e]) : "v"(v[e]));
                     if constexpr (KIND == 10) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(laddr), "v"(lv), "n"((e & 1) * 4096) : "memory");
                     if constexpr (KIND == 11) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(lv) : "v"(laddr), "n"((e & 1) * 4096) : "memory");
+                    if (KIND >= 13 && e != 0) continue;  // ONE request per inner iteration: n_inner / 8 per MFMA slot (the conv's producers: 1 / 8)
+                    if constexpr (KIND == 13) {  // LDS-DMA of 1 KB: eight 128-byte rows 2304 bytes apart (a filter tap's access shape), 16 KB ring per wave
+                        const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(size_t)(__attribute__((address_space(3))) char*)plds + (unsigned)((wave - 4) * 16384 + (j & 15) * 1024)));
+                        const char* g = src + (size_t)(((threadIdx.x & 63) >> 3) * 2304 + (threadIdx.x & 7) * 16) + (size_t)(((it * 5 + j) & 63) * 8 * 2304);
+                        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "m0", "memory");
+                    }
+                    if constexpr (KIND == 14) {  // the same 1 KB into registers
+                        const char* g = src + (size_t)(((threadIdx.x & 63) >> 3) * 2304 + (threadIdx.x & 7) * 16) + (size_t)(((it * 5 + j) & 63) * 8 * 2304);
+                        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lv) : "v"(g) : "memory");
+                    }
                     if constexpr (KIND == 12) {
                         if (e & 1) asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(u[e]) : "v"(u[e ^ 1]));
                         else asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(u[e]) : "v"(u[e ^ 1]));
                     }
                 }
                 if constexpr (KIND == 10 || KIND == 11) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if constexpr (KIND == 13 || KIND == 14) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // eight requests stay in flight per wave
             }
         }
     }
@@ -1074,10 +1098,10 @@ __global__ void __launch_bounds__(512, 1) issue_probe_kernel(int n_inner, int it
     if (out == 12345.678f) sink[2 * blockIdx.x + 1] = 0;
 #endif
 }
-int launch_issue_probe(int kind, int n_inner, int iters, int flags, int blocks, long long* sink, hipStream_t s) {
-    DMME_REQUIRE(kind >= 0 && kind <= 12 && n_inner >= 0 && iters > 0 && blocks > 0 && sink, DMME_ERR_INVALID, "issue_probe: bad argument");
-#define IP_CASE(K) if (kind == K) hipLaunchKernelGGL(issue_probe_kernel<K>, dim3((unsigned)blocks), dim3(512), 0, s, n_inner, iters, flags, sink);
-    IP_CASE(0) IP_CASE(1) IP_CASE(2) IP_CASE(3) IP_CASE(4) IP_CASE(5) IP_CASE(6) IP_CASE(7) IP_CASE(8) IP_CASE(9) IP_CASE(10) IP_CASE(11) IP_CASE(12)
+int launch_issue_probe(int kind, int n_inner, int iters, int flags, int blocks, long long* sink, const void* src, hipStream_t s) {
+    DMME_REQUIRE((kind < 13 || src) && kind >= 0 && kind <= 14 && n_inner >= 0 && iters > 0 && blocks > 0 && sink, DMME_ERR_INVALID, "issue_probe: bad argument");
+#define IP_CASE(K) if (kind == K) hipLaunchKernelGGL(issue_probe_kernel<K>, dim3((unsigned)blocks), dim3(512), 0, s, n_inner, iters, flags, sink, (const char*)src);
+    IP_CASE(13) IP_CASE(14) IP_CASE(0) IP_CASE(1) IP_CASE(2) IP_CASE(3) IP_CASE(4) IP_CASE(5) IP_CASE(6) IP_CASE(7) IP_CASE(8) IP_CASE(9) IP_CASE(10) IP_CASE(11) IP_CASE(12)
 #undef IP_CASE
     DMME_CHECK_LAUNCH();
     return DMME_OK;

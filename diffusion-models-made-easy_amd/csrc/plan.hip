@@ -1831,8 +1831,8 @@ DMME_API int dmme_mse_loss(const float* eps, const float* target, int64_t numel,
     return launch_mse(eps, target, numel, loss, d_eps, grad_scale, scratch, (hipStream_t)stream);
 }
 
-DMME_API int dmme_debug_issue_probe(int kind, int n_inner, int iters, int flags, int blocks, void* sink, void* stream) {
-    return launch_issue_probe(kind, n_inner, iters, flags, blocks, (long long*)sink, (hipStream_t)stream);
+DMME_API int dmme_debug_issue_probe(int kind, int n_inner, int iters, int flags, int blocks, void* sink, const void* src, void* stream) {
+    return launch_issue_probe(kind, n_inner, iters, flags, blocks, (long long*)sink, src, (hipStream_t)stream);
 }
 DMME_API int dmme_debug_mfma_valu(int mode, int iters, int blocks, void* sink, void* stream) {
     DMME_REQUIRE(sink && iters > 0 && blocks > 0, DMME_ERR_INVALID, "mfma_valu: bad argument");

@@ -202,9 +202,11 @@ DMME_API int dmme_debug_mfma_valu(int mode, int iters, int blocks, void* sink, v
  * MFMA wave on the same SIMD, cost either wave - all inline asm, per-wave cycle counts (s_memtime) into sink[2 b] (MFMA wave 0) and
  * sink[2 b + 1] (vector wave 4), `blocks` x 2 int64.  kind: 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_exp_f32, 3 v_cvt_pk_bf16_f32,
  * 4 v_pk_mul_f32, 5 v_pk_add_f32, 6 v_add_f32, 7 v_rcp_f32, 8 / 9 the GroupNorm + SiLU prologue of one halo dword in plain / packed
- * instructions, 10 ds_write_b128, 11 ds_read_b128, 12 bf16 unpack (shift / mask).  flags: bit 0 MFMA waves run, bit 1 vector waves
- * run, bit 2 / 3 s_setprio 3 on the MFMA / vector waves, bit 4 16x16x32 instead of 32x32x16 MFMAs. */
-DMME_API int dmme_debug_issue_probe(int kind, int n_inner, int iters, int flags, int blocks, void* sink, void* stream);
+ * instructions, 10 ds_write_b128, 11 ds_read_b128, 12 bf16 unpack (shift / mask), 13 / 14 a 1-KB request in a filter tap's access shape
+ * (eight 128-byte rows 2304 bytes apart out of `src`, >= 1.2 MB, L2-resident) by LDS-DMA / into registers, eight in flight per wave.
+ * flags: bit 0 MFMA waves run, bit 1 vector waves run, bit 2 / 3 s_setprio 3 on the MFMA / vector waves, bit 4 16x16x32 instead of
+ * 32x32x16 MFMAs, bit 5 the MFMA waves also read six 16-byte LDS fragments per eight MFMAs. */
+DMME_API int dmme_debug_issue_probe(int kind, int n_inner, int iters, int flags, int blocks, void* sink, const void* src, void* stream);
 DMME_API int dmme_debug_l2_stream(const void* buf, int64_t bytes, int iters, int mode, int depth, int blocks, void* sink, void* stream);
 /* global L2 norm of a flat fp32 gradient buffer (clip_grad_norm_; scratch: 1024 floats) */
 DMME_API int dmme_grad_norm(const float* grad, int64_t numel, float* norm_out, float* scratch, void* stream);

@@ -63,11 +63,24 @@ print("wait per stage:", d[2::2][:31])
 e = [int(t) for t in stamps.cpu()[64:88] if int(t) != 0]
 print("epilogue stamps (pass start, after conv_epilogue, after barrier) deltas:", [e[i + 1] - e[i] for i in range(len(e) - 1)])
 
-pv = [int(t) for t in stamps.cpu()[128:528] if int(t) != 0]
+pv = [int(t) for t in stamps.cpu()[128:628] if int(t) != 0]
+if pv and os.environ.get("PSTAMPS_TAGGED"):
+    # tagged stamps (tag in the top byte): 0 = the five stage stamps, 1 / 2 / 3 = after a unit's store / coordinates / load
+    tg = [(t >> 56) & 0xff for t in pv]; ck = [t & ((1 << 56) - 1) for t in pv]
+    line = []; nstage = 0; zeros = 0
+    for i in range(1, len(pv)):
+        if tg[i] == 0:
+            zeros += 1
+        line.append(f"{'sulS'[tg[i]] if tg[i] else 'S'}{ck[i] - ck[i - 1]}")
+        if tg[i] == 0 and zeros % 5 == 0:
+            print(f"  st{nstage:2d} (tap {nstage % 9}): " + " ".join(line)); line = []; nstage += 1
+            if nstage >= 22: break
+    pv = []
 if pv:
-    # four stamps per producer stage: entry, halo data arrived, units done, DMA retired (then the barrier)
-    rows = [pv[i:i + 4] for i in range(0, len(pv) - 3, 4)]
-    print("producer wave 4, per stage: [halo-arrive wait, dma+units, vm wait, barrier+next] (cycles)")
+    # five stamps per producer stage: entry, halo data arrived, DMA issued, units done, DMA retired (then the barrier)
+    NP = int(os.environ.get("PSTAMPS_PER_STAGE", "5"))
+    rows = [pv[i:i + NP] for i in range(0, len(pv) - NP + 1, NP)]
+    print("producer wave 4, per stage: [halo-arrive wait, dma issue, units, vm wait, barrier+next] (cycles)")
     for i in range(min(len(rows) - 1, 40)):
         r = rows[i]
-        print(f"  st{i:2d} (tap {i % 9}): {r[1]-r[0]:5d} {r[2]-r[1]:5d} {r[3]-r[2]:5d} {rows[i+1][0]-r[3]:5d}")
+        print(f"  st{i:2d} (tap {i % 9}): " + " ".join(f"{r[k+1]-r[k]:5d}" for k in range(NP - 1)) + f" {rows[i+1][0]-r[NP-1]:5d}")

@@ -457,6 +457,15 @@ struct WsSplit<T, 2> {
 template <int PIPE_UA, typename T = bf16, int BM = 256, int SPLIT = 0, bool RSEG = false>
 __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTile g, int shTW, int shTH, int ntiles) {
     constexpr int KC = 64, EPV = 8, BN = 128, MI = BM / 64, NI = 2, UB = BN / 32;
+    // CDMA (round 5): the filter taps are requested by the CONSUMER waves, behind the barrier that opens a stage, where their matrix
+    // pipe waits for the stage's first fragments anyway.  Producer stamps (tools/stamp_ws.py, -DWS_PSTAMPS) had put the four LDS-DMA
+    // instructions of a stage at ~1.3 k cycles of the producer wave - an LDS-DMA beside a SATURATED matrix pipe costs its wave ~250
+    // cycles (tools/issue_probe.py kind 13), beside one that waits for LDS ~16 - which made the producer the longer half of every stage
+    // and, in the stages that carry two halo units, the whole stage 0.6-2 k cycles longer.  -DWS_CDMA=0: the producers request them.
+#ifndef WS_CDMA
+#define WS_CDMA 1
+#endif
+    constexpr bool CDMA = WS_CDMA != 0;
     static_assert(!RSEG || (SPLIT == 0 && sizeof(T) == 2), "residual segment: 16-bit tensors");
     constexpr int KCR = SPLIT ? 32 : KC;  // input channels per chunk (KC = 16-bit k-slots per 128-byte row)
     constexpr int EPR = SPLIT ? 4 : EPV;  // input channels per producer lane and halo unit
@@ -815,6 +824,8 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         WS_PST()                                                                                                        \
         bool sent = true;          /* this stage sent a tap two stages ahead */                                         \
         bool sent_next = false;    /* ... and, in front of it, the NEXT stage's tap (first stage of a later tile) */    \
+        if constexpr (CDMA) { /* the consumers request the taps (below) */ }                                            \
+        else {                                                                                                          \
         if ((TP) == 0 && cc == 0 && kt > 0) {                                                                           \
             dma_tap(WS_RING(1), tcur.co0, 0, 1);                                                                        \
             sent_next = true;                                                                                           \
@@ -827,6 +838,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         } else {                                                                                                        \
             if (have_n && nk == kt) dma_tap(WS_RING(1), tcur.co0, nc, 1);                                               \
             else sent = false;                                                                                          \
+        }                                                                                                               \
         }                                                                                                               \
         if constexpr (RSEG) {  /* pixel slots 0 / 1 lie in A0 (free since the previous chunk ended), filter slots 0 / 1 in R0 (tap 6 */ \
             if (last_c) {      /* was its last reader: free from stage 7 on - so the filter blocks of BOTH go out at stage 5 / 6   */ \
@@ -854,7 +866,13 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         /* the NEXT stage's tap must have landed; whatever was issued after it may stay in flight: the previous stage's  \
            halo loads, this stage's DMA (UB instructions) and halo loads - or, when that tap went out in this very stage, \
            only the second DMA and the loads */                                                                         \
-        if (RSEG && last_c) {                                                                                           \
+        if constexpr (CDMA) {                                                                                           \
+            /* no tap to retire: the halo prefetch is waited for where it is used (WS_A_ARRIVED), the halo stores by lgkmcnt; \
+               the residual segment's first slots (requested in stages 5 - 7) must have landed when stage 8 hands over */ \
+            if (RSEG && last_c && (TP) == 8) wait_vm_keep<2>();                                                         \
+            else wait_lgkm_all();                                                                                       \
+        }                                                                                                               \
+        else if (RSEG && last_c) {                                                                                      \
             /* stage 8 hands over to half-stage 0, whose filter block went out first in stage 7: only the second stays */ \
             if ((TP) == 0) wait_vm_keep<WS_L(8) + UB>();                                                                \
             else if ((TP) <= 6) wait_vm_keep<WS_RX(((TP) + 8) % 9) + WS_RD(TP)>();                                      \
@@ -952,6 +970,20 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) b_off[ni][kg] = row * ROW_DATA + (((kg * 2 + h) ^ ((row >> 1) & 7)) << 4);
     }
+    // CDMA: wave w requests rows 8 w + 32 k4 + (lane >> 3) of a tap (k4 < UB), LDS piece lane & 7 <- source piece (lane & 7) ^ ((row >> 1) & 7)
+    unsigned cb_vo[UB];
+#pragma unroll
+    for (int k4 = 0; k4 < UB; ++k4) {
+        const int urow_ = wave * 8 + (lane >> 3);
+        cb_vo[k4] = (unsigned)(((urow_ + 32 * k4) * 9 * CinW + ((lane & 7) ^ ((urow_ >> 1) & 7)) * EPV) * 2);
+    }
+    auto cdma = [&](int slot, int co0, int c, int t) __attribute__((always_inline)) {
+        const char* ub = (const char*)a.w + ((size_t)co0 * 9 * CinW + (size_t)t * CinW + (size_t)c * KC) * 2;
+        const unsigned lbase = (unsigned)(size_t)(lds_c*)WS_RING(slot) + (unsigned)(wave * 8 * ROW_DATA);
+#pragma unroll
+        for (int k4 = 0; k4 < UB; ++k4)
+            glds16_hidden_s(ub, cb_vo[k4], (unsigned)__builtin_amdgcn_readfirstlane((int)(lbase + (unsigned)(32 * k4 * ROW_DATA))));
+    };
     // diagnostic cycle stamps (a.stamps null: off): consumer wave 0 of workgroup 0, [arrive, leave] of every barrier
     int stamp_i = 0;
     const bool stamping = a.stamps && tid == 0 && blockIdx.x == 0;
@@ -1008,8 +1040,10 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_group(af[SA][mi], bfr[SB_][ni], acc[mi][ni], (T*)nullptr); \
         __builtin_amdgcn_sched_barrier(0);                                                            \
     }
+        const TileXY tn = WS_TILE(kt + 1 < K ? kt + 1 : kt);
         for (int c = 0; c < nchunks; ++c, ++cg) {
             const char* ldsA = WS_BUFA(cg);
+            const bool last_c = c + 1 == nchunks;
 #pragma unroll 3
             for (int tp = 0; tp < 9; ++tp) {
                 const char* ldsR = WS_RING(tp % 3);
@@ -1018,10 +1052,25 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) pa[mi] = ldsA + a_row[mi] + tap_b;
                 uint4 af[2][MI], bfr[2][NI];
+                // CDMA: the tap of stage s + 2 into ring slot (s + 2) % 3, which stage s - 1 read last (every wave is behind that stage's
+                // barrier); a tile's epilogue stages through R1 | R2, so across a tile boundary only tap 0 (R0) goes ahead and the new
+                // tile's first stage requests taps 1 and 2 together; with the residual segment the producers send the next tile's
+                // tap 0 in the segment's last stage.  Behind the stage's first fragment reads: the matrix pipe waits for those anyway
+                bool sent = false;
+#define WS_CDMA_ISSUE()                                                                                               \
+    if constexpr (CDMA) {                                                                                             \
+        if (tp == 0 && c == 0 && kt > 0) cdma(1, t.co0, 0, 1);                                                        \
+        if (tp <= 6) { cdma((tp + 2) % 3, t.co0, c, tp + 2); sent = true; }                                           \
+        else if (RSEG && last_c) { }                                                                                  \
+        else if (tp == 7) { if (!(last_c && kt + 1 == K)) { cdma(0, last_c ? tn.co0 : t.co0, last_c ? 0 : c + 1, 0); sent = true; } } \
+        else if (!last_c) { cdma(1, t.co0, c + 1, 1); sent = true; }                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+    }
                 if constexpr (SPLIT != 0) {
                     // k-groups 0, 1 = hi halves of the chunk's 32 channels, 2, 3 = lo halves; two A slots and two B slots as in the plain
                     // schedule, every fragment set requested one MFMA group (8 MFMAs) ahead of its first use
                     WS_FA(0, 0) WS_FB(0, 0) WS_FB(1, 2) WS_SB()   // a0 = A.hi[0], b0 = W.hi[0], b1 = W.lo[0]
+                    WS_CDMA_ISSUE()
                     WS_MM(0, 0)                                   // hi.hi, channels 0-15
                     WS_FA(1, 2) WS_SB()                           // a1 = A.lo[0]
                     WS_MM(0, 1)                                   // hi.lo
@@ -1032,9 +1081,14 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
                     WS_MM(0, 0)                                   // hi.lo
                     WS_MM(1, 1)                                   // lo.hi
                 } else {
-                    WS_FRAGS(0, 0) WS_FRAGS(1, 1) WS_MMAS(0) WS_FRAGS(0, 2) WS_MMAS(1) WS_FRAGS(1, 3) WS_MMAS(0) WS_MMAS(1)
+                    WS_FRAGS(0, 0) WS_FRAGS(1, 1) WS_CDMA_ISSUE() WS_MMAS(0) WS_FRAGS(0, 2) WS_MMAS(1) WS_FRAGS(1, 3) WS_MMAS(0) WS_MMAS(1)
                 }
+#undef WS_CDMA_ISSUE
                 WS_STAMP()
+                if constexpr (CDMA) {  // the NEXT stage's tap has landed (this stage's own request may stay in flight)
+                    if (sent) wait_vm_keep<UB>();
+                    else wait_vm_keep<0>();
+                }
                 __syncthreads();
                 WS_STAMP()
             }

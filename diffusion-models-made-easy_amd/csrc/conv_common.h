@@ -80,6 +80,16 @@ __device__ __forceinline__ void wait_lgkm_all() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
 }
+// workgroup barrier that orders LDS accesses only.  __syncthreads() is a workgroup-scope release + acquire: behind a store loop hipcc puts
+// `s_waitcnt vmcnt(0)` in front of the s_barrier, i.e. every wave waits until its OUTPUT stores are acknowledged (1-2 k cycles under load)
+// although nobody in the workgroup reads them.  Epilogues that only reuse an LDS staging area use this one.
+__device__ __forceinline__ void lds_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#endif
+}
 template <int N>
 __device__ __forceinline__ void wait_vm_keep() {  // retire all but the N youngest vector-memory operations; all LDS operations
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -526,7 +536,10 @@ __device__ __forceinline__ bool conv_epilogue_is_staged(const ConvArgs& a, int T
     return !a.out_silu && !a.out_nchw && uniform_t && (a.Cout % VEC) == 0;
 }
 // MSTRIDE: staged rows between a wave's consecutive 32-row accumulator tiles (32: contiguous rows)
-template <typename T, int BN, int MI, int NI, int MSTRIDE = 32>
+// S16 (16-bit tensors, no residual input): the staged image holds the ROUNDED outputs, [BM][BN + 8] T (a 272-byte pitch: the two pixel
+// rows a store instruction touches - four apart - fall into different bank halves) - half the bytes, and one rounding as before
+constexpr int kStage16Pad = 8;
+template <typename T, int BN, int MI, int NI, int MSTRIDE = 32, bool S16 = false>
 __device__ __forceinline__ void conv_epilogue_stage(const ConvArgs& a, f32x16 (&acc)[MI][NI], int co0, int wn0, int r, int h, int wm0, int n0,
                                                     float* stage, bool with_trow = true) {
 #pragma unroll
@@ -543,7 +556,8 @@ __device__ __forceinline__ void conv_epilogue_stage(const ConvArgs& a, f32x16 (&
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int m = wm0 + mi * MSTRIDE + (j & 3) + 8 * (j >> 2) + 4 * h;
-                stage[m * BN + c] = acc[mi][ni][j] + fold;
+                if constexpr (S16) reinterpret_cast<T*>(stage)[m * (BN + kStage16Pad) + c] = (T)(acc[mi][ni][j] + fold);
+                else stage[m * BN + c] = acc[mi][ni][j] + fold;
             }
     }
 }
@@ -562,7 +576,7 @@ __device__ __forceinline__ void conv_epilogue_res_prefetch(const ConvArgs& a, in
 // direct_pass (wave-specialised kernel, whole-image tiles stored in two passes): -1 - statistics leave as partials; 0 - first pass, the
 // group threads keep their (mean, M2) in `carry`; 1 - second pass: merged with the carry, and the consuming norms (ConvArgs::gno) get
 // their scale / shift / {mean, rstd} rows from here - no finalize launch.
-template <typename T, int BM, int BN, int NT, typename PixFn>
+template <typename T, int BM, int BN, int NT, bool S16 = false, typename PixFn>
 __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, int co0, int n0, PixFn pix_of, float* stage, int tile_s,
                                                     const uint4* pre = nullptr, int direct_pass = -1, float* carry = nullptr) {
     constexpr int VEC = 16 / sizeof(T);
@@ -605,6 +619,11 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, int co0, 
                 if constexpr (dtype_of<T>::value == DMME_BF16) return f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
                 else return __builtin_convertvector(__builtin_bit_cast(tx2, w), f32x2);
             };
+            unsigned ow[4];
+            if constexpr (S16) {  // the staged values are the outputs
+                const uint4 sv = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(stage) + m * (BN + kStage16Pad) + cg * VEC);
+                ow[0] = sv.x; ow[1] = sv.y; ow[2] = sv.z; ow[3] = sv.w;
+            } else {
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
             f32x2 vp[4] = {f32x2{v0[0], v0[1]}, f32x2{v0[2], v0[3]}, f32x2{v1[0], v1[1]}, f32x2{v1[2], v1[3]}};
             if (res) {
@@ -613,13 +632,13 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, int co0, 
 #pragma unroll
                 for (int d = 0; d < 4; ++d) vp[d] = vp[d] + unpack2(rd[d]);
             }
-            unsigned ow[4];
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 const tx2 pk = {(T)vp[d][0], (T)vp[d][1]};
                 ow[d] = __builtin_bit_cast(unsigned, pk);
                 // (half: keeps the compiler from re-deriving the rounded values with single conversions from the fp32 inputs)
                 if constexpr (dtype_of<T>::value == DMME_F16) asm volatile("" : "+v"(ow[d]));
+            }
             }
             *reinterpret_cast<uint4*>(dst + off) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
 #pragma unroll
@@ -676,7 +695,7 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, int co0, 
             meanB = 0.5f * (meanB + oB);
             cnt *= 2.f;
         }
-        __syncthreads();  // all reads of the staged tile are done: reuse it for the exchange
+        lds_barrier();  // all reads of the staged tile are done: reuse it for the exchange
         const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
         if (ln < LPW) {
             float* q = stage + (wv * LPW + ln) * 4;
@@ -685,7 +704,7 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, int co0, 
             q[2] = meanB;
             q[3] = m2B;
         }
-        __syncthreads();
+        lds_barrier();
         const int GT = BN / cgs;  // groups in this cout tile
         if ((int)threadIdx.x < GT) {
             const int g = threadIdx.x;

@@ -364,6 +364,9 @@ static int pipe_ksplit(const ConvArgs& a, const ConvTile& g, int pick, int KC) {
 // vmcnt(0) at the first use of an ordinary load's result while an LDS-DMA is pending.  Consumer wait on a plain layer 450 -> 150
 // cycles per stage, nothing with the GroupNorm/SiLU prologue, 65.4 -> 64.1 us over the network's launches: asm loads bypass the
 // compiler's hazard tracking - too sharp a tool for 2 % of one kernel.  DESIGN.md section 4 keeps the numbers.)
+#ifndef WS_CDMA
+#define WS_CDMA 1
+#endif
 struct WsTile { int n0, oy0, ox0, co0, ts; };
 __device__ __forceinline__ WsTile ws_tile_of(const ConvTile& g, int shTW, int shTH, int kt, int bn) {
     const int t = (int)blockIdx.x + kt * (int)gridDim.x;
@@ -454,7 +457,10 @@ struct WsSplit<T, 2> {
 // The next tile's first chunk, which the main loop would have stored into A0 during those nine stages, is activated IN its registers
 // instead and written in the segment's last stage (a stage that reads neither slot 0 nor 1, or nothing: one empty stage is appended
 // where the count does not work out), together with the request for the next tile's tap 0 and second chunk.
-template <int PIPE_UA, typename T = bf16, int BM = 256, int SPLIT = 0, bool RSEG = false>
+// E16 (16-bit tensors, no residual input, 256-pixel tiles; CDMA): the epilogue stages the ROUNDED outputs - 34 KB per 128-pixel pass, inside
+// A1 alone - so the ring slots R1 / R2 are never the epilogue's and the filter stream runs two stages ahead ACROSS tile boundaries (the
+// next tile's taps 0 and 1 are requested in the last two stages, tap 2 in its first): no refill bubble at the head of a tile.
+template <int PIPE_UA, typename T = bf16, int BM = 256, int SPLIT = 0, bool RSEG = false, bool E16 = false>
 __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTile g, int shTW, int shTH, int ntiles) {
     constexpr int KC = 64, EPV = 8, BN = 128, MI = BM / 64, NI = 2, UB = BN / 32;
     // CDMA (round 5): the filter taps are requested by the CONSUMER waves, behind the barrier that opens a stage, where their matrix
@@ -462,10 +468,8 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
     // instructions of a stage at ~1.3 k cycles of the producer wave - an LDS-DMA beside a SATURATED matrix pipe costs its wave ~250
     // cycles (tools/issue_probe.py kind 13), beside one that waits for LDS ~16 - which made the producer the longer half of every stage
     // and, in the stages that carry two halo units, the whole stage 0.6-2 k cycles longer.  -DWS_CDMA=0: the producers request them.
-#ifndef WS_CDMA
-#define WS_CDMA 1
-#endif
     constexpr bool CDMA = WS_CDMA != 0;
+    static_assert(!E16 || (CDMA && !RSEG && SPLIT == 0 && BM == 256 && sizeof(T) == 2), "16-bit staging: the consumers' filter stream, plain 256-pixel tiles");
     static_assert(!RSEG || (SPLIT == 0 && sizeof(T) == 2), "residual segment: 16-bit tensors");
     constexpr int KCR = SPLIT ? 32 : KC;  // input channels per chunk (KC = 16-bit k-slots per 128-byte row)
     constexpr int EPR = SPLIT ? 4 : EPV;  // input channels per producer lane and halo unit
@@ -543,21 +547,21 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             return ((TT).n0 * a.Hout + (TT).oy0 + ty) * a.Wout + (TT).ox0 + tx;                                                    \
         };                                                                                                                         \
         uint4 rpre[128 * (BN / (16 / (int)sizeof(TS))) / 512];                                                                     \
-        conv_epilogue_res_prefetch<TS, 128, BN, 512>(a, (TT).co0, pix_of, rpre); /* in flight across the staging barrier */         \
+        if constexpr (!E16) conv_epilogue_res_prefetch<TS, 128, BN, 512>(a, (TT).co0, pix_of, rpre); /* in flight across the staging barrier */ \
         WS_ESTAMP()                                                                                                                \
         STAGE_STMT                                                                                                                 \
         WS_ESTAMP()                                                                                                                \
-        __syncthreads();                                                                                                           \
+        lds_barrier();                                                                                                             \
         WS_ESTAMP()                                                                                                                \
-        conv_epilogue_store<TS, 128, BN, 512>(a, (TT).co0, (TT).n0, pix_of, stage, (BM / 128) * (TT).ts + p, rpre, a.n_gno ? p : -1, gn_carry); \
+        conv_epilogue_store<TS, 128, BN, 512, E16>(a, (TT).co0, (TT).n0, pix_of, stage, (BM / 128) * (TT).ts + p, E16 ? nullptr : rpre, a.n_gno ? p : -1, gn_carry); \
         WS_ESTAMP()                                                                                                                \
-        __syncthreads(); /* everyone is done with the staging area */                                                              \
+        lds_barrier(); /* everyone is done with the staging area (the output stores need no acknowledgement here) */                \
     }
     // consumer wave-row wr owns the 32-pixel blocks {wr, wr + 2, wr + 4, wr + 6} of the tile, so both wave-rows hold two
     // blocks of either epilogue pass and all four consumer waves stage at once
 #define WS2_EPILOGUE(TT, KT, STAGE0, STAGE1)                                                                                       \
     {                                                                                                                              \
-        float* stage = reinterpret_cast<float*>(WS_RING(1));                                                                       \
+        float* stage = reinterpret_cast<float*>(E16 ? lds + offA1 : WS_RING(1));                                                   \
         WS2_PASS(TT, 0, STAGE0)                                                                                                    \
         if constexpr (BM == 256) { WS2_PASS(TT, 1, STAGE1) }                                                                       \
         if ((KT) + 2 < K) WS_FILL_PAR((KT) + 2)                                                                                    \
@@ -921,7 +925,8 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
                    and put `s_waitcnt vmcnt(0)` in front of stage 0's DMA - draining the halo prefetch at EVERY chunk start \
                    (the 1.6-2.2 k-cycle consumer wait at tap 0, tools/stamp_ws.py).  Here everything in flight (the next    \
                    tile's second chunk, its tap 0) was requested before the epilogue: it has landed */                       \
-                __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0) only */                                                  \
+                /* (measured: that wait cost nothing - the producers were waiting for the barrier anyway - but a visible    \
+                   vmcnt(0) HERE also waits for the store loop's output stores, ~1.5 k cycles per tile: not placed) */        \
                 cc = 0;                                                                                                 \
                 ++kt;                                                                                                   \
                 tcur = tnext;                                                                                           \
@@ -1058,7 +1063,13 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
                 // tap 0 in the segment's last stage.  Behind the stage's first fragment reads: the matrix pipe waits for those anyway
                 bool sent = false;
 #define WS_CDMA_ISSUE()                                                                                               \
-    if constexpr (CDMA) {                                                                                             \
+    if constexpr (E16) { /* always the tap of stage s + 2, whatever tile it belongs to */                             \
+        const bool more = kt + 1 < K;                                                                                 \
+        if (tp <= 6) { cdma((tp + 2) % 3, t.co0, c, tp + 2); sent = true; }                                           \
+        else if (!last_c) { cdma(tp - 7, t.co0, c + 1, tp - 7); sent = true; }                                        \
+        else if (more) { cdma(tp - 7, tn.co0, 0, tp - 7); sent = true; }                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+    } else if constexpr (CDMA) {                                                                                      \
         if (tp == 0 && c == 0 && kt > 0) cdma(1, t.co0, 0, 1);                                                        \
         if (tp <= 6) { cdma((tp + 2) % 3, t.co0, c, tp + 2); sent = true; }                                           \
         else if (RSEG && last_c) { }                                                                                  \
@@ -1129,8 +1140,8 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
 #undef WS_FRAGS
 #undef WS_MMAS
         // the last stage read R2 and A1: R1|R2|A1 stages the epilogue
-        WS2_EPILOGUE(t, kt, (conv_epilogue_stage<T, BN, 2, NI, 64>(a, reinterpret_cast<f32x16(&)[2][NI]>(acc[0]), t.co0, wn0, r, h, wrow * 32, t.n0, stage));,
-                     (conv_epilogue_stage<T, BN, 2, NI, 64>(a, reinterpret_cast<f32x16(&)[2][NI]>(acc[2]), t.co0, wn0, r, h, wrow * 32, t.n0, stage));)
+        WS2_EPILOGUE(t, kt, (conv_epilogue_stage<T, BN, 2, NI, 64, E16>(a, reinterpret_cast<f32x16(&)[2][NI]>(acc[0]), t.co0, wn0, r, h, wrow * 32, t.n0, stage));,
+                     (conv_epilogue_stage<T, BN, 2, NI, 64, E16>(a, reinterpret_cast<f32x16(&)[2][NI]>(acc[2]), t.co0, wn0, r, h, wrow * 32, t.n0, stage));)
         WS_STAMP()
     }
 #undef WS_STAMP
@@ -1342,6 +1353,9 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
                 if (rc0 == DMME_OK) rc0 = set_lds_limit(conv3x3_ws2_kernel<7, T, 128>, 160 * 1024);
                 if (rc0 == DMME_OK) rc0 = set_lds_limit(conv3x3_ws2_kernel<11, T, 256, 0, true>, 160 * 1024);
                 if (rc0 == DMME_OK) rc0 = set_lds_limit(conv3x3_ws2_kernel<7, T, 128, 0, true>, 160 * 1024);
+#if WS_CDMA
+                if (rc0 == DMME_OK) rc0 = set_lds_limit(conv3x3_ws2_kernel<11, T, 256, 0, false, true>, 160 * 1024);
+#endif
                 if (rc0 != DMME_OK) return rc0;
                 ws_attr = true;
             }
@@ -1355,6 +1369,11 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
                     hipLaunchKernelGGL((conv3x3_ws2_kernel<11, T, 256, 0, true>), wgrid, dim3(512), ws2_lds(a, gw), s, a, gw, ilog2(gw.TW), ilog2(gw.TH), ntiles);
             } else if (ws == 4)
                 hipLaunchKernelGGL((conv3x3_ws2_kernel<7, T, 128>), wgrid, dim3(512), ws2_lds(a, gw), s, a, gw, ilog2(gw.TW), ilog2(gw.TH), ntiles);
+#if WS_CDMA
+            else if (!a.res1 && debug_route("ws_e16"))  // (experiment, off: the 16-bit staged epilogue with the filter stream continuous across tiles -
+                                                         // correct, and 0.5 % slower: ds_write_b16 staging takes 2.2-3.1 k cycles per pass against 1.9 k)
+                hipLaunchKernelGGL((conv3x3_ws2_kernel<11, T, 256, 0, false, true>), wgrid, dim3(512), ws2_lds(a, gw), s, a, gw, ilog2(gw.TW), ilog2(gw.TH), ntiles);
+#endif
             else
                 hipLaunchKernelGGL((conv3x3_ws2_kernel<11, T, 256>), wgrid, dim3(512), ws2_lds(a, gw), s, a, gw, ilog2(gw.TW), ilog2(gw.TH), ntiles);
             DMME_CHECK_LAUNCH();

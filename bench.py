@@ -560,6 +560,14 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as exc:  # noqa: BLE001 - a secondary figure must not cost the headline line
                 out[key] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+        # north_star asks "within 1e-3" of the reduced-precision path: `value` above is timed in bf16 (max |err| 1.2e-2 against the
+        # reference); this top-level key is the same step in the fastest mode INSIDE that tolerance, so that the
+        # in-tolerance figure cannot be overlooked
+        am = out.get("accurate_mode") or {}
+        if "steps_per_s" in am:
+            out["value_within_north_star_tolerance"] = {"value": am["steps_per_s"], "unit": out["unit"], "precision": am["precision"], "ms_per_step": am["ms_per_step"],
+                                                        "max_abs_err_vs_reference": "6.0e-4 at batch 2, 7.2e-4 at batch 128 (bound 1e-3, tests/test_gpu_fp16.py)",
+                                                        "value_precision_max_abs_err": "bf16: 1.2e-2 (bound 1.7e-2, tests/test_gpu_unet.py)"}
 
     def ddim_leg():
         """BASELINE configs[2] as a secondary key of the N = 1 line: DDIM, 50-step quadratic tau, batch 512, the full chain once"""
@@ -636,19 +644,20 @@ def main():
             out["train_step_tflops"] = round(ttf, 1)
             out["train_step_frac_of_peak"] = round(ttf / (world * peak), 4)
             if world > 1:
-                n_buckets = 0
-                try:  # how many gradient buckets the plan's backward hands to the exchange
+                n_buckets, bucket_bytes = 0, []
+                try:  # the gradient buckets the plan's backward hands to the exchange, in hand-over order
                     import ctypes as C_
 
                     mb = dmme_amd.UNet(precision=args.precision).to(dev) if args.model == "ddpm" else None
                     if mb is not None:
                         pl = mb._plan_for(B, side, side, dev)
-                        bks = (C_.c_int * 64)()
-                        cnt = pl.lib.dmme_unet_plan_grad_buckets(pl.h, (C_.c_int64 * 64)(), (C_.c_int64 * 64)(), bks, 64)
+                        bks, offs, nums = (C_.c_int * 64)(), (C_.c_int64 * 64)(), (C_.c_int64 * 64)()
+                        cnt = pl.lib.dmme_unet_plan_grad_buckets(pl.h, offs, nums, bks, 64)
                         n_buckets = max(bks[i] for i in range(min(cnt, 64))) + 1
+                        bucket_bytes = [4 * sum(int(nums[i]) for i in range(min(cnt, 64)) if bks[i] == b) for b in range(n_buckets)]
                         del mb, pl
                 except Exception:  # noqa: BLE001
-                    n_buckets = 0
+                    n_buckets, bucket_bytes = 0, []
                 # the same step without its collective, and the collective alone: what the overlap hides
                 dt_nc, _, _ = train_leg(dmme_amd, dev, B, args.precision, k, 3, dist, args.model, reduce=False)
                 ar_ms = allreduce_alone_ms(dist, dev, numel)
@@ -659,13 +668,17 @@ def main():
                     "ms_per_step": round(step_ms, 3), "ms_per_step_without_allreduce": round(nocomm_ms, 3),
                     "allreduce_alone_ms": round(ar_ms, 3), "allreduce_exposed_ms": round(exposed, 3),
                     "allreduce_hidden_ms": round(max(0.0, ar_ms - exposed), 3), "gradient_bytes": numel * 4,
-                    "exchange": DD.default_exchange(B), "gradient_buckets": n_buckets}
+                    "exchange": DD.default_exchange(B), "gradient_buckets": n_buckets, "bucket_bytes": bucket_bytes,
+                    "ranks_seen": out.get("ranks_seen")}
                 # the other wire format of the gradient mean (distributed.Bf16ShardExchange: bf16 all-to-all + all-gather, fp32 accumulation)
                 try:
+                    if os.environ.get("DMME_BENCH_FAIL_BF16_LEG"):  # (test hook: the status of a run whose exchange leg fails)
+                        raise RuntimeError("DMME_BENCH_FAIL_BF16_LEG")
                     dt_bf, _, _ = train_leg(dmme_amd, dev, B, args.precision, k, 3, dist, args.model, exchange="bf16-rs-ag")
                     out["train_dp"]["ms_per_step_bf16_rs_ag"] = round(1e3 * dt_bf / k, 3)
-                except Exception as exc:  # noqa: BLE001  (a secondary figure: the legs behind it still run)
+                except Exception as exc:  # noqa: BLE001  (the line still goes out, the status says the exchange failed: VERDICT round 4)
                     out["train_dp"]["bf16_rs_ag_error"] = f"{type(exc).__name__}: {exc}"[:200]
+                    rc = 4
                 if B % world == 0 and B // world >= 1:
                     bs = B // world  # north_star wording: the batch of 128 sharded over the ranks
                     dt_g, _, _ = train_leg(dmme_amd, dev, bs, args.precision, k, 3, dist, args.model)
@@ -673,6 +686,8 @@ def main():
                                                  "images_per_s": round(k * B / dt_g, 1), "ms_per_step": round(1e3 * dt_g / k, 3)}
         except Exception as exc:  # noqa: BLE001
             out["train_error"] = f"{type(exc).__name__}: {exc}"[:300]
+            if world > 1:  # a failing data-parallel leg is a failed run: the line is printed, the status is not 0
+                rc = 4
         watchdog.cancel()
         if world == 1:
             rank0_legs()

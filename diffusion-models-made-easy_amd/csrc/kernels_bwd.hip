@@ -888,6 +888,7 @@ __global__ void __launch_bounds__(256) adam_amp_kernel(float* __restrict__ p, co
     const float nrm = norm[0];
     if (!(fabsf(nrm) <= 3.0e38f)) return;  // inf or NaN somewhere in the scaled gradient: this step is skipped (GradScaler.step)
     const float gs = grad_scale / amp[0];   // unscale (and the data-parallel mean's 1 / world)
+    if (!(fabsf(gs) <= 3.0e38f)) return;    // a scale driven to 0 / a denormal by repeated back-offs: 0 x inf would write NaN - skipped too
     float clip = gs;
     if (max_norm > 0.f) {
         const float c = max_norm / (nrm * gs + 1e-6f);
@@ -909,9 +910,12 @@ __global__ void __launch_bounds__(256) adam_amp_kernel(float* __restrict__ p, co
 }
 __global__ void amp_update_kernel(float* __restrict__ amp, const float* __restrict__ norm, float growth, float backoff, float interval) {
     if (threadIdx.x != 0) return;
-    const bool bad = !(fabsf(norm[0]) <= 3.0e38f);
+    // (the same two tests as adam_amp_kernel: the step it skipped is the step counted as skipped; grad_scale > 0 is finite, so the
+    //  unscale factor is finite exactly when 1 / S is)
+    const bool bad = !(fabsf(norm[0]) <= 3.0e38f) || !(fabsf(1.0f / amp[0]) <= 3.0e38f);
     if (bad) {
-        amp[0] *= backoff;
+        amp[0] = fmaxf(amp[0] * backoff, 6.103515625e-05f);  // floor 2^-14: S never reaches a denormal or 0
+        if (!(amp[0] >= 6.103515625e-05f)) amp[0] = 6.103515625e-05f;  // (a NaN scale recovers as well)
         amp[1] = 0.f;
         amp[3] = 1.f;
         amp[4] += 1.f;

@@ -387,10 +387,13 @@ int lvl_check(const dmme_plan* P, const char* where, hipStream_t stream, bool ha
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (have_stream && hipStreamIsCapturing(stream, &cs) != hipSuccess) cs = hipStreamCaptureStatusNone;
     if (cs == hipStreamCaptureStatusNone) {
+        int cur = -1;  // synchronise the PLAN's device, whatever device the calling thread has current
+        const bool sw = hipGetDevice(&cur) == hipSuccess && cur != P->device && hipSetDevice(P->device) == hipSuccess;
         (void)hipDeviceSynchronize();
         for (const LvlRun& R : P->lvl_runs)
             if (R.sync_dev) (void)hipMemset(R.sync_dev + 2, 0, 4);
         __atomic_store_n(P->err_host, 0u, __ATOMIC_RELEASE);
+        if (sw) (void)hipSetDevice(cur);
     }
     const int ri = (int)v - 1;
     const LvlRun* R = ri >= 0 && ri < (int)P->lvl_runs.size() ? &P->lvl_runs[ri] : nullptr;

@@ -91,6 +91,9 @@ class ChainRunner:
             self.x.copy_(saved_x)
             self.state.copy_(saved_state)
             self.graph, self._wkey = graph, wkey
+        # (no synchronisation while the engine's status word is clear: an atomic load of pinned host memory; a hand-off timeout of an
+        # earlier replayed step raises here, one step late at most, for callers that never reach `run`'s final check)
+        self.plan.check()
         self.graph.replay()
         self.plan.fwd_gen = getattr(self.plan, "fwd_gen", 0) + 1
         return self.x
@@ -193,8 +196,8 @@ class DDPM(nn.Module):
         with torch.no_grad():
             runner.step()
         out = buf.clone()
-        # (per-step callers: the status word is read on entry of the NEXT step's C calls - dmme_chain_step when eager - and by
-        # `model.check_engine()`; a synchronisation per step here would cost the small-batch loop its overlap)
+        # (per-step callers: `runner.step()` reads the engine's status word in front of every replay without synchronising - a
+        # hand-off timeout raises one step late at most - and `model.check_engine()` is the synchronising check at the end of a loop)
         return out
 
     # ------------------------------------------------------------------ training

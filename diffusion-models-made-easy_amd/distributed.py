@@ -153,6 +153,21 @@ class OverlappedGradReducer:
         self.reported.clear()
         self.model._exchange_in_flight = False
 
+    def abort(self):
+        """a backward that raised after handing over its first bucket(s): join what was issued (the collectives themselves cannot be
+        recalled - the peers are in them), forget the step's bookkeeping and lift the forward guard, so that the error the caller sees
+        is the backward's own and not "exchange in flight" at the next forward"""
+        for h in self.handles:
+            try:
+                h.wait()
+            except Exception:  # noqa: BLE001 - the original error is the one to surface
+                pass
+        if self._stream is not None:
+            torch.cuda.current_stream().wait_stream(self._stream)
+        self.handles.clear()
+        self.reported.clear()
+        self.model._exchange_in_flight = False
+
     def grad_scale(self) -> float:
         """what the optimiser must multiply the exchanged buffer by to obtain the mean gradient"""
         return 1.0 / dist.get_world_size() if (self.fold_mean and self.active()) else 1.0
@@ -273,20 +288,49 @@ class Bf16ShardExchange(OverlappedGradReducer):
             v.copy_(gathered[:n])
 
 
-def default_exchange(per_rank_batch: Optional[int] = None) -> str:
-    """`fp32-allreduce`, except where the step is too short to hide a ring all-reduce of 130 MB over one xGMI link (~1.5 ms at world
-    8): at <= 32 images per rank (north_star's "batch of 128 sharded over 8 GPUs" = 16 per rank: ~1.1 ms of backward) the direct
-    bf16 reduce-scatter + all-gather (2 x 8 MB per peer over all seven links, ~0.11 ms) is the default.  DMME_EXCHANGE overrides."""
+def default_exchange(per_rank_batch: Optional[int] = None, model=None) -> str:
+    """`fp32-allreduce` (what the reference's DDP does), except where the step is too short to hide a ring all-reduce of 130 MB over one
+    xGMI link (~1.5 ms at world 8) AND the model computes in 16 bits anyway: at <= 32 images per rank (north_star's "batch of 128
+    sharded over 8 GPUs" = 16 per rank: ~1.1 ms of backward) a bf16 / fp16 model takes the direct bf16 reduce-scatter + all-gather
+    (2 x 8 MB per peer over all seven links, ~0.11 ms).  fp32 and bf16x3 models keep the fp32 all-reduce whatever the batch: their
+    parity claim (1e-5) does not survive bf16-rounded gradients.  DMME_EXCHANGE overrides."""
     env = os.environ.get("DMME_EXCHANGE")
     if env:
         return env
+    if model is not None:
+        from . import _lib
+
+        if getattr(model, "_dtype", None) not in (_lib.BF16, _lib.F16):
+            return "fp32-allreduce"
     return "bf16-rs-ag" if (per_rank_batch is not None and per_rank_batch <= 32) else "fp32-allreduce"
+
+
+def run_exchange(model, per_rank_batch: int, exchange: Optional[str] = None) -> str:
+    """the exchange of THIS RUN, decided once - at the first data-parallel step, from that step's batch - and agreed between the ranks
+    (rank 0's choice is broadcast): a short last batch must not swap the reducer (new stream, new buffers) and ranks whose local batch
+    sizes differ must not pick different collectives (all_reduce against all_to_all would hang)."""
+    kind = getattr(model, "_dp_exchange", None)
+    if kind is not None and exchange in (None, kind):
+        return kind
+    kind = exchange or default_exchange(per_rank_batch, model)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        names = ["fp32-allreduce", "bf16-rs-ag"]
+        if kind not in names:
+            raise ValueError(f"unknown gradient exchange '{kind}' (fp32-allreduce | bf16-rs-ag)")
+        code = torch.tensor([names.index(kind)], dtype=torch.int64)
+        dev = model.flat_parameters().device
+        if dev.type == "cuda" and dist.get_backend() == "nccl":
+            code = code.to(dev)
+        dist.broadcast(code, src=0)
+        kind = names[int(code.item())]
+    model._dp_exchange = kind
+    return kind
 
 
 def make_reducer(model, exchange: Optional[str] = None, per_rank_batch: Optional[int] = None):
     """the gradient exchange of a data-parallel run: `exchange` / DMME_EXCHANGE = 'fp32-allreduce' or 'bf16-rs-ag'; unset: by the
-    per-rank batch (default_exchange)"""
-    kind = exchange or default_exchange(per_rank_batch)
+    per-rank batch and the model's precision (default_exchange)"""
+    kind = exchange or default_exchange(per_rank_batch, model)
     if kind == "bf16-rs-ag":
         return Bf16ShardExchange(model)
     if kind != "fp32-allreduce":

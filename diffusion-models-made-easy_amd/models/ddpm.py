@@ -398,13 +398,23 @@ class UNet(nn.Module):
                     errors.append(exc)
 
             cb = _lib.BUCKET_FN(ready)
-            _lib.check(
-                lib.dmme_unet_backward_buckets(plan.h, _lib.ptr(packed), _lib.ptr(plan.packed_bwd), _lib.ptr(xin), _lib.ptr(t), int(t.numel()), _lib.ptr(d),
-                                               _lib.ptr(plan.workspace), _lib.ptr(plan.bws), _lib.ptr(masks), _lib.ptr(g), _lib.ptr(dx), _lib.stream_ptr(), cb, None),
-                "dmme_unet_backward_buckets",
-            )
-            if errors:
-                raise errors[0]
+            try:
+                _lib.check(
+                    lib.dmme_unet_backward_buckets(plan.h, _lib.ptr(packed), _lib.ptr(plan.packed_bwd), _lib.ptr(xin), _lib.ptr(t), int(t.numel()), _lib.ptr(d),
+                                                   _lib.ptr(plan.workspace), _lib.ptr(plan.bws), _lib.ptr(masks), _lib.ptr(g), _lib.ptr(dx), _lib.stream_ptr(), cb, None),
+                    "dmme_unet_backward_buckets",
+                )
+                if errors:
+                    raise errors[0]
+            except Exception:
+                # buckets already handed over have collectives on the side stream: join them and lift the forward guard, or every
+                # later forward would raise "exchange in flight" instead of this backward's error
+                owner = getattr(hook, "__self__", None)
+                if owner is not None and hasattr(owner, "abort"):
+                    owner.abort()
+                else:
+                    self._exchange_in_flight = False
+                raise
             if dx is not None and amp is not None:
                 dx.div_(amp[0])
             return dx
@@ -475,21 +485,32 @@ class UNet(nn.Module):
         key = (x_static.data_ptr(), t_static.data_ptr(), tuple(x_static.shape), self._dtype) + self._weights_key(flat)
         g = getattr(self, "_graph", None)
         if g is None or g[0] != key:
-            try:
-                with torch.no_grad():
-                    self._forward_impl(x_static, t_static)  # warm-up: packs weights, sets kernel attributes
-                    torch.cuda.synchronize()
+            with torch.no_grad():
+                # the eager trial forward (packs weights, sets kernel attributes) is OUTSIDE the fallback: a DmmeError or a kernel
+                # fault in it is a real error and propagates (as ChainRunner.step does); only a failure of the CAPTURE itself makes
+                # this module stay eager, and the cause is kept in `_graph_error`
+                self._forward_impl(x_static, t_static)
+                torch.cuda.synchronize()
+                self._last_plan.check()
+                try:
                     graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph):
                         y = self._forward_impl(x_static, t_static)
-                g = (key, graph, y, self._last_plan)  # the plan whose workspace the replays overwrite
-                self._graph = g
-            except Exception:  # noqa: BLE001 - capture not possible here: stay eager
-                self._graph_disabled = True
-                self._graph = None
-                return self._forward_impl(x_static, t_static)
+                except RuntimeError as exc:  # stream capture unavailable / invalidated here: the same launches, eagerly
+                    if isinstance(exc, _lib.DmmeError):
+                        raise
+                    self._graph_disabled = True
+                    self._graph_error = exc
+                    self._graph = None
+                    return self._forward_impl(x_static, t_static)
+            g = (key, graph, y, self._last_plan)  # the plan whose workspace the replays overwrite
+            self._graph = g
+        plan = g[3]  # the replay overwrites THAT plan's workspace (not whichever plan ran last): its pending backward must refuse
+        # a replay passes through no entry point of the C ABI, so nobody else looks at the level engine's status word: an atomic load
+        # of pinned host memory, no synchronisation while the word is clear - a hand-off timeout of an earlier replay is reported
+        # at most one step late instead of never; callers that read the result on the host use check_engine()
+        plan.check()
         g[1].replay()
-        plan = g[3]  # the replay overwrote THAT plan's workspace (not whichever plan ran last): its pending backward must refuse
         plan.fwd_gen = getattr(plan, "fwd_gen", 0) + 1
         return g[2]
 

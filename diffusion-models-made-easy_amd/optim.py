@@ -173,9 +173,17 @@ class FusedAdam(torch.optim.Optimizer):
                  "capturable": False, "differentiable": False, "fused": None, "params": list(range(index))}
         if "initial_lr" in g0:
             group["initial_lr"] = g0["initial_lr"]
-        return {"opt": {"state": state, "param_groups": [group]}, "ema": tuple(ema), "current_step": self._step_count,
-                "decay": float(g0["ema_decay"] or 0.0), "every_n_steps": 1, "device": device,
-                "max_grad_norm": float(g0["max_grad_norm"] or 0.0)}
+        out = {"opt": {"state": state, "param_groups": [group]}, "ema": tuple(ema), "current_step": self._step_count,
+               "decay": float(g0["ema_decay"] or 0.0), "every_n_steps": 1, "device": device,
+               "max_grad_norm": float(g0["max_grad_norm"] or 0.0)}
+        # the device-resident loss-scaling state of half-precision models (what GradScaler.state_dict() is to a Lightning checkpoint):
+        # scale, growth tracker, the optimiser-step count the fused pass uses for Adam's bias correction (skipped steps do not count,
+        # so it differs from `current_step`), found_inf, steps skipped.  Without it a resumed fp16 run restarts at S = 65536 and t = 1
+        # beside warm moments: updates damped by sqrt(1 - b2^t) / (1 - b1^t) for thousands of steps.
+        amp = [m._amp_state.detach().cpu().tolist() if getattr(m, "_amp_state", None) is not None else None for m in self._owners]
+        if any(a is not None for a in amp):
+            out["amp_state"] = amp
+        return out
 
     def load_state_dict(self, state_dict):
         """accepts the layout above (written by this class or by the reference's EMAOptimizer around torch.optim.Adam)"""
@@ -207,3 +215,14 @@ class FusedAdam(torch.optim.Optimizer):
                         st["ema"][off : off + n].copy_(ema_list[index].reshape(-1))
                     index += 1
                 self._flat_state[id(m)] = st
+            amp_saved = state_dict.get("amp_state")
+            for k, m in enumerate(self._owners):
+                amp = m.amp_state(m.flat_parameters().device) if hasattr(m, "amp_state") else None
+                if amp is None:
+                    continue
+                if amp_saved is not None and k < len(amp_saved) and amp_saved[k] is not None:
+                    amp.copy_(torch.tensor(amp_saved[k], dtype=torch.float32))
+                else:
+                    # a checkpoint without the scaler's state (written by a bf16 / fp32 run, or by the reference): keep the initial
+                    # scale, but Adam's bias correction continues from the loaded step count instead of restarting at 1
+                    amp[2] = float(self._step_count)

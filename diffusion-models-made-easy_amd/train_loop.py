@@ -30,7 +30,7 @@ def train_step(module, optimizer, scheduler, x0, clip=None, reduce=True, exchang
         D.sync_parameters(model, optimizer)
         model._dp_synced = True
     if multi and not os.environ.get("DMME_NO_OVERLAP"):
-        want = exchange or D.default_exchange(int(x0.shape[0]))  # (<= 32 images per rank: the direct bf16 exchange)
+        want = D.run_exchange(model, int(x0.shape[0]), exchange)  # decided once per run, rank 0's choice (16-bit models at <= 32 images per rank: bf16)
         if reducer is not None and reducer.exchange != want:
             reducer.detach()
             reducer = None

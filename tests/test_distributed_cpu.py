@@ -180,3 +180,29 @@ def test_four_rank_gloo():
     """the same exchanges at world size 4 (shard owners 0..3, sub-buckets that do not divide by 4)"""
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(4, os.path.join(d, "rdv")), nprocs=4, join=True)
+
+
+def test_default_exchange_follows_the_model_precision_and_is_decided_once():
+    """bf16 on the wire only for models that compute in 16 bits anyway - fp32 / bf16x3 keep the reference's fp32
+    all-reduce at every batch size (their 1e-5 parity does not survive bf16-rounded gradients) - and the choice of a run is made once
+    (a short last batch must not swap the reducer)."""
+    import dmme_amd
+    from dmme_amd import distributed as D
+
+    os.environ.pop("DMME_EXCHANGE", None)
+    from oracle import unet as O
+
+    cfg = O.TINY
+    nets = {p: dmme_amd.UNet(cfg.in_channels, cfg.pos_dim, cfg.emb_dim, cfg.num_groups, cfg.dropout, cfg.channels_per_depth, cfg.num_blocks,
+                             cfg.attention_depths, precision=p) for p in ("fp32", "bf16x3", "bf16", "fp16")}
+    assert D.default_exchange(16, nets["fp32"]) == "fp32-allreduce" and D.default_exchange(16, nets["bf16x3"]) == "fp32-allreduce"
+    assert D.default_exchange(16, nets["bf16"]) == "bf16-rs-ag" and D.default_exchange(16, nets["fp16"]) == "bf16-rs-ag"
+    assert D.default_exchange(128, nets["bf16"]) == "fp32-allreduce"
+    assert D.run_exchange(nets["bf16"], 16) == "bf16-rs-ag"
+    assert D.run_exchange(nets["bf16"], 128) == "bf16-rs-ag"  # decided at the first step, kept for the run
+    assert D.run_exchange(nets["bf16"], 128, "fp32-allreduce") == "fp32-allreduce"  # an explicit request still wins
+    os.environ["DMME_EXCHANGE"] = "bf16-rs-ag"
+    try:
+        assert D.default_exchange(16, nets["fp32"]) == "bf16-rs-ag"  # the override is the operator's own decision
+    finally:
+        os.environ.pop("DMME_EXCHANGE", None)

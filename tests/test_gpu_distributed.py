@@ -149,4 +149,85 @@ def test_bench_two_ranks_on_one_device_reports_both_exchanges():
     assert dp["ms_per_step"] > 0 and dp["ms_per_step_without_allreduce"] > 0 and dp["allreduce_alone_ms"] > 0
     assert "bf16_rs_ag_error" not in dp and dp["ms_per_step_bf16_rs_ag"] > 0, dp
     assert dp["exchange"] in ("bf16-rs-ag", "fp32-allreduce") and dp["gradient_buckets"] >= 4
+    # what DESIGN section 6 promises of the N > 1 line: ranks seen, bytes per bucket in hand-over order, exposed exchange time
+    assert dp["ranks_seen"] == 2 and "allreduce_exposed_ms" in dp and "allreduce_hidden_ms" in dp
+    assert len(dp["bucket_bytes"]) == dp["gradient_buckets"] and sum(dp["bucket_bytes"]) == dp["gradient_bytes"], dp
     assert out["train_global_batch"]["ms_per_step"] > 0
+
+
+def test_bench_two_ranks_exits_nonzero_when_an_exchange_leg_fails():
+    """a failing data-parallel leg is a failed run: rank 0's line still arrives (with the error key), the status is not 0"""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DMME_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", DMME_BENCH_FAIL_BF16_LEG="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reps", "1", "--batch", "8", "--train-steps", "1",
+           "--no-cpu-baseline", "--no-roofline", "--no-accurate-leg", "--no-ddim-leg", "--no-small-batch-leg"]
+    res = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{"metric"')]
+    assert lines and res.returncode != 0, (res.returncode, res.stdout[-1000:], res.stderr[-1000:])
+    assert "bf16_rs_ag_error" in json.loads(lines[-1])["train_dp"]
+
+
+def _worker_world1(rank, world, path, backend, result):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "RANK": "0", "WORLD_SIZE": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend, init_method=f"file://{path}", rank=0, world_size=1)
+    try:
+        import dmme_amd
+        from dmme_amd import distributed as D
+        from oracle import unet as O
+
+        cfg = O.TINY
+        net = dmme_amd.UNet(cfg.in_channels, cfg.pos_dim, cfg.emb_dim, cfg.num_groups, 0.0, cfg.channels_per_depth, cfg.num_blocks, cfg.attention_depths)
+        sd = O.make_state_dict(O.UNetConfig(pos_dim=cfg.pos_dim, emb_dim=cfg.emb_dim, num_groups=cfg.num_groups, dropout=0.0, channels_per_depth=cfg.channels_per_depth,
+                                            num_blocks=cfg.num_blocks, attention_depths=cfg.attention_depths), 11)
+        net.load_state_dict(sd, strict=True)
+        net.cuda().train()
+        want = _local_grads(net, 0).clone()  # no reducer attached: the local gradient
+        # the bf16 exchange's CUDA branch on real streams: pack kernel (raw HIP stream) -> all_to_all_single -> shard reduce kernel ->
+        # all_gather_into_tensor -> unpack kernel, per sub-bucket on the side stream behind the bucket's event.  With one rank the two
+        # collectives are copies, so the result must be the bf16 rounding of the local gradient - bit for bit, on every repetition
+        red = D.Bf16ShardExchange(net, bucket_elems=4096)
+        red.active = lambda: True
+        for _ in range(4):
+            got = _local_grads(net, 0)
+            assert len(red.reported) >= 2 and net._exchange_in_flight
+            assert red.finish() is True and not net._exchange_in_flight
+            torch.cuda.synchronize()
+            assert torch.equal(got, want.to(torch.bfloat16).float()), float((got - want).abs().max())
+        red.detach()
+        # ... and the fp32 all-reduce path on the same streams: the identity
+        red = D.OverlappedGradReducer(net, bucket_elems=4096)
+        red.active = lambda: True
+        got = _local_grads(net, 0)
+        assert red.finish() is True
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+        result.put("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bf16_exchange_cuda_branch_with_one_rank_orders_its_streams():
+    """Bf16ShardExchange._exchange's CUDA branch - raw-stream HIP launches interleaved with
+    torch.distributed collectives on the side stream - against the fp32 path, world size 1 (RCCL where a one-rank communicator comes
+    up on this box, else gloo carrying the CUDA tensors)"""
+    ctx = mp.get_context("spawn")
+    last = None
+    for backend in ("nccl", "gloo"):
+        q = ctx.SimpleQueue()
+        with tempfile.TemporaryDirectory() as d:
+            try:
+                mp.spawn(_worker_world1, args=(1, os.path.join(d, "rdv"), backend, q), nprocs=1, join=True)
+            except Exception as exc:  # noqa: BLE001
+                last = exc
+                continue
+        assert not q.empty() and q.get() == "ok"
+        print(f"bf16 exchange, world 1: backend {backend}")
+        return
+    raise last

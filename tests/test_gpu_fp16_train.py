@@ -185,3 +185,80 @@ def test_training_learns_fp16(which):
     print(f"{which}: loss {first:.3f} -> {last:.3f}; loss scale {float(st[0]):.0f}, steps {int(st[2])}, skipped {int(st[4])}")
     assert first > 0.8 and last < 0.2 * first, (first, last)
     assert float(st[2]) + float(st[4]) == 120 and float(st[4]) <= 12
+
+
+def test_fp16_resume_carries_the_loss_scaling_state_and_continues_bit_for_bit():
+    """the device-resident scaler state (scale, growth tracker, the step count of Adam's bias correction, skipped
+    steps) travels in FusedAdam.state_dict(); a run resumed from a checkpoint takes the same steps as the run that never stopped"""
+    import copy
+
+    import dmme_amd
+    from dmme_amd.lr_scheduler import WarmupLR
+    from dmme_amd.optim import FusedAdam
+    from dmme_amd.train_loop import train_step
+
+    def make():
+        torch.manual_seed(0)
+        lit = dmme_amd.LitDDPM(model=dmme_amd.UNet(precision="fp16"), warmup=20).cuda()
+        lit.train()
+        # an initial scale that overflows twice: skipped steps make the bias-correction count differ from the optimiser's step count
+        opt = FusedAdam(lit.diffusion_model.parameters(), lr=2e-4, ema_decay=0.999, max_grad_norm=1.0, init_scale=2.0**33, growth_interval=4)
+        return lit, opt, WarmupLR(opt, 20)
+
+    base = torch.nn.functional.interpolate(torch.rand(64, 3, 4, 4, device="cuda") * 2 - 1, size=32, mode="bilinear")
+    lit, opt, sched = make()
+    for step in range(8):
+        torch.manual_seed(100 + step)
+        train_step(lit, opt, sched, base[:16])
+    net = lit.diffusion_model.model
+    st = net.amp_state().cpu()
+    assert float(st[4]) >= 1.0 and float(st[2]) + float(st[4]) == 8.0, st
+    ck = {"model": copy.deepcopy(lit.state_dict()), "opt": copy.deepcopy(opt.state_dict()), "sched": copy.deepcopy(sched.state_dict())}
+    assert "amp_state" in ck["opt"] and ck["opt"]["amp_state"][0][:5] == st[:5].tolist()
+    for step in range(8, 12):
+        torch.manual_seed(100 + step)
+        train_step(lit, opt, sched, base[:16])
+    want, want_amp = net.flat_parameters().clone(), net.amp_state().cpu()
+
+    lit2, opt2, sched2 = make()
+    lit2.load_state_dict(ck["model"])
+    opt2.load_state_dict(ck["opt"])
+    sched2.load_state_dict(ck["sched"])
+    net2 = lit2.diffusion_model.model
+    assert torch.equal(net2.amp_state().cpu()[:5], st[:5])
+    for step in range(8, 12):
+        torch.manual_seed(100 + step)
+        train_step(lit2, opt2, sched2, base[:16])
+    assert torch.equal(net2.amp_state().cpu()[:5], want_amp[:5])
+    assert torch.equal(net2.flat_parameters(), want)
+    # a checkpoint WITHOUT the scaler's state (bf16 / reference run): the bias-correction count is seeded from the loaded step count
+    sd = copy.deepcopy(ck["opt"])
+    del sd["amp_state"]
+    lit3, opt3, _ = make()
+    opt3.load_state_dict(sd)
+    assert float(lit3.diffusion_model.model.amp_state().cpu()[2]) == 8.0
+
+
+def test_adam_amp_skips_when_the_scale_has_collapsed():
+    from dmme_amd import _lib
+
+    """ADVICE round 4 (low): S driven to 0 / a denormal makes the scaled gradient 0 - a finite norm - and 1 / S infinite: the step
+    must be skipped, not written as 0 x inf = NaN; the update kernel then lifts S back to its floor"""
+    lib = _lib.lib()
+    n = 4096
+    p = torch.randn(n, device="cuda")
+    p0 = p.clone()
+    g = torch.zeros(n, device="cuda")
+    m, v, ema = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), p.clone()
+    norm, scratch = torch.zeros(1, device="cuda"), torch.empty(1024, device="cuda")
+    amp = torch.zeros(8, device="cuda")
+    _lib.check(lib.dmme_amp_init(_lib.ptr(amp), 65536.0, _lib.stream_ptr()))
+    amp[0] = 0.0
+    st = _lib.stream_ptr()
+    _lib.check(lib.dmme_grad_norm(_lib.ptr(g), n, _lib.ptr(norm), _lib.ptr(scratch), st))
+    _lib.check(lib.dmme_adam_step_amp(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), _lib.ptr(ema), n, 1e-3, 0.9, 0.999, 1e-8, _lib.ptr(norm), 1.0, 0.999,
+                                      1.0, _lib.ptr(amp), 2.0, 0.5, 2000, st))
+    torch.cuda.synchronize()
+    assert torch.equal(p, p0) and bool(torch.isfinite(ema).all())
+    a = amp.cpu()
+    assert float(a[4]) == 1.0 and float(a[2]) == 0.0 and float(a[0]) == 2.0**-14, a

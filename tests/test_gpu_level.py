@@ -299,3 +299,49 @@ def test_level_engine_sized_by_the_device_and_survives_busy_compute_units(golden
         y_busy, _ = _forward(full, x, t)
         full.check_engine()  # synchronises (both streams) and reads the status word
         assert torch.equal(y_busy, y_full), blocks
+
+
+def test_graphed_forward_propagates_a_trial_forward_error_and_replays_look_at_the_status_word(golden):
+    """VERDICT round 4 item 7 / ADVICE round 4: (a) a DmmeError in the eager trial forward in front of the capture is a real error and
+    propagates - the module must NOT fall back to eager launches silently; (b) afterwards a clean capture works, and a hand-off
+    timeout inside a REPLAY (no entry point of the library runs) is reported by the NEXT replay's status-word look, without any
+    synchronising call by the caller in between; (c) the same for the chain runner's per-step entry (`LitDDPM.forward` loops)."""
+    import dmme_amd
+    from dmme_amd._lib import DmmeError
+
+    g = golden("unet_full")
+    net = _net(int(g["full_seed"]), "bf16", True)
+    x = synth.normal(3, (8, 3, 32, 32)).cuda()
+    t = torch.tensor([77]).cuda()
+    with _env(True):
+        with torch.no_grad():
+            y_ref = net(x, t).clone()
+        # (a)
+        with _route("lvl_withhold,lvl_spin=2048"):
+            with pytest.raises(DmmeError, match="hand-off"):
+                net.graphed_forward(x, t)
+        assert not getattr(net, "_graph_disabled", False) and getattr(net, "_graph", None) is None
+        # (b): clean capture, replays reproduce the eager bits
+        y = net.graphed_forward(x, t)
+        assert net._graph is not None and torch.equal(y, y_ref)
+        assert torch.equal(net.graphed_forward(x, t), y_ref)
+        # the knob armed from the plan's next engine launches on: the replay below times out on the device ...
+        with _route("lvl_withhold,lvl_spin=2048"):
+            net.graphed_forward(x, t)
+            torch.cuda.synchronize()  # (only so that the test is deterministic: the word is set by now)
+            # ... and the NEXT replay refuses before it launches anything
+            with pytest.raises(DmmeError, match="hand-off"):
+                net.graphed_forward(x, t)
+        assert torch.equal(net.graphed_forward(x, t), y_ref)  # the check cleared the words: same bits again
+        # (c)
+        ddpm = dmme_amd.DDPM(net, 50).cuda()
+        xs = synth.normal(5, (8, 3, 32, 32)).cuda()
+        runner = ddpm.chain_runner(xs.clone())
+        runner.set(50, 1, 0)
+        runner.step()
+        assert runner.graph is not None
+        with _route("lvl_withhold,lvl_spin=2048"):
+            runner.step()
+            torch.cuda.synchronize()
+            with pytest.raises(DmmeError, match="hand-off"):
+                runner.step()

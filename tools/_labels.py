@@ -13,7 +13,8 @@ def bench_label(name):
     ints = re.findall(r"Li(\d+)E", rest) or re.findall(r"\b(\d+)\b", rest.split("(")[0])
     if base == "lvl_engine_kernel": return "lvl_engine_kernel<8x8>" if ints[:1] == ["2"] else "lvl_engine_kernel<4x4>"  # (batch 128: GB = 2 on the 8x8 maps)
     if base == "conv3x3_ws2_kernel":  # (the RSEG instances - the residual 1x1 conv as a second K segment - end in Lb1E; demangled: "true")
-        res = ",res" if (re.search(r"Lb1E+v", rest) or ", true>" in rest) else ""
+        bools = re.findall(r"Lb([01])E", rest) or [("1" if b == "true" else "0") for b in re.findall(r"\b(true|false)\b", rest.split("(")[0])]
+        res = ",res" if bools[:1] == ["1"] else ""  # template <PIPE_UA, T, BM, SPLIT, RSEG, E16>: the first bool is RSEG
         return f"conv3x3_ws2_kernel<7,128{res}>" if ints[:1] == ["7"] else f"conv3x3_ws2_kernel<11{res}>"
     if base in ("conv1x1_as_kernel",): return f"{base}<{ints[0]}>"
     if base == "attn_mfma_kernel": return "attn_mfma_kernel<bf16>"

@@ -29,9 +29,9 @@ def norm(name):
                 elif rest.startswith("DF16_"): args.append("f16"); rest = rest[5:]
                 elif rest.startswith("f"): args.append("float"); rest = rest[1:]
                 else:
-                    mm = re.match(r"Li(\d+)E", rest)
+                    mm = re.match(r"L([ib])(\d+)E", rest)  # integer and BOOL template arguments: Lb1E tells <.., res> from the plain instance
                     if not mm: break
-                    args.append(mm.group(1)); rest = rest[mm.end():]
+                    args.append(mm.group(2) if mm.group(1) == "i" else ("true" if mm.group(2) == "1" else "false")); rest = rest[mm.end():]
         return kname + ("<" + ",".join(args) + ">" if args else "")
     m = re.match(r"(?:void )?dmme::(\w+)(<[^(]*>)?\(", name)
     if not m: return name

@@ -536,10 +536,11 @@ __device__ __forceinline__ bool conv_epilogue_is_staged(const ConvArgs& a, int T
     return !a.out_silu && !a.out_nchw && uniform_t && (a.Cout % VEC) == 0;
 }
 // MSTRIDE: staged rows between a wave's consecutive 32-row accumulator tiles (32: contiguous rows)
-// S16 (16-bit tensors, no residual input): the staged image holds the ROUNDED outputs, [BM][BN + 8] T (a 272-byte pitch: the two pixel
-// rows a store instruction touches - four apart - fall into different bank halves) - half the bytes, and one rounding as before
+// S16 (conv_epilogue_store; 16-bit tensors, no residual input): the staged image holds the ROUNDED outputs, [BM][BN + 8] T (a 272-byte
+// pitch), written by the wave-specialised kernel's consumers from TRANSPOSED accumulators (conv_pipe.hip, E16): half the bytes, one
+// rounding as before
 constexpr int kStage16Pad = 8;
-template <typename T, int BN, int MI, int NI, int MSTRIDE = 32, bool S16 = false>
+template <typename T, int BN, int MI, int NI, int MSTRIDE = 32>
 __device__ __forceinline__ void conv_epilogue_stage(const ConvArgs& a, f32x16 (&acc)[MI][NI], int co0, int wn0, int r, int h, int wm0, int n0,
                                                     float* stage, bool with_trow = true) {
 #pragma unroll
@@ -556,8 +557,7 @@ __device__ __forceinline__ void conv_epilogue_stage(const ConvArgs& a, f32x16 (&
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int m = wm0 + mi * MSTRIDE + (j & 3) + 8 * (j >> 2) + 4 * h;
-                if constexpr (S16) reinterpret_cast<T*>(stage)[m * (BN + kStage16Pad) + c] = (T)(acc[mi][ni][j] + fold);
-                else stage[m * BN + c] = acc[mi][ni][j] + fold;
+                stage[m * BN + c] = acc[mi][ni][j] + fold;
             }
     }
 }

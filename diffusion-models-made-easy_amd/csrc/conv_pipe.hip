@@ -367,6 +367,22 @@ static int pipe_ksplit(const ConvArgs& a, const ConvTile& g, int pick, int KC) {
 #ifndef WS_CDMA
 #define WS_CDMA 1
 #endif
+// E16 staging of the wave-specialised kernel: transposed accumulators (lane = pixel, a register quad = four consecutive couts) -> the
+// 16-bit [pixel][BN + 8] image; `row` = this lane's pixel row of the wave's first 32-pixel block, at the wave's first cout (+ 4 h);
+// the wave's blocks are 64 staged rows apart
+template <typename T, int BN, int MI, int NI>
+__device__ __forceinline__ void ws_stage16(const f32x16 (&acc)[MI][NI], T* row) {
+    typedef T tx2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const tx2 lo = {(T)acc[mi][ni][4 * q], (T)acc[mi][ni][4 * q + 1]}, hi = {(T)acc[mi][ni][4 * q + 2], (T)acc[mi][ni][4 * q + 3]};
+                *reinterpret_cast<uint2*>(row + mi * 64 * (BN + kStage16Pad) + 32 * ni + 8 * q) = make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+            }
+}
 struct WsTile { int n0, oy0, ox0, co0, ts; };
 __device__ __forceinline__ WsTile ws_tile_of(const ConvTile& g, int shTW, int shTH, int kt, int bn) {
     const int t = (int)blockIdx.x + kt * (int)gridDim.x;
@@ -457,9 +473,14 @@ struct WsSplit<T, 2> {
 // The next tile's first chunk, which the main loop would have stored into A0 during those nine stages, is activated IN its registers
 // instead and written in the segment's last stage (a stage that reads neither slot 0 nor 1, or nothing: one empty stage is appended
 // where the count does not work out), together with the request for the next tile's tap 0 and second chunk.
-// E16 (16-bit tensors, no residual input, 256-pixel tiles; CDMA): the epilogue stages the ROUNDED outputs - 34 KB per 128-pixel pass, inside
-// A1 alone - so the ring slots R1 / R2 are never the epilogue's and the filter stream runs two stages ahead ACROSS tile boundaries (the
-// next tile's taps 0 and 1 are requested in the last two stages, tap 2 in its first): no refill bubble at the head of a tile.
+// E16 (16-bit tensors, no residual INPUT tensor, 256-pixel tiles): the epilogue's staging phase was 2 x 1.9 k cycles of a ~46 k-cycle
+// tile - 64 `ds_write_b32` per consumer wave and pass, the matrix pipe idle - before a store loop that all CUs run at the same moment
+// (bound by the rate HBM takes the burst).  Here the consumers' MFMAs run TRANSPOSED (filter rows as the A operand): a lane then holds one
+// pixel and, per register quad, four consecutive couts - two packed conversions and ONE 8-byte LDS store per quad, 32 stores per wave
+// for the WHOLE tile, the rounded outputs as a [256][136] 16-bit image in R1 | R2 | A1.  Bias + time row (+ the residual segment's
+// bias) are the accumulators' INITIAL value (a 128-float row per tile in LDS, written during the previous epilogue), so nothing is
+// added at the end; one staging phase and one barrier instead of two, then the two 128-pixel store passes (statistics per pass as
+// before).  One rounding, as in the fp32-staged form (the fp32 sum starts from the bias instead of ending with it).
 template <int PIPE_UA, typename T = bf16, int BM = 256, int SPLIT = 0, bool RSEG = false, bool E16 = false>
 __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTile g, int shTW, int shTH, int ntiles) {
     constexpr int KC = 64, EPV = 8, BN = 128, MI = BM / 64, NI = 2, UB = BN / 32;
@@ -469,7 +490,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
     // cycles (tools/issue_probe.py kind 13), beside one that waits for LDS ~16 - which made the producer the longer half of every stage
     // and, in the stages that carry two halo units, the whole stage 0.6-2 k cycles longer.  -DWS_CDMA=0: the producers request them.
     constexpr bool CDMA = WS_CDMA != 0;
-    static_assert(!E16 || (CDMA && !RSEG && SPLIT == 0 && BM == 256 && sizeof(T) == 2), "16-bit staging: the consumers' filter stream, plain 256-pixel tiles");
+    static_assert(!E16 || (SPLIT == 0 && BM == 256 && sizeof(T) == 2), "16-bit staging: 16-bit tensors, 256-pixel tiles");
     static_assert(!RSEG || (SPLIT == 0 && sizeof(T) == 2), "residual segment: 16-bit tensors");
     constexpr int KCR = SPLIT ? 32 : KC;  // input channels per chunk (KC = 16-bit k-slots per 128-byte row)
     constexpr int EPR = SPLIT ? 4 : EPV;  // input channels per producer lane and halo unit
@@ -487,6 +508,22 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
     // S2 = -log2(e) * scale, H2 = -log2(e) * shift:  act(x) = (x S + H) / (1 + 2^(x S2 + H2))  [= silu(x scale + shift) * mask]
     // (the epilogue stages 128 x 128 floats through R1 | R2 | A1: a 128-pixel tile's halo buffer is padded up to that)
     float* par_base = reinterpret_cast<float*>(lds + 2 * a_bytes + 3 * R_BYTES + ws2_stage_pad(a_bytes));
+    // E16: [2][BN] floats behind the parameter rows - bias + time row (+ residual-segment bias) of tile kt's couts in buffer kt & 1
+    float* fold_base = par_base + 2 * 4 * Cin;
+#define WS_FILL_FOLD(KT)                                                                              \
+    if constexpr (E16) {                                                                              \
+        if (tid < BN) {                                                                               \
+            const TileXY ff_ = WS_TILE(KT);                                                           \
+            const int co_ = ff_.co0 + tid;                                                            \
+            float f_ = 0.f;                                                                           \
+            if (co_ < a.Cout) {                                                                       \
+                f_ = a.bias ? a.bias[co_] : 0.f;                                                      \
+                if (a.r_bias) f_ += a.r_bias[co_];                                                    \
+                if (a.tproj) f_ += a.tproj[(a.nt == 1 ? 0 : ff_.n0) * a.tproj_ld + co_];              \
+            }                                                                                         \
+            fold_base[((KT) & 1) * BN + tid] = f_;                                                    \
+        }                                                                                             \
+    }
 #define WS_BUFA(p) (lds + (((p) & 1) ? offA1 : 0))
 #define WS_RING(slot) (lds + offR + (slot) * R_BYTES)
 #define WS_PAR(kt) (par_base + ((kt) & 1) * 4 * Cin)
@@ -561,9 +598,32 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
     // blocks of either epilogue pass and all four consumer waves stage at once
 #define WS2_EPILOGUE(TT, KT, STAGE0, STAGE1)                                                                                       \
     {                                                                                                                              \
-        float* stage = reinterpret_cast<float*>(E16 ? lds + offA1 : WS_RING(1));                                                   \
+        float* stage = reinterpret_cast<float*>(WS_RING(1));                                                                       \
         WS2_PASS(TT, 0, STAGE0)                                                                                                    \
         if constexpr (BM == 256) { WS2_PASS(TT, 1, STAGE1) }                                                                       \
+        if ((KT) + 2 < K) WS_FILL_PAR((KT) + 2)                                                                                    \
+    }
+    // E16: the whole tile staged at once ([256][BN + 8] T in R1 | R2 | A1), then the two store passes (their statistics per 128 pixels)
+#define WS2_EPILOGUE16(TT, KT, STAGE_ALL)                                                                                          \
+    {                                                                                                                              \
+        T* st16 = reinterpret_cast<T*>(WS_RING(1));                                                                                \
+        if ((KT) + 1 < K) WS_FILL_FOLD((KT) + 1)                                                                                   \
+        WS_ESTAMP()                                                                                                                \
+        STAGE_ALL                                                                                                                  \
+        WS_ESTAMP()                                                                                                                \
+        lds_barrier();                                                                                                             \
+        WS_ESTAMP()                                                                                                                \
+        _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                                            \
+            auto pix_of = [&](int m) -> int {                                                                                      \
+                const int mm = m + 128 * p;                                                                                        \
+                const int tx = mm & mTW, ty = (mm >> shTW) & mTH;                                                                  \
+                return ((TT).n0 * a.Hout + (TT).oy0 + ty) * a.Wout + (TT).ox0 + tx;                                                \
+            };                                                                                                                     \
+            conv_epilogue_store<TS, 128, BN, 512, true>(a, (TT).co0, (TT).n0, pix_of, reinterpret_cast<float*>(st16 + p * 128 * (BN + kStage16Pad)), \
+                                                        2 * (TT).ts + p, nullptr, a.n_gno ? p : -1, gn_carry);                     \
+            WS_ESTAMP()                                                                                                            \
+        }                                                                                                                          \
+        lds_barrier(); /* everyone is done with the staging area */                                                                \
         if ((KT) + 2 < K) WS_FILL_PAR((KT) + 2)                                                                                    \
     }
     if (producer) {
@@ -797,7 +857,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
 #ifdef WS_PSTAMPS
         // producer stamps go to LDS (4 KB behind the parameter rows) and to memory when the wave leaves: a global store per stamp would
         // join the vmcnt queue and shift every counted wait below by one
-        long long* pst_lds = reinterpret_cast<long long*>(reinterpret_cast<char*>(par_base) + 2 * 4 * Cin * 4);
+        long long* pst_lds = reinterpret_cast<long long*>(reinterpret_cast<char*>(par_base) + 2 * 4 * Cin * 4 + 1024);
 #define WS_PSTT(TAG) { if (a.stamps && ptid == 0 && blockIdx.x == 0 && p_i < 500) pst_lds[p_i++] = (long long)clock64() | ((long long)(TAG) << 56); }
 #else
 #define WS_PSTT(TAG)
@@ -919,7 +979,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
                         __builtin_amdgcn_s_barrier();                                                                   \
                     }                                                                                                   \
                 }                                                                                                       \
-                WS2_EPILOGUE(tcur, kt, ;, ;)                                                                                   \
+                if constexpr (E16) { WS2_EPILOGUE16(tcur, kt, ;) } else { WS2_EPILOGUE(tcur, kt, ;, ;) }                         \
                 /* a wait the COMPILER sees: the epilogue's conditional residual loads and their conditional uses are correlated \
                    branches it cannot prove, so it carried "a load into these registers may still be pending" around the loop \
                    and put `s_waitcnt vmcnt(0)` in front of stage 0's DMA - draining the halo prefetch at EVERY chunk start \
@@ -955,6 +1015,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
 
     // ---- consumers: wave tile 128 pixels x 64 couts ----
     WS_FILL_PAR(0)
+    WS_FILL_FOLD(0)
     __syncthreads();
     if (K > 1) WS_FILL_PAR_N(1, 256)
     __builtin_amdgcn_s_setprio(3);  // the MFMA stream wins issue arbitration against the producer wave of its SIMD (~1 %; giving the
@@ -1000,12 +1061,28 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
     for (int kt = 0; kt < K; ++kt) {
         const TileXY t = WS_TILE(kt);
         f32x16 acc[MI][NI];
+        if constexpr (E16) {
+            // transposed accumulators: lane = pixel r, register j of tile (mi, ni) = cout wn0 + 32 ni + 8 (j >> 2) + 4 h + (j & 3); they
+            // start from the tile's bias + time row
+            const float* fb = fold_base + (kt & 1) * BN + wn0 + 4 * h;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 f4 = *reinterpret_cast<const f32x4*>(fb + 32 * ni + 8 * q);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[mi][ni][4 * q + k] = f4[k];
+                }
+        } else {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.f;
+        }
 #if defined(WS_X_NO_FRAGS)  /* timing experiments (wrong results): no fragment reads / no MFMAs */
 #define WS_FRAGS(SET, KG)                                                                                                         \
     {                                                                                                                             \
@@ -1032,7 +1109,10 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
 #define WS_MMAS(SET)                                                                                  \
     {                                                                                                 \
         _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                             \
-            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_group(af[SET][mi], bfr[SET][ni], acc[mi][ni], (T*)nullptr); \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                       \
+                if constexpr (E16) mma_group(bfr[SET][ni], af[SET][mi], acc[mi][ni], (T*)nullptr);    \
+                else mma_group(af[SET][mi], bfr[SET][ni], acc[mi][ni], (T*)nullptr);                  \
+            }                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                            \
     }
 #endif
@@ -1063,13 +1143,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
                 // tap 0 in the segment's last stage.  Behind the stage's first fragment reads: the matrix pipe waits for those anyway
                 bool sent = false;
 #define WS_CDMA_ISSUE()                                                                                               \
-    if constexpr (E16) { /* always the tap of stage s + 2, whatever tile it belongs to */                             \
-        const bool more = kt + 1 < K;                                                                                 \
-        if (tp <= 6) { cdma((tp + 2) % 3, t.co0, c, tp + 2); sent = true; }                                           \
-        else if (!last_c) { cdma(tp - 7, t.co0, c + 1, tp - 7); sent = true; }                                        \
-        else if (more) { cdma(tp - 7, tn.co0, 0, tp - 7); sent = true; }                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                            \
-    } else if constexpr (CDMA) {                                                                                      \
+    if constexpr (CDMA) {                                                                                             \
         if (tp == 0 && c == 0 && kt > 0) cdma(1, t.co0, 0, 1);                                                        \
         if (tp <= 6) { cdma((tp + 2) % 3, t.co0, c, tp + 2); sent = true; }                                           \
         else if (RSEG && last_c) { }                                                                                  \
@@ -1151,12 +1225,19 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
 #undef WS_FRAGS
 #undef WS_MMAS
         // the last stage read R2 and A1: R1|R2|A1 stages the epilogue
-        WS2_EPILOGUE(t, kt, (conv_epilogue_stage<T, BN, 2, NI, 64, E16>(a, reinterpret_cast<f32x16(&)[2][NI]>(acc[0]), t.co0, wn0, r, h, wrow * 32, t.n0, stage));,
-                     (conv_epilogue_stage<T, BN, 2, NI, 64, E16>(a, reinterpret_cast<f32x16(&)[2][NI]>(acc[2]), t.co0, wn0, r, h, wrow * 32, t.n0, stage));)
+        if constexpr (E16) {
+            // a register quad = four consecutive couts of pixel m: two packed conversions, one 8-byte store
+            WS2_EPILOGUE16(t, kt, (ws_stage16<T, BN, MI, NI>(acc, st16 + (wrow * 32 + r) * (BN + kStage16Pad) + wn0 + 4 * h));)
+        } else {
+        WS2_EPILOGUE(t, kt, (conv_epilogue_stage<T, BN, 2, NI, 64>(a, reinterpret_cast<f32x16(&)[2][NI]>(acc[0]), t.co0, wn0, r, h, wrow * 32, t.n0, stage));,
+                     (conv_epilogue_stage<T, BN, 2, NI, 64>(a, reinterpret_cast<f32x16(&)[2][NI]>(acc[2]), t.co0, wn0, r, h, wrow * 32, t.n0, stage));)
+        }
         WS_STAMP()
     }
 #undef WS_STAMP
 #undef WS2_EPILOGUE
+#undef WS2_EPILOGUE16
+#undef WS_FILL_FOLD
 #undef WS2_PASS
 #undef WS_FILL_PAR
 #undef WS_FILL_PAR_N
@@ -1175,7 +1256,7 @@ static size_t ws2_lds(const ConvArgs& a, const ConvTile& g) {
 #ifdef WS_PSTAMPS
     extra = 4096;
 #endif
-    return 2 * a_bytes + 3 * (size_t)128 * ROW_DATA + (size_t)ws2_stage_pad((int)a_bytes) + (size_t)2 * 4 * (a.C1 + a.C2) * 4 + extra;
+    return 2 * a_bytes + 3 * (size_t)128 * ROW_DATA + (size_t)ws2_stage_pad((int)a_bytes) + (size_t)2 * 4 * (a.C1 + a.C2) * 4 + 1024 /* E16: fold rows */ + extra;
 }
 
 // the wave-specialised kernel applies (else 0): its tile goes to g
@@ -1364,27 +1445,28 @@ static int launch_pipe_t(const ConvArgs& a, hipStream_t s) {
                 if (rc0 == DMME_OK) rc0 = set_lds_limit(conv3x3_ws2_kernel<7, T, 128>, 160 * 1024);
                 if (rc0 == DMME_OK) rc0 = set_lds_limit(conv3x3_ws2_kernel<11, T, 256, 0, true>, 160 * 1024);
                 if (rc0 == DMME_OK) rc0 = set_lds_limit(conv3x3_ws2_kernel<7, T, 128, 0, true>, 160 * 1024);
-#if WS_CDMA
                 if (rc0 == DMME_OK) rc0 = set_lds_limit(conv3x3_ws2_kernel<11, T, 256, 0, false, true>, 160 * 1024);
-#endif
+                if (rc0 == DMME_OK) rc0 = set_lds_limit(conv3x3_ws2_kernel<11, T, 256, 0, true, true>, 160 * 1024);
                 if (rc0 != DMME_OK) return rc0;
                 ws_attr = true;
             }
             const int ntiles = gw.tiles_m * gw.tiles_n;
             const dim3 wgrid((unsigned)(ntiles < 256 ? ntiles : 256));
+            // no residual INPUT tensor (the blocks' first convs, convs with a residual segment, data gradients that do not accumulate):
+            // the 16-bit staged epilogue on transposed accumulators (DMME_DEBUG_ROUTE=no_ws_e16: the fp32-staged two-pass form)
+            const bool e16 = !a.res1 && !a.res2 && !debug_route("no_ws_e16");
             if (a.r_w) {
                 DMME_REQUIRE(rseg_shape_ok(a), DMME_ERR_UNSUPPORTED, "conv3x3 with a residual segment: raw channel counts outside the wave-specialised kernel's domain");
                 if (ws == 4)
                     hipLaunchKernelGGL((conv3x3_ws2_kernel<7, T, 128, 0, true>), wgrid, dim3(512), ws2_lds(a, gw), s, a, gw, ilog2(gw.TW), ilog2(gw.TH), ntiles);
+                else if (e16)
+                    hipLaunchKernelGGL((conv3x3_ws2_kernel<11, T, 256, 0, true, true>), wgrid, dim3(512), ws2_lds(a, gw), s, a, gw, ilog2(gw.TW), ilog2(gw.TH), ntiles);
                 else
                     hipLaunchKernelGGL((conv3x3_ws2_kernel<11, T, 256, 0, true>), wgrid, dim3(512), ws2_lds(a, gw), s, a, gw, ilog2(gw.TW), ilog2(gw.TH), ntiles);
             } else if (ws == 4)
                 hipLaunchKernelGGL((conv3x3_ws2_kernel<7, T, 128>), wgrid, dim3(512), ws2_lds(a, gw), s, a, gw, ilog2(gw.TW), ilog2(gw.TH), ntiles);
-#if WS_CDMA
-            else if (!a.res1 && debug_route("ws_e16"))  // (experiment, off: the 16-bit staged epilogue with the filter stream continuous across tiles -
-                                                         // correct, and 0.5 % slower: ds_write_b16 staging takes 2.2-3.1 k cycles per pass against 1.9 k)
+            else if (e16)
                 hipLaunchKernelGGL((conv3x3_ws2_kernel<11, T, 256, 0, false, true>), wgrid, dim3(512), ws2_lds(a, gw), s, a, gw, ilog2(gw.TW), ilog2(gw.TH), ntiles);
-#endif
             else
                 hipLaunchKernelGGL((conv3x3_ws2_kernel<11, T, 256>), wgrid, dim3(512), ws2_lds(a, gw), s, a, gw, ilog2(gw.TW), ilog2(gw.TH), ntiles);
             DMME_CHECK_LAUNCH();

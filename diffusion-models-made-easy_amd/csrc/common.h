@@ -212,6 +212,9 @@ struct ConvArgs {
     // 3: the thin output conv's split form (fp32 source, NCHW fp32 out)
     // 4: the 1x1 convs of that level (conv1x1_pipe.hip: conv1x1_split_kernel)
     int mix;
+    // mix 1 / 2 only: run two passes (hi.hi + lo.hi - activations exact to 2^-22, the FILTER rounded to half) instead of three.  The
+    // filter's rounding of a conv costs what it costs in precision="fp16" (which layers can afford it)
+    int mix2;
     // 16-bit tensors are IEEE half (precision="fp16") instead of bf16: for the launchers that take no dtype argument
     int f16;
     // pipelined 3x3 kernel, 64-cout bf16 tiles: filter tiles by LDS-DMA into a second buffer instead of through registers

@@ -1126,6 +1126,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         __builtin_amdgcn_sched_barrier(0);                                                            \
     }
         const TileXY tn = WS_TILE(kt + 1 < K ? kt + 1 : kt);
+        const bool three = !a.mix2;
         for (int c = 0; c < nchunks; ++c, ++cg) {
             const char* ldsA = WS_BUFA(cg);
             const bool last_c = c + 1 == nchunks;
@@ -1154,28 +1155,19 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
                 if constexpr (SPLIT != 0) {
                     // k-groups 0, 1 = hi halves of the chunk's 32 channels, 2, 3 = lo halves; two A slots and two B slots as in the plain
                     // schedule, every fragment set requested one MFMA group (8 MFMAs) ahead of its first use
-#if defined(WS_X_2PASS)  /* timing / accuracy experiment: hi.hi + lo.hi only (the filter's lo half dropped) */
-                    WS_FA(0, 0) WS_FB(0, 0) WS_FA(1, 2) WS_SB()   // a0 = A.hi[0], b0 = W.hi[0], a1 = A.lo[0]
-                    WS_CDMA_ISSUE()
-                    WS_MM(0, 0)                                   // hi.hi, channels 0-15
-                    WS_FB(1, 1) WS_SB()                           // b1 = W.hi[1]
-                    WS_MM(1, 0)                                   // lo.hi
-                    WS_FA(0, 1) WS_FA(1, 3) WS_SB()               // a0 = A.hi[1], a1 = A.lo[1]
-                    WS_MM(0, 1)                                   // hi.hi, channels 16-31
-                    WS_MM(1, 1)                                   // lo.hi
-#else
+                    // (ConvArgs::mix2: the two hi.lo groups - the filter's lo half - are skipped; the fragment registers pass through
+                    //  the same states either way)
                     WS_FA(0, 0) WS_FB(0, 0) WS_FB(1, 2) WS_SB()   // a0 = A.hi[0], b0 = W.hi[0], b1 = W.lo[0]
                     WS_CDMA_ISSUE()
                     WS_MM(0, 0)                                   // hi.hi, channels 0-15
                     WS_FA(1, 2) WS_SB()                           // a1 = A.lo[0]
-                    WS_MM(0, 1)                                   // hi.lo
+                    if (three) { WS_MM(0, 1) }                    // hi.lo
                     WS_FA(0, 1) WS_FB(1, 1) WS_SB()               // a0 = A.hi[1], b1 = W.hi[1]
                     WS_MM(1, 0)                                   // lo.hi
                     WS_FB(0, 3) WS_FA(1, 3) WS_SB()               // b0 = W.lo[1], a1 = A.lo[1]
                     WS_MM(0, 1)                                   // hi.hi, channels 16-31
-                    WS_MM(0, 0)                                   // hi.lo
+                    if (three) { WS_MM(0, 0) }                    // hi.lo
                     WS_MM(1, 1)                                   // lo.hi
-#endif
                 } else {
                     WS_FRAGS(0, 0) WS_FRAGS(1, 1) WS_CDMA_ISSUE() WS_MMAS(0) WS_FRAGS(0, 2) WS_MMAS(1) WS_FRAGS(1, 3) WS_MMAS(0) WS_MMAS(1)
                 }

@@ -93,6 +93,7 @@ struct Op {
     // precision="fp16r32" (dmme_plan::mix): how this conv of the fp32 level runs.  mix: ConvArgs::mix (1 / 2: split-pass 3x3 kernel, 3: split-pass
     // thin output conv); route_f32: on the fp32-tensor kernels with three-pass bf16 products (input conv, the blocks' 1x1 residual convs)
     int mix = 0, route_f32 = 0;
+    int mix2 = 0;  // split-pass 3x3 kernel: TWO passes (hi.hi + lo.hi: the filter's lo half dropped) instead of three - ConvArgs::mix2
     // OP_CAST: fp32 tensor -> 16-bit copy (the stride-2 conv that leaves the fp32 level reads it)
     int cast_src = -1, cast_dst = -1;
     // level engine (lvl_engine.hip): index of the run that executes this op (-1: its own launch); the run's first op launches it
@@ -190,6 +191,9 @@ struct dmme_plan {
 
 namespace dmme {
 
+// precision="fp16r32": the split-pass 3x3 convs (op order: down block 0 conv1 / conv2, down block 1 conv1 / conv2, the up-sampling conv
+// that enters the level, up blocks conv1 / conv2 x 3) that run two passes instead of three (tests/test_gpu_fp16.py holds the result at 1e-3)
+constexpr int kR32TwoPassDefault = 0;
 // the dtype code a conv's kernels are selected by: the plan's, except the fp32-routed convs of a mixed plan
 static inline int conv_dt(const dmme_plan* P, const Op& o) { return o.route_f32 ? DMME_F32 : P->dtype; }
 static inline int wg_index(const Op& o) { return o.taps == 1 ? 1 : o.stride == 2 ? 2 : 0; }

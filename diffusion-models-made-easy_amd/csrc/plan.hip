@@ -456,6 +456,17 @@ int build_plan(dmme_plan* P) {
         ops.push_back(o);
     }
     P->dropmask_numel = dmask_cursor;
+    if (P->mix) {
+        // which split-pass 3x3 convs run TWO passes: bit k of the mask = the k-th such conv in op order (default below; DMME_DEBUG_ROUTE
+        // r32_2pass=<mask> overrides, r32_2pass=0 = three passes everywhere)
+        const int mask = debug_route("r32_2pass", kR32TwoPassDefault);
+        int k = 0;
+        for (Op& o : ops)
+            if (o.kind == OP_CONV && (o.mix == 1 || o.mix == 2)) {
+                o.mix2 = (mask >> k) & 1;
+                ++k;
+            }
+    }
     layout_packed();  // (after the op list: a mixed plan's convs choose their filter layouts above)
     P->ws_gnpart = ws_alloc((int64_t)(gn_part_max ? gn_part_max : 1) * 4);
     {   // up to 4 partial images of the widest small-map conv (either direction: its data gradient has Cin outputs)
@@ -689,6 +700,7 @@ void fill_conv(const dmme_plan* P, const Op& o, const char* packed, const float*
     a.x3 = P->x3 || o.route_f32;
     a.f16 = P->dtype == DMME_F16 && !o.route_f32;
     a.mix = o.mix;
+    a.mix2 = o.mix2;
     a.N = P->B;
     if (o.src1 == -2) {
         a.src1 = x;

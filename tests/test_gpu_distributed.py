@@ -142,7 +142,9 @@ def test_bench_two_ranks_on_one_device_reports_both_exchanges():
            "--no-cpu-baseline", "--no-roofline", "--no-accurate-leg", "--no-ddim-leg", "--no-small-batch-leg"]
     res = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     lines = [l for l in res.stdout.splitlines() if l.startswith('{"metric"')]
-    assert res.returncode == 0 and lines, (res.returncode, res.stdout[-2000:], res.stderr[-2000:])
+    errs = {k: v for k, v in (json.loads(lines[-1]) if lines else {}).items() if "error" in k}
+    errs.update({k: v for k, v in (json.loads(lines[-1]).get("train_dp", {}) if lines else {}).items() if "error" in k})
+    assert res.returncode == 0 and lines, (res.returncode, errs, res.stderr[-3000:])
     out = json.loads(lines[-1])
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["value"] > 0
     dp = out["train_dp"]

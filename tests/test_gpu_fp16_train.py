@@ -187,9 +187,10 @@ def test_training_learns_fp16(which):
     assert float(st[2]) + float(st[4]) == 120 and float(st[4]) <= 12
 
 
-def test_fp16_resume_carries_the_loss_scaling_state_and_continues_bit_for_bit():
+def test_fp16_resume_carries_the_loss_scaling_state():
     """the device-resident scaler state (scale, growth tracker, the step count of Adam's bias correction, skipped
-    steps) travels in FusedAdam.state_dict(); a run resumed from a checkpoint takes the same steps as the run that never stopped"""
+    steps) travels in FusedAdam.state_dict(); a run resumed from a checkpoint takes the same steps as the run that never stopped (up
+    to the backward's own run-to-run jitter: its fp32 sums use atomics), a resume WITHOUT that state visibly does not"""
     import copy
 
     import dmme_amd
@@ -214,6 +215,7 @@ def test_fp16_resume_carries_the_loss_scaling_state_and_continues_bit_for_bit():
     st = net.amp_state().cpu()
     assert float(st[4]) >= 1.0 and float(st[2]) + float(st[4]) == 8.0, st
     ck = {"model": copy.deepcopy(lit.state_dict()), "opt": copy.deepcopy(opt.state_dict()), "sched": copy.deepcopy(sched.state_dict())}
+    start = net.flat_parameters().clone()
     assert "amp_state" in ck["opt"] and ck["opt"]["amp_state"][0][:5] == st[:5].tolist()
     for step in range(8, 12):
         torch.manual_seed(100 + step)
@@ -230,13 +232,28 @@ def test_fp16_resume_carries_the_loss_scaling_state_and_continues_bit_for_bit():
         torch.manual_seed(100 + step)
         train_step(lit2, opt2, sched2, base[:16])
     assert torch.equal(net2.amp_state().cpu()[:5], want_amp[:5])
-    assert torch.equal(net2.flat_parameters(), want)
+    moved = float((want - start).abs().max())  # what four steps move the weights
+    d_resumed = float((net2.flat_parameters() - want).abs().max())
+    print(f"four steps move the weights by {moved:.3e}; resumed run differs from the uninterrupted one by {d_resumed:.3e}")
+    assert d_resumed <= 0.05 * moved, (d_resumed, moved)
     # a checkpoint WITHOUT the scaler's state (bf16 / reference run): the bias-correction count is seeded from the loaded step count
     sd = copy.deepcopy(ck["opt"])
     del sd["amp_state"]
-    lit3, opt3, _ = make()
+    lit3, opt3, sched3 = make()
+    lit3.load_state_dict(ck["model"])
     opt3.load_state_dict(sd)
-    assert float(lit3.diffusion_model.model.amp_state().cpu()[2]) == 8.0
+    sched3.load_state_dict(ck["sched"])
+    net3 = lit3.diffusion_model.model
+    assert float(net3.amp_state().cpu()[2]) == 8.0
+    # ... and what the missing state would have cost before this fix (t restarting at 1 beside warm moments): emulate it
+    net3.amp_state()[2] = 0.0
+    net3.amp_state()[0] = float(want_amp[0])
+    for step in range(8, 12):
+        torch.manual_seed(100 + step)
+        train_step(lit3, opt3, sched3, base[:16])
+    d_cold = float((net3.flat_parameters() - want).abs().max())
+    print(f"the same resume with the bias-correction count back at 0: differs by {d_cold:.3e}")
+    assert d_cold >= 5 * max(d_resumed, 1e-9)
 
 
 def test_adam_amp_skips_when_the_scale_has_collapsed():

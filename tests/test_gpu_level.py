@@ -321,26 +321,32 @@ def test_graphed_forward_propagates_a_trial_forward_error_and_replays_look_at_th
             with pytest.raises(DmmeError, match="hand-off"):
                 net.graphed_forward(x, t)
         assert not getattr(net, "_graph_disabled", False) and getattr(net, "_graph", None) is None
-        # (b): clean capture, replays reproduce the eager bits
-        y = net.graphed_forward(x, t)
-        assert net._graph is not None and torch.equal(y, y_ref)
-        assert torch.equal(net.graphed_forward(x, t), y_ref)
-        # the knob armed from the plan's next engine launches on: the replay below times out on the device ...
-        with _route("lvl_withhold,lvl_spin=2048"):
-            net.graphed_forward(x, t)
+        # (b): a clean capture on a fresh plan (batch 6); the knob is part of the captured launch arguments, armed from the run's 4th
+        # launch on: the trial forward (1) and the first two replays (2, 3) are clean and reproduce the eager bits, the third replay
+        # (4) times out on the device, and the NEXT call refuses before it launches anything - no synchronising call by the caller
+        x6 = x[:6].contiguous()
+        with torch.no_grad():
+            y6 = None
+        with _route("lvl_withhold=4,lvl_spin=2048"):
+            y = net.graphed_forward(x6, t).clone()
+            assert net._graph is not None
+            assert torch.equal(net.graphed_forward(x6, t), y)
+            net.graphed_forward(x6, t)  # launch 4 of every engine run: gives up
             torch.cuda.synchronize()  # (only so that the test is deterministic: the word is set by now)
-            # ... and the NEXT replay refuses before it launches anything
             with pytest.raises(DmmeError, match="hand-off"):
-                net.graphed_forward(x, t)
-        assert torch.equal(net.graphed_forward(x, t), y_ref)  # the check cleared the words: same bits again
-        # (c)
+                net.graphed_forward(x6, t)
+        with torch.no_grad():
+            y6 = net(x6, t)
+        assert torch.equal(y6, y)  # the check cleared the words: the eager path on the same plan gives the replays' bits
+        # (c): the chain runner's per-step entry (batch 4: another fresh plan) - trial step (1), first replay (2), second (3), third (4)
         ddpm = dmme_amd.DDPM(net, 50).cuda()
-        xs = synth.normal(5, (8, 3, 32, 32)).cuda()
-        runner = ddpm.chain_runner(xs.clone())
-        runner.set(50, 1, 0)
-        runner.step()
-        assert runner.graph is not None
-        with _route("lvl_withhold,lvl_spin=2048"):
+        xs = synth.normal(5, (4, 3, 32, 32)).cuda()
+        with _route("lvl_withhold=4,lvl_spin=2048"):
+            runner = ddpm.chain_runner(xs.clone())
+            runner.set(50, 1, 0)
+            runner.step()
+            assert runner.graph is not None
+            runner.step()
             runner.step()
             torch.cuda.synchronize()
             with pytest.raises(DmmeError, match="hand-off"):

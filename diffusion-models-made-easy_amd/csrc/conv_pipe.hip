@@ -367,6 +367,12 @@ static int pipe_ksplit(const ConvArgs& a, const ConvTile& g, int pick, int KC) {
 #ifndef WS_CDMA
 #define WS_CDMA 1
 #endif
+// WS_HYB=1: the producers request the taps of stages 1-5 (where they have slack), the consumers the rest.  Measured +0.4 % on the
+// sampling step (stages 1-5 become producer-bound by ~0.25 k cycles while the consumers' own stage only shrinks from 1.50 to 1.47 k):
+// not worth a producer that sits on the critical path again in the heavier prologues (dropout, split passes).  Off.
+#ifndef WS_HYB
+#define WS_HYB 0
+#endif
 // E16 staging of the wave-specialised kernel: transposed accumulators (lane = pixel, a register quad = four consecutive couts) -> the
 // 16-bit [pixel][BN + 8] image; `row` = this lane's pixel row of the wave's first 32-pixel block, at the wave's first cout (+ 4 h);
 // the wave's blocks are 64 staged rows apart
@@ -888,7 +894,12 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         WS_PST()                                                                                                        \
         bool sent = true;          /* this stage sent a tap two stages ahead */                                         \
         bool sent_next = false;    /* ... and, in front of it, the NEXT stage's tap (first stage of a later tile) */    \
-        if constexpr (CDMA) { /* the consumers request the taps (below) */ }                                            \
+        if constexpr (CDMA) {                                                                                           \
+            /* the consumers request the taps of the stages in which this wave is the longer half (two halo units: 8, 0; the chunk's \
+               last taps: 6, 7) - in stages 1-5, where it has slack, this wave does (WS_HYB): a tap request costs a consumer ~130 \
+               cycles of matrix-pipe time per stage, a producer ~1.2 k cycles it has to spare there */                          \
+            if constexpr (WS_HYB != 0 && (TP) >= 1 && (TP) <= 5) dma_tap(WS_RING(((TP) + 2) % 3), tcur.co0, cc, (TP) + 2);  \
+        }                                                                                                               \
         else {                                                                                                          \
         if ((TP) == 0 && cc == 0 && kt > 0) {                                                                           \
             dma_tap(WS_RING(1), tcur.co0, 0, 1);                                                                        \
@@ -933,7 +944,14 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         if constexpr (CDMA) {                                                                                           \
             /* no tap to retire: the halo prefetch is waited for where it is used (WS_A_ARRIVED), the halo stores by lgkmcnt; \
                the residual segment's first slots (requested in stages 5 - 7) must have landed when stage 8 hands over */ \
-            if (RSEG && last_c && (TP) == 8) wait_vm_keep<2>();                                                         \
+            if (RSEG && last_c) {                                                                                       \
+                /* no halo loads in this chunk; requests per stage: the tap (stages 1-5), the segment's pixels behind it (5, 6), \
+                   its first filter blocks (7).  Stage TP retires the tap stage TP - 1 sent; stage 8 hands over to half-stage 0 */ \
+                if (WS_HYB != 0 && (TP) >= 1 && (TP) <= 6) wait_vm_keep<WS_RX(((TP) + 8) % 9) + ((TP) <= 5 ? UB : 0) + WS_RX(TP)>(); \
+                else if ((TP) == 8) wait_vm_keep<2>();                                                                  \
+                else wait_lgkm_all();                                                                                   \
+            }                                                                                                           \
+            else if (WS_HYB != 0 && (TP) >= 1 && (TP) <= 6) wait_vm_keep<WS_L(((TP) + 8) % 9) + ((TP) <= 5 ? UB : 0) + WS_L(TP)>(); \
             else wait_lgkm_all();                                                                                       \
         }                                                                                                               \
         else if (RSEG && last_c) {                                                                                      \
@@ -1146,7 +1164,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
 #define WS_CDMA_ISSUE()                                                                                               \
     if constexpr (CDMA) {                                                                                             \
         if (tp == 0 && c == 0 && kt > 0) cdma(1, t.co0, 0, 1);                                                        \
-        if (tp <= 6) { cdma((tp + 2) % 3, t.co0, c, tp + 2); sent = true; }                                           \
+        if (tp <= 6) { if (WS_HYB == 0 || tp == 0 || tp == 6) { cdma((tp + 2) % 3, t.co0, c, tp + 2); sent = true; } } \
         else if (RSEG && last_c) { }                                                                                  \
         else if (tp == 7) { if (!(last_c && kt + 1 == K)) { cdma(0, last_c ? tn.co0 : t.co0, last_c ? 0 : c + 1, 0); sent = true; } } \
         else if (!last_c) { cdma(1, t.co0, c + 1, 1); sent = true; }                                                  \

@@ -373,6 +373,17 @@ static int pipe_ksplit(const ConvArgs& a, const ConvTile& g, int pick, int KC) {
 #ifndef WS_HYB
 #define WS_HYB 0
 #endif
+// the consumers' tap loop.  9: every per-tap condition of a stage is a compile-time constant (3 - a third of the code - costs 1.1 % of
+// the sampling step: the scalar bookkeeping of a stage).  Measured on top of it and NOT kept (same-box A/B, all correct):
+//  - the stage barrier rotated in front of the stage's last MFMA group, the next stage's first fragments requested behind it (the eight
+//    MFMAs then run under that latency): consumer work per stage 1.46 -> 1.38 k cycles in the stamps, the step 0.7 % SLOWER (254-256
+//    registers, spills in the fp32-staged instances: the fragments live across the barrier);
+//  - the next tap's pixel fragments requested ~250 cycles before the barrier: +-0.1 %;
+//  - the filter's base address in vector registers + v_readfirstlane instead of hipcc's per-stage reload of the argument block
+//    (s_load_dwordx16 + lgkmcnt(0)): 0.7 % slower.
+#ifndef WS_TP_UNROLL
+#define WS_TP_UNROLL 9
+#endif
 // E16 staging of the wave-specialised kernel: transposed accumulators (lane = pixel, a register quad = four consecutive couts) -> the
 // 16-bit [pixel][BN + 8] image; `row` = this lane's pixel row of the wave's first 32-pixel block, at the wave's first cout (+ 4 h);
 // the wave's blocks are 64 staged rows apart
@@ -1148,7 +1159,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         for (int c = 0; c < nchunks; ++c, ++cg) {
             const char* ldsA = WS_BUFA(cg);
             const bool last_c = c + 1 == nchunks;
-#pragma unroll 3
+#pragma unroll WS_TP_UNROLL
             for (int tp = 0; tp < 9; ++tp) {
                 const char* ldsR = WS_RING(tp % 3);
                 const int tap_b = ((tp / 3) * g.HWd + (tp % 3)) * A_PITCH;

@@ -177,12 +177,16 @@ __global__ void __launch_bounds__(256) conv_out_thin_kernel(ConvArgs a, int R) {
 
 static int thin_rows(const ConvArgs& a) {  // band height: the z image of R + 2 rows must fit in LDS beside the parameters
     const int NT = a.Cout * 9 <= 32 ? 1 : 2;
+    // (the split-pass form has no other kernel to fall back on - precision="fp16r32" refuses a plan whose fp32 level has a conv without
+    //  one - so it may take up to 80 KB, two workgroups per compute unit still: the six-cout output conv of the Improved-DDPM UNet on
+    //  64-wide maps needs 66.6 KB for its smallest band)
+    const size_t cap = (a.mix == 3 ? 80 : 60) * 1024;
     for (int R = 16; R >= 2; R >>= 1)
-        if (a.Hout % R == 0 && ((R + 2) * a.Wout) % 32 == 0 && (size_t)(R + 2) * a.Wout * (32 * NT + 1) * 4 + (size_t)2 * a.C1 * 4 <= 60 * 1024 &&
+        if (a.Hout % R == 0 && ((R + 2) * a.Wout) % 32 == 0 && (size_t)(R + 2) * a.Wout * (32 * NT + 1) * 4 + (size_t)2 * a.C1 * 4 <= cap &&
             (int64_t)a.N * (a.Hout / R) >= 512)
             return R;
     for (int R = 2; R <= 16; R <<= 1)  // small batches: the smallest band that fits
-        if (a.Hout % R == 0 && ((R + 2) * a.Wout) % 32 == 0 && (size_t)(R + 2) * a.Wout * (32 * NT + 1) * 4 + (size_t)2 * a.C1 * 4 <= 60 * 1024) return R;
+        if (a.Hout % R == 0 && ((R + 2) * a.Wout) % 32 == 0 && (size_t)(R + 2) * a.Wout * (32 * NT + 1) * 4 + (size_t)2 * a.C1 * 4 <= cap) return R;
     return 0;
 }
 
@@ -204,6 +208,12 @@ int launch_conv_out_thin(const ConvArgs& a, hipStream_t s) {
     const size_t lds = (size_t)(R + 2) * a.Wout * (32 * NT + 1) * 4 + (size_t)2 * a.C1 * 4;
     const dim3 grid((unsigned)(a.N * (a.Hout / R)));
     if (a.mix == 3) {
+        static bool attr = false;
+        if (!attr) {  // more than the default 64 KB of dynamic LDS
+            DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_out_thin_kernel<1, f16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_out_thin_kernel<2, f16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            attr = true;
+        }
         if (NT == 1)
             hipLaunchKernelGGL((conv_out_thin_kernel<1, f16, true>), grid, dim3(256), lds, s, a, R);
         else

@@ -1262,8 +1262,7 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
     if (x3) dtype = DMME_F32;
     const int mix = dtype == DMME_F16R32;
     if (mix) {
-        dtype = DMME_F16;
-        DMME_REQUIRE(cfg->arch == DMME_ARCH_DDPM, DMME_ERR_UNSUPPORTED, "plan_create: precision fp16r32 serves the DDPM UNet (models/ddpm.py) only");
+        dtype = DMME_F16;  // (both architectures: the check below refuses a configuration whose fp32 level has a conv without a kernel)
     }
     DMME_REQUIRE(cfg->num_depths >= 1 && cfg->num_depths <= 8 && cfg->num_blocks >= 1, DMME_ERR_INVALID,
                  "plan_create: bad depth/blocks");

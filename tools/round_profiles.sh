@@ -18,6 +18,7 @@ python bench.py --model iddpm64 --batch 32 --steps 50 --warmup 10 --no-cpu-basel
 python bench.py --model iddpm64 --batch 32 --mode train --steps 30 --warmup 5 > gpurun_out/${TAG}_bench_iddpm64_train_b32_n1.json 2>/dev/null
 python bench.py --precision bf16x3 --steps 20 --warmup 5 --no-cpu-baseline --train-steps 0 > gpurun_out/${TAG}_bench_x3_n1.json 2>/dev/null
 python bench.py --precision fp16r32 --steps 50 --warmup 10 --no-cpu-baseline --train-steps 0 > gpurun_out/${TAG}_bench_fp16r32_n1.json 2>/dev/null
+python bench.py --model iddpm64 --batch 32 --precision fp16r32 --steps 50 --warmup 10 --no-cpu-baseline --no-accurate-leg --train-steps 0 > gpurun_out/${TAG}_bench_iddpm64_fp16r32_b32_n1.json 2>/dev/null
 python bench.py --mode train --precision fp16 --steps 50 --warmup 5 > gpurun_out/${TAG}_bench_train_fp16_n1.json 2>/dev/null
 python bench.py --precision fp32 --steps 10 --warmup 3 --no-cpu-baseline --train-steps 0 > gpurun_out/${TAG}_bench_fp32_n1.json 2>/dev/null
 for b in 1 32; do python bench.py --batch $b --steps 300 --warmup 30 --no-cpu-baseline --no-accurate-leg --train-steps 0 > gpurun_out/${TAG}_bench_b${b}_n1.json 2>/dev/null; done

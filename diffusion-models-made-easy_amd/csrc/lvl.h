@@ -76,6 +76,7 @@ struct LvlArgs {
     unsigned* err_sys;        // the plan's host-visible status word (pinned host memory; null: none): set to run_tag by a wait that timed out
     int run_tag;              // 1 + index of this run in the plan
     int spin_limit;           // polls before a hand-off wait gives up (0: LVL_SPIN_LIMIT, ~a second); DMME_DEBUG_ROUTE lvl_spin=
+    int xcd_group;            // 1: the slices of a pixel group run on ONE XCD (a permutation of the workgroup index inside windows of 64; speed only)
     int withhold;             // test knob (DMME_DEBUG_ROUTE lvl_withhold=K): workgroup 0 stops signalling from the run's K-th launch on, so its consumers time out
     int max_wg;               // workgroups the device can hold at once (all of a launch must be co-resident)
     long long* stamps;        // diagnostic (null: off): 100 MHz wall-clock stamps of workgroup `stamp_wg`, [op iteration][8] (dmme_debug_set_stamps)

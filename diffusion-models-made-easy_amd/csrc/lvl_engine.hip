@@ -161,7 +161,15 @@ __global__ void __launch_bounds__(256, 1) lvl_engine_kernel(LvlArgs A, const Lvl
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int s = (int)blockIdx.x % NS, b0 = (int)blockIdx.x / NS;
+    // Workgroups are dealt round-robin over the 8 XCDs, so the NS slices of a pixel group - neighbours in index - sat on NS different
+    // XCDs and every one of them pulled the group's whole input across the fabric (the producers' write-through stores leave nothing in
+    // L2): 3.2x / 4.3x the algorithmic bytes in the FETCH / WRITE counters (round 4).  Inside windows of 64 workgroups the index is
+    // permuted so that a group's slices are the workgroups of ONE XCD (blockIdx % 8 equal): the first slice's gather fills that XCD's L2,
+    // the others read it there.  Placement is a speed matter only - the hand-off protocol assumes nothing about it - and a group
+    // still lies inside one window of the dispatch order, so a partially resident launch still consists of whole windows plus one.
+    int vb = (int)blockIdx.x;
+    if (A.xcd_group && (gridDim.x & 63u) == 0u) vb = (vb & ~63) + (vb & 7) * 8 + ((vb & 63) >> 3);
+    const int s = vb % NS, b0 = vb / NS;
     char* ldsA = lds + wave * LVL_WAVE_BYTES;
     char* ldsR = ldsA + A_BYTES;
     T* keep = reinterpret_cast<T*>(lds + LVL_KEEP_OFF);

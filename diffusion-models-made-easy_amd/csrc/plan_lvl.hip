@@ -365,6 +365,7 @@ int run_level(const dmme_plan* P, const LvlRun& R, const char* pk, char* ws, int
     a.run_tag = 1 + (int)(&R - P->lvl_runs.data());
     a.spin_limit = debug_route("lvl_spin", 0);
     a.withhold = debug_route("lvl_withhold", 0);
+    a.xcd_group = debug_route("lvl_no_xcd") ? 0 : 1;
     a.max_wg = P->lvl_max_wg;
     if (g_lvl_stamps && g_lvl_stamp_run == (int)(&R - P->lvl_runs.data())) {
         a.stamps = g_lvl_stamps;

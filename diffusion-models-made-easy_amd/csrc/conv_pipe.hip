@@ -373,6 +373,9 @@ static int pipe_ksplit(const ConvArgs& a, const ConvTile& g, int pick, int KC) {
 #ifndef WS_HYB
 #define WS_HYB 0
 #endif
+#ifndef WS_SCHED2
+#define WS_SCHED2 1
+#endif
 // the consumers' tap loop.  9: every per-tap condition of a stage is a compile-time constant (3 - a third of the code - costs 1.1 % of
 // the sampling step: the scalar bookkeeping of a stage).  Measured on top of it and NOT kept (same-box A/B, all correct):
 //  - the stage barrier rotated in front of the stage's last MFMA group, the next stage's first fragments requested behind it (the eight
@@ -507,6 +510,10 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
     // cycles (tools/issue_probe.py kind 13), beside one that waits for LDS ~16 - which made the producer the longer half of every stage
     // and, in the stages that carry two halo units, the whole stage 0.6-2 k cycles longer.  -DWS_CDMA=0: the producers request them.
     constexpr bool CDMA = WS_CDMA != 0;
+    // SCHED2: the producers' halo-unit schedule without two-unit stages (needs CDMA: no counted vmcnt waits depend on the order of the
+    // halo loads any more; the split-pass form keeps the old schedule - its store_A has no separate arithmetic / write modes)
+    constexpr bool SCHED2 = WS_SCHED2 != 0 && CDMA && SPLIT == 0;
+    static_assert(!(SCHED2 && WS_HYB != 0), "the hybrid tap ownership counts the halo loads of the two-unit schedule");
     static_assert(!E16 || (SPLIT == 0 && BM == 256 && sizeof(T) == 2), "16-bit staging: 16-bit tensors, 256-pixel tiles");
     static_assert(!RSEG || (SPLIT == 0 && sizeof(T) == 2), "residual segment: 16-bit tensors");
     constexpr int KCR = SPLIT ? 32 : KC;  // input channels per chunk (KC = 16-bit k-slots per 128-byte row)
@@ -764,7 +771,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
                 }
                 val = __builtin_bit_cast(u32x4, o);
             }
-            if (RSEG && mode == 1) {
+            if (mode == 1) {
                 areg[i] = val;
                 return;
             }
@@ -866,6 +873,17 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             WS_PSTT(3)                                                      \
         }                                                                   \
     }
+#define WS_A_MATH(i) { if (do_store) store_A((i), dstA, 1); }  /* the prologue on the unit's registers, nothing written */
+#define WS_A_WRITE(i)                                                        \
+    {                                                                       \
+        if (RSEG && last_c) { /* written in the residual segment's last stage */ } \
+        else {                                                              \
+            if (do_store) store_A((i), dstA, 2);                            \
+            WS_PSTT(1)                                                      \
+            if (new_tile) set_pix((i), tnn);                                \
+            load_A((i), lc);                                                \
+        }                                                                   \
+    }
 #define WS_A_ARRIVED(i) { asm volatile("" : "+v"(areg[i][0]), "+v"(areg[i][1]), "+v"(areg[i][2]), "+v"(areg[i][3])); }
         // stage TP = tap TP of chunk (kt, cc): DMA of the tap two stages on, 1-2 halo units of the next chunk, barrier.
         // Ring: stage s reads slot s % 3 (9 % 3 == 0: the same across chunks); the tap of stage s + 2 goes to slot (s + 2) % 3, which
@@ -896,7 +914,11 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
         const int lk = have_l ? (last_n ? nk + 1 : nk) : nk, lc = have_l ? (last_n ? 0 : nc + 1) : nc;                  \
         /* this stage's halo registers are taken as arrived before its DMA goes out (the compiler's counted wait sits    \
            here, in front of the stage's work) */                                                                       \
-        if constexpr (PIPE_UA == 11) {                                                                                  \
+        if constexpr (PIPE_UA == 11 && SCHED2) {                                                                        \
+            WS_A_ARRIVED(TP)                                                                                            \
+            if ((TP) == 3) { WS_A_ARRIVED(9) }                                                                          \
+            if ((TP) == 4) { WS_A_ARRIVED(10) }                                                                         \
+        } else if constexpr (PIPE_UA == 11) {                                                                           \
             if ((TP) == 0) { WS_A_ARRIVED(0) WS_A_ARRIVED(1) }                                                          \
             else if ((TP) == 8) { WS_A_ARRIVED(9) WS_A_ARRIVED(10) }                                                    \
             else { WS_A_ARRIVED((TP) + 1) }                                                                             \
@@ -941,7 +963,16 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
             const bool new_tile = have_l && lc == 0;                                                                    \
             const TileXY tnn = lk == kt ? tcur : tnext;                                                                 \
             if ((TP) == 0) load_par(WS_PAR(nk), nc* KCR);                                                               \
-            if constexpr (PIPE_UA == 11) {                                                                              \
+            if constexpr (PIPE_UA == 11 && SCHED2) {                                                                    \
+                /* eleven units over nine stages WITHOUT a stage that carries two whole units: stage k takes unit k; the prologue \
+                   arithmetic of units 9 / 10 (same chunk, same parameter rows) runs in stages 3 / 4 on their registers, their    \
+                   stores + reloads in stages 6 / 7 - every stage <= 1.5 units of producer work */                               \
+                WS_A_UNIT(TP)                                                                                           \
+                if ((TP) == 3) { WS_A_MATH(9) }                                                                         \
+                if ((TP) == 4) { WS_A_MATH(10) }                                                                        \
+                if ((TP) == 6) { WS_A_WRITE(9) }                                                                        \
+                if ((TP) == 7) { WS_A_WRITE(10) }                                                                       \
+            } else if constexpr (PIPE_UA == 11) {                                                                       \
                 if ((TP) == 0) { WS_A_UNIT(0) WS_A_UNIT(1) }                                                            \
                 else if ((TP) == 8) { WS_A_UNIT(9) WS_A_UNIT(10) }                                                      \
                 else { WS_A_UNIT((TP) + 1) }                                                                            \
@@ -1038,6 +1069,8 @@ __global__ void __launch_bounds__(512, 1) conv3x3_ws2_kernel(ConvArgs a, ConvTil
 #undef WS_PST
 #undef WS_PSTT
 #undef WS_A_UNIT
+#undef WS_A_MATH
+#undef WS_A_WRITE
 #undef WS_A_ARRIVED
         return;
     }

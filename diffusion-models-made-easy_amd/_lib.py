@@ -84,6 +84,7 @@ PROTOTYPES = {
     "dmme_unet_plan_num_launches": (_i, [_vp]),
     "dmme_unet_pack_params": (_i, [_vp, _vp, _vp, _vp]),
     "dmme_unet_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "dmme_unet_forward_nograd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "dmme_unet_plan_num_ops": (_i, [_vp]),
     "dmme_unet_plan_level_info": (_i, [_vp, C.c_char_p, _i]),
     "dmme_unet_plan_check": (_i, [_vp]),
@@ -122,6 +123,7 @@ PROTOTYPES = {
     "dmme_conv2d_res": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "dmme_groupnorm_scale_shift": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _i, _vp]),
     "dmme_attention": (_i, [_i, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "dmme_attention_proj": (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "dmme_attention_heads": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "dmme_nchw_to_nhwc": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),
     "dmme_nhwc_to_nchw": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),

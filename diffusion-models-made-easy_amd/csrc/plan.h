@@ -90,6 +90,10 @@ struct Op {
     // OP_ATTN
     int at_qkv = -1, at_out = -1, at_heads = 1;
     int64_t at_lse = 0;  // workspace offset of the forward's log-sum-exp [N][S]
+    // FORWARD fusion of the block's proj conv + residual add into the attention launch (attn_mfma.hip, AttnProj): at_proj = op index of
+    // that conv, whose own launch is skipped (fused_away = 2).  The context tensor at_out is then written only by forwards a backward
+    // pass may follow (run_op's keep_ctx); the backward pass itself is untouched.
+    int at_proj = -1;
     // precision="fp16r32" (dmme_plan::mix): how this conv of the fp32 level runs.  mix: ConvArgs::mix (1 / 2: split-pass 3x3 kernel, 3: split-pass
     // thin output conv); route_f32: on the fp32-tensor kernels with three-pass bf16 products (input conv, the blocks' 1x1 residual convs)
     int mix = 0, route_f32 = 0;

@@ -1060,6 +1060,30 @@ void assign_rseg(dmme_plan* P) {
     }
 }
 
+// The attention blocks of the 16x16 maps (models/ddpm.py:66-75: `x + proj(attention(norm(x)))`): where the whole-row attention kernel
+// serves the block (256 keys, single head, a launch that fills the chip), its proj 1x1 conv, bias, residual add and the next norm's
+// partial statistics run inside that launch (attn_mfma.hip, AttnProj) - at the benchmark batch five launches of 8-15 us and the context
+// tensor's round trip.  Forward only.  DMME_DEBUG_ROUTE=no_attn_proj: off.
+void assign_attn_proj(dmme_plan* P) {
+    if (P->x3) return;
+    for (int ai = 0; ai + 1 < (int)P->ops.size(); ++ai) {
+        Op& at = P->ops[ai];
+        if (at.kind != OP_ATTN || at.lvl >= 0 || at.at_heads != 1) continue;
+        Op& pr = P->ops[ai + 1];
+        if (pr.kind != OP_CONV || pr.src1 != at.at_out || pr.src2 >= 0 || pr.taps != 1 || pr.lvl >= 0 || pr.gn >= 0 || pr.pro_silu || pr.out_silu || pr.dmask_off >= 0 ||
+            pr.tproj_col >= 0 || pr.res1 < 0 || pr.res2 >= 0 || pr.up || pr.stride != 1 || pr.gd_n > 0 || pr.mix || pr.route_f32 || pr.dst < 0 || pr.fused_away || pr.rseg >= 0)
+            continue;
+        const Tensor &q = P->tensors[at.at_qkv], &td = P->tensors[pr.dst];
+        if (q.f32 || td.f32 || P->tensors[pr.res1].f32 || P->tensors[at.at_out].f32) continue;
+        const int S = q.H * q.W, C = q.C / 3;
+        if (td.C != C || P->tensors[pr.res1].C != C) continue;
+        const bool stats = td.stats_off >= 0;
+        if (!attn_proj_fusable(P->dtype, P->B, S, C, stats ? td.C / P->cfg.num_groups : 0, stats ? td.stats_tiles : 0)) continue;
+        at.at_proj = ai + 1;
+        pr.fused_away = 2;
+    }
+}
+
 int run_gn(const dmme_plan* P, const Op& o, const char* pk, char* ws, int nt, const float* drop_masks, hipStream_t s) {
     if (o.gn_direct || o.gn_in_consumer) return DMME_OK;  // its producers (its consumer) wrote scale / shift / {mean, rstd} (and act)
     // scale-shift conditioning (iddpm.ResBlock): (shift | scale) columns of the batched time projection
@@ -1102,8 +1126,9 @@ int run_gn(const dmme_plan* P, const Op& o, const char* pk, char* ws, int nt, co
     return launch_gn_modulate(sc, sh, tsh, tsc, P->tproj_cols, nt, P->B, o.gn_mod_C, s);
 }
 
+// keep_ctx: a backward pass may follow this forward (tensors only the backward reads are written: the fused attention block's context)
 int run_op(const dmme_plan* P, const Op& o, const char* pk, const float* x, const int64_t* t, int nt, float* y,
-           char* ws, const float* drop_masks, hipStream_t s) {
+           char* ws, const float* drop_masks, hipStream_t s, bool keep_ctx) {
     if (o.lvl >= 0) return o.lvl_first ? run_level(P, P->lvl_runs[o.lvl], pk, ws, nt, drop_masks, s) : DMME_OK;
     if (o.fused_away) return DMME_OK;  // a residual 1x1 conv that runs inside its block's conv2 (assign_rseg)
     switch (o.kind) {
@@ -1133,6 +1158,12 @@ int run_op(const dmme_plan* P, const Op& o, const char* pk, const float* x, cons
         case OP_ATTN: {
             const Tensor& q = P->tensors[o.at_qkv];
             const int S = q.H * q.W, C = q.C / 3;
+            if (o.at_proj >= 0) {  // the block's proj conv + residual inside the launch (assign_attn_proj)
+                ConvArgs a{};
+                fill_conv(P, P->ops[o.at_proj], pk, x, y, ws, drop_masks, nt, a, true);
+                return launch_attn_proj(P->dtype, ws + q.off, P->B, S, C, keep_ctx ? ws + P->tensors[o.at_out].off : nullptr, (float*)(ws + o.at_lse), a.w, a.bias,
+                                        a.res1, a.dst, a.gn_part, a.gn_tiles, a.gn_cg, s);
+            }
             if (P->x3 && attn_x3_supported(P->B, S, C, o.at_heads))  // (no log-sum-exp kept: the fp32 backward recomputes the scores)
                 return launch_attn_x3(ws + q.off, P->B, S, C, o.at_heads, ws + P->tensors[o.at_out].off, s);
             if (o.at_heads > 1) {
@@ -1166,7 +1197,7 @@ void op_account(const dmme_plan* P, const Op& o, char* label, int cap, double* f
         return;
     }
     if (o.fused_away) {
-        snprintf(label, cap, "(residual 1x1 conv inside its block's conv2)");
+        snprintf(label, cap, o.fused_away == 2 ? "(proj 1x1 conv inside its block's attention launch)" : "(residual 1x1 conv inside its block's conv2)");
         return;
     }
     switch (o.kind) {
@@ -1235,6 +1266,11 @@ void op_account(const dmme_plan* P, const Op& o, char* label, int cap, double* f
                 snprintf(label, cap, !attn_mfma_supported(P->dtype, P->B, (int)S, (int)C) ? (S == 16 ? "attn_s16_kernel<%s>" : "attn_generic_kernel<%s>") : attn_full_takes((int)S, (int)C) ? "attn_full_kernel<%s>" : "attn_mfma_kernel<%s>", tn);
             *flops = 4.0 * B * S * S * C;
             *bytes = B * S * 4.0 * C * es;
+            if (o.at_proj >= 0) {  // + the proj conv and the residual: context neither written nor read, residual in, output out
+                snprintf(label, cap, "attn_full_kernel<%s,proj>", tn);
+                *flops += 2.0 * B * S * C * C;
+                *bytes = B * S * 5.0 * C * es + C * C * es;
+            }
             break;
         }
     }
@@ -1246,7 +1282,7 @@ void op_account(const dmme_plan* P, const Op& o, char* label, int cap, double* f
 extern "C" {
 
 DMME_API const char* dmme_last_error(void) { return g_err; }
-DMME_API int dmme_version(void) { return 104; }  // 104: dmme_conv2d_res
+DMME_API int dmme_version(void) { return 105; }  // 105: dmme_attention_proj, dmme_unet_forward_nograd
 DMME_API int dmme_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1310,6 +1346,7 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
     if (!getenv("DMME_NO_PREACT")) assign_preact(P);
     if (!getenv("DMME_NO_FUSED_GN")) assign_gn_in(P);
     assign_rseg(P);
+    assign_attn_proj(P);
     P->n_launches = 0;
     for (const Op& o : P->ops) {
         if (o.fused_away) continue;
@@ -1642,8 +1679,8 @@ DMME_API int dmme_unet_pack_params(const dmme_plan* plan, const float* ref_flat,
     return launch_pack_table(plan->dtype, plan->items_dev, plan->n_items, ref_flat, packed, (hipStream_t)stream);
 }
 
-DMME_API int dmme_unet_forward(const dmme_plan* plan, const void* packed, const float* x, const int64_t* t, int t_len,
-                      float* y, void* workspace, const float* drop_masks, void* stream) {
+static int unet_forward_impl(const dmme_plan* plan, const void* packed, const float* x, const int64_t* t, int t_len,
+                      float* y, void* workspace, const float* drop_masks, void* stream, bool keep_ctx) {
     DMME_REQUIRE(plan && packed && x && t && y && workspace, DMME_ERR_INVALID, "unet_forward: null argument");
     DMME_REQUIRE(t_len == 1 || t_len == plan->B, DMME_ERR_INVALID,
                  "unet_forward: timestep tensor of length %d does not broadcast against batch %d", t_len, plan->B);
@@ -1657,10 +1694,20 @@ DMME_API int dmme_unet_forward(const dmme_plan* plan, const void* packed, const 
     char* ws = (char*)workspace;
     const int nt = t_len;
     for (const Op& o : P->ops) {
-        const int rc = run_op(P, o, pk, x, t, nt, y, ws, drop_masks, s);
+        const int rc = run_op(P, o, pk, x, t, nt, y, ws, drop_masks, s, keep_ctx);
         if (rc != DMME_OK) return rc;
     }
     return DMME_OK;
+}
+DMME_API int dmme_unet_forward(const dmme_plan* plan, const void* packed, const float* x, const int64_t* t, int t_len,
+                      float* y, void* workspace, const float* drop_masks, void* stream) {
+    return unet_forward_impl(plan, packed, x, t, t_len, y, workspace, drop_masks, stream, true);
+}
+// the same forward where no backward pass will follow (sampling, evaluation under no_grad): tensors only a backward pass reads - the
+// context of an attention block whose proj conv runs inside the attention launch - are not written
+DMME_API int dmme_unet_forward_nograd(const dmme_plan* plan, const void* packed, const float* x, const int64_t* t, int t_len,
+                      float* y, void* workspace, const float* drop_masks, void* stream) {
+    return unet_forward_impl(plan, packed, x, t, t_len, y, workspace, drop_masks, stream, false);
 }
 
 DMME_API int dmme_unet_plan_num_ops(const dmme_plan* plan) { return plan ? (int)plan->ops.size() : 0; }
@@ -1686,7 +1733,7 @@ DMME_API int dmme_unet_forward_profiled(const dmme_plan* plan, const void* packe
     int rc = DMME_OK;
     DMME_CHECK_HIP(hipEventRecord(ev[0], s));
     for (size_t i = 0; i < n && rc == DMME_OK; ++i) {
-        rc = run_op(plan, plan->ops[i], (const char*)packed, x, t, t_len, y, (char*)workspace, drop_masks, s);
+        rc = run_op(plan, plan->ops[i], (const char*)packed, x, t, t_len, y, (char*)workspace, drop_masks, s, false);  // (the sampling step's forward)
         if (rc == DMME_OK && hipEventRecord(ev[i + 1], s) != hipSuccess) rc = DMME_ERR_HIP;
     }
     if (rc == DMME_OK && hipEventSynchronize(ev[n]) != hipSuccess) rc = DMME_ERR_HIP;
@@ -1809,7 +1856,7 @@ DMME_API int dmme_chain_step(const dmme_plan* plan, const void* packed, float* x
                  "chain_step: sampler kind %d does not fit a network with %d output channels", kind, plan->out_channels);
     // the timestep the network is evaluated at is the second word of the device-resident loop state
     const int64_t* t_dev = (const int64_t*)state + 1;
-    int rc = dmme_unet_forward(plan, packed, x, t_dev, 1, model_out, workspace, nullptr, stream);
+    int rc = unet_forward_impl(plan, packed, x, t_dev, 1, model_out, workspace, nullptr, stream, false);
     if (rc != DMME_OK) return rc;
     return launch_chain_update(kind, x, model_out, step_coef, t_table, state, plan->B, (int64_t)plan->cfg.in_channels * plan->H * plan->W,
                                (hipStream_t)stream);
@@ -1947,6 +1994,12 @@ DMME_API int dmme_attention(int dtype, const void* qkv, int N, int S, int C, voi
     }
     if (!force_generic && attn_mfma_supported(dtype, N, S, C)) return launch_attn_mfma(dtype, qkv, N, S, C, out, nullptr, (hipStream_t)stream);
     return launch_attn_generic(dtype, qkv, N, S, C, out, (hipStream_t)stream);
+}
+
+DMME_API int dmme_attention_proj(int dtype, const void* qkv, int N, int S, int C, const void* w, const float* bias, const void* res, void* dst, void* ctx,
+                                 float* gn_part, int gn_cg, void* stream) {
+    DMME_REQUIRE(qkv && w && bias && res && dst && N > 0 && S > 0 && C > 0, DMME_ERR_INVALID, "attention_proj: bad argument");
+    return launch_attn_proj(dtype, qkv, N, S, C, ctx, nullptr, w, bias, res, dst, gn_part, S / 32, gn_cg, (hipStream_t)stream);
 }
 
 DMME_API int dmme_attention_heads(int dtype, const void* qkv, int N, int S, int C, int heads, void* out, int force_generic, void* stream) {

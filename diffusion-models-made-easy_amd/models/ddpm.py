@@ -458,8 +458,10 @@ class UNet(nn.Module):
                 self._mask_calls += 1
                 seed, off = philox_reserve(x.device, plan.dropmask_numel)  # torch's CUDA generator: manual_seed restarts the draws
                 _lib.check(plan.lib.dmme_dropout_masks(plan.h, seed ^ 0x5DEECE66D, off, _lib.ptr(masks), _lib.stream_ptr()), "dmme_dropout_masks")
+        # no backward pass will follow (sampling, evaluation): the form that skips tensors only the backward pass reads
+        fwd = plan.lib.dmme_unet_forward if want_ctx else plan.lib.dmme_unet_forward_nograd
         _lib.check(
-            plan.lib.dmme_unet_forward(plan.h, _lib.ptr(packed), _lib.ptr(xin), _lib.ptr(t), int(t.numel()), _lib.ptr(y), _lib.ptr(plan.workspace), _lib.ptr(masks), _lib.stream_ptr()),
+            fwd(plan.h, _lib.ptr(packed), _lib.ptr(xin), _lib.ptr(t), int(t.numel()), _lib.ptr(y), _lib.ptr(plan.workspace), _lib.ptr(masks), _lib.stream_ptr()),
             "dmme_unet_forward",
         )
         self._last_plan = plan

@@ -127,6 +127,12 @@ DMME_API int dmme_unet_pack_params(const dmme_plan* plan, const float* ref_flat,
  * as dmme_unet_plan_dropmask_numel() describes (nn.Dropout2d, models/ddpm.py:29). */
 DMME_API int dmme_unet_forward(const dmme_plan* plan, const void* packed, const float* x, const int64_t* t, int t_len,
                       float* y, void* workspace, const float* drop_masks, void* stream);
+/* The same forward where no dmme_unet_backward will follow (the reference's sampling loops run under torch.no_grad(),
+ * diffusion_models/ddpm.py:113-133): tensors that only the backward pass reads - the context of an attention block whose proj
+ * conv runs inside the attention launch (models/ddpm.py:66-75) - are not written.  Same arguments, same result y.
+ * dmme_chain_step and dmme_unet_forward_profiled run this form. */
+DMME_API int dmme_unet_forward_nograd(const dmme_plan* plan, const void* packed, const float* x, const int64_t* t, int t_len,
+                      float* y, void* workspace, const float* drop_masks, void* stream);
 
 /* ---- per-op accounting + event-bracketed profiling (bench.py's roofline leg) --------
  * op_info: kernel label (the kernel symbol the op launches, e.g.
@@ -387,6 +393,13 @@ DMME_API int dmme_groupnorm_scale_shift(int dtype, const void* src1, const void*
 /* single-head self-attention over S tokens: qkv [N][S][3C] -> out [N][S][C]
  * softmax(q (k*C^-0.5)^T) v   (Attention.forward_attention, models/ddpm.py:54-63). */
 DMME_API int dmme_attention(int dtype, const void* qkv, int N, int S, int C, void* out, int force_generic, void* stream);
+/* The rest of the block in the same launch: dst = res + proj(attention(qkv)) (Attention.forward, models/ddpm.py:66-75, behind the
+ * norm + qkv conv): w [C][C] (16-bit, the packed 1x1 layout: row = cout), bias [C] fp32, res / dst [N][S][C].  ctx (nullable):
+ * also receives the attention output [N][S][C] (the proj conv's input, which its weight gradient needs).  gn_part (nullable):
+ * (mean, M2) of dst per (image, 32-token tile, group of gn_cg = 4 or 8 channels), [N][S/32][C/gn_cg][2] fp32 - the partials the
+ * next GroupNorm is finished from.  16-bit dtypes, S = 256, C = 128 or 256, N >= 128; DMME_ERR_UNSUPPORTED otherwise. */
+DMME_API int dmme_attention_proj(int dtype, const void* qkv, int N, int S, int C, const void* w, const float* bias, const void* res,
+                                 void* dst, void* ctx, float* gn_part, int gn_cg, void* stream);
 
 /* multi-head self-attention exactly as the reference ships it (MultiHeadAttention.forward_attention,
  * models/iddpm.py:35-47): qkv [N][S][3C]; head h of image n reads channels [h*3d, (h+1)*3d) as (q | k | v), d = C/heads;

@@ -60,7 +60,8 @@ def test_plan_is_host_only_and_reports_errors():
     info = buf.value.decode()
     assert info.startswith("runs=3") and info.count("map=8x8") == 2 and info.count("map=4x4") == 1 and info.count("workgroups=256") == 3, info
     # ... and, since round 4, minus the seven 1x1 residual convs of the 32x32 / 16x16 levels that run inside their block's conv2 (51 now)
-    assert n_ops >= n_launch >= 48 and n_launch <= 55, (n_ops, n_launch)
+    # ... and, since round 5, minus the proj convs of the five 16x16 attention blocks, which run inside the attention launch (45 now)
+    assert n_ops >= n_launch >= 43 and n_launch <= 50, (n_ops, n_launch)
     label = C.create_string_buffer(128)
     fl, by = C.c_double(), C.c_double()
     total = 0.0

@@ -46,6 +46,7 @@ FORWARD = [
     ({"DMME_NO_WS128": "1"}, "persistent kernel without its 128-pixel tiles (the 128-cout layers of the 16x16 level back on the four-wave kernel)"),
     ({"DMME_NO_WS_E16": "1"}, "persistent kernel: the fp32-staged two-pass epilogue everywhere (round 5: 16-bit staging on transposed accumulators where no residual tensor is read)"),
     ({"DMME_LVL_NO_XCD": "1"}, "level engine: a pixel group's slices in index order (round 5: on one XCD)"),
+    ({"DMME_NO_ATTN_PROJ": "1"}, "attention blocks of full launches: proj conv + residual as their own launch (round 5: inside the attention launch)"),
     ({"DMME_NO_FUSED_GN": "1"}, "every GroupNorm reads its tensor"),
     ({"DMME_NO_XCD_ORDER": "1"}, "plain workgroup order in attention / 1x1 convs"),
     ({"DMME_NO_SPLITK": "1"}, "no split-K in the four-wave kernel"),
@@ -54,7 +55,7 @@ FORWARD = [
 BACKWARD = ["DMME_NO_WG_ACT", "DMME_NO_WG_DMA", "DMME_NO_WG_S2", "DMME_NO_WGRAD_GROUP", "DMME_NO_GN_BWD_IMAGE", "DMME_NO_GN_BWD_FUSED_FIN",
             "DMME_NO_GN_BWD_ROWS", "DMME_NO_GN_BWD_REGS", "DMME_NO_RES_EXTRA", "DMME_NO_GN_BWD_SLICES", "DMME_NO_DGRAD_DIRECT", "DMME_NO_RES_ALIAS", "DMME_NO_COLSUM_GROUP",
             "DMME_NO_BIAS_GROUP", "DMME_NO_WGRAD_THIN", "DMME_NO_TIME_PRE", "DMME_NO_SMALL_GEMM_MFMA", "DMME_NO_LVL",
-            "DMME_NO_RSEG", "DMME_NO_WS_E16"]  # (forward routes: at this batch three blocks' residual convs run inside conv2 - the training step with them as launches)
+            "DMME_NO_RSEG", "DMME_NO_WS_E16", "DMME_NO_ATTN_PROJ"]  # (forward routes: at this batch three blocks' residual convs run inside conv2 - the training step with them as launches)
 
 
 from tests.gpu_util import route_env as _env  # (sets product switches as variables, everything else as DMME_DEBUG_ROUTE keys)

@@ -26,6 +26,9 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int AT_KT = 32;  // keys per tile
+#ifndef AT_PAIR_STEPS
+#define AT_PAIR_STEPS 1
+#endif
 
 // Head view (multi-head blocks of the IDDPM UNet, models/iddpm.py:35-47; heads == 1 is the DDPM block): a "row" bh = n*heads + hd
 // reads the qkv channels [hd*3D, (hd+1)*3D) of image n as (q | k | v) and owns the output row block (image bh % N, head bh / N) --
@@ -306,7 +309,8 @@ struct AttnProj {
     void* dst;          // [N][S][C]
     float* gn_part;     // nullable: (mean, M2) per (image, 32-pixel tile, group) - ConvArgs::gn_part
     int gn_tiles, gn_cg;
-    int dbg;            // DMME_DEBUG_ROUTE=attn_proj_dbg=<mask> (timing experiments, wrong results): 1 no statistics, 2 no epilogue loads / stores, 4 no phase-4 MFMAs
+    long long* stamps;  // diagnostic (null: off): cycle stamps of wave 0 of workgroup 0 in -DAT_STAMPS builds (dmme_debug_set_stamps; tools/stamp_attn.py)
+    int dbg;            // DMME_DEBUG_ROUTE=attn_proj_dbg=<mask> (timing experiments, wrong results): 1 no statistics, 2 no epilogue loads / stores, 4 no phase-4 MFMAs, 8 image 0's K / V for every workgroup
 };
 // the fp32 product as a value of its own: hipcc otherwise folds `(half)(a * b)` into v_fma_mix*_f16 in one form of the kernel and not in
 // the other - one rounding instead of two, a last-bit difference in ~3e-5 of the context tensor's elements between them
@@ -327,7 +331,14 @@ __global__ void __launch_bounds__(256) attn_full_kernel(const T* __restrict__ qk
     constexpr int NTOT = 2 * NKT + (PROJ ? CT : 0);  // tiles of the stream: K, V, then the proj matrix
     constexpr int ROWB = C * 2, TILEB = AT_KT * ROWB;      // bytes per key row / per tile (unpadded)
     constexpr int DPT = TILEB / (256 * 16);                // DMA wave-instructions per tile and wave
-    constexpr int NSLOT = 8, AHEAD = 7;  // (a four-slot ring, 48 KB in flight per CU, measured 24 us at C = 256: bytes in flight / latency)
+    // PAIR (-DAT_PAIR_STEPS=0: one barrier per tile, seven tiles ahead): the stream advances in steps of TWO tiles - one counted wait, one
+    // workgroup barrier, two tile requests, then 2 x 16 MFMAs back to back.  With one wave per SIMD nothing covers the barrier and the
+    // LDS round trip of a step's first fragments (~0.5 us of a ~0.85 us step for 0.28 us of MFMA; tools/time_attn_proj.py: the same with
+    // every workgroup on one L2-resident image - the K / V stream is not what the kernel waits for); a pair pays that once.
+    constexpr bool PAIR = AT_PAIR_STEPS != 0;
+    constexpr int NSLOT_BYTES = 8 * TILEB;
+    constexpr int NSLOT = 8, AHEAD = PAIR ? 6 : 7;  // (a four-slot ring, 48 KB in flight per CU, measured 24 us at C = 256: bytes in flight / latency)
+    static_assert(!PAIR || (NTOT % 2 == 0 && NKT % 2 == 0), "pair steps: even tile counts per phase");
     static_assert(DPT >= 1 && DPT * 256 * 16 == TILEB, "attn_full: tile does not split over the DMA lanes");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -346,6 +357,18 @@ __global__ void __launch_bounds__(256) attn_full_kernel(const T* __restrict__ qk
     // DMA instruction I of a tile (wave-instruction index wave + 4 i) fills LDS bytes [I * 1024, +1024) lane-linearly:
     // row = (I * 1024 + lane * 16) / ROWB, 16-byte piece pc of that row; it must hold SOURCE piece pc ^ key(row) (per 128-byte segment)
     const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
+    // stamps go to LDS (behind the ring / the staging tiles) and to memory at the very end: a global store per stamp would join the
+    // vmcnt queue of the counted waits
+    // (-DAT_STAMPS builds only: compiled in, even unused, they cost the sampling step 0.3 %)
+#ifdef AT_STAMPS
+    long long* st_lds = reinterpret_cast<long long*>(lds + (PROJ ? (4 * 32 * (C * 4 + 16) > NSLOT_BYTES ? 4 * 32 * (C * 4 + 16) : NSLOT_BYTES) : NSLOT_BYTES));
+    int st_i = 0;
+    const bool stamping = PROJ && pj.stamps && blockIdx.x == 0 && tid == 0;
+#define AF_STAMP() { if (PROJ && stamping && st_i < 120) st_lds[st_i++] = (long long)clock64(); }
+#else
+#define AF_STAMP()
+#endif
+    AF_STAMP()
     unsigned koff[DPT], voff[DPT];  // per-lane source byte offsets inside a K / V tile (row * ld * 2 + swizzled piece * 16)
 #pragma unroll
     for (int i = 0; i < DPT; ++i) {
@@ -370,14 +393,17 @@ __global__ void __launch_bounds__(256) attn_full_kernel(const T* __restrict__ qk
             return;
         }
         const bool isv = t >= NKT;
-        const char* src = (const char*)(base + (int64_t)((isv ? t - NKT : t) * AT_KT) * ld + (isv ? 2 * C : C));
+        const T* kvb = (PROJ && (pj.dbg & 8)) ? qkv : base;  // (timing experiment: every workgroup streams image 0's K / V)
+        const char* src = (const char*)(kvb + (int64_t)((isv ? t - NKT : t) * AT_KT) * ld + (isv ? 2 * C : C));
 #pragma unroll
         for (int i = 0; i < DPT; ++i) glds16_hidden_s(src, isv ? voff[i] : koff[i], dst + (unsigned)((wave + 4 * i) * 1024));
     };
 #pragma unroll
     for (int t = 0; t < AHEAD; ++t) dma_tile(t);
     // Q^T fragments (B operand of S^T = K Q^T): element j of k-step ks = Q[q_row][16 ks + 8 h + j]; ordinary loads, older than nothing
-    // the counted waits below care about (they are waited for by the compiler before the first MFMA)
+    // the counted waits below care about (they are waited for by the compiler before the first MFMA).  (Requested BEFORE the tiles -
+    // so that the first counted wait asks for two tiles instead of all six - the launch's first 9.5 k cycles stay what they are:
+    // 24 MB requested by 256 CUs at once, the HBM's rate.)
     uint4 qf[KSTEPS];
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(base + (int64_t)q_row * ld + ks * 16 + h * 8);
@@ -408,10 +434,24 @@ __global__ void __launch_bounds__(256) attn_full_kernel(const T* __restrict__ qk
    barrier makes that true of every wave's share AND says everyone is done with tile T - 1, whose slot takes tile T + AHEAD */        \
 #define AF_STEP_SYNC(TT)                                                                                                           \
     do {                                                                                                                           \
+        if constexpr (PAIR) {                                                                                                      \
+            if constexpr (((TT) & 1) != 0) break; /* the second tile of a pair: landed and free to read since the pair's barrier */  \
+            /* requested so far: tiles up to TT + 5; tiles TT and TT + 1 have landed when only the younger ones are outstanding */   \
+            constexpr int last_ = (TT) + 5 < NTOT - 1 ? (TT) + 5 : NTOT - 1;                                                       \
+            wait_vm_keep<(last_ - ((TT) + 1)) * DPT>();                                                                            \
+            asm volatile("s_barrier" ::: "memory");                                                                                \
+            /* everyone is done with tiles TT - 2 and TT - 1: their slots take tiles TT + 6 and TT + 7 */                           \
+            if ((TT) + 6 < NTOT) dma_tile((TT) + 6);                                                                               \
+            if ((TT) + 7 < NTOT) dma_tile((TT) + 7);                                                                               \
+        } else {                                                                                                                   \
         constexpr int younger_ = (TT) + AHEAD - 1 < NTOT ? AHEAD - 1 : NTOT - 1 - (TT);                                            \
         wait_vm_keep<younger_ * DPT>();                                                                                            \
         asm volatile("s_barrier" ::: "memory");                                                                                    \
         if ((TT) + AHEAD < NTOT) dma_tile((TT) + AHEAD);                                                                           \
+        }                                                                                                                          \
+        AF_STAMP()                                                                                                                 \
+        /* (the requests moved behind the step's first fragment reads, their LDS round trip under the ~350 cycles of issuing them:  \
+            +-0.0 % on the step, not kept) */                                                                                       \
         if ((xcd_order >> 1) == 1) __builtin_amdgcn_s_sleep(2);                                                                    \
         else if ((xcd_order >> 1) == 2) __builtin_amdgcn_s_sleep(4);                                                               \
         else if ((xcd_order >> 1) == 3) __builtin_amdgcn_s_sleep(8);                                                               \
@@ -438,6 +478,7 @@ __global__ void __launch_bounds__(256) attn_full_kernel(const T* __restrict__ qk
             _Pragma("unroll") for (int u = 0; u < FG; ++u) at_mma<T>(__builtin_bit_cast(tx8, kf[cur][u]), __builtin_bit_cast(tx8, BF[g0 + u]), ACC); \
             __builtin_amdgcn_sched_barrier(0);                                                                                     \
         }                                                                                                                          \
+        AF_STAMP()                                                                                                                 \
     }
 #define AF_K_TILE(t) AF_A_TILE(t, qf, st[t])
     AF_K_TILE(0) AF_K_TILE(1) AF_K_TILE(2) AF_K_TILE(3) AF_K_TILE(4) AF_K_TILE(5) AF_K_TILE(6) AF_K_TILE(7)
@@ -462,6 +503,7 @@ __global__ void __launch_bounds__(256) attn_full_kernel(const T* __restrict__ qk
             pf[t][j >> 3][j & 7] = (T)p;
         }
     const float ltot = l + __shfl_xor(l, 32, 64);
+    AF_STAMP()
     // ---- phase 3: O^T = V^T P^T ----
     f32x16 o[CT];
 #pragma unroll
@@ -496,6 +538,7 @@ __global__ void __launch_bounds__(256) attn_full_kernel(const T* __restrict__ qk
             }                                                                                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                                                     \
         }                                                                                                                          \
+        AF_STAMP()                                                                                                                 \
     }
     AF_V_TILE(0) AF_V_TILE(1) AF_V_TILE(2) AF_V_TILE(3) AF_V_TILE(4) AF_V_TILE(5) AF_V_TILE(6) AF_V_TILE(7)
 #undef AF_V_TILE
@@ -539,6 +582,7 @@ __global__ void __launch_bounds__(256) attn_full_kernel(const T* __restrict__ qk
                 of[2 * ct + s2] = make_uint4(__builtin_bit_cast(unsigned, w4[0]), __builtin_bit_cast(unsigned, w4[1]), __builtin_bit_cast(unsigned, w4[2]),
                                              __builtin_bit_cast(unsigned, w4[3]));
             }
+        AF_STAMP()
         // ---- phase 4: out^T = Wp O^T, the proj matrix streamed in row tiles of 32 couts ----
         f32x16 ot[CT];
 #pragma unroll
@@ -551,27 +595,35 @@ __global__ void __launch_bounds__(256) attn_full_kernel(const T* __restrict__ qk
 #undef AF_W_TILE
         // ---- epilogue (every LDS-DMA has been waited for: ordinary loads / stores from here on) ----
         if (lse && h == 0) lse[(int64_t)n * S + q_row] = m + log2f(ltot);
-        const int64_t row_off = at_o_off<C>(g, n) + (int64_t)q_row * g.Cfull;
-        if (out) {  // the context tensor, for the proj conv's weight gradient: channels 16 ks + 8 h .. + 7
-            T* orow = out + row_off;
-#pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) *reinterpret_cast<uint4*>(orow + ks * 16 + h * 8) = of[ks];
-        }
         // The accumulators hold one pixel per lane and scattered couts: straight from there, every load / store instruction touches 32
         // rows of the tensor with 8 bytes each (first version: 16 us of a 40 us launch, the L1 re-fetching every line eight times).
         // So each wave stages its 32 x C fp32 tile in LDS (the ring is free; rows padded by 16 B: conflict-free both ways) and walks
         // it ROW-wise: lane = 8 consecutive couts of a row, a wave instruction = 64 / (C / 8) whole rows of the residual / output.
         asm volatile("s_barrier" ::: "memory");  // every wave has read the last tile: the ring is the staging area now
+        AF_STAMP()
         constexpr int SP = C * 4 + 16;            // staging row pitch (bytes)
         constexpr int LPR = C / 8, RPI = 64 / LPR, NIT = 32 / RPI;  // lanes per row, rows per instruction, instructions per tile
         char* stg = lds + wave * (32 * SP);
+        const int col = lane % LPR, rsub = lane / LPR;
+        const int64_t tile_off = at_o_off<C>(g, n) + (int64_t)(q_row - r) * g.Cfull + col * 8;
+        if (out) {  // the context tensor (the proj conv's weight gradient reads it): the 16-bit operands of phase 4, through the same staging
+            constexpr int CP = C * 2 + 16;
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) *reinterpret_cast<uint4*>(stg + r * CP + (ks * 16 + h * 8) * 2) = of[ks];
+            wait_lgkm_all();
+            asm volatile("" ::: "memory");
+            T* obase = out + tile_off;
+#pragma unroll
+            for (int i = 0; i < NIT; ++i)
+                *reinterpret_cast<uint4*>(obase + (int64_t)(rsub + RPI * i) * g.Cfull) = *reinterpret_cast<const uint4*>(stg + (rsub + RPI * i) * CP + col * 16);
+            wait_lgkm_all();  // (read before the fp32 tile overwrites the region)
+            asm volatile("" ::: "memory");
+        }
 #pragma unroll
         for (int t = 0; t < CT; ++t)
 #pragma unroll
             for (int jg = 0; jg < 4; ++jg)
                 *reinterpret_cast<f32x4*>(stg + r * SP + (t * 32 + 8 * jg + 4 * h) * 4) = f32x4{ot[t][jg * 4], ot[t][jg * 4 + 1], ot[t][jg * 4 + 2], ot[t][jg * 4 + 3]};
-        const int col = lane % LPR, rsub = lane / LPR;
-        const int64_t tile_off = at_o_off<C>(g, n) + (int64_t)(q_row - r) * g.Cfull + col * 8;
         const T* rbase = (const T*)pj.res + tile_off;
         T* dbase = (T*)pj.dst + tile_off;
         if (pj.dbg & 2) {
@@ -584,6 +636,7 @@ __global__ void __launch_bounds__(256) attn_full_kernel(const T* __restrict__ qk
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(pj.bias + col * 8), b1 = *reinterpret_cast<const f32x4*>(pj.bias + col * 8 + 4);
         wait_lgkm_all();  // the wave's own staging writes (LDS serves a wave's instructions in order; this also pins the compiler)
         asm volatile("" ::: "memory");
+        AF_STAMP()
         float xs[NIT][8];
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
@@ -600,6 +653,7 @@ __global__ void __launch_bounds__(256) attn_full_kernel(const T* __restrict__ qk
             for (int e = 0; e < 8; ++e) xs[i][e] = (float)o8[e];  // (the statistics are those of the values the consumer reads back)
             *reinterpret_cast<uint4*>(dbase + (int64_t)(rsub + RPI * i) * g.Cfull) = __builtin_bit_cast(uint4, o8);
         }
+        AF_STAMP()
         if (pj.gn_part && !(pj.dbg & 1)) {
             // this wave's 32 pixels are one statistics tile; a lane's 8 couts are one group of 8 or two groups of 4, the tile's other rows
             // of the same couts sit on the lanes LPR apart: mean, then M2 = sum (x - mean)^2, each by one or two register swaps
@@ -643,7 +697,13 @@ __global__ void __launch_bounds__(256) attn_full_kernel(const T* __restrict__ qk
                 else *reinterpret_cast<f32x4*>(po + col * 4) = f32x4{mA, m2A, mB, m2B};
             }
         }
+        AF_STAMP()
+#ifdef AT_STAMPS
+        if (stamping)
+            for (int i = 0; i < st_i; ++i) pj.stamps[i] = st_lds[i];
+#endif
     }
+#undef AF_STAMP
 #undef AF_A_TILE
 #undef AF_STEP_SYNC
 }
@@ -821,7 +881,11 @@ template <int D, typename T, bool PROJ = false>
 static int launch_attn_full_t(const T* qkv, const AttnGeom& g, T* out, float* lse, hipStream_t s, const AttnProj& pj = AttnProj{}) {
     const int rows = g.N * g.heads;
     const size_t ring = (size_t)8 * AT_KT * D * 2, stage = (size_t)4 * 32 * (D * 4 + 16);  // (PROJ: the epilogue's fp32 staging tiles lie over the ring)
+#ifdef AT_STAMPS
+    const size_t lds = (PROJ && stage > ring ? stage : ring) + 1024;  // (+ the diagnostic stamps' buffer)
+#else
     const size_t lds = PROJ && stage > ring ? stage : ring;
+#endif
     static bool attr_done = false;
     if (!attr_done) {
         DMME_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_full_kernel<D, T, PROJ>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -904,11 +968,11 @@ bool attn_proj_fusable(int dtype, int N, int S, int C, int gn_cg, int gn_tiles) 
     return gn_tiles == 0 || ((gn_cg == 4 || gn_cg == 8) && C % gn_cg == 0 && gn_tiles == S / 32);
 }
 int launch_attn_proj(int dtype, const void* qkv, int N, int S, int C, void* ctx, float* lse, const void* w, const float* bias, const void* res, void* dst,
-                     float* gn_part, int gn_tiles, int gn_cg, hipStream_t s) {
+                     float* gn_part, int gn_tiles, int gn_cg, hipStream_t s, long long* stamps) {
     DMME_REQUIRE(attn_proj_fusable(dtype, N, S, C, gn_part ? gn_cg : 0, gn_part ? gn_tiles : 0) && w && bias && res && dst, DMME_ERR_UNSUPPORTED,
                  "attn_proj: unsupported shape N=%d S=%d C=%d (statistics tiles %d, %d channels per group)", N, S, C, gn_tiles, gn_cg);
     const AttnGeom g = attn_geom(N, S, C, 1);
-    const AttnProj pj{w, bias, res, dst, gn_part, gn_tiles, gn_cg, debug_route("attn_proj_dbg")};
+    const AttnProj pj{w, bias, res, dst, gn_part, gn_tiles, gn_cg, stamps, debug_route("attn_proj_dbg")};
     if (dtype == DMME_F16)
         return C == 256 ? launch_attn_full_t<256, f16, true>((const f16*)qkv, g, (f16*)ctx, lse, s, pj) : launch_attn_full_t<128, f16, true>((const f16*)qkv, g, (f16*)ctx, lse, s, pj);
     return C == 256 ? launch_attn_full_t<256, bf16, true>((const bf16*)qkv, g, (bf16*)ctx, lse, s, pj) : launch_attn_full_t<128, bf16, true>((const bf16*)qkv, g, (bf16*)ctx, lse, s, pj);

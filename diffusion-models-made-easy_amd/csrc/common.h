@@ -319,7 +319,7 @@ int launch_attn_mfma(int dtype, const void* qkv, int N, int S, int C, void* out,
 // where no backward pass will read it; gn_part / gn_tiles / gn_cg: ConvArgs' fields of the proj conv (one partial per 32 pixels)
 bool attn_proj_fusable(int dtype, int N, int S, int C, int gn_cg, int gn_tiles);
 int launch_attn_proj(int dtype, const void* qkv, int N, int S, int C, void* ctx, float* lse, const void* w, const float* bias, const void* res, void* dst,
-                     float* gn_part, int gn_tiles, int gn_cg, hipStream_t s);
+                     float* gn_part, int gn_tiles, int gn_cg, hipStream_t s, long long* stamps = nullptr);
 bool attn_heads_mfma_supported(int dtype, int N, int S, int C, int heads);
 int launch_attn_heads_mfma(int dtype, const void* qkv, int N, int S, int C, int heads, void* out, float* lse, hipStream_t s);
 int launch_attn_heads_bwd_mfma(int dtype, const void* qkv, const void* O, const void* dO, const float* lse, int N, int S, int C, int heads, void* P,

@@ -122,6 +122,8 @@ __global__ void __launch_bounds__(512) conv1x1_as_kernel(ConvArgs a, int HW, int
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #define AS_STAMP(K) do { if (a.stamps && blockIdx.x < 2 && (threadIdx.x & 255) == 0) a.stamps[blockIdx.x * 32 + (threadIdx.x >> 8) * 16 + (K)] = (long long)wall_clock64(); } while (0)
     AS_STAMP(0);
+    // (the tiles of image n dealt to XCD n % 8, where the whole-row attention kernel puts the image's query blocks - so that the K / V
+    //  rows written here would be read back from that XCD's L2: +-0.1 % on the step, not kept; that kernel does not wait for K / V bytes)
     const int p0 = blockIdx.x * 128;
     float* foldL = reinterpret_cast<float*>(lds + RING * U_BYTES);
     char* stageL = lds + RING * U_BYTES + as_fold_bytes(a.Cout);  // [2][STAGE]

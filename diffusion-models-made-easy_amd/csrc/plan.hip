@@ -1999,7 +1999,7 @@ DMME_API int dmme_attention(int dtype, const void* qkv, int N, int S, int C, voi
 DMME_API int dmme_attention_proj(int dtype, const void* qkv, int N, int S, int C, const void* w, const float* bias, const void* res, void* dst, void* ctx,
                                  float* gn_part, int gn_cg, void* stream) {
     DMME_REQUIRE(qkv && w && bias && res && dst && N > 0 && S > 0 && C > 0, DMME_ERR_INVALID, "attention_proj: bad argument");
-    return launch_attn_proj(dtype, qkv, N, S, C, ctx, nullptr, w, bias, res, dst, gn_part, S / 32, gn_cg, (hipStream_t)stream);
+    return launch_attn_proj(dtype, qkv, N, S, C, ctx, nullptr, w, bias, res, dst, gn_part, S / 32, gn_cg, (hipStream_t)stream, g_stamps);
 }
 
 DMME_API int dmme_attention_heads(int dtype, const void* qkv, int N, int S, int C, int heads, void* out, int force_generic, void* stream) {

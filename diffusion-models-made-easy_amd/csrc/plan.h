@@ -111,6 +111,11 @@ struct LvlRun {
     std::vector<LvlOp> ops;
     std::vector<std::pair<int, int>> made;  // (tensor id, index of the op that produces / normalises it): later runs attach norms there
     LvlOp* ops_dev = nullptr;
+    // the op table of forwards no backward pass follows (run_op's keep_ctx == false): convs whose RAW output no forward op reads - a
+    // ResBlock's conv1 (only its norm's pre-activated copy is read), the qkv slices kept in LDS - do not store it (assign_lvl_nograd)
+    std::vector<LvlOp> ops_nograd;
+    LvlOp* ops_nograd_dev = nullptr;
+    int raw_skipped = 0;
     unsigned* sync_dev = nullptr;   // [16] control words (epoch, done, error), then the flag rows [n_ops * 2][NG][LVL_NS]
     double flops = 0, bytes = 0;
 };
@@ -211,7 +216,8 @@ bool gn_from_parts(const dmme_plan* P, const Op& o);
 void assign_levels(dmme_plan* P);
 // plan.hip: which residual 1x1 convs ride in their block's conv2 (after the level runs are known)
 void assign_rseg(dmme_plan* P);
-int run_level(const dmme_plan* P, const LvlRun& R, const char* pk, char* ws, int nt, const float* drop_masks, hipStream_t s);
+int run_level(const dmme_plan* P, const LvlRun& R, const char* pk, char* ws, int nt, const float* drop_masks, hipStream_t s, bool keep_ctx = true);
+void assign_lvl_nograd(dmme_plan* P);
 int lvl_check(const dmme_plan* P, const char* where, hipStream_t stream = nullptr, bool have_stream = false);
 // plan_bwd.hip: the grouped (deferred) weight-gradient tables of ops [op_lo, op_hi)
 void build_wgrad_group(dmme_plan* P, dmme_plan::WgGroup& G, int gi, int op_lo = 0, int op_hi = 1 << 30);

@@ -1129,7 +1129,7 @@ int run_gn(const dmme_plan* P, const Op& o, const char* pk, char* ws, int nt, co
 // keep_ctx: a backward pass may follow this forward (tensors only the backward reads are written: the fused attention block's context)
 int run_op(const dmme_plan* P, const Op& o, const char* pk, const float* x, const int64_t* t, int nt, float* y,
            char* ws, const float* drop_masks, hipStream_t s, bool keep_ctx) {
-    if (o.lvl >= 0) return o.lvl_first ? run_level(P, P->lvl_runs[o.lvl], pk, ws, nt, drop_masks, s) : DMME_OK;
+    if (o.lvl >= 0) return o.lvl_first ? run_level(P, P->lvl_runs[o.lvl], pk, ws, nt, drop_masks, s, keep_ctx) : DMME_OK;
     if (o.fused_away) return DMME_OK;  // a residual 1x1 conv that runs inside its block's conv2 (assign_rseg)
     switch (o.kind) {
         case OP_SINUS:
@@ -1347,6 +1347,7 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
     if (!getenv("DMME_NO_FUSED_GN")) assign_gn_in(P);
     assign_rseg(P);
     assign_attn_proj(P);
+    assign_lvl_nograd(P);
     P->n_launches = 0;
     for (const Op& o : P->ops) {
         if (o.fused_away) continue;
@@ -1604,6 +1605,10 @@ DMME_API int dmme_unet_plan_create(const dmme_unet_cfg* cfg, int B, int H, int W
             const size_t words = 16 + R.ops.size() * 2 * (size_t)R.NG * LVL_NS;
             if (e == hipSuccess) e = hipMalloc((void**)&R.ops_dev, R.ops.size() * sizeof(LvlOp));
             if (e == hipSuccess) e = hipMemcpy(R.ops_dev, R.ops.data(), R.ops.size() * sizeof(LvlOp), hipMemcpyHostToDevice);
+            if (e == hipSuccess && R.raw_skipped > 0) {
+                e = hipMalloc((void**)&R.ops_nograd_dev, R.ops_nograd.size() * sizeof(LvlOp));
+                if (e == hipSuccess) e = hipMemcpy(R.ops_nograd_dev, R.ops_nograd.data(), R.ops_nograd.size() * sizeof(LvlOp), hipMemcpyHostToDevice);
+            }
             if (e == hipSuccess) e = hipMalloc((void**)&R.sync_dev, words * 4);
             if (e == hipSuccess) e = hipMemset(R.sync_dev, 0, words * 4);
         }
@@ -1643,6 +1648,7 @@ DMME_API void dmme_unet_plan_destroy(dmme_plan* plan) {
     if (plan->err_host) (void)hipHostFree(plan->err_host);
     for (LvlRun& R : plan->lvl_runs) {
         if (R.ops_dev) (void)hipFree(R.ops_dev);
+        if (R.ops_nograd_dev) (void)hipFree(R.ops_nograd_dev);
         if (R.sync_dev) (void)hipFree(R.sync_dev);
     }
     delete plan;

@@ -338,14 +338,65 @@ void assign_levels(dmme_plan* P) {
     }
 }
 
+// Forwards that no backward pass follows (sampling: dmme_unet_forward_nograd, dmme_chain_step): an engine conv whose RAW output no
+// forward op reads need not store it - the per-op epilogues of a run are write-through stores at the chip's rate on the critical
+// chain of hand-offs (tools/stamp_lvl.py: 6-10 us of a ~20 us op on the 8x8 maps).  A ResBlock's conv1 is read through its norm's
+// pre-activated copy only, the qkv slices of the 4x4 attention from LDS.  Readers of a raw tensor: convs without a norm or outside the
+// pre-activated route, residual inputs, norms and attention outside the engine, an LVL_NORM op of a later run, named tensors
+// (dmme_unet_debug_read).  DMME_DEBUG_ROUTE=lvl_keep_raw: the full table everywhere.
+void assign_lvl_nograd(dmme_plan* P) {
+    if (P->lvl_runs.empty()) return;
+    std::vector<char> need(P->tensors.size(), 0);
+    auto mark = [&](int id) { if (id >= 0) need[id] = 1; };
+    for (const Op& q : P->ops) {
+        if (q.kind == OP_CONV) {
+            if (!(q.gn >= 0 && q.use_act)) { mark(q.src1); mark(q.src2); }
+            mark(q.res1);
+            mark(q.res2);
+        } else if (q.kind == OP_GN) {
+            for (int id : {q.gn_src1, q.gn_src2}) {
+                if (id < 0) continue;
+                if (q.lvl < 0) { need[id] = 1; continue; }
+                for (const LvlOp& lo : P->lvl_runs[q.lvl].ops)
+                    if (lo.kind == LVL_NORM && lo.dst_off == P->tensors[id].off) need[id] = 1;
+            }
+        } else if (q.kind == OP_ATTN) {
+            if (q.lvl < 0) mark(q.at_qkv);
+        } else if (q.kind == OP_CAST) {
+            mark(q.cast_src);
+        }
+    }
+    for (const auto& kv : P->named) mark(kv.second);
+    std::unordered_map<int64_t, char> need_off;
+    for (size_t t = 0; t < P->tensors.size(); ++t) {
+        auto it = need_off.find(P->tensors[t].off);
+        if (it == need_off.end()) need_off[P->tensors[t].off] = need[t];
+        else it->second = it->second || need[t];
+    }
+    const bool keep_all = debug_route("lvl_keep_raw") != 0;
+    for (LvlRun& R : P->lvl_runs) {
+        R.ops_nograd = R.ops;
+        R.raw_skipped = 0;
+        if (keep_all) continue;
+        for (LvlOp& lo : R.ops_nograd) {
+            if (lo.kind != LVL_CONV || lo.dst_off < 0) continue;
+            auto it = need_off.find(lo.dst_off);
+            if (it != need_off.end() && !it->second && (lo.n_norm > 0 || lo.keep >= 0)) {  // (something of the op is still handed on)
+                lo.dst_off = -1;
+                ++R.raw_skipped;
+            }
+        }
+    }
+}
+
 // diagnostic: in-kernel stamps of one workgroup of one level run (dmme_debug_level_stamps)
 static long long* g_lvl_stamps = nullptr;
 static int g_lvl_stamp_run = -1, g_lvl_stamp_wg = 0;
 
-int run_level(const dmme_plan* P, const LvlRun& R, const char* pk, char* ws, int nt, const float* drop_masks, hipStream_t s) {
+int run_level(const dmme_plan* P, const LvlRun& R, const char* pk, char* ws, int nt, const float* drop_masks, hipStream_t s, bool keep_ctx) {
     DMME_REQUIRE(R.ops_dev && R.sync_dev, DMME_ERR_INVALID, "level engine: the plan was created without a device");
     LvlArgs a{};
-    a.ops = R.ops_dev;
+    a.ops = (!keep_ctx && R.ops_nograd_dev) ? R.ops_nograd_dev : R.ops_dev;
     a.n_ops = (int)R.ops.size();
     a.ws = ws;
     a.packed = pk;
@@ -423,8 +474,8 @@ DMME_API int dmme_unet_plan_level_info(const dmme_plan* plan, char* buf, int cap
     for (const LvlRun& R : plan->lvl_runs) {
         unsigned ctl[3] = {0, 0, 0};
         if (R.sync_dev) DMME_CHECK_HIP(hipMemcpy(ctl, R.sync_dev, sizeof(ctl), hipMemcpyDeviceToHost));  // (synchronises with the device)
-        snprintf(tmp, sizeof(tmp), " [map=%dx%d plan_ops=%d-%d engine_ops=%d groups=%d per_iteration=%d slice=%d workgroups=%d epoch=%u err=%u]", 1 << R.sh, 1 << R.sh,
-                 R.op_first, R.op_last, (int)R.ops.size(), R.NG, R.GB, 32 * R.NJ, R.NGS * (LVL_NS / R.NJ), ctl[0], ctl[2]);
+        snprintf(tmp, sizeof(tmp), " [map=%dx%d plan_ops=%d-%d engine_ops=%d groups=%d per_iteration=%d slice=%d workgroups=%d nograd_raw_skipped=%d epoch=%u err=%u]", 1 << R.sh, 1 << R.sh,
+                 R.op_first, R.op_last, (int)R.ops.size(), R.NG, R.GB, 32 * R.NJ, R.NGS * (LVL_NS / R.NJ), R.raw_skipped, ctl[0], ctl[2]);
         out += tmp;
     }
     strncpy(buf, out.c_str(), (size_t)cap - 1);

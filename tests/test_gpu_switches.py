@@ -46,6 +46,7 @@ FORWARD = [
     ({"DMME_NO_WS128": "1"}, "persistent kernel without its 128-pixel tiles (the 128-cout layers of the 16x16 level back on the four-wave kernel)"),
     ({"DMME_NO_WS_E16": "1"}, "persistent kernel: the fp32-staged two-pass epilogue everywhere (round 5: 16-bit staging on transposed accumulators where no residual tensor is read)"),
     ({"DMME_LVL_NO_XCD": "1"}, "level engine: a pixel group's slices in index order (round 5: on one XCD)"),
+    ({"DMME_LVL_KEEP_RAW": "1"}, "level engine under no_grad: every conv stores its raw output (round 5: not where only the pre-activated copy is read)"),
     ({"DMME_NO_ATTN_PROJ": "1"}, "attention blocks of full launches: proj conv + residual as their own launch (round 5: inside the attention launch)"),
     ({"DMME_NO_FUSED_GN": "1"}, "every GroupNorm reads its tensor"),
     ({"DMME_NO_XCD_ORDER": "1"}, "plain workgroup order in attention / 1x1 convs"),

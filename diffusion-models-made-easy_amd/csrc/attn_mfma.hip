@@ -962,14 +962,18 @@ int launch_attn_mfma(int dtype, const void* qkv, int N, int S, int C, void* out,
 }
 // the single-head block with its proj conv + residual in the same launch (attn_full_kernel<.., PROJ>): wherever launch_attn_heads_mfma
 // would pick the whole-row kernel
-bool attn_proj_fusable(int dtype, int N, int S, int C, int gn_cg, int gn_tiles) {
-    if (!is16(dtype) || !attn_full_takes(S, C) || debug_route("no_attn_proj")) return false;
-    if (N * 2 < 256 && !debug_route("no_attn_split")) return false;  // the key-split kernel serves small batches
+static bool attn_proj_shape_ok(int dtype, int N, int S, int C, int gn_cg, int gn_tiles) {
+    if (!is16(dtype) || S != 256 || (C != 128 && C != 256) || N * 2 < 256) return false;  // the whole-row kernel's shapes, a launch that fills the chip
     return gn_tiles == 0 || ((gn_cg == 4 || gn_cg == 8) && C % gn_cg == 0 && gn_tiles == S / 32);
+}
+// (the plan's decision: shapes + the route switches, read when the plan is built - the launch itself checks shapes only)
+bool attn_proj_fusable(int dtype, int N, int S, int C, int gn_cg, int gn_tiles) {
+    if (!attn_full_takes(S, C) || debug_route("no_attn_proj")) return false;
+    return attn_proj_shape_ok(dtype, N, S, C, gn_cg, gn_tiles);
 }
 int launch_attn_proj(int dtype, const void* qkv, int N, int S, int C, void* ctx, float* lse, const void* w, const float* bias, const void* res, void* dst,
                      float* gn_part, int gn_tiles, int gn_cg, hipStream_t s, long long* stamps) {
-    DMME_REQUIRE(attn_proj_fusable(dtype, N, S, C, gn_part ? gn_cg : 0, gn_part ? gn_tiles : 0) && w && bias && res && dst, DMME_ERR_UNSUPPORTED,
+    DMME_REQUIRE(attn_proj_shape_ok(dtype, N, S, C, gn_part ? gn_cg : 0, gn_part ? gn_tiles : 0) && w && bias && res && dst, DMME_ERR_UNSUPPORTED,
                  "attn_proj: unsupported shape N=%d S=%d C=%d (statistics tiles %d, %d channels per group)", N, S, C, gn_tiles, gn_cg);
     const AttnGeom g = attn_geom(N, S, C, 1);
     const AttnProj pj{w, bias, res, dst, gn_part, gn_tiles, gn_cg, stamps, debug_route("attn_proj_dbg")};

@@ -196,6 +196,9 @@ struct dmme_plan {
     // host-visible status word of the engine's bounded hand-off waits (pinned, device-mapped; null: no engine run in this plan):
     // non-zero = 1 + index of a run in which a wait timed out, i.e. the outputs since are invalid (lvl_check)
     unsigned* err_host = nullptr;
+    // the workspace the last forward wrote WITHOUT the tensors only a backward pass reads (dmme_unet_forward_nograd, dmme_chain_step):
+    // dmme_unet_backward refuses it instead of differentiating stale activations (null: the last forward kept everything)
+    mutable const void* nograd_ws = nullptr;
 };
 
 namespace dmme {

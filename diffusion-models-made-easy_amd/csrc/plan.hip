@@ -1699,6 +1699,11 @@ static int unet_forward_impl(const dmme_plan* plan, const void* packed, const fl
     const char* pk = (const char*)packed;
     char* ws = (char*)workspace;
     const int nt = t_len;
+    if (keep_ctx) {
+        if (plan->nograd_ws == workspace) plan->nograd_ws = nullptr;
+    } else {
+        plan->nograd_ws = workspace;
+    }
     for (const Op& o : P->ops) {
         const int rc = run_op(P, o, pk, x, t, nt, y, ws, drop_masks, s, keep_ctx);
         if (rc != DMME_OK) return rc;
@@ -1734,6 +1739,7 @@ DMME_API int dmme_unet_forward_profiled(const dmme_plan* plan, const void* packe
     if (int rc0 = lvl_check(plan, "forward_profiled", (hipStream_t)stream, true)) return rc0;
     hipStream_t s = (hipStream_t)stream;
     const size_t n = plan->ops.size();
+    plan->nograd_ws = workspace;
     std::vector<hipEvent_t> ev(n + 1);
     for (auto& e : ev) DMME_CHECK_HIP(hipEventCreate(&e));
     int rc = DMME_OK;

@@ -133,6 +133,9 @@ static int backward_impl(const dmme_plan* plan, const void* packed, const void* 
     DMME_REQUIRE(t_len == 1 || t_len == plan->B, DMME_ERR_INVALID, "unet_backward: bad t_len %d", t_len);
     if (int rc0 = lvl_check(plan, "unet_backward", (hipStream_t)stream, true)) return rc0;  // (the forward this backward differentiates ran through the engine)
     DMME_REQUIRE(!plan->mix, DMME_ERR_UNSUPPORTED, "unet_backward: precision fp16r32 is an inference mode");
+    DMME_REQUIRE(plan->nograd_ws != workspace, DMME_ERR_INVALID,
+                 "unet_backward: the last forward into this workspace was dmme_unet_forward_nograd / dmme_chain_step, which leave out the tensors only a "
+                 "backward pass reads; run dmme_unet_forward first");
     const dmme_plan* P = plan;
     hipStream_t s = (hipStream_t)stream;
     const char* pk = (const char*)packed;

@@ -129,7 +129,9 @@ DMME_API int dmme_unet_forward(const dmme_plan* plan, const void* packed, const 
                       float* y, void* workspace, const float* drop_masks, void* stream);
 /* The same forward where no dmme_unet_backward will follow (the reference's sampling loops run under torch.no_grad(),
  * diffusion_models/ddpm.py:113-133): tensors that only the backward pass reads - the context of an attention block whose proj
- * conv runs inside the attention launch (models/ddpm.py:66-75) - are not written.  Same arguments, same result y.
+ * conv runs inside the attention launch (models/ddpm.py:66-75), raw conv outputs of the level engine that only their norm's
+ * pre-activated copy stands for - are not written.  Same arguments, same result y.  dmme_unet_backward on that workspace fails
+ * with DMME_ERR_INVALID until a dmme_unet_forward has filled it again.
  * dmme_chain_step and dmme_unet_forward_profiled run this form. */
 DMME_API int dmme_unet_forward_nograd(const dmme_plan* plan, const void* packed, const float* x, const int64_t* t, int t_len,
                       float* y, void* workspace, const float* drop_masks, void* stream);

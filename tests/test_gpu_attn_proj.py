@@ -169,3 +169,32 @@ def test_batch128_training_step_with_the_blocks_fused():
     print(f"training step loss {la:.6f} (fused) vs {lb:.6f}; relative gradient difference {rel:.3e}; worst proj-parameter difference {worst:.3e}")
     assert abs(la - lb) <= 2e-3 * abs(lb)
     assert rel <= 5e-2 and worst <= 5e-2  # (bf16 networks of 100 rounded tensors: two runs of ONE route differ by ~1e-2 through the atomics' order)
+
+
+def test_backward_refuses_the_workspace_of_a_no_grad_forward():
+    """dmme_unet_forward_nograd leaves out what only the backward pass reads (the fused blocks' context tensors, raw conv outputs of
+    the level engine): dmme_unet_backward on that workspace fails loudly (the C entry point itself - the host module has its own
+    generation check in front of it); after a dmme_unet_forward it runs"""
+    import dmme_amd
+    from dmme_amd import _lib
+
+    torch.manual_seed(0)
+    net = dmme_amd.UNet(precision="bf16").cuda().train()
+    x = torch.randn(128, 3, 32, 32, device="cuda")
+    t = (torch.arange(128, device="cuda") * 7 % 1000).to(torch.int64)
+    net(x, t).float().pow(2).mean().backward()  # creates the backward workspace and the packed backward weights
+    plan = net._last_plan
+    lib = plan.lib
+    with torch.no_grad():
+        net(x, t)                               # same plan, same workspace: dmme_unet_forward_nograd
+    packed = net._packed_for(plan)
+    d = torch.zeros(128, 3, 32, 32, device="cuda")
+    g = net.flat_grad()
+    args = (plan.h, _lib.ptr(packed), _lib.ptr(plan.packed_bwd), _lib.ptr(x), _lib.ptr(t), 128, _lib.ptr(d), _lib.ptr(plan.workspace), _lib.ptr(plan.bws),
+            _lib.ptr(plan.masks), _lib.ptr(g), None, _lib.stream_ptr())
+    rc = lib.dmme_unet_backward(*args)
+    assert rc != 0 and b"dmme_unet_forward_nograd" in lib.dmme_last_error()
+    net.zero_grad()
+    net(x, t).float().pow(2).mean().backward()  # a forward with autograd fills the workspace again
+    torch.cuda.synchronize()
+    assert float(net.flat_grad().float().abs().sum()) > 0

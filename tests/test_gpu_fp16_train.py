@@ -232,10 +232,12 @@ def test_fp16_resume_carries_the_loss_scaling_state():
         torch.manual_seed(100 + step)
         train_step(lit2, opt2, sched2, base[:16])
     assert torch.equal(net2.amp_state().cpu()[:5], want_amp[:5])
-    moved = float((want - start).abs().max())  # what four steps move the weights
-    d_resumed = float((net2.flat_parameters() - want).abs().max())
-    print(f"four steps move the weights by {moved:.3e}; resumed run differs from the uninterrupted one by {d_resumed:.3e}")
-    assert d_resumed <= 0.05 * moved, (d_resumed, moved)
+    # (L2 norms over the 35.7 M weights: the MAXIMUM difference is an extreme-value statistic of the backward's run-to-run jitter - one
+    #  weight whose tiny gradient changes sign moves the other way by a full Adam step - and crossed 5 % of the maximum movement in 1 run of 5)
+    moved = float((want - start).double().norm())  # what four steps move the weights
+    d_resumed = float((net2.flat_parameters() - want).double().norm())
+    print(f"four steps move the weights by {moved:.3e} (L2); resumed run differs from the uninterrupted one by {d_resumed:.3e}")
+    assert d_resumed <= 0.02 * moved, (d_resumed, moved)  # measured 1.4-2.6e-4 of the movement
     # a checkpoint WITHOUT the scaler's state (bf16 / reference run): the bias-correction count is seeded from the loaded step count
     sd = copy.deepcopy(ck["opt"])
     del sd["amp_state"]
@@ -251,9 +253,9 @@ def test_fp16_resume_carries_the_loss_scaling_state():
     for step in range(8, 12):
         torch.manual_seed(100 + step)
         train_step(lit3, opt3, sched3, base[:16])
-    d_cold = float((net3.flat_parameters() - want).abs().max())
+    d_cold = float((net3.flat_parameters() - want).double().norm())
     print(f"the same resume with the bias-correction count back at 0: differs by {d_cold:.3e}")
-    assert d_cold >= 5 * max(d_resumed, 1e-9)
+    assert d_cold >= 20 * max(d_resumed, 1e-9)  # measured 0.7 of the movement
 
 
 def test_adam_amp_skips_when_the_scale_has_collapsed():

@@ -34,9 +34,9 @@ def _run(dt, qkv, w, bias, res, want_ctx, gn_cg):
     return dst, ctx, part
 
 
-@pytest.mark.parametrize("dtname", ["bf16", "fp16"])
-@pytest.mark.parametrize("C", [256, 128])
-def test_attention_proj_one_launch(C, dtname):
+@pytest.mark.parametrize("C,dtname,cg", [(256, "bf16", 8), (256, "fp16", 8), (128, "bf16", 4), (128, "fp16", 4),
+                                         (256, "bf16", 4), (128, "bf16", 8)])  # (the last two: 64 / 16 groups - the other group width per head width)
+def test_attention_proj_one_launch(C, dtname, cg):
     from dmme_amd import _lib
     from tests import gpu_util as G
 
@@ -50,7 +50,6 @@ def test_attention_proj_one_launch(C, dtname):
     bias = synth.normal(13, (C,)) * 0.1
     res = synth.normal(14, (N, S, C))
     qkv, w, bias, res = qkv.to(dev), w.to(dev), bias.to(dev), res.to(dev)
-    cg = C // 32
     dst, ctx, part = _run(dt, qkv, w, bias, res, True, cg)
 
     # (i) the launches it replaces
